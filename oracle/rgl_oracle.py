@@ -1,0 +1,647 @@
+"""CPU oracle for the RGL relational-graph forward pass and the model-predictive rollout.
+
+TEST INFRASTRUCTURE ONLY.  Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
+`bench.py` may import this module; the product (`relationalgraphlearning_amd`) never does.
+
+What it is: a restatement, in this repo's own words, of the arithmetic of the reference's hot path,
+written as pure functions over plain fp32 tensors (torch CPU, because the reference's arithmetic *is*
+ATen CPU: linear / matmul / softmax / relu, plus numpy scalar code for rewards).  It exists in two
+shapes:
+
+  * a *sequential* planner that walks the action tree one batch-1 forward at a time in exactly the
+    order the reference does (`mprl_predict_sequential`, `gcn_predict_sequential`) -- this is "the
+    reference PyTorch-CPU path" used as the reference-faithful CPU baseline;
+  * a *batched*, level-synchronous planner (`mprl_predict_batched`) doing the same arithmetic for B
+    root scenes at once -- used to check the GPU path at sizes the sequential walk cannot reach.
+
+Parity pin: every function here is checked against fixtures produced by importing the reference
+itself in the build container (`tests/golden/make_golden.py` -> `tests/golden/*.npz`,
+`tests/test_oracle_golden.py`).  The reference ships no golden vectors of its own.
+
+Reference lines each function follows (paths relative to the upstream repo):
+  mlp_forward                 crowd_nav/policy/helpers.py:5-13
+  similarity_matrix           crowd_nav/policy/graph_model.py:63-97
+  rgl_forward                 crowd_nav/policy/graph_model.py:99-130
+  value_estimator_forward     crowd_nav/policy/value_estimator.py:11-20
+  state_predictor_humans      crowd_nav/policy/state_predictor.py:20-39
+  next_robot_state            crowd_nav/policy/state_predictor.py:41-60
+  linear_humans               crowd_nav/policy/state_predictor.py:109-118
+  mprl_action_space           crowd_nav/policy/model_predictive_rl.py:155-190
+  point_to_segment_dist       crowd_sim/envs/utils/utils.py:4-26
+  estimate_reward             crowd_nav/policy/model_predictive_rl.py:304-357
+  mprl_predict_sequential     crowd_nav/policy/model_predictive_rl.py:192-302
+  cadrl_action_space          crowd_nav/policy/cadrl.py:91-111
+  rotate_pairwise             crowd_nav/policy/cadrl.py:241-276
+  gcn_value_forward           crowd_nav/policy/gcn.py:85-128
+  compute_reward_g            crowd_nav/policy/multi_human_rl.py:73-96
+  gcn_predict_sequential      crowd_nav/policy/multi_human_rl.py:12-71
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+SIMILARITIES = ("embedded_gaussian", "gaussian", "cosine", "cosine_softmax", "concatenation",
+                "squared", "equal_attention", "diagonal")
+
+
+@dataclass
+class OracleConfig:
+    # graph
+    num_layer: int = 2
+    x_dim: int = 32
+    similarity: str = "embedded_gaussian"
+    layerwise_graph: bool = False
+    skip_connection: bool = True
+    # world
+    kinematics: str = "holonomic"
+    time_step: float = 0.25
+    gamma: float = 0.9
+    v_pref: float = 1.0
+    speed_samples: int = 5
+    rotation_samples: int = 16
+    rotation_constraint: float = float(np.pi / 3)
+    # planner (path M)
+    planning_depth: int = 1
+    planning_width: int = 1
+    do_action_clip: bool = False
+    sparse_search: bool = False
+    linear_state_predictor: bool = False
+
+
+# --------------------------------------------------------------------------------------------------
+# parameter handling: the oracle consumes the reference's own state-dict key names
+# --------------------------------------------------------------------------------------------------
+def mlp_layers(sd: Dict[str, torch.Tensor], prefix: str):
+    """Collect (W, b) of a Sequential[Linear(,ReLU)...] stored as '<prefix><i>.weight'."""
+    idx = sorted({int(k[len(prefix):].split(".")[0]) for k in sd
+                  if k.startswith(prefix) and k.endswith(".weight")})
+    return [(sd["%s%d.weight" % (prefix, i)], sd["%s%d.bias" % (prefix, i)]) for i in idx]
+
+
+def mlp_forward(x, layers, last_relu):
+    n = len(layers)
+    for i, (w, b) in enumerate(layers):
+        x = torch.nn.functional.linear(x, w, b)
+        if i != n - 1 or last_relu:
+            x = torch.relu(x)
+    return x
+
+
+def graph_weights(gsd, cfg):
+    ws = [gsd["Ws.%d" % i] for i in range(cfg.num_layer)] if "Ws.0" in gsd else \
+         [gsd["w%d" % (i + 1)] for i in range(cfg.num_layer)]          # path G names them w1, w2
+    return ws
+
+
+# --------------------------------------------------------------------------------------------------
+# graph forward
+# --------------------------------------------------------------------------------------------------
+def similarity_matrix(X, gsd, mode):
+    B, N, _ = X.shape
+    Xt = X.transpose(1, 2)
+    if mode == "embedded_gaussian":
+        return torch.softmax(torch.matmul(torch.matmul(X, gsd["w_a"]), Xt), dim=2)
+    if mode == "gaussian":
+        return torch.softmax(torch.matmul(X, Xt), dim=2)
+    if mode in ("cosine", "cosine_softmax"):
+        S = torch.matmul(X, Xt)
+        m = torch.norm(S, dim=2, keepdim=True)            # row norms of S itself (reference quirk)
+        C = S / torch.matmul(m, m.transpose(1, 2))
+        return C if mode == "cosine" else torch.softmax(C, dim=2)
+    if mode == "concatenation":
+        xi = X.unsqueeze(2).expand(B, N, N, X.shape[2])
+        xj = X.unsqueeze(1).expand(B, N, N, X.shape[2])
+        pairs = torch.cat([xi, xj], dim=3).reshape(B, N * N, -1)
+        return mlp_forward(pairs, mlp_layers(gsd, "w_a."), last_relu=True).reshape(B, N, N)
+    if mode == "squared":
+        S = torch.matmul(X, Xt)
+        S2 = S * S
+        return S2 / S2.sum(dim=2, keepdim=True)
+    if mode == "equal_attention":
+        return (torch.ones(N, N) / N).expand(B, N, N)
+    if mode == "diagonal":
+        return torch.eye(N, N).expand(B, N, N)
+    raise NotImplementedError(mode)
+
+
+def propagate_layers(X, gsd, cfg):
+    """Shared by path M (RGL) and path G (ValueNetwork): L x  H <- relu(A H W) (+ H)."""
+    ws = graph_weights(gsd, cfg)
+    A = None
+    if not cfg.layerwise_graph:
+        A = similarity_matrix(X, gsd, cfg.similarity)
+    A_first = A
+    H = X
+    for l in range(cfg.num_layer):
+        if cfg.layerwise_graph:
+            A = similarity_matrix(H, gsd, cfg.similarity)
+            if A_first is None:
+                A_first = A
+        nxt = torch.relu(torch.matmul(torch.matmul(A, H), ws[l]))
+        if cfg.skip_connection:
+            nxt = nxt + H
+        H = nxt
+    return H, A_first
+
+
+def rgl_embed(robot, humans, gsd):
+    xr = mlp_forward(robot, mlp_layers(gsd, "w_r."), last_relu=True)
+    xh = mlp_forward(humans, mlp_layers(gsd, "w_h."), last_relu=True)
+    return torch.cat([xr, xh], dim=1)
+
+
+def rgl_forward(robot, humans, gsd, cfg):
+    """robot (B,1,9), humans (B,H,5) -> (H_L (B,N,X), A (B,N,N))."""
+    return propagate_layers(rgl_embed(robot, humans, gsd), gsd, cfg)
+
+
+def value_estimator_forward(robot, humans, gsd, vsd, cfg):
+    H, _ = rgl_forward(robot, humans, gsd, cfg)
+    return mlp_forward(H[:, 0, :], mlp_layers(vsd, ""), last_relu=False)      # (B,1)
+
+
+def state_predictor_humans(robot, humans, gsd, msd, cfg):
+    H, _ = rgl_forward(robot, humans, gsd, cfg)
+    return mlp_forward(H, mlp_layers(msd, ""), last_relu=False)[:, 1:, :]      # (B,H,5)
+
+
+def linear_humans(humans):
+    nxt = humans.clone()
+    nxt[..., 0] = nxt[..., 0] + nxt[..., 2]          # no time-step factor: reference quirk, kept
+    nxt[..., 1] = nxt[..., 1] + nxt[..., 3]
+    return nxt
+
+
+def next_robot_state(robot, action, cfg):
+    """robot (...,9) fp32 tensor, action = (a0, a1) python/np float64 -> same shape."""
+    nxt = robot.clone()
+    dt = cfg.time_step
+    if cfg.kinematics == "holonomic":
+        nxt[..., 0] = nxt[..., 0] + action[0] * dt
+        nxt[..., 1] = nxt[..., 1] + action[1] * dt
+        nxt[..., 2] = action[0]
+        nxt[..., 3] = action[1]
+    else:
+        # the reference adds the rotation to slot 7 (v_pref), not slot 8 (theta); kept as is
+        nxt[..., 7] = nxt[..., 7] + action[1]
+        nxt[..., 0] = nxt[..., 0] + torch.cos(nxt[..., 7]) * action[0] * dt
+        nxt[..., 1] = nxt[..., 1] + torch.sin(nxt[..., 7]) * action[0] * dt
+        nxt[..., 2] = torch.cos(nxt[..., 7]) * action[0]
+        nxt[..., 3] = torch.sin(nxt[..., 7]) * action[0]
+    return nxt
+
+
+# --------------------------------------------------------------------------------------------------
+# action spaces
+# --------------------------------------------------------------------------------------------------
+def _speeds_rotations(cfg, v_pref):
+    speeds = [(np.exp((i + 1) / cfg.speed_samples) - 1) / (np.e - 1) * v_pref
+              for i in range(cfg.speed_samples)]
+    if cfg.kinematics == "holonomic":
+        rotations = np.linspace(0, 2 * np.pi, cfg.rotation_samples, endpoint=False)
+    else:
+        rotations = np.linspace(-cfg.rotation_constraint, cfg.rotation_constraint, cfg.rotation_samples)
+    return speeds, rotations
+
+
+def mprl_action_space(cfg, v_pref=1.0, sparse_rotation_samples=8):
+    """Path M table: stop action, then speed-major (speed outer, rotation inner).
+    Returns (actions float64 (A,2), group ids int (A,))."""
+    speeds, rotations = _speeds_rotations(cfg, v_pref)
+    holo = cfg.kinematics == "holonomic"
+    acts, groups = [(0.0, 0.0)], [0]
+    for j, s in enumerate(speeds):
+        band = 0 if j < 3 else 1
+        for i, r in enumerate(rotations):
+            groups.append(band * sparse_rotation_samples + i // 2)
+            acts.append((s * np.cos(r), s * np.sin(r)) if holo else (s, r))
+    return np.asarray(acts, dtype=np.float64), np.asarray(groups, dtype=np.int64)
+
+
+def cadrl_action_space(cfg, v_pref=1.0):
+    """Path G table: stop action, then rotation-major (rotation outer, speed inner)."""
+    speeds, rotations = _speeds_rotations(cfg, v_pref)
+    holo = cfg.kinematics == "holonomic"
+    acts = [(0.0, 0.0)]
+    for r in rotations:
+        for s in speeds:
+            acts.append((s * np.cos(r), s * np.sin(r)) if holo else (s, r))
+    return np.asarray(acts, dtype=np.float64)
+
+
+# --------------------------------------------------------------------------------------------------
+# rewards (numpy scalar arithmetic, dtype follows the inputs exactly like the reference)
+# --------------------------------------------------------------------------------------------------
+def point_to_segment_dist(x1, y1, x2, y2, x3, y3):
+    px, py = x2 - x1, y2 - y1
+    if px == 0 and py == 0:
+        return np.linalg.norm((x3 - x1, y3 - y1))
+    u = ((x3 - x1) * px + (y3 - y1) * py) / (px * px + py * py)
+    u = 1 if u > 1 else (0 if u < 0 else u)
+    return np.linalg.norm((x1 + u * px - x3, y1 + u * py - y3))
+
+
+def estimate_reward(robot, humans, action, cfg):
+    """robot: 9 scalars, humans: iterable of 5-scalar rows (python floats for a root JointState,
+    np.float32 for states that came back from tensors), action: 2 np.float64 scalars."""
+    dt = cfg.time_step
+    rpx, rpy, _, _, rrad, gx, gy, _, rtheta = robot
+    holo = cfg.kinematics == "holonomic"
+    dmin, collision = float("inf"), False
+    for h in humans:
+        px, py = h[0] - rpx, h[1] - rpy
+        if holo:
+            vx, vy = h[2] - action[0], h[3] - action[1]
+        else:
+            vx = h[2] - action[0] * np.cos(action[1] + rtheta)
+            vy = h[3] - action[0] * np.sin(action[1] + rtheta)
+        ex, ey = px + vx * dt, py + vy * dt
+        d = point_to_segment_dist(px, py, ex, ey, 0, 0) - h[4] - rrad
+        if d < 0:
+            collision = True
+            break
+        if d < dmin:
+            dmin = d
+    if holo:
+        nx, ny = rpx + action[0] * dt, rpy + action[1] * dt
+    else:
+        th = rtheta + action[1]
+        nx, ny = rpx + np.cos(th) * action[0] * dt, rpy + np.sin(th) * action[0] * dt
+    reaching = np.linalg.norm(np.array((nx, ny)) - np.array([gx, gy])) < rrad
+    if collision:
+        return -0.25
+    if reaching:
+        return 1
+    if dmin < 0.2:
+        return (dmin - 0.2) * 0.5 * dt
+    return 0
+
+
+def _tensor_state_scalars(robot_t, humans_t):
+    r = robot_t.reshape(-1).numpy()
+    h = humans_t.reshape(-1, humans_t.shape[-1]).numpy()
+    return [r[i] for i in range(9)], [[row[i] for i in range(5)] for row in h]
+
+
+# --------------------------------------------------------------------------------------------------
+# path M planner -- sequential, reference order
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class MprlParams:
+    ve_graph: Dict[str, torch.Tensor]
+    value_network: Dict[str, torch.Tensor]
+    sp_graph: Optional[Dict[str, torch.Tensor]] = None      # None with the linear predictor
+    motion_predictor: Optional[Dict[str, torch.Tensor]] = None
+
+    @staticmethod
+    def from_checkpoint(ck):
+        """`ck` = the dict the reference's ModelPredictiveRL.get_state_dict() returns."""
+        if "graph_model1" in ck:
+            return MprlParams(ck["graph_model1"], ck["value_network"], ck["graph_model2"],
+                              ck["motion_predictor"])
+        if "motion_predictor" in ck:
+            return MprlParams(ck["graph_model"], ck["value_network"], ck["graph_model"],
+                              ck["motion_predictor"])
+        return MprlParams(ck["graph_model"], ck["value_network"])
+
+
+@dataclass
+class SeqTrace:
+    """What the sequential walk saw (for fixtures / debugging)."""
+    n_value_forwards: int = 0
+    n_predictor_forwards: int = 0
+    root_clip_values: Optional[np.ndarray] = None       # (A,) one-step values of every root action
+    root_clipped: Optional[List[int]] = None            # action indices kept at the root
+    root_values: Optional[np.ndarray] = None            # value of each kept root action
+
+
+def _normalized_gamma(cfg):
+    return pow(cfg.gamma, cfg.time_step * cfg.v_pref)
+
+
+def mprl_predict_sequential(robot9, humans, P: MprlParams, cfg: OracleConfig, trace: SeqTrace = None):
+    """robot9: 9 python floats; humans: list of 5-float rows (a root JointState's contents).
+    Returns (action index, max value float32).  Walks the tree exactly as the reference does."""
+    actions, groups = mprl_action_space(cfg, robot9[7])
+    gamma = _normalized_gamma(cfg)
+    trace = trace if trace is not None else SeqTrace()
+
+    def V(state):
+        trace.n_value_forwards += 1
+        return value_estimator_forward(state[0], state[1], P.ve_graph, P.value_network, cfg).reshape(())
+
+    def SP(state, a):
+        trace.n_predictor_forwards += 1
+        nr = next_robot_state(state[0].reshape(-1), a, cfg).reshape(1, 1, 9)
+        if cfg.linear_state_predictor:
+            nh = linear_humans(state[1])
+        else:
+            nh = state_predictor_humans(state[0], state[1], P.sp_graph, P.motion_predictor, cfg)
+        return (nr, nh)
+
+    def reward_of(state, a, root):
+        if root:
+            return estimate_reward(robot9, humans, a, cfg)
+        r, h = _tensor_state_scalars(state[0], state[1])
+        return estimate_reward(r, h, a, cfg)
+
+    def clip(state, width, root):
+        vals = []
+        for a in actions:
+            nxt = SP(state, a)
+            ret = V(nxt)
+            vals.append(reward_of(state, a, root) + gamma * ret)
+        vals_np = np.array([float(v) for v in vals], dtype=np.float32)
+        if cfg.sparse_search:
+            seen, keep = set(), []
+            for idx in np.argsort(vals_np)[::-1]:
+                if groups[idx] not in seen:
+                    keep.append(int(idx))
+                    seen.add(groups[idx])
+                    if len(keep) == width:
+                        break
+        else:
+            keep = [int(i) for i in np.argpartition(vals_np, -width)[-width:]]
+        return keep, vals_np
+
+    def plan(state, depth, width):
+        v = V(state)
+        if depth == 1:
+            return v
+        keep = clip(state, width, False)[0] if cfg.do_action_clip else list(range(len(actions)))
+        rets = []
+        for ai in keep:
+            a = actions[ai]
+            nxt = SP(state, a)
+            r = reward_of(state, a, False)
+            nv = plan(nxt, depth - 1, width)
+            rets.append(v / depth + (depth - 1) / depth * (gamma * nv + r))
+        return rets[int(np.argmax([float(x) for x in rets]))]
+
+    root = (torch.tensor([[robot9]], dtype=torch.float32),
+            torch.tensor([humans], dtype=torch.float32).reshape(1, len(humans), 5))
+    if cfg.do_action_clip:
+        keep, vals_np = clip(root, cfg.planning_width, True)
+        trace.root_clip_values = vals_np
+    else:
+        keep = list(range(len(actions)))
+    trace.root_clipped = keep
+    best, best_v, root_vals = None, float("-inf"), []
+    for ai in keep:
+        a = actions[ai]
+        nxt = SP(root, a)
+        ret = plan(nxt, cfg.planning_depth, cfg.planning_width)
+        val = estimate_reward(robot9, humans, a, cfg) + gamma * ret
+        root_vals.append(float(val))
+        if val > best_v:
+            best_v, best = val, ai
+    trace.root_values = np.array(root_vals, dtype=np.float32)
+    return best, np.float32(best_v)
+
+
+# --------------------------------------------------------------------------------------------------
+# path M planner -- batched, level synchronous (same arithmetic, B roots at once)
+# --------------------------------------------------------------------------------------------------
+def estimate_reward_batched(robot, humans, actions, cfg, root):
+    """robot (P,9) fp32, humans (P,H,5) fp32, actions (A,2) float64 -> rewards (P,A) float64.
+    Vectorised transcription of `estimate_reward`; `root` selects float64 differences (JointState
+    inputs) versus the float32 differences the reference gets from tensor-born states."""
+    dt = cfg.time_step
+    r = robot.numpy()
+    h = humans.numpy()
+    if root:
+        r = r.astype(np.float64)
+        h = h.astype(np.float64)
+    px = (h[:, :, 0] - r[:, None, 0])[:, None, :]                    # (P,1,H)
+    py = (h[:, :, 1] - r[:, None, 1])[:, None, :]
+    holo = cfg.kinematics == "holonomic"
+    if holo:
+        avx, avy = actions[None, :, None, 0], actions[None, :, None, 1]
+    else:
+        th = actions[None, :, None, 1] + r[:, None, None, 8].astype(np.float64)
+        avx, avy = actions[None, :, None, 0] * np.cos(th), actions[None, :, None, 0] * np.sin(th)
+    vx = h[:, None, :, 2].astype(np.float64) - avx                      # (P,A,H)
+    vy = h[:, None, :, 3].astype(np.float64) - avy
+    pxd, pyd = px.astype(np.float64), py.astype(np.float64)
+    ex, ey = pxd + vx * dt, pyd + vy * dt
+    sx, sy = ex - pxd, ey - pyd
+    den = sx * sx + sy * sy
+    degenerate = (sx == 0) & (sy == 0)
+    u = np.where(degenerate, 0.0, (-pxd * sx - pyd * sy) / np.where(degenerate, 1.0, den))
+    u = np.clip(u, 0.0, 1.0)
+    cx, cy = pxd + u * sx, pyd + u * sy
+    dist = np.sqrt(cx * cx + cy * cy)
+    closest = dist - h[:, None, :, 4] - r[:, None, None, 4]                # (P,A,H)
+    collided = closest < 0
+    # first-collision break: dmin only matters when no human collides at all
+    collision = collided.any(axis=2)
+    dmin = closest.min(axis=2)
+    if holo:
+        nx = r[:, None, 0] + actions[None, :, 0] * dt
+        ny = r[:, None, 1] + actions[None, :, 1] * dt
+    else:
+        th = r[:, None, 8].astype(np.float64) + actions[None, :, 1]
+        nx = r[:, None, 0] + np.cos(th) * actions[None, :, 0] * dt
+        ny = r[:, None, 1] + np.sin(th) * actions[None, :, 0] * dt
+    gd = np.sqrt((nx - r[:, None, 5]) ** 2 + (ny - r[:, None, 6]) ** 2)
+    reaching = gd < r[:, None, 4]
+    rew = np.where(dmin < 0.2, (dmin - 0.2) * 0.5 * dt, 0.0)
+    rew = np.where(reaching, 1.0, rew)
+    rew = np.where(collision, -0.25, rew)
+    return rew
+
+
+def _children_robot(robot, actions, cfg):
+    """robot (P,9) -> (P,A,9) next robot states with the reference's fp32 update order."""
+    P, A = robot.shape[0], actions.shape[0]
+    out = robot[:, None, :].repeat(1, A, 1)
+    dt = cfg.time_step
+    if cfg.kinematics == "holonomic":
+        dvx = torch.tensor(actions[:, 0] * dt, dtype=torch.float64).to(torch.float32)
+        dvy = torch.tensor(actions[:, 1] * dt, dtype=torch.float64).to(torch.float32)
+        out[:, :, 0] = out[:, :, 0] + dvx[None, :]
+        out[:, :, 1] = out[:, :, 1] + dvy[None, :]
+        out[:, :, 2] = torch.tensor(actions[:, 0]).to(torch.float32)[None, :]
+        out[:, :, 3] = torch.tensor(actions[:, 1]).to(torch.float32)[None, :]
+    else:
+        for ai in range(A):
+            out[:, ai, :] = next_robot_state(robot, actions[ai], cfg)
+    return out
+
+
+def select_top(values, width, groups, sparse):
+    """values (P,A) fp32 numpy -> (P,width) kept indices, ordered by descending value
+    (ties: lower index first; sparse mode reproduces the reference's reversed-argsort walk)."""
+    P, A = values.shape
+    keep = np.zeros((P, width), dtype=np.int64)
+    for p in range(P):
+        if sparse:
+            seen, k = set(), []
+            for idx in np.argsort(values[p])[::-1]:
+                if groups[idx] not in seen:
+                    k.append(idx)
+                    seen.add(groups[idx])
+                    if len(k) == width:
+                        break
+            keep[p, :len(k)] = k
+        else:
+            order = np.lexsort((np.arange(A), -values[p].astype(np.float64)))
+            keep[p] = order[:width]
+    return keep
+
+
+def mprl_expand_batched(robot, humans, P: MprlParams, cfg, actions, root):
+    """One tree level for a batch of parents.
+    robot (Pn,9), humans (Pn,H,5) -> dict(next_humans (Pn,H,5), child_robot (Pn,A,9),
+    child_value (Pn,A) fp32 = V(child), reward (Pn,A) fp32, value1 (Pn,A) fp32 = r + g*V)."""
+    Pn, A = robot.shape[0], actions.shape[0]
+    if cfg.linear_state_predictor:
+        nh = linear_humans(humans)
+    else:
+        nh = state_predictor_humans(robot[:, None, :], humans, P.sp_graph, P.motion_predictor, cfg)
+    cr = _children_robot(robot, actions, cfg)
+    H = humans.shape[1]
+    cv = value_estimator_forward(cr.reshape(Pn * A, 1, 9),
+                                 nh[:, None].expand(Pn, A, H, 5).reshape(Pn * A, H, 5),
+                                 P.ve_graph, P.value_network, cfg).reshape(Pn, A)
+    rew = torch.tensor(estimate_reward_batched(robot, humans, actions, cfg, root)).to(torch.float32)
+    gamma = _normalized_gamma(cfg)
+    value1 = rew + gamma * cv
+    return dict(next_humans=nh, child_robot=cr, child_value=cv, reward=rew, value1=value1)
+
+
+def mprl_predict_batched(robot, humans, P: MprlParams, cfg: OracleConfig, return_levels=False):
+    """robot (B,9), humans (B,H,5) fp32 tensors -> (best action (B,) int64, best value (B,) fp32,
+    root_values (B,W0) fp32, root_kept (B,W0) int64).  W0 = width if clipping else |A|."""
+    actions, groups = mprl_action_space(cfg, cfg.v_pref)
+    A = actions.shape[0]
+    gamma = _normalized_gamma(cfg)
+    D = cfg.planning_depth
+    w = cfg.planning_width if cfg.do_action_clip else A
+    B = robot.shape[0]
+    levels = []
+    pr, ph = robot, humans
+    for lvl in range(D):
+        ex = mprl_expand_batched(pr, ph, P, cfg, actions, root=(lvl == 0))
+        if cfg.do_action_clip:
+            keep = select_top(ex["value1"].numpy(), w, groups, cfg.sparse_search)
+        else:
+            keep = np.tile(np.arange(A), (pr.shape[0], 1))
+        ex["keep"] = torch.tensor(keep)
+        levels.append(ex)
+        if lvl + 1 < D:
+            kt = ex["keep"]
+            pr = torch.gather(ex["child_robot"], 1, kt[:, :, None].expand(-1, -1, 9)).reshape(-1, 9)
+            ph = ex["next_humans"][:, None].expand(-1, w, -1, -1).reshape(-1, ph.shape[1], 5)
+    # back-up, deepest level first.  ret(level l parent-slot) for d = D - l ... see V_planning
+    kt = levels[D - 1]["keep"]
+    nv = torch.gather(levels[D - 1]["child_value"], 1, kt)            # V_planning(child, 1) = V(child)
+    for lvl in range(D - 1, 0, -1):
+        d = D - lvl + 1                                               # depth argument at this level
+        ex = levels[lvl]
+        kt = ex["keep"]
+        r = torch.gather(ex["reward"], 1, kt)
+        v_parent = torch.gather(levels[lvl - 1]["child_value"], 1, levels[lvl - 1]["keep"]).reshape(-1, 1)
+        ret = v_parent / d + (d - 1) / d * (gamma * nv + r)
+        nv = ret.max(dim=1).values.reshape(-1, w)                     # becomes V_planning(parent, d)
+    r0 = torch.gather(levels[0]["reward"], 1, levels[0]["keep"])
+    root_vals = r0 + gamma * nv
+    # first strict maximum in kept order
+    best_slot = torch.tensor(np.argmax(root_vals.numpy(), axis=1))
+    best_a = torch.gather(levels[0]["keep"], 1, best_slot[:, None]).reshape(-1)
+    best_v = torch.gather(root_vals, 1, best_slot[:, None]).reshape(-1)
+    out = (best_a, best_v, root_vals, levels[0]["keep"])
+    return out + (levels,) if return_levels else out
+
+
+# --------------------------------------------------------------------------------------------------
+# path G: pairwise rotated features + ValueNetwork + one-step search
+# --------------------------------------------------------------------------------------------------
+def rotate_pairwise(state14, kinematics="holonomic"):
+    """(R,14) [robot 9 | human 5] -> (R,13) agent-centric relation features."""
+    s = state14
+    dx, dy = s[:, 5] - s[:, 0], s[:, 6] - s[:, 1]
+    rot = torch.atan2(dy, dx)
+    c, sn = torch.cos(rot), torch.sin(rot)
+    dg = torch.norm(torch.stack([dx, dy], dim=1), 2, dim=1)
+    vx = s[:, 2] * c + s[:, 3] * sn
+    vy = s[:, 3] * c - s[:, 2] * sn
+    theta = (s[:, 8] - rot) if kinematics == "unicycle" else torch.zeros_like(dg)
+    vx1 = s[:, 11] * c + s[:, 12] * sn
+    vy1 = s[:, 12] * c - s[:, 11] * sn
+    px1 = (s[:, 9] - s[:, 0]) * c + (s[:, 10] - s[:, 1]) * sn
+    py1 = (s[:, 10] - s[:, 1]) * c - (s[:, 9] - s[:, 0]) * sn
+    da = torch.norm(torch.stack([s[:, 0] - s[:, 9], s[:, 1] - s[:, 10]], dim=1), 2, dim=1)
+    return torch.stack([dg, s[:, 7], theta, s[:, 4], vx, vy, px1, py1, vx1, vy1, s[:, 13], da,
+                        s[:, 4] + s[:, 13]], dim=1)
+
+
+def gcn_value_forward(state13, sd, cfg, self_dim=6):
+    """(B,H,13) -> (value (B,1), A (B,N,N)).  Only num_layer in {1,2} exists on path G."""
+    xr = mlp_forward(state13[:, 0, :self_dim], mlp_layers(sd, "w_r."), last_relu=True)
+    xh = mlp_forward(state13[:, :, self_dim:], mlp_layers(sd, "w_h."), last_relu=True)
+    X = torch.cat([xr.unsqueeze(1), xh], dim=1)
+    if cfg.num_layer == 1:
+        A = similarity_matrix(X, sd, cfg.similarity)
+        feat = torch.relu(torch.matmul(torch.matmul(A, X), sd["w1"]))[:, 0, :]   # no skip with one layer
+    elif cfg.num_layer == 2:
+        A = similarity_matrix(X, sd, cfg.similarity)
+        h1 = torch.relu(torch.matmul(torch.matmul(A, X), sd["w1"]))
+        if cfg.skip_connection:
+            h1 = h1 + X
+        A2 = similarity_matrix(h1, sd, cfg.similarity) if cfg.layerwise_graph else A
+        h2 = torch.relu(torch.matmul(torch.matmul(A2, h1), sd["w2"]))
+        if cfg.skip_connection:
+            h2 = h2 + h1
+        feat = h2[:, 0, :]
+    else:
+        raise NotImplementedError
+    return mlp_forward(feat, mlp_layers(sd, "value_net."), last_relu=False), A
+
+
+def compute_reward_g(nav, humans, dt):
+    """nav: 9 float64 scalars (propagated robot), humans: rows of 5 float64 (propagated humans)."""
+    dmin, collision = float("inf"), False
+    for h in humans:
+        d = np.linalg.norm((nav[0] - h[0], nav[1] - h[1])) - nav[4] - h[4]
+        if d < 0:
+            collision = True
+            break
+        if d < dmin:
+            dmin = d
+    reaching = np.linalg.norm((nav[0] - nav[5], nav[1] - nav[6])) < nav[4]
+    if collision:
+        return -0.25
+    if reaching:
+        return 1
+    if dmin < 0.2:
+        return (dmin - 0.2) * 0.5 * dt
+    return 0
+
+
+def gcn_predict_sequential(robot9, humans, sd, cfg):
+    """One-step lookahead of path G: returns (action index, action_values (A,) float64 list)."""
+    actions = cadrl_action_space(cfg, robot9[7])
+    dt = cfg.time_step
+    gam = pow(cfg.gamma, dt * robot9[7])
+    vals = []
+    best, best_v = None, float("-inf")
+    for ai, a in enumerate(actions):
+        if cfg.kinematics == "holonomic":
+            nr = [robot9[0] + a[0] * dt, robot9[1] + a[1] * dt, a[0], a[1]] + list(robot9[4:9])
+        else:
+            th = robot9[8] + a[1]
+            nvx, nvy = a[0] * np.cos(th), a[0] * np.sin(th)
+            nr = [robot9[0] + nvx * dt, robot9[1] + nvy * dt, nvx, nvy] + list(robot9[4:8]) + [th]
+        nh = [[h[0] + h[2] * dt, h[1] + h[3] * dt, h[2], h[3], h[4]] for h in humans]
+        rew = compute_reward_g(nr, nh, dt)
+        joint = torch.tensor([list(nr) + list(h) for h in nh], dtype=torch.float32)
+        rot = rotate_pairwise(joint, cfg.kinematics).unsqueeze(0)
+        v = gcn_value_forward(rot, sd, cfg)[0].item()
+        val = rew + gam * v
+        vals.append(val)
+        if val > best_v:
+            best_v, best = val, ai
+    return best, vals

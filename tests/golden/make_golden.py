@@ -1,0 +1,579 @@
+"""Generate the golden fixtures by running the upstream reference itself (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Writes tests/golden/*.npz.  Fixtures are DATA (inputs, weights and the outputs the reference
+produced); no reference source travels.  The GPU box never runs this script -- it only reads the
+committed .npz files.
+
+Shims applied to the reference *at run time, in memory* (SURVEY.md §8c), never to its files:
+  * everything runs under torch.no_grad() (np.array() of grad-tracking tensors raises),
+  * the value estimator's output is reshaped to a 0-d tensor (np.argpartition over (1,1) tensors
+    raises on current numpy); values are unchanged.
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_loader  # noqa: E402
+
+policy_factory = ref_loader.load_reference()
+
+from crowd_nav.policy.graph_model import RGL  # noqa: E402
+from crowd_nav.policy.value_estimator import ValueEstimator  # noqa: E402
+from crowd_nav.policy.state_predictor import StatePredictor, LinearStatePredictor  # noqa: E402
+from crowd_nav.policy import gcn as ref_gcn  # noqa: E402
+from crowd_sim.envs.utils.state import FullState, ObservableState, JointState  # noqa: E402
+from crowd_sim.envs.utils.action import ActionXY, ActionRot  # noqa: E402
+from crowd_sim.envs.utils.utils import point_to_segment_dist  # noqa: E402
+
+SIMS = ["embedded_gaussian", "gaussian", "cosine", "cosine_softmax", "concatenation", "squared",
+        "equal_attention", "diagonal"]
+
+
+def policy_config(name="mp_separate", **over):
+    mod = importlib.import_module("crowd_nav.configs.icra_benchmark." + name)
+    pc = mod.PolicyConfig()
+    for k, v in over.items():
+        sect, key = k.split("__")
+        setattr(getattr(pc, sect), key, v)
+    return pc
+
+
+def flat(prefix, sd):
+    return {prefix + k: v.detach().cpu().numpy().astype(np.float32) for k, v in sd.items()}
+
+
+def synth_scene(rng, B, H, moving=True):
+    """Seeded crowd states: robot on a radius-4 circle heading to the antipode, humans U(-5,5)^2
+    kept >= 0.8 apart from everything (mirrors the clearance rule of the simulator)."""
+    robot = np.zeros((B, 9), np.float32)
+    humans = np.zeros((B, H, 5), np.float32)
+    for b in range(B):
+        ang = rng.uniform(0, 2 * np.pi)
+        p = 4 * np.array([np.cos(ang), np.sin(ang)]) + rng.uniform(-0.5, 0.5, 2)
+        v = rng.uniform(-1, 1, 2) if moving else np.zeros(2)
+        sp = np.linalg.norm(v)
+        if sp > 1:
+            v = v / sp
+        g = -4 * np.array([np.cos(ang), np.sin(ang)])
+        robot[b] = [p[0], p[1], v[0], v[1], 0.3, g[0], g[1], 1.0, np.pi / 2]
+        placed = [p]
+        for h in range(H):
+            for _ in range(10000):
+                q = rng.uniform(-5, 5, 2)
+                if all(np.linalg.norm(q - o) >= 0.8 for o in placed):
+                    break
+            placed.append(q)
+            hv = rng.uniform(-1, 1, 2) if moving else np.zeros(2)
+            humans[b, h] = [q[0], q[1], hv[0], hv[1], 0.3]
+    return robot, humans
+
+
+def crowd_around_robot(rng, robot, humans, dmin, dmax):
+    """Re-place every human at a random bearing, dmin..dmax from its scene's robot (in place)."""
+    for b in range(robot.shape[0]):
+        for h in range(humans.shape[1]):
+            d, ang = rng.uniform(dmin, dmax), rng.uniform(0, 2 * np.pi)
+            humans[b, h, 0] = robot[b, 0] + d * np.cos(ang)
+            humans[b, h, 1] = robot[b, 1] + d * np.sin(ang)
+
+
+# --------------------------------------------------------------------------------------------------
+# master weights: one random-init set (reference constructors under a torch seed) and a
+# "trained-like" set (w_a, Ws scaled by 1/sqrt(32) so the softmax is not one-hot)
+# --------------------------------------------------------------------------------------------------
+def make_master(seed, scale):
+    torch.manual_seed(seed)
+    pc = policy_config(gcn__num_layer=3)
+    g1 = RGL(pc, 9, 5)
+    g2 = RGL(pc, 9, 5)
+    ve = ValueEstimator(pc, g1)
+    sp = StatePredictor(pc, g2, 0.25)
+    pcc = policy_config(gcn__num_layer=3, gcn__similarity_function="concatenation")
+    gc = RGL(pcc, 9, 5)
+    master = {}
+    master.update(flat("graph_model1.", g1.state_dict()))
+    master.update(flat("graph_model2.", g2.state_dict()))
+    master.update(flat("value_network.", ve.value_network.state_dict()))
+    master.update(flat("motion_predictor.", sp.human_motion_predictor.state_dict()))
+    master.update({"concat_w_a." + k[len("w_a."):]: v.detach().numpy().astype(np.float32)
+                   for k, v in gc.state_dict().items() if k.startswith("w_a.")})
+    if scale != 1.0:
+        for k in list(master):
+            if k.endswith(".w_a") or ".Ws." in k:
+                master[k] = (master[k] * scale).astype(np.float32)
+    return master
+
+
+def graph_sd(master, which, L, similarity):
+    pre = which + "."
+    sd = {k[len(pre):]: torch.tensor(v) for k, v in master.items()
+          if k.startswith(pre) and not k[len(pre):].startswith("Ws.")}
+    for l in range(L):
+        sd["Ws.%d" % l] = torch.tensor(master[pre + "Ws.%d" % l])
+    if similarity == "concatenation":
+        sd.pop("w_a")
+        for k, v in master.items():
+            if k.startswith("concat_w_a."):
+                sd["w_a." + k[len("concat_w_a."):]] = torch.tensor(v)
+    elif similarity != "embedded_gaussian":
+        sd.pop("w_a")
+    return sd
+
+
+def sub_sd(master, which):
+    pre = which + "."
+    return {k[len(pre):]: torch.tensor(v) for k, v in master.items() if k.startswith(pre)}
+
+
+def build_ref_modules(master, L=2, similarity="embedded_gaussian", layerwise=False, skip=True, share=False):
+    pc = policy_config(gcn__num_layer=L, gcn__similarity_function=similarity,
+                       gcn__layerwise_graph=layerwise, gcn__skip_connection=skip)
+    g1 = RGL(pc, 9, 5)
+    g1.load_state_dict(graph_sd(master, "graph_model1", L, similarity))
+    if share:
+        g2 = g1
+    else:
+        g2 = RGL(pc, 9, 5)
+        g2.load_state_dict(graph_sd(master, "graph_model2", L, similarity))
+    ve = ValueEstimator(pc, g1)
+    ve.value_network.load_state_dict(sub_sd(master, "value_network"))
+    sp = StatePredictor(pc, g2, 0.25)
+    sp.human_motion_predictor.load_state_dict(sub_sd(master, "motion_predictor"))
+    return pc, g1, g2, ve, sp
+
+
+# --------------------------------------------------------------------------------------------------
+def gen_forward_kats(masters, out):
+    rng = np.random.RandomState(11)
+    cases = []
+    # default-flag sweeps over crowd size / depth of the GCN / weight flavour
+    for H, B, L, flavour in [(1, 3, 2, "rand"), (5, 4, 2, "rand"), (5, 4, 2, "trained"), (19, 3, 2, "trained"),
+                             (19, 2, 1, "rand"), (49, 2, 3, "trained"), (19, 2, 3, "rand")]:
+        cases.append(dict(H=H, B=B, L=L, flavour=flavour, sim="embedded_gaussian", layerwise=False, skip=True))
+    # every similarity x layerwise x skip on a small crowd
+    for sim in SIMS:
+        for lw in (False, True):
+            for sk in (False, True):
+                cases.append(dict(H=5, B=3, L=2, flavour="trained", sim=sim, layerwise=lw, skip=sk))
+    meta = []
+    for ci, c in enumerate(cases):
+        robot, humans = synth_scene(rng, c["B"], c["H"])
+        pc, g1, g2, ve, sp = build_ref_modules(masters[c["flavour"]], c["L"], c["sim"], c["layerwise"], c["skip"])
+        r = torch.tensor(robot).unsqueeze(1)
+        h = torch.tensor(humans)
+        with torch.no_grad():
+            HL = g1((r, h))
+            X = torch.cat([g1.w_r(r), g1.w_h(h)], dim=1)
+            A = g1.compute_similarity_matrix(X)
+            val = ve((r, h))
+            nh = sp((r, h), None)[1]
+        k = "f%02d." % ci
+        out[k + "robot"], out[k + "humans"] = robot, humans
+        out[k + "H_L"], out[k + "A"] = HL.numpy(), A.numpy().astype(np.float32)
+        out[k + "value"], out[k + "humans_next"] = val.numpy(), nh.numpy()
+        meta.append("%d|%d|%d|%s|%s|%d|%d" % (c["H"], c["B"], c["L"], c["flavour"], c["sim"],
+                                              int(c["layerwise"]), int(c["skip"])))
+    out["forward_cases"] = np.array(meta)
+
+
+def gen_state_predictor_kats(masters, out):
+    rng = np.random.RandomState(12)
+    robot, humans = synth_scene(rng, 1, 5)
+    pc, g1, g2, ve, sp = build_ref_modules(masters["trained"])
+    r = torch.tensor(robot).unsqueeze(1)
+    h = torch.tensor(humans)
+    acts = [ActionXY(0, 0), ActionXY(np.float64(0.3), np.float64(-0.7)), ActionXY(np.float64(-1.0), np.float64(0.123456789))]
+    nr = []
+    with torch.no_grad():
+        for a in acts:
+            o = sp((r, h), a)
+            nr.append(o[0].numpy().reshape(9))
+        lin = LinearStatePredictor(pc, 0.25)
+        lo = lin((r, h), acts[1])
+    out["sp.robot"], out["sp.humans"] = robot, humans
+    out["sp.actions"] = np.array([[a.vx, a.vy] for a in acts], np.float64)
+    out["sp.next_robot"] = np.array(nr, np.float32)
+    out["sp.linear_next_robot"] = lo[0].numpy().reshape(9)
+    out["sp.linear_next_humans"] = lo[1].numpy()
+    # unicycle kinematics (pins the slot-7 quirk)
+    pcu = policy_config(action_space__kinematics="unicycle")
+    spu = StatePredictor(pcu, g2, 0.25)
+    ua = ActionRot(np.float64(0.8), np.float64(0.4))
+    with torch.no_grad():
+        out["sp.unicycle_next_robot"] = spu.compute_next_state(r, ua).numpy().reshape(9)
+    out["sp.unicycle_action"] = np.array([ua.v, ua.r], np.float64)
+    # restore the class-level shared config attribute the constructor above mutated
+    policy_config(action_space__kinematics="holonomic")
+
+
+def gen_action_spaces(out):
+    pc = policy_config()
+    pol = policy_factory["model_predictive_rl"]()
+    pol.configure(pc)
+    pol.build_action_space(1.0)
+    out["act.mprl"] = np.array([[a.vx, a.vy] for a in pol.action_space], np.float64)
+    out["act.mprl_groups"] = np.array(pol.action_group_index, np.int64)
+    pg = policy_factory["gcn"]()
+    pg.configure(policy_config("rgl"))
+    pg.build_action_space(1.0)
+    out["act.gcn"] = np.array([[a.vx, a.vy] for a in pg.action_space], np.float64)
+    pol2 = policy_factory["model_predictive_rl"]()
+    pol2.configure(pc)
+    pol2.build_action_space(0.7)
+    out["act.mprl_vpref07"] = np.array([[a.vx, a.vy] for a in pol2.action_space], np.float64)
+    # unicycle tables
+    pcu = policy_config(action_space__kinematics="unicycle")
+    pu = policy_factory["model_predictive_rl"]()
+    pu.configure(pcu)
+    pu.build_action_space(1.0)
+    out["act.mprl_unicycle"] = np.array([[a.v, a.r] for a in pu.action_space], np.float64)
+    policy_config(action_space__kinematics="holonomic")
+
+
+def gen_reward_kats(out):
+    pc = policy_config()
+    pol = policy_factory["model_predictive_rl"]()
+    pol.configure(pc)
+    pol.set_time_step(0.25)
+    # hand-built states hitting: free, discomfort, collision, goal, degenerate segment, clamped ends
+    R = FullState(0.0, 0.0, 0.0, 0.0, 0.3, 3.0, 0.0, 1.0, 0.0)
+    cases = [
+        ("free", R, [ObservableState(3.0, 3.0, 0.1, 0.0, 0.3)], ActionXY(0.5, 0.0)),
+        ("discomfort", R, [ObservableState(0.75, 0.0, 0.0, 0.0, 0.3)], ActionXY(0.0, 0.5)),
+        ("collision", R, [ObservableState(0.7, 0.0, -0.5, 0.0, 0.3)], ActionXY(1.0, 0.0)),
+        ("collision_first", R, [ObservableState(0.5, 0.0, 0.0, 0.0, 0.3), ObservableState(0.9, 0.3, 0.0, 0.0, 0.3)], ActionXY(0.0, 0.0)),
+        ("goal", FullState(2.8, 0.0, 0.0, 0.0, 0.3, 3.0, 0.0, 1.0, 0.0), [ObservableState(-3.0, 3.0, 0.0, 0.0, 0.3)], ActionXY(0.5, 0.0)),
+        ("degenerate", R, [ObservableState(0.72, 0.0, 0.0, 0.0, 0.3)], ActionXY(0.0, 0.0)),
+        ("clamp_u1", R, [ObservableState(2.0, 0.0, -1.0, 0.0, 0.3)], ActionXY(1.0, 0.0)),
+        ("clamp_u0", R, [ObservableState(0.9, 0.0, 1.0, 0.0, 0.3)], ActionXY(-1.0, 0.0)),
+        ("two_humans", R, [ObservableState(0.0, 0.78, 0.0, 0.0, 0.3), ObservableState(-0.74, 0.0, 0.0, 0.0, 0.3)], ActionXY(0.2, 0.0)),
+    ]
+    names, robots, humans, acts, r_joint, r_tensor, nh = [], [], [], [], [], [], []
+    for name, rs, hs, a in cases:
+        a = ActionXY(np.float64(a.vx), np.float64(a.vy))
+        js = JointState(rs, hs)
+        r_joint.append(float(pol.estimate_reward(js, a)))
+        ts = js.to_tensor(add_batch_size=True)
+        r_tensor.append(float(pol.estimate_reward(ts, a)))
+        names.append(name)
+        robots.append(rs.to_tuple())
+        hh = np.zeros((2, 5), np.float64)
+        for i, h_ in enumerate(hs):
+            hh[i] = h_.to_tuple()
+        humans.append(hh)
+        nh.append(len(hs))
+        acts.append([a.vx, a.vy])
+    out["rew.names"] = np.array(names)
+    out["rew.robot"] = np.array(robots, np.float64)
+    out["rew.humans"] = np.array(humans, np.float64)
+    out["rew.n_humans"] = np.array(nh, np.int64)
+    out["rew.actions"] = np.array(acts, np.float64)
+    out["rew.joint"] = np.array(r_joint, np.float64)
+    out["rew.tensor"] = np.array(r_tensor, np.float64)
+    # random sweep (tensor-born states, all 81 actions) -- the bulk check for the batched reward
+    rng = np.random.RandomState(13)
+    pol.build_action_space(1.0)
+    robot, hum = synth_scene(rng, 6, 7)
+    for b, lo in enumerate([0.45, 0.62, 0.7, 0.85, 1.0, 1.3]):   # crowd so every branch is populated
+        crowd_around_robot(rng, robot[b:b + 1], hum[b:b + 1], lo, lo + 1.5)
+    sweep = np.zeros((6, len(pol.action_space)), np.float64)
+    sweep_joint = np.zeros_like(sweep)
+    for b in range(6):
+        ts = (torch.tensor(robot[b]).reshape(1, 1, 9), torch.tensor(hum[b]).reshape(1, 7, 5))
+        js = JointState(FullState(*[float(x) for x in robot[b]]),
+                        [ObservableState(*[float(x) for x in row]) for row in hum[b]])
+        for ai, a in enumerate(pol.action_space):
+            sweep[b, ai] = pol.estimate_reward(ts, a)
+            sweep_joint[b, ai] = pol.estimate_reward(js, a)
+    out["rew.sweep_robot"], out["rew.sweep_humans"] = robot, hum
+    out["rew.sweep_tensor"], out["rew.sweep_joint"] = sweep, sweep_joint
+    # point_to_segment_dist
+    pts = np.array([[0, 0, 1, 0, 0.5, 1], [0, 0, 1, 0, 2, 1], [0, 0, 1, 0, -1, -1], [1, 1, 1, 1, 4, 5],
+                    [-1, 2, 3, -2, 0, 0], [0.3, 0.1, 0.3, 0.1, 0, 0]], np.float64)
+    out["p2s.in"] = pts
+    out["p2s.out"] = np.array([point_to_segment_dist(*p) for p in pts], np.float64)
+    # path G reward
+    pg = policy_factory["gcn"]()
+    pg.configure(policy_config("rgl"))
+    pg.time_step = 0.25
+    g_out = []
+    for name, rs, hs, a in cases:
+        g_out.append(float(pg.compute_reward(rs, hs)))
+    out["rew.g"] = np.array(g_out, np.float64)
+
+
+# --------------------------------------------------------------------------------------------------
+class PlanRecorder:
+    """Wraps a reference ModelPredictiveRL so one predict() call yields the numbers a test needs."""
+
+    def __init__(self, pol):
+        self.pol = pol
+        self.nest = 0
+        self.top_returns = []
+        self.clipped = None
+        self.nv = 0
+        self.nsp = 0
+        ve_fwd = pol.value_estimator.forward
+
+        def ve(state):
+            self.nv += 1
+            return ve_fwd(state).reshape(())
+        pol.value_estimator.forward = ve
+        if not isinstance(pol.state_predictor, LinearStatePredictor):
+            sp_fwd = pol.state_predictor.forward
+
+            def spf(state, action, detach=False):
+                self.nsp += 1
+                return sp_fwd(state, action, detach)
+            pol.state_predictor.forward = spf
+        vp = pol.V_planning
+
+        def vplan(state, depth, width):
+            self.nest += 1
+            try:
+                ret = vp(state, depth, width)
+            finally:
+                self.nest -= 1
+            if self.nest == 0:
+                self.top_returns.append(float(ret[0]))
+            return ret
+        pol.V_planning = vplan
+        ac = pol.action_clip
+
+        def aclip(state, action_space, width, depth=1):
+            res = ac(state, action_space, width, depth)
+            if self.nest == 0:
+                self.clipped = [self._index(a) for a in res]
+            return res
+        pol.action_clip = aclip
+
+    def _index(self, a):
+        for i, b in enumerate(self.pol.action_space):
+            if a is b:
+                return i
+        raise KeyError
+
+    def run(self, js):
+        self.top_returns, self.clipped, self.nv, self.nsp = [], None, 0, 0
+        with torch.no_grad():
+            action = self.pol.predict(js)
+        return self._index(action)
+
+
+def make_ref_mprl(master, D, w, clip, sparse, variant, L=2):
+    name = {"separate": "mp_separate", "shared": "mp_detach", "linear": "mp_linear"}[variant]
+    pc = policy_config(name, gcn__num_layer=L, model_predictive_rl__planning_depth=D,
+                       model_predictive_rl__planning_width=w, model_predictive_rl__do_action_clip=clip)
+    pc.model_predictive_rl.sparse_search = sparse
+    pol = policy_factory["model_predictive_rl"]()
+    pol.configure(pc)
+    pol.value_estimator.graph_model.load_state_dict(graph_sd(master, "graph_model1", L, "embedded_gaussian"))
+    pol.value_estimator.value_network.load_state_dict(sub_sd(master, "value_network"))
+    if variant == "separate":
+        pol.state_predictor.graph_model.load_state_dict(graph_sd(master, "graph_model2", L, "embedded_gaussian"))
+    if variant != "linear":
+        pol.state_predictor.human_motion_predictor.load_state_dict(sub_sd(master, "motion_predictor"))
+    pol.set_time_step(0.25)
+    pol.set_phase("test")
+    pol.set_device(torch.device("cpu"))
+    return pol
+
+
+def joint_state_of(robot_row, human_rows):
+    return JointState(FullState(*[float(x) for x in robot_row]),
+                      [ObservableState(*[float(x) for x in row]) for row in human_rows])
+
+
+def gen_planning_kats(masters, scenes, out):
+    rng = np.random.RandomState(14)
+    r5, h5 = synth_scene(rng, 3, 5)
+    r19, h19 = synth_scene(rng, 2, 19)
+    # crowd one scene so that reward branches fire inside the tree
+    crowd_around_robot(rng, r5[2:3], h5[2:3], 0.7, 2.5)
+    sets = {
+        "s5": (r5, h5), "s19": (r19, h19),
+        "env": (scenes["test_robot"][:3].astype(np.float32), scenes["test_humans"][:3].astype(np.float32)),
+    }
+    for k, (r, h) in sets.items():
+        out["plan.scene.%s.robot" % k], out["plan.scene.%s.humans" % k] = r, h
+    plans = [  # (tag, scene set, D, w, clip, sparse, variant, flavour)
+        ("d1", "s5", 1, 1, False, False, "separate", "trained"),
+        ("d1env", "env", 1, 1, False, False, "separate", "trained"),
+        ("d1rand", "s5", 1, 1, False, False, "separate", "rand"),
+        ("d2w1", "s5", 2, 1, True, False, "separate", "trained"),
+        ("d2w2", "s5", 2, 2, True, False, "separate", "trained"),
+        ("d2w2env", "env", 2, 2, True, False, "separate", "trained"),
+        ("d2w2n20", "s19", 2, 2, True, False, "separate", "trained"),
+        ("d3w2", "s5", 3, 2, True, False, "separate", "trained"),
+        ("d2w10", "s5", 2, 10, True, False, "separate", "trained"),
+        ("d2w2sparse", "s5", 2, 2, True, True, "separate", "trained"),
+        ("d2w4sparse", "s5", 2, 4, True, True, "separate", "trained"),
+        ("d2w2shared", "s5", 2, 2, True, False, "shared", "trained"),
+        ("d2w2linear", "s5", 2, 2, True, False, "linear", "trained"),
+        ("d1linear", "env", 1, 1, False, False, "linear", "trained"),
+    ]
+    meta = []
+    for tag, sk, D, w, clip, sparse, variant, flavour in plans:
+        pol = make_ref_mprl(masters[flavour], D, w, clip, sparse, variant)
+        rec = PlanRecorder(pol)
+        r, h = sets[sk]
+        gamma = pol.get_normalized_gamma()
+        acts, maxv, clipvals, kept, rootvals, counts = [], [], [], [], [], []
+        for b in range(r.shape[0]):
+            js = joint_state_of(r[b], h[b])
+            ai = rec.run(js)
+            acts.append(ai)
+            nA = len(pol.action_space)
+            if clip:
+                one_step = rec.top_returns[:nA]
+                main = rec.top_returns[nA:]
+                keep = rec.clipped
+                cv = [float(np.float32(pol.estimate_reward(js, pol.action_space[i])) +
+                            np.float32(gamma) * np.float32(one_step[i])) for i in range(nA)]
+                clipvals.append(cv)
+            else:
+                main = rec.top_returns
+                keep = list(range(nA))
+            rv = [float(np.float32(np.float32(pol.estimate_reward(js, pol.action_space[i])) +
+                                   np.float32(gamma) * np.float32(m))) for i, m in zip(keep, main)]
+            kept.append(keep)
+            rootvals.append(rv)
+            maxv.append(max(rv))
+            counts.append([rec.nv, rec.nsp])
+        k = "plan.%s." % tag
+        out[k + "action"] = np.array(acts, np.int64)
+        out[k + "max_value"] = np.array(maxv, np.float32)
+        out[k + "kept"] = np.array(kept, np.int64)
+        out[k + "root_values"] = np.array(rootvals, np.float32)
+        out[k + "counts"] = np.array(counts, np.int64)
+        if clip:
+            out[k + "clip_values"] = np.array(clipvals, np.float32)
+        meta.append("%s|%s|%d|%d|%d|%d|%s|%s" % (tag, sk, D, w, int(clip), int(sparse), variant, flavour))
+    out["plan_cases"] = np.array(meta)
+
+
+# --------------------------------------------------------------------------------------------------
+def gen_path_g(out, scenes):
+    torch.manual_seed(5)
+    pc = policy_config("rgl")
+    pol = policy_factory["gcn"]()
+    pol.configure(pc)
+    sd = pol.model.state_dict()
+    with torch.no_grad():
+        sd["w_a"].mul_(1 / np.sqrt(32))
+        sd["w1"].mul_(1 / np.sqrt(32))
+        sd["w2"].mul_(1 / np.sqrt(32))
+    out.update(flat("g.weights.", sd))
+    pol.set_phase("test")
+    pol.set_device(torch.device("cpu"))
+    pol.time_step = 0.25
+    # rotate KAT
+    rng = np.random.RandomState(15)
+    s14 = rng.uniform(-3, 3, (7, 14)).astype(np.float32)
+    s14[:, 4] = 0.3
+    s14[:, 13] = 0.35
+    out["g.rotate_in"] = s14
+    out["g.rotate_out"] = pol.rotate(torch.tensor(s14)).numpy()
+    pol.kinematics = "unicycle"
+    out["g.rotate_out_unicycle"] = pol.rotate(torch.tensor(s14)).numpy()
+    pol.kinematics = "holonomic"
+    # ValueNetwork KATs: L=2 (skip, non-layerwise = shipped config), plus flag variants and L=1
+    x13 = rng.uniform(-2, 2, (4, 5, 13)).astype(np.float32)
+    out["g.vn_in"] = x13
+    variants = [(2, False, True), (2, True, True), (2, False, False), (2, True, False), (1, False, True)]
+    meta = []
+    for L, lw, sk in variants:
+        pcv = policy_config("rgl", gcn__num_layer=L, gcn__layerwise_graph=lw, gcn__skip_connection=sk)
+        pv = policy_factory["gcn"]()
+        pv.configure(pcv)
+        msd = {k: v for k, v in sd.items() if not (L == 1 and k == "w2")}
+        pv.model.load_state_dict(msd)
+        with torch.no_grad():
+            v = pv.model(torch.tensor(x13))
+        tag = "L%d_lw%d_sk%d" % (L, int(lw), int(sk))
+        out["g.vn_value." + tag] = v.numpy()
+        out["g.vn_A0." + tag] = np.asarray(pv.model.A, np.float32)
+        meta.append(tag)
+    out["g_cases"] = np.array(meta)
+    policy_config("rgl", gcn__num_layer=2, gcn__layerwise_graph=False, gcn__skip_connection=True)
+    # predict on env scenes + a moving synthetic scene
+    rs, hs = scenes["test_robot"][:3], scenes["test_humans"][:3]
+    r2, h2 = synth_scene(np.random.RandomState(16), 2, 5)
+    rs = np.concatenate([rs, r2.astype(np.float64)])
+    hs = np.concatenate([hs, h2.astype(np.float64)])
+    acts, avals, A0 = [], [], []
+    for b in range(rs.shape[0]):
+        js = joint_state_of(rs[b], hs[b])
+        with torch.no_grad():
+            a = pol.predict(js)
+        acts.append([i for i, x in enumerate(pol.action_space) if x is a][0])
+        avals.append(pol.action_values)
+        A0.append(np.asarray(pol.get_matrix_A(), np.float32))
+    out["g.pred_robot"], out["g.pred_humans"] = rs, hs
+    out["g.pred_action"] = np.array(acts, np.int64)
+    out["g.pred_action_values"] = np.array(avals, np.float64)
+    out["g.pred_A_last"] = np.array(A0)
+
+
+def gen_env_scenes():
+    """Initial JointStates of the simulator's seeded cases (pure numpy scene generation)."""
+    import gym
+    from crowd_sim.envs.utils.robot import Robot
+    from crowd_sim.envs.policy import orca
+    # scene generation instantiates human policies; ORCA's constructor needs nothing from rvo2
+    envc = importlib.import_module("crowd_nav.configs.icra_benchmark.mp_separate").EnvConfig()
+    env = gym.make("CrowdSim-v0")
+    env.configure(envc)
+    robot = Robot(envc, "robot")
+    robot.time_step = env.time_step
+    pol = policy_factory["model_predictive_rl"]()
+    pol.configure(policy_config())
+    robot.set_policy(pol)
+    env.set_robot(robot)
+    scenes = {}
+    for phase, n in (("test", 10), ("val", 4)):
+        R, Hs = [], []
+        for k in range(n):
+            ob = env.reset(phase, k)
+            R.append(robot.get_full_state().to_tuple())
+            Hs.append([o.to_tuple() for o in ob])
+        scenes[phase + "_robot"] = np.array(R, np.float64)
+        scenes[phase + "_humans"] = np.array(Hs, np.float64)
+    return scenes
+
+
+def main():
+    torch.set_num_threads(1)
+    masters = {"rand": make_master(1, 1.0), "trained": make_master(2, 1.0 / np.sqrt(32.0))}
+    np.savez(os.path.join(HERE, "weights_rand.npz"), **masters["rand"])
+    np.savez(os.path.join(HERE, "weights_trained.npz"), **masters["trained"])
+    scenes = gen_env_scenes()
+    np.savez(os.path.join(HERE, "scenes.npz"), **scenes)
+    fw = {}
+    gen_forward_kats(masters, fw)
+    gen_state_predictor_kats(masters, fw)
+    np.savez(os.path.join(HERE, "forward.npz"), **fw)
+    misc = {}
+    gen_action_spaces(misc)
+    gen_reward_kats(misc)
+    np.savez(os.path.join(HERE, "actions_rewards.npz"), **misc)
+    pl = {}
+    gen_planning_kats(masters, scenes, pl)
+    np.savez(os.path.join(HERE, "planning.npz"), **pl)
+    pg = {}
+    gen_path_g(pg, scenes)
+    np.savez(os.path.join(HERE, "path_g.npz"), **pg)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print("%-24s %8.1f KB" % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))
+
+
+if __name__ == "__main__":
+    main()

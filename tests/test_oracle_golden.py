@@ -1,0 +1,198 @@
+"""Pins the CPU oracle against fixtures produced by the reference itself (tests/golden/make_golden.py).
+
+These run on CPU (`-m "not gpu"`).  Tolerances: fp32 forward 2e-6 abs/rel-ish (measured noise ~1e-7),
+rewards 1e-7 (float64 scalar code), action tables exact to 1e-15.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rgl_oracle as orc
+from tests import golden_io as gio
+
+
+def cfg_of(c, **kw):
+    return orc.OracleConfig(num_layer=c.get("L", 2), similarity=c.get("sim", "embedded_gaussian"),
+                            layerwise_graph=c.get("layerwise", False), skip_connection=c.get("skip", True), **kw)
+
+
+def close(a, b, tol):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    scale = max(1.0, float(np.abs(b).max()))
+    assert a.shape == b.shape
+    assert np.abs(a - b).max() <= tol * scale, (np.abs(a - b).max(), scale)
+
+
+@pytest.mark.parametrize("c", gio.forward_cases(), ids=lambda c: "f%02d-%s-H%d-L%d-lw%d-sk%d" % (
+    c["idx"], c["sim"], c["H"], c["L"], c["layerwise"], c["skip"]))
+def test_forward_kats(c):
+    fw = gio.load("forward")
+    k = "f%02d." % c["idx"]
+    m = gio.master(c["flavour"])
+    cfg = cfg_of(c)
+    g1 = gio.graph_sd(m, "graph_model1", c["L"], c["sim"])
+    g2 = gio.graph_sd(m, "graph_model2", c["L"], c["sim"])
+    robot = torch.tensor(fw[k + "robot"]).unsqueeze(1)
+    humans = torch.tensor(fw[k + "humans"])
+    H_L, _ = orc.rgl_forward(robot, humans, g1, cfg)
+    A = orc.similarity_matrix(orc.rgl_embed(robot, humans, g1), g1, c["sim"])
+    val = orc.value_estimator_forward(robot, humans, g1, gio.sub_sd(m, "value_network"), cfg)
+    nh = orc.state_predictor_humans(robot, humans, g2, gio.sub_sd(m, "motion_predictor"), cfg)
+    close(H_L.numpy(), fw[k + "H_L"], 2e-6)
+    close(A.numpy(), fw[k + "A"], 2e-6)
+    close(val.numpy(), fw[k + "value"], 2e-6)
+    close(nh.numpy(), fw[k + "humans_next"], 2e-6)
+
+
+def test_state_predictor_kats():
+    fw = gio.load("forward")
+    cfg = orc.OracleConfig()
+    r = torch.tensor(fw["sp.robot"]).reshape(9)
+    for a, want in zip(fw["sp.actions"], fw["sp.next_robot"]):
+        got = orc.next_robot_state(r, a, cfg).numpy()
+        assert np.array_equal(got, want)
+    got = orc.linear_humans(torch.tensor(fw["sp.humans"])).numpy()
+    assert np.array_equal(got, fw["sp.linear_next_humans"])
+    assert np.array_equal(orc.next_robot_state(r, fw["sp.actions"][1], cfg).numpy(), fw["sp.linear_next_robot"])
+    ucfg = orc.OracleConfig(kinematics="unicycle")
+    got = orc.next_robot_state(r, fw["sp.unicycle_action"], ucfg).numpy()
+    close(got, fw["sp.unicycle_next_robot"], 1e-6)
+    assert got[8] == r.numpy()[8] and got[7] != r.numpy()[7]     # the slot-7 quirk is pinned
+
+
+def test_action_spaces():
+    ar = gio.load("actions_rewards")
+    acts, groups = orc.mprl_action_space(orc.OracleConfig(), 1.0)
+    assert np.abs(acts - ar["act.mprl"]).max() < 1e-15
+    assert np.array_equal(groups, ar["act.mprl_groups"])
+    assert np.abs(orc.mprl_action_space(orc.OracleConfig(), 0.7)[0] - ar["act.mprl_vpref07"]).max() < 1e-15
+    assert np.abs(orc.cadrl_action_space(orc.OracleConfig(), 1.0) - ar["act.gcn"]).max() < 1e-15
+    ua = orc.mprl_action_space(orc.OracleConfig(kinematics="unicycle"), 1.0)[0]
+    assert np.abs(ua - ar["act.mprl_unicycle"]).max() < 1e-15
+
+
+def test_reward_kats():
+    ar = gio.load("actions_rewards")
+    cfg = orc.OracleConfig()
+    for i, name in enumerate(ar["rew.names"]):
+        n = int(ar["rew.n_humans"][i])
+        robot = [float(x) for x in ar["rew.robot"][i]]
+        humans = [[float(x) for x in row] for row in ar["rew.humans"][i][:n]]
+        a = ar["rew.actions"][i]
+        assert abs(orc.estimate_reward(robot, humans, a, cfg) - ar["rew.joint"][i]) < 1e-12, name
+        r32 = [np.float32(x) for x in robot]
+        h32 = [[np.float32(x) for x in row] for row in humans]
+        assert abs(orc.estimate_reward(r32, h32, a, cfg) - ar["rew.tensor"][i]) < 1e-12, name
+        assert abs(orc.compute_reward_g(robot, humans, 0.25) - ar["rew.g"][i]) < 1e-12, name
+    # every branch must actually be present in the KAT set
+    assert {-0.25, 1.0, 0.0} <= set(np.round(ar["rew.joint"], 6)) and (ar["rew.joint"] < 0).sum() >= 3
+
+
+def test_reward_sweep_batched():
+    ar = gio.load("actions_rewards")
+    cfg = orc.OracleConfig()
+    acts, _ = orc.mprl_action_space(cfg, 1.0)
+    r = torch.tensor(ar["rew.sweep_robot"])
+    h = torch.tensor(ar["rew.sweep_humans"])
+    got_t = orc.estimate_reward_batched(r, h, acts, cfg, root=False)
+    got_j = orc.estimate_reward_batched(r, h, acts, cfg, root=True)
+    assert np.abs(got_t - ar["rew.sweep_tensor"]).max() < 1e-7
+    assert np.abs(got_j - ar["rew.sweep_joint"]).max() < 1e-7
+    vals = np.round(ar["rew.sweep_tensor"], 6)
+    assert (vals == -0.25).any() and (vals == 0).any() and ((vals < 0) & (vals > -0.25)).any()
+
+
+def test_point_to_segment():
+    ar = gio.load("actions_rewards")
+    for p, want in zip(ar["p2s.in"], ar["p2s.out"]):
+        assert abs(orc.point_to_segment_dist(*p) - want) < 1e-15
+
+
+@pytest.mark.parametrize("c", gio.plan_cases(), ids=lambda c: c["tag"])
+def test_planning_sequential(c):
+    """The reference-order walk: same action, same values, same number of forwards."""
+    pl = gio.load("planning")
+    k = "plan.%s." % c["tag"]
+    P = gio.oracle_params(c["flavour"], 2, c["variant"])
+    cfg = orc.OracleConfig(planning_depth=c["D"], planning_width=c["w"], do_action_clip=c["clip"],
+                           sparse_search=c["sparse"], linear_state_predictor=(c["variant"] == "linear"))
+    R = pl["plan.scene.%s.robot" % c["scene"]]
+    Hh = pl["plan.scene.%s.humans" % c["scene"]]
+    with torch.no_grad():
+        for b in range(R.shape[0]):
+            tr = orc.SeqTrace()
+            a, v = orc.mprl_predict_sequential([float(x) for x in R[b]], [[float(x) for x in row] for row in Hh[b]],
+                                               P, cfg, tr)
+            assert a == int(pl[k + "action"][b])
+            assert abs(float(v) - float(pl[k + "max_value"][b])) < 2e-6 * max(1.0, abs(float(v)))
+            assert tr.root_clipped == [int(x) for x in pl[k + "kept"][b]]
+            close(tr.root_values, pl[k + "root_values"][b], 2e-6)
+            if c["clip"]:
+                close(tr.root_clip_values, pl[k + "clip_values"][b], 2e-6)
+            assert tr.n_value_forwards == int(pl[k + "counts"][b][0])
+            if c["variant"] != "linear":
+                assert tr.n_predictor_forwards == int(pl[k + "counts"][b][1])
+
+
+@pytest.mark.parametrize("c", gio.plan_cases(), ids=lambda c: c["tag"])
+def test_planning_batched(c):
+    """The level-synchronous restatement gives the reference's decisions and values."""
+    pl = gio.load("planning")
+    k = "plan.%s." % c["tag"]
+    P = gio.oracle_params(c["flavour"], 2, c["variant"])
+    cfg = orc.OracleConfig(planning_depth=c["D"], planning_width=c["w"], do_action_clip=c["clip"],
+                           sparse_search=c["sparse"], linear_state_predictor=(c["variant"] == "linear"))
+    R = torch.tensor(pl["plan.scene.%s.robot" % c["scene"]].astype(np.float32))
+    Hh = torch.tensor(pl["plan.scene.%s.humans" % c["scene"]].astype(np.float32))
+    with torch.no_grad():
+        a, v, rv, kept, levels = orc.mprl_predict_batched(R, Hh, P, cfg, return_levels=True)
+    assert np.array_equal(a.numpy(), pl[k + "action"])
+    close(v.numpy(), pl[k + "max_value"], 3e-6)
+    # kept sets agree as sets (order inside the clipped set is a tie-break detail)
+    for b in range(R.shape[0]):
+        assert sorted(kept[b].tolist()) == sorted(pl[k + "kept"][b].tolist())
+        order = [kept[b].tolist().index(int(i)) for i in pl[k + "kept"][b]]
+        close(rv[b].numpy()[order], pl[k + "root_values"][b], 3e-6)
+    if c["clip"]:
+        close(levels[0]["value1"].numpy(), pl[k + "clip_values"], 3e-6)
+
+
+def test_forward_counts_match_survey():
+    pl = gio.load("planning")
+    want = {"d1": 81, "d2w2": 249, "d3w2": 581}
+    for tag, n in want.items():
+        assert (pl["plan.%s.counts" % tag][:, 0] == n).all()
+
+
+def test_path_g_rotate_and_value_network():
+    g = gio.load("path_g")
+    sd = gio.path_g_sd()
+    close(orc.rotate_pairwise(torch.tensor(g["g.rotate_in"])).numpy(), g["g.rotate_out"], 1e-6)
+    close(orc.rotate_pairwise(torch.tensor(g["g.rotate_in"]), "unicycle").numpy(), g["g.rotate_out_unicycle"], 1e-6)
+    x = torch.tensor(g["g.vn_in"])
+    for tag in g["g_cases"]:
+        tag = str(tag)
+        L, lw, sk = int(tag[1]), bool(int(tag[5])), bool(int(tag[9]))
+        cfg = orc.OracleConfig(num_layer=L, layerwise_graph=lw, skip_connection=sk)
+        v, A = orc.gcn_value_forward(x, sd, cfg)
+        close(v.numpy(), g["g.vn_value." + tag], 2e-6)
+        close(A[0].numpy(), g["g.vn_A0." + tag], 2e-6)
+
+
+def test_path_g_predict():
+    g = gio.load("path_g")
+    sd = gio.path_g_sd()
+    cfg = orc.OracleConfig()
+    for b in range(g["g.pred_robot"].shape[0]):
+        a, vals = orc.gcn_predict_sequential([float(x) for x in g["g.pred_robot"][b]],
+                                             [[float(x) for x in row] for row in g["g.pred_humans"][b]], sd, cfg)
+        assert a == int(g["g.pred_action"][b])
+        close(np.array(vals), g["g.pred_action_values"][b], 2e-6)
+
+
+def test_env_scene_fixture_matches_survey_probe():
+    sc = gio.load("scenes")
+    assert np.allclose(sc["test_robot"][0], [0, -4, 0, 0, 0.3, 0, 4, 1, np.pi / 2])
+    assert np.allclose(sc["test_humans"][0][0][:2], [-2.66256, -2.83799], atol=1e-5)
+    assert sc["test_humans"].shape == (10, 5, 5)
