@@ -1,0 +1,231 @@
+/*
+ * rgl_hip.h -- C ABI of librgl_hip.so: the MI355X (gfx950) implementation of the RGL
+ * relational-graph forward pass and the model-predictive rollout that calls it.
+ *
+ * The upstream project is pure Python + torch; it has no FFI of its own.  Each entry point
+ * below therefore replaces a *Python* interface of the reference (cited per function, paths
+ * relative to the upstream repo), and INTEGRATION.md shows the ctypes stub a maintainer of the
+ * reference would add to call it.
+ *
+ * Conventions (all entry points):
+ *   - every `const float*` / `float*` / `int*` / `double*` argument that is documented as
+ *     "device" is a DEVICE pointer owned by the caller (e.g. a contiguous fp32 torch tensor);
+ *     the library never allocates, frees or retains device memory;
+ *   - descriptor structs (RglMlp, RglGraph, MprlPlanner) live in HOST memory and are read
+ *     during the call only; the device pointers inside them must stay valid until the work
+ *     queued on `stream` has finished;
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream); no call synchronises the device, so all of them may be captured into a hipGraph;
+ *   - return value: 0 on success, a positive hipError_t if the runtime reported one, or one of
+ *     the negative RGL_ERR_* codes below.  No exceptions cross this boundary;
+ *   - thread safety: calls on distinct streams may run concurrently; there is no hidden
+ *     global state.
+ *
+ * Matrix layouts:
+ *   - MLP layer l maps dims[l] -> dims[l+1];  weight[l] is row-major [dims[l]][dims[l+1]]
+ *     ("k-major", i.e. torch `linear.weight.t().contiguous()`); rgl_transpose_f32 produces it
+ *     on device from the torch (out,in) layout.  bias[l] has dims[l+1] entries.
+ *   - w_a and Ws[l] are row-major [x_dim][x_dim] exactly as the reference stores them
+ *     (they multiply from the right: X @ w_a, (A H) @ Ws[l]).
+ *   - agent states: robot rows are 9 floats [px,py,vx,vy,radius,gx,gy,v_pref,theta], human rows
+ *     5 floats [px,py,vx,vy,radius] (crowd_sim/envs/utils/state.py:27-28,51-52).
+ */
+#ifndef RGL_HIP_H
+#define RGL_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGL_ABI_VERSION 1
+
+#define RGL_MAX_MLP_LAYERS 6
+#define RGL_MAX_GCN_LAYERS 8
+#define RGL_MAX_NODES 64    /* N = humans + 1 */
+#define RGL_MAX_XDIM 64
+#define RGL_MAX_WIDTH 256   /* widest MLP layer */
+#define RGL_MAX_ACTIONS 256
+
+#define RGL_OK 0
+#define RGL_ERR_BAD_SHAPE (-1)      /* N, x_dim, widths or counts outside the limits above     */
+#define RGL_ERR_BAD_MODE (-2)       /* unknown similarity / kinematics / inconsistent flags    */
+#define RGL_ERR_NULL (-3)           /* a required pointer is NULL                              */
+#define RGL_ERR_WORKSPACE (-4)      /* workspace too small (see mprl_tree_workspace_bytes)     */
+#define RGL_ERR_LDS (-5)            /* configuration does not fit the 160 KiB LDS of one CU    */
+
+typedef void* rgl_stream_t;         /* hipStream_t */
+
+/* similarity functions of RGL.compute_similarity_matrix (crowd_nav/policy/graph_model.py:63-97) */
+enum {
+    RGL_SIM_EMBEDDED_GAUSSIAN = 0,
+    RGL_SIM_GAUSSIAN = 1,
+    RGL_SIM_COSINE = 2,
+    RGL_SIM_COSINE_SOFTMAX = 3,
+    RGL_SIM_CONCATENATION = 4,
+    RGL_SIM_SQUARED = 5,
+    RGL_SIM_EQUAL_ATTENTION = 6,
+    RGL_SIM_DIAGONAL = 7
+};
+
+enum { RGL_HOLONOMIC = 0, RGL_UNICYCLE = 1 };
+
+/* Sequential[Linear, ReLU, ...]  (crowd_nav/policy/helpers.py:5-13) */
+typedef struct RglMlp {
+    int n_layers;                              /* 0 = absent                                   */
+    int last_relu;                             /* ReLU after the last layer too                */
+    int dims[RGL_MAX_MLP_LAYERS + 1];
+    const float* weight[RGL_MAX_MLP_LAYERS];   /* device, [dims[l]][dims[l+1]]                 */
+    const float* bias[RGL_MAX_MLP_LAYERS];     /* device, [dims[l+1]]                          */
+} RglMlp;
+
+/* parameters + flags of one relational graph model
+ * (RGL.__init__, crowd_nav/policy/graph_model.py:11-61; gcn.ValueNetwork.__init__, gcn.py:11-47) */
+typedef struct RglGraph {
+    RglMlp w_r;                 /* robot/self-state embedding, dims[0] = robot_dim (9 | 6)     */
+    RglMlp w_h;                 /* human embedding, dims[0] = human_dim (5 | 7)                */
+    int x_dim;
+    int num_layer;
+    int similarity;             /* RGL_SIM_*                                                   */
+    int layerwise_graph;
+    int skip_connection;
+    int reserved;
+    const float* w_a;           /* device [x_dim][x_dim]; embedded_gaussian only               */
+    RglMlp w_a_mlp;             /* concatenation only: 2*x_dim -> hidden -> 1, last_relu       */
+    const float* Ws[RGL_MAX_GCN_LAYERS];   /* device, each [x_dim][x_dim]                      */
+} RglGraph;
+
+/* ---------------------------------------------------------------------------------------------
+ * rgl_graph_forward_f32 -- batched relational-graph forward with optional heads.
+ * Replaces: RGL.forward (graph_model.py:99-130), ValueEstimator.forward (value_estimator.py:11-20),
+ *           the graph+motion part of StatePredictor.forward (state_predictor.py:20-39) and the
+ *           network part of gcn.ValueNetwork.forward (gcn.py:95-128).
+ *   robot      device [n_scenes][robot_dim]
+ *   humans     device [n_scenes / scenes_per_crowd][H][human_dim]; scene s reads crowd
+ *              s / scenes_per_crowd (sibling scenes of a rollout share their humans)
+ *   value_head NULL or the MLP applied to node 0 of the last layer  -> value_out[n_scenes]
+ *   motion_head NULL or the MLP applied to every node; rows 1..H    -> humans_next[n_scenes][H][out]
+ *   H_out      NULL or device [n_scenes][N][x_dim]   (last-layer node features)
+ *   A_out      NULL or device [n_scenes][N][N]       (first adjacency computed)
+ * Limits: N = H+1 <= RGL_MAX_NODES, x_dim <= RGL_MAX_XDIM, widths <= RGL_MAX_WIDTH.
+ * ------------------------------------------------------------------------------------------- */
+int rgl_graph_forward_f32(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
+                          const float* robot, const float* humans,
+                          int n_scenes, int scenes_per_crowd, int H,
+                          float* H_out, float* A_out, float* value_out, float* humans_next,
+                          rgl_stream_t stream);
+
+/* rgl_transpose_f32 -- dst[c][r] = src[r][c]; turns a torch Linear weight (out,in) into the
+ * k-major layout RglMlp wants.  Host-side convenience of this ABI (no reference counterpart). */
+int rgl_transpose_f32(const float* src, float* dst, int rows, int cols, rgl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * gcn_rotate_f32 -- pairwise relation features: (R,14) [robot 9 | human 5] -> (R,13)
+ * agent-centric rows [dg, v_pref, theta, radius, vx, vy, px1, py1, vx1, vy1, radius1, da,
+ * radius_sum].  Replaces CADRL.rotate (crowd_nav/policy/cadrl.py:241-276).
+ * ------------------------------------------------------------------------------------------- */
+int gcn_rotate_f32(const float* joint14, float* rotated13, int n_rows, int kinematics,
+                   rgl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * gcn_predict_f32 -- path G one-step lookahead for B scenes x A actions, fused on device:
+ * propagate robot (action) and humans (constant velocity), compute_reward, rotate, ValueNetwork,
+ * value = reward + gamma^(dt*v_pref) * V, first-max argmax.
+ * Replaces the search loop of MultiHumanRL.predict (crowd_nav/policy/multi_human_rl.py:36-64),
+ * compute_reward (:73-96) and CADRL.propagate (cadrl.py:113-138).
+ *   robot  device [B][9], humans device [B][H][5], actions device [A][2] (float64; (vx,vy) or (v,r))
+ *   workspace device, >= gcn_predict_workspace_bytes(B, H, A) bytes
+ *   action_values device [B][A] (float32), best_action device [B] (int32)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct GcnPlanner {
+    RglGraph graph;             /* w_r.dims[0] = 6, w_h.dims[0] = 7                             */
+    RglMlp value_head;          /* gcn.ValueNetwork.value_net                                   */
+    int kinematics;
+    int num_actions;
+    double time_step;
+    double gamma;               /* raw gamma; discount is gamma^(time_step * v_pref)            */
+    const double* actions;      /* device [A][2]                                                */
+} GcnPlanner;
+
+size_t gcn_predict_workspace_bytes(int B, int H, int A);
+int gcn_predict_f32(const GcnPlanner* planner, const float* robot, const float* humans, int B, int H,
+                    void* workspace, size_t workspace_bytes,
+                    float* action_values, int* best_action, rgl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Path M: model-predictive rollout (crowd_nav/policy/model_predictive_rl.py:192-357).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct MprlPlanner {
+    RglGraph value_graph;       /* ValueEstimator.graph_model                                   */
+    RglMlp value_head;          /* ValueEstimator.value_network                                 */
+    RglGraph predictor_graph;   /* StatePredictor.graph_model (may alias value_graph's weights) */
+    RglMlp motion_head;         /* StatePredictor.human_motion_predictor                        */
+    int linear_state_predictor; /* 1: humans' = humans + v (no dt; state_predictor.py:109-118)  */
+    int kinematics;
+    int num_actions;
+    int planning_depth;
+    int planning_width;
+    int do_action_clip;
+    int sparse_search;
+    int reserved;
+    double time_step;
+    double gamma_bar;           /* gamma^(time_step * v_pref), get_normalized_gamma (:104-105)  */
+    const double* actions;      /* device [A][2] float64, table of build_action_space (:155-190)*/
+    const int* action_groups;   /* device [A], action_group_index (sparse search); may be NULL  */
+} MprlPlanner;
+
+/* One tree level for P parent states (the unit `action_clip` evaluates, :242-269):
+ *   humans_next[p]      = StatePredictor humans of parent p (or the linear approximation)
+ *   child_robot[p][a]   = compute_next_state(robot[p], action a)        (state_predictor.py:41-60)
+ *   reward[p][a]        = estimate_reward(parent p, action a)           (:304-357)
+ *   child_value[p][a]   = ValueEstimator(child_robot[p][a], humans_next[p])
+ *   value1[p][a]        = reward + gamma_bar * child_value
+ * parents_are_joint_states: 1 for root states that came from float64 JointStates (position
+ * differences taken in float64), 0 for tensor-born states (differences rounded to float32 first,
+ * as tensor_to_joint_state + numpy scalars do).
+ * All outputs device; child_robot [P][A][9], the others [P][A] / [P][H][5]. */
+int mprl_expand_f32(const MprlPlanner* planner, const float* robot, const float* humans, int P, int H,
+                    int parents_are_joint_states,
+                    float* humans_next, float* child_robot, float* reward, float* child_value,
+                    float* value1, rgl_stream_t stream);
+
+/* The dominant kernel of the rollout on its own: child_value[p][a] = ValueEstimator(child_robot[p][a],
+ * humans_next[p]) for the A sibling children of each of P parents (siblings share their crowd).
+ * Same code path mprl_expand_f32 / mprl_tree_search_f32 use; exported so it can be timed and
+ * tested in isolation (value_estimator.py:11-20 applied to model_predictive_rl.py:245-250's loop). */
+int mprl_value_children_f32(const MprlPlanner* planner, const float* child_robot, const float* humans_next,
+                            int P, int H, float* child_value, rgl_stream_t stream);
+
+/* Whole depth-D search for B root scenes: level-synchronous expansion, top-w clipping
+ * (argpartition / sparse grouped variant), V_planning back-up (:271-302), first-max argmax.
+ *   best_action device [B] int32, best_value device [B] float32
+ *   root_values NULL or device [B][W0] float32, root_kept NULL or device [B][W0] int32, with
+ *   W0 = planning_width if do_action_clip else num_actions; kept actions are ordered by
+ *   descending one-step value (ties: lower action index first). */
+size_t mprl_tree_workspace_bytes(const MprlPlanner* planner, int B, int H);
+int mprl_tree_search_f32(const MprlPlanner* planner, const float* robot, const float* humans, int B, int H,
+                         int roots_are_joint_states, void* workspace, size_t workspace_bytes,
+                         int* best_action, float* best_value, float* root_values, int* root_kept,
+                         rgl_stream_t stream);
+
+/* Where level `level` keeps its arrays inside the workspace (byte offsets), so a host can read
+ * back the best trajectory (ModelPredictiveRL.traj) or any intermediate without a second pass. */
+typedef struct MprlLevelView {
+    long long n_parents;
+    long long robot_off, humans_off;          /* parent states of this level                   */
+    long long humans_next_off, child_robot_off, reward_off, child_value_off, value1_off;
+    long long keep_off;                       /* int32 [P][W]                                  */
+    long long backup_off;                     /* float32 [P][W] returns of the kept children   */
+    long long best_slot_off;                  /* int32 [P] first-max slot among the kept       */
+} MprlLevelView;
+int mprl_tree_level_view(const MprlPlanner* planner, int B, int H, int level, MprlLevelView* view);
+
+/* library identification: ABI version and the gfx target the device code was built for */
+int rgl_abi_version(void);
+const char* rgl_build_target(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGL_HIP_H */

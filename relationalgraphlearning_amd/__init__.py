@@ -1,0 +1,13 @@
+"""relationalgraphlearning_amd -- MI355X-native RGL relational-graph forward pass and
+model-predictive rollout (the hot path of ChanganVR/RelationalGraphLearning), behind the
+reference's own Policy / nn.Module surface.  Device code: hand-written HIP for gfx950 in
+csrc/, exposed through the C ABI of include/rgl_hip.h (librgl_hip.so)."""
+from . import _native
+from .actions import ActionXY, ActionRot
+from .nets import mlp, RGL, ValueEstimator, StatePredictor, LinearStatePredictor, ValueNetwork
+from .policy import Policy, ModelPredictiveRL, GCN, register
+from .rollout import TreeSearch, GcnSearch, ShardedRollout, rotate, shard_bounds
+
+__all__ = ["ActionXY", "ActionRot", "mlp", "RGL", "ValueEstimator", "StatePredictor", "LinearStatePredictor",
+           "ValueNetwork", "Policy", "ModelPredictiveRL", "GCN", "register", "TreeSearch", "GcnSearch",
+           "ShardedRollout", "rotate", "shard_bounds"]

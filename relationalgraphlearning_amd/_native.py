@@ -1,0 +1,121 @@
+"""ctypes binding of librgl_hip.so (the C ABI declared in include/rgl_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, the product
+raises.  The CPU oracle under `oracle/` is test infrastructure and is never imported from here.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librgl_hip.so")
+
+MAX_MLP_LAYERS = 6
+MAX_GCN_LAYERS = 8
+MAX_NODES = 64
+MAX_XDIM = 64
+MAX_WIDTH = 256
+MAX_ACTIONS = 256
+ABI_VERSION = 1
+
+SIMILARITY = {"embedded_gaussian": 0, "gaussian": 1, "cosine": 2, "cosine_softmax": 3, "concatenation": 4,
+              "squared": 5, "equal_attention": 6, "diagonal": 7}
+KINEMATICS = {"holonomic": 0, "unicycle": 1}
+
+ERRORS = {-1: "RGL_ERR_BAD_SHAPE", -2: "RGL_ERR_BAD_MODE", -3: "RGL_ERR_NULL", -4: "RGL_ERR_WORKSPACE",
+          -5: "RGL_ERR_LDS"}
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+c_double_p = C.POINTER(C.c_double)
+
+
+class RglMlp(C.Structure):
+    _fields_ = [("n_layers", C.c_int), ("last_relu", C.c_int), ("dims", C.c_int * (MAX_MLP_LAYERS + 1)),
+                ("weight", C.c_void_p * MAX_MLP_LAYERS), ("bias", C.c_void_p * MAX_MLP_LAYERS)]
+
+
+class RglGraph(C.Structure):
+    _fields_ = [("w_r", RglMlp), ("w_h", RglMlp), ("x_dim", C.c_int), ("num_layer", C.c_int),
+                ("similarity", C.c_int), ("layerwise_graph", C.c_int), ("skip_connection", C.c_int),
+                ("reserved", C.c_int), ("w_a", C.c_void_p), ("w_a_mlp", RglMlp),
+                ("Ws", C.c_void_p * MAX_GCN_LAYERS)]
+
+
+class GcnPlanner(C.Structure):
+    _fields_ = [("graph", RglGraph), ("value_head", RglMlp), ("kinematics", C.c_int), ("num_actions", C.c_int),
+                ("time_step", C.c_double), ("gamma", C.c_double), ("actions", C.c_void_p)]
+
+
+class MprlPlanner(C.Structure):
+    _fields_ = [("value_graph", RglGraph), ("value_head", RglMlp), ("predictor_graph", RglGraph),
+                ("motion_head", RglMlp), ("linear_state_predictor", C.c_int), ("kinematics", C.c_int),
+                ("num_actions", C.c_int), ("planning_depth", C.c_int), ("planning_width", C.c_int),
+                ("do_action_clip", C.c_int), ("sparse_search", C.c_int), ("reserved", C.c_int),
+                ("time_step", C.c_double), ("gamma_bar", C.c_double), ("actions", C.c_void_p),
+                ("action_groups", C.c_void_p)]
+
+
+class MprlLevelView(C.Structure):
+    _fields_ = [(n, C.c_longlong) for n in
+                ("n_parents", "robot_off", "humans_off", "humans_next_off", "child_robot_off", "reward_off",
+                 "child_value_off", "value1_off", "keep_off", "backup_off", "best_slot_off")]
+
+
+# name -> (restype, argtypes); every symbol include/rgl_hip.h declares
+SIGNATURES = {
+    "rgl_graph_forward_f32": (C.c_int, [C.POINTER(RglGraph), C.POINTER(RglMlp), C.POINTER(RglMlp), C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    "rgl_transpose_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "gcn_rotate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "gcn_predict_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "gcn_predict_f32": (C.c_int, [C.POINTER(GcnPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mprl_expand_f32": (C.c_int, [C.POINTER(MprlPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mprl_value_children_f32": (C.c_int, [C.POINTER(MprlPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p]),
+    "mprl_tree_workspace_bytes": (C.c_size_t, [C.POINTER(MprlPlanner), C.c_int, C.c_int]),
+    "mprl_tree_search_f32": (C.c_int, [C.POINTER(MprlPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
+    "mprl_tree_level_view": (C.c_int, [C.POINTER(MprlPlanner), C.c_int, C.c_int, C.c_int, C.POINTER(MprlLevelView)]),
+    "rgl_abi_version": (C.c_int, []),
+    "rgl_build_target": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises NativeLibraryError (never falls back) when it cannot be used."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                "librgl_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C relationalgraphlearning_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise NativeLibraryError("librgl_hip.so lacks symbol %s" % name) from e
+            fn.restype = res
+            fn.argtypes = args
+        if handle.rgl_abi_version() != ABI_VERSION:
+            raise NativeLibraryError("librgl_hip.so ABI %d != expected %d" % (handle.rgl_abi_version(), ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc in ERRORS:
+        raise NativeLibraryError("%s failed: %s" % (what, ERRORS[rc]))
+    raise NativeLibraryError("%s failed: hipError_t %d" % (what, rc))

@@ -1,0 +1,60 @@
+// Shared helpers of the librgl_hip translation units (host + device).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rgl_hip.h"
+
+#define RGL_HIP_TRY(expr)                          \
+    do {                                           \
+        hipError_t e__ = (expr);                   \
+        if (e__ != hipSuccess) return (int)e__;    \
+    } while (0)
+
+#define RGL_LAUNCH_CHECK()                         \
+    do {                                           \
+        hipError_t e__ = hipGetLastError();        \
+        if (e__ != hipSuccess) return (int)e__;    \
+    } while (0)
+
+namespace rgl {
+
+constexpr int kLdsBytesPerCu = 160 * 1024;
+
+inline int validate_mlp(const RglMlp& m, int want_in, int want_out) {
+    if (m.n_layers < 1 || m.n_layers > RGL_MAX_MLP_LAYERS) return RGL_ERR_BAD_SHAPE;
+    for (int l = 0; l <= m.n_layers; ++l)
+        if (m.dims[l] < 1 || m.dims[l] > RGL_MAX_WIDTH) return RGL_ERR_BAD_SHAPE;
+    for (int l = 0; l < m.n_layers; ++l)
+        if (!m.weight[l] || !m.bias[l]) return RGL_ERR_NULL;
+    if (want_in > 0 && m.dims[0] != want_in) return RGL_ERR_BAD_SHAPE;
+    if (want_out > 0 && m.dims[m.n_layers] != want_out) return RGL_ERR_BAD_SHAPE;
+    return RGL_OK;
+}
+
+inline int validate_graph(const RglGraph& g, int H) {
+    if (H < 1 || H + 1 > RGL_MAX_NODES) return RGL_ERR_BAD_SHAPE;
+    if (g.x_dim < 1 || g.x_dim > RGL_MAX_XDIM) return RGL_ERR_BAD_SHAPE;
+    if (g.num_layer < 0 || g.num_layer > RGL_MAX_GCN_LAYERS) return RGL_ERR_BAD_SHAPE;
+    if (g.similarity < RGL_SIM_EMBEDDED_GAUSSIAN || g.similarity > RGL_SIM_DIAGONAL) return RGL_ERR_BAD_MODE;
+    int rc = validate_mlp(g.w_r, 0, g.x_dim);
+    if (rc) return rc;
+    rc = validate_mlp(g.w_h, 0, g.x_dim);
+    if (rc) return rc;
+    if (g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN && !g.w_a) return RGL_ERR_NULL;
+    if (g.similarity == RGL_SIM_CONCATENATION) {
+        rc = validate_mlp(g.w_a_mlp, 2 * g.x_dim, 1);
+        if (rc) return rc;
+        if (g.w_a_mlp.n_layers != 2) return RGL_ERR_BAD_SHAPE;   // 2X -> hidden -> 1, as the reference builds it
+    }
+    for (int l = 0; l < g.num_layer; ++l)
+        if (!g.Ws[l]) return RGL_ERR_NULL;
+    return RGL_OK;
+}
+
+inline int mlp_max_hidden(const RglMlp& m) {
+    int w = 0;
+    for (int l = 1; l < m.n_layers; ++l) w = m.dims[l] > w ? m.dims[l] : w;
+    return w;
+}
+
+}  // namespace rgl

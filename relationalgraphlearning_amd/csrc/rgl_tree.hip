@@ -1,0 +1,641 @@
+// rgl_tree.hip -- the model-predictive rollout on device (path M) and the one-step search of
+// path G.  Level-synchronous: every tree level is a handful of launches over ALL parents of
+// that level, no host round trip, no allocation (caller-provided workspace) -> capturable in a
+// hipGraph.
+//
+// Follows (reference paths): crowd_nav/policy/model_predictive_rl.py:192-357 (predict,
+// action_clip, V_planning, estimate_reward), state_predictor.py:41-60,109-118,
+// crowd_sim/envs/utils/utils.py:4-26, multi_human_rl.py:36-96, cadrl.py:113-138,241-276.
+#include "rgl_common.h"
+
+namespace rgl {
+int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
+                           const float* robot, const float* humans, int n_scenes, int scenes_per_crowd, int H,
+                           float* H_out, float* A_out, float* value_out, float* humans_next, hipStream_t stream);
+int launch_value_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
+                          float* child_value, hipStream_t stream);   // rgl_fast.hip (falls back to generic)
+}  // namespace rgl
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ double seg_point_dist_origin(double px, double py, double ex, double ey, bool f32_degenerate,
+                                                        float fpx, float fpy) {
+    // distance from the origin to the segment (px,py)-(ex,ey); utils.py:4-26 with (x3,y3) = 0
+    const double sx = ex - px, sy = ey - py;
+    if (sx == 0.0 && sy == 0.0) {
+        if (f32_degenerate) return (double)sqrtf(__fadd_rn(__fmul_rn(fpx, fpx), __fmul_rn(fpy, fpy)));
+        return sqrt(px * px + py * py);
+    }
+    double u = ((0.0 - px) * sx + (0.0 - py) * sy) / (sx * sx + sy * sy);
+    u = u > 1.0 ? 1.0 : (u < 0.0 ? 0.0 : u);
+    const double cx = px + u * sx, cy = py + u * sy;
+    return sqrt(cx * cx + cy * cy);
+}
+
+// One thread per (parent, action): next robot state + estimate_reward.
+__global__ void mprl_children_kernel(const float* __restrict__ robot, const float* __restrict__ humans,
+                                     int humans_per, const double* __restrict__ actions, int P, int H, int A,
+                                     int kinematics, double dt, int joint, float* __restrict__ child_robot,
+                                     float* __restrict__ reward) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)P * A) return;
+    const int p = (int)(idx / A), a = (int)(idx - (long long)p * A);
+    const float* r = robot + (size_t)p * 9;
+    const float* hs = humans + (size_t)(p / humans_per) * H * 5;
+    const double a0 = actions[2 * a], a1 = actions[2 * a + 1];
+    float c[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c[i] = r[i];
+    double avx, avy, nx, ny;
+    if (kinematics == RGL_HOLONOMIC) {
+        c[0] = __fadd_rn(r[0], (float)(a0 * dt));
+        c[1] = __fadd_rn(r[1], (float)(a1 * dt));
+        c[2] = (float)a0;
+        c[3] = (float)a1;
+        avx = a0;
+        avy = a1;
+        nx = (double)r[0] + a0 * dt;
+        ny = (double)r[1] + a1 * dt;
+    } else {
+        // the reference rotates slot 7 (v_pref), not slot 8 (theta): kept (state_predictor.py:53-58)
+        const float th7 = __fadd_rn(r[7], (float)a1);
+        const float cs = cosf(th7), sn = sinf(th7);
+        c[7] = th7;
+        c[0] = __fadd_rn(r[0], (float)((double)cs * a0 * dt));
+        c[1] = __fadd_rn(r[1], (float)((double)sn * a0 * dt));
+        c[2] = (float)((double)cs * a0);
+        c[3] = (float)((double)sn * a0);
+        // estimate_reward uses theta (slot 8) for the relative velocity and the goal test
+        const double th = a1 + (double)r[8];
+        avx = a0 * cos(th);
+        avy = a0 * sin(th);
+        const double th2 = (double)r[8] + a1;
+        nx = (double)r[0] + cos(th2) * a0 * dt;
+        ny = (double)r[1] + sin(th2) * a0 * dt;
+    }
+    float* co = child_robot + (size_t)idx * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) co[i] = c[i];
+
+    bool collision = false;
+    double dmin = INFINITY;
+    for (int h = 0; h < H; ++h) {
+        const float* hu = hs + h * 5;
+        double px, py;
+        float fpx = 0.f, fpy = 0.f;
+        if (joint) {
+            px = (double)hu[0] - (double)r[0];
+            py = (double)hu[1] - (double)r[1];
+        } else {
+            fpx = __fsub_rn(hu[0], r[0]);
+            fpy = __fsub_rn(hu[1], r[1]);
+            px = (double)fpx;
+            py = (double)fpy;
+        }
+        const double vx = (double)hu[2] - avx, vy = (double)hu[3] - avy;
+        const double ex = px + vx * dt, ey = py + vy * dt;
+        const double d = seg_point_dist_origin(px, py, ex, ey, !joint, fpx, fpy) - (double)hu[4] - (double)r[4];
+        if (d < 0.0) collision = true;
+        if (d < dmin) dmin = d;
+    }
+    const double gx = nx - (double)r[5], gy = ny - (double)r[6];
+    const bool reaching = sqrt(gx * gx + gy * gy) < (double)r[4];
+    double rew;
+    if (collision) rew = -0.25;
+    else if (reaching) rew = 1.0;
+    else if (dmin < 0.2) rew = (dmin - 0.2) * 0.5 * dt;
+    else rew = 0.0;
+    reward[idx] = (float)rew;
+}
+
+__global__ void linear_humans_kernel(const float* __restrict__ humans, float* __restrict__ out, long long n_rows) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const float* h = humans + i * 5;
+    float* o = out + i * 5;
+    o[0] = __fadd_rn(h[0], h[2]);       // no time-step factor (state_predictor.py:115-116)
+    o[1] = __fadd_rn(h[1], h[3]);
+    o[2] = h[2];
+    o[3] = h[3];
+    o[4] = h[4];
+}
+
+__global__ void gather_parent_humans_kernel(const float* __restrict__ humans, int humans_per, int H, long long P,
+                                            float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * H * 5) return;
+    const long long p = i / (H * 5), rest = i - p * (H * 5);
+    out[i] = humans[(p / humans_per) * H * 5 + rest];
+}
+
+// One thread per parent: one-step values, top-w clipping, next level's robot states.
+__global__ void mprl_select_kernel(const float* __restrict__ reward, const float* __restrict__ child_value,
+                                   const float* __restrict__ child_robot, const int* __restrict__ groups, int P,
+                                   int A, int W, int clip, int sparse, float gamma_f, float* __restrict__ value1,
+                                   int* __restrict__ keep, float* __restrict__ next_robot) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float* rw = reward + (size_t)p * A;
+    const float* cv = child_value + (size_t)p * A;
+    float* v1 = value1 + (size_t)p * A;
+    for (int a = 0; a < A; ++a) v1[a] = __fadd_rn(rw[a], __fmul_rn(gamma_f, cv[a]));
+    int* kp = keep + (size_t)p * W;
+    if (!clip) {
+        for (int a = 0; a < A; ++a) kp[a] = a;
+    } else {
+        unsigned long long taken[RGL_MAX_ACTIONS / 64] = {0, 0, 0, 0};
+        unsigned long long seen_groups = 0ull;          // sparse search: <= 64 groups
+        int n = 0;
+        while (n < W) {
+            int best = -1;
+            float bv = 0.f;
+            for (int a = 0; a < A; ++a) {
+                if (taken[a >> 6] & (1ull << (a & 63))) continue;
+                const float v = v1[a];
+                if (best < 0 || v > bv || (bv != bv && v == v)) {   // a NaN is only kept when nothing else is left
+                    best = a;
+                    bv = v;
+                }
+            }
+            if (best < 0) break;
+            taken[best >> 6] |= 1ull << (best & 63);
+            if (sparse) {
+                const int gi = groups[best];
+                if (seen_groups & (1ull << gi)) continue;
+                seen_groups |= 1ull << gi;
+            }
+            kp[n++] = best;
+        }
+        for (; n < W; ++n) kp[n] = kp[n > 0 ? n - 1 : 0];   // unreachable for validated inputs
+    }
+    if (next_robot) {
+        for (int k = 0; k < W; ++k) {
+            const float* src = child_robot + ((size_t)p * A + kp[k]) * 9;
+            float* dst = next_robot + ((size_t)p * W + k) * 9;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) dst[i] = src[i];
+        }
+    }
+}
+
+// value1 = reward + gamma_bar * V(child), each op rounded to fp32 like the reference's tensor arithmetic
+__global__ void one_step_value_kernel(const float* __restrict__ r, const float* __restrict__ v, float g, long long n,
+                                      float* __restrict__ o) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = __fadd_rn(r[i], __fmul_rn(g, v[i]));
+}
+
+// Deepest level: V_planning(child, 1) = V(child).
+__global__ void mprl_leaf_kernel(const float* __restrict__ child_value, const int* __restrict__ keep, int P, int A,
+                                 int W, float* __restrict__ backup) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)P * W) return;
+    const long long p = i / W;
+    backup[i] = child_value[p * A + keep[i]];
+}
+
+// Level l >= 1, one thread per parent p: ret_k = v/d + (d-1)/d * (gamma*nv_k + r_k); the max goes to
+// the slot of p in its own parent's backup row (model_predictive_rl.py:293,298-302).
+__global__ void mprl_backup_kernel(const float* __restrict__ reward, const int* __restrict__ keep,
+                                   const float* __restrict__ backup, const float* __restrict__ up_child_value,
+                                   const int* __restrict__ up_keep, int P, int A, int W, int d, float gamma_f,
+                                   float* __restrict__ up_backup, int* __restrict__ best_slot) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int q = p / W, slot = p - q * W;
+    const float v = up_child_value[(size_t)q * A + up_keep[(size_t)q * W + slot]];
+    const float v_over_d = __fdiv_rn(v, (float)d);
+    const float c = (float)((double)(d - 1) / (double)d);
+    float best = 0.f;
+    int bk = -1;
+    for (int k = 0; k < W; ++k) {
+        const float r = reward[(size_t)p * A + keep[(size_t)p * W + k]];
+        const float inner = __fadd_rn(__fmul_rn(gamma_f, backup[(size_t)p * W + k]), r);
+        const float ret = __fadd_rn(v_over_d, __fmul_rn(c, inner));
+        if (bk < 0 || ret > best) {
+            best = ret;
+            bk = k;
+        }
+    }
+    up_backup[(size_t)q * W + slot] = best;
+    best_slot[p] = bk;
+}
+
+__global__ void mprl_root_kernel(const float* __restrict__ reward, const int* __restrict__ keep,
+                                 const float* __restrict__ backup, int B, int A, int W, float gamma_f,
+                                 int* __restrict__ best_action, float* __restrict__ best_value,
+                                 float* __restrict__ root_values, int* __restrict__ root_kept,
+                                 int* __restrict__ best_slot) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float best = -INFINITY;
+    int bk = -1;
+    for (int k = 0; k < W; ++k) {
+        const int a = keep[(size_t)b * W + k];
+        const float val = __fadd_rn(reward[(size_t)b * A + a], __fmul_rn(gamma_f, backup[(size_t)b * W + k]));
+        if (root_values) root_values[(size_t)b * W + k] = val;
+        if (root_kept) root_kept[(size_t)b * W + k] = a;
+        if (val > best) {                      // strict '>' keeps the first maximum (:228)
+            best = val;
+            bk = k;
+        }
+    }
+    best_action[b] = bk >= 0 ? keep[(size_t)b * W + bk] : -1;   // -1 <=> 'Value network is not well trained'
+    best_value[b] = best;
+    best_slot[b] = bk;
+}
+
+// ------------------------------------------------------------------------------------------------
+// path G
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rotate_row(const float* s, int unicycle, float* o) {
+    // cadrl.py:241-276; every product/sum individually rounded like the chain of torch ops
+    const float dx = __fsub_rn(s[5], s[0]), dy = __fsub_rn(s[6], s[1]);
+    const float rot = atan2f(dy, dx);
+    const float c = cosf(rot), sn = sinf(rot);
+    o[0] = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    o[1] = s[7];
+    o[2] = unicycle ? __fsub_rn(s[8], rot) : 0.f;
+    o[3] = s[4];
+    o[4] = __fadd_rn(__fmul_rn(s[2], c), __fmul_rn(s[3], sn));
+    o[5] = __fsub_rn(__fmul_rn(s[3], c), __fmul_rn(s[2], sn));
+    const float rx = __fsub_rn(s[9], s[0]), ry = __fsub_rn(s[10], s[1]);
+    o[6] = __fadd_rn(__fmul_rn(rx, c), __fmul_rn(ry, sn));
+    o[7] = __fsub_rn(__fmul_rn(ry, c), __fmul_rn(rx, sn));
+    o[8] = __fadd_rn(__fmul_rn(s[11], c), __fmul_rn(s[12], sn));
+    o[9] = __fsub_rn(__fmul_rn(s[12], c), __fmul_rn(s[11], sn));
+    o[10] = s[13];
+    const float ax = __fsub_rn(s[0], s[9]), ay = __fsub_rn(s[1], s[10]);
+    o[11] = sqrtf(__fadd_rn(__fmul_rn(ax, ax), __fmul_rn(ay, ay)));
+    o[12] = __fadd_rn(s[4], s[13]);
+}
+
+__global__ void gcn_rotate_kernel(const float* __restrict__ in14, float* __restrict__ out13, int R, int unicycle) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    float s[14], o[13];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) s[k] = in14[(size_t)i * 14 + k];
+    rotate_row(s, unicycle, o);
+#pragma unroll
+    for (int k = 0; k < 13; ++k) out13[(size_t)i * 13 + k] = o[k];
+}
+
+// One thread per (scene, action, human): propagate, rotate; thread h == 0 also does compute_reward.
+__global__ void gcn_prepare_kernel(const float* __restrict__ robot, const float* __restrict__ humans,
+                                   const double* __restrict__ actions, int B, int H, int A, int kinematics, double dt,
+                                   float* __restrict__ self6, float* __restrict__ hum7, float* __restrict__ reward) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * A * H) return;
+    const int h = (int)(idx % H);
+    const long long sa = idx / H;
+    const int a = (int)(sa % A), b = (int)(sa / A);
+    const float* r = robot + (size_t)b * 9;
+    const double a0 = actions[2 * a], a1 = actions[2 * a + 1];
+    // CADRL.propagate in float64, as python floats
+    double nr[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) nr[i] = (double)r[i];
+    if (kinematics == RGL_HOLONOMIC) {
+        nr[0] = (double)r[0] + a0 * dt;
+        nr[1] = (double)r[1] + a1 * dt;
+        nr[2] = a0;
+        nr[3] = a1;
+    } else {
+        const double th = (double)r[8] + a1;
+        nr[2] = a0 * cos(th);
+        nr[3] = a0 * sin(th);
+        nr[0] = (double)r[0] + nr[2] * dt;
+        nr[1] = (double)r[1] + nr[3] * dt;
+        nr[8] = th;
+    }
+    const float* hu = humans + ((size_t)b * H + h) * 5;
+    float s[14], o[13];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s[i] = (float)nr[i];
+    s[9] = (float)((double)hu[0] + (double)hu[2] * dt);
+    s[10] = (float)((double)hu[1] + (double)hu[3] * dt);
+    s[11] = hu[2];
+    s[12] = hu[3];
+    s[13] = hu[4];
+    rotate_row(s, kinematics == RGL_UNICYCLE, o);
+    float* h7 = hum7 + ((size_t)sa * H + h) * 7;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) h7[i] = o[6 + i];
+    if (h == 0) {
+        float* s6 = self6 + (size_t)sa * 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s6[i] = o[i];
+        // compute_reward (multi_human_rl.py:73-96): END-point distances, float64
+        bool collision = false;
+        double dmin = INFINITY;
+        const float* hb = humans + (size_t)b * H * 5;
+        for (int j = 0; j < H; ++j) {
+            const double hx = (double)hb[j * 5] + (double)hb[j * 5 + 2] * dt;
+            const double hy = (double)hb[j * 5 + 1] + (double)hb[j * 5 + 3] * dt;
+            const double ddx = nr[0] - hx, ddy = nr[1] - hy;
+            const double d = sqrt(ddx * ddx + ddy * ddy) - nr[4] - (double)hb[j * 5 + 4];
+            if (d < 0.0) collision = true;
+            if (d < dmin) dmin = d;
+        }
+        const double gx = nr[0] - nr[5], gy = nr[1] - nr[6];
+        const bool reaching = sqrt(gx * gx + gy * gy) < nr[4];
+        double rew;
+        if (collision) rew = -0.25;
+        else if (reaching) rew = 1.0;
+        else if (dmin < 0.2) rew = (dmin - 0.2) * 0.5 * dt;
+        else rew = 0.0;
+        reward[sa] = (float)rew;
+    }
+}
+
+__global__ void gcn_argmax_kernel(const float* __restrict__ robot, const float* __restrict__ reward,
+                                  const float* __restrict__ value, int B, int A, double gamma, double dt,
+                                  float* __restrict__ action_values, int* __restrict__ best_action) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double disc = pow(gamma, dt * (double)robot[(size_t)b * 9 + 7]);
+    double best = -INFINITY;
+    int ba = -1;
+    for (int a = 0; a < A; ++a) {
+        const double v = (double)reward[(size_t)b * A + a] + disc * (double)value[(size_t)b * A + a];
+        action_values[(size_t)b * A + a] = (float)v;
+        if (v > best) {
+            best = v;
+            ba = a;
+        }
+    }
+    best_action[b] = ba;
+}
+
+inline dim3 grid_for(long long n, int block = kBlock) { return dim3((unsigned)((n + block - 1) / block)); }
+
+// ------------------------------------------------------------------------------------------------
+// workspace layout of the tree search
+// ------------------------------------------------------------------------------------------------
+struct LevelLayout {
+    long long P;
+    long long robot, humans, humans_next, child_robot, reward, child_value, value1, keep, backup, best_slot;
+};
+
+inline long long align_up(long long x) { return (x + 255) & ~255ll; }
+
+inline int plan_levels(const MprlPlanner& pl, int B, int H, LevelLayout* lv, long long* total) {
+    const int A = pl.num_actions, D = pl.planning_depth;
+    const int W = pl.do_action_clip ? pl.planning_width : A;
+    long long off = 0, P = B;
+    for (int l = 0; l < D; ++l) {
+        LevelLayout& L = lv[l];
+        L.P = P;
+        L.robot = off;        off = align_up(off + (l == 0 ? 0 : P * 9 * 4));          // level 0 reads the caller's arrays
+        L.humans = -1;                                                               // = previous level's humans_next
+        L.humans_next = off;  off = align_up(off + P * H * 5 * 4);
+        L.child_robot = off;  off = align_up(off + P * A * 9 * 4);
+        L.reward = off;       off = align_up(off + P * A * 4);
+        L.child_value = off;  off = align_up(off + P * A * 4);
+        L.value1 = off;       off = align_up(off + P * A * 4);
+        L.keep = off;         off = align_up(off + P * W * 4);
+        L.backup = off;       off = align_up(off + P * W * 4);
+        L.best_slot = off;    off = align_up(off + P * 4);
+        if (l > 0) lv[l].humans = lv[l - 1].humans_next;
+        P *= W;
+        if (P > (1ll << 31) / (A * 9)) return RGL_ERR_BAD_SHAPE;
+    }
+    *total = off;
+    return RGL_OK;
+}
+
+inline int validate_planner(const MprlPlanner& pl, int H) {
+    if (pl.num_actions < 1 || pl.num_actions > RGL_MAX_ACTIONS) return RGL_ERR_BAD_SHAPE;
+    if (pl.planning_depth < 1 || pl.planning_depth > 8) return RGL_ERR_BAD_SHAPE;
+    if (pl.do_action_clip && (pl.planning_width < 1 || pl.planning_width > pl.num_actions)) return RGL_ERR_BAD_SHAPE;
+    if (pl.kinematics != RGL_HOLONOMIC && pl.kinematics != RGL_UNICYCLE) return RGL_ERR_BAD_MODE;
+    if (!pl.actions) return RGL_ERR_NULL;
+    if (pl.do_action_clip && pl.sparse_search && !pl.action_groups) return RGL_ERR_NULL;
+    int rc = rgl::validate_graph(pl.value_graph, H);
+    if (rc) return rc;
+    rc = rgl::validate_mlp(pl.value_head, pl.value_graph.x_dim, 1);
+    if (rc) return rc;
+    if (pl.value_graph.w_r.dims[0] != 9 || pl.value_graph.w_h.dims[0] != 5) return RGL_ERR_BAD_SHAPE;
+    if (!pl.linear_state_predictor) {
+        rc = rgl::validate_graph(pl.predictor_graph, H);
+        if (rc) return rc;
+        rc = rgl::validate_mlp(pl.motion_head, pl.predictor_graph.x_dim, 5);
+        if (rc) return rc;
+        if (pl.predictor_graph.w_r.dims[0] != 9 || pl.predictor_graph.w_h.dims[0] != 5) return RGL_ERR_BAD_SHAPE;
+    }
+    return RGL_OK;
+}
+
+// One level: steps 1-3 of the header comment of mprl_expand_f32.
+int expand_level(const MprlPlanner& pl, const float* robot, const float* humans, int humans_per, int P, int H, int joint,
+                 float* humans_next, float* child_robot, float* reward, float* child_value, hipStream_t st) {
+    const int A = pl.num_actions;
+    if (pl.linear_state_predictor) {
+        if (humans_per == 1) {
+            hipLaunchKernelGGL(linear_humans_kernel, grid_for((long long)P * H), dim3(kBlock), 0, st, humans, humans_next,
+                               (long long)P * H);
+        } else {
+            hipLaunchKernelGGL(gather_parent_humans_kernel, grid_for((long long)P * H * 5), dim3(kBlock), 0, st, humans,
+                               humans_per, H, (long long)P, humans_next);
+            hipLaunchKernelGGL(linear_humans_kernel, grid_for((long long)P * H), dim3(kBlock), 0, st, humans_next,
+                               humans_next, (long long)P * H);
+        }
+        RGL_LAUNCH_CHECK();
+    } else {
+        int rc = rgl::launch_generic_forward(&pl.predictor_graph, nullptr, &pl.motion_head, robot, humans, P, humans_per, H,
+                                             nullptr, nullptr, nullptr, humans_next, st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(mprl_children_kernel, grid_for((long long)P * A), dim3(kBlock), 0, st, robot, humans, humans_per,
+                       pl.actions, P, H, A, pl.kinematics, pl.time_step, joint, child_robot, reward);
+    RGL_LAUNCH_CHECK();
+    return rgl::launch_value_children(&pl, child_robot, humans_next, P, H, child_value, st);
+}
+
+}  // namespace
+
+extern "C" int mprl_expand_f32(const MprlPlanner* planner, const float* robot, const float* humans, int P, int H,
+                               int parents_are_joint_states, float* humans_next, float* child_robot, float* reward,
+                               float* child_value, float* value1, rgl_stream_t stream) {
+    if (!planner || !robot || !humans || !humans_next || !child_robot || !reward || !child_value) return RGL_ERR_NULL;
+    if (P < 0) return RGL_ERR_BAD_SHAPE;
+    int rc = validate_planner(*planner, H);
+    if (rc) return rc;
+    if (P == 0) return RGL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    rc = expand_level(*planner, robot, humans, 1, P, H, parents_are_joint_states, humans_next, child_robot, reward,
+                      child_value, st);
+    if (rc) return rc;
+    if (value1) {
+        const long long n = (long long)P * planner->num_actions;
+        hipLaunchKernelGGL(one_step_value_kernel, grid_for(n), dim3(kBlock), 0, st, reward, child_value,
+                           (float)planner->gamma_bar, n, value1);
+        RGL_LAUNCH_CHECK();
+    }
+    return RGL_OK;
+}
+
+extern "C" int mprl_value_children_f32(const MprlPlanner* planner, const float* child_robot, const float* humans_next,
+                                       int P, int H, float* child_value, rgl_stream_t stream) {
+    if (!planner || !child_robot || !humans_next || !child_value) return RGL_ERR_NULL;
+    if (P < 0) return RGL_ERR_BAD_SHAPE;
+    int rc = validate_planner(*planner, H);
+    if (rc) return rc;
+    if (P == 0) return RGL_OK;
+    return rgl::launch_value_children(planner, child_robot, humans_next, P, H, child_value, (hipStream_t)stream);
+}
+
+extern "C" size_t mprl_tree_workspace_bytes(const MprlPlanner* planner, int B, int H) {
+    if (!planner || B < 1 || planner->planning_depth < 1 || planner->planning_depth > 8) return 0;
+    LevelLayout lv[8];
+    long long total = 0;
+    if (plan_levels(*planner, B, H, lv, &total)) return 0;
+    return (size_t)total;
+}
+
+extern "C" int mprl_tree_level_view(const MprlPlanner* planner, int B, int H, int level, MprlLevelView* view) {
+    if (!planner || !view) return RGL_ERR_NULL;
+    if (planner->planning_depth < 1 || planner->planning_depth > 8 || level < 0 || level >= planner->planning_depth)
+        return RGL_ERR_BAD_SHAPE;
+    LevelLayout lv[8];
+    long long total = 0;
+    int rc = plan_levels(*planner, B, H, lv, &total);
+    if (rc) return rc;
+    const LevelLayout& L = lv[level];
+    view->n_parents = L.P;
+    view->robot_off = level == 0 ? -1 : L.robot;
+    view->humans_off = L.humans;
+    view->humans_next_off = L.humans_next;
+    view->child_robot_off = L.child_robot;
+    view->reward_off = L.reward;
+    view->child_value_off = L.child_value;
+    view->value1_off = L.value1;
+    view->keep_off = L.keep;
+    view->backup_off = L.backup;
+    view->best_slot_off = L.best_slot;
+    return RGL_OK;
+}
+
+extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* robot, const float* humans, int B, int H,
+                                    int roots_are_joint_states, void* workspace, size_t workspace_bytes,
+                                    int* best_action, float* best_value, float* root_values, int* root_kept,
+                                    rgl_stream_t stream) {
+    if (!planner || !robot || !humans || !workspace || !best_action || !best_value) return RGL_ERR_NULL;
+    if (B < 1) return RGL_ERR_BAD_SHAPE;
+    int rc = validate_planner(*planner, H);
+    if (rc) return rc;
+    const MprlPlanner& pl = *planner;
+    const int A = pl.num_actions, D = pl.planning_depth;
+    const int W = pl.do_action_clip ? pl.planning_width : A;
+    if (pl.do_action_clip && pl.sparse_search) {
+        // the grouped walk can only ever keep one action per group: refuse widths it cannot fill
+        if (W > 16) return RGL_ERR_BAD_MODE;
+    }
+    LevelLayout lv[8];
+    long long total = 0;
+    rc = plan_levels(pl, B, H, lv, &total);
+    if (rc) return rc;
+    if ((long long)workspace_bytes < total) return RGL_ERR_WORKSPACE;
+    char* ws = (char*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const float gamma_f = (float)pl.gamma_bar;
+
+    for (int l = 0; l < D; ++l) {
+        const LevelLayout& L = lv[l];
+        const int P = (int)L.P;
+        const float* pr = l == 0 ? robot : (const float*)(ws + L.robot);
+        const float* ph = l == 0 ? humans : (const float*)(ws + L.humans);
+        const int humans_per = l == 0 ? 1 : W;
+        rc = expand_level(pl, pr, ph, humans_per, P, H, l == 0 ? roots_are_joint_states : 0,
+                          (float*)(ws + L.humans_next), (float*)(ws + L.child_robot), (float*)(ws + L.reward),
+                          (float*)(ws + L.child_value), st);
+        if (rc) return rc;
+        float* next_robot = l + 1 < D ? (float*)(ws + lv[l + 1].robot) : nullptr;
+        hipLaunchKernelGGL(mprl_select_kernel, grid_for(P, 64), dim3(64), 0, st, (const float*)(ws + L.reward),
+                           (const float*)(ws + L.child_value), (const float*)(ws + L.child_robot), pl.action_groups, P, A,
+                           W, pl.do_action_clip, pl.sparse_search, gamma_f, (float*)(ws + L.value1), (int*)(ws + L.keep),
+                           next_robot);
+        RGL_LAUNCH_CHECK();
+    }
+    {
+        const LevelLayout& L = lv[D - 1];
+        hipLaunchKernelGGL(mprl_leaf_kernel, grid_for(L.P * W), dim3(kBlock), 0, st, (const float*)(ws + L.child_value),
+                           (const int*)(ws + L.keep), (int)L.P, A, W, (float*)(ws + L.backup));
+        RGL_LAUNCH_CHECK();
+    }
+    for (int l = D - 1; l >= 1; --l) {
+        const LevelLayout& L = lv[l];
+        const LevelLayout& U = lv[l - 1];
+        hipLaunchKernelGGL(mprl_backup_kernel, grid_for(L.P, 64), dim3(64), 0, st, (const float*)(ws + L.reward),
+                           (const int*)(ws + L.keep), (const float*)(ws + L.backup), (const float*)(ws + U.child_value),
+                           (const int*)(ws + U.keep), (int)L.P, A, W, D - l + 1, gamma_f, (float*)(ws + U.backup),
+                           (int*)(ws + L.best_slot));
+        RGL_LAUNCH_CHECK();
+    }
+    {
+        const LevelLayout& L = lv[0];
+        hipLaunchKernelGGL(mprl_root_kernel, grid_for(B, 64), dim3(64), 0, st, (const float*)(ws + L.reward),
+                           (const int*)(ws + L.keep), (const float*)(ws + L.backup), B, A, W, gamma_f, best_action,
+                           best_value, root_values, root_kept, (int*)(ws + L.best_slot));
+        RGL_LAUNCH_CHECK();
+    }
+    return RGL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// path G entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int gcn_rotate_f32(const float* joint14, float* rotated13, int n_rows, int kinematics,
+                              rgl_stream_t stream) {
+    if (!joint14 || !rotated13) return RGL_ERR_NULL;
+    if (n_rows < 0) return RGL_ERR_BAD_SHAPE;
+    if (kinematics != RGL_HOLONOMIC && kinematics != RGL_UNICYCLE) return RGL_ERR_BAD_MODE;
+    if (n_rows == 0) return RGL_OK;
+    hipLaunchKernelGGL(gcn_rotate_kernel, grid_for(n_rows), dim3(kBlock), 0, (hipStream_t)stream, joint14, rotated13,
+                       n_rows, kinematics == RGL_UNICYCLE);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
+extern "C" size_t gcn_predict_workspace_bytes(int B, int H, int A) {
+    if (B < 1 || H < 1 || A < 1) return 0;
+    const long long S = (long long)B * A;
+    return (size_t)(align_up(S * 6 * 4) + align_up(S * H * 7 * 4) + align_up(S * 4) + align_up(S * 4));
+}
+
+extern "C" int gcn_predict_f32(const GcnPlanner* planner, const float* robot, const float* humans, int B, int H,
+                               void* workspace, size_t workspace_bytes, float* action_values, int* best_action,
+                               rgl_stream_t stream) {
+    if (!planner || !robot || !humans || !workspace || !action_values || !best_action) return RGL_ERR_NULL;
+    if (B < 1) return RGL_ERR_BAD_SHAPE;
+    const GcnPlanner& pl = *planner;
+    if (pl.num_actions < 1 || pl.num_actions > RGL_MAX_ACTIONS || !pl.actions) return RGL_ERR_BAD_SHAPE;
+    if (pl.kinematics != RGL_HOLONOMIC && pl.kinematics != RGL_UNICYCLE) return RGL_ERR_BAD_MODE;
+    int rc = rgl::validate_graph(pl.graph, H);
+    if (rc) return rc;
+    if (pl.graph.w_r.dims[0] != 6 || pl.graph.w_h.dims[0] != 7) return RGL_ERR_BAD_SHAPE;
+    rc = rgl::validate_mlp(pl.value_head, pl.graph.x_dim, 1);
+    if (rc) return rc;
+    const int A = pl.num_actions;
+    if (workspace_bytes < gcn_predict_workspace_bytes(B, H, A)) return RGL_ERR_WORKSPACE;
+    const long long S = (long long)B * A;
+    char* ws = (char*)workspace;
+    float* self6 = (float*)ws;              ws += align_up(S * 6 * 4);
+    float* hum7 = (float*)ws;               ws += align_up(S * H * 7 * 4);
+    float* reward = (float*)ws;             ws += align_up(S * 4);
+    float* value = (float*)ws;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gcn_prepare_kernel, grid_for(S * H), dim3(kBlock), 0, st, robot, humans, pl.actions, B, H, A,
+                       pl.kinematics, pl.time_step, self6, hum7, reward);
+    RGL_LAUNCH_CHECK();
+    rc = rgl::launch_generic_forward(&pl.graph, &pl.value_head, nullptr, self6, hum7, (int)S, 1, H, nullptr, nullptr,
+                                     value, nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gcn_argmax_kernel, grid_for(B, 64), dim3(64), 0, st, robot, reward, value, B, A, pl.gamma,
+                       pl.time_step, action_values, best_action);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}

@@ -1,0 +1,431 @@
+"""Policy classes with the reference's Policy.predict() surface, backed by the HIP rollout.
+
+Mirrors (reference paths): crowd_sim/envs/policy/policy.py:6-65 (`Policy`),
+crowd_nav/policy/model_predictive_rl.py:15-370 (`ModelPredictiveRL`), crowd_nav/policy/gcn.py:131-157 +
+multi_human_rl.py:12-112 + cadrl.py:70-138 (`GCN`), crowd_nav/policy/policy_factory.py:9-13 (registration).
+
+`register(policy_factory)` installs the classes under the reference's keys ('model_predictive_rl', 'gcn'),
+so crowd_nav's train.py / test.py pick them up unchanged.
+"""
+import logging
+
+import numpy as np
+import torch
+
+from . import actions as act
+from .nets import RGL, ValueEstimator, StatePredictor, LinearStatePredictor, ValueNetwork
+from .rollout import TreeSearch, GcnSearch, rotate
+
+
+class Policy(object):
+    def __init__(self):
+        self.trainable = False
+        self.phase = None
+        self.model = None
+        self.device = None
+        self.last_state = None
+        self.time_step = None
+        self.env = None
+
+    def configure(self, config):
+        raise NotImplementedError
+
+    def set_phase(self, phase):
+        self.phase = phase
+
+    def set_device(self, device):
+        self.device = device
+
+    def set_env(self, env):
+        self.env = env
+
+    def set_time_step(self, time_step):
+        self.time_step = time_step
+
+    def get_model(self):
+        return self.model
+
+    def save_model(self, file):
+        torch.save(self.model.state_dict(), file)
+
+    def load_model(self, file):
+        self.model.load_state_dict(torch.load(file))
+
+    def get_state_dict(self):
+        return self.model.state_dict()
+
+    def load_state_dict(self, state_dict):
+        self.model.load_state_dict(state_dict)
+
+    def predict(self, state):
+        raise NotImplementedError
+
+    @staticmethod
+    def reach_destination(state):
+        r = state.robot_state
+        return bool(np.linalg.norm((r.py - r.gy, r.px - r.gx)) < r.radius)
+
+
+def _state_rows(state):
+    """JointState -> (robot row of 9 floats, list of human rows of 5 floats)."""
+    r = state.robot_state
+    robot = [r.px, r.py, r.vx, r.vy, r.radius, r.gx, r.gy, r.v_pref, r.theta]
+    humans = [[h.px, h.py, h.vx, h.vy, h.radius] for h in state.human_states]
+    return robot, humans
+
+
+def _check_ready(policy):
+    if policy.phase is None or policy.device is None:
+        raise AttributeError('Phase, device attributes have to be set!')
+    if policy.phase == 'train' and policy.epsilon is None:
+        raise AttributeError('Epsilon attribute has to be set in training phase')
+
+
+class ModelPredictiveRL(Policy):
+    """d-step model-predictive policy over the relational graph value/predictor networks (path M)."""
+
+    def __init__(self):
+        super().__init__()
+        self.name = 'ModelPredictiveRL'
+        self.trainable = True
+        self.multiagent_training = True
+        self.kinematics = None
+        self.epsilon = None
+        self.gamma = None
+        self.sampling = None
+        self.speed_samples = None
+        self.rotation_samples = None
+        self.action_space = None
+        self.rotation_constraint = None
+        self.speeds = None
+        self.rotations = None
+        self.action_values = None
+        self.robot_state_dim = 9
+        self.human_state_dim = 5
+        self.v_pref = 1
+        self.share_graph_model = None
+        self.value_estimator = None
+        self.linear_state_predictor = None
+        self.state_predictor = None
+        self.planning_depth = None
+        self.planning_width = None
+        self.do_action_clip = None
+        self.sparse_search = None
+        self.sparse_speed_samples = 2
+        self.sparse_rotation_samples = 8
+        self.action_group_index = []
+        self.traj = None
+        self._search = None
+
+    # -- wiring ----------------------------------------------------------------------------------
+    def configure(self, config):
+        self.set_common_parameters(config)
+        mp = config.model_predictive_rl
+        self.planning_depth = mp.planning_depth
+        self.do_action_clip = mp.do_action_clip
+        if hasattr(mp, 'sparse_search'):
+            self.sparse_search = mp.sparse_search
+        self.planning_width = mp.planning_width
+        self.share_graph_model = mp.share_graph_model
+        self.linear_state_predictor = mp.linear_state_predictor
+        value_graph = RGL(config, self.robot_state_dim, self.human_state_dim)
+        self.value_estimator = ValueEstimator(config, value_graph)
+        if self.linear_state_predictor:
+            self.state_predictor = LinearStatePredictor(config, self.time_step)
+            self.model = [value_graph, self.value_estimator.value_network]
+        elif self.share_graph_model:
+            self.state_predictor = StatePredictor(config, value_graph, self.time_step)
+            self.model = [value_graph, self.value_estimator.value_network,
+                          self.state_predictor.human_motion_predictor]
+        else:
+            predictor_graph = RGL(config, self.robot_state_dim, self.human_state_dim)
+            self.state_predictor = StatePredictor(config, predictor_graph, self.time_step)
+            self.model = [value_graph, predictor_graph, self.value_estimator.value_network,
+                          self.state_predictor.human_motion_predictor]
+        self._search = None
+        logging.info('Planning depth: {}'.format(self.planning_depth))
+        logging.info('Planning width: {}'.format(self.planning_width))
+        logging.info('Sparse search: {}'.format(self.sparse_search))
+        if self.planning_depth > 1 and not self.do_action_clip:
+            logging.warning('Performing d-step planning without action space clipping!')
+
+    def set_common_parameters(self, config):
+        self.gamma = config.rl.gamma
+        a = config.action_space
+        self.kinematics = a.kinematics
+        self.sampling = a.sampling
+        self.speed_samples = a.speed_samples
+        self.rotation_samples = a.rotation_samples
+        self.rotation_constraint = a.rotation_constraint
+
+    def set_device(self, device):
+        self.device = device
+        for m in self.model:
+            m.to(device)
+        self._search = None
+
+    def set_epsilon(self, epsilon):
+        self.epsilon = epsilon
+
+    def set_time_step(self, time_step):
+        self.time_step = time_step
+        self.state_predictor.time_step = time_step
+        self._search = None
+
+    def get_normalized_gamma(self):
+        return pow(self.gamma, self.time_step * self.v_pref)
+
+    def get_model(self):
+        return self.value_estimator
+
+    def get_traj(self):
+        return self.traj
+
+    # -- checkpoints: same nested layout as upstream ---------------------------------------------
+    def get_state_dict(self):
+        ve, sp = self.value_estimator, self.state_predictor
+        if not sp.trainable:
+            return {'graph_model': ve.graph_model.state_dict(), 'value_network': ve.value_network.state_dict()}
+        if self.share_graph_model:
+            return {'graph_model': ve.graph_model.state_dict(), 'value_network': ve.value_network.state_dict(),
+                    'motion_predictor': sp.human_motion_predictor.state_dict()}
+        return {'graph_model1': ve.graph_model.state_dict(), 'graph_model2': sp.graph_model.state_dict(),
+                'value_network': ve.value_network.state_dict(),
+                'motion_predictor': sp.human_motion_predictor.state_dict()}
+
+    def load_state_dict(self, state_dict):
+        ve, sp = self.value_estimator, self.state_predictor
+        if sp.trainable and not self.share_graph_model:
+            ve.graph_model.load_state_dict(state_dict['graph_model1'])
+            sp.graph_model.load_state_dict(state_dict['graph_model2'])
+        else:
+            ve.graph_model.load_state_dict(state_dict['graph_model'])
+        ve.value_network.load_state_dict(state_dict['value_network'])
+        if sp.trainable:
+            sp.human_motion_predictor.load_state_dict(state_dict['motion_predictor'])
+
+    def save_model(self, file):
+        torch.save(self.get_state_dict(), file)
+
+    def load_model(self, file):
+        self.load_state_dict(torch.load(file, map_location=self.device))
+
+    # -- action space ----------------------------------------------------------------------------
+    def build_action_space(self, v_pref):
+        actions, groups, speeds, rotations = act.speed_major_table(
+            v_pref, self.speed_samples, self.rotation_samples, self.kinematics, self.rotation_constraint,
+            self.sparse_rotation_samples)
+        self.action_space = actions
+        self.action_group_index = groups
+        self.speeds = speeds
+        self.rotations = rotations
+        self._search = None
+
+    def tree_search(self):
+        """The device search object for the current configuration (rebuilt when settings change)."""
+        key = (self.planning_depth, self.planning_width, bool(self.do_action_clip), bool(self.sparse_search),
+               self.kinematics, self.time_step, self.gamma, id(self.state_predictor))
+        if self._search is None or self._search[0] != key:
+            if self.action_space is None:
+                self.build_action_space(self.v_pref)
+            ts = TreeSearch(self.value_estimator, self.state_predictor, act.as_array(self.action_space),
+                            self.action_group_index, self.kinematics, self.time_step, self.get_normalized_gamma(),
+                            self.planning_depth, self.planning_width, self.do_action_clip, self.sparse_search)
+            self._search = (key, ts)
+        return self._search[1]
+
+    # -- decisions -------------------------------------------------------------------------------
+    def predict(self, state):
+        _check_ready(self)
+        if self.reach_destination(state):
+            return act.stop_action(self.kinematics)
+        if self.action_space is None:
+            self.build_action_space(state.robot_state.v_pref)
+        probability = np.random.random()          # drawn in every phase, like upstream, to keep RNG streams aligned
+        if self.phase == 'train' and probability < self.epsilon:
+            max_action = self.action_space[np.random.choice(len(self.action_space))]
+            max_traj = None
+        else:
+            robot_t, humans_t = self._root_tensors(state)
+            ts = self.tree_search()
+            with torch.no_grad():
+                out = ts.search(robot_t, humans_t, roots_are_joint_states=True)
+            idx = int(out["best_action"][0])
+            if idx < 0:
+                raise ValueError('Value network is not well trained.')
+            max_action = self.action_space[idx]
+            max_traj = None
+            if self.phase != 'train':
+                max_traj = [(s, None if a is None else self.action_space[a], r) for s, a, r in ts.best_trajectory(0)]
+        if self.phase == 'train':
+            self.last_state = self.transform(state)
+        else:
+            self.traj = max_traj
+        return max_action
+
+    def predict_batch(self, robot, humans, roots_are_joint_states=False):
+        """Additive API: robot (B,9), humans (B,H,5) device tensors -> (action index (B,), value (B,))."""
+        if self.action_space is None:
+            self.build_action_space(self.v_pref)
+        with torch.no_grad():
+            out = self.tree_search().search(robot, humans, roots_are_joint_states=roots_are_joint_states)
+        return out["best_action"], out["best_value"]
+
+    def _root_tensors(self, state):
+        robot, humans = _state_rows(state)
+        robot_t = torch.tensor([robot], dtype=torch.float32, device=self.device)
+        humans_t = torch.tensor([humans], dtype=torch.float32, device=self.device).reshape(1, len(humans), 5)
+        return robot_t, humans_t
+
+    def transform(self, state):
+        robot, humans = _state_rows(state)
+        return (torch.tensor([robot], dtype=torch.float32, device=self.device),
+                torch.tensor(humans, dtype=torch.float32, device=self.device))
+
+
+class GCN(Policy):
+    """One-step lookahead policy over rotated pairwise states with the graph ValueNetwork (path G)."""
+
+    def __init__(self):
+        super().__init__()
+        self.name = 'GCN'
+        self.trainable = True
+        self.multiagent_training = None
+        self.kinematics = None
+        self.epsilon = None
+        self.gamma = None
+        self.sampling = None
+        self.speed_samples = None
+        self.rotation_samples = None
+        self.query_env = None
+        self.action_space = None
+        self.rotation_constraint = None
+        self.speeds = None
+        self.rotations = None
+        self.action_values = None
+        self.with_om = None
+        self.cell_num = None
+        self.cell_size = None
+        self.om_channel_size = None
+        self.self_state_dim = 6
+        self.human_state_dim = 7
+        self.joint_state_dim = self.self_state_dim + self.human_state_dim
+        self._search = None
+
+    def configure(self, config):
+        gc = config.gcn
+        self.multiagent_training = gc.multiagent_training
+        self.set_common_parameters(config)
+        self.model = ValueNetwork(self.input_dim(), self.self_state_dim, gc.num_layer, gc.X_dim, gc.wr_dims, gc.wh_dims,
+                                  gc.final_state_dim, gc.gcn2_w1_dim, gc.planning_dims, gc.similarity_function,
+                                  gc.layerwise_graph, gc.skip_connection)
+        self._search = None
+        logging.info('GCN layers: {}'.format(gc.num_layer))
+        logging.info('Policy: {}'.format(self.name))
+
+    def set_common_parameters(self, config):
+        self.gamma = config.rl.gamma
+        a = config.action_space
+        self.kinematics = a.kinematics
+        self.sampling = a.sampling
+        self.speed_samples = a.speed_samples
+        self.rotation_samples = a.rotation_samples
+        self.query_env = a.query_env
+        self.rotation_constraint = a.rotation_constraint
+        self.cell_num = config.om.cell_num
+        self.cell_size = config.om.cell_size
+        self.om_channel_size = config.om.om_channel_size
+
+    def input_dim(self):
+        return self.joint_state_dim        # occupancy maps are never enabled for this policy (with_om stays None)
+
+    def set_device(self, device):
+        self.device = device
+        self.model.to(device)
+        self._search = None
+
+    def set_epsilon(self, epsilon):
+        self.epsilon = epsilon
+
+    def load_model(self, file):
+        self.model.load_state_dict(torch.load(file, map_location=self.device))
+
+    def get_matrix_A(self):
+        return self.model.A
+
+    def build_action_space(self, v_pref):
+        actions, speeds, rotations = act.rotation_major_table(v_pref, self.speed_samples, self.rotation_samples,
+                                                              self.kinematics, self.rotation_constraint)
+        self.action_space = actions
+        self.speeds = speeds
+        self.rotations = rotations
+        self._search = None
+
+    def gcn_search(self):
+        key = (self.kinematics, self.time_step, self.gamma)
+        if self._search is None or self._search[0] != key:
+            self._search = (key, GcnSearch(self.model, act.as_array(self.action_space), self.kinematics,
+                                           self.time_step, self.gamma))
+        return self._search[1]
+
+    def predict(self, state):
+        _check_ready(self)
+        if self.reach_destination(state):
+            return act.stop_action(self.kinematics)
+        if self.action_space is None:
+            self.build_action_space(state.robot_state.v_pref)
+        if not state.human_states:
+            raise NotImplementedError("empty crowds fall back to CADRL's greedy action upstream, which is bit-rotted "
+                                      "there (state.self_state) and outside the relational-graph path")
+        if self.query_env:
+            raise NotImplementedError("query_env=True needs the simulator's one-step lookahead per action; "
+                                      "the shipped configs use query_env=False")
+        probability = np.random.random()
+        if self.phase == 'train' and probability < self.epsilon:
+            max_action = self.action_space[np.random.choice(len(self.action_space))]
+        else:
+            robot, humans = _state_rows(state)
+            robot_t = torch.tensor([robot], dtype=torch.float32, device=self.device)
+            humans_t = torch.tensor([humans], dtype=torch.float32, device=self.device)
+            with torch.no_grad():
+                vals, best = self.gcn_search().search(robot_t, humans_t)
+                # keep the visual-debug hook: adjacency of the LAST action's graph, as the sequential loop leaves it
+                self._refresh_adjacency(robot, humans)
+            self.action_values = [float(v) for v in vals[0].cpu()]
+            idx = int(best[0])
+            if idx < 0:
+                raise ValueError('Value network is not well trained. ')
+            max_action = self.action_space[idx]
+        if self.phase == 'train':
+            self.last_state = self.transform(state)
+        return max_action
+
+    def _refresh_adjacency(self, robot, humans):
+        last = self.action_space[-1]
+        nxt = self.propagate_robot(robot, last)
+        nh = [[h[0] + h[2] * self.time_step, h[1] + h[3] * self.time_step, h[2], h[3], h[4]] for h in humans]
+        joint = torch.tensor([list(nxt) + h for h in nh], dtype=torch.float32, device=self.device)
+        self.model(rotate(joint, self.kinematics).unsqueeze(0))
+
+    def propagate_robot(self, robot, action):
+        dt = self.time_step
+        if self.kinematics == 'holonomic':
+            return [robot[0] + action.vx * dt, robot[1] + action.vy * dt, action.vx, action.vy] + list(robot[4:9])
+        th = robot[8] + action.r
+        vx, vy = action.v * np.cos(th), action.v * np.sin(th)
+        return [robot[0] + vx * dt, robot[1] + vy * dt, vx, vy] + list(robot[4:8]) + [th]
+
+    def rotate(self, state):
+        return rotate(state, self.kinematics)
+
+    def transform(self, state):
+        robot, humans = _state_rows(state)
+        joint = torch.tensor([robot + h for h in humans], dtype=torch.float32, device=self.device)
+        return rotate(joint, self.kinematics)
+
+
+def register(policy_factory):
+    """Install the HIP-backed classes under the reference's registry keys."""
+    policy_factory['model_predictive_rl'] = ModelPredictiveRL
+    policy_factory['gcn'] = GCN
+    return policy_factory

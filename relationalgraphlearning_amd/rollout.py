@@ -1,0 +1,312 @@
+"""Batched action-tree rollout on the MI355X and its multi-GPU sharding.
+
+`TreeSearch` drives mprl_tree_search_f32 / mprl_expand_f32 (path M: the depth-D search of
+crowd_nav/policy/model_predictive_rl.py:192-302 for B root scenes at once); `GcnSearch` drives
+gcn_predict_f32 (path G: the one-step search of crowd_nav/policy/multi_human_rl.py:36-64).
+`ShardedRollout` splits root scenes over the ranks of a torch.distributed group (one process per
+GPU) and exchanges the per-shard results with ONE all-gather -- RCCL over xGMI on the GPU box,
+gloo in the CPU tests.  Root trees are independent, so there is no other communication.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .nets import _require_device_tensor, _stream
+
+
+class _Workspace:
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+class TreeSearch:
+    """Depth-D, width-w model-predictive search for batches of root scenes (path M)."""
+
+    def __init__(self, value_estimator, state_predictor, actions, action_groups, kinematics="holonomic",
+                 time_step=0.25, gamma_bar=0.9 ** 0.25, planning_depth=1, planning_width=1, do_action_clip=False,
+                 sparse_search=False):
+        self.value_estimator = value_estimator
+        self.state_predictor = state_predictor            # StatePredictor module or LinearStatePredictor
+        self.actions_np = np.ascontiguousarray(np.asarray(actions, dtype=np.float64))
+        self.groups_np = None if action_groups is None else np.asarray(action_groups, dtype=np.int32)
+        self.kinematics = kinematics
+        self.time_step = float(time_step)
+        self.gamma_bar = float(gamma_bar)
+        self.planning_depth = int(planning_depth)
+        self.planning_width = int(planning_width)
+        self.do_action_clip = bool(do_action_clip)
+        self.sparse_search = bool(sparse_search)
+        self._dev_tables = {}
+        self._ws = _Workspace()
+        self.last = None            # outputs of the most recent search (device tensors)
+
+    # -- descriptors -----------------------------------------------------------------------------
+    @property
+    def num_actions(self):
+        return self.actions_np.shape[0]
+
+    @property
+    def kept_per_node(self):
+        return self.planning_width if self.do_action_clip else self.num_actions
+
+    def logical_value_evals_per_root(self):
+        """Number of ValueEstimator forwards the reference performs for one decision."""
+        A, w, D = self.num_actions, self.kept_per_node, self.planning_depth
+
+        def V(d):                       # forwards inside V_planning(state, d)
+            if d == 1:
+                return 1
+            clip = A if self.do_action_clip else 0
+            return 1 + clip + w * V(d - 1)
+        root_clip = A if self.do_action_clip else 0
+        return root_clip + w * V(D)
+
+    def _tables(self, device):
+        key = str(device)
+        if key not in self._dev_tables:
+            act = torch.tensor(self.actions_np, dtype=torch.float64, device=device)
+            grp = None if self.groups_np is None else torch.tensor(self.groups_np, dtype=torch.int32, device=device)
+            self._dev_tables[key] = (act, grp)
+        return self._dev_tables[key]
+
+    def planner(self, device):
+        pl = nat.MprlPlanner()
+        ve = self.value_estimator
+        pl.value_graph = ve.graph_model.descriptor()
+        pl.value_head = ve.head_descriptor()
+        linear = not getattr(self.state_predictor, "trainable", False)
+        pl.linear_state_predictor = int(linear)
+        if not linear:
+            pl.predictor_graph = self.state_predictor.graph_model.descriptor()
+            pl.motion_head = self.state_predictor.head_descriptor()
+        pl.kinematics = nat.KINEMATICS[self.kinematics]
+        pl.num_actions = self.num_actions
+        pl.planning_depth = self.planning_depth
+        pl.planning_width = self.planning_width
+        pl.do_action_clip = int(self.do_action_clip)
+        pl.sparse_search = int(self.sparse_search)
+        pl.time_step = self.time_step
+        pl.gamma_bar = self.gamma_bar
+        act, grp = self._tables(device)
+        pl.actions = act.data_ptr()
+        pl.action_groups = None if grp is None else grp.data_ptr()
+        return pl
+
+    # -- device calls ----------------------------------------------------------------------------
+    def search(self, robot, humans, roots_are_joint_states=True, want_root_values=True):
+        """robot (B,9), humans (B,H,5) fp32 device tensors -> dict of device tensors:
+        best_action (B,) int32, best_value (B,) fp32, root_values/root_kept (B,W0)."""
+        robot = _require_device_tensor(robot, "robot states")
+        humans = _require_device_tensor(humans, "human states")
+        B, H = robot.shape[0], humans.shape[1]
+        dev = robot.device
+        with torch.cuda.device(dev):
+            pl = self.planner(dev)
+            lib = nat.lib()
+            nbytes = lib.mprl_tree_workspace_bytes(C.byref(pl), B, H)
+            if nbytes == 0:
+                raise nat.NativeLibraryError("mprl_tree_workspace_bytes rejected the configuration")
+            ws = self._ws.get(nbytes, dev)
+            W0 = self.kept_per_node
+            out = {"best_action": torch.empty(B, dtype=torch.int32, device=dev),
+                   "best_value": torch.empty(B, dtype=torch.float32, device=dev)}
+            rv = rk = None
+            if want_root_values:
+                out["root_values"] = torch.empty(B, W0, dtype=torch.float32, device=dev)
+                out["root_kept"] = torch.empty(B, W0, dtype=torch.int32, device=dev)
+                rv, rk = out["root_values"].data_ptr(), out["root_kept"].data_ptr()
+            rc = lib.mprl_tree_search_f32(C.byref(pl), robot.data_ptr(), humans.data_ptr(), B, H,
+                                          int(roots_are_joint_states), ws.data_ptr(), ws.numel(),
+                                          out["best_action"].data_ptr(), out["best_value"].data_ptr(), rv, rk, _stream())
+        nat.check(rc, "mprl_tree_search_f32")
+        self.last = dict(out, B=B, H=H, robot=robot, humans=humans, planner=pl, workspace=ws)
+        return out
+
+    def expand(self, robot, humans, parents_are_joint_states=True):
+        """One tree level for P parents (what `action_clip` evaluates); all outputs device tensors."""
+        robot = _require_device_tensor(robot, "robot states")
+        humans = _require_device_tensor(humans, "human states")
+        P, H, A = robot.shape[0], humans.shape[1], self.num_actions
+        dev = robot.device
+        o = {"humans_next": torch.empty(P, H, 5, device=dev), "child_robot": torch.empty(P, A, 9, device=dev),
+             "reward": torch.empty(P, A, device=dev), "child_value": torch.empty(P, A, device=dev),
+             "value1": torch.empty(P, A, device=dev)}
+        with torch.cuda.device(dev):
+            pl = self.planner(dev)
+            rc = nat.lib().mprl_expand_f32(C.byref(pl), robot.data_ptr(), humans.data_ptr(), P, H,
+                                           int(parents_are_joint_states), o["humans_next"].data_ptr(),
+                                           o["child_robot"].data_ptr(), o["reward"].data_ptr(),
+                                           o["child_value"].data_ptr(), o["value1"].data_ptr(), _stream())
+        nat.check(rc, "mprl_expand_f32")
+        return o
+
+    def value_children(self, child_robot, humans_next, out=None):
+        """child_robot (P,A,9), humans_next (P,H,5) -> child_value (P,A): the dominant kernel alone."""
+        child_robot = _require_device_tensor(child_robot, "child robot states")
+        humans_next = _require_device_tensor(humans_next, "next human states")
+        P, H = humans_next.shape[0], humans_next.shape[1]
+        dev = child_robot.device
+        if out is None:
+            out = torch.empty(P, self.num_actions, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            pl = self.planner(dev)
+            rc = nat.lib().mprl_value_children_f32(C.byref(pl), child_robot.data_ptr(), humans_next.data_ptr(), P, H,
+                                                   out.data_ptr(), _stream())
+        nat.check(rc, "mprl_value_children_f32")
+        return out
+
+    def level_arrays(self, level):
+        """Views into the workspace of the last search for one tree level (device tensors)."""
+        L = self.last
+        view = nat.MprlLevelView()
+        nat.check(nat.lib().mprl_tree_level_view(C.byref(L["planner"]), L["B"], L["H"], level, C.byref(view)),
+                  "mprl_tree_level_view")
+        ws, P, A, W, H = L["workspace"], int(view.n_parents), self.num_actions, self.kept_per_node, L["H"]
+
+        def f32(off, *shape):
+            n = int(np.prod(shape))
+            return ws[off:off + 4 * n].view(torch.float32).reshape(*shape)
+
+        def i32(off, *shape):
+            n = int(np.prod(shape))
+            return ws[off:off + 4 * n].view(torch.int32).reshape(*shape)
+        arr = {"n_parents": P,
+               "humans_next": f32(view.humans_next_off, P, H, 5), "child_robot": f32(view.child_robot_off, P, A, 9),
+               "reward": f32(view.reward_off, P, A), "child_value": f32(view.child_value_off, P, A),
+               "value1": f32(view.value1_off, P, A), "keep": i32(view.keep_off, P, W),
+               "backup": f32(view.backup_off, P, W), "best_slot": i32(view.best_slot_off, P)}
+        if level == 0:
+            arr["robot"], arr["humans"], arr["humans_per"] = L["robot"], L["humans"], 1
+        else:
+            arr["robot"] = f32(view.robot_off, P, 9)
+            arr["humans"] = f32(view.humans_off, P // W, H, 5)
+            arr["humans_per"] = W
+        return arr
+
+    def best_trajectory(self, b=0):
+        """[(robot (1,1,9), humans (1,H,5)), action index | None, reward | None] along the best branch
+        of root scene `b` -- the content of ModelPredictiveRL.traj (model_predictive_rl.py:231,298-302)."""
+        traj, p = [], b
+        W = self.kept_per_node
+        for lvl in range(self.planning_depth):
+            arr = self.level_arrays(lvl)
+            slot = int(arr["best_slot"][p])
+            a = int(arr["keep"][p, slot])
+            state = (arr["robot"][p].reshape(1, 1, 9).clone(),
+                     arr["humans"][p // arr["humans_per"]].unsqueeze(0).clone())
+            traj.append((state, a, float(arr["reward"][p, a])))
+            last = (arr["child_robot"][p, a].reshape(1, 1, 9).clone(), arr["humans_next"][p].unsqueeze(0).clone())
+            p = p * W + slot
+        traj.append((last, None, None))
+        return traj
+
+
+class GcnSearch:
+    """One-step lookahead over the rotation-major action table with the path-G ValueNetwork."""
+
+    def __init__(self, value_network, actions, kinematics="holonomic", time_step=0.25, gamma=0.9):
+        self.model = value_network
+        self.actions_np = np.ascontiguousarray(np.asarray(actions, dtype=np.float64))
+        self.kinematics = kinematics
+        self.time_step = float(time_step)
+        self.gamma = float(gamma)
+        self._dev_tables = {}
+        self._ws = _Workspace()
+
+    def search(self, robot, humans):
+        """robot (B,9), humans (B,H,5) -> (action_values (B,A) fp32, best_action (B,) int32), device tensors."""
+        robot = _require_device_tensor(robot, "robot states")
+        humans = _require_device_tensor(humans, "human states")
+        B, H, A = robot.shape[0], humans.shape[1], self.actions_np.shape[0]
+        dev = robot.device
+        key = str(dev)
+        if key not in self._dev_tables:
+            self._dev_tables[key] = torch.tensor(self.actions_np, dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            pl = nat.GcnPlanner()
+            pl.graph = self.model.descriptor()
+            pl.value_head = self.model.head_descriptor()
+            pl.kinematics = nat.KINEMATICS[self.kinematics]
+            pl.num_actions = A
+            pl.time_step = self.time_step
+            pl.gamma = self.gamma
+            pl.actions = self._dev_tables[key].data_ptr()
+            lib = nat.lib()
+            ws = self._ws.get(lib.gcn_predict_workspace_bytes(B, H, A), dev)
+            vals = torch.empty(B, A, dtype=torch.float32, device=dev)
+            best = torch.empty(B, dtype=torch.int32, device=dev)
+            rc = lib.gcn_predict_f32(C.byref(pl), robot.data_ptr(), humans.data_ptr(), B, H, ws.data_ptr(), ws.numel(),
+                                     vals.data_ptr(), best.data_ptr(), _stream())
+        nat.check(rc, "gcn_predict_f32")
+        return vals, best
+
+
+def rotate(joint14, kinematics="holonomic"):
+    """(R,14) -> (R,13) pairwise relation features on device (CADRL.rotate, cadrl.py:241-276)."""
+    joint14 = _require_device_tensor(joint14, "joint states")
+    out = torch.empty(joint14.shape[0], 13, dtype=torch.float32, device=joint14.device)
+    with torch.cuda.device(joint14.device):
+        rc = nat.lib().gcn_rotate_f32(joint14.data_ptr(), out.data_ptr(), joint14.shape[0],
+                                      nat.KINEMATICS[kinematics], _stream())
+    nat.check(rc, "gcn_rotate_f32")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# multi-GPU: shard the root scenes, one all-gather of the results
+# --------------------------------------------------------------------------------------------------
+def shard_bounds(n_items, world_size, rank):
+    """Contiguous, balanced split: the first (n % world) ranks get one extra item."""
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class ShardedRollout:
+    """Runs `search_fn(robot_shard, humans_shard) -> (best_action (b,), best_value (b,))` on this
+    rank's contiguous slice of the roots and all-gathers `[action, value]` rows from every rank.
+
+    The only collective is one `all_gather_into_tensor` of (ceil(B/world), 2) fp32 per rank -- a few
+    KB, latency-bound; on MI355X this is RCCL over xGMI (`backend="nccl"`), in the CPU tests gloo."""
+
+    def __init__(self, search_fn, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.search_fn = search_fn
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def run(self, robot, humans):
+        """robot (B,9), humans (B,H,5): the FULL root batch (identical on every rank).
+        Returns (best_action (B,) int64, best_value (B,) fp32) on the device of the inputs."""
+        B = robot.shape[0]
+        lo, hi = shard_bounds(B, self.world, self.rank)
+        return self.run_local(robot[lo:hi], humans[lo:hi], B)
+
+    def run_local(self, robot_shard, humans_shard, total):
+        """Same, when each rank already holds only its shard (`total` = global root count)."""
+        per = -(-total // self.world)
+        packed = torch.zeros(per, 2, dtype=torch.float32, device=robot_shard.device)
+        n = robot_shard.shape[0]
+        if n > 0:
+            act, val = self.search_fn(robot_shard, humans_shard)
+            packed[:n, 0] = act.to(torch.float32)
+            packed[:n, 1] = val
+        if self.world == 1:
+            return packed[:n, 0].to(torch.int64), packed[:n, 1].clone()
+        gathered = torch.empty(self.world * per, 2, dtype=torch.float32, device=packed.device)
+        self.dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        pieces_a, pieces_v = [], []
+        for r in range(self.world):
+            lo, hi = shard_bounds(total, self.world, r)
+            pieces_a.append(gathered[r * per:r * per + (hi - lo), 0])
+            pieces_v.append(gathered[r * per:r * per + (hi - lo), 1])
+        return torch.cat(pieces_a).to(torch.int64), torch.cat(pieces_v)

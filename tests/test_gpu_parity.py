@@ -1,0 +1,320 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden fixtures and the CPU oracle.
+
+Tolerance (north star): |value_gpu - value_ref| <= 1e-4 in fp32 on identical crowd states; written
+here as 1e-4 * max(1, max|ref|) so the random-init weight sets (values of order 10..100) are held to
+the same relative bar.  Integer results (actions, kept sets) and fp32-exact kinematics must be equal.
+"""
+import numpy as np
+import pytest
+import torch
+
+import relationalgraphlearning_amd as rga
+from relationalgraphlearning_amd import _native as nat
+from relationalgraphlearning_amd.config import policy_config
+from oracle import rgl_oracle as orc
+from tests import golden_io as gio
+from tests.helpers import make_mprl_policy, make_gcn_policy, JS
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def close(a, b, tol=TOL):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, (err, scale)
+    return err
+
+
+def build_modules(c, dev):
+    cfg = policy_config(gcn__num_layer=c["L"], gcn__similarity_function=c["sim"],
+                        gcn__layerwise_graph=c["layerwise"], gcn__skip_connection=c["skip"])
+    m = gio.master(c["flavour"])
+    g1 = rga.RGL(cfg, 9, 5)
+    g1.load_state_dict(gio.graph_sd(m, "graph_model1", c["L"], c["sim"]))
+    g2 = rga.RGL(cfg, 9, 5)
+    g2.load_state_dict(gio.graph_sd(m, "graph_model2", c["L"], c["sim"]))
+    ve = rga.ValueEstimator(cfg, g1)
+    ve.value_network.load_state_dict(gio.sub_sd(m, "value_network"))
+    sp = rga.StatePredictor(cfg, g2, 0.25)
+    sp.human_motion_predictor.load_state_dict(gio.sub_sd(m, "motion_predictor"))
+    return g1.to(dev), ve.to(dev), sp.to(dev)
+
+
+@pytest.mark.parametrize("c", gio.forward_cases(), ids=lambda c: "f%02d-%s-H%d-L%d-lw%d-sk%d" % (
+    c["idx"], c["sim"], c["H"], c["L"], c["layerwise"], c["skip"]))
+def test_forward_kats(c, dev):
+    fw = gio.load("forward")
+    k = "f%02d." % c["idx"]
+    g1, ve, sp = build_modules(c, dev)
+    robot = torch.tensor(fw[k + "robot"]).unsqueeze(1).to(dev)
+    humans = torch.tensor(fw[k + "humans"]).to(dev)
+    with torch.no_grad():
+        H_L = g1((robot, humans))
+        A0 = g1.A
+        val = ve((robot, humans))
+        nr, nh = sp((robot, humans), None)
+    close(H_L.cpu().numpy(), fw[k + "H_L"])
+    close(A0, fw[k + "A"][0])
+    close(val.cpu().numpy(), fw[k + "value"])
+    close(nh.cpu().numpy(), fw[k + "humans_next"])
+    assert nr is None
+
+
+def test_state_predictor_robot_update(dev):
+    fw = gio.load("forward")
+    c = dict(L=2, sim="embedded_gaussian", layerwise=False, skip=True, flavour="trained")
+    _, _, sp = build_modules(c, dev)
+    r = torch.tensor(fw["sp.robot"]).unsqueeze(1).to(dev)
+    h = torch.tensor(fw["sp.humans"]).to(dev)
+    with torch.no_grad():
+        for a, want in zip(fw["sp.actions"], fw["sp.next_robot"]):
+            nr, _ = sp((r, h), rga.ActionXY(a[0], a[1]))
+            assert np.array_equal(nr.cpu().numpy().reshape(9), want)
+    lin = rga.LinearStatePredictor(policy_config(), 0.25)
+    nr, nh = lin((r, h), rga.ActionXY(*fw["sp.actions"][1]))
+    assert np.array_equal(nh.cpu().numpy(), fw["sp.linear_next_humans"])
+    assert np.array_equal(nr.cpu().numpy().reshape(9), fw["sp.linear_next_robot"])
+
+
+def test_expand_level_against_oracle(dev):
+    """child robots bit-exact, rewards to 1e-7, child values / predicted humans to tolerance."""
+    ar = gio.load("actions_rewards")
+    robot = torch.tensor(ar["rew.sweep_robot"])
+    humans = torch.tensor(ar["rew.sweep_humans"])
+    pol = make_mprl_policy("trained", D=1, device=dev)
+    pol.build_action_space(1.0)
+    ts = pol.tree_search()
+    P = gio.oracle_params("trained")
+    cfg = orc.OracleConfig()
+    acts, _ = orc.mprl_action_space(cfg, 1.0)
+    for joint in (True, False):
+        got = ts.expand(robot.to(dev), humans.to(dev), parents_are_joint_states=joint)
+        with torch.no_grad():
+            want = orc.mprl_expand_batched(robot, humans, P, cfg, acts, root=joint)
+        assert np.array_equal(got["child_robot"].cpu().numpy(), want["child_robot"].numpy())
+        assert np.abs(got["reward"].cpu().numpy() - want["reward"].numpy()).max() < 1e-7
+        close(got["humans_next"].cpu().numpy(), want["next_humans"].numpy())
+        close(got["child_value"].cpu().numpy(), want["child_value"].numpy())
+        close(got["value1"].cpu().numpy(), want["value1"].numpy())
+    # and straight against what the reference itself returned for these states
+    got = ts.expand(robot.to(dev), humans.to(dev), parents_are_joint_states=False)
+    assert np.abs(got["reward"].cpu().numpy() - ar["rew.sweep_tensor"]).max() < 1e-7
+    got = ts.expand(robot.to(dev), humans.to(dev), parents_are_joint_states=True)
+    assert np.abs(got["reward"].cpu().numpy() - ar["rew.sweep_joint"]).max() < 1e-7
+
+
+def test_reward_kats(dev):
+    ar = gio.load("actions_rewards")
+    pol = make_mprl_policy("trained", D=1, device=dev)
+    for i, name in enumerate(ar["rew.names"]):
+        n = int(ar["rew.n_humans"][i])
+        robot = torch.tensor(ar["rew.robot"][i:i + 1].astype(np.float32)).to(dev)
+        humans = torch.tensor(ar["rew.humans"][i:i + 1, :n].astype(np.float32)).to(dev)
+        ts = rga.TreeSearch(pol.value_estimator, pol.state_predictor, ar["rew.actions"][i:i + 1], None)
+        got = ts.expand(robot, humans, parents_are_joint_states=False)
+        assert abs(float(got["reward"][0, 0]) - ar["rew.tensor"][i]) < 1e-7, name
+
+
+@pytest.mark.parametrize("c", gio.plan_cases(), ids=lambda c: c["tag"])
+def test_planning_kats(c, dev):
+    pl = gio.load("planning")
+    k = "plan.%s." % c["tag"]
+    pol = make_mprl_policy(c["flavour"], c["D"], c["w"], c["clip"], c["sparse"], c["variant"], device=dev)
+    R = torch.tensor(pl["plan.scene.%s.robot" % c["scene"]].astype(np.float32)).to(dev)
+    Hh = torch.tensor(pl["plan.scene.%s.humans" % c["scene"]].astype(np.float32)).to(dev)
+    pol.build_action_space(1.0)
+    ts = pol.tree_search()
+    out = ts.search(R, Hh, roots_are_joint_states=True)
+    assert np.array_equal(out["best_action"].cpu().numpy().astype(np.int64), pl[k + "action"])
+    close(out["best_value"].cpu().numpy(), pl[k + "max_value"])
+    kept = out["root_kept"].cpu().numpy()
+    rv = out["root_values"].cpu().numpy()
+    for b in range(R.shape[0]):
+        assert sorted(kept[b].tolist()) == sorted(pl[k + "kept"][b].tolist())
+        order = [kept[b].tolist().index(int(i)) for i in pl[k + "kept"][b]]
+        close(rv[b][order], pl[k + "root_values"][b])
+    if c["clip"]:
+        close(ts.level_arrays(0)["value1"].cpu().numpy(), pl[k + "clip_values"])
+    assert ts.logical_value_evals_per_root() == int(pl[k + "counts"][0][0])
+
+
+def test_predict_joint_state_api(dev):
+    """Policy.predict(JointState) -> ActionXY, traj of D+1 entries, errors of the reference contract."""
+    pl = gio.load("planning")
+    pol = make_mprl_policy("trained", 2, 2, True, device=None)
+    js = JS(pl["plan.scene.s5.robot"][0], pl["plan.scene.s5.humans"][0])
+    with pytest.raises(AttributeError):
+        pol.predict(js)                       # device not set
+    pol.set_device(dev)
+    a = pol.predict(js)
+    want = pol.action_space[int(pl["plan.d2w2.action"][0])]
+    assert isinstance(a, rga.ActionXY) and a == want
+    traj = pol.get_traj()
+    assert len(traj) == 3 and traj[-1][1] is None and traj[0][1] == a
+    assert traj[0][0][0].shape == (1, 1, 9) and traj[0][0][1].shape == (1, 5, 5)
+    pol.set_phase("train")
+    with pytest.raises(AttributeError):
+        pol.predict(js)                       # epsilon not set
+    pol.set_epsilon(0.0)
+    assert pol.predict(js) == want
+    assert pol.last_state[0].shape == (1, 9) and pol.last_state[1].shape == (5, 5)
+    at_goal = JS([0, 4, 0, 0, 0.3, 0, 4, 1, 0], pl["plan.scene.s5.humans"][0])
+    assert pol.predict(at_goal) == rga.ActionXY(0, 0)
+
+
+def test_checkpoint_roundtrip(dev, tmp_path):
+    pol = make_mprl_policy("trained", 1, device=dev)
+    f = str(tmp_path / "rl_model.pth")
+    pol.save_model(f)
+    ck = torch.load(f)
+    assert set(ck) == {"graph_model1", "graph_model2", "value_network", "motion_predictor"}
+    assert set(ck["graph_model1"]) == {"w_a", "w_r.0.weight", "w_r.0.bias", "w_r.2.weight", "w_r.2.bias",
+                                        "w_h.0.weight", "w_h.0.bias", "w_h.2.weight", "w_h.2.bias", "Ws.0", "Ws.1"}
+    pol2 = make_mprl_policy("rand", 1, device=dev)
+    pol2.load_model(f)
+    pl = gio.load("planning")
+    R = torch.tensor(pl["plan.scene.s5.robot"].astype(np.float32)).to(dev)
+    Hh = torch.tensor(pl["plan.scene.s5.humans"].astype(np.float32)).to(dev)
+    a1, v1 = pol.predict_batch(R, Hh)
+    a2, v2 = pol2.predict_batch(R, Hh)
+    assert torch.equal(a1, a2) and torch.equal(v1, v2)       # cache invalidation on load_state_dict works
+
+
+# ---------------------------------------------------------------------------------------------------
+# larger seeded batches against the batched oracle
+# ---------------------------------------------------------------------------------------------------
+def seeded_scenes(seed, B, H):
+    rng = np.random.RandomState(seed)
+    robot = np.zeros((B, 9), np.float32)
+    humans = np.zeros((B, H, 5), np.float32)
+    ang = rng.uniform(0, 2 * np.pi, B)
+    robot[:, 0], robot[:, 1] = 4 * np.cos(ang), 4 * np.sin(ang)
+    robot[:, 2:4] = rng.uniform(-0.7, 0.7, (B, 2))
+    robot[:, 4] = 0.3
+    robot[:, 5], robot[:, 6] = -4 * np.cos(ang), -4 * np.sin(ang)
+    robot[:, 7] = 1.0
+    robot[:, 8] = np.pi / 2
+    humans[:, :, 0:2] = rng.uniform(-5, 5, (B, H, 2))
+    humans[:, :, 2:4] = rng.uniform(-1, 1, (B, H, 2))
+    humans[:, :, 4] = 0.3
+    return torch.tensor(robot), torch.tensor(humans)
+
+
+@pytest.mark.parametrize("H,D,w,clip,B,L", [(4, 1, 1, False, 96, 2), (5, 1, 1, False, 64, 2), (19, 2, 2, True, 24, 2),
+                                             (19, 3, 2, True, 6, 2), (49, 2, 2, True, 4, 3), (3, 2, 81, False, 2, 2)])
+def test_tree_vs_batched_oracle(H, D, w, clip, B, L, dev):
+    robot, humans = seeded_scenes(100 + H + D, B, H)
+    pol = make_mprl_policy("trained", D, w, clip, L=L, device=dev)
+    cfg = orc.OracleConfig(num_layer=L, planning_depth=D, planning_width=w, do_action_clip=clip)
+    with torch.no_grad():
+        oa, ov, orv, okept = orc.mprl_predict_batched(robot, humans, gio.oracle_params("trained", L), cfg)
+    act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
+    out = pol.tree_search().last
+    close(val.cpu().numpy(), ov.numpy())
+    close(out["root_values"].cpu().numpy(), orv.numpy())
+    same = act.cpu().numpy().astype(np.int64) == oa.numpy()
+    # a different argmax is only acceptable on a numerical tie of the two candidates
+    for b in np.nonzero(~same)[0]:
+        assert abs(float(val[b]) - float(ov[b])) < 1e-5
+    assert same.mean() > 0.95
+
+
+def test_properties_at_full_size(dev):
+    """BASELINE config 3 (N=20, L=2, D=2, w=2, B=2048): size-independent properties."""
+    B, H = 2048, 19
+    robot, humans = seeded_scenes(7, B, H)
+    pol = make_mprl_policy("trained", 2, 2, True, device=dev)
+    r, h = robot.to(dev), humans.to(dev)
+    a1, v1 = pol.predict_batch(r, h)
+    a1, v1 = a1.clone(), v1.clone()
+    a2, v2 = pol.predict_batch(r, h)
+    assert torch.equal(a1, a2) and torch.equal(v1, v2)                      # deterministic
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).to(dev)
+    a3, v3 = pol.predict_batch(r[perm], h[perm])
+    assert torch.equal(a3, a1[perm]) and torch.equal(v3, v1[perm])          # roots are independent
+    a4, v4 = pol.predict_batch(r[:64], h[:64])
+    assert torch.equal(a4, a1[:64]) and torch.equal(v4, v1[:64])            # batch-size independent
+    hp = torch.randperm(H, generator=torch.Generator().manual_seed(2)).to(dev)
+    a5, v5 = pol.predict_batch(r, h[:, hp])                                 # humans are an unordered set
+    assert float((v5 - v1).abs().max()) < 1e-4
+    assert float((a5 == a1).float().mean()) > 0.99
+    # value back-up sanity: the chosen value is the max of the reported root values
+    out = pol.tree_search().last
+    assert torch.equal(out["root_values"].max(dim=1).values, out["best_value"])
+    # spot-check 16 roots against the oracle at this size
+    cfg = orc.OracleConfig(planning_depth=2, planning_width=2, do_action_clip=True)
+    with torch.no_grad():
+        oa, ov, _, _ = orc.mprl_predict_batched(robot[:16], humans[:16], gio.oracle_params("trained"), cfg)
+    close(v1[:16].cpu().numpy(), ov.numpy())
+
+
+# ---------------------------------------------------------------------------------------------------
+# path G
+# ---------------------------------------------------------------------------------------------------
+def test_path_g_rotate(dev):
+    g = gio.load("path_g")
+    x = torch.tensor(g["g.rotate_in"]).to(dev)
+    close(rga.rotate(x).cpu().numpy(), g["g.rotate_out"], 2e-6)
+    close(rga.rotate(x, "unicycle").cpu().numpy(), g["g.rotate_out_unicycle"], 2e-6)
+
+
+def test_path_g_value_network(dev):
+    g = gio.load("path_g")
+    x = torch.tensor(g["g.vn_in"]).to(dev)
+    for tag in g["g_cases"]:
+        tag = str(tag)
+        L, lw, sk = int(tag[1]), bool(int(tag[5])), bool(int(tag[9]))
+        pol = make_gcn_policy(L, lw, sk, device=dev)
+        with torch.no_grad():
+            v = pol.model(x)
+            v2 = pol.model((x, None))                       # (tensor, lengths) form is accepted too
+        close(v.cpu().numpy(), g["g.vn_value." + tag])
+        assert torch.equal(v, v2)
+        close(pol.model.A, g["g.vn_A0." + tag])
+
+
+def test_path_g_predict(dev):
+    g = gio.load("path_g")
+    pol = make_gcn_policy(device=dev)
+    for b in range(g["g.pred_robot"].shape[0]):
+        js = JS(g["g.pred_robot"][b], g["g.pred_humans"][b])
+        a = pol.predict(js)
+        assert a == pol.action_space[int(g["g.pred_action"][b])]
+        close(np.array(pol.action_values), g["g.pred_action_values"][b])
+        close(pol.get_matrix_A(), g["g.pred_A_last"][b])
+    # batched device API against the sequential oracle
+    robot = torch.tensor(g["g.pred_robot"].astype(np.float32)).to(dev)
+    humans = torch.tensor(g["g.pred_humans"].astype(np.float32)).to(dev)
+    vals, best = pol.gcn_search().search(robot, humans)
+    assert np.array_equal(best.cpu().numpy().astype(np.int64), g["g.pred_action"])
+    close(vals.cpu().numpy(), g["g.pred_action_values"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# error behaviour: loud, never a silent fallback
+# ---------------------------------------------------------------------------------------------------
+def test_no_cpu_fallback_and_no_silent_autograd(dev):
+    c = dict(L=2, sim="embedded_gaussian", layerwise=False, skip=True, flavour="trained")
+    g1, ve, sp = build_modules(c, dev)
+    r = torch.zeros(1, 1, 9)
+    h = torch.zeros(1, 3, 5)
+    with torch.no_grad(), pytest.raises(nat.NativeLibraryError):
+        ve((r, h))                                            # CPU tensors
+    with pytest.raises(NotImplementedError):
+        ve((r.to(dev), h.to(dev)))                            # gradients requested
+    with torch.no_grad(), pytest.raises(nat.NativeLibraryError):
+        ve((r.to(dev), torch.zeros(1, 64, 5, device=dev)))    # N = 65 > RGL_MAX_NODES
+
+
+def test_library_reports_target():
+    assert nat.lib().rgl_build_target() == b"gfx950"

@@ -1,0 +1,152 @@
+"""CPU-side tests (-m "not gpu"): the C ABI library loads and exports every declared symbol, host
+logic (action tables, sharding, configs, checkpoints) is right, and the product refuses to run
+without the device path."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import relationalgraphlearning_amd as rga
+from relationalgraphlearning_amd import _native as nat
+from relationalgraphlearning_amd.config import policy_config
+from tests import golden_io as gio
+from tests.helpers import make_mprl_policy, make_gcn_policy, JS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rgl_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|size_t|const char\*)\s+(\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(nat.SIGNATURES), declared ^ set(nat.SIGNATURES)
+    assert os.path.exists(nat.LIB_PATH), "run __graft_entry__.build() first"
+    handle = ctypes.CDLL(nat.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    lib = nat.lib()
+    assert lib.rgl_abi_version() == nat.ABI_VERSION
+    assert lib.rgl_build_target() == b"gfx950"
+
+
+def test_struct_layout_matches_header_sizes():
+    # sizes implied by include/rgl_hip.h on LP64 (ints 4 B, pointers 8 B, natural alignment)
+    mlp = 4 + 4 + 4 * 7 + 4 + 8 * 6 + 8 * 6          # 4 B padding after dims[7] for pointer alignment
+    assert ctypes.sizeof(nat.RglMlp) == mlp
+    graph = 2 * mlp + 6 * 4 + 8 + mlp + 8 * 8
+    assert ctypes.sizeof(nat.RglGraph) == graph
+    assert ctypes.sizeof(nat.MprlLevelView) == 11 * 8
+    assert ctypes.sizeof(nat.MprlPlanner) == 2 * graph + 2 * mlp + 8 * 4 + 2 * 8 + 2 * 8
+    assert ctypes.sizeof(nat.GcnPlanner) == graph + mlp + 2 * 4 + 2 * 8 + 8
+
+
+def test_host_side_argument_checks_without_gpu():
+    lib = nat.lib()
+    # NULL pointers and bad shapes are rejected on the host before any launch
+    assert lib.rgl_transpose_f32(None, None, 4, 4, None) == -3
+    assert lib.gcn_rotate_f32(None, None, 4, 0, None) == -3
+    assert lib.mprl_tree_workspace_bytes(None, 4, 5) == 0
+    assert lib.gcn_predict_workspace_bytes(4, 5, 81) > 0
+    pl = nat.MprlPlanner()
+    pl.planning_depth, pl.planning_width, pl.num_actions, pl.do_action_clip = 2, 2, 81, 1
+    n2 = lib.mprl_tree_workspace_bytes(ctypes.byref(pl), 2048, 19)
+    pl.planning_depth = 3
+    n3 = lib.mprl_tree_workspace_bytes(ctypes.byref(pl), 2048, 19)
+    assert 0 < n2 < n3 < (1 << 31)
+    view = nat.MprlLevelView()
+    assert lib.mprl_tree_level_view(ctypes.byref(pl), 2048, 19, 2, ctypes.byref(view)) == 0
+    assert view.n_parents == 2048 * 4
+    assert lib.mprl_tree_level_view(ctypes.byref(pl), 2048, 19, 3, ctypes.byref(view)) == -1
+
+
+def test_product_refuses_cpu_tensors():
+    pol = make_mprl_policy("trained", 1)
+    pol.set_device(torch.device("cpu"))
+    pl = gio.load("planning")
+    js = JS(pl["plan.scene.s5.robot"][0], pl["plan.scene.s5.humans"][0])
+    with pytest.raises(nat.NativeLibraryError):
+        pol.predict(js)
+    with torch.no_grad(), pytest.raises(nat.NativeLibraryError):
+        pol.value_estimator((torch.zeros(1, 1, 9), torch.zeros(1, 2, 5)))
+    g = make_gcn_policy()
+    g.set_device(torch.device("cpu"))
+    with pytest.raises(nat.NativeLibraryError):
+        g.predict(js)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "relationalgraphlearning_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "/root/reference" not in text, f
+
+
+def test_action_tables_and_groups():
+    ar = gio.load("actions_rewards")
+    pol = make_mprl_policy("trained")
+    pol.build_action_space(1.0)
+    assert len(pol.action_space) == 81 and pol.action_space[0] == rga.ActionXY(0, 0)
+    from relationalgraphlearning_amd.actions import as_array
+    assert np.array_equal(as_array(pol.action_space), ar["act.mprl"])
+    assert pol.action_group_index == ar["act.mprl_groups"].tolist()
+    g = make_gcn_policy()
+    g.build_action_space(1.0)
+    assert np.array_equal(as_array(g.action_space), ar["act.gcn"])
+
+
+def test_parameter_names_and_shapes_match_reference_checkpoints():
+    pol = make_mprl_policy("rand", L=3)
+    sd = pol.get_state_dict()
+    m = gio.master("rand")
+    for k, v in sd["graph_model1"].items():
+        assert tuple(v.shape) == m["graph_model1." + k].shape, k
+    assert [tuple(v.shape) for v in sd["value_network"].values()] == \
+        [(32, 32), (32,), (100, 32), (100,), (100, 100), (100,), (1, 100), (1,)]
+    assert [tuple(v.shape) for v in sd["motion_predictor"].values()] == [(64, 32), (64,), (5, 64), (5,)]
+    shared = make_mprl_policy("rand", variant="shared")
+    assert set(shared.get_state_dict()) == {"graph_model", "value_network", "motion_predictor"}
+    assert shared.state_predictor.graph_model is shared.value_estimator.graph_model
+    lin = make_mprl_policy("rand", variant="linear")
+    assert set(lin.get_state_dict()) == {"graph_model", "value_network"} and not lin.state_predictor.trainable
+    g = make_gcn_policy()
+    assert set(g.get_state_dict()) == set(gio.path_g_sd())
+    assert pol.get_model() is pol.value_estimator
+    assert abs(pol.get_normalized_gamma() - 0.9 ** 0.25) < 1e-15
+
+
+def test_logical_eval_counts():
+    assert make_mprl_policy("rand", 1).tree_search().logical_value_evals_per_root() == 81
+    assert make_mprl_policy("rand", 2, 2, True).tree_search().logical_value_evals_per_root() == 249
+    assert make_mprl_policy("rand", 3, 2, True).tree_search().logical_value_evals_per_root() == 581
+    assert make_mprl_policy("rand", 2, 1, False).tree_search().logical_value_evals_per_root() == 81 * 82
+
+
+def test_registration_uses_reference_keys():
+    factory = {}
+    rga.register(factory)
+    assert factory["model_predictive_rl"] is rga.ModelPredictiveRL and factory["gcn"] is rga.GCN
+    p = factory["model_predictive_rl"]()
+    for attr in ("trainable", "phase", "model", "device", "last_state", "time_step", "env", "name",
+                 "multiagent_training", "kinematics", "planning_depth", "traj", "state_predictor"):
+        assert hasattr(p, attr), attr
+    for meth in ("configure", "set_phase", "set_device", "set_env", "set_time_step", "set_epsilon", "get_model",
+                 "save_model", "load_model", "get_state_dict", "load_state_dict", "predict", "transform",
+                 "get_normalized_gamma", "get_traj"):
+        assert callable(getattr(p, meth)), meth
+    q = factory["gcn"]()
+    assert hasattr(q, "action_values") and callable(q.get_matrix_A)
+
+
+def test_shard_bounds_cover_everything_once():
+    for n in (0, 1, 7, 8, 2048, 4097):
+        for world in (1, 2, 3, 8):
+            spans = [rga.shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,63 @@
+"""world_size-2 test of the multi-GPU path on CPU (gloo): shard the roots, one all-gather.
+
+The per-shard search is injected (here: the CPU oracle), so the test exercises exactly the code
+bench.py runs under RCCL -- ShardedRollout -- without a GPU."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import golden_io as gio
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from relationalgraphlearning_amd import ShardedRollout
+    from oracle import rgl_oracle as orc
+    torch.set_num_threads(1)
+    pl = gio.load("planning")
+    robot = torch.tensor(np.tile(pl["plan.scene.s5.robot"], (3, 1))[:total].astype(np.float32))
+    humans = torch.tensor(np.tile(pl["plan.scene.s5.humans"], (3, 1, 1))[:total].astype(np.float32))
+    robot[:, 0] += torch.arange(total) * 0.01            # make every root distinct
+    P = gio.oracle_params("trained")
+    cfg = orc.OracleConfig(planning_depth=2, planning_width=2, do_action_clip=True)
+    calls = []
+
+    def search(r, h):
+        calls.append(r.shape[0])
+        with torch.no_grad():
+            a, v, _, _ = orc.mprl_predict_batched(r, h, P, cfg)
+        return a, v
+    sr = ShardedRollout(search)
+    act, val = sr.run(robot, humans)
+    torch.save({"act": act, "val": val, "calls": calls}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_rollout_matches_single_process(tmp_path):
+    total, world = 7, 2                                   # uneven split: 4 + 3
+    mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(world)]
+    assert res[0]["calls"] == [4] and res[1]["calls"] == [3]
+    assert torch.equal(res[0]["act"], res[1]["act"]) and torch.equal(res[0]["val"], res[1]["val"])
+    from oracle import rgl_oracle as orc
+    pl = gio.load("planning")
+    robot = torch.tensor(np.tile(pl["plan.scene.s5.robot"], (3, 1))[:total].astype(np.float32))
+    humans = torch.tensor(np.tile(pl["plan.scene.s5.humans"], (3, 1, 1))[:total].astype(np.float32))
+    robot[:, 0] += torch.arange(total) * 0.01
+    cfg = orc.OracleConfig(planning_depth=2, planning_width=2, do_action_clip=True)
+    with torch.no_grad():
+        a, v, _, _ = orc.mprl_predict_batched(robot, humans, gio.oracle_params("trained"), cfg)
+    assert torch.equal(res[0]["act"], a) and torch.equal(res[0]["val"], v)
