@@ -184,18 +184,22 @@ typedef struct MprlPlanner {
  * parents_are_joint_states: 1 for root states that came from float64 JointStates (position
  * differences taken in float64), 0 for tensor-born states (differences rounded to float32 first,
  * as tensor_to_joint_state + numpy scalars do).
- * All outputs device; child_robot [P][A][9], the others [P][A] / [P][H][5]. */
+ * All outputs device; child_robot [P][A][9], the others [P][A] / [P][H][5].  `workspace` as for
+ * mprl_value_children_f32 (NULL allowed: general kernel). */
 int mprl_expand_f32(const MprlPlanner* planner, const float* robot, const float* humans, int P, int H,
                     int parents_are_joint_states,
                     float* humans_next, float* child_robot, float* reward, float* child_value,
-                    float* value1, rgl_stream_t stream);
+                    float* value1, void* workspace, size_t workspace_bytes, rgl_stream_t stream);
 
 /* The dominant kernel of the rollout on its own: child_value[p][a] = ValueEstimator(child_robot[p][a],
  * humans_next[p]) for the A sibling children of each of P parents (siblings share their crowd).
  * Same code path mprl_expand_f32 / mprl_tree_search_f32 use; exported so it can be timed and
- * tested in isolation (value_estimator.py:11-20 applied to model_predictive_rl.py:245-250's loop). */
+ * tested in isolation.  `workspace` (device, mprl_value_children_workspace_bytes) carries the
+ * [P*A][64] hand-off between the two MFMA stages; without it (NULL) the general kernel runs (value_estimator.py:11-20 applied to model_predictive_rl.py:245-250's loop). */
+size_t mprl_value_children_workspace_bytes(const MprlPlanner* planner, int P, int H);
 int mprl_value_children_f32(const MprlPlanner* planner, const float* child_robot, const float* humans_next,
-                            int P, int H, float* child_value, rgl_stream_t stream);
+                            int P, int H, float* child_value, void* workspace, size_t workspace_bytes,
+                            rgl_stream_t stream);
 
 /* Whole depth-D search for B root scenes: level-synchronous expansion, top-w clipping
  * (argpartition / sparse grouped variant), V_planning back-up (:271-302), first-max argmax.

@@ -1,17 +1,634 @@
-// rgl_fast.hip -- MFMA kernels for the shipped configuration (embedded_gaussian, non-layerwise,
-// skip connection, x_dim 32, hidden 64).  Until they are in place every call routes to the
-// general kernel of rgl_generic.hip (same results, lower throughput).
+// rgl_fast.hip -- f32-MFMA kernels for the shipped configuration of the relational graph
+// (embedded_gaussian similarity, one adjacency for all layers, x_dim 32, embedding MLPs
+// 9->64->32 / 5->64->32, value head 32->D1->D2->D3->1), specialised for the shape the rollout
+// actually produces: the A sibling children of one parent share their crowd and differ only in
+// the robot row.
+//
+//   stage 1  children_graph_kernel : one workgroup per parent.
+//       prologue  human embeddings Xh, G = Xh*Wa, S_hh = G*Xh^T            (once per parent, VALU)
+//       B1/B2     robot embeddings of 16 children at a time as an MFMA chain in "transposed" form
+//                 (activations = B operand, kept in registers: the 4 D registers of one MFMA are
+//                 the B operands of 4 k-steps of the next, with the k index permuted to match),
+//                 then the robot row / robot column of every child's similarity matrix
+//       B3        per 16 (child,node) columns: softmax computed in-lane directly in the MFMA
+//                 B-operand layout, A*X as MFMA with the SHARED human rows as A operand plus a
+//                 rank-1 update for the per-child robot row, *W by MFMA with W in registers,
+//                 relu (+skip); node features staged in wave-private LDS; the last layer needs
+//                 only the robot node: t_c = A_c[0,:] * H_c  (wave-level reduction)
+//   stage 2  robot_head_kernel     : h = relu(t*W_last) (+skip), value head; one register-resident
+//                 MFMA chain per 16 children, weights as pre-permuted A fragments in LDS.
+//
+// f32 MFMA (v_mfma_f32_16x16x4_f32) is exact fp32 at the vector-FMA rate; results differ from the
+// general kernel only by summation order.  Anything outside the envelope above falls back to the
+// general kernel (same numbers, lower speed) -- never to the CPU.
+//
+// Follows (reference paths): crowd_nav/policy/graph_model.py:99-130, value_estimator.py:11-20,
+// model_predictive_rl.py:245-250 (the loop whose iterations these kernels run side by side).
 #include "rgl_common.h"
+
+#include <cstdlib>
 
 namespace rgl {
 int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
                            const float* robot, const float* humans, int n_scenes, int scenes_per_crowd, int H,
                            float* H_out, float* A_out, float* value_out, float* humans_next, hipStream_t stream);
+}
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XD = 32;    // x_dim
+constexpr int HID = 64;   // embedding hidden width
+constexpr int XLD = 36;   // LDS row stride of 32-wide feature rows (16-byte aligned, bank-skewed)
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+// Compiler-only fence: stops hipcc from hoisting every operand-fragment load of a long unrolled MFMA
+// chain to the top (which costs hundreds of VGPRs); each k-group loads its fragments right before use.
+__device__ __forceinline__ void load_fence() { asm volatile("" ::: "memory"); }
+
+// ------------------------------------------------------------------------------------------------
+// stage 1
+// ------------------------------------------------------------------------------------------------
+struct ChildArgs {
+    const float *wr1, *br1, *wr2, *br2;   // robot embedding, k-major: [9][64], [64], [64][32], [32]
+    const float *wh1, *bh1, *wh2, *bh2;   // human embedding:          [5][64], [64], [64][32], [32]
+    const float* wa;                      // [32][32]
+    const float* Ws[RGL_MAX_GCN_LAYERS];  // [32][32] each; the LAST layer's weight is applied in stage 2
+    int L, skip;
+    const float* child_robot;             // [P][A][9]
+    const float* humans;                  // [P][H][5]
+    int P, A, H;
+    float* rows_out;                      // [P*A][64] = [ t_c (32) | H_{L-1}[robot] (32) ]
+    // derived layout
+    int N, SLD, NT, CT, CPC, G, tiles_per_group, n_groups, GC;
+    int off_xh, off_gm, off_shh, off_s0, off_sc0, off_x0, off_hid, off_wave, wave_stride, two_buffers;
+};
+
+template <int KS>
+__global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const ChildArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int N = a.N, H = a.H, A = a.A, SLD = a.SLD;
+    float* Xh = lds + a.off_xh;     // [16*NT][XLD]  node-indexed, rows 0 and >= N are zero
+    float* Gm = lds + a.off_gm;     // [16*NT][XLD]
+    float* Shh = lds + a.off_shh;   // [N][SLD]      node-indexed, columns >= N are -inf
+    float* S0 = lds + a.off_s0;     // [16*CT][SLD]  S_c[0][j]
+    float* Sc0 = lds + a.off_sc0;   // [16*CT][SLD]  S_c[i][0]
+    float* X0 = lds + a.off_x0;     // [16*CT][XLD]  robot embedding of every child
+    float* hid = lds + a.off_hid;   // [H][HID]
+    float* Hw = lds + a.off_wave + wave * a.wave_stride;     // [GC][XLD]   (x2 when L >= 3)
+    float* Hw2 = Hw + a.GC * XLD;
+    float* P0w = Hw + (a.two_buffers ? 2 : 1) * a.GC * XLD;   // [G][SLD]  robot-row attention of the group's children
+    const float NEG_INF = -INFINITY;
+
+    for (int p = blockIdx.x; p < a.P; p += gridDim.x) {
+        // ---------------- prologue: crowd-only quantities, shared by all children -----------------------
+        const float* hsrc = a.humans + (size_t)p * H * 5;
+        for (int idx = tid; idx < 16 * a.NT * XLD; idx += kThreads) { Xh[idx] = 0.f; Gm[idx] = 0.f; }
+        for (int idx = tid; idx < H * HID; idx += kThreads) {
+            const int j = idx / HID, u = idx - j * HID;
+            float acc = a.bh1[u];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc = fmaf(hsrc[j * 5 + k], a.wh1[k * HID + u], acc);
+            hid[idx] = fmaxf(acc, 0.f);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < H * XD; idx += kThreads) {
+            const int j = idx / XD, f = idx - j * XD;
+            float acc = a.bh2[f];
+            for (int u = 0; u < HID; ++u) acc = fmaf(hid[j * HID + u], a.wh2[u * XD + f], acc);
+            Xh[(j + 1) * XLD + f] = fmaxf(acc, 0.f);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < H * XD; idx += kThreads) {
+            const int j = idx / XD, g = idx - j * XD;
+            float acc = 0.f;
+            for (int f = 0; f < XD; ++f) acc = fmaf(Xh[(j + 1) * XLD + f], a.wa[f * XD + g], acc);
+            Gm[(j + 1) * XLD + g] = acc;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < N * SLD; idx += kThreads) {
+            const int i = idx / SLD, j = idx - i * SLD;
+            float v = NEG_INF;
+            if (i >= 1 && j >= 1 && j < N) {
+                v = 0.f;
+                for (int f = 0; f < XD; ++f) v = fmaf(Gm[i * XLD + f], Xh[j * XLD + f], v);
+            }
+            Shh[idx] = v;
+        }
+        // (no barrier needed before B1: it reads Xh/Gm, which were fenced above, and writes S0/Sc0/X0)
+
+        // ---------------- B1/B2: robot embedding and robot row/column of S for 16 children per pass -----
+        for (int ct = wave; ct < a.CT; ct += kWaves) {
+            const int c = 16 * ct + n;
+            const int cc = c < A ? c : A - 1;
+            const float* rr = a.child_robot + ((size_t)p * A + cc) * 9;
+            f32x4 hacc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int k = 4 * s + q;
+                const float b = k < 9 ? rr[k] : 0.f;
+#pragma unroll
+                for (int ht = 0; ht < 4; ++ht) {
+                    const float w = k < 9 ? a.wr1[k * HID + 16 * ht + n] : 0.f;
+                    hacc[ht] = mfma4(w, b, hacc[ht]);
+                }
+            }
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hacc[ht][r] = fmaxf(hacc[ht][r] + a.br1[16 * ht + 4 * q + r], 0.f);
+            f32x4 xacc[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot)
+                        xacc[ot] = mfma4(a.wr2[(16 * ht + 4 * q + r) * XD + 16 * ot + n], hacc[ht][r], xacc[ot]);
+            }
+            load_fence();
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xacc[ot][r] = fmaxf(xacc[ot][r] + a.br2[16 * ot + 4 * q + r], 0.f);
+                *reinterpret_cast<f32x4*>(&X0[c * XLD + 16 * ot + 4 * q]) = xacc[ot];
+            }
+            f32x4 gacc[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int gt = 0; gt < 2; ++gt)
+                        gacc[gt] = mfma4(a.wa[(16 * ot + 4 * q + r) * XD + 16 * gt + n], xacc[ot][r], gacc[gt]);
+            }
+            load_fence();
+            float s00 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s00 = fmaf(gacc[t][r], xacc[t][r], s00);
+            s00 += __shfl_xor(s00, 16);
+            s00 += __shfl_xor(s00, 32);
+            for (int nt = 0; nt < a.NT; ++nt) {
+                load_fence();
+                f32x4 sc = zero4(), s0 = zero4();
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    const f32x4 gq = *reinterpret_cast<const f32x4*>(&Gm[(16 * nt + n) * XLD + 16 * ot + 4 * q]);
+                    const f32x4 xq = *reinterpret_cast<const f32x4*>(&Xh[(16 * nt + n) * XLD + 16 * ot + 4 * q]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sc = mfma4(gq[r], xacc[ot][r], sc);    // S_c[node][0] = G[node] . x0_c
+                        s0 = mfma4(xq[r], gacc[ot][r], s0);    // S_c[0][node] = (x0_c Wa) . Xh[node]
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int node = 16 * nt + 4 * q + r;
+                    float vs = sc[r], v0 = s0[r];
+                    if (node == 0) { vs = s00; v0 = s00; }
+                    if (node >= N) { vs = NEG_INF; v0 = NEG_INF; }
+                    if (node < SLD) { Sc0[c * SLD + node] = vs; S0[c * SLD + node] = v0; }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---------------- B3: graph layers, G children per wave at a time --------------------------------
+        float xh_a[2][KS];   // A operand of (A_c X): A[i = feature][k <-> node j = 4s+q], shared by every child
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int j = 4 * s + q;
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) xh_a[ft][s] = (j >= 1 && j < N) ? Xh[j * XLD + 16 * ft + n] : 0.f;
+        }
+        float w_a[2][8];     // A operand of (. W_l): A[i = out feature][k <-> in feature 16ft+4q+r]
+        if (a.L >= 2) {
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+                    w_a[ot][kk] = a.Ws[0][(16 * (kk >> 2) + 4 * q + (kk & 3)) * XD + 16 * ot + n];
+        }
+        for (int g = wave; g < a.n_groups; g += kWaves) {
+            const int c0 = g * a.G;
+            const int Gv = (A - c0) < a.G ? (A - c0) : a.G;
+            const int cols = Gv * a.CPC;
+            float* cur = Hw;
+            float* nxt = Hw2;
+            for (int layer = 0; layer < (a.L >= 2 ? a.L - 1 : 1); ++layer) {
+                if (layer >= 1) {
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                        for (int kk = 0; kk < 8; ++kk)
+                            w_a[ot][kk] = a.Ws[layer][(16 * (kk >> 2) + 4 * q + (kk & 3)) * XD + 16 * ot + n];
+                }
+                for (int t = 0; t < a.tiles_per_group; ++t) {
+                    const int m = 16 * t + n;
+                    const bool valid = m < cols;
+                    const int cl = valid ? m / a.CPC : 0;
+                    const int i = valid ? m - cl * a.CPC : 0;
+                    const int c = c0 + cl;
+                    // similarity row of node i of child c, in B-operand order: lane (n,q) holds j = 4s+q
+                    const float* rowp = (i == 0) ? &S0[c * SLD] : &Shh[i * SLD];
+                    float v[KS];
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) v[s] = rowp[4 * s + q];
+                    if (i > 0 && q == 0) v[0] = Sc0[c * SLD + i];
+                    float mx = v[0];
+#pragma unroll
+                    for (int s = 1; s < KS; ++s) mx = fmaxf(mx, v[s]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    float sum = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        v[s] = __expf(v[s] - mx);
+                        sum += v[s];
+                    }
+                    sum += __shfl_xor(sum, 16);
+                    sum += __shfl_xor(sum, 32);
+                    const float inv = valid ? 1.0f / sum : 0.f;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) v[s] *= inv;
+                    if (layer == 0 && valid && i == 0) {
+#pragma unroll
+                        for (int s = 0; s < KS; ++s)
+                            if (4 * s + q < SLD) P0w[cl * SLD + 4 * s + q] = v[s];
+                    }
+                    if (a.L < 2) continue;
+                    f32x4 acc[2] = {zero4(), zero4()};
+                    f32x4 x0c[2];
+                    x0c[0] = *reinterpret_cast<const f32x4*>(&X0[c * XLD + 4 * q]);
+                    x0c[1] = *reinterpret_cast<const f32x4*>(&X0[c * XLD + 16 + 4 * q]);
+                    if (layer == 0) {
+                        // (A_c X_c)^T = Xh^T P  +  x0_c (x) P[robot column]
+#pragma unroll
+                        for (int s = 0; s < KS; ++s)
+#pragma unroll
+                            for (int ft = 0; ft < 2; ++ft) acc[ft] = mfma4(xh_a[ft][s], v[s], acc[ft]);
+                        const float p0 = __shfl(v[0], n);
+#pragma unroll
+                        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[ft][r] = fmaf(p0, x0c[ft][r], acc[ft][r]);
+                    } else {
+                        // deeper layers: every child has its own node features -> one masked pass per child in the tile
+                        const int first = (16 * t) / a.CPC;
+                        int lastc = (16 * t + 15 < cols ? 16 * t + 15 : cols - 1) / a.CPC;
+                        for (int cx = first; cx <= lastc; ++cx) {
+#pragma unroll
+                            for (int s = 0; s < KS; ++s) {
+                                const int j = 4 * s + q;
+                                const float b = (valid && cl == cx) ? v[s] : 0.f;
+#pragma unroll
+                                for (int ft = 0; ft < 2; ++ft) {
+                                    const float av = j < N ? cur[(cx * N + j) * XLD + 16 * ft + n] : 0.f;
+                                    acc[ft] = mfma4(av, b, acc[ft]);
+                                }
+                            }
+                        }
+                    }
+                    f32x4 o[2] = {zero4(), zero4()};
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int ot = 0; ot < 2; ++ot) o[ot] = mfma4(w_a[ot][4 * ft + r], acc[ft][r], o[ot]);
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot) {
+                        f32x4 sk;
+                        if (layer == 0) sk = (i == 0) ? x0c[ot] : *reinterpret_cast<const f32x4*>(&Xh[i * XLD + 16 * ot + 4 * q]);
+                        else sk = *reinterpret_cast<const f32x4*>(&cur[m * XLD + 16 * ot + 4 * q]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float hval = fmaxf(o[ot][r], 0.f);
+                            if (a.skip) hval += sk[r];
+                            o[ot][r] = hval;
+                        }
+                        float* dst = (layer == 0) ? Hw : nxt;
+                        *reinterpret_cast<f32x4*>(&dst[m * XLD + 16 * ot + 4 * q]) = o[ot];
+                    }
+                }
+                if (layer >= 1) { float* tmp = cur; cur = nxt; nxt = tmp; }
+            }
+            // last layer, robot node only:  t_c = sum_j A_c[0][j] * H_c[j],   plus H_c[0] for the skip connection
+            for (int cl = lane >> 5; cl < Gv; cl += 2) {
+                const int f = lane & 31;
+                const int c = c0 + cl;
+                float tsum = 0.f, hprev;
+                if (a.L >= 2) {
+                    for (int j = 0; j < N; ++j) tsum = fmaf(P0w[cl * SLD + j], cur[(cl * N + j) * XLD + f], tsum);
+                    hprev = cur[(cl * N) * XLD + f];
+                } else {
+                    hprev = X0[c * XLD + f];
+                    tsum = P0w[cl * SLD] * hprev;
+                    for (int j = 1; j < N; ++j) tsum = fmaf(P0w[cl * SLD + j], Xh[j * XLD + f], tsum);
+                }
+                float* out = a.rows_out + ((size_t)p * A + c) * 64;
+                out[f] = tsum;
+                out[32 + f] = hprev;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 2:  rows [t | hprev] -> value
+// ------------------------------------------------------------------------------------------------
+struct HeadArgs {
+    const float* w_last;          // [32][32] last GCN layer
+    const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;   // value head, k-major
+    int skip;
+    const float* rows;            // [M][64]
+    float* value;                 // [M]
+    int M, n_tiles;
+};
+
+template <int D>
+struct Tiles { static constexpr int v = (D + 15) / 16; };
+
+// A-fragment image of W (k-major [IN][OUT]) for the transposed product: fragment (ot, it, r), lane (i = l&15, q):
+//   W[in = 16*it + 4q + r][out = 16*ot + i]   (0 outside)
+template <int IN, int OUT>
+__device__ __forceinline__ void fill_frags(float* dst, const float* __restrict__ W, int tid) {
+    constexpr int IT = Tiles<IN>::v, OT = Tiles<OUT>::v;
+    for (int idx = tid; idx < OT * IT * 4 * 64; idx += kThreads) {
+        const int l = idx & 63, fr = idx >> 6;
+        const int r = fr & 3, it = (fr >> 2) % IT, ot = (fr >> 2) / IT;
+        const int in = 16 * it + 4 * (l >> 4) + r, out = 16 * ot + (l & 15);
+        dst[idx] = (in < IN && out < OUT) ? W[in * OUT + out] : 0.f;
+    }
+}
+
+template <int OUT>
+__device__ __forceinline__ void fill_bias(float* dst, const float* __restrict__ b, int tid) {
+    for (int idx = tid; idx < Tiles<OUT>::v * 16; idx += kThreads) dst[idx] = idx < OUT ? b[idx] : 0.f;
+}
+
+template <int IN, int OUT>
+__device__ __forceinline__ void layer_mfma(const float* frags, const f32x4 (&in)[Tiles<IN>::v], f32x4 (&out)[Tiles<OUT>::v],
+                                           int lane) {
+    constexpr int IT = Tiles<IN>::v, OT = Tiles<OUT>::v;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) out[ot] = zero4();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        load_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) out[ot] = mfma4(frags[((ot * IT + it) * 4 + r) * 64 + lane], in[it][r], out[ot]);
+    }
+    load_fence();
+}
+
+template <int OUT>
+__device__ __forceinline__ void bias_relu(const float* bias, f32x4 (&x)[Tiles<OUT>::v], int q) {
+#pragma unroll
+    for (int ot = 0; ot < Tiles<OUT>::v; ++ot) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * q]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[ot][r] = fmaxf(x[ot][r] + b[r], 0.f);
+    }
+}
+
+template <int D1, int D2, int D3>
+struct HeadLds {
+    static constexpr int f_last = 0;
+    static constexpr int f1 = f_last + 2 * 2 * 4 * 64;
+    static constexpr int f2 = f1 + Tiles<D1>::v * 2 * 4 * 64;
+    static constexpr int f3 = f2 + Tiles<D2>::v * Tiles<D1>::v * 4 * 64;
+    static constexpr int b1 = f3 + Tiles<D3>::v * Tiles<D2>::v * 4 * 64;
+    static constexpr int b2 = b1 + Tiles<D1>::v * 16;
+    static constexpr int b3 = b2 + Tiles<D2>::v * 16;
+    static constexpr int w4 = b3 + Tiles<D3>::v * 16;
+    static constexpr int total = w4 + Tiles<D3>::v * 16;
+};
+
+template <int D1, int D2, int D3>
+__global__ __launch_bounds__(kThreads, 2) void robot_head_kernel(const HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using LO = HeadLds<D1, D2, D3>;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    fill_frags<XD, XD>(lds + LO::f_last, a.w_last, tid);
+    fill_frags<XD, D1>(lds + LO::f1, a.w1, tid);
+    fill_frags<D1, D2>(lds + LO::f2, a.w2, tid);
+    fill_frags<D2, D3>(lds + LO::f3, a.w3, tid);
+    fill_bias<D1>(lds + LO::b1, a.b1, tid);
+    fill_bias<D2>(lds + LO::b2, a.b2, tid);
+    fill_bias<D3>(lds + LO::b3, a.b3, tid);
+    fill_bias<D3>(lds + LO::w4, a.w4, tid);      // w4 is [D3][1]: same padded vector layout as a bias
+    __syncthreads();
+    const float b4 = a.b4[0];
+    for (int tile = blockIdx.x * kWaves + wave; tile < a.n_tiles; tile += gridDim.x * kWaves) {
+        const int row = 16 * tile + n;
+        const int rc = row < a.M ? row : a.M - 1;
+        const float* src = a.rows + (size_t)rc * 64;
+        f32x4 tin[2], hp[2];
+        tin[0] = *reinterpret_cast<const f32x4*>(src + 4 * q);
+        tin[1] = *reinterpret_cast<const f32x4*>(src + 16 + 4 * q);
+        hp[0] = *reinterpret_cast<const f32x4*>(src + 32 + 4 * q);
+        hp[1] = *reinterpret_cast<const f32x4*>(src + 48 + 4 * q);
+        f32x4 h[2];
+        layer_mfma<XD, XD>(lds + LO::f_last, tin, h, lane);
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = fmaxf(h[ot][r], 0.f);
+                if (a.skip) x += hp[ot][r];
+                h[ot][r] = x;
+            }
+        f32x4 a1[Tiles<D1>::v];
+        layer_mfma<XD, D1>(lds + LO::f1, h, a1, lane);
+        bias_relu<D1>(lds + LO::b1, a1, q);
+        f32x4 a2[Tiles<D2>::v];
+        layer_mfma<D1, D2>(lds + LO::f2, a1, a2, lane);
+        bias_relu<D2>(lds + LO::b2, a2, q);
+        f32x4 a3[Tiles<D3>::v];
+        layer_mfma<D2, D3>(lds + LO::f3, a2, a3, lane);
+        bias_relu<D3>(lds + LO::b3, a3, q);
+        float v = 0.f;
+#pragma unroll
+        for (int ot = 0; ot < Tiles<D3>::v; ++ot) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(&lds[LO::w4 + 16 * ot + 4 * q]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v = fmaf(a3[ot][r], w[r], v);
+        }
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (q == 0 && row < a.M) a.value[row] = v + b4;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+inline bool mlp_is(const RglMlp& m, int d0, int d1, int d2, bool last_relu) {
+    return m.n_layers == 2 && m.dims[0] == d0 && m.dims[1] == d1 && m.dims[2] == d2 && (m.last_relu != 0) == last_relu;
+}
+
+inline int head_variant(const RglMlp& h) {
+    if (h.n_layers != 4 || h.last_relu || h.dims[0] != XD || h.dims[4] != 1) return -1;
+    if (h.dims[1] == 32 && h.dims[2] == 100 && h.dims[3] == 100) return 0;     // ValueEstimator default
+    if (h.dims[1] == 150 && h.dims[2] == 100 && h.dims[3] == 100) return 1;    // gcn.ValueNetwork default
+    return -1;
+}
+
+inline bool fast_path_enabled() {
+    static const bool off = [] { const char* e = getenv("RGL_FORCE_GENERIC"); return e && e[0] == '1'; }();
+    return !off;
+}
+
+struct ChildPlan {
+    ChildArgs a;
+    int ks_bucket;
+    size_t lds_bytes;
+    bool ok;
+};
+
+inline ChildPlan plan_children(const RglGraph& g, int P, int A, int H) {
+    ChildPlan pl;
+    pl.ok = false;
+    if (!fast_path_enabled()) return pl;
+    if (g.similarity != RGL_SIM_EMBEDDED_GAUSSIAN || g.layerwise_graph || g.x_dim != XD) return pl;
+    if (g.num_layer < 1 || !mlp_is(g.w_r, 9, HID, XD, true) || !mlp_is(g.w_h, 5, HID, XD, true)) return pl;
+    const int N = H + 1;
+    if (N > 64 || A > 96 || A < 1) return pl;
+    ChildArgs& a = pl.a;
+    a.N = N;
+    const int ks = (N + 3) / 4;
+    pl.ks_bucket = ks <= 2 ? 2 : ks <= 5 ? 5 : ks <= 8 ? 8 : ks <= 13 ? 13 : 16;
+    a.SLD = 4 * pl.ks_bucket + 1;
+    a.NT = (N + 15) / 16;
+    a.CT = (A + 15) / 16;
+    a.L = g.num_layer;
+    a.skip = g.skip_connection;
+    a.CPC = a.L >= 2 ? N : 1;
+    // children per group: complete tiles when possible, bounded wave-private staging
+    int G;
+    if (a.CPC == 1) G = 16;
+    else {
+        int gcd = 16, x = N;
+        while (x) { int tmp = gcd % x; gcd = x; x = tmp; }
+        G = 16 / gcd;                                   // smallest G with G*N % 16 == 0
+        while (G > 1 && ((G * N + 15) / 16) * 16 * XLD * (a.L >= 3 ? 2 : 1) > 6144) G = (G + 1) / 2;   // <= 24 KiB per wave
+    }
+    a.G = G;
+    a.tiles_per_group = (G * a.CPC + 15) / 16;
+    a.GC = a.tiles_per_group * 16;
+    a.n_groups = (A + G - 1) / G;
+    a.two_buffers = a.L >= 3 ? 1 : 0;
+    int off = 0;
+    auto take = [&](int nfl) { int o = off; off += (nfl + 3) & ~3; return o; };
+    a.off_xh = take(16 * a.NT * XLD);
+    a.off_gm = take(16 * a.NT * XLD);
+    a.off_shh = take(N * a.SLD);
+    a.off_s0 = take(16 * a.CT * a.SLD);
+    a.off_sc0 = take(16 * a.CT * a.SLD);
+    a.off_x0 = take(16 * a.CT * XLD);
+    a.off_hid = take(H * HID);
+    a.wave_stride = (((a.two_buffers ? 2 : 1) * a.GC * XLD + G * a.SLD) + 3) & ~3;
+    a.off_wave = take(kWaves * a.wave_stride);
+    pl.lds_bytes = (size_t)off * sizeof(float);
+    if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
+    a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];
+    a.wh1 = g.w_h.weight[0]; a.bh1 = g.w_h.bias[0]; a.wh2 = g.w_h.weight[1]; a.bh2 = g.w_h.bias[1];
+    a.wa = g.w_a;
+    for (int l = 0; l < RGL_MAX_GCN_LAYERS; ++l) a.Ws[l] = l < g.num_layer ? g.Ws[l] : nullptr;
+    a.P = P; a.A = A; a.H = H;
+    pl.ok = true;
+    return pl;
+}
+
+template <int KS>
+int launch_children(const ChildPlan& pl, hipStream_t st) {
+    auto kern = children_graph_kernel<KS>;
+    if (pl.lds_bytes > 64 * 1024)
+        RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)pl.lds_bytes));
+    const int grid = pl.a.P < 256 * 16 ? pl.a.P : 256 * 16;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), pl.lds_bytes, st, pl.a);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
+template <int D1, int D2, int D3>
+int launch_head(const HeadArgs& ha, hipStream_t st) {
+    auto kern = robot_head_kernel<D1, D2, D3>;
+    const size_t lds_bytes = (size_t)HeadLds<D1, D2, D3>::total * sizeof(float);
+    if (lds_bytes > 64 * 1024)
+        RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_bytes));
+    int grid = (ha.n_tiles + kWaves - 1) / kWaves;
+    const int cap = lds_bytes > 80 * 1024 ? 256 : 512;          // resident workgroups: 1 or 2 per CU
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, st, ha);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
+}  // namespace
+
+namespace rgl {
+
+size_t value_children_workspace_bytes(const MprlPlanner* pl, int P, int H) {
+    return (size_t)P * pl->num_actions * 64 * sizeof(float);
+}
 
 // V(child) for the A children of each of P parents; children of one parent share humans_next[p].
 int launch_value_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
-                          float* child_value, hipStream_t stream) {
-    return launch_generic_forward(&pl->value_graph, &pl->value_head, nullptr, child_robot, humans_next,
-                                  P * pl->num_actions, pl->num_actions, H, nullptr, nullptr, child_value, nullptr, stream);
+                          float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const int A = pl->num_actions;
+    ChildPlan cp = plan_children(pl->value_graph, P, A, H);
+    const int hv = head_variant(pl->value_head);
+    if (!cp.ok || hv < 0 || !workspace || workspace_bytes < value_children_workspace_bytes(pl, P, H)) {
+        return launch_generic_forward(&pl->value_graph, &pl->value_head, nullptr, child_robot, humans_next, P * A, A, H,
+                                      nullptr, nullptr, child_value, nullptr, stream);
+    }
+    cp.a.child_robot = child_robot;
+    cp.a.humans = humans_next;
+    cp.a.rows_out = (float*)workspace;
+    int rc;
+    switch (cp.ks_bucket) {
+        case 2: rc = launch_children<2>(cp, stream); break;
+        case 5: rc = launch_children<5>(cp, stream); break;
+        case 8: rc = launch_children<8>(cp, stream); break;
+        case 13: rc = launch_children<13>(cp, stream); break;
+        default: rc = launch_children<16>(cp, stream); break;
+    }
+    if (rc) return rc;
+    HeadArgs ha;
+    const RglGraph& g = pl->value_graph;
+    const RglMlp& h = pl->value_head;
+    ha.w_last = g.Ws[g.num_layer - 1];
+    ha.w1 = h.weight[0]; ha.b1 = h.bias[0];
+    ha.w2 = h.weight[1]; ha.b2 = h.bias[1];
+    ha.w3 = h.weight[2]; ha.b3 = h.bias[2];
+    ha.w4 = h.weight[3]; ha.b4 = h.bias[3];
+    ha.skip = g.skip_connection;
+    ha.rows = (const float*)workspace;
+    ha.value = child_value;
+    ha.M = P * A;
+    ha.n_tiles = (ha.M + 15) / 16;
+    return hv == 0 ? launch_head<32, 100, 100>(ha, stream) : launch_head<150, 100, 100>(ha, stream);
 }
+
 }  // namespace rgl

@@ -13,7 +13,8 @@ int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, cons
                            const float* robot, const float* humans, int n_scenes, int scenes_per_crowd, int H,
                            float* H_out, float* A_out, float* value_out, float* humans_next, hipStream_t stream);
 int launch_value_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
-                          float* child_value, hipStream_t stream);   // rgl_fast.hip (falls back to generic)
+                          float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream);   // rgl_fast.hip
+size_t value_children_workspace_bytes(const MprlPlanner* pl, int P, int H);
 }  // namespace rgl
 
 namespace {
@@ -382,7 +383,8 @@ struct LevelLayout {
 
 inline long long align_up(long long x) { return (x + 255) & ~255ll; }
 
-inline int plan_levels(const MprlPlanner& pl, int B, int H, LevelLayout* lv, long long* total) {
+inline int plan_levels(const MprlPlanner& pl, int B, int H, LevelLayout* lv, long long* total,
+                       long long* scratch_off = nullptr, long long* scratch_bytes = nullptr) {
     const int A = pl.num_actions, D = pl.planning_depth;
     const int W = pl.do_action_clip ? pl.planning_width : A;
     long long off = 0, P = B;
@@ -400,9 +402,14 @@ inline int plan_levels(const MprlPlanner& pl, int B, int H, LevelLayout* lv, lon
         L.backup = off;       off = align_up(off + P * W * 4);
         L.best_slot = off;    off = align_up(off + P * 4);
         if (l > 0) lv[l].humans = lv[l - 1].humans_next;
-        P *= W;
+        if (l + 1 < D) P *= W;
         if (P > (1ll << 31) / (A * 9)) return RGL_ERR_BAD_SHAPE;
     }
+    // hand-off buffer of the two-stage value kernels, sized for the widest (= deepest) level
+    const long long sb = (long long)rgl::value_children_workspace_bytes(&pl, (int)P, H);
+    if (scratch_off) *scratch_off = off;
+    if (scratch_bytes) *scratch_bytes = sb;
+    off = align_up(off + sb);
     *total = off;
     return RGL_OK;
 }
@@ -431,7 +438,8 @@ inline int validate_planner(const MprlPlanner& pl, int H) {
 
 // One level: steps 1-3 of the header comment of mprl_expand_f32.
 int expand_level(const MprlPlanner& pl, const float* robot, const float* humans, int humans_per, int P, int H, int joint,
-                 float* humans_next, float* child_robot, float* reward, float* child_value, hipStream_t st) {
+                 float* humans_next, float* child_robot, float* reward, float* child_value, void* scratch,
+                 size_t scratch_bytes, hipStream_t st) {
     const int A = pl.num_actions;
     if (pl.linear_state_predictor) {
         if (humans_per == 1) {
@@ -452,14 +460,15 @@ int expand_level(const MprlPlanner& pl, const float* robot, const float* humans,
     hipLaunchKernelGGL(mprl_children_kernel, grid_for((long long)P * A), dim3(kBlock), 0, st, robot, humans, humans_per,
                        pl.actions, P, H, A, pl.kinematics, pl.time_step, joint, child_robot, reward);
     RGL_LAUNCH_CHECK();
-    return rgl::launch_value_children(&pl, child_robot, humans_next, P, H, child_value, st);
+    return rgl::launch_value_children(&pl, child_robot, humans_next, P, H, child_value, scratch, scratch_bytes, st);
 }
 
 }  // namespace
 
 extern "C" int mprl_expand_f32(const MprlPlanner* planner, const float* robot, const float* humans, int P, int H,
                                int parents_are_joint_states, float* humans_next, float* child_robot, float* reward,
-                               float* child_value, float* value1, rgl_stream_t stream) {
+                               float* child_value, float* value1, void* workspace, size_t workspace_bytes,
+                               rgl_stream_t stream) {
     if (!planner || !robot || !humans || !humans_next || !child_robot || !reward || !child_value) return RGL_ERR_NULL;
     if (P < 0) return RGL_ERR_BAD_SHAPE;
     int rc = validate_planner(*planner, H);
@@ -467,7 +476,7 @@ extern "C" int mprl_expand_f32(const MprlPlanner* planner, const float* robot, c
     if (P == 0) return RGL_OK;
     hipStream_t st = (hipStream_t)stream;
     rc = expand_level(*planner, robot, humans, 1, P, H, parents_are_joint_states, humans_next, child_robot, reward,
-                      child_value, st);
+                      child_value, workspace, workspace_bytes, st);
     if (rc) return rc;
     if (value1) {
         const long long n = (long long)P * planner->num_actions;
@@ -478,14 +487,21 @@ extern "C" int mprl_expand_f32(const MprlPlanner* planner, const float* robot, c
     return RGL_OK;
 }
 
+extern "C" size_t mprl_value_children_workspace_bytes(const MprlPlanner* planner, int P, int H) {
+    if (!planner || P < 1 || H < 1) return 0;
+    return rgl::value_children_workspace_bytes(planner, P, H);
+}
+
 extern "C" int mprl_value_children_f32(const MprlPlanner* planner, const float* child_robot, const float* humans_next,
-                                       int P, int H, float* child_value, rgl_stream_t stream) {
+                                       int P, int H, float* child_value, void* workspace, size_t workspace_bytes,
+                                       rgl_stream_t stream) {
     if (!planner || !child_robot || !humans_next || !child_value) return RGL_ERR_NULL;
     if (P < 0) return RGL_ERR_BAD_SHAPE;
     int rc = validate_planner(*planner, H);
     if (rc) return rc;
     if (P == 0) return RGL_OK;
-    return rgl::launch_value_children(planner, child_robot, humans_next, P, H, child_value, (hipStream_t)stream);
+    return rgl::launch_value_children(planner, child_robot, humans_next, P, H, child_value, workspace, workspace_bytes,
+                                      (hipStream_t)stream);
 }
 
 extern "C" size_t mprl_tree_workspace_bytes(const MprlPlanner* planner, int B, int H) {
@@ -535,8 +551,8 @@ extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* rob
         if (W > 16) return RGL_ERR_BAD_MODE;
     }
     LevelLayout lv[8];
-    long long total = 0;
-    rc = plan_levels(pl, B, H, lv, &total);
+    long long total = 0, scratch_off = 0, scratch_bytes = 0;
+    rc = plan_levels(pl, B, H, lv, &total, &scratch_off, &scratch_bytes);
     if (rc) return rc;
     if ((long long)workspace_bytes < total) return RGL_ERR_WORKSPACE;
     char* ws = (char*)workspace;
@@ -551,7 +567,7 @@ extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* rob
         const int humans_per = l == 0 ? 1 : W;
         rc = expand_level(pl, pr, ph, humans_per, P, H, l == 0 ? roots_are_joint_states : 0,
                           (float*)(ws + L.humans_next), (float*)(ws + L.child_robot), (float*)(ws + L.reward),
-                          (float*)(ws + L.child_value), st);
+                          (float*)(ws + L.child_value), ws + scratch_off, (size_t)scratch_bytes, st);
         if (rc) return rc;
         float* next_robot = l + 1 < D ? (float*)(ws + lv[l + 1].robot) : nullptr;
         hipLaunchKernelGGL(mprl_select_kernel, grid_for(P, 64), dim3(64), 0, st, (const float*)(ws + L.reward),

@@ -45,6 +45,7 @@ class TreeSearch:
         self.sparse_search = bool(sparse_search)
         self._dev_tables = {}
         self._ws = _Workspace()
+        self._ws2 = _Workspace()    # hand-off buffer of the stand-alone expand / value_children calls
         self.last = None            # outputs of the most recent search (device tensors)
 
     # -- descriptors -----------------------------------------------------------------------------
@@ -140,10 +141,12 @@ class TreeSearch:
              "value1": torch.empty(P, A, device=dev)}
         with torch.cuda.device(dev):
             pl = self.planner(dev)
+            ws = self._ws2.get(nat.lib().mprl_value_children_workspace_bytes(C.byref(pl), P, H), dev)
             rc = nat.lib().mprl_expand_f32(C.byref(pl), robot.data_ptr(), humans.data_ptr(), P, H,
                                            int(parents_are_joint_states), o["humans_next"].data_ptr(),
                                            o["child_robot"].data_ptr(), o["reward"].data_ptr(),
-                                           o["child_value"].data_ptr(), o["value1"].data_ptr(), _stream())
+                                           o["child_value"].data_ptr(), o["value1"].data_ptr(), ws.data_ptr(),
+                                           ws.numel(), _stream())
         nat.check(rc, "mprl_expand_f32")
         return o
 
@@ -157,8 +160,9 @@ class TreeSearch:
             out = torch.empty(P, self.num_actions, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
             pl = self.planner(dev)
+            ws = self._ws2.get(nat.lib().mprl_value_children_workspace_bytes(C.byref(pl), P, H), dev)
             rc = nat.lib().mprl_value_children_f32(C.byref(pl), child_robot.data_ptr(), humans_next.data_ptr(), P, H,
-                                                   out.data_ptr(), _stream())
+                                                   out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
         nat.check(rc, "mprl_value_children_f32")
         return out
 

@@ -190,6 +190,34 @@ def test_checkpoint_roundtrip(dev, tmp_path):
     assert torch.equal(a1, a2) and torch.equal(v1, v2)       # cache invalidation on load_state_dict works
 
 
+@pytest.mark.parametrize("H,L,flavour,skip,P", [(19, 2, "trained", True, 5), (19, 2, "rand", True, 3), (5, 2, "trained", True, 7),
+                                                 (4, 2, "trained", False, 4), (1, 2, "trained", True, 3),
+                                                 (19, 1, "trained", True, 4), (19, 3, "trained", True, 3),
+                                                 (49, 3, "trained", True, 2), (49, 2, "rand", False, 2),
+                                                 (63, 2, "trained", True, 2), (30, 3, "rand", True, 2),
+                                                 (7, 3, "trained", False, 5)])
+def test_value_children_mfma_path_vs_general_kernel(H, L, flavour, skip, P, dev):
+    """The two-stage MFMA path (mprl_value_children_f32) against the general kernel (module forward)
+    and the oracle, on children that share their crowd exactly like the rollout's siblings."""
+    pol = make_mprl_policy(flavour, 1, L=L, skip=skip, device=dev)
+    pol.build_action_space(1.0)
+    ts = pol.tree_search()
+    A = ts.num_actions
+    robot, humans = seeded_scenes(300 + H + L, P, H)
+    acts, _ = orc.mprl_action_space(orc.OracleConfig(), 1.0)
+    cr = orc._children_robot(robot, acts, orc.OracleConfig())                  # (P,A,9)
+    got = ts.value_children(cr.to(dev), humans.to(dev)).cpu()
+    with torch.no_grad():
+        general = pol.value_estimator((cr.reshape(P * A, 1, 9).to(dev),
+                                       humans[:, None].expand(P, A, H, 5).reshape(P * A, H, 5).contiguous().to(dev)))
+        cfg = orc.OracleConfig(num_layer=L, skip_connection=skip)
+        Pm = gio.oracle_params(flavour, L)
+        want = orc.value_estimator_forward(cr.reshape(P * A, 1, 9), humans[:, None].expand(P, A, H, 5).reshape(P * A, H, 5),
+                                           Pm.ve_graph, Pm.value_network, cfg)
+    close(general.cpu().numpy().reshape(P, A), want.numpy().reshape(P, A))
+    close(got.numpy(), want.numpy().reshape(P, A))
+
+
 # ---------------------------------------------------------------------------------------------------
 # larger seeded batches against the batched oracle
 # ---------------------------------------------------------------------------------------------------
