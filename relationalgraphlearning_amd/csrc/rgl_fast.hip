@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
             float* cur = Hw;
             float* nxt = Hw2;
             for (int layer = 0; layer < (a.L >= 2 ? a.L - 1 : 1); ++layer) {
-                if (layer >= 1) {
+                if (a.L >= 3 && (layer >= 1 || g != wave)) {     // more than one full layer: the registers rotate
 #pragma unroll
                     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
