@@ -55,19 +55,25 @@ __device__ __forceinline__ void load_fence() { asm volatile("" ::: "memory"); }
 // ------------------------------------------------------------------------------------------------
 // stage 1
 // ------------------------------------------------------------------------------------------------
+constexpr int WLD = 36;    // LDS row stride of the 32-column weight images (k-major); 4*WLD % 32 == 16 keeps the
+                           // four 16-lane k-groups of an MFMA A-operand read on disjoint banks
+constexpr int W1LD = 80;   // same for the 64-column image of wr1 (rows differ by 1 between k-groups)
+
 struct ChildArgs {
     const float *wr1, *br1, *wr2, *br2;   // robot embedding, k-major: [9][64], [64], [64][32], [32]
     const float *wh1, *bh1, *wh2, *bh2;   // human embedding:          [5][64], [64], [64][32], [32]
     const float* wa;                      // [32][32]
     const float* Ws[RGL_MAX_GCN_LAYERS];  // [32][32] each; the LAST layer's weight is applied in stage 2
     int L, skip;
+    int mode;                             // 1: L == 1   2: L == 2 (streamed robot-row aggregation)   3: L >= 3 (staged)
     const float* child_robot;             // [P][A][9]
     const float* humans;                  // [P][H][5]
     int P, A, H;
     float* rows_out;                      // [P*A][64] = [ t_c (32) | H_{L-1}[robot] (32) ]
-    // derived layout
+    // derived layout (float offsets into LDS)
     int N, SLD, NT, CT, CPC, G, tiles_per_group, n_groups, GC;
-    int off_xh, off_gm, off_shh, off_s0, off_sc0, off_x0, off_hid, off_wave, wave_stride, two_buffers;
+    int off_wh1, off_bh1, off_wh2, off_bh2, off_wa, off_wr1, off_br1, off_wr2, off_br2;   // persistent weight image
+    int off_xh, off_shh, off_s0, off_sc0, off_x0, off_wave, wave_stride;                  // per-parent data
 };
 
 template <int KS>
@@ -77,17 +83,54 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
     const int lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
     const int N = a.N, H = a.H, A = a.A, SLD = a.SLD;
+    const float* wh1 = lds + a.off_wh1;   // [5][HID]
+    const float* bh1 = lds + a.off_bh1;
+    const float* wh2 = lds + a.off_wh2;   // [HID][WLD]
+    const float* bh2 = lds + a.off_bh2;
+    const float* wa = lds + a.off_wa;     // [XD][WLD]
+    const float* wr1 = lds + a.off_wr1;   // [12][W1LD], rows 9..11 zero
+    const float* br1 = lds + a.off_br1;
+    const float* wr2 = lds + a.off_wr2;   // [HID][WLD]
+    const float* br2 = lds + a.off_br2;
     float* Xh = lds + a.off_xh;     // [16*NT][XLD]  node-indexed, rows 0 and >= N are zero
-    float* Gm = lds + a.off_gm;     // [16*NT][XLD]
     float* Shh = lds + a.off_shh;   // [N][SLD]      node-indexed, columns >= N are -inf
     float* S0 = lds + a.off_s0;     // [16*CT][SLD]  S_c[0][j]
     float* Sc0 = lds + a.off_sc0;   // [16*CT][SLD]  S_c[i][0]
     float* X0 = lds + a.off_x0;     // [16*CT][XLD]  robot embedding of every child
-    float* hid = lds + a.off_hid;   // [H][HID]
-    float* Hw = lds + a.off_wave + wave * a.wave_stride;     // [GC][XLD]   (x2 when L >= 3)
-    float* Hw2 = Hw + a.GC * XLD;
-    float* P0w = Hw + (a.two_buffers ? 2 : 1) * a.GC * XLD;   // [G][SLD]  robot-row attention of the group's children
+    float* hid = X0;                // [H][HID]      (prologue only; dead before X0 is written)
+    float* Gm = lds + a.off_wave;   // [16*NT][XLD]  (prologue + B1/B2 only; the wave-private area is idle until B3)
+    float* wbase = lds + a.off_wave + wave * a.wave_stride;
+    // wave-private area, by mode:   2: buf[16][XLD] | Tacc[G][32] | Hprev[G][32] | P0w[G][SLD]
+    //                               3: Hw[GC][XLD] | Hw2[GC][XLD] | P0w[G][SLD]          1: P0w[16][SLD]
+    float* buf = wbase;
+    float* Tacc = wbase + 16 * XLD;
+    float* Hprev = Tacc + a.G * 32;
+    float* Hw = wbase;
+    float* Hw2 = wbase + a.GC * XLD;
+    float* P0w = a.mode == 2 ? Hprev + a.G * 32 : (a.mode == 3 ? wbase + 2 * a.GC * XLD : wbase);
     const float NEG_INF = -INFINITY;
+
+    // ---------------- once per workgroup: weight image ------------------------------------------------
+    {
+        float* w = lds;
+        for (int i = tid; i < 5 * HID; i += kThreads) w[a.off_wh1 + i] = a.wh1[i];
+        for (int i = tid; i < HID; i += kThreads) { w[a.off_bh1 + i] = a.bh1[i]; w[a.off_br1 + i] = a.br1[i]; }
+        for (int i = tid; i < XD; i += kThreads) { w[a.off_bh2 + i] = a.bh2[i]; w[a.off_br2 + i] = a.br2[i]; }
+        for (int i = tid; i < HID * XD; i += kThreads) {
+            const int r = i / XD, c = i - r * XD;
+            w[a.off_wh2 + r * WLD + c] = a.wh2[i];
+            w[a.off_wr2 + r * WLD + c] = a.wr2[i];
+        }
+        for (int i = tid; i < XD * XD; i += kThreads) {
+            const int r = i / XD, c = i - r * XD;
+            w[a.off_wa + r * WLD + c] = a.wa[i];
+        }
+        for (int i = tid; i < 12 * HID; i += kThreads) {
+            const int r = i / HID, c = i - r * HID;
+            w[a.off_wr1 + r * W1LD + c] = r < 9 ? a.wr1[i] : 0.f;
+        }
+    }
+    __syncthreads();
 
     for (int p = blockIdx.x; p < a.P; p += gridDim.x) {
         // ---------------- prologue: crowd-only quantities, shared by all children -----------------------
@@ -95,23 +138,25 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
         for (int idx = tid; idx < 16 * a.NT * XLD; idx += kThreads) { Xh[idx] = 0.f; Gm[idx] = 0.f; }
         for (int idx = tid; idx < H * HID; idx += kThreads) {
             const int j = idx / HID, u = idx - j * HID;
-            float acc = a.bh1[u];
+            float acc = bh1[u];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) acc = fmaf(hsrc[j * 5 + k], a.wh1[k * HID + u], acc);
+            for (int k = 0; k < 5; ++k) acc = fmaf(hsrc[j * 5 + k], wh1[k * HID + u], acc);
             hid[idx] = fmaxf(acc, 0.f);
         }
         __syncthreads();
         for (int idx = tid; idx < H * XD; idx += kThreads) {
             const int j = idx / XD, f = idx - j * XD;
-            float acc = a.bh2[f];
-            for (int u = 0; u < HID; ++u) acc = fmaf(hid[j * HID + u], a.wh2[u * XD + f], acc);
+            float acc = bh2[f];
+#pragma unroll 8
+            for (int u = 0; u < HID; ++u) acc = fmaf(hid[j * HID + u], wh2[u * WLD + f], acc);
             Xh[(j + 1) * XLD + f] = fmaxf(acc, 0.f);
         }
         __syncthreads();
         for (int idx = tid; idx < H * XD; idx += kThreads) {
             const int j = idx / XD, g = idx - j * XD;
             float acc = 0.f;
-            for (int f = 0; f < XD; ++f) acc = fmaf(Xh[(j + 1) * XLD + f], a.wa[f * XD + g], acc);
+#pragma unroll 8
+            for (int f = 0; f < XD; ++f) acc = fmaf(Xh[(j + 1) * XLD + f], wa[f * WLD + g], acc);
             Gm[(j + 1) * XLD + g] = acc;
         }
         __syncthreads();
@@ -120,11 +165,13 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
             float v = NEG_INF;
             if (i >= 1 && j >= 1 && j < N) {
                 v = 0.f;
+#pragma unroll 8
                 for (int f = 0; f < XD; ++f) v = fmaf(Gm[i * XLD + f], Xh[j * XLD + f], v);
             }
             Shh[idx] = v;
         }
-        // (no barrier needed before B1: it reads Xh/Gm, which were fenced above, and writes S0/Sc0/X0)
+        // (no barrier needed before B1: it reads Xh/Gm, which were fenced above, and writes S0/Sc0/X0;
+        //  X0 aliases `hid`, whose last readers finished before the barrier after the Xh loop)
 
         // ---------------- B1/B2: robot embedding and robot row/column of S for 16 children per pass -----
         for (int ct = wave; ct < a.CT; ct += kWaves) {
@@ -137,15 +184,14 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
                 const int k = 4 * s + q;
                 const float b = k < 9 ? rr[k] : 0.f;
 #pragma unroll
-                for (int ht = 0; ht < 4; ++ht) {
-                    const float w = k < 9 ? a.wr1[k * HID + 16 * ht + n] : 0.f;
-                    hacc[ht] = mfma4(w, b, hacc[ht]);
-                }
+                for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wr1[k * W1LD + 16 * ht + n], b, hacc[ht]);
             }
 #pragma unroll
-            for (int ht = 0; ht < 4; ++ht)
+            for (int ht = 0; ht < 4; ++ht) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&br1[16 * ht + 4 * q]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hacc[ht][r] = fmaxf(hacc[ht][r] + a.br1[16 * ht + 4 * q + r], 0.f);
+                for (int r = 0; r < 4; ++r) hacc[ht][r] = fmaxf(hacc[ht][r] + bb[r], 0.f);
+            }
             f32x4 xacc[2] = {zero4(), zero4()};
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) {
@@ -154,13 +200,14 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int ot = 0; ot < 2; ++ot)
-                        xacc[ot] = mfma4(a.wr2[(16 * ht + 4 * q + r) * XD + 16 * ot + n], hacc[ht][r], xacc[ot]);
+                        xacc[ot] = mfma4(wr2[(16 * ht + 4 * q + r) * WLD + 16 * ot + n], hacc[ht][r], xacc[ot]);
             }
             load_fence();
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&br2[16 * ot + 4 * q]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xacc[ot][r] = fmaxf(xacc[ot][r] + a.br2[16 * ot + 4 * q + r], 0.f);
+                for (int r = 0; r < 4; ++r) xacc[ot][r] = fmaxf(xacc[ot][r] + bb[r], 0.f);
                 *reinterpret_cast<f32x4*>(&X0[c * XLD + 16 * ot + 4 * q]) = xacc[ot];
             }
             f32x4 gacc[2] = {zero4(), zero4()};
@@ -171,7 +218,7 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int gt = 0; gt < 2; ++gt)
-                        gacc[gt] = mfma4(a.wa[(16 * ot + 4 * q + r) * XD + 16 * gt + n], xacc[ot][r], gacc[gt]);
+                        gacc[gt] = mfma4(wa[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], gacc[gt]);
             }
             load_fence();
             float s00 = 0.f;
@@ -204,7 +251,7 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
                 }
             }
         }
-        __syncthreads();
+        __syncthreads();      // Gm is dead from here on: its storage becomes the wave-private area
 
         // ---------------- B3: graph layers, G children per wave at a time --------------------------------
         float xh_a[2][KS];   // A operand of (A_c X): A[i = feature][k <-> node j = 4s+q], shared by every child
@@ -228,6 +275,8 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
             const int cols = Gv * a.CPC;
             float* cur = Hw;
             float* nxt = Hw2;
+            if (a.mode == 2)
+                for (int idx = lane; idx < a.G * 32; idx += 64) Tacc[idx] = 0.f;
             for (int layer = 0; layer < (a.L >= 2 ? a.L - 1 : 1); ++layer) {
                 if (a.L >= 3 && (layer >= 1 || g != wave)) {     // more than one full layer: the registers rotate
 #pragma unroll
@@ -309,6 +358,7 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
                         for (int r = 0; r < 4; ++r)
 #pragma unroll
                             for (int ot = 0; ot < 2; ++ot) o[ot] = mfma4(w_a[ot][4 * ft + r], acc[ft][r], o[ot]);
+                    float* dst = a.mode == 2 ? buf + n * XLD : ((layer == 0 ? Hw : nxt) + m * XLD);
 #pragma unroll
                     for (int ot = 0; ot < 2; ++ot) {
                         f32x4 sk;
@@ -320,8 +370,34 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
                             if (a.skip) hval += sk[r];
                             o[ot][r] = hval;
                         }
-                        float* dst = (layer == 0) ? Hw : nxt;
-                        *reinterpret_cast<f32x4*>(&dst[m * XLD + 16 * ot + 4 * q]) = o[ot];
+                        *reinterpret_cast<f32x4*>(&dst[16 * ot + 4 * q]) = o[ot];
+                    }
+                    if (a.mode == 2) {
+                        // stream the robot-row aggregation t_c += A_c[0][i] * H_c[i]: each half-wave walks 8 of the
+                        // tile's 16 columns with a register accumulator per feature, flushed when the child changes
+                        const int f = lane & 31, hh = lane >> 5;
+                        int mm = 16 * t + 8 * hh;
+                        int ccl = mm / N, ii = mm - ccl * N;
+                        float accv = 0.f;
+                        int cur_cl = ccl;
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) {
+                            if (mm < cols) {
+                                if (ccl != cur_cl) {
+                                    atomicAdd(&Tacc[cur_cl * 32 + f], accv);
+                                    accv = 0.f;
+                                    cur_cl = ccl;
+                                }
+                                const float hv = buf[(8 * hh + it) * XLD + f];
+                                accv = fmaf(P0w[ccl * SLD + ii], hv, accv);
+                                if (ii == 0) Hprev[ccl * 32 + f] = hv;
+                            }
+                            ++mm;
+                            if (++ii == N) { ii = 0; ++ccl; }
+                        }
+                        // two separately masked flushes: lanes f and f+32 may target the same word, keep a fixed order
+                        if (hh == 0 && 16 * t < cols) atomicAdd(&Tacc[cur_cl * 32 + f], accv);
+                        if (hh == 1 && 16 * t + 8 < cols) atomicAdd(&Tacc[cur_cl * 32 + f], accv);
                     }
                 }
                 if (layer >= 1) { float* tmp = cur; cur = nxt; nxt = tmp; }
@@ -331,7 +407,10 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
                 const int f = lane & 31;
                 const int c = c0 + cl;
                 float tsum = 0.f, hprev;
-                if (a.L >= 2) {
+                if (a.mode == 2) {
+                    tsum = Tacc[cl * 32 + f];
+                    hprev = Hprev[cl * 32 + f];
+                } else if (a.mode == 3) {
                     for (int j = 0; j < N; ++j) tsum = fmaf(P0w[cl * SLD + j], cur[(cl * N + j) * XLD + f], tsum);
                     hprev = cur[(cl * N) * XLD + f];
                 } else {
@@ -521,32 +600,47 @@ inline ChildPlan plan_children(const RglGraph& g, int P, int A, int H) {
     a.CT = (A + 15) / 16;
     a.L = g.num_layer;
     a.skip = g.skip_connection;
+    a.mode = a.L == 1 ? 1 : (a.L == 2 ? 2 : 3);
     a.CPC = a.L >= 2 ? N : 1;
-    // children per group: complete tiles when possible, bounded wave-private staging
+    // children per group: complete tiles when possible (G*N % 16 == 0), bounded wave-private storage
     int G;
     if (a.CPC == 1) G = 16;
     else {
         int gcd = 16, x = N;
         while (x) { int tmp = gcd % x; gcd = x; x = tmp; }
-        G = 16 / gcd;                                   // smallest G with G*N % 16 == 0
-        while (G > 1 && ((G * N + 15) / 16) * 16 * XLD * (a.L >= 3 ? 2 : 1) > 6144) G = (G + 1) / 2;   // <= 24 KiB per wave
+        G = 16 / gcd;
+        if (a.mode == 3)
+            while (G > 1 && ((G * N + 15) / 16) * 16 * XLD * 2 > 6144) G = (G + 1) / 2;   // staged layers: <= 24 KiB per wave
     }
     a.G = G;
     a.tiles_per_group = (G * a.CPC + 15) / 16;
     a.GC = a.tiles_per_group * 16;
     a.n_groups = (A + G - 1) / G;
-    a.two_buffers = a.L >= 3 ? 1 : 0;
     int off = 0;
     auto take = [&](int nfl) { int o = off; off += (nfl + 3) & ~3; return o; };
+    a.off_wh1 = take(5 * HID);
+    a.off_bh1 = take(HID);
+    a.off_wh2 = take(HID * WLD);
+    a.off_bh2 = take(XD);
+    a.off_wa = take(XD * WLD);
+    a.off_wr1 = take(12 * W1LD);
+    a.off_br1 = take(HID);
+    a.off_wr2 = take(HID * WLD);
+    a.off_br2 = take(XD);
     a.off_xh = take(16 * a.NT * XLD);
-    a.off_gm = take(16 * a.NT * XLD);
     a.off_shh = take(N * a.SLD);
     a.off_s0 = take(16 * a.CT * a.SLD);
     a.off_sc0 = take(16 * a.CT * a.SLD);
-    a.off_x0 = take(16 * a.CT * XLD);
-    a.off_hid = take(H * HID);
-    a.wave_stride = (((a.two_buffers ? 2 : 1) * a.GC * XLD + G * a.SLD) + 3) & ~3;
-    a.off_wave = take(kWaves * a.wave_stride);
+    const int x0_floats = 16 * a.CT * XLD, hid_floats = H * HID;
+    a.off_x0 = take(x0_floats > hid_floats ? x0_floats : hid_floats);
+    int wave_floats;
+    if (a.mode == 2) wave_floats = 16 * XLD + 2 * G * 32 + G * a.SLD;
+    else if (a.mode == 3) wave_floats = 2 * a.GC * XLD + G * a.SLD;
+    else wave_floats = 16 * a.SLD;
+    a.wave_stride = (wave_floats + 3) & ~3;
+    const int gm_floats = 16 * a.NT * XLD;                       // Gm borrows the (idle) wave-private area
+    const int wave_total = kWaves * a.wave_stride > gm_floats ? kWaves * a.wave_stride : gm_floats;
+    a.off_wave = take(wave_total);
     pl.lds_bytes = (size_t)off * sizeof(float);
     if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
     a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];
@@ -564,7 +658,8 @@ int launch_children(const ChildPlan& pl, hipStream_t st) {
     if (pl.lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)pl.lds_bytes));
-    const int grid = pl.a.P < 256 * 16 ? pl.a.P : 256 * 16;
+    const int per_cu = pl.lds_bytes * 2 <= (size_t)rgl::kLdsBytesPerCu ? 2 : 1;
+    const int grid = pl.a.P < 256 * per_cu ? pl.a.P : 256 * per_cu;      // persistent: the weight image is built once
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), pl.lds_bytes, st, pl.a);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
