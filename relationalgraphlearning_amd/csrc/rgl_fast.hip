@@ -52,6 +52,23 @@ __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 // chain to the top (which costs hundreds of VGPRs); each k-group loads its fragments right before use.
 __device__ __forceinline__ void load_fence() { asm volatile("" ::: "memory"); }
 
+// Butterfly reductions over the four 16-lane k-groups of a wave (lanes l, l^16, l^32, l^48), on the VALU
+// (gfx950 v_permlane16_swap / v_permlane32_swap) instead of the LDS crossbar (ds_bpermute).
+__device__ __forceinline__ float kgroups_max(float x) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float kgroups_sum(float x) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// m / N for 0 <= m < 65536 and 1 <= N <= 64 with magic = floor(2^32 / N) + 1
+__device__ __forceinline__ int div_small(int m, unsigned magic) { return (int)__umulhi((unsigned)m, magic); }
+
 // ------------------------------------------------------------------------------------------------
 // stage 1
 // ------------------------------------------------------------------------------------------------
@@ -72,11 +89,12 @@ struct ChildArgs {
     float* rows_out;                      // [P*A][64] = [ t_c (32) | H_{L-1}[robot] (32) ]
     // derived layout (float offsets into LDS)
     int N, SLD, NT, CT, CPC, G, tiles_per_group, n_groups, GC;
+    unsigned magicN;                      // floor(2^32 / N) + 1
     int off_wh1, off_bh1, off_wh2, off_bh2, off_wa, off_wr1, off_br1, off_wr2, off_br2;   // persistent weight image
     int off_xh, off_shh, off_s0, off_sc0, off_x0, off_wave, wave_stride;                  // per-parent data
 };
 
-template <int KS>
+template <int KS, int MODE>
 __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const ChildArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -100,14 +118,10 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
     float* hid = X0;                // [H][HID]      (prologue only; dead before X0 is written)
     float* Gm = lds + a.off_wave;   // [16*NT][XLD]  (prologue + B1/B2 only; the wave-private area is idle until B3)
     float* wbase = lds + a.off_wave + wave * a.wave_stride;
-    // wave-private area, by mode:   2: buf[16][XLD] | Tacc[G][32] | Hprev[G][32] | P0w[G][SLD]
-    //                               3: Hw[GC][XLD] | Hw2[GC][XLD] | P0w[G][SLD]          1: P0w[16][SLD]
-    float* buf = wbase;
-    float* Tacc = wbase + 16 * XLD;
-    float* Hprev = Tacc + a.G * 32;
+    // wave-private area, by mode:   1: P0w[16][SLD]    2: P0w[G][SLD]    3: Hw[GC][XLD] | Hw2[GC][XLD] | P0w[G][SLD]
     float* Hw = wbase;
     float* Hw2 = wbase + a.GC * XLD;
-    float* P0w = a.mode == 2 ? Hprev + a.G * 32 : (a.mode == 3 ? wbase + 2 * a.GC * XLD : wbase);
+    float* P0w = MODE == 3 ? wbase + 2 * a.GC * XLD : wbase;
     const float NEG_INF = -INFINITY;
 
     // ---------------- once per workgroup: weight image ------------------------------------------------
@@ -261,8 +275,8 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) xh_a[ft][s] = (j >= 1 && j < N) ? Xh[j * XLD + 16 * ft + n] : 0.f;
         }
-        float w_a[2][8];     // A operand of (. W_l): A[i = out feature][k <-> in feature 16ft+4q+r]
-        if (a.L >= 2) {
+        float w_a[2][8];     // W_l[in = 16ft+4q+r][out = 16ot+n]: A operand of W^T*T^T, or B operand of T*W
+        if (MODE >= 2) {
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -275,10 +289,10 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
             const int cols = Gv * a.CPC;
             float* cur = Hw;
             float* nxt = Hw2;
-            if (a.mode == 2)
-                for (int idx = lane; idx < a.G * 32; idx += 64) Tacc[idx] = 0.f;
-            for (int layer = 0; layer < (a.L >= 2 ? a.L - 1 : 1); ++layer) {
-                if (a.L >= 3 && (layer >= 1 || g != wave)) {     // more than one full layer: the registers rotate
+            f32x4 tacc[2] = {zero4(), zero4()};     // MODE 2: t_c accumulators, [child slot 4q+r][feature 16ot+n]
+            const int n_layers_here = MODE == 3 ? a.L - 1 : 1;
+            for (int layer = 0; layer < n_layers_here; ++layer) {
+                if (MODE == 3 && (layer >= 1 || g != wave)) {     // more than one full layer: the registers rotate
 #pragma unroll
                     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -288,8 +302,13 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
                 for (int t = 0; t < a.tiles_per_group; ++t) {
                     const int m = 16 * t + n;
                     const bool valid = m < cols;
-                    const int cl = valid ? m / a.CPC : 0;
-                    const int i = valid ? m - cl * a.CPC : 0;
+                    int cl = 0, i = 0;
+                    if (MODE == 1) cl = valid ? m : 0;
+                    else {
+                        cl = div_small(m, a.magicN);
+                        i = m - cl * N;
+                        if (!valid) { cl = 0; i = 0; }
+                    }
                     const int c = c0 + cl;
                     // similarity row of node i of child c, in B-operand order: lane (n,q) holds j = 4s+q
                     const float* rowp = (i == 0) ? &S0[c * SLD] : &Shh[i * SLD];
@@ -300,25 +319,22 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
                     float mx = v[0];
 #pragma unroll
                     for (int s = 1; s < KS; ++s) mx = fmaxf(mx, v[s]);
-                    mx = fmaxf(mx, __shfl_xor(mx, 16));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    mx = kgroups_max(mx);
                     float sum = 0.f;
 #pragma unroll
                     for (int s = 0; s < KS; ++s) {
                         v[s] = __expf(v[s] - mx);
                         sum += v[s];
                     }
-                    sum += __shfl_xor(sum, 16);
-                    sum += __shfl_xor(sum, 32);
-                    const float inv = valid ? 1.0f / sum : 0.f;
+                    sum = kgroups_sum(sum);
+                    const float inv = valid ? __builtin_amdgcn_rcpf(sum) : 0.f;
 #pragma unroll
                     for (int s = 0; s < KS; ++s) v[s] *= inv;
                     if (layer == 0 && valid && i == 0) {
 #pragma unroll
-                        for (int s = 0; s < KS; ++s)
-                            if (4 * s + q < SLD) P0w[cl * SLD + 4 * s + q] = v[s];
+                        for (int s = 0; s < KS; ++s) P0w[cl * SLD + 4 * s + q] = v[s];
                     }
-                    if (a.L < 2) continue;
+                    if (MODE == 1) continue;
                     f32x4 acc[2] = {zero4(), zero4()};
                     f32x4 x0c[2];
                     x0c[0] = *reinterpret_cast<const f32x4*>(&X0[c * XLD + 4 * q]);
@@ -351,76 +367,93 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
                             }
                         }
                     }
-                    f32x4 o[2] = {zero4(), zero4()};
+                    if (MODE == 2) {
+                        // H1pre = T * W with T^T's registers as the A operand: the result lands as
+                        // [column 4q+r][feature 16ot+n], i.e. already in B-operand order for the contraction over columns
+                        f32x4 o[2] = {zero4(), zero4()};
 #pragma unroll
-                    for (int ft = 0; ft < 2; ++ft)
+                        for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
+                            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                            for (int ot = 0; ot < 2; ++ot) o[ot] = mfma4(w_a[ot][4 * ft + r], acc[ft][r], o[ot]);
-                    float* dst = a.mode == 2 ? buf + n * XLD : ((layer == 0 ? Hw : nxt) + m * XLD);
-#pragma unroll
-                    for (int ot = 0; ot < 2; ++ot) {
-                        f32x4 sk;
-                        if (layer == 0) sk = (i == 0) ? x0c[ot] : *reinterpret_cast<const f32x4*>(&Xh[i * XLD + 16 * ot + 4 * q]);
-                        else sk = *reinterpret_cast<const f32x4*>(&cur[m * XLD + 16 * ot + 4 * q]);
+                                for (int ot = 0; ot < 2; ++ot) o[ot] = mfma4(acc[ft][r], w_a[ot][4 * ft + r], o[ot]);
+                        // per register r: column mr = 16t + 4q + r  ->  (child slot, node)
+                        int mr = 16 * t + 4 * q;
+                        int clr = div_small(mr, a.magicN);
+                        int ir = mr - clr * N;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float hval = fmaxf(o[ot][r], 0.f);
-                            if (a.skip) hval += sk[r];
-                            o[ot][r] = hval;
-                        }
-                        *reinterpret_cast<f32x4*>(&dst[16 * ot + 4 * q]) = o[ot];
-                    }
-                    if (a.mode == 2) {
-                        // stream the robot-row aggregation t_c += A_c[0][i] * H_c[i]: each half-wave walks 8 of the
-                        // tile's 16 columns with a register accumulator per feature, flushed when the child changes
-                        const int f = lane & 31, hh = lane >> 5;
-                        int mm = 16 * t + 8 * hh;
-                        int ccl = mm / N, ii = mm - ccl * N;
-                        float accv = 0.f;
-                        int cur_cl = ccl;
+                            const bool vr = mr < cols;
+                            const int cr = c0 + (vr ? clr : 0);
+                            const int irr = vr ? ir : 0;
+                            const float* skp = (irr == 0) ? &X0[cr * XLD + n] : &Xh[irr * XLD + n];
+                            const float sel = vr ? P0w[(vr ? clr : 0) * SLD + irr] : 0.f;     // A_c[0][node]
+                            const float asel = (clr == n) ? sel : 0.f;                         // selector row of slot n
+                            float* hp = a.rows_out + ((size_t)p * A + cr) * 64 + 32 + n;
 #pragma unroll
-                        for (int it = 0; it < 8; ++it) {
-                            if (mm < cols) {
-                                if (ccl != cur_cl) {
-                                    atomicAdd(&Tacc[cur_cl * 32 + f], accv);
-                                    accv = 0.f;
-                                    cur_cl = ccl;
-                                }
-                                const float hv = buf[(8 * hh + it) * XLD + f];
-                                accv = fmaf(P0w[ccl * SLD + ii], hv, accv);
-                                if (ii == 0) Hprev[ccl * 32 + f] = hv;
+                            for (int ot = 0; ot < 2; ++ot) {
+                                float hval = fmaxf(o[ot][r], 0.f);
+                                if (a.skip) hval += skp[16 * ot];
+                                if (vr && irr == 0) hp[16 * ot] = hval;                        // H_{L-1}[robot] for the skip of the last layer
+                                tacc[ot] = mfma4(asel, hval, tacc[ot]);                        // t_c += A_c[0][node] * H[node]
                             }
-                            ++mm;
-                            if (++ii == N) { ii = 0; ++ccl; }
+                            ++mr;
+                            if (++ir == N) { ir = 0; ++clr; }
                         }
-                        // two separately masked flushes: lanes f and f+32 may target the same word, keep a fixed order
-                        if (hh == 0 && 16 * t < cols) atomicAdd(&Tacc[cur_cl * 32 + f], accv);
-                        if (hh == 1 && 16 * t + 8 < cols) atomicAdd(&Tacc[cur_cl * 32 + f], accv);
+                    } else {
+                        f32x4 o[2] = {zero4(), zero4()};
+#pragma unroll
+                        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                for (int ot = 0; ot < 2; ++ot) o[ot] = mfma4(w_a[ot][4 * ft + r], acc[ft][r], o[ot]);
+                        float* dst = (layer == 0 ? Hw : nxt) + m * XLD;
+#pragma unroll
+                        for (int ot = 0; ot < 2; ++ot) {
+                            f32x4 sk;
+                            if (layer == 0) sk = (i == 0) ? x0c[ot] : *reinterpret_cast<const f32x4*>(&Xh[i * XLD + 16 * ot + 4 * q]);
+                            else sk = *reinterpret_cast<const f32x4*>(&cur[m * XLD + 16 * ot + 4 * q]);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float hval = fmaxf(o[ot][r], 0.f);
+                                if (a.skip) hval += sk[r];
+                                o[ot][r] = hval;
+                            }
+                            *reinterpret_cast<f32x4*>(&dst[16 * ot + 4 * q]) = o[ot];
+                        }
                     }
                 }
                 if (layer >= 1) { float* tmp = cur; cur = nxt; nxt = tmp; }
             }
             // last layer, robot node only:  t_c = sum_j A_c[0][j] * H_c[j],   plus H_c[0] for the skip connection
-            for (int cl = lane >> 5; cl < Gv; cl += 2) {
-                const int f = lane & 31;
-                const int c = c0 + cl;
-                float tsum = 0.f, hprev;
-                if (a.mode == 2) {
-                    tsum = Tacc[cl * 32 + f];
-                    hprev = Hprev[cl * 32 + f];
-                } else if (a.mode == 3) {
-                    for (int j = 0; j < N; ++j) tsum = fmaf(P0w[cl * SLD + j], cur[(cl * N + j) * XLD + f], tsum);
-                    hprev = cur[(cl * N) * XLD + f];
-                } else {
-                    hprev = X0[c * XLD + f];
-                    tsum = P0w[cl * SLD] * hprev;
-                    for (int j = 1; j < N; ++j) tsum = fmaf(P0w[cl * SLD + j], Xh[j * XLD + f], tsum);
+            if (MODE == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int slot = 4 * q + r;
+                    if (slot < Gv) {
+                        float* out = a.rows_out + ((size_t)p * A + c0 + slot) * 64 + n;
+                        out[0] = tacc[0][r];
+                        out[16] = tacc[1][r];
+                    }
                 }
-                float* out = a.rows_out + ((size_t)p * A + c) * 64;
-                out[f] = tsum;
-                out[32 + f] = hprev;
+            } else {
+                for (int cl = lane >> 5; cl < Gv; cl += 2) {
+                    const int f = lane & 31;
+                    const int c = c0 + cl;
+                    float tsum = 0.f, hprev;
+                    if (MODE == 3) {
+                        for (int j = 0; j < N; ++j) tsum = fmaf(P0w[cl * SLD + j], cur[(cl * N + j) * XLD + f], tsum);
+                        hprev = cur[(cl * N) * XLD + f];
+                    } else {
+                        hprev = X0[c * XLD + f];
+                        tsum = P0w[cl * SLD] * hprev;
+                        for (int j = 1; j < N; ++j) tsum = fmaf(P0w[cl * SLD + j], Xh[j * XLD + f], tsum);
+                    }
+                    float* out = a.rows_out + ((size_t)p * A + c) * 64;
+                    out[f] = tsum;
+                    out[32 + f] = hprev;
+                }
             }
         }
         __syncthreads();
@@ -593,6 +626,7 @@ inline ChildPlan plan_children(const RglGraph& g, int P, int A, int H) {
     if (N > 64 || A > 96 || A < 1) return pl;
     ChildArgs& a = pl.a;
     a.N = N;
+    a.magicN = (unsigned)((1ull << 32) / (unsigned)N) + 1u;
     const int ks = (N + 3) / 4;
     pl.ks_bucket = ks <= 2 ? 2 : ks <= 5 ? 5 : ks <= 8 ? 8 : ks <= 13 ? 13 : 16;
     a.SLD = 4 * pl.ks_bucket + 1;
@@ -634,7 +668,7 @@ inline ChildPlan plan_children(const RglGraph& g, int P, int A, int H) {
     const int x0_floats = 16 * a.CT * XLD, hid_floats = H * HID;
     a.off_x0 = take(x0_floats > hid_floats ? x0_floats : hid_floats);
     int wave_floats;
-    if (a.mode == 2) wave_floats = 16 * XLD + 2 * G * 32 + G * a.SLD;
+    if (a.mode == 2) wave_floats = G * a.SLD;
     else if (a.mode == 3) wave_floats = 2 * a.GC * XLD + G * a.SLD;
     else wave_floats = 16 * a.SLD;
     a.wave_stride = (wave_floats + 3) & ~3;
@@ -652,9 +686,9 @@ inline ChildPlan plan_children(const RglGraph& g, int P, int A, int H) {
     return pl;
 }
 
-template <int KS>
-int launch_children(const ChildPlan& pl, hipStream_t st) {
-    auto kern = children_graph_kernel<KS>;
+template <int KS, int MODE>
+int launch_children_mode(const ChildPlan& pl, hipStream_t st) {
+    auto kern = children_graph_kernel<KS, MODE>;
     if (pl.lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)pl.lds_bytes));
@@ -663,6 +697,15 @@ int launch_children(const ChildPlan& pl, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), pl.lds_bytes, st, pl.a);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
+}
+
+template <int KS>
+int launch_children(const ChildPlan& pl, hipStream_t st) {
+    switch (pl.a.mode) {
+        case 1: return launch_children_mode<KS, 1>(pl, st);
+        case 2: return launch_children_mode<KS, 2>(pl, st);
+        default: return launch_children_mode<KS, 3>(pl, st);
+    }
 }
 
 template <int D1, int D2, int D3>
