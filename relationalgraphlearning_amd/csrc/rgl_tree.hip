@@ -15,6 +15,8 @@ int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, cons
 int launch_value_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
                           float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream);   // rgl_fast.hip
 size_t value_children_workspace_bytes(const MprlPlanner* pl, int P, int H);
+int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float* humans, int crowds_per, int P, int H,
+                          float* humans_next, void* workspace, size_t workspace_bytes, hipStream_t stream);   // rgl_fast.hip
 }  // namespace rgl
 
 namespace {
@@ -453,8 +455,7 @@ int expand_level(const MprlPlanner& pl, const float* robot, const float* humans,
         }
         RGL_LAUNCH_CHECK();
     } else {
-        int rc = rgl::launch_generic_forward(&pl.predictor_graph, nullptr, &pl.motion_head, robot, humans, P, humans_per, H,
-                                             nullptr, nullptr, nullptr, humans_next, st);
+        int rc = rgl::launch_predict_humans(&pl, robot, humans, humans_per, P, H, humans_next, scratch, scratch_bytes, st);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(mprl_children_kernel, grid_for((long long)P * A), dim3(kBlock), 0, st, robot, humans, humans_per,
