@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librgl_hip.so")
+LIB_PATH = os.environ.get("RGL_HIP_LIBRARY") or os.path.join(_HERE, "lib", "librgl_hip.so")   # override: debug builds only
 
 MAX_MLP_LAYERS = 6
 MAX_GCN_LAYERS = 8

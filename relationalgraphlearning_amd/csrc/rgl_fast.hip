@@ -69,12 +69,42 @@ __device__ __forceinline__ float kgroups_sum(float x) {
 // m / N for 0 <= m < 65536 and 1 <= N <= 64 with magic = floor(2^32 / N) + 1
 __device__ __forceinline__ int div_small(int m, unsigned magic) { return (int)__umulhi((unsigned)m, magic); }
 
+// Optional phase timing (-DRGL_PHASE_TIMING, tools/phase_timing.py): per-wave s_memtime deltas summed per phase.
+#ifdef RGL_PHASE_TIMING
+__device__ unsigned long long g_phase_cycles[16];
+#define PHASE_START()                                                      \
+    unsigned long long phase_acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0};          \
+    unsigned long long phase_t0__ = __builtin_amdgcn_s_memtime()
+#define PHASE_MARK(idx)                                                    \
+    do {                                                                   \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime();     \
+        phase_acc__[idx] += now__ - phase_t0__;                            \
+        phase_t0__ = now__;                                                \
+    } while (0)
+#define PHASE_FLUSH()                                                      \
+    do {                                                                   \
+        if ((threadIdx.x & 63) == 0)                                       \
+            for (int i__ = 0; i__ < 8; ++i__) atomicAdd(&g_phase_cycles[i__], phase_acc__[i__]); \
+    } while (0)
+#else
+#define PHASE_MARK(idx) do { } while (0)
+#define PHASE_START() do { } while (0)
+#define PHASE_FLUSH() do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // stage 1
 // ------------------------------------------------------------------------------------------------
 constexpr int WLD = 36;    // LDS row stride of the 32-column weight images (k-major); 4*WLD % 32 == 16 keeps the
                            // four 16-lane k-groups of an MFMA A-operand read on disjoint banks
 constexpr int W1LD = 80;   // same for the 64-column image of wr1 (rows differ by 1 between k-groups)
+
+#ifndef STAGE1_THREADS
+#define STAGE1_THREADS 512
+#endif
+constexpr int kThreads1 = STAGE1_THREADS;        // stage 1: 8 waves per parent, two workgroups per CU -> 4 waves/SIMD
+constexpr int kWaves1 = kThreads1 / 64;
+#define STAGE1_WAVES_PER_SIMD (STAGE1_THREADS / 128)
 
 struct ChildArgs {
     const float *wr1, *br1, *wr2, *br2;   // robot embedding, k-major: [9][64], [64], [64][32], [32]
@@ -90,15 +120,19 @@ struct ChildArgs {
     // derived layout (float offsets into LDS)
     int N, SLD, NT, CT, CPC, G, tiles_per_group, n_groups, GC;
     unsigned magicN;                      // floor(2^32 / N) + 1
+    int n_waves;                          // waves per workgroup (4..8), chosen to balance n_groups
     int off_wh1, off_bh1, off_wh2, off_bh2, off_wa, off_wr1, off_br1, off_wr2, off_br2;   // persistent weight image
     int off_xh, off_shh, off_s0, off_sc0, off_x0, off_wave, wave_stride;                  // per-parent data
 };
 
-template <int KS, int MODE>
-__global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const ChildArgs a) {
+// VAGG: robot-row aggregation on the VALU (valid when a tile holds at most two children, i.e. N >= 16) instead of
+// the general MFMA selector product.
+template <int KS, int MODE, bool VAGG>
+__global__ __launch_bounds__(kThreads1, STAGE1_WAVES_PER_SIMD) void children_graph_kernel(const ChildArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int nthreads = a.n_waves * 64;
     const int n = lane & 15, q = lane >> 4;
     const int N = a.N, H = a.H, A = a.A, SLD = a.SLD;
     const float* wh1 = lds + a.off_wh1;   // [5][HID]
@@ -127,30 +161,32 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
     // ---------------- once per workgroup: weight image ------------------------------------------------
     {
         float* w = lds;
-        for (int i = tid; i < 5 * HID; i += kThreads) w[a.off_wh1 + i] = a.wh1[i];
-        for (int i = tid; i < HID; i += kThreads) { w[a.off_bh1 + i] = a.bh1[i]; w[a.off_br1 + i] = a.br1[i]; }
-        for (int i = tid; i < XD; i += kThreads) { w[a.off_bh2 + i] = a.bh2[i]; w[a.off_br2 + i] = a.br2[i]; }
-        for (int i = tid; i < HID * XD; i += kThreads) {
+        for (int i = tid; i < 5 * HID; i += nthreads) w[a.off_wh1 + i] = a.wh1[i];
+        for (int i = tid; i < HID; i += nthreads) { w[a.off_bh1 + i] = a.bh1[i]; w[a.off_br1 + i] = a.br1[i]; }
+        for (int i = tid; i < XD; i += nthreads) { w[a.off_bh2 + i] = a.bh2[i]; w[a.off_br2 + i] = a.br2[i]; }
+        for (int i = tid; i < HID * XD; i += nthreads) {
             const int r = i / XD, c = i - r * XD;
             w[a.off_wh2 + r * WLD + c] = a.wh2[i];
             w[a.off_wr2 + r * WLD + c] = a.wr2[i];
         }
-        for (int i = tid; i < XD * XD; i += kThreads) {
+        for (int i = tid; i < XD * XD; i += nthreads) {
             const int r = i / XD, c = i - r * XD;
             w[a.off_wa + r * WLD + c] = a.wa[i];
         }
-        for (int i = tid; i < 12 * HID; i += kThreads) {
+        for (int i = tid; i < 12 * HID; i += nthreads) {
             const int r = i / HID, c = i - r * HID;
             w[a.off_wr1 + r * W1LD + c] = r < 9 ? a.wr1[i] : 0.f;
         }
     }
     __syncthreads();
 
+    PHASE_START();
     for (int p = blockIdx.x; p < a.P; p += gridDim.x) {
+        PHASE_MARK(0);          // loop overhead / final barrier of the previous parent
         // ---------------- prologue: crowd-only quantities, shared by all children -----------------------
         const float* hsrc = a.humans + (size_t)p * H * 5;
-        for (int idx = tid; idx < 16 * a.NT * XLD; idx += kThreads) { Xh[idx] = 0.f; Gm[idx] = 0.f; }
-        for (int idx = tid; idx < H * HID; idx += kThreads) {
+        for (int idx = tid; idx < 16 * a.NT * XLD; idx += nthreads) { Xh[idx] = 0.f; Gm[idx] = 0.f; }
+        for (int idx = tid; idx < H * HID; idx += nthreads) {
             const int j = idx / HID, u = idx - j * HID;
             float acc = bh1[u];
 #pragma unroll
@@ -158,7 +194,7 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
             hid[idx] = fmaxf(acc, 0.f);
         }
         __syncthreads();
-        for (int idx = tid; idx < H * XD; idx += kThreads) {
+        for (int idx = tid; idx < H * XD; idx += nthreads) {
             const int j = idx / XD, f = idx - j * XD;
             float acc = bh2[f];
 #pragma unroll 8
@@ -166,7 +202,7 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
             Xh[(j + 1) * XLD + f] = fmaxf(acc, 0.f);
         }
         __syncthreads();
-        for (int idx = tid; idx < H * XD; idx += kThreads) {
+        for (int idx = tid; idx < H * XD; idx += nthreads) {
             const int j = idx / XD, g = idx - j * XD;
             float acc = 0.f;
 #pragma unroll 8
@@ -174,7 +210,7 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
             Gm[(j + 1) * XLD + g] = acc;
         }
         __syncthreads();
-        for (int idx = tid; idx < N * SLD; idx += kThreads) {
+        for (int idx = tid; idx < N * SLD; idx += nthreads) {
             const int i = idx / SLD, j = idx - i * SLD;
             float v = NEG_INF;
             if (i >= 1 && j >= 1 && j < N) {
@@ -186,9 +222,10 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
         }
         // (no barrier needed before B1: it reads Xh/Gm, which were fenced above, and writes S0/Sc0/X0;
         //  X0 aliases `hid`, whose last readers finished before the barrier after the Xh loop)
+        PHASE_MARK(1);          // prologue
 
         // ---------------- B1/B2: robot embedding and robot row/column of S for 16 children per pass -----
-        for (int ct = wave; ct < a.CT; ct += kWaves) {
+        for (int ct = wave; ct < a.CT; ct += a.n_waves) {
             const int c = 16 * ct + n;
             const int cc = c < A ? c : A - 1;
             const float* rr = a.child_robot + ((size_t)p * A + cc) * 9;
@@ -265,7 +302,9 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
                 }
             }
         }
+        PHASE_MARK(2);          // B1/B2 work
         __syncthreads();      // Gm is dead from here on: its storage becomes the wave-private area
+        PHASE_MARK(3);          // B1/B2 barrier wait
 
         // ---------------- B3: graph layers, G children per wave at a time --------------------------------
         float xh_a[2][KS];   // A operand of (A_c X): A[i = feature][k <-> node j = 4s+q], shared by every child
@@ -283,13 +322,15 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
                 for (int kk = 0; kk < 8; ++kk)
                     w_a[ot][kk] = a.Ws[0][(16 * (kk >> 2) + 4 * q + (kk & 3)) * XD + 16 * ot + n];
         }
-        for (int g = wave; g < a.n_groups; g += kWaves) {
+        for (int g = wave; g < a.n_groups; g += a.n_waves) {
             const int c0 = g * a.G;
             const int Gv = (A - c0) < a.G ? (A - c0) : a.G;
             const int cols = Gv * a.CPC;
             float* cur = Hw;
             float* nxt = Hw2;
             f32x4 tacc[2] = {zero4(), zero4()};     // MODE 2: t_c accumulators, [child slot 4q+r][feature 16ot+n]
+            float run_t[2] = {0.f, 0.f};            // MODE 2 / VAGG: running t_c of child slot run_cl (wave-uniform)
+            int run_cl = 0;
             const int n_layers_here = MODE == 3 ? a.L - 1 : 1;
             for (int layer = 0; layer < n_layers_here; ++layer) {
                 if (MODE == 3 && (layer >= 1 || g != wave)) {     // more than one full layer: the registers rotate
@@ -381,6 +422,8 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
                         int mr = 16 * t + 4 * q;
                         int clr = div_small(mr, a.magicN);
                         int ir = mr - clr * N;
+                        const int lo = div_small(16 * t, a.magicN);        // slot of the tile's first column (wave-uniform)
+                        float plo[2] = {0.f, 0.f}, phi[2] = {0.f, 0.f};
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const bool vr = mr < cols;
@@ -389,16 +432,46 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
                             const float* skp = (irr == 0) ? &X0[cr * XLD + n] : &Xh[irr * XLD + n];
                             const float sel = vr ? P0w[(vr ? clr : 0) * SLD + irr] : 0.f;     // A_c[0][node]
                             const float asel = (clr == n) ? sel : 0.f;                         // selector row of slot n
+                            const float wlo = (clr == lo) ? sel : 0.f, whi = (clr == lo) ? 0.f : sel;
                             float* hp = a.rows_out + ((size_t)p * A + cr) * 64 + 32 + n;
 #pragma unroll
                             for (int ot = 0; ot < 2; ++ot) {
                                 float hval = fmaxf(o[ot][r], 0.f);
                                 if (a.skip) hval += skp[16 * ot];
                                 if (vr && irr == 0) hp[16 * ot] = hval;                        // H_{L-1}[robot] for the skip of the last layer
-                                tacc[ot] = mfma4(asel, hval, tacc[ot]);                        // t_c += A_c[0][node] * H[node]
+                                if (VAGG) {
+                                    plo[ot] = fmaf(wlo, hval, plo[ot]);                        // t_c += A_c[0][node] * H[node]
+                                    phi[ot] = fmaf(whi, hval, phi[ot]);
+                                } else {
+                                    tacc[ot] = mfma4(asel, hval, tacc[ot]);
+                                }
                             }
                             ++mr;
                             if (++ir == N) { ir = 0; ++clr; }
+                        }
+                        if (VAGG) {
+                            // children are contiguous column ranges: the tile continues child `lo` and may start `lo+1`
+                            if (lo != run_cl) {
+                                if (q == 0 && run_cl < Gv) {
+                                    float* out = a.rows_out + ((size_t)p * A + c0 + run_cl) * 64 + n;
+                                    out[0] = run_t[0];
+                                    out[16] = run_t[1];
+                                }
+                                run_t[0] = run_t[1] = 0.f;
+                                run_cl = lo;
+                            }
+                            run_t[0] += kgroups_sum(plo[0]);
+                            run_t[1] += kgroups_sum(plo[1]);
+                            if (lo + 1 < Gv && (lo + 1) * N < 16 * t + 16) {
+                                if (q == 0) {
+                                    float* out = a.rows_out + ((size_t)p * A + c0 + run_cl) * 64 + n;
+                                    out[0] = run_t[0];
+                                    out[16] = run_t[1];
+                                }
+                                run_t[0] = kgroups_sum(phi[0]);
+                                run_t[1] = kgroups_sum(phi[1]);
+                                run_cl = lo + 1;
+                            }
                         }
                     } else {
                         f32x4 o[2] = {zero4(), zero4()};
@@ -427,7 +500,13 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
                 if (layer >= 1) { float* tmp = cur; cur = nxt; nxt = tmp; }
             }
             // last layer, robot node only:  t_c = sum_j A_c[0][j] * H_c[j],   plus H_c[0] for the skip connection
-            if (MODE == 2) {
+            if (MODE == 2 && VAGG) {
+                if (q == 0 && run_cl < Gv) {
+                    float* out = a.rows_out + ((size_t)p * A + c0 + run_cl) * 64 + n;
+                    out[0] = run_t[0];
+                    out[16] = run_t[1];
+                }
+            } else if (MODE == 2) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int slot = 4 * q + r;
@@ -456,8 +535,11 @@ __global__ __launch_bounds__(kThreads, 2) void children_graph_kernel(const Child
                 }
             }
         }
+        PHASE_MARK(4);          // B3 work
         __syncthreads();
+        PHASE_MARK(5);          // end-of-parent barrier wait
     }
+    PHASE_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -673,7 +755,10 @@ inline ChildPlan plan_children(const RglGraph& g, int P, int A, int H) {
     else wave_floats = 16 * a.SLD;
     a.wave_stride = (wave_floats + 3) & ~3;
     const int gm_floats = 16 * a.NT * XLD;                       // Gm borrows the (idle) wave-private area
-    const int wave_total = kWaves * a.wave_stride > gm_floats ? kWaves * a.wave_stride : gm_floats;
+    // waves per workgroup: 8 (two per SIMD; measured better than counts that balance n_groups exactly but load the
+    // four SIMDs unevenly), 4 when there is too little work to share
+    a.n_waves = a.n_groups >= 6 ? kWaves1 : 4;
+    const int wave_total = a.n_waves * a.wave_stride > gm_floats ? a.n_waves * a.wave_stride : gm_floats;
     a.off_wave = take(wave_total);
     pl.lds_bytes = (size_t)off * sizeof(float);
     if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
@@ -686,15 +771,15 @@ inline ChildPlan plan_children(const RglGraph& g, int P, int A, int H) {
     return pl;
 }
 
-template <int KS, int MODE>
+template <int KS, int MODE, bool VAGG>
 int launch_children_mode(const ChildPlan& pl, hipStream_t st) {
-    auto kern = children_graph_kernel<KS, MODE>;
+    auto kern = children_graph_kernel<KS, MODE, VAGG>;
     if (pl.lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)pl.lds_bytes));
     const int per_cu = pl.lds_bytes * 2 <= (size_t)rgl::kLdsBytesPerCu ? 2 : 1;
     const int grid = pl.a.P < 256 * per_cu ? pl.a.P : 256 * per_cu;      // persistent: the weight image is built once
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), pl.lds_bytes, st, pl.a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(pl.a.n_waves * 64), pl.lds_bytes, st, pl.a);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }
@@ -702,9 +787,9 @@ int launch_children_mode(const ChildPlan& pl, hipStream_t st) {
 template <int KS>
 int launch_children(const ChildPlan& pl, hipStream_t st) {
     switch (pl.a.mode) {
-        case 1: return launch_children_mode<KS, 1>(pl, st);
-        case 2: return launch_children_mode<KS, 2>(pl, st);
-        default: return launch_children_mode<KS, 3>(pl, st);
+        case 1: return launch_children_mode<KS, 1, false>(pl, st);
+        case 2: return pl.a.N >= 16 ? launch_children_mode<KS, 2, true>(pl, st) : launch_children_mode<KS, 2, false>(pl, st);
+        default: return launch_children_mode<KS, 3, false>(pl, st);
     }
 }
 
@@ -993,6 +1078,18 @@ int launch_scene(const SceneArgs& sa, size_t lds_bytes, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef RGL_PHASE_TIMING
+extern "C" int rgl_debug_read_phase_cycles(unsigned long long* out16, int reset) {
+    RGL_HIP_TRY(hipDeviceSynchronize());
+    RGL_HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        RGL_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)));
+    }
+    return 0;
+}
+#endif
 
 namespace rgl {
 

@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Per-phase cycle breakdown of children_graph_kernel (debug build: make -C relationalgraphlearning_amd/csrc timing).
+
+    RGL_HIP_LIBRARY=relationalgraphlearning_amd/lib/librgl_hip_timing.so python tools/phase_timing.py
+"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("RGL_HIP_LIBRARY", os.path.join(ROOT, "relationalgraphlearning_amd", "lib", "librgl_hip_timing.so"))
+import bench  # noqa: E402
+from relationalgraphlearning_amd import _native as nat  # noqa: E402
+
+
+class A:
+    layers, depth, width, humans = 2, 2, 2, 19
+
+
+def main():
+    P = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    dev = torch.device("cuda:0")
+    pol = bench.make_policy(A, dev)
+    ts = pol.tree_search()
+    robot, humans = bench.synth_scenes(5, P, A.humans)
+    ex = ts.expand(robot.to(dev), humans.to(dev), parents_are_joint_states=False)
+    lib = nat.lib()
+    raw = C.CDLL(nat.LIB_PATH)
+    buf = (C.c_ulonglong * 16)()
+    raw.rgl_debug_read_phase_cycles(buf, 1)
+    reps = 3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ts.value_children(ex["child_robot"], ex["humans_next"])
+    e1.record()
+    torch.cuda.synchronize()
+    raw.rgl_debug_read_phase_cycles(buf, 1)
+    names = ["loop/prev barrier", "prologue", "B1/B2 work", "B1/B2 barrier", "B3 work", "end barrier"]
+    waves = 7 * P * reps          # per (wave, parent); 7 waves per workgroup at N=20, A=81
+    tot = sum(buf[i] for i in range(6))
+    print("P=%d  %.3f ms per call (stage 1+2)" % (P, e0.elapsed_time(e1) / reps))
+    for i, nm in enumerate(names):
+        print("  %-18s %9.0f cycles per wave per parent   %5.1f %%" % (nm, buf[i] / waves, 100.0 * buf[i] / tot))
+    print("  total              %9.0f" % (tot / waves))
+
+
+if __name__ == "__main__":
+    main()
