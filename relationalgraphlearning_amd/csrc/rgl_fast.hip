@@ -68,6 +68,8 @@ __device__ __forceinline__ float kgroups_sum(float x) {
 }
 // m / N for 0 <= m < 65536 and 1 <= N <= 64 with magic = floor(2^32 / N) + 1
 __device__ __forceinline__ int div_small(int m, unsigned magic) { return (int)__umulhi((unsigned)m, magic); }
+// relu as ONE instruction (v_med3_f32): fmaxf() on MFMA results costs an extra canonicalising v_max
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
 
 // Optional phase timing (-DRGL_PHASE_TIMING, tools/phase_timing.py): per-wave s_memtime deltas summed per phase.
 #ifdef RGL_PHASE_TIMING
@@ -105,6 +107,9 @@ constexpr int W1LD = 80;   // same for the 64-column image of wr1 (rows differ b
 constexpr int kThreads1 = STAGE1_THREADS;        // stage 1: 8 waves per parent, two workgroups per CU -> 4 waves/SIMD
 constexpr int kWaves1 = kThreads1 / 64;
 #define STAGE1_WAVES_PER_SIMD (STAGE1_THREADS / 128)
+#ifndef STAGE1_STAGGER
+#define STAGE1_STAGGER 0                         // x64 cycles
+#endif
 
 struct ChildArgs {
     const float *wr1, *br1, *wr2, *br2;   // robot embedding, k-major: [9][64], [64], [64][32], [32]
@@ -127,7 +132,7 @@ struct ChildArgs {
 
 // VAGG: robot-row aggregation on the VALU (valid when a tile holds at most two children, i.e. N >= 16) instead of
 // the general MFMA selector product.
-template <int KS, int MODE, bool VAGG>
+template <int KS, int MODE, bool VAGG, bool SKIP>
 __global__ __launch_bounds__(kThreads1, STAGE1_WAVES_PER_SIMD) void children_graph_kernel(const ChildArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -322,6 +327,9 @@ __global__ __launch_bounds__(kThreads1, STAGE1_WAVES_PER_SIMD) void children_gra
                 for (int kk = 0; kk < 8; ++kk)
                     w_a[ot][kk] = a.Ws[0][(16 * (kk >> 2) + 4 * q + (kk & 3)) * XD + 16 * ot + n];
         }
+        // the two waves a workgroup places on each SIMD (w, w+4) would run the tile loop in lockstep, colliding on the
+        // matrix pipe and idling it together; start the second one about half a tile later
+        if (STAGE1_STAGGER > 0 && wave >= 4) __builtin_amdgcn_s_sleep(STAGE1_STAGGER);
         for (int g = wave; g < a.n_groups; g += a.n_waves) {
             const int c0 = g * a.G;
             const int Gv = (A - c0) < a.G ? (A - c0) : a.G;
@@ -376,6 +384,30 @@ __global__ __launch_bounds__(kThreads1, STAGE1_WAVES_PER_SIMD) void children_gra
                         for (int s = 0; s < KS; ++s) P0w[cl * SLD + 4 * s + q] = v[s];
                     }
                     if (MODE == 1) continue;
+                    // MODE 2 / VAGG: operands of the epilogue, fetched NOW so their LDS latency hides under the MFMAs.
+                    // Register r of the swapped product holds column mr = 16t + 4q + r -> (child slot clr, node ir).
+                    float e_sel[4], e_sk[2][4];
+                    int e_cl[4];
+                    if (MODE == 2 && VAGG) {
+                        int mr = 16 * t + 4 * q;
+                        int clr = div_small(mr, a.magicN);
+                        int ir = mr - clr * N;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool vr = mr < cols;
+                            const int cs = vr ? clr : 0, is = vr ? ir : 0;
+                            const float pv = P0w[cs * SLD + is];                      // A_c[0][node]
+                            e_sel[r] = vr ? pv : 0.f;
+                            e_cl[r] = clr;
+                            if (SKIP) {
+                                const int off = (is == 0) ? a.off_x0 + (c0 + cs) * XLD : a.off_xh + is * XLD;
+                                e_sk[0][r] = lds[off + n];
+                                e_sk[1][r] = lds[off + 16 + n];
+                            }
+                            ++mr;
+                            if (++ir == N) { ir = 0; ++clr; }
+                        }
+                    }
                     f32x4 acc[2] = {zero4(), zero4()};
                     f32x4 x0c[2];
                     x0c[0] = *reinterpret_cast<const f32x4*>(&X0[c * XLD + 4 * q]);
@@ -408,9 +440,8 @@ __global__ __launch_bounds__(kThreads1, STAGE1_WAVES_PER_SIMD) void children_gra
                             }
                         }
                     }
-                    if (MODE == 2) {
-                        // H1pre = T * W with T^T's registers as the A operand: the result lands as
-                        // [column 4q+r][feature 16ot+n], i.e. already in B-operand order for the contraction over columns
+                    if (MODE == 2 && VAGG) {
+                        // H1pre = T * W with T^T's registers as the A operand: the result lands as [column 4q+r][feature 16ot+n]
                         f32x4 o[2] = {zero4(), zero4()};
 #pragma unroll
                         for (int ft = 0; ft < 2; ++ft)
@@ -418,60 +449,83 @@ __global__ __launch_bounds__(kThreads1, STAGE1_WAVES_PER_SIMD) void children_gra
                             for (int r = 0; r < 4; ++r)
 #pragma unroll
                                 for (int ot = 0; ot < 2; ++ot) o[ot] = mfma4(acc[ft][r], w_a[ot][4 * ft + r], o[ot]);
-                        // per register r: column mr = 16t + 4q + r  ->  (child slot, node)
+                        const int lo = div_small(16 * t, a.magicN);        // slot of the tile's first column (wave-uniform)
+                        float plo[2] = {0.f, 0.f}, phi[2] = {0.f, 0.f};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float wlo = (e_cl[r] == lo) ? e_sel[r] : 0.f, whi = (e_cl[r] == lo) ? 0.f : e_sel[r];
+#pragma unroll
+                            for (int ot = 0; ot < 2; ++ot) {
+                                float hval = relu1(o[ot][r]);
+                                if (SKIP) hval += e_sk[ot][r];
+                                o[ot][r] = hval;
+                                plo[ot] = fmaf(wlo, hval, plo[ot]);                            // t_c += A_c[0][node] * H[node]
+                                phi[ot] = fmaf(whi, hval, phi[ot]);
+                            }
+                        }
+                        // H_{L-1}[robot] of the children whose robot column (node 0) lies in this tile: wave-uniform walk
+                        for (int k = div_small(16 * t + N - 1, a.magicN); k * N < 16 * t + 16 && k < Gv; ++k) {
+                            const int ml = k * N - 16 * t, q0 = ml >> 2, r0 = ml & 3;
+                            const float h0 = r0 == 0 ? o[0][0] : r0 == 1 ? o[0][1] : r0 == 2 ? o[0][2] : o[0][3];
+                            const float h1 = r0 == 0 ? o[1][0] : r0 == 1 ? o[1][1] : r0 == 2 ? o[1][2] : o[1][3];
+                            if (q == q0) {
+                                float* hp = a.rows_out + ((size_t)p * A + c0 + k) * 64 + 32 + n;
+                                hp[0] = h0;
+                                hp[16] = h1;
+                            }
+                        }
+                        // children are contiguous column ranges: the tile continues child `lo` and may start `lo+1`
+                        if (lo != run_cl) {
+                            if (q == 0 && run_cl < Gv) {
+                                float* out = a.rows_out + ((size_t)p * A + c0 + run_cl) * 64 + n;
+                                out[0] = run_t[0];
+                                out[16] = run_t[1];
+                            }
+                            run_t[0] = run_t[1] = 0.f;
+                            run_cl = lo;
+                        }
+                        run_t[0] += kgroups_sum(plo[0]);
+                        run_t[1] += kgroups_sum(plo[1]);
+                        if (lo + 1 < Gv && (lo + 1) * N < 16 * t + 16) {
+                            if (q == 0) {
+                                float* out = a.rows_out + ((size_t)p * A + c0 + run_cl) * 64 + n;
+                                out[0] = run_t[0];
+                                out[16] = run_t[1];
+                            }
+                            run_t[0] = kgroups_sum(phi[0]);
+                            run_t[1] = kgroups_sum(phi[1]);
+                            run_cl = lo + 1;
+                        }
+                    } else if (MODE == 2) {
+                        // general selector form (any N): contraction over the tile's columns as one more MFMA product
+                        f32x4 o[2] = {zero4(), zero4()};
+#pragma unroll
+                        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                for (int ot = 0; ot < 2; ++ot) o[ot] = mfma4(acc[ft][r], w_a[ot][4 * ft + r], o[ot]);
                         int mr = 16 * t + 4 * q;
                         int clr = div_small(mr, a.magicN);
                         int ir = mr - clr * N;
-                        const int lo = div_small(16 * t, a.magicN);        // slot of the tile's first column (wave-uniform)
-                        float plo[2] = {0.f, 0.f}, phi[2] = {0.f, 0.f};
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const bool vr = mr < cols;
                             const int cr = c0 + (vr ? clr : 0);
                             const int irr = vr ? ir : 0;
                             const float* skp = (irr == 0) ? &X0[cr * XLD + n] : &Xh[irr * XLD + n];
-                            const float sel = vr ? P0w[(vr ? clr : 0) * SLD + irr] : 0.f;     // A_c[0][node]
-                            const float asel = (clr == n) ? sel : 0.f;                         // selector row of slot n
-                            const float wlo = (clr == lo) ? sel : 0.f, whi = (clr == lo) ? 0.f : sel;
+                            const float pv = P0w[(vr ? clr : 0) * SLD + irr];
+                            const float asel = (vr && clr == n) ? pv : 0.f;                    // selector row of slot n
                             float* hp = a.rows_out + ((size_t)p * A + cr) * 64 + 32 + n;
 #pragma unroll
                             for (int ot = 0; ot < 2; ++ot) {
-                                float hval = fmaxf(o[ot][r], 0.f);
-                                if (a.skip) hval += skp[16 * ot];
+                                float hval = relu1(o[ot][r]);
+                                if (SKIP) hval += skp[16 * ot];
                                 if (vr && irr == 0) hp[16 * ot] = hval;                        // H_{L-1}[robot] for the skip of the last layer
-                                if (VAGG) {
-                                    plo[ot] = fmaf(wlo, hval, plo[ot]);                        // t_c += A_c[0][node] * H[node]
-                                    phi[ot] = fmaf(whi, hval, phi[ot]);
-                                } else {
-                                    tacc[ot] = mfma4(asel, hval, tacc[ot]);
-                                }
+                                tacc[ot] = mfma4(asel, hval, tacc[ot]);                        // t_c += A_c[0][node] * H[node]
                             }
                             ++mr;
                             if (++ir == N) { ir = 0; ++clr; }
-                        }
-                        if (VAGG) {
-                            // children are contiguous column ranges: the tile continues child `lo` and may start `lo+1`
-                            if (lo != run_cl) {
-                                if (q == 0 && run_cl < Gv) {
-                                    float* out = a.rows_out + ((size_t)p * A + c0 + run_cl) * 64 + n;
-                                    out[0] = run_t[0];
-                                    out[16] = run_t[1];
-                                }
-                                run_t[0] = run_t[1] = 0.f;
-                                run_cl = lo;
-                            }
-                            run_t[0] += kgroups_sum(plo[0]);
-                            run_t[1] += kgroups_sum(plo[1]);
-                            if (lo + 1 < Gv && (lo + 1) * N < 16 * t + 16) {
-                                if (q == 0) {
-                                    float* out = a.rows_out + ((size_t)p * A + c0 + run_cl) * 64 + n;
-                                    out[0] = run_t[0];
-                                    out[16] = run_t[1];
-                                }
-                                run_t[0] = kgroups_sum(phi[0]);
-                                run_t[1] = kgroups_sum(phi[1]);
-                                run_cl = lo + 1;
-                            }
                         }
                     } else {
                         f32x4 o[2] = {zero4(), zero4()};
@@ -490,7 +544,7 @@ __global__ __launch_bounds__(kThreads1, STAGE1_WAVES_PER_SIMD) void children_gra
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 float hval = fmaxf(o[ot][r], 0.f);
-                                if (a.skip) hval += sk[r];
+                                if (SKIP) hval += sk[r];
                                 o[ot][r] = hval;
                             }
                             *reinterpret_cast<f32x4*>(&dst[16 * ot + 4 * q]) = o[ot];
@@ -540,6 +594,360 @@ __global__ __launch_bounds__(kThreads1, STAGE1_WAVES_PER_SIMD) void children_gra
         PHASE_MARK(5);          // end-of-parent barrier wait
     }
     PHASE_FLUSH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 1, rank-1 form (L == 2, N <= 32): on gfx950 the f32 MFMA and the VALU do not co-execute
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so what counts is MFMA cycles PLUS VALU cycles.  Siblings share every
+// human row of X and of S except the robot column, hence for a human row i of child c
+//     (A_c X_c)_i W1 = ( alpha_i * UW_i + beta_i * (x0_c W1) ) / Z_i ,
+// with the crowd-only UW_i = (sum_{j>=1} e^{S_ij - msh_i} Xh_j) W1, Zsh_i = sum_{j>=1} e^{S_ij - msh_i},
+// msh_i = max_{j>=1} S_ij, and per child m = max(msh_i, S_c[i][0]), alpha = e^{msh_i - m}, beta = e^{S_c[i][0] - m},
+// Z = alpha*Zsh_i + beta (an exactly re-associated, overflow-safe softmax).  Because p >= 0,
+// p * relu(x) = relu(p * x), so the robot-row aggregation t_c = sum_i A_c[0][i] H_c[i] folds into the same pass:
+// ~5 VALU ops per (row, feature) instead of 26 MFMAs per 16 columns.  The robot row itself costs one batched
+// MFMA product (T_0 W1) per 16 children.
+// ------------------------------------------------------------------------------------------------
+struct Rank1Args {
+    const float *wr1, *br1, *wr2, *br2, *wh1, *bh1, *wh2, *bh2, *wa, *w1;
+    const float* child_robot;             // [P][A][9]
+    const float* humans;                  // [P][H][5]
+    int P, A, H, N, CT, NT, SLD, n_waves;
+    float* rows_out;                      // [P*A][64]
+    int off_wh1, off_bh1, off_wh2, off_bh2, off_wa, off_wr1, off_br1, off_wr2, off_br2, off_w1;   // weight image
+    int off_xh, off_gm, off_shh, off_uw, off_msh, off_zsh, off_s0, off_sc0, off_x0, off_y0, off_tp, off_p00, off_scal;
+};
+
+#define DPP_QUAD_XOR1 0xB1
+#define DPP_QUAD_XOR2 0x4E
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xF, 0xF, false));
+}
+// all-reduce over the 32 lanes of a half-wave (lanes l and l^32 stay separate)
+__device__ __forceinline__ float half_max(float x) {
+    x = fmaxf(x, dpp_mov<DPP_QUAD_XOR1>(x));
+    x = fmaxf(x, dpp_mov<DPP_QUAD_XOR2>(x));
+    x = fmaxf(x, dpp_mov<DPP_ROW_HALF_MIRROR>(x));
+    x = fmaxf(x, dpp_mov<DPP_ROW_MIRROR>(x));
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float x) {
+    x += dpp_mov<DPP_QUAD_XOR1>(x);
+    x += dpp_mov<DPP_QUAD_XOR2>(x);
+    x += dpp_mov<DPP_ROW_HALF_MIRROR>(x);
+    x += dpp_mov<DPP_ROW_MIRROR>(x);
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <int HR, bool SKIP>      // HR >= N: human rows held in registers (padded rows contribute exactly 0)
+__global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nthreads = a.n_waves * 64;
+    const int n = lane & 15, q = lane >> 4;
+    const int N = a.N, H = a.H, A = a.A, SLD = a.SLD;
+    const float* wh1 = lds + a.off_wh1;
+    const float* bh1 = lds + a.off_bh1;
+    const float* wh2 = lds + a.off_wh2;
+    const float* bh2 = lds + a.off_bh2;
+    const float* wa = lds + a.off_wa;
+    const float* wr1 = lds + a.off_wr1;
+    const float* br1 = lds + a.off_br1;
+    const float* wr2 = lds + a.off_wr2;
+    const float* br2 = lds + a.off_br2;
+    const float* w1 = lds + a.off_w1;     // [XD][WLD]
+    float* Xh = lds + a.off_xh;           // [16*NT][XLD]
+    float* Gm = lds + a.off_gm;           // [16*NT][XLD]
+    float* Shh = lds + a.off_shh;         // [N][SLD]   S_ij, later E_ij = exp(S_ij - msh_i)
+    float* UW = lds + a.off_uw;           // [N][XLD]
+    float* msh = lds + a.off_msh;         // [32]
+    float* zsh = lds + a.off_zsh;         // [32]
+    float* S0 = lds + a.off_s0;           // [16*CT][SLD]
+    float* Sc0 = lds + a.off_sc0;         // [16*CT][SLD]
+    float* X0 = lds + a.off_x0;           // [16*CT][XLD]
+    float* Y0 = lds + a.off_y0;           // [16*CT][XLD]  x0 W1, later T_0
+    float* TP = lds + a.off_tp;           // [16*CT][XLD]  t_c without the robot-row term
+    float* P00 = lds + a.off_p00;         // [16*CT]
+    float* hid = Y0;                      // [H][HID] (prologue only; 16*CT*XLD >= H*HID is checked on the host)
+    float* U = TP;                        // [N][XLD]  (prologue only)
+    float* scal = lds + a.off_scal + wave * (2 * 32 * 4);   // [2][32][4] per wave
+    const float NEG_INF = -INFINITY;
+
+    {   // weight image, once per workgroup
+        float* w = lds;
+        for (int i = tid; i < 5 * HID; i += nthreads) w[a.off_wh1 + i] = a.wh1[i];
+        for (int i = tid; i < HID; i += nthreads) { w[a.off_bh1 + i] = a.bh1[i]; w[a.off_br1 + i] = a.br1[i]; }
+        for (int i = tid; i < XD; i += nthreads) { w[a.off_bh2 + i] = a.bh2[i]; w[a.off_br2 + i] = a.br2[i]; }
+        for (int i = tid; i < HID * XD; i += nthreads) {
+            const int r = i / XD, c = i - r * XD;
+            w[a.off_wh2 + r * WLD + c] = a.wh2[i];
+            w[a.off_wr2 + r * WLD + c] = a.wr2[i];
+        }
+        for (int i = tid; i < XD * XD; i += nthreads) {
+            const int r = i / XD, c = i - r * XD;
+            w[a.off_wa + r * WLD + c] = a.wa[i];
+            w[a.off_w1 + r * WLD + c] = a.w1[i];
+        }
+        for (int i = tid; i < 12 * HID; i += nthreads) {
+            const int r = i / HID, c = i - r * HID;
+            w[a.off_wr1 + r * W1LD + c] = r < 9 ? a.wr1[i] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    for (int p = blockIdx.x; p < a.P; p += gridDim.x) {
+        // ---------------- prologue (crowd only) ----------------------------------------------------------
+        const float* hsrc = a.humans + (size_t)p * H * 5;
+        for (int idx = tid; idx < 16 * a.NT * XLD; idx += nthreads) { Xh[idx] = 0.f; Gm[idx] = 0.f; }
+        for (int idx = tid; idx < H * HID; idx += nthreads) {
+            const int j = idx / HID, u = idx - j * HID;
+            float acc = bh1[u];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc = fmaf(hsrc[j * 5 + k], wh1[k * HID + u], acc);
+            hid[idx] = fmaxf(acc, 0.f);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < H * XD; idx += nthreads) {
+            const int j = idx / XD, f = idx - j * XD;
+            float acc = bh2[f];
+#pragma unroll 8
+            for (int u = 0; u < HID; ++u) acc = fmaf(hid[j * HID + u], wh2[u * WLD + f], acc);
+            Xh[(j + 1) * XLD + f] = fmaxf(acc, 0.f);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < H * XD; idx += nthreads) {
+            const int j = idx / XD, g = idx - j * XD;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int f = 0; f < XD; ++f) acc = fmaf(Xh[(j + 1) * XLD + f], wa[f * WLD + g], acc);
+            Gm[(j + 1) * XLD + g] = acc;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < N * SLD; idx += nthreads) {
+            const int i = idx / SLD, j = idx - i * SLD;
+            float v = NEG_INF;
+            if (i >= 1 && j >= 1 && j < N) {
+                v = 0.f;
+#pragma unroll 8
+                for (int f = 0; f < XD; ++f) v = fmaf(Gm[i * XLD + f], Xh[j * XLD + f], v);
+            }
+            Shh[idx] = v;
+        }
+        __syncthreads();
+        if (tid < 32) {                     // crowd-only row maxima
+            float mx = NEG_INF;
+            if (tid >= 1 && tid < N)
+                for (int j = 1; j < N; ++j) mx = fmaxf(mx, Shh[tid * SLD + j]);
+            msh[tid] = mx;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < N * SLD; idx += nthreads) {
+            const int i = idx / SLD, j = idx - i * SLD;
+            Shh[idx] = (i >= 1 && j >= 1 && j < N) ? __expf(Shh[idx] - msh[i]) : 0.f;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < N * XD; idx += nthreads) {       // U_i = sum_j E_ij Xh_j ;  Zsh_i = sum_j E_ij
+            const int i = idx / XD, f = idx - i * XD;
+            float acc = 0.f, z = 0.f;
+            for (int j = 1; j < N; ++j) {
+                const float e = Shh[i * SLD + j];
+                acc = fmaf(e, Xh[j * XLD + f], acc);
+                z += e;
+            }
+            U[i * XLD + f] = acc;
+            if (f == 0) zsh[i] = z;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < N * XD; idx += nthreads) {       // UW_i = U_i W1
+            const int i = idx / XD, g = idx - i * XD;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int f = 0; f < XD; ++f) acc = fmaf(U[i * XLD + f], w1[f * WLD + g], acc);
+            UW[i * XLD + g] = acc;
+        }
+        __syncthreads();
+
+        // ---------------- B1/B2: per 16 children: x0, y = x0 W1, robot row / column of S -------------------
+        for (int ct = wave; ct < a.CT; ct += a.n_waves) {
+            const int c = 16 * ct + n;
+            const int cc = c < A ? c : A - 1;
+            const float* rr = a.child_robot + ((size_t)p * A + cc) * 9;
+            f32x4 hacc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int k = 4 * s + q;
+                const float b = k < 9 ? rr[k] : 0.f;
+#pragma unroll
+                for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wr1[k * W1LD + 16 * ht + n], b, hacc[ht]);
+            }
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&br1[16 * ht + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hacc[ht][r] = relu1(hacc[ht][r] + bb[r]);
+            }
+            f32x4 xacc[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot)
+                        xacc[ot] = mfma4(wr2[(16 * ht + 4 * q + r) * WLD + 16 * ot + n], hacc[ht][r], xacc[ot]);
+            }
+            load_fence();
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&br2[16 * ot + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xacc[ot][r] = relu1(xacc[ot][r] + bb[r]);
+                *reinterpret_cast<f32x4*>(&X0[c * XLD + 16 * ot + 4 * q]) = xacc[ot];
+            }
+            f32x4 gacc[2] = {zero4(), zero4()}, yacc[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int gt = 0; gt < 2; ++gt) {
+                        gacc[gt] = mfma4(wa[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], gacc[gt]);
+                        yacc[gt] = mfma4(w1[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], yacc[gt]);
+                    }
+            }
+            load_fence();
+            *reinterpret_cast<f32x4*>(&Y0[c * XLD + 4 * q]) = yacc[0];
+            *reinterpret_cast<f32x4*>(&Y0[c * XLD + 16 + 4 * q]) = yacc[1];
+            float s00 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s00 = fmaf(gacc[t][r], xacc[t][r], s00);
+            s00 = kgroups_sum(s00);
+            for (int nt = 0; nt < a.NT; ++nt) {
+                load_fence();
+                f32x4 sc = zero4(), s0 = zero4();
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    const f32x4 gq = *reinterpret_cast<const f32x4*>(&Gm[(16 * nt + n) * XLD + 16 * ot + 4 * q]);
+                    const f32x4 xq = *reinterpret_cast<const f32x4*>(&Xh[(16 * nt + n) * XLD + 16 * ot + 4 * q]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sc = mfma4(gq[r], xacc[ot][r], sc);
+                        s0 = mfma4(xq[r], gacc[ot][r], s0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int node = 16 * nt + 4 * q + r;
+                    float vs = sc[r], v0 = s0[r];
+                    if (node == 0) { vs = s00; v0 = s00; }
+                    if (node >= N) { vs = NEG_INF; v0 = NEG_INF; }
+                    if (node < SLD) { Sc0[c * SLD + node] = vs; S0[c * SLD + node] = v0; }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---------------- row phase: two children per pass (half-wave each), lane = feature -------------------
+        {
+            const int hh = lane >> 5, f = lane & 31;
+            float uwr[HR], xhr[HR];
+#pragma unroll
+            for (int i = 1; i < HR; ++i) {
+                uwr[i] = i < N ? UW[i * XLD + f] : 0.f;
+                xhr[i] = i < N ? Xh[i * XLD + f] : 0.f;
+            }
+            const float my_msh = (f >= 1 && f < N) ? msh[f] : 0.f;      // lane f doubles as row index i = f in the scalar step
+            const float my_zsh = (f >= 1 && f < N) ? zsh[f] : 1.f;
+            float* sc_mine = scal + (hh * 32) * 4;
+            const int n_pairs = (A + 1) / 2;
+            for (int pair = wave; pair < n_pairs; pair += a.n_waves) {
+                const int c = 2 * pair + hh;
+                const bool cv = c < A;
+                const int cc = cv ? c : A - 1;
+                // (1) per-row scalars; lane f = row i
+                const int i = f;
+                const float s0v = i < N ? S0[cc * SLD + i] : NEG_INF;
+                const float mx0 = half_max(s0v);
+                const float e0 = __expf(s0v - mx0);
+                const float z0 = half_sum(e0);
+                const float pv = e0 * __builtin_amdgcn_rcpf(z0);                  // A_c[0][i]
+                float av = 0.f, bv = 0.f;
+                if (i >= 1 && i < N) {
+                    const float scv = Sc0[cc * SLD + i];
+                    const float m = fmaxf(my_msh, scv);
+                    const float al = __expf(my_msh - m), be = __expf(scv - m);
+                    const float iz = __builtin_amdgcn_rcpf(fmaf(al, my_zsh, be));
+                    av = pv * al * iz;
+                    bv = pv * be * iz;
+                }
+                *reinterpret_cast<f32x4*>(&sc_mine[i * 4]) = f32x4{av, bv, i < N ? pv : 0.f, 0.f};
+                // (2) rows: racc = sum_i relu(a_i UW_i + b_i y) ; t0h = sum_i p_i Xh_i
+                const float yv = Y0[cc * XLD + f];
+                const float x0v = X0[cc * XLD + f];
+                float racc = 0.f, t0h = 0.f;
+#pragma unroll
+                for (int ii = 1; ii < HR; ++ii) {
+                    const f32x4 sv = *reinterpret_cast<const f32x4*>(&sc_mine[ii * 4]);
+                    t0h = fmaf(sv[2], xhr[ii], t0h);
+                    racc += relu1(fmaf(sv[0], uwr[ii], sv[1] * yv));
+                }
+                const float p00 = sc_mine[2];
+                // (3) hand the robot row to the batched MFMA pass
+                if (cv) {
+                    Y0[c * XLD + f] = fmaf(p00, x0v, t0h);                     // T_0 = (A_c X_c)[0]
+                    TP[c * XLD + f] = SKIP ? racc + t0h : racc;               // t_c without the robot-row term
+                    if (f == 0) P00[c] = p00;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---------------- robot row: H1_0 = relu(T_0 W1)(+x0), t_c += p00 * H1_0, rows out ---------------------
+        for (int ct = wave; ct < a.CT; ct += a.n_waves) {
+            const int c = 16 * ct + n;
+            f32x4 o[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+                load_fence();
+                const f32x4 tb = *reinterpret_cast<const f32x4*>(&Y0[c * XLD + 16 * ft + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot)
+                        o[ot] = mfma4(w1[(16 * ft + 4 * q + r) * WLD + 16 * ot + n], tb[r], o[ot]);
+            }
+            if (c < A) {
+                const float p00 = P00[c];
+                float* out = a.rows_out + ((size_t)p * A + c) * 64;
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(&X0[c * XLD + 16 * ot + 4 * q]);
+                    const f32x4 tp = *reinterpret_cast<const f32x4*>(&TP[c * XLD + 16 * ot + 4 * q]);
+                    f32x4 h, t;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float hv = relu1(o[ot][r]);
+                        if (SKIP) hv += xv[r];
+                        h[r] = hv;
+                        t[r] = fmaf(p00, hv, tp[r]);
+                    }
+                    *reinterpret_cast<f32x4*>(out + 16 * ot + 4 * q) = t;
+                    *reinterpret_cast<f32x4*>(out + 32 + 16 * ot + 4 * q) = h;
+                }
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -771,9 +1179,9 @@ inline ChildPlan plan_children(const RglGraph& g, int P, int A, int H) {
     return pl;
 }
 
-template <int KS, int MODE, bool VAGG>
-int launch_children_mode(const ChildPlan& pl, hipStream_t st) {
-    auto kern = children_graph_kernel<KS, MODE, VAGG>;
+template <int KS, int MODE, bool VAGG, bool SKIP>
+int launch_children_skip(const ChildPlan& pl, hipStream_t st) {
+    auto kern = children_graph_kernel<KS, MODE, VAGG, SKIP>;
     if (pl.lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)pl.lds_bytes));
@@ -782,6 +1190,11 @@ int launch_children_mode(const ChildPlan& pl, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(pl.a.n_waves * 64), pl.lds_bytes, st, pl.a);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
+}
+
+template <int KS, int MODE, bool VAGG>
+int launch_children_mode(const ChildPlan& pl, hipStream_t st) {
+    return pl.a.skip ? launch_children_skip<KS, MODE, VAGG, true>(pl, st) : launch_children_skip<KS, MODE, VAGG, false>(pl, st);
 }
 
 template <int KS>
@@ -1077,6 +1490,83 @@ int launch_scene(const SceneArgs& sa, size_t lds_bytes, hipStream_t st) {
     return RGL_OK;
 }
 
+
+struct Rank1Plan {
+    Rank1Args a;
+    size_t lds_bytes;
+    int hr;
+    bool ok;
+};
+
+inline bool rank1_enabled() {
+    static const bool off = [] { const char* e = getenv("RGL_CHILDREN_TILE_KERNEL"); return e && e[0] == '1'; }();
+    return !off;
+}
+
+inline Rank1Plan plan_rank1(const RglGraph& g, int P, int A, int H) {
+    Rank1Plan pl;
+    pl.ok = false;
+    if (!fast_path_enabled() || !rank1_enabled()) return pl;
+    if (g.similarity != RGL_SIM_EMBEDDED_GAUSSIAN || g.layerwise_graph || g.x_dim != XD || g.num_layer != 2) return pl;
+    if (!mlp_is(g.w_r, 9, HID, XD, true) || !mlp_is(g.w_h, 5, HID, XD, true)) return pl;
+    const int N = H + 1;
+    if (N > 32 || A > 96 || A < 1) return pl;
+    Rank1Args& a = pl.a;
+    a.N = N; a.H = H; a.A = A; a.P = P;
+    pl.hr = N <= 8 ? 8 : (N <= 20 ? 20 : 32);
+    a.SLD = N | 1;                              // odd row stride >= N
+    a.NT = (N + 15) / 16;
+    a.CT = (A + 15) / 16;
+    a.n_waves = 8;
+    int off = 0;
+    auto take = [&](int nfl) { int o = off; off += (nfl + 3) & ~3; return o; };
+    a.off_wh1 = take(5 * HID); a.off_bh1 = take(HID); a.off_wh2 = take(HID * WLD); a.off_bh2 = take(XD);
+    a.off_wa = take(XD * WLD); a.off_wr1 = take(12 * W1LD); a.off_br1 = take(HID); a.off_wr2 = take(HID * WLD);
+    a.off_br2 = take(XD); a.off_w1 = take(XD * WLD);
+    a.off_xh = take(16 * a.NT * XLD);
+    a.off_gm = take(16 * a.NT * XLD);
+    a.off_shh = take(N * a.SLD);
+    a.off_uw = take(32 * XLD);
+    a.off_msh = take(32);
+    a.off_zsh = take(32);
+    a.off_s0 = take(16 * a.CT * a.SLD);
+    a.off_sc0 = take(16 * a.CT * a.SLD);
+    a.off_x0 = take(16 * a.CT * XLD);
+    const int y0_floats = 16 * a.CT * XLD > H * HID ? 16 * a.CT * XLD : H * HID;      // also hosts `hid`
+    a.off_y0 = take(y0_floats);
+    const int tp_floats = 16 * a.CT * XLD > 32 * XLD ? 16 * a.CT * XLD : 32 * XLD;     // also hosts U
+    a.off_tp = take(tp_floats);
+    a.off_p00 = take(16 * a.CT);
+    a.off_scal = take(a.n_waves * 2 * 32 * 4);
+    pl.lds_bytes = (size_t)off * sizeof(float);
+    if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
+    a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];
+    a.wh1 = g.w_h.weight[0]; a.bh1 = g.w_h.bias[0]; a.wh2 = g.w_h.weight[1]; a.bh2 = g.w_h.bias[1];
+    a.wa = g.w_a; a.w1 = g.Ws[0];
+    pl.ok = true;
+    return pl;
+}
+
+template <int HR, bool SKIP>
+int launch_rank1_t(const Rank1Plan& pl, hipStream_t st) {
+    auto kern = children_rank1_kernel<HR, SKIP>;
+    if (pl.lds_bytes > 64 * 1024)
+        RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)pl.lds_bytes));
+    const int grid = pl.a.P < 256 ? pl.a.P : 256;          // persistent: one 16-wave workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(pl.a.n_waves * 64), pl.lds_bytes, st, pl.a);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
+inline int launch_rank1(const Rank1Plan& pl, bool skip, hipStream_t st) {
+    switch (pl.hr) {
+        case 8: return skip ? launch_rank1_t<8, true>(pl, st) : launch_rank1_t<8, false>(pl, st);
+        case 20: return skip ? launch_rank1_t<20, true>(pl, st) : launch_rank1_t<20, false>(pl, st);
+        default: return skip ? launch_rank1_t<32, true>(pl, st) : launch_rank1_t<32, false>(pl, st);
+    }
+}
+
 }  // namespace
 
 #ifdef RGL_PHASE_TIMING
@@ -1161,6 +1651,13 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
     cp.a.humans = humans_next;
     cp.a.rows_out = (float*)workspace;
     int rc;
+    Rank1Plan rp = plan_rank1(pl->value_graph, P, A, H);
+    if (rp.ok) {
+        rp.a.child_robot = child_robot;
+        rp.a.humans = humans_next;
+        rp.a.rows_out = (float*)workspace;
+        rc = launch_rank1(rp, pl->value_graph.skip_connection != 0, stream);
+    } else
     switch (cp.ks_bucket) {
         case 2: rc = launch_children<2>(cp, stream); break;
         case 5: rc = launch_children<5>(cp, stream); break;
