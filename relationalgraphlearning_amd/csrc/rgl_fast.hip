@@ -615,7 +615,8 @@ struct Rank1Args {
     int P, A, H, N, CT, NT, SLD, n_waves;
     float* rows_out;                      // [P*A][64]
     int off_wh1, off_bh1, off_wh2, off_bh2, off_wa, off_wr1, off_br1, off_wr2, off_br2, off_w1;   // weight image
-    int off_xh, off_gm, off_shh, off_uw, off_msh, off_zsh, off_s0, off_sc0, off_x0, off_y0, off_tp, off_p00, off_scal;
+    int off_crowd, crowd_stride;          // double-buffered crowd block: Xh | Gm | UW | msh | zsh
+    int off_s0, off_sc0, off_x0, off_y0, off_tp, off_p00, off_scal;
 };
 
 #define DPP_QUAD_XOR1 0xB1
@@ -645,7 +646,7 @@ __device__ __forceinline__ float half_sum(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <int HR, bool SKIP>      // HR >= N: human rows held in registers (padded rows contribute exactly 0)
+template <int HR, int NT, bool SKIP>      // HR >= N: human rows held in registers (padded rows contribute exactly 0)
 __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -653,36 +654,37 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
     const int nthreads = a.n_waves * 64;
     const int n = lane & 15, q = lane >> 4;
     const int N = a.N, H = a.H, A = a.A, SLD = a.SLD;
-    const float* wh1 = lds + a.off_wh1;
+    const float* wh1 = lds + a.off_wh1;   // [8][W1LD], rows 5..7 zero
     const float* bh1 = lds + a.off_bh1;
-    const float* wh2 = lds + a.off_wh2;
+    const float* wh2 = lds + a.off_wh2;   // [HID][WLD]
     const float* bh2 = lds + a.off_bh2;
-    const float* wa = lds + a.off_wa;
-    const float* wr1 = lds + a.off_wr1;
+    const float* wa = lds + a.off_wa;     // [XD][WLD]
+    const float* wr1 = lds + a.off_wr1;   // [12][W1LD], rows 9..11 zero
     const float* br1 = lds + a.off_br1;
     const float* wr2 = lds + a.off_wr2;
     const float* br2 = lds + a.off_br2;
     const float* w1 = lds + a.off_w1;     // [XD][WLD]
-    float* Xh = lds + a.off_xh;           // [16*NT][XLD]
-    float* Gm = lds + a.off_gm;           // [16*NT][XLD]
-    float* Shh = lds + a.off_shh;         // [N][SLD]   S_ij, later E_ij = exp(S_ij - msh_i)
-    float* UW = lds + a.off_uw;           // [N][XLD]
-    float* msh = lds + a.off_msh;         // [32]
-    float* zsh = lds + a.off_zsh;         // [32]
     float* S0 = lds + a.off_s0;           // [16*CT][SLD]
     float* Sc0 = lds + a.off_sc0;         // [16*CT][SLD]
     float* X0 = lds + a.off_x0;           // [16*CT][XLD]
     float* Y0 = lds + a.off_y0;           // [16*CT][XLD]  x0 W1, later T_0
     float* TP = lds + a.off_tp;           // [16*CT][XLD]  t_c without the robot-row term
     float* P00 = lds + a.off_p00;         // [16*CT]
-    float* hid = Y0;                      // [H][HID] (prologue only; 16*CT*XLD >= H*HID is checked on the host)
-    float* U = TP;                        // [N][XLD]  (prologue only)
     float* scal = lds + a.off_scal + wave * (2 * 32 * 4);   // [2][32][4] per wave
     const float NEG_INF = -INFINITY;
+    // crowd block b: Xh[16*NT][XLD] | Gm[16*NT][XLD] | UW[16*NT][XLD] | msh[16*NT] | zsh[16*NT]
+    auto crowd_xh = [&](int b) { return lds + a.off_crowd + b * a.crowd_stride; };
+    auto crowd_gm = [&](int b) { return lds + a.off_crowd + b * a.crowd_stride + 16 * NT * XLD; };
+    auto crowd_uw = [&](int b) { return lds + a.off_crowd + b * a.crowd_stride + 2 * 16 * NT * XLD; };
+    auto crowd_msh = [&](int b) { return lds + a.off_crowd + b * a.crowd_stride + 3 * 16 * NT * XLD; };
+    auto crowd_zsh = [&](int b) { return lds + a.off_crowd + b * a.crowd_stride + 3 * 16 * NT * XLD + 16 * NT; };
 
     {   // weight image, once per workgroup
         float* w = lds;
-        for (int i = tid; i < 5 * HID; i += nthreads) w[a.off_wh1 + i] = a.wh1[i];
+        for (int i = tid; i < 8 * HID; i += nthreads) {
+            const int r = i / HID, c = i - r * HID;
+            w[a.off_wh1 + r * W1LD + c] = r < 5 ? a.wh1[i] : 0.f;
+        }
         for (int i = tid; i < HID; i += nthreads) { w[a.off_bh1 + i] = a.bh1[i]; w[a.off_br1 + i] = a.br1[i]; }
         for (int i = tid; i < XD; i += nthreads) { w[a.off_bh2 + i] = a.bh2[i]; w[a.off_br2 + i] = a.br2[i]; }
         for (int i = tid; i < HID * XD; i += nthreads) {
@@ -702,81 +704,153 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
     }
     __syncthreads();
 
-    for (int p = blockIdx.x; p < a.P; p += gridDim.x) {
-        // ---------------- prologue (crowd only) ----------------------------------------------------------
-        const float* hsrc = a.humans + (size_t)p * H * 5;
-        for (int idx = tid; idx < 16 * a.NT * XLD; idx += nthreads) { Xh[idx] = 0.f; Gm[idx] = 0.f; }
-        for (int idx = tid; idx < H * HID; idx += nthreads) {
-            const int j = idx / HID, u = idx - j * HID;
-            float acc = bh1[u];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) acc = fmaf(hsrc[j * 5 + k], wh1[k * HID + u], acc);
-            hid[idx] = fmaxf(acc, 0.f);
-        }
-        __syncthreads();
-        for (int idx = tid; idx < H * XD; idx += nthreads) {
-            const int j = idx / XD, f = idx - j * XD;
-            float acc = bh2[f];
-#pragma unroll 8
-            for (int u = 0; u < HID; ++u) acc = fmaf(hid[j * HID + u], wh2[u * WLD + f], acc);
-            Xh[(j + 1) * XLD + f] = fmaxf(acc, 0.f);
-        }
-        __syncthreads();
-        for (int idx = tid; idx < H * XD; idx += nthreads) {
-            const int j = idx / XD, g = idx - j * XD;
-            float acc = 0.f;
-#pragma unroll 8
-            for (int f = 0; f < XD; ++f) acc = fmaf(Xh[(j + 1) * XLD + f], wa[f * WLD + g], acc);
-            Gm[(j + 1) * XLD + g] = acc;
-        }
-        __syncthreads();
-        for (int idx = tid; idx < N * SLD; idx += nthreads) {
-            const int i = idx / SLD, j = idx - i * SLD;
-            float v = NEG_INF;
-            if (i >= 1 && j >= 1 && j < N) {
-                v = 0.f;
-#pragma unroll 8
-                for (int f = 0; f < XD; ++f) v = fmaf(Gm[i * XLD + f], Xh[j * XLD + f], v);
-            }
-            Shh[idx] = v;
-        }
-        __syncthreads();
-        if (tid < 32) {                     // crowd-only row maxima
-            float mx = NEG_INF;
-            if (tid >= 1 && tid < N)
-                for (int j = 1; j < N; ++j) mx = fmaxf(mx, Shh[tid * SLD + j]);
-            msh[tid] = mx;
-        }
-        __syncthreads();
-        for (int idx = tid; idx < N * SLD; idx += nthreads) {
-            const int i = idx / SLD, j = idx - i * SLD;
-            Shh[idx] = (i >= 1 && j >= 1 && j < N) ? __expf(Shh[idx] - msh[i]) : 0.f;
-        }
-        __syncthreads();
-        for (int idx = tid; idx < N * XD; idx += nthreads) {       // U_i = sum_j E_ij Xh_j ;  Zsh_i = sum_j E_ij
-            const int i = idx / XD, f = idx - i * XD;
-            float acc = 0.f, z = 0.f;
-            for (int j = 1; j < N; ++j) {
-                const float e = Shh[i * SLD + j];
-                acc = fmaf(e, Xh[j * XLD + f], acc);
-                z += e;
-            }
-            U[i * XLD + f] = acc;
-            if (f == 0) zsh[i] = z;
-        }
-        __syncthreads();
-        for (int idx = tid; idx < N * XD; idx += nthreads) {       // UW_i = U_i W1
-            const int i = idx / XD, g = idx - i * XD;
-            float acc = 0.f;
-#pragma unroll 8
-            for (int f = 0; f < XD; ++f) acc = fmaf(U[i * XLD + f], w1[f * WLD + g], acc);
-            UW[i * XLD + g] = acc;
-        }
-        __syncthreads();
+    // Wave roles in the embedding phase: waves [0, CT) embed 16 children each; waves [CT, CT+NT) run the crowd-only
+    // prologue of the NEXT parent (one 16-node column tile each) into the other crowd buffer.
+    const bool child_wave = wave < a.CT;
+    const int pct = wave - a.CT;                       // prologue column tile
+    const bool crowd_wave = pct >= 0 && pct < NT;
+    f32x4 pg[2];                                       // prologue: G^T of my column tile, carried across the mid barrier
+    bool node_ok = false;
+    int node = 0;
 
-        // ---------------- B1/B2: per 16 children: x0, y = x0 W1, robot row / column of S -------------------
-        for (int ct = wave; ct < a.CT; ct += a.n_waves) {
-            const int c = 16 * ct + n;
+    // crowd prologue, part 1: Xh = w_h(humans), G = Xh Wa   (transposed MFMA chain, 16 nodes per wave)
+    auto prologue1 = [&](int pp, int b) {
+        float* Xh = crowd_xh(b);
+        float* Gm = crowd_gm(b);
+        node = 16 * pct + n;
+        node_ok = node >= 1 && node < N;
+        const float* hsrc = a.humans + ((size_t)pp * H + (node_ok ? node - 1 : 0)) * 5;
+        f32x4 hacc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = 4 * s + q;
+            const float bv = (node_ok && k < 5) ? hsrc[k] : 0.f;
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wh1[k * W1LD + 16 * ht + n], bv, hacc[ht]);
+        }
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(&bh1[16 * ht + 4 * q]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hacc[ht][r] = relu1(hacc[ht][r] + bb[r]);
+        }
+        f32x4 xacc[2] = {zero4(), zero4()};
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            load_fence();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+                    xacc[ot] = mfma4(wh2[(16 * ht + 4 * q + r) * WLD + 16 * ot + n], hacc[ht][r], xacc[ot]);
+        }
+        load_fence();
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(&bh2[16 * ot + 4 * q]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xacc[ot][r] = node_ok ? relu1(xacc[ot][r] + bb[r]) : 0.f;   // robot slot / padding rows are zero
+            *reinterpret_cast<f32x4*>(&Xh[node * XLD + 16 * ot + 4 * q]) = xacc[ot];
+        }
+        pg[0] = zero4();
+        pg[1] = zero4();
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+            load_fence();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int gt = 0; gt < 2; ++gt)
+                    pg[gt] = mfma4(wa[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], pg[gt]);
+        }
+        load_fence();
+        *reinterpret_cast<f32x4*>(&Gm[node * XLD + 4 * q]) = pg[0];
+        *reinterpret_cast<f32x4*>(&Gm[node * XLD + 16 + 4 * q]) = pg[1];
+    };
+    // part 2 (needs every Xh row): S_ij = G_i . Xh_j over humans j, msh/E/Zsh, U = E Xh, UW = U W1
+    auto prologue2 = [&](int b) {
+        const float* Xh = crowd_xh(b);
+        float* UW = crowd_uw(b);
+        f32x4 e[NT];
+        float mx = NEG_INF;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            load_fence();
+            f32x4 sacc = zero4();
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+                const f32x4 xa = *reinterpret_cast<const f32x4*>(&Xh[(16 * jt + n) * XLD + 16 * ft + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc = mfma4(xa[r], pg[ft][r], sacc);      // [j = 16jt+4q+r][i = my node]
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * jt + 4 * q + r;
+                if (j < 1 || j >= N) sacc[r] = NEG_INF;
+                mx = fmaxf(mx, sacc[r]);
+            }
+            e[jt] = sacc;
+        }
+        mx = kgroups_max(mx);
+        if (!node_ok) mx = 0.f;
+        float z = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e[jt][r] = node_ok ? __expf(e[jt][r] - mx) : 0.f;
+                z += e[jt][r];
+            }
+        z = kgroups_sum(z);
+        if (q == 0) {
+            crowd_msh(b)[node] = mx;
+            crowd_zsh(b)[node] = node_ok ? z : 1.f;
+        }
+        f32x4 u[2] = {zero4(), zero4()};
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            load_fence();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a0 = Xh[(16 * jt + 4 * q + r) * XLD + n];
+                const float a1 = Xh[(16 * jt + 4 * q + r) * XLD + 16 + n];
+                u[0] = mfma4(a0, e[jt][r], u[0]);                                         // U^T[f][i] = sum_j Xh[j][f] E[i][j]
+                u[1] = mfma4(a1, e[jt][r], u[1]);
+            }
+        }
+        f32x4 uw[2] = {zero4(), zero4()};
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+            load_fence();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+                    uw[ot] = mfma4(w1[(16 * ft + 4 * q + r) * WLD + 16 * ot + n], u[ft][r], uw[ot]);
+        }
+        load_fence();
+        *reinterpret_cast<f32x4*>(&UW[node * XLD + 4 * q]) = uw[0];
+        *reinterpret_cast<f32x4*>(&UW[node * XLD + 16 + 4 * q]) = uw[1];
+    };
+
+    PHASE_START();
+    int buf = 0;
+    if ((int)blockIdx.x < a.P) {               // prime the pipeline: crowd block of the first parent
+        if (crowd_wave) prologue1(blockIdx.x, 0);
+        __syncthreads();
+        if (crowd_wave) prologue2(0);
+        __syncthreads();
+    }
+    for (int p = blockIdx.x; p < a.P; p += gridDim.x) {
+        PHASE_MARK(0);
+        const int pn = p + gridDim.x;
+        const float* Xh = crowd_xh(buf);
+        const float* Gm = crowd_gm(buf);
+        // ---------------- embedding phase, first half: x0, y = x0 W1, g0 = x0 Wa  ||  prologue1(next parent) -----
+        f32x4 xacc[2] = {zero4(), zero4()}, gacc[2] = {zero4(), zero4()};
+        const int c = 16 * wave + n;              // meaningful for child waves only
+        float s00 = 0.f;
+        if (child_wave) {
             const int cc = c < A ? c : A - 1;
             const float* rr = a.child_robot + ((size_t)p * A + cc) * 9;
             f32x4 hacc[4] = {zero4(), zero4(), zero4(), zero4()};
@@ -793,7 +867,6 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hacc[ht][r] = relu1(hacc[ht][r] + bb[r]);
             }
-            f32x4 xacc[2] = {zero4(), zero4()};
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) {
                 load_fence();
@@ -811,7 +884,7 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
                 for (int r = 0; r < 4; ++r) xacc[ot][r] = relu1(xacc[ot][r] + bb[r]);
                 *reinterpret_cast<f32x4*>(&X0[c * XLD + 16 * ot + 4 * q]) = xacc[ot];
             }
-            f32x4 gacc[2] = {zero4(), zero4()}, yacc[2] = {zero4(), zero4()};
+            f32x4 yacc[2] = {zero4(), zero4()};
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
                 load_fence();
@@ -826,13 +899,21 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
             load_fence();
             *reinterpret_cast<f32x4*>(&Y0[c * XLD + 4 * q]) = yacc[0];
             *reinterpret_cast<f32x4*>(&Y0[c * XLD + 16 + 4 * q]) = yacc[1];
-            float s00 = 0.f;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s00 = fmaf(gacc[t][r], xacc[t][r], s00);
             s00 = kgroups_sum(s00);
-            for (int nt = 0; nt < a.NT; ++nt) {
+        } else if (crowd_wave && pn < a.P) {
+            prologue1(pn, buf ^ 1);
+        }
+        PHASE_MARK(1);
+        __syncthreads();
+        PHASE_MARK(2);
+        // ---------------- embedding phase, second half: robot row / column of S  ||  prologue2(next parent) -------
+        if (child_wave) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
                 load_fence();
                 f32x4 sc = zero4(), s0 = zero4();
 #pragma unroll
@@ -847,18 +928,23 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int node = 16 * nt + 4 * q + r;
+                    const int nd = 16 * nt + 4 * q + r;
                     float vs = sc[r], v0 = s0[r];
-                    if (node == 0) { vs = s00; v0 = s00; }
-                    if (node >= N) { vs = NEG_INF; v0 = NEG_INF; }
-                    if (node < SLD) { Sc0[c * SLD + node] = vs; S0[c * SLD + node] = v0; }
+                    if (nd == 0) { vs = s00; v0 = s00; }
+                    if (nd >= N) { vs = NEG_INF; v0 = NEG_INF; }
+                    if (nd < SLD) { Sc0[c * SLD + nd] = vs; S0[c * SLD + nd] = v0; }
                 }
             }
+        } else if (crowd_wave && pn < a.P) {
+            prologue2(buf ^ 1);
         }
+        PHASE_MARK(3);
         __syncthreads();
+        PHASE_MARK(4);
 
         // ---------------- row phase: two children per pass (half-wave each), lane = feature -------------------
         {
+            const float* UW = crowd_uw(buf);
             const int hh = lane >> 5, f = lane & 31;
             float uwr[HR], xhr[HR];
 #pragma unroll
@@ -866,14 +952,14 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
                 uwr[i] = i < N ? UW[i * XLD + f] : 0.f;
                 xhr[i] = i < N ? Xh[i * XLD + f] : 0.f;
             }
-            const float my_msh = (f >= 1 && f < N) ? msh[f] : 0.f;      // lane f doubles as row index i = f in the scalar step
-            const float my_zsh = (f >= 1 && f < N) ? zsh[f] : 1.f;
+            const float my_msh = (f >= 1 && f < N) ? crowd_msh(buf)[f] : 0.f;      // lane f doubles as row index i = f
+            const float my_zsh = (f >= 1 && f < N) ? crowd_zsh(buf)[f] : 1.f;
             float* sc_mine = scal + (hh * 32) * 4;
             const int n_pairs = (A + 1) / 2;
             for (int pair = wave; pair < n_pairs; pair += a.n_waves) {
-                const int c = 2 * pair + hh;
-                const bool cv = c < A;
-                const int cc = cv ? c : A - 1;
+                const int ch = 2 * pair + hh;
+                const bool cv = ch < A;
+                const int cc = cv ? ch : A - 1;
                 // (1) per-row scalars; lane f = row i
                 const int i = f;
                 const float s0v = i < N ? S0[cc * SLD + i] : NEG_INF;
@@ -904,17 +990,18 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
                 const float p00 = sc_mine[2];
                 // (3) hand the robot row to the batched MFMA pass
                 if (cv) {
-                    Y0[c * XLD + f] = fmaf(p00, x0v, t0h);                     // T_0 = (A_c X_c)[0]
-                    TP[c * XLD + f] = SKIP ? racc + t0h : racc;               // t_c without the robot-row term
-                    if (f == 0) P00[c] = p00;
+                    Y0[ch * XLD + f] = fmaf(p00, x0v, t0h);                    // T_0 = (A_c X_c)[0]
+                    TP[ch * XLD + f] = SKIP ? racc + t0h : racc;              // t_c without the robot-row term
+                    if (f == 0) P00[ch] = p00;
                 }
             }
         }
+        PHASE_MARK(5);
         __syncthreads();
+        PHASE_MARK(6);
 
         // ---------------- robot row: H1_0 = relu(T_0 W1)(+x0), t_c += p00 * H1_0, rows out ---------------------
-        for (int ct = wave; ct < a.CT; ct += a.n_waves) {
-            const int c = 16 * ct + n;
+        if (child_wave) {
             f32x4 o[2] = {zero4(), zero4()};
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
@@ -946,8 +1033,11 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
                 }
             }
         }
+        PHASE_MARK(7);
         __syncthreads();
+        buf ^= 1;
     }
+    PHASE_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1517,25 +1607,19 @@ inline Rank1Plan plan_rank1(const RglGraph& g, int P, int A, int H) {
     a.SLD = N | 1;                              // odd row stride >= N
     a.NT = (N + 15) / 16;
     a.CT = (A + 15) / 16;
-    a.n_waves = 8;
+    a.n_waves = 8;                              // CT (<= 6) child waves + NT (<= 2) crowd waves
     int off = 0;
     auto take = [&](int nfl) { int o = off; off += (nfl + 3) & ~3; return o; };
-    a.off_wh1 = take(5 * HID); a.off_bh1 = take(HID); a.off_wh2 = take(HID * WLD); a.off_bh2 = take(XD);
+    a.off_wh1 = take(8 * W1LD); a.off_bh1 = take(HID); a.off_wh2 = take(HID * WLD); a.off_bh2 = take(XD);
     a.off_wa = take(XD * WLD); a.off_wr1 = take(12 * W1LD); a.off_br1 = take(HID); a.off_wr2 = take(HID * WLD);
     a.off_br2 = take(XD); a.off_w1 = take(XD * WLD);
-    a.off_xh = take(16 * a.NT * XLD);
-    a.off_gm = take(16 * a.NT * XLD);
-    a.off_shh = take(N * a.SLD);
-    a.off_uw = take(32 * XLD);
-    a.off_msh = take(32);
-    a.off_zsh = take(32);
+    a.crowd_stride = 3 * 16 * a.NT * XLD + 2 * 16 * a.NT;
+    a.off_crowd = take(2 * a.crowd_stride);
     a.off_s0 = take(16 * a.CT * a.SLD);
     a.off_sc0 = take(16 * a.CT * a.SLD);
     a.off_x0 = take(16 * a.CT * XLD);
-    const int y0_floats = 16 * a.CT * XLD > H * HID ? 16 * a.CT * XLD : H * HID;      // also hosts `hid`
-    a.off_y0 = take(y0_floats);
-    const int tp_floats = 16 * a.CT * XLD > 32 * XLD ? 16 * a.CT * XLD : 32 * XLD;     // also hosts U
-    a.off_tp = take(tp_floats);
+    a.off_y0 = take(16 * a.CT * XLD);
+    a.off_tp = take(16 * a.CT * XLD);
     a.off_p00 = take(16 * a.CT);
     a.off_scal = take(a.n_waves * 2 * 32 * 4);
     pl.lds_bytes = (size_t)off * sizeof(float);
@@ -1547,9 +1631,9 @@ inline Rank1Plan plan_rank1(const RglGraph& g, int P, int A, int H) {
     return pl;
 }
 
-template <int HR, bool SKIP>
+template <int HR, int NT, bool SKIP>
 int launch_rank1_t(const Rank1Plan& pl, hipStream_t st) {
-    auto kern = children_rank1_kernel<HR, SKIP>;
+    auto kern = children_rank1_kernel<HR, NT, SKIP>;
     if (pl.lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)pl.lds_bytes));
@@ -1561,9 +1645,10 @@ int launch_rank1_t(const Rank1Plan& pl, hipStream_t st) {
 
 inline int launch_rank1(const Rank1Plan& pl, bool skip, hipStream_t st) {
     switch (pl.hr) {
-        case 8: return skip ? launch_rank1_t<8, true>(pl, st) : launch_rank1_t<8, false>(pl, st);
-        case 20: return skip ? launch_rank1_t<20, true>(pl, st) : launch_rank1_t<20, false>(pl, st);
-        default: return skip ? launch_rank1_t<32, true>(pl, st) : launch_rank1_t<32, false>(pl, st);
+        case 8: return skip ? launch_rank1_t<8, 1, true>(pl, st) : launch_rank1_t<8, 1, false>(pl, st);
+        case 20: return pl.a.NT == 1 ? (skip ? launch_rank1_t<20, 1, true>(pl, st) : launch_rank1_t<20, 1, false>(pl, st))
+                                     : (skip ? launch_rank1_t<20, 2, true>(pl, st) : launch_rank1_t<20, 2, false>(pl, st));
+        default: return skip ? launch_rank1_t<32, 2, true>(pl, st) : launch_rank1_t<32, 2, false>(pl, st);
     }
 }
 

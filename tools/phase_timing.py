@@ -39,9 +39,10 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     raw.rgl_debug_read_phase_cycles(buf, 1)
-    names = ["loop/prev barrier", "prologue", "B1/B2 work", "B1/B2 barrier", "B3 work", "end barrier"]
-    waves = 7 * P * reps          # per (wave, parent); 7 waves per workgroup at N=20, A=81
-    tot = sum(buf[i] for i in range(6))
+    names = ["loop", "embed-1 / crowd-1 work", "mid barrier", "embed-2 / crowd-2 work", "barrier", "row phase work",
+             "row barrier", "robot-row pass (+end barrier next loop)"]
+    waves = 8 * P * reps          # per (wave, parent); rank-1 kernel, 8 waves per workgroup
+    tot = sum(buf[i] for i in range(8))
     print("P=%d  %.3f ms per call (stage 1+2)" % (P, e0.elapsed_time(e1) / reps))
     for i, nm in enumerate(names):
         print("  %-18s %9.0f cycles per wave per parent   %5.1f %%" % (nm, buf[i] / waves, 100.0 * buf[i] / tot))
