@@ -133,52 +133,84 @@ __global__ void gather_parent_humans_kernel(const float* __restrict__ humans, in
     out[i] = humans[(p / humans_per) * H * 5 + rest];
 }
 
-// One thread per parent: one-step values, top-w clipping, next level's robot states.
-__global__ void mprl_select_kernel(const float* __restrict__ reward, const float* __restrict__ child_value,
+__device__ __forceinline__ int bi_fallback(const int* kl, int k) { return k > 0 ? kl[k - 1] : 0; }
+
+// One WAVE per parent: one-step values, top-w clipping (argpartition semantics; sparse: one action per group in
+// descending value order), next level's robot states.  Lane l owns actions l, l+64, l+128, l+192.
+__global__ __launch_bounds__(256) void mprl_select_kernel(const float* __restrict__ reward, const float* __restrict__ child_value,
                                    const float* __restrict__ child_robot, const int* __restrict__ groups, int P,
                                    int A, int W, int clip, int sparse, float gamma_f, float* __restrict__ value1,
                                    int* __restrict__ keep, float* __restrict__ next_robot) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int kept_lds[4][RGL_MAX_ACTIONS];         // per-wave copy of the kept indices for the gather below
+    const int lane = threadIdx.x & 63;
+    int* kl = kept_lds[threadIdx.x >> 6];
+    const int p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= P) return;
     const float* rw = reward + (size_t)p * A;
     const float* cv = child_value + (size_t)p * A;
     float* v1 = value1 + (size_t)p * A;
-    for (int a = 0; a < A; ++a) v1[a] = __fadd_rn(rw[a], __fmul_rn(gamma_f, cv[a]));
+    float val[4];
+    bool avail[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int a = lane + 64 * k;
+        avail[k] = a < A;
+        val[k] = 0.f;
+        if (avail[k]) {
+            val[k] = __fadd_rn(rw[a], __fmul_rn(gamma_f, cv[a]));
+            v1[a] = val[k];
+        }
+    }
     int* kp = keep + (size_t)p * W;
     if (!clip) {
-        for (int a = 0; a < A; ++a) kp[a] = a;
+        for (int a = lane; a < A; a += 64) { kp[a] = a; kl[a] = a; }
     } else {
-        unsigned long long taken[RGL_MAX_ACTIONS / 64] = {0, 0, 0, 0};
-        unsigned long long seen_groups = 0ull;          // sparse search: <= 64 groups
-        int n = 0;
-        while (n < W) {
-            int best = -1;
+        unsigned long long seen_groups = 0ull;          // sparse search: <= 64 groups (wave-uniform)
+        int nkept = 0;
+        while (nkept < W) {
+            // lane-local best: larger value first, then lower index; a NaN is only taken when nothing else is left
+            int bi = -1;
             float bv = 0.f;
-            for (int a = 0; a < A; ++a) {
-                if (taken[a >> 6] & (1ull << (a & 63))) continue;
-                const float v = v1[a];
-                if (best < 0 || v > bv || (bv != bv && v == v)) {   // a NaN is only kept when nothing else is left
-                    best = a;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!avail[k]) continue;
+                const float v = val[k];
+                if (bi < 0 || v > bv || (bv != bv && v == v)) {
+                    bi = lane + 64 * k;
                     bv = v;
                 }
             }
-            if (best < 0) break;
-            taken[best >> 6] |= 1ull << (best & 63);
+            // wave argmax over (value, index)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ov = __shfl_xor(bv, off);
+                const int oi = __shfl_xor(bi, off);
+                const bool take = oi >= 0 && (bi < 0 || ov > bv || (bv != bv && ov == ov) || (ov == bv && oi < bi));
+                if (take) {
+                    bv = ov;
+                    bi = oi;
+                }
+            }
+            if (bi < 0) break;                          // nothing left (wave-uniform)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (lane + 64 * k == bi) avail[k] = false;
             if (sparse) {
-                const int gi = groups[best];
+                const int gi = groups[bi];
                 if (seen_groups & (1ull << gi)) continue;
                 seen_groups |= 1ull << gi;
             }
-            kp[n++] = best;
+            if (lane == 0) { kp[nkept] = bi; kl[nkept] = bi; }
+            ++nkept;
         }
-        for (; n < W; ++n) kp[n] = kp[n > 0 ? n - 1 : 0];   // unreachable for validated inputs
+        if (lane == 0)
+            for (int k = nkept; k < W; ++k) { kp[k] = bi_fallback(kl, k); kl[k] = kp[k]; }   // unreachable for validated inputs
     }
     if (next_robot) {
-        for (int k = 0; k < W; ++k) {
-            const float* src = child_robot + ((size_t)p * A + kp[k]) * 9;
-            float* dst = next_robot + ((size_t)p * W + k) * 9;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) dst[i] = src[i];
+        for (int idx = lane; idx < W * 9; idx += 64) {      // same wave wrote kl: LDS operations of a wave execute in order
+            const int k = idx / 9, i = idx - k * 9;
+            const int a = kl[k];
+            next_robot[((size_t)p * W + k) * 9 + i] = child_robot[((size_t)p * A + a) * 9 + i];
         }
     }
 }
@@ -571,7 +603,7 @@ extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* rob
                           (float*)(ws + L.child_value), ws + scratch_off, (size_t)scratch_bytes, st);
         if (rc) return rc;
         float* next_robot = l + 1 < D ? (float*)(ws + lv[l + 1].robot) : nullptr;
-        hipLaunchKernelGGL(mprl_select_kernel, grid_for(P, 64), dim3(64), 0, st, (const float*)(ws + L.reward),
+        hipLaunchKernelGGL(mprl_select_kernel, grid_for(P, 4), dim3(256), 0, st, (const float*)(ws + L.reward),
                            (const float*)(ws + L.child_value), (const float*)(ws + L.child_robot), pl.action_groups, P, A,
                            W, pl.do_action_clip, pl.sparse_search, gamma_f, (float*)(ws + L.value1), (int*)(ws + L.keep),
                            next_robot);
