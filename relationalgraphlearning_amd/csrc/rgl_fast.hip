@@ -1058,9 +1058,9 @@ struct Tiles { static constexpr int v = (D + 15) / 16; };
 // A-fragment image of W (k-major [IN][OUT]) for the transposed product: fragment (ot, it, r), lane (i = l&15, q):
 //   W[in = 16*it + 4q + r][out = 16*ot + i]   (0 outside)
 template <int IN, int OUT>
-__device__ __forceinline__ void fill_frags(float* dst, const float* __restrict__ W, int tid) {
+__device__ __forceinline__ void fill_frags(float* dst, const float* __restrict__ W, int tid, int nthr = kThreads) {
     constexpr int IT = Tiles<IN>::v, OT = Tiles<OUT>::v;
-    for (int idx = tid; idx < OT * IT * 4 * 64; idx += kThreads) {
+    for (int idx = tid; idx < OT * IT * 4 * 64; idx += nthr) {
         const int l = idx & 63, fr = idx >> 6;
         const int r = fr & 3, it = (fr >> 2) % IT, ot = (fr >> 2) / IT;
         const int in = 16 * it + 4 * (l >> 4) + r, out = 16 * ot + (l & 15);
@@ -1069,16 +1069,18 @@ __device__ __forceinline__ void fill_frags(float* dst, const float* __restrict__
 }
 
 template <int OUT>
-__device__ __forceinline__ void fill_bias(float* dst, const float* __restrict__ b, int tid) {
-    for (int idx = tid; idx < Tiles<OUT>::v * 16; idx += kThreads) dst[idx] = idx < OUT ? b[idx] : 0.f;
+__device__ __forceinline__ void fill_bias(float* dst, const float* __restrict__ b, int tid, int nthr = kThreads) {
+    for (int idx = tid; idx < Tiles<OUT>::v * 16; idx += nthr) dst[idx] = idx < OUT ? b[idx] : 0.f;
 }
 
+// out = W^T in (+ bias): the accumulators START at the bias (no zero-init moves, no add afterwards).
 template <int IN, int OUT>
 __device__ __forceinline__ void layer_mfma(const float* frags, const f32x4 (&in)[Tiles<IN>::v], f32x4 (&out)[Tiles<OUT>::v],
-                                           int lane) {
+                                           int lane, const float* bias = nullptr) {
     constexpr int IT = Tiles<IN>::v, OT = Tiles<OUT>::v;
+    const int q = lane >> 4;
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) out[ot] = zero4();
+    for (int ot = 0; ot < OT; ++ot) out[ot] = bias ? *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * q]) : zero4();
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         load_fence();
@@ -1088,6 +1090,14 @@ __device__ __forceinline__ void layer_mfma(const float* frags, const f32x4 (&in)
             for (int ot = 0; ot < OT; ++ot) out[ot] = mfma4(frags[((ot * IT + it) * 4 + r) * 64 + lane], in[it][r], out[ot]);
     }
     load_fence();
+}
+
+template <int OUT>
+__device__ __forceinline__ void relu_tiles(f32x4 (&x)[Tiles<OUT>::v]) {
+#pragma unroll
+    for (int ot = 0; ot < Tiles<OUT>::v; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[ot][r] = relu1(x[ot][r]);
 }
 
 template <int OUT>
@@ -1113,23 +1123,26 @@ struct HeadLds {
     static constexpr int total = w4 + Tiles<D3>::v * 16;
 };
 
+constexpr int kHeadThreads = 512;     // 8 waves share one weight image; two workgroups per CU -> 4 waves/SIMD
+constexpr int kHeadWaves = kHeadThreads / 64;
+
 template <int D1, int D2, int D3>
-__global__ __launch_bounds__(kThreads, 2) void robot_head_kernel(const HeadArgs a) {
+__global__ __launch_bounds__(kHeadThreads, 2) void robot_head_kernel(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using LO = HeadLds<D1, D2, D3>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
-    fill_frags<XD, XD>(lds + LO::f_last, a.w_last, tid);
-    fill_frags<XD, D1>(lds + LO::f1, a.w1, tid);
-    fill_frags<D1, D2>(lds + LO::f2, a.w2, tid);
-    fill_frags<D2, D3>(lds + LO::f3, a.w3, tid);
-    fill_bias<D1>(lds + LO::b1, a.b1, tid);
-    fill_bias<D2>(lds + LO::b2, a.b2, tid);
-    fill_bias<D3>(lds + LO::b3, a.b3, tid);
-    fill_bias<D3>(lds + LO::w4, a.w4, tid);      // w4 is [D3][1]: same padded vector layout as a bias
+    fill_frags<XD, XD>(lds + LO::f_last, a.w_last, tid, kHeadThreads);
+    fill_frags<XD, D1>(lds + LO::f1, a.w1, tid, kHeadThreads);
+    fill_frags<D1, D2>(lds + LO::f2, a.w2, tid, kHeadThreads);
+    fill_frags<D2, D3>(lds + LO::f3, a.w3, tid, kHeadThreads);
+    fill_bias<D1>(lds + LO::b1, a.b1, tid, kHeadThreads);
+    fill_bias<D2>(lds + LO::b2, a.b2, tid, kHeadThreads);
+    fill_bias<D3>(lds + LO::b3, a.b3, tid, kHeadThreads);
+    fill_bias<D3>(lds + LO::w4, a.w4, tid, kHeadThreads);      // w4 is [D3][1]: same padded vector layout as a bias
     __syncthreads();
     const float b4 = a.b4[0];
-    for (int tile = blockIdx.x * kWaves + wave; tile < a.n_tiles; tile += gridDim.x * kWaves) {
+    for (int tile = blockIdx.x * kHeadWaves + wave; tile < a.n_tiles; tile += gridDim.x * kHeadWaves) {
         const int row = 16 * tile + n;
         const int rc = row < a.M ? row : a.M - 1;
         const float* src = a.rows + (size_t)rc * 64;
@@ -1144,19 +1157,19 @@ __global__ __launch_bounds__(kThreads, 2) void robot_head_kernel(const HeadArgs 
         for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float x = fmaxf(h[ot][r], 0.f);
+                float x = relu1(h[ot][r]);
                 if (a.skip) x += hp[ot][r];
                 h[ot][r] = x;
             }
         f32x4 a1[Tiles<D1>::v];
-        layer_mfma<XD, D1>(lds + LO::f1, h, a1, lane);
-        bias_relu<D1>(lds + LO::b1, a1, q);
+        layer_mfma<XD, D1>(lds + LO::f1, h, a1, lane, lds + LO::b1);
+        relu_tiles<D1>(a1);
         f32x4 a2[Tiles<D2>::v];
-        layer_mfma<D1, D2>(lds + LO::f2, a1, a2, lane);
-        bias_relu<D2>(lds + LO::b2, a2, q);
+        layer_mfma<D1, D2>(lds + LO::f2, a1, a2, lane, lds + LO::b2);
+        relu_tiles<D2>(a2);
         f32x4 a3[Tiles<D3>::v];
-        layer_mfma<D2, D3>(lds + LO::f3, a2, a3, lane);
-        bias_relu<D3>(lds + LO::b3, a3, q);
+        layer_mfma<D2, D3>(lds + LO::f3, a2, a3, lane, lds + LO::b3);
+        relu_tiles<D3>(a3);
         float v = 0.f;
 #pragma unroll
         for (int ot = 0; ot < Tiles<D3>::v; ++ot) {
@@ -1303,10 +1316,10 @@ int launch_head(const HeadArgs& ha, hipStream_t st) {
     if (lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_bytes));
-    int grid = (ha.n_tiles + kWaves - 1) / kWaves;
+    int grid = (ha.n_tiles + kHeadWaves - 1) / kHeadWaves;
     const int cap = lds_bytes > 80 * 1024 ? 256 : 512;          // resident workgroups: 1 or 2 per CU
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, st, ha);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kHeadThreads), lds_bytes, st, ha);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }
@@ -1343,11 +1356,11 @@ __global__ __launch_bounds__(kThreads, 2) void row_mlp2_kernel(const RowMlpArgs 
 #pragma unroll
         for (int r = 0; r < 4; ++r) in[0][r] = (4 * q + r) < IN ? src[4 * q + r] : 0.f;
         f32x4 h[4];
-        layer_mfma<IN, HID>(lds + F1, in, h, lane);
-        bias_relu<HID>(lds + B1, h, q);
+        layer_mfma<IN, HID>(lds + F1, in, h, lane, lds + B1);
+        relu_tiles<HID>(h);
         f32x4 o[2];
-        layer_mfma<HID, XD>(lds + F2, h, o, lane);
-        bias_relu<XD>(lds + B2, o, q);
+        layer_mfma<HID, XD>(lds + F2, h, o, lane, lds + B2);
+        relu_tiles<XD>(o);
         if (row < a.M) {
             float* dst = a.out + (size_t)row * XD;
             *reinterpret_cast<f32x4*>(dst + 4 * q) = o[0];
