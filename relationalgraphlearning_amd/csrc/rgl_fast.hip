@@ -306,6 +306,8 @@ __global__ __launch_bounds__(kThreads1, STAGE1_WAVES_PER_SIMD) void children_gra
                     if (node < SLD) { Sc0[c * SLD + node] = vs; S0[c * SLD + node] = v0; }
                 }
             }
+            // the row stride covers 4*KS entries; entries past the last node tile are padding too
+            for (int k = 16 * a.NT + q; k < SLD; k += 4) { Sc0[c * SLD + k] = NEG_INF; S0[c * SLD + k] = NEG_INF; }
         }
         PHASE_MARK(2);          // B1/B2 work
         __syncthreads();      // Gm is dead from here on: its storage becomes the wave-private area

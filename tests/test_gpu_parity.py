@@ -195,7 +195,11 @@ def test_checkpoint_roundtrip(dev, tmp_path):
                                                  (19, 1, "trained", True, 4), (19, 3, "trained", True, 3),
                                                  (49, 3, "trained", True, 2), (49, 2, "rand", False, 2),
                                                  (63, 2, "trained", True, 2), (30, 3, "rand", True, 2),
-                                                 (7, 3, "trained", False, 5)])
+                                                 (7, 3, "trained", False, 5), (31, 2, "trained", True, 2),
+                                                 (15, 2, "rand", True, 3), (12, 2, "trained", False, 3),
+                                                 (7, 2, "rand", True, 4), (31, 1, "trained", True, 2),
+                                                 (12, 3, "trained", True, 2), (9, 1, "rand", True, 3),
+                                                 (15, 3, "trained", False, 2)])
 def test_value_children_mfma_path_vs_general_kernel(H, L, flavour, skip, P, dev):
     """The two-stage MFMA path (mprl_value_children_f32) against the general kernel (module forward)
     and the oracle, on children that share their crowd exactly like the rollout's siblings."""
@@ -216,6 +220,60 @@ def test_value_children_mfma_path_vs_general_kernel(H, L, flavour, skip, P, dev)
                                            Pm.ve_graph, Pm.value_network, cfg)
     close(general.cpu().numpy().reshape(P, A), want.numpy().reshape(P, A))
     close(got.numpy(), want.numpy().reshape(P, A))
+
+
+def test_tile_kernel_variant_forced(dev):
+    """With RGL_CHILDREN_TILE_KERNEL=1 the MFMA tile kernel handles L=2, N<=32 too (the rank-1 kernel is the
+    default there).  The switch is read once per process, so this runs in a child process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+from oracle import rgl_oracle as orc
+from tests import golden_io as gio
+from tests.helpers import make_mprl_policy
+from tests.test_gpu_parity import seeded_scenes
+dev = torch.device("cuda:0")
+for H, skip in ((19, True), (5, True), (9, False), (1, True), (12, True), (15, False), (16, True), (31, True)):
+    pol = make_mprl_policy("trained", 1, L=2, skip=skip, device=dev)
+    pol.build_action_space(1.0)
+    ts = pol.tree_search()
+    A = ts.num_actions
+    robot, humans = seeded_scenes(700 + H, 3, H)
+    acts, _ = orc.mprl_action_space(orc.OracleConfig(), 1.0)
+    cr = orc._children_robot(robot, acts, orc.OracleConfig())
+    got = ts.value_children(cr.to(dev), humans.to(dev)).cpu().numpy()
+    Pm = gio.oracle_params("trained", 2)
+    with torch.no_grad():
+        want = orc.value_estimator_forward(cr.reshape(3 * A, 1, 9), humans[:, None].expand(3, A, H, 5).reshape(3 * A, H, 5),
+                                           Pm.ve_graph, Pm.value_network, orc.OracleConfig(skip_connection=skip)).numpy().reshape(3, A)
+    err = np.abs(got - want).max()
+    assert err < 1e-4 * max(1.0, np.abs(want).max()), (H, skip, err)
+print("OK")
+'''
+    env = dict(os.environ, RGL_CHILDREN_TILE_KERNEL="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("H,L,flavour,skip,P", [(1, 2, "trained", True, 5), (15, 2, "trained", True, 4), (16, 2, "rand", True, 3),
+                                                 (31, 1, "trained", True, 3), (49, 3, "trained", True, 2),
+                                                 (63, 2, "trained", False, 2), (19, 3, "rand", True, 3), (7, 4, "trained", True, 3)])
+def test_state_predictor_mfma_path_vs_oracle(H, L, flavour, skip, P, dev):
+    """mprl_expand_f32's predicted humans (row-MLP embeddings + scene_graph_kernel with the motion head fused)."""
+    if L > 3:
+        pytest.skip("fixtures hold three GCN layers")
+    pol = make_mprl_policy(flavour, 1, L=L, skip=skip, device=dev)
+    pol.build_action_space(1.0)
+    robot, humans = seeded_scenes(500 + H + L, P, H)
+    got = pol.tree_search().expand(robot.to(dev), humans.to(dev))["humans_next"].cpu().numpy()
+    Pm = gio.oracle_params(flavour, L)
+    cfg = orc.OracleConfig(num_layer=L, skip_connection=skip)
+    with torch.no_grad():
+        want = orc.state_predictor_humans(robot[:, None, :], humans, Pm.sp_graph, Pm.motion_predictor, cfg).numpy()
+    close(got, want)
 
 
 # ---------------------------------------------------------------------------------------------------
