@@ -1271,9 +1271,16 @@ inline ChildPlan plan_children(const RglGraph& g, int P, int A, int H) {
     // waves per workgroup: 8 (two per SIMD; measured better than counts that balance n_groups exactly but load the
     // four SIMDs unevenly), 4 when there is too little work to share
     a.n_waves = a.n_groups >= 6 ? kWaves1 : 4;
-    const int wave_total = a.n_waves * a.wave_stride > gm_floats ? a.n_waves * a.wave_stride : gm_floats;
-    a.off_wave = take(wave_total);
-    pl.lds_bytes = (size_t)off * sizeof(float);
+    // staged modes carry node features per wave: give up waves (8 -> 4 -> 2) before giving up the MFMA path
+    const int off_before_waves = off;
+    for (;;) {
+        off = off_before_waves;
+        const int wave_total = a.n_waves * a.wave_stride > gm_floats ? a.n_waves * a.wave_stride : gm_floats;
+        a.off_wave = take(wave_total);
+        pl.lds_bytes = (size_t)off * sizeof(float);
+        if (pl.lds_bytes <= (size_t)rgl::kLdsBytesPerCu || a.n_waves <= 2) break;
+        a.n_waves /= 2;
+    }
     if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
     a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];
     a.wh1 = g.w_h.weight[0]; a.bh1 = g.w_h.bias[0]; a.wh2 = g.w_h.weight[1]; a.bh2 = g.w_h.bias[1];
