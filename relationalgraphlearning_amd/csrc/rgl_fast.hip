@@ -68,8 +68,9 @@ __device__ __forceinline__ float kgroups_sum(float x) {
 }
 // m / N for 0 <= m < 65536 and 1 <= N <= 64 with magic = floor(2^32 / N) + 1
 __device__ __forceinline__ int div_small(int m, unsigned magic) { return (int)__umulhi((unsigned)m, magic); }
-// relu as ONE instruction (v_med3_f32): fmaxf() on MFMA results costs an extra canonicalising v_max
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+// relu as ONE full-rate instruction: on the bit patterns, max(int(x), 0) maps every negative float (and -0) to +0
+// and leaves positive floats untouched (v_max_i32).  fmaxf() / med3 cost a canonicalising v_max extra on MFMA results.
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
 // Optional phase timing (-DRGL_PHASE_TIMING, tools/phase_timing.py): per-wave s_memtime deltas summed per phase.
 #ifdef RGL_PHASE_TIMING
