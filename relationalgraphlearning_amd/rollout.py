@@ -285,8 +285,9 @@ class ShardedRollout:
         self.dist = dist
         self.search_fn = search_fn
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.rank = dist.get_rank(group) if self.active else 0
 
     def run(self, robot, humans):
         """robot (B,9), humans (B,H,5): the FULL root batch (identical on every rank).
@@ -304,7 +305,7 @@ class ShardedRollout:
             act, val = self.search_fn(robot_shard, humans_shard)
             packed[:n, 0] = act.to(torch.float32)
             packed[:n, 1] = val
-        if self.world == 1:
+        if not self.active:
             return packed[:n, 0].to(torch.int64), packed[:n, 1].clone()
         gathered = torch.empty(self.world * per, 2, dtype=torch.float32, device=packed.device)
         self.dist.all_gather_into_tensor(gathered, packed, group=self.group)
