@@ -116,6 +116,28 @@ int rgl_graph_forward_f32(const RglGraph* graph, const RglMlp* value_head, const
                           float* H_out, float* A_out, float* value_out, float* humans_next,
                           rgl_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * rgl_graph_backward_f32 -- gradients of rgl_graph_forward_f32's outputs with respect to every
+ * parameter, summed over the n_scenes scenes (deterministic: per-scene slabs reduced in scene order).
+ * Replaces: torch autograd through RGL.forward / ValueEstimator.forward / StatePredictor.forward /
+ * gcn.ValueNetwork.forward as driven by MPRLTrainer / VNRLTrainer (crowd_nav/utils/trainer.py:110-161,
+ * 199-250).  Supported: similarity embedded_gaussian | gaussian, layerwise_graph = 0 (else RGL_ERR_BAD_MODE).
+ *   d_value [n_scenes], d_humans_next [n_scenes][H][out], d_H [n_scenes][N][x_dim]: upstream gradients of the
+ *   corresponding forward outputs (device; NULL = zero).  detach_graph = 1 reproduces
+ *   StatePredictor(..., detach=True): only the heads receive gradients.
+ *   grad_out device [rgl_graph_param_count()]: w_r (W0,b0,W1,b1,..), w_h, w_a (embedded_gaussian only),
+ *   Ws[0..L-1], value head, motion head; Linear weights k-major [in][out] like the forward's.
+ *   workspace device, >= rgl_graph_backward_workspace_bytes().  Each scene has its own crowd here
+ *   (scenes_per_crowd = 1: the training batches are independent transitions).
+ * ------------------------------------------------------------------------------------------- */
+int rgl_graph_param_count(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head);
+size_t rgl_graph_backward_workspace_bytes(const RglGraph* graph, const RglMlp* value_head,
+                                          const RglMlp* motion_head, int n_scenes);
+int rgl_graph_backward_f32(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
+                           const float* robot, const float* humans, int n_scenes, int H, int detach_graph,
+                           const float* d_value, const float* d_humans_next, const float* d_H,
+                           float* grad_out, void* workspace, size_t workspace_bytes, rgl_stream_t stream);
+
 /* rgl_transpose_f32 -- dst[c][r] = src[r][c]; turns a torch Linear weight (out,in) into the
  * k-major layout RglMlp wants.  Host-side convenience of this ABI (no reference counterpart). */
 int rgl_transpose_f32(const float* src, float* dst, int rows, int cols, rgl_stream_t stream);

@@ -1,0 +1,86 @@
+"""Autograd for the HIP forward: `GraphFunction` runs rgl_graph_forward_f32 in forward and
+rgl_graph_backward_f32 in backward, so crowd_nav's trainers (MPRLTrainer / VNRLTrainer,
+crowd_nav/utils/trainer.py:110-161,199-250) can optimise the modules of `nets.py` with torch optimizers.
+Gradients flow to parameters only (the states of a replay batch are data)."""
+import ctypes as C
+
+import torch
+
+from . import _native as nat
+
+
+def linear_params(seq):
+    out = []
+    for m in seq:
+        if isinstance(m, torch.nn.Linear):
+            out += [m.weight, m.bias]
+    return out
+
+
+class GraphFunction(torch.autograd.Function):
+    """forward(spec, robot, humans, *params) -> tuple of requested outputs.
+
+    `spec` (plain python object, not a tensor) provides:
+       graph() / value_head() / motion_head()  -> ctypes descriptors (or None), built from the CURRENT parameters
+       want_H, detach_graph                    -> flags
+       param_shapes                            -> [(kind, shape)] in slab order, kind in {'linear_w','vector','matrix'}
+    `params` are the parameter tensors in slab order; they are inputs only so that autograd tracks them."""
+
+    @staticmethod
+    def forward(ctx, spec, robot, humans, *params):
+        from .nets import graph_forward
+        out = graph_forward(spec.graph(), spec.value_head(), spec.motion_head(), robot, humans,
+                            want_H=spec.want_H, want_A=spec.want_A)
+        ctx.spec = spec
+        ctx.save_for_backward(robot, humans)
+        ctx.n_params = len(params)
+        ctx.keys = [k for k in ("H", "value", "humans_next", "A") if k in out]
+        for k in ("A",):
+            if k in out:
+                ctx.mark_non_differentiable(out[k])
+        return tuple(out[k] for k in ctx.keys)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        spec = ctx.spec
+        robot, humans = ctx.saved_tensors
+        g = dict(zip(ctx.keys, grads))
+        S, H = robot.shape[0], humans.shape[1]
+        graph, vh, mh = spec.graph(), spec.value_head(), spec.motion_head()
+        lib = nat.lib()
+        vhp = C.byref(vh) if vh is not None else None
+        mhp = C.byref(mh) if mh is not None else None
+        n = lib.rgl_graph_param_count(C.byref(graph), vhp, mhp)
+        if n <= 0:
+            nat.check(n, "rgl_graph_param_count")
+        dev = robot.device
+
+        def ptr(name):
+            t = g.get(name)
+            if t is None:
+                return None, None
+            t = t.contiguous().to(torch.float32)
+            return t, t.data_ptr()
+        dv_t, dv = ptr("value")
+        dm_t, dm = ptr("humans_next")
+        dh_t, dh = ptr("H")
+        flat = torch.empty(n, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.rgl_graph_backward_workspace_bytes(C.byref(graph), vhp, mhp, S), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.rgl_graph_backward_f32(C.byref(graph), vhp, mhp, robot.data_ptr(), humans.data_ptr(), S, H,
+                                            int(spec.detach_graph), dv, dm, dh, flat.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        nat.check(rc, "rgl_graph_backward_f32")
+        grads_out, off = [], 0
+        for kind, shape in spec.param_shapes:
+            cnt = 1
+            for d in shape:
+                cnt *= d
+            piece = flat[off:off + cnt]
+            off += cnt
+            if kind == "linear_w":           # slab holds k-major [in][out]; torch wants (out, in)
+                grads_out.append(piece.view(shape[1], shape[0]).t().contiguous())
+            else:
+                grads_out.append(piece.view(*shape).clone())
+        assert off == n, (off, n)
+        return (None, None, None) + tuple(grads_out)

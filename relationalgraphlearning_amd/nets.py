@@ -44,11 +44,63 @@ def _require_device_tensor(t, what):
     return t.contiguous()
 
 
-def _refuse_autograd(params):
-    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-        raise NotImplementedError(
-            "gradients through the HIP forward are not implemented yet; wrap inference in torch.no_grad() "
-            "(training backward is the next row of the hot-path scope, SURVEY.md §8f)")
+def _needs_grad(params):
+    return torch.is_grad_enabled() and any(p.requires_grad for p in params)
+
+
+class _Spec(object):
+    """What autograd.GraphFunction needs to re-create the descriptors and to split the gradient slab."""
+
+    def __init__(self, graph_module, value_seq=None, motion_seq=None, value_desc=None, motion_desc=None, want_H=False,
+                 want_A=False, detach_graph=False):
+        self.graph_module = graph_module
+        self.value_desc, self.motion_desc = value_desc, motion_desc
+        self.want_H, self.want_A, self.detach_graph = want_H, want_A, detach_graph
+        gm = graph_module
+        if gm.similarity_function not in ("embedded_gaussian", "gaussian") or gm.layerwise_graph:
+            raise NotImplementedError("gradients on the HIP path cover similarity embedded_gaussian|gaussian with one "
+                                      "adjacency for all layers (the shipped configurations); got %s, layerwise=%s"
+                                      % (gm.similarity_function, gm.layerwise_graph))
+        from .autograd import linear_params
+        self.params, self.param_shapes = [], []
+
+        def add_mlp(seq):
+            for m in seq:
+                if isinstance(m, nn.Linear):
+                    self.params += [m.weight, m.bias]
+                    self.param_shapes += [("linear_w", tuple(m.weight.shape)), ("vector", tuple(m.bias.shape))]
+        add_mlp(gm.w_r)
+        add_mlp(gm.w_h)
+        if gm.similarity_function == "embedded_gaussian":
+            self.params.append(gm.w_a)
+            self.param_shapes.append(("matrix", tuple(gm.w_a.shape)))
+        for w in gm._graph_weights():
+            self.params.append(w)
+            self.param_shapes.append(("matrix", tuple(w.shape)))
+        if value_seq is not None:
+            add_mlp(value_seq)
+        if motion_seq is not None:
+            add_mlp(motion_seq)
+
+    def graph(self):
+        return self.graph_module.descriptor()
+
+    def value_head(self):
+        return None if self.value_desc is None else self.value_desc()
+
+    def motion_head(self):
+        return None if self.motion_desc is None else self.motion_desc()
+
+
+def _graph_apply(spec, robot, humans):
+    from .autograd import GraphFunction
+    robot = _require_device_tensor(robot, "robot states")
+    humans = _require_device_tensor(humans, "human states")
+    outs = GraphFunction.apply(spec, robot, humans, *spec.params)
+    keys = [k for k in ("H", "value", "humans_next", "A") if
+            (k == "H" and spec.want_H) or (k == "value" and spec.value_desc is not None) or
+            (k == "humans_next" and spec.motion_desc is not None) or (k == "A" and spec.want_A)]
+    return dict(zip(keys, outs))
 
 
 def _linears(seq):
@@ -209,12 +261,14 @@ class RGL(_GraphCore):
 
     def forward(self, state):
         robot, humans = state
-        _refuse_autograd(list(self.parameters()))
         if robot.dim() != 3 or humans.dim() != 3:
             raise AssertionError("states must be (batch, agents, features)")
-        out = graph_forward(self.descriptor(), None, None, robot.reshape(robot.shape[0], -1), humans,
-                            want_H=True, want_A=True)
-        self._A_dev = out["A"][0]
+        if _needs_grad(list(self.parameters())):
+            out = _graph_apply(_Spec(self, want_H=True, want_A=True), robot.reshape(robot.shape[0], -1), humans)
+        else:
+            out = graph_forward(self.descriptor(), None, None, robot.reshape(robot.shape[0], -1), humans,
+                                want_H=True, want_A=True)
+        self._A_dev = out["A"][0].detach()
         return out["H"]
 
 
@@ -231,7 +285,9 @@ class ValueEstimator(nn.Module):
     def forward(self, state):
         robot, humans = state
         assert len(robot.shape) == 3 and len(humans.shape) == 3
-        _refuse_autograd(list(self.parameters()))
+        if _needs_grad(list(self.parameters())):
+            spec = _Spec(self.graph_model, value_seq=self.value_network, value_desc=self.head_descriptor)
+            return _graph_apply(spec, robot.reshape(robot.shape[0], -1), humans)["value"]
         out = graph_forward(self.graph_model.descriptor(), self.head_descriptor(), None,
                             robot.reshape(robot.shape[0], -1), humans)
         return out["value"]
@@ -254,9 +310,13 @@ class StatePredictor(nn.Module):
     def forward(self, state, action, detach=False):
         robot, humans = state
         assert len(robot.shape) == 3 and len(humans.shape) == 3
-        _refuse_autograd(list(self.parameters()))
-        out = graph_forward(self.graph_model.descriptor(), None, self.head_descriptor(),
-                            robot.reshape(robot.shape[0], -1), humans)
+        if _needs_grad(list(self.parameters())):
+            spec = _Spec(self.graph_model, motion_seq=self.human_motion_predictor, motion_desc=self.head_descriptor,
+                         detach_graph=bool(detach))
+            out = _graph_apply(spec, robot.reshape(robot.shape[0], -1), humans)
+        else:
+            out = graph_forward(self.graph_model.descriptor(), None, self.head_descriptor(),
+                                robot.reshape(robot.shape[0], -1), humans)
         next_robot = None if action is None else self.compute_next_state(robot, action)
         return [next_robot, out["humans_next"]]
 
@@ -355,10 +415,13 @@ class ValueNetwork(_GraphCore):
 
     def forward(self, state_input):
         state = state_input[0] if isinstance(state_input, tuple) else state_input
-        _refuse_autograd(list(self.parameters()))
         state = _require_device_tensor(state, "rotated joint states")
         d = self.self_state_dim
-        out = graph_forward(self.descriptor(), self.head_descriptor(), None, state[:, 0, :d].contiguous(),
-                            state[:, :, d:].contiguous(), want_A=True)
-        self._A_dev = out["A"][0]
+        if _needs_grad(list(self.parameters())):
+            spec = _Spec(self, value_seq=self.value_net, value_desc=self.head_descriptor, want_A=True)
+            out = _graph_apply(spec, state[:, 0, :d].contiguous(), state[:, :, d:].contiguous())
+        else:
+            out = graph_forward(self.descriptor(), self.head_descriptor(), None, state[:, 0, :d].contiguous(),
+                                state[:, :, d:].contiguous(), want_A=True)
+        self._A_dev = out["A"][0].detach()
         return out["value"]

@@ -396,10 +396,138 @@ def test_no_cpu_fallback_and_no_silent_autograd(dev):
     h = torch.zeros(1, 3, 5)
     with torch.no_grad(), pytest.raises(nat.NativeLibraryError):
         ve((r, h))                                            # CPU tensors
+    lw = build_modules(dict(L=2, sim="cosine", layerwise=True, skip=True, flavour="trained"), dev)[1]
     with pytest.raises(NotImplementedError):
-        ve((r.to(dev), h.to(dev)))                            # gradients requested
+        lw((r.to(dev), h.to(dev)))                            # gradients for a structure the backward does not cover
     with torch.no_grad(), pytest.raises(nat.NativeLibraryError):
         ve((r.to(dev), torch.zeros(1, 64, 5, device=dev)))    # N = 65 > RGL_MAX_NODES
+
+
+# ---------------------------------------------------------------------------------------------------
+# training path: gradients through the HIP forward (rgl_graph_backward_f32) against torch autograd on the oracle
+# ---------------------------------------------------------------------------------------------------
+def _oracle_leafs(module_sd):
+    return {k: v.detach().cpu().clone().requires_grad_(True) for k, v in module_sd.items()}
+
+
+def _grad_close(got, want, name, tol=2e-4):
+    got, want = got.detach().cpu().numpy().astype(np.float64), want.detach().numpy().astype(np.float64)
+    scale = max(1e-3, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max())
+    assert err <= tol * scale, (name, err, scale)
+
+
+@pytest.mark.parametrize("H,L,sim,skip,flavour,B", [(5, 2, "embedded_gaussian", True, "trained", 7),
+                                                     (19, 2, "embedded_gaussian", True, "trained", 4),
+                                                     (5, 3, "embedded_gaussian", False, "trained", 5),
+                                                     (3, 1, "gaussian", True, "trained", 6),
+                                                     (5, 2, "embedded_gaussian", True, "rand", 3)])
+def test_gradients_value_estimator_and_state_predictor(H, L, sim, skip, flavour, B, dev):
+    c = dict(L=L, sim=sim, layerwise=False, skip=skip, flavour=flavour)
+    g1, ve, sp = build_modules(c, dev)
+    robot, humans = seeded_scenes(900 + H + L, B, H)
+    cfg = orc.OracleConfig(num_layer=L, similarity=sim, skip_connection=skip)
+    wv = torch.linspace(-1.0, 1.5, B).reshape(B, 1)
+    # value estimator
+    for p_ in ve.parameters():
+        p_.grad = None
+    out = ve((robot.unsqueeze(1).to(dev), humans.to(dev)))
+    (out * wv.to(dev)).sum().backward()
+    gsd, vsd = _oracle_leafs(ve.graph_model.state_dict()), _oracle_leafs(ve.value_network.state_dict())
+    want = orc.value_estimator_forward(robot.unsqueeze(1), humans, gsd, vsd, cfg)
+    close(out.detach().cpu().numpy(), want.detach().numpy())
+    (want * wv).sum().backward()
+    for k, v in ve.graph_model.named_parameters():
+        _grad_close(v.grad, gsd[k].grad, "graph." + k)
+    for k, v in ve.value_network.named_parameters():
+        _grad_close(v.grad, vsd[k].grad, "value." + k)
+    # state predictor, with and without detach
+    wm = torch.randn(B, H, 5, generator=torch.Generator().manual_seed(3))
+    for detach in (False, True):
+        for p_ in sp.parameters():
+            p_.grad = None
+        _, nh = sp((robot.unsqueeze(1).to(dev), humans.to(dev)), None, detach=detach)
+        (nh * wm.to(dev)).sum().backward()
+        gsd, msd = _oracle_leafs(sp.graph_model.state_dict()), _oracle_leafs(sp.human_motion_predictor.state_dict())
+        emb, _ = orc.rgl_forward(robot.unsqueeze(1), humans, gsd, cfg)
+        if detach:
+            emb = emb.detach()
+        wantm = orc.mlp_forward(emb, orc.mlp_layers(msd, ""), last_relu=False)[:, 1:, :]
+        (wantm * wm).sum().backward()
+        for k, v in sp.human_motion_predictor.named_parameters():
+            _grad_close(v.grad, msd[k].grad, "motion." + k)
+        for k, v in sp.graph_model.named_parameters():
+            if detach:
+                assert v.grad is None or float(v.grad.abs().max()) == 0.0
+            else:
+                _grad_close(v.grad, gsd[k].grad, "sp_graph." + k)
+
+
+def test_gradients_rgl_output_and_path_g(dev):
+    c = dict(L=2, sim="embedded_gaussian", layerwise=False, skip=True, flavour="trained")
+    g1, _, _ = build_modules(c, dev)
+    robot, humans = seeded_scenes(77, 4, 5)
+    wH = torch.randn(4, 6, 32, generator=torch.Generator().manual_seed(5))
+    out = g1((robot.unsqueeze(1).to(dev), humans.to(dev)))
+    (out * wH.to(dev)).sum().backward()
+    gsd = _oracle_leafs(g1.state_dict())
+    want, _ = orc.rgl_forward(robot.unsqueeze(1), humans, gsd, orc.OracleConfig())
+    (want * wH).sum().backward()
+    for k, v in g1.named_parameters():
+        _grad_close(v.grad, gsd[k].grad, "rgl." + k)
+    # path G value network (L=2 and the skip-less one-layer variant)
+    g = gio.load("path_g")
+    x = torch.tensor(g["g.vn_in"])
+    for L in (2, 1):
+        pol = make_gcn_policy(L, False, True, device=dev)
+        v = pol.model(x.to(dev))
+        v.sum().backward()
+        sd = _oracle_leafs(pol.model.state_dict())
+        wantv, _ = orc.gcn_value_forward(x, sd, orc.OracleConfig(num_layer=L))
+        wantv.sum().backward()
+        for k, p_ in pol.model.named_parameters():
+            _grad_close(p_.grad, sd[k].grad, "gcn%d.%s" % (L, k))
+
+
+def test_training_step_matches_cpu_autograd(dev):
+    """Five Adam steps of the value-estimator TD regression (the body of MPRLTrainer.optimize_batch,
+    crowd_nav/utils/trainer.py:110-161) on the HIP path versus the same loop on the CPU oracle."""
+    c = dict(L=2, sim="embedded_gaussian", layerwise=False, skip=True, flavour="trained")
+    _, ve, _ = build_modules(c, dev)
+    import copy
+    target = copy.deepcopy(ve)
+    robot, humans = seeded_scenes(31, 100, 5)
+    nrobot, nhumans = seeded_scenes(32, 100, 5)
+    rewards = torch.linspace(-0.25, 1.0, 100).reshape(100, 1)
+    gamma_bar = 0.9 ** 0.25
+    gsd, vsd = _oracle_leafs(ve.graph_model.state_dict()), _oracle_leafs(ve.value_network.state_dict())
+    tg = {k: v.detach().clone() for k, v in gsd.items()}
+    tv = {k: v.detach().clone() for k, v in vsd.items()}
+    cfg = orc.OracleConfig()
+    opt_gpu = torch.optim.Adam(ve.parameters(), lr=1e-3)
+    opt_cpu = torch.optim.Adam(list(gsd.values()) + list(vsd.values()), lr=1e-3)
+    crit = torch.nn.MSELoss()
+    losses_gpu, losses_cpu = [], []
+    for _ in range(5):
+        opt_gpu.zero_grad()
+        out = ve((robot.unsqueeze(1).to(dev), humans.to(dev)))
+        tgt = rewards.to(dev) + gamma_bar * target((nrobot.unsqueeze(1).to(dev), nhumans.to(dev)))
+        loss = crit(out, tgt)
+        loss.backward()
+        opt_gpu.step()
+        losses_gpu.append(float(loss))
+        opt_cpu.zero_grad()
+        o2 = orc.value_estimator_forward(robot.unsqueeze(1), humans, gsd, vsd, cfg)
+        with torch.no_grad():
+            t2 = rewards + gamma_bar * orc.value_estimator_forward(nrobot.unsqueeze(1), nhumans, tg, tv, cfg)
+        l2 = crit(o2, t2)
+        l2.backward()
+        opt_cpu.step()
+        losses_cpu.append(float(l2))
+    assert np.allclose(losses_gpu, losses_cpu, rtol=2e-4, atol=1e-6), (losses_gpu, losses_cpu)
+    assert losses_gpu[-1] < losses_gpu[0]
+    for k, v in ve.graph_model.named_parameters():
+        close(v.detach().cpu().numpy(), gsd[k].detach().numpy(), 5e-4)
 
 
 def test_library_reports_target():
