@@ -515,7 +515,7 @@ def test_training_step_matches_cpu_autograd(dev):
         loss = crit(out, tgt)
         loss.backward()
         opt_gpu.step()
-        losses_gpu.append(float(loss))
+        losses_gpu.append(float(loss.detach()))
         opt_cpu.zero_grad()
         o2 = orc.value_estimator_forward(robot.unsqueeze(1), humans, gsd, vsd, cfg)
         with torch.no_grad():
@@ -523,7 +523,7 @@ def test_training_step_matches_cpu_autograd(dev):
         l2 = crit(o2, t2)
         l2.backward()
         opt_cpu.step()
-        losses_cpu.append(float(l2))
+        losses_cpu.append(float(l2.detach()))
     assert np.allclose(losses_gpu, losses_cpu, rtol=2e-4, atol=1e-6), (losses_gpu, losses_cpu)
     assert losses_gpu[-1] < losses_gpu[0]
     for k, v in ve.graph_model.named_parameters():
