@@ -6,8 +6,10 @@ from . import _native
 from .actions import ActionXY, ActionRot
 from .nets import mlp, RGL, ValueEstimator, StatePredictor, LinearStatePredictor, ValueNetwork
 from .policy import Policy, ModelPredictiveRL, GCN, register
+from .state import FullState, ObservableState, JointState, tensor_to_joint_state
 from .rollout import TreeSearch, GcnSearch, ShardedRollout, rotate, shard_bounds
 
 __all__ = ["ActionXY", "ActionRot", "mlp", "RGL", "ValueEstimator", "StatePredictor", "LinearStatePredictor",
            "ValueNetwork", "Policy", "ModelPredictiveRL", "GCN", "register", "TreeSearch", "GcnSearch",
-           "ShardedRollout", "rotate", "shard_bounds"]
+           "ShardedRollout", "rotate", "shard_bounds", "FullState", "ObservableState", "JointState",
+           "tensor_to_joint_state"]

@@ -1103,16 +1103,6 @@ __device__ __forceinline__ void relu_tiles(f32x4 (&x)[Tiles<OUT>::v]) {
         for (int r = 0; r < 4; ++r) x[ot][r] = relu1(x[ot][r]);
 }
 
-template <int OUT>
-__device__ __forceinline__ void bias_relu(const float* bias, f32x4 (&x)[Tiles<OUT>::v], int q) {
-#pragma unroll
-    for (int ot = 0; ot < Tiles<OUT>::v; ++ot) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * q]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[ot][r] = fmaxf(x[ot][r] + b[r], 0.f);
-    }
-}
-
 template <int D1, int D2, int D3>
 struct HeadLds {
     static constexpr int f_last = 0;
