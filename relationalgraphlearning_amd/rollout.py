@@ -130,6 +130,17 @@ class TreeSearch:
         self.last = dict(out, B=B, H=H, robot=robot, humans=humans, planner=pl, workspace=ws)
         return out
 
+    def capture(self, robot, humans, roots_are_joint_states=True):
+        """Capture one whole search into a hipGraph (torch.cuda.CUDAGraph).  Returns (graph, outputs): copy new root
+        states into `robot` / `humans` in place, call graph.replay(), read `outputs` -- no Python or launch overhead
+        per decision.  The library allocates nothing and never synchronises, which is what makes this legal."""
+        self.search(robot, humans, roots_are_joint_states)          # warm-up: workspace, descriptors, function attributes
+        torch.cuda.synchronize(robot.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.search(robot, humans, roots_are_joint_states)
+        return graph, out
+
     def expand(self, robot, humans, parents_are_joint_states=True):
         """One tree level for P parents (what `action_clip` evaluates); all outputs device tensors."""
         robot = _require_device_tensor(robot, "robot states")

@@ -359,6 +359,29 @@ def test_state_containers_roundtrip(dev):
     assert isinstance(pol.predict(js), rga.ActionXY)
 
 
+def test_whole_search_is_graph_capturable(dev):
+    """No allocation / sync inside mprl_tree_search_f32: a complete depth-2 search replays from a hipGraph."""
+    robot, humans = seeded_scenes(55, 64, 19)
+    r, h = robot.to(dev), humans.to(dev)
+    pol = make_mprl_policy("trained", 2, 2, True, device=dev)
+    pol.build_action_space(1.0)
+    ts = pol.tree_search()
+    ref = ts.search(r, h)
+    ref_a, ref_v = ref["best_action"].clone(), ref["best_value"].clone()
+    graph, out = ts.capture(r, h)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out["best_action"], ref_a) and torch.equal(out["best_value"], ref_v)
+    robot2, humans2 = seeded_scenes(56, 64, 19)                    # new inputs, same buffers
+    r.copy_(robot2.to(dev))
+    h.copy_(humans2.to(dev))
+    graph.replay()
+    torch.cuda.synchronize()
+    got_a, got_v = out["best_action"].clone(), out["best_value"].clone()
+    fresh = ts.search(robot2.to(dev), humans2.to(dev))
+    assert torch.equal(got_a, fresh["best_action"]) and torch.equal(got_v, fresh["best_value"])
+
+
 def test_properties_at_full_size(dev):
     """BASELINE config 3 (N=20, L=2, D=2, w=2, B=2048): size-independent properties."""
     B, H = 2048, 19
