@@ -155,7 +155,8 @@ def gen_forward_kats(masters, out):
     cases = []
     # default-flag sweeps over crowd size / depth of the GCN / weight flavour
     for H, B, L, flavour in [(1, 3, 2, "rand"), (5, 4, 2, "rand"), (5, 4, 2, "trained"), (19, 3, 2, "trained"),
-                             (19, 2, 1, "rand"), (49, 2, 3, "trained"), (19, 2, 3, "rand")]:
+                             (19, 2, 1, "rand"), (49, 2, 3, "trained"), (19, 2, 3, "rand"), (5, 1, 2, "trained"),
+                             (5, 64, 2, "trained")]:
         cases.append(dict(H=H, B=B, L=L, flavour=flavour, sim="embedded_gaussian", layerwise=False, skip=True))
     # every similarity x layerwise x skip on a small crowd
     for sim in SIMS:
