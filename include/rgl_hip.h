@@ -247,6 +247,37 @@ typedef struct MprlLevelView {
 } MprlLevelView;
 int mprl_tree_level_view(const MprlPlanner* planner, int B, int H, int level, MprlLevelView* view);
 
+/* ---------------------------------------------------------------------------------------------
+ * Batched crowd simulator (next row of the scope table): B independent environments, float64 state.
+ * crowd_step_f64 replaces CrowdSim.step (crowd_sim/envs/crowd_sim.py:252-368) incl. Agent.step /
+ * compute_position (crowd_sim/envs/utils/agent.py:113-139) and, for human_policy LINEAR, Linear.predict
+ * (crowd_sim/envs/policy/linear.py:16-22).  ORCA humans (external rvo2) are out of scope: supply their
+ * actions with human_policy GIVEN.
+ *   robot [B][9], humans [B][H][5], time [B], done [B] (int, in/out): updated in place when update != 0
+ *   (update = 0 is the reference's onestep_lookahead: outputs only); environments with done != 0 are frozen.
+ *   human_goals [B][H][2], human_vpref [B][H] (LINEAR); human_actions [B][H][2] (GIVEN); robot_action [B][2]
+ *   = (vx,vy) or (v,r).  Outputs: reward [B] fp32, info [B] CROWD_INFO_*, dmin [B] (closest approach; -1 on collision).
+ * crowd_observe_f32: the fp32 (robot [B][9], humans [B][H][5]) view policies consume (JointState.to_tensor,
+ * crowd_sim/envs/utils/state.py:64-79).
+ * ------------------------------------------------------------------------------------------- */
+enum { CROWD_INFO_NOTHING = 0, CROWD_INFO_DISCOMFORT = 1, CROWD_INFO_COLLISION = 2, CROWD_INFO_REACH_GOAL = 3,
+       CROWD_INFO_TIMEOUT = 4, CROWD_INFO_DONE = 5 };
+enum { CROWD_HUMAN_GIVEN = 0, CROWD_HUMAN_LINEAR = 1, CROWD_HUMAN_CONSTANT_VELOCITY = 2 };
+
+typedef struct CrowdSimConfig {
+    double time_step, time_limit;
+    double success_reward, collision_penalty, discomfort_dist, discomfort_penalty_factor;
+    int kinematics;             /* of the robot: RGL_HOLONOMIC | RGL_UNICYCLE */
+    int human_policy;           /* CROWD_HUMAN_* */
+} CrowdSimConfig;
+
+int crowd_step_f64(const CrowdSimConfig* cfg, double* robot, double* humans, const double* human_goals,
+                   const double* human_vpref, const double* robot_action, const double* human_actions,
+                   double* time, int* done, int B, int H, int update, float* reward, int* info, double* dmin,
+                   rgl_stream_t stream);
+int crowd_observe_f32(const double* robot, const double* humans, int B, int H, float* robot32, float* humans32,
+                      rgl_stream_t stream);
+
 /* library identification: ABI version and the gfx target the device code was built for */
 int rgl_abi_version(void);
 const char* rgl_build_target(void);

@@ -55,6 +55,12 @@ class MprlPlanner(C.Structure):
                 ("action_groups", C.c_void_p)]
 
 
+class CrowdSimConfig(C.Structure):
+    _fields_ = [("time_step", C.c_double), ("time_limit", C.c_double), ("success_reward", C.c_double),
+                ("collision_penalty", C.c_double), ("discomfort_dist", C.c_double),
+                ("discomfort_penalty_factor", C.c_double), ("kinematics", C.c_int), ("human_policy", C.c_int)]
+
+
 class MprlLevelView(C.Structure):
     _fields_ = [(n, C.c_longlong) for n in
                 ("n_parents", "robot_off", "humans_off", "humans_next_off", "child_robot_off", "reward_off",
@@ -87,6 +93,10 @@ SIGNATURES = {
                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     "mprl_tree_level_view": (C.c_int, [C.POINTER(MprlPlanner), C.c_int, C.c_int, C.c_int, C.POINTER(MprlLevelView)]),
+    "crowd_step_f64": (C.c_int, [C.POINTER(CrowdSimConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
+    "crowd_observe_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rgl_abi_version": (C.c_int, []),
     "rgl_build_target": (C.c_char_p, []),
 }

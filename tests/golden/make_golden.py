@@ -550,6 +550,78 @@ def gen_env_scenes():
     return scenes
 
 
+INFO_CODES = {"": 0, "Discomfort": 1, "Collision": 2, "Reaching goal": 3, "Timeout": 4}
+
+
+def gen_sim_kats(out):
+    """Trajectories of the reference simulator's step() with its `linear` human policy (rvo2-free) under three
+    scripted robot behaviours.  In-memory shim: the reference's Linear.predict reads `state.self_state`, an attribute
+    JointState no longer has (bit-rot); it is aliased to `robot_state` here, nothing on disk changes."""
+    import gym
+    from crowd_sim.envs.utils.robot import Robot
+    JointState.self_state = property(lambda self_: self_.robot_state)
+    mod = importlib.import_module("crowd_nav.configs.icra_benchmark.mp_separate")
+    envc = mod.EnvConfig()
+    old_policy, old_central = envc.humans.policy, envc.sim.centralized_planning
+    envc.humans.policy = "linear"
+    envc.sim.centralized_planning = False
+    try:
+        env = gym.make("CrowdSim-v0")
+        env.configure(envc)
+        robot = Robot(envc, "robot")
+        robot.time_step = env.time_step
+        pol = policy_factory["model_predictive_rl"]()
+        pol.configure(policy_config())
+        robot.set_policy(pol)
+        env.set_robot(robot)
+        pol.build_action_space(1.0)
+        table = np.array([[a.vx, a.vy] for a in pol.action_space], np.float64)
+        meta = []
+        for script, cases in (("greedy", (0, 1, 2)), ("late", (0, 1, 2)), ("random", (0,)), ("stop", (1,))):
+            for case in cases:
+                env.reset("test", case)
+                rng = np.random.RandomState(100 + case)
+                R = [robot.get_full_state().to_tuple()]
+                Hs = [[h.get_full_state().to_tuple() for h in env.humans]]
+                acts, rew, done_l, info_l, dmin_l, times = [], [], [], [], [], [env.global_time]
+                for t in range(140):
+                    if script == "greedy" or (script == "late" and t >= 44):
+                        goal = np.array([robot.gx - robot.px, robot.gy - robot.py])
+                        ai = int(np.argmax(table @ goal))
+                    elif script == "random":
+                        ai = int(rng.randint(0, len(table)))
+                    else:
+                        ai = 0
+                    a = pol.action_space[ai]
+                    a = ActionXY(np.float64(a.vx), np.float64(a.vy))
+                    _, reward, done, info = env.step(a)
+                    acts.append(ai)
+                    rew.append(float(reward))
+                    done_l.append(int(done))
+                    info_l.append(INFO_CODES[str(info)])
+                    dmin_l.append(float(info.min_dist) if str(info) == "Discomfort" else np.nan)
+                    R.append(robot.get_full_state().to_tuple())
+                    Hs.append([h.get_full_state().to_tuple() for h in env.humans])
+                    times.append(env.global_time)
+                    if done:
+                        break
+                k = "sim.%s%d." % (script, case)
+                out[k + "robot"] = np.array(R, np.float64)
+                out[k + "humans"] = np.array(Hs, np.float64)
+                out[k + "actions"] = np.array(acts, np.int64)
+                out[k + "reward"] = np.array(rew, np.float64)
+                out[k + "done"] = np.array(done_l, np.int64)
+                out[k + "info"] = np.array(info_l, np.int64)
+                out[k + "dmin"] = np.array(dmin_l, np.float64)
+                out[k + "time"] = np.array(times, np.float64)
+                meta.append("%s%d|%d" % (script, case, case))
+        out["sim_cases"] = np.array(meta)
+        out["sim.action_table"] = table
+    finally:
+        envc.humans.policy, envc.sim.centralized_planning = old_policy, old_central
+        del JointState.self_state
+
+
 def main():
     torch.set_num_threads(1)
     masters = {"rand": make_master(1, 1.0), "trained": make_master(2, 1.0 / np.sqrt(32.0))}
@@ -571,6 +643,9 @@ def main():
     pg = {}
     gen_path_g(pg, scenes)
     np.savez(os.path.join(HERE, "path_g.npz"), **pg)
+    sim = {}
+    gen_sim_kats(sim)
+    np.savez(os.path.join(HERE, "sim.npz"), **sim)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-24s %8.1f KB" % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))
