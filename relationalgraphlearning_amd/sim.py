@@ -105,11 +105,17 @@ class BatchedCrowdSim(object):
         self.human_policy = human_policy
         self.kinematics = kinematics
         self.B = 0
+        self._scene_cache = {}
 
     # -- state ---------------------------------------------------------------------------------------------------
     def reset(self, phase, cases):
         """Load seeded cases (one environment each).  Returns the fp32 observation (robot (B,9), humans (B,H,5))."""
-        scenes = [generate_scene(self.cfg, phase, int(k)) for k in cases]
+        scenes = []
+        for k in cases:                      # scene generation is sequential host work (seeded rejection sampling): memoise
+            key = (phase, int(k), self.cfg.scenario, self.cfg.human_num, self.cfg.randomize_attributes)
+            if key not in self._scene_cache:
+                self._scene_cache[key] = generate_scene(self.cfg, phase, int(k))
+            scenes.append(self._scene_cache[key])
         return self.load(np.stack([s[0] for s in scenes]), np.stack([s[1] for s in scenes]),
                          np.stack([s[2] for s in scenes]), np.stack([s[3] for s in scenes]))
 
