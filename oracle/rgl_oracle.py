@@ -36,7 +36,7 @@ Reference lines each function follows (paths relative to the upstream repo):
   compute_reward_g            crowd_nav/policy/multi_human_rl.py:73-96
   gcn_predict_sequential      crowd_nav/policy/multi_human_rl.py:12-71
 """
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional
 
 import numpy as np

@@ -10,7 +10,6 @@ library or a request for gradients raise -- there is no eager/CPU fallback to hi
 """
 import ctypes as C
 
-import numpy as np
 import torch
 import torch.nn as nn
 
@@ -61,7 +60,6 @@ class _Spec(object):
             raise NotImplementedError("gradients on the HIP path cover similarity embedded_gaussian|gaussian with one "
                                       "adjacency for all layers (the shipped configurations); got %s, layerwise=%s"
                                       % (gm.similarity_function, gm.layerwise_graph))
-        from .autograd import linear_params
         self.params, self.param_shapes = [], []
 
         def add_mlp(seq):

@@ -27,7 +27,6 @@ policy_factory = ref_loader.load_reference()
 from crowd_nav.policy.graph_model import RGL  # noqa: E402
 from crowd_nav.policy.value_estimator import ValueEstimator  # noqa: E402
 from crowd_nav.policy.state_predictor import StatePredictor, LinearStatePredictor  # noqa: E402
-from crowd_nav.policy import gcn as ref_gcn  # noqa: E402
 from crowd_sim.envs.utils.state import FullState, ObservableState, JointState  # noqa: E402
 from crowd_sim.envs.utils.action import ActionXY, ActionRot  # noqa: E402
 from crowd_sim.envs.utils.utils import point_to_segment_dist  # noqa: E402
@@ -527,7 +526,6 @@ def gen_env_scenes():
     """Initial JointStates of the simulator's seeded cases (pure numpy scene generation)."""
     import gym
     from crowd_sim.envs.utils.robot import Robot
-    from crowd_sim.envs.policy import orca
     # scene generation instantiates human policies; ORCA's constructor needs nothing from rvo2
     envc = importlib.import_module("crowd_nav.configs.icra_benchmark.mp_separate").EnvConfig()
     env = gym.make("CrowdSim-v0")

@@ -1,7 +1,4 @@
 """Test helpers: build product policies/modules loaded with the golden weight sets."""
-import numpy as np
-import torch
-
 import relationalgraphlearning_amd as rga
 from relationalgraphlearning_amd.config import policy_config
 from tests import golden_io as gio

@@ -11,7 +11,6 @@ import torch
 
 import relationalgraphlearning_amd as rga
 from relationalgraphlearning_amd import _native as nat
-from relationalgraphlearning_amd.config import policy_config
 from tests import golden_io as gio
 from tests.helpers import make_mprl_policy, make_gcn_policy, JS
 
