@@ -53,6 +53,9 @@ extern "C" {
 #define RGL_ERR_BAD_MODE (-2)       /* unknown similarity / kinematics / inconsistent flags    */
 #define RGL_ERR_NULL (-3)           /* a required pointer is NULL                              */
 #define RGL_ERR_WORKSPACE (-4)      /* workspace too small (see mprl_tree_workspace_bytes)     */
+#define RGL_CONTRACT_F32 0
+#define RGL_CONTRACT_F16 1
+
 #define RGL_ERR_LDS (-5)            /* configuration does not fit the 160 KiB LDS of one CU    */
 
 typedef void* rgl_stream_t;         /* hipStream_t */
@@ -190,7 +193,10 @@ typedef struct MprlPlanner {
     int planning_width;
     int do_action_clip;
     int sparse_search;
-    int reserved;
+    int contraction_dtype;      /* RGL_CONTRACT_F32 (reference arithmetic) | RGL_CONTRACT_F16: f16 inputs, f32   *
+                                 * accumulate for the dense products of the middle GCN layer of the children's  *
+                                 * value graph (BASELINE configs[4]); RGL_ERR_BAD_MODE when the configuration   *
+                                 * has no such kernel (needs embedded_gaussian, L = 3, N <= 64)                 */
     double time_step;
     double gamma_bar;           /* gamma^(time_step * v_pref), get_normalized_gamma (:104-105)  */
     const double* actions;      /* device [A][2] float64, table of build_action_space (:155-190)*/

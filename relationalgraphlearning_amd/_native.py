@@ -20,6 +20,7 @@ ABI_VERSION = 1
 SIMILARITY = {"embedded_gaussian": 0, "gaussian": 1, "cosine": 2, "cosine_softmax": 3, "concatenation": 4,
               "squared": 5, "equal_attention": 6, "diagonal": 7}
 KINEMATICS = {"holonomic": 0, "unicycle": 1}
+CONTRACTION_DTYPES = {"f32": 0, "f16": 1}
 
 ERRORS = {-1: "RGL_ERR_BAD_SHAPE", -2: "RGL_ERR_BAD_MODE", -3: "RGL_ERR_NULL", -4: "RGL_ERR_WORKSPACE",
           -5: "RGL_ERR_LDS"}
@@ -50,7 +51,7 @@ class MprlPlanner(C.Structure):
     _fields_ = [("value_graph", RglGraph), ("value_head", RglMlp), ("predictor_graph", RglGraph),
                 ("motion_head", RglMlp), ("linear_state_predictor", C.c_int), ("kinematics", C.c_int),
                 ("num_actions", C.c_int), ("planning_depth", C.c_int), ("planning_width", C.c_int),
-                ("do_action_clip", C.c_int), ("sparse_search", C.c_int), ("reserved", C.c_int),
+                ("do_action_clip", C.c_int), ("sparse_search", C.c_int), ("contraction_dtype", C.c_int),
                 ("time_step", C.c_double), ("gamma_bar", C.c_double), ("actions", C.c_void_p),
                 ("action_groups", C.c_void_p)]
 

@@ -24,84 +24,21 @@
 //
 // Follows (reference paths): crowd_nav/policy/graph_model.py:99-130, value_estimator.py:11-20,
 // model_predictive_rl.py:245-250 (the loop whose iterations these kernels run side by side).
-#include "rgl_common.h"
-
-#include <cstdlib>
+#include "rgl_mfma.h"
 
 namespace rgl {
 int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
                            const float* robot, const float* humans, int n_scenes, int scenes_per_crowd, int H,
                            float* H_out, float* A_out, float* value_out, float* humans_next, hipStream_t stream);
+int launch_deep_children(const RglGraph* g, int P, int A, int H, const float* child_robot, const float* humans_next,
+                         float* rows_out, int f16, hipStream_t stream);      // rgl_deep.hip; 1 = outside its envelope
 }
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int XD = 32;    // x_dim
-constexpr int HID = 64;   // embedding hidden width
-constexpr int XLD = 36;   // LDS row stride of 32-wide feature rows (16-byte aligned, bank-skewed)
-constexpr int kThreads = 256;
-constexpr int kWaves = 4;
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-// Compiler-only fence: stops hipcc from hoisting every operand-fragment load of a long unrolled MFMA
-// chain to the top (which costs hundreds of VGPRs); each k-group loads its fragments right before use.
-__device__ __forceinline__ void load_fence() { asm volatile("" ::: "memory"); }
-
-// Butterfly reductions over the four 16-lane k-groups of a wave (lanes l, l^16, l^32, l^48), on the VALU
-// (gfx950 v_permlane16_swap / v_permlane32_swap) instead of the LDS crossbar (ds_bpermute).
-__device__ __forceinline__ float kgroups_max(float x) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float kgroups_sum(float x) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// m / N for 0 <= m < 65536 and 1 <= N <= 64 with magic = floor(2^32 / N) + 1
-__device__ __forceinline__ int div_small(int m, unsigned magic) { return (int)__umulhi((unsigned)m, magic); }
-// relu as ONE full-rate instruction: on the bit patterns, max(int(x), 0) maps every negative float (and -0) to +0
-// and leaves positive floats untouched (v_max_i32).  fmaxf() / med3 cost a canonicalising v_max extra on MFMA results.
-__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
-
-// Optional phase timing (-DRGL_PHASE_TIMING, tools/phase_timing.py): per-wave s_memtime deltas summed per phase.
-#ifdef RGL_PHASE_TIMING
-__device__ unsigned long long g_phase_cycles[16];
-#define PHASE_START()                                                      \
-    unsigned long long phase_acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0};          \
-    unsigned long long phase_t0__ = __builtin_amdgcn_s_memtime()
-#define PHASE_MARK(idx)                                                    \
-    do {                                                                   \
-        const unsigned long long now__ = __builtin_amdgcn_s_memtime();     \
-        phase_acc__[idx] += now__ - phase_t0__;                            \
-        phase_t0__ = now__;                                                \
-    } while (0)
-#define PHASE_FLUSH()                                                      \
-    do {                                                                   \
-        if ((threadIdx.x & 63) == 0)                                       \
-            for (int i__ = 0; i__ < 8; ++i__) atomicAdd(&g_phase_cycles[i__], phase_acc__[i__]); \
-    } while (0)
-#else
-#define PHASE_MARK(idx) do { } while (0)
-#define PHASE_START() do { } while (0)
-#define PHASE_FLUSH() do { } while (0)
-#endif
-
 // ------------------------------------------------------------------------------------------------
 // stage 1
 // ------------------------------------------------------------------------------------------------
-constexpr int WLD = 36;    // LDS row stride of the 32-column weight images (k-major); 4*WLD % 32 == 16 keeps the
-                           // four 16-lane k-groups of an MFMA A-operand read on disjoint banks
-constexpr int W1LD = 80;   // same for the 64-column image of wr1 (rows differ by 1 between k-groups)
-
 #ifndef STAGE1_THREADS
 #define STAGE1_THREADS 512
 #endif
@@ -621,33 +558,6 @@ struct Rank1Args {
     int off_crowd, crowd_stride;          // double-buffered crowd block: Xh | Gm | UW | msh | zsh
     int off_s0, off_sc0, off_x0, off_y0, off_tp, off_p00, off_scal;
 };
-
-#define DPP_QUAD_XOR1 0xB1
-#define DPP_QUAD_XOR2 0x4E
-#define DPP_ROW_HALF_MIRROR 0x141
-#define DPP_ROW_MIRROR 0x140
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float x) {
-    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xF, 0xF, false));
-}
-// all-reduce over the 32 lanes of a half-wave (lanes l and l^32 stay separate)
-__device__ __forceinline__ float half_max(float x) {
-    x = fmaxf(x, dpp_mov<DPP_QUAD_XOR1>(x));
-    x = fmaxf(x, dpp_mov<DPP_QUAD_XOR2>(x));
-    x = fmaxf(x, dpp_mov<DPP_ROW_HALF_MIRROR>(x));
-    x = fmaxf(x, dpp_mov<DPP_ROW_MIRROR>(x));
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float half_sum(float x) {
-    x += dpp_mov<DPP_QUAD_XOR1>(x);
-    x += dpp_mov<DPP_QUAD_XOR2>(x);
-    x += dpp_mov<DPP_ROW_HALF_MIRROR>(x);
-    x += dpp_mov<DPP_ROW_MIRROR>(x);
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 
 template <int HR, int NT, bool SKIP>      // HR >= N: human rows held in registers (padded rows contribute exactly 0)
 __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args a) {
@@ -1176,25 +1086,6 @@ __global__ __launch_bounds__(kHeadThreads, 2) void robot_head_kernel(const HeadA
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// host side
-// ------------------------------------------------------------------------------------------------
-inline bool mlp_is(const RglMlp& m, int d0, int d1, int d2, bool last_relu) {
-    return m.n_layers == 2 && m.dims[0] == d0 && m.dims[1] == d1 && m.dims[2] == d2 && (m.last_relu != 0) == last_relu;
-}
-
-inline int head_variant(const RglMlp& h) {
-    if (h.n_layers != 4 || h.last_relu || h.dims[0] != XD || h.dims[4] != 1) return -1;
-    if (h.dims[1] == 32 && h.dims[2] == 100 && h.dims[3] == 100) return 0;     // ValueEstimator default
-    if (h.dims[1] == 150 && h.dims[2] == 100 && h.dims[3] == 100) return 1;    // gcn.ValueNetwork default
-    return -1;
-}
-
-inline bool fast_path_enabled() {
-    static const bool off = [] { const char* e = getenv("RGL_FORCE_GENERIC"); return e && e[0] == '1'; }();
-    return !off;
-}
-
 struct ChildPlan {
     ChildArgs a;
     int ks_bucket;
@@ -1601,11 +1492,6 @@ struct Rank1Plan {
     bool ok;
 };
 
-inline bool rank1_enabled() {
-    static const bool off = [] { const char* e = getenv("RGL_CHILDREN_TILE_KERNEL"); return e && e[0] == '1'; }();
-    return !off;
-}
-
 inline Rank1Plan plan_rank1(const RglGraph& g, int P, int A, int H) {
     Rank1Plan pl;
     pl.ok = false;
@@ -1741,6 +1627,11 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
     const int A = pl->num_actions;
     ChildPlan cp = plan_children(pl->value_graph, P, A, H);
     const int hv = head_variant(pl->value_head);
+    const bool want_f16 = pl->contraction_dtype == RGL_CONTRACT_F16;
+    if (pl->contraction_dtype != RGL_CONTRACT_F32 && !want_f16) return RGL_ERR_BAD_MODE;
+    if (want_f16 && (!cp.ok || hv < 0 || pl->value_graph.num_layer != 3 || !workspace ||
+                     workspace_bytes < value_children_workspace_bytes(pl, P, H)))
+        return RGL_ERR_BAD_MODE;
     if (!cp.ok || hv < 0 || !workspace || workspace_bytes < value_children_workspace_bytes(pl, P, H)) {
         return launch_generic_forward(&pl->value_graph, &pl->value_head, nullptr, child_robot, humans_next, P * A, A, H,
                                       nullptr, nullptr, child_value, nullptr, stream);
@@ -1748,9 +1639,15 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
     cp.a.child_robot = child_robot;
     cp.a.humans = humans_next;
     cp.a.rows_out = (float*)workspace;
-    int rc;
+    int rc = 1;
     Rank1Plan rp = plan_rank1(pl->value_graph, P, A, H);
-    if (rp.ok) {
+    if (!rp.ok || want_f16) {
+        rc = launch_deep_children(&pl->value_graph, P, A, H, child_robot, humans_next, (float*)workspace, want_f16, stream);
+        if (rc == 1 && want_f16) return RGL_ERR_BAD_MODE;
+    }
+    if (rc != 1) {
+        // launched (or failed) above
+    } else if (rp.ok) {
         rp.a.child_robot = child_robot;
         rp.a.humans = humans_next;
         rp.a.rows_out = (float*)workspace;

@@ -115,6 +115,7 @@ class ModelPredictiveRL(Policy):
         self.sparse_rotation_samples = 8
         self.action_group_index = []
         self.traj = None
+        self.contraction_dtype = "f32"      # additive: "f16" = f16-input MFMA for the dense middle-layer products
         self._search = None
 
     # -- wiring ----------------------------------------------------------------------------------
@@ -125,6 +126,8 @@ class ModelPredictiveRL(Policy):
         self.do_action_clip = mp.do_action_clip
         if hasattr(mp, 'sparse_search'):
             self.sparse_search = mp.sparse_search
+        if hasattr(mp, 'contraction_dtype'):
+            self.contraction_dtype = mp.contraction_dtype
         self.planning_width = mp.planning_width
         self.share_graph_model = mp.share_graph_model
         self.linear_state_predictor = mp.linear_state_predictor
@@ -224,13 +227,14 @@ class ModelPredictiveRL(Policy):
     def tree_search(self):
         """The device search object for the current configuration (rebuilt when settings change)."""
         key = (self.planning_depth, self.planning_width, bool(self.do_action_clip), bool(self.sparse_search),
-               self.kinematics, self.time_step, self.gamma, id(self.state_predictor))
+               self.kinematics, self.time_step, self.gamma, id(self.state_predictor), self.contraction_dtype)
         if self._search is None or self._search[0] != key:
             if self.action_space is None:
                 self.build_action_space(self.v_pref)
             ts = TreeSearch(self.value_estimator, self.state_predictor, act.as_array(self.action_space),
                             self.action_group_index, self.kinematics, self.time_step, self.get_normalized_gamma(),
-                            self.planning_depth, self.planning_width, self.do_action_clip, self.sparse_search)
+                            self.planning_depth, self.planning_width, self.do_action_clip, self.sparse_search,
+                            self.contraction_dtype)
             self._search = (key, ts)
         return self._search[1]
 

@@ -31,7 +31,7 @@ class TreeSearch:
 
     def __init__(self, value_estimator, state_predictor, actions, action_groups, kinematics="holonomic",
                  time_step=0.25, gamma_bar=0.9 ** 0.25, planning_depth=1, planning_width=1, do_action_clip=False,
-                 sparse_search=False):
+                 sparse_search=False, contraction_dtype="f32"):
         self.value_estimator = value_estimator
         self.state_predictor = state_predictor            # StatePredictor module or LinearStatePredictor
         self.actions_np = np.ascontiguousarray(np.asarray(actions, dtype=np.float64))
@@ -43,6 +43,7 @@ class TreeSearch:
         self.planning_width = int(planning_width)
         self.do_action_clip = bool(do_action_clip)
         self.sparse_search = bool(sparse_search)
+        self.contraction_dtype = contraction_dtype     # "f32" (reference arithmetic) | "f16" (BASELINE configs[4])
         self._dev_tables = {}
         self._ws = _Workspace()
         self._ws2 = _Workspace()    # hand-off buffer of the stand-alone expand / value_children calls
@@ -93,6 +94,7 @@ class TreeSearch:
         pl.planning_width = self.planning_width
         pl.do_action_clip = int(self.do_action_clip)
         pl.sparse_search = int(self.sparse_search)
+        pl.contraction_dtype = nat.CONTRACTION_DTYPES[self.contraction_dtype]
         pl.time_step = self.time_step
         pl.gamma_bar = self.gamma_bar
         act, grp = self._tables(device)

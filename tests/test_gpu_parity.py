@@ -199,7 +199,10 @@ def test_checkpoint_roundtrip(dev, tmp_path):
                                                  (15, 2, "rand", True, 3), (12, 2, "trained", False, 3),
                                                  (7, 2, "rand", True, 4), (31, 1, "trained", True, 2),
                                                  (12, 3, "trained", True, 2), (9, 1, "rand", True, 3),
-                                                 (15, 3, "trained", False, 2)])
+                                                 (15, 3, "trained", False, 2), (32, 2, "trained", True, 3),
+                                                 (39, 3, "rand", False, 2), (54, 3, "trained", True, 2),
+                                                 (46, 3, "trained", False, 9), (3, 3, "trained", True, 4),
+                                                 (47, 2, "trained", True, 2), (33, 3, "rand", True, 2)])
 def test_value_children_mfma_path_vs_general_kernel(H, L, flavour, skip, P, dev):
     """The two-stage MFMA path (mprl_value_children_f32) against the general kernel (module forward)
     and the oracle, on children that share their crowd exactly like the rollout's siblings."""
@@ -223,8 +226,8 @@ def test_value_children_mfma_path_vs_general_kernel(H, L, flavour, skip, P, dev)
 
 
 def test_tile_kernel_variant_forced(dev):
-    """With RGL_CHILDREN_TILE_KERNEL=1 the MFMA tile kernel handles L=2, N<=32 too (the rank-1 kernel is the
-    default there).  The switch is read once per process, so this runs in a child process."""
+    """With RGL_CHILDREN_TILE_KERNEL=1 the MFMA tile kernel also handles what the shared-crowd kernels (rank-1: L=2,
+    N<=32; deep: L in {2,3}, N<=56) take by default.  The switch is read once per process, so this runs in a child process."""
     import os
     import subprocess
     import sys
@@ -235,8 +238,9 @@ from tests import golden_io as gio
 from tests.helpers import make_mprl_policy
 from tests.test_gpu_parity import seeded_scenes
 dev = torch.device("cuda:0")
-for H, skip in ((19, True), (5, True), (9, False), (1, True), (12, True), (15, False), (16, True), (31, True)):
-    pol = make_mprl_policy("trained", 1, L=2, skip=skip, device=dev)
+for H, skip, L in ((19, True, 2), (5, True, 2), (9, False, 2), (1, True, 2), (12, True, 2), (15, False, 2), (16, True, 2),
+                   (31, True, 2), (49, True, 3), (19, False, 3), (40, True, 2), (7, True, 3)):
+    pol = make_mprl_policy("trained", 1, L=L, skip=skip, device=dev)
     pol.build_action_space(1.0)
     ts = pol.tree_search()
     A = ts.num_actions
@@ -244,12 +248,13 @@ for H, skip in ((19, True), (5, True), (9, False), (1, True), (12, True), (15, F
     acts, _ = orc.mprl_action_space(orc.OracleConfig(), 1.0)
     cr = orc._children_robot(robot, acts, orc.OracleConfig())
     got = ts.value_children(cr.to(dev), humans.to(dev)).cpu().numpy()
-    Pm = gio.oracle_params("trained", 2)
+    Pm = gio.oracle_params("trained", L)
     with torch.no_grad():
         want = orc.value_estimator_forward(cr.reshape(3 * A, 1, 9), humans[:, None].expand(3, A, H, 5).reshape(3 * A, H, 5),
-                                           Pm.ve_graph, Pm.value_network, orc.OracleConfig(skip_connection=skip)).numpy().reshape(3, A)
+                                           Pm.ve_graph, Pm.value_network,
+                                           orc.OracleConfig(num_layer=L, skip_connection=skip)).numpy().reshape(3, A)
     err = np.abs(got - want).max()
-    assert err < 1e-4 * max(1.0, np.abs(want).max()), (H, skip, err)
+    assert err < 1e-4 * max(1.0, np.abs(want).max()), (H, skip, L, err)
 print("OK")
 '''
     env = dict(os.environ, RGL_CHILDREN_TILE_KERNEL="1")
@@ -313,6 +318,58 @@ def test_tree_vs_batched_oracle(H, D, w, clip, B, L, dev):
     for b in np.nonzero(~same)[0]:
         assert abs(float(val[b]) - float(ov[b])) < 1e-5
     assert same.mean() > 0.95
+
+
+F16_TOL = 1e-3      # BASELINE configs[4]: f16-input MFMA for the dense middle-layer products, f32 accumulate (measured ~1e-5)
+
+
+@pytest.mark.parametrize("H,skip,flavour", [(49, True, "trained"), (19, True, "trained"), (33, False, "trained"),
+                                            (5, True, "trained"), (55, True, "trained"), (49, True, "rand")])
+def test_value_children_f16_contraction(H, skip, flavour, dev):
+    """contraction_dtype = "f16" (3-layer graph, shared-crowd deep kernel): values within F16_TOL of the fp32 oracle,
+    and not bit-identical to the fp32 path (i.e. the f16 kernel really ran)."""
+    L, P = 3, 3
+    pol = make_mprl_policy(flavour, 1, L=L, skip=skip, device=dev)
+    pol.build_action_space(1.0)
+    robot, humans = seeded_scenes(900 + H, P, H)
+    acts, _ = orc.mprl_action_space(orc.OracleConfig(), 1.0)
+    cr = orc._children_robot(robot, acts, orc.OracleConfig())
+    got = {}
+    for dt in ("f32", "f16"):
+        pol.contraction_dtype = dt
+        ts = pol.tree_search()
+        assert ts.contraction_dtype == dt
+        got[dt] = ts.value_children(cr.to(dev), humans.to(dev)).cpu().numpy()
+    A = got["f32"].shape[1]
+    Pm = gio.oracle_params(flavour, L)
+    with torch.no_grad():
+        want = orc.value_estimator_forward(cr.reshape(P * A, 1, 9), humans[:, None].expand(P, A, H, 5).reshape(P * A, H, 5),
+                                           Pm.ve_graph, Pm.value_network,
+                                           orc.OracleConfig(num_layer=L, skip_connection=skip)).numpy().reshape(P, A)
+    close(got["f32"], want)
+    close(got["f16"], want, tol=F16_TOL)
+    assert not np.array_equal(got["f16"], got["f32"])
+
+
+def test_f16_tree_search_and_refusals(dev):
+    """configs[4] shape (N = 50, L = 3, D = 2, w = 2) with the f16 products: root values within F16_TOL, same decisions as
+    the fp32 oracle except on numerical ties; configurations without an f16 kernel are refused, not silently run in fp32."""
+    H, L, B = 49, 3, 6
+    robot, humans = seeded_scenes(77, B, H)
+    pol = make_mprl_policy("trained", 2, 2, True, L=L, device=dev)
+    pol.contraction_dtype = "f16"
+    cfg = orc.OracleConfig(num_layer=L, planning_depth=2, planning_width=2, do_action_clip=True)
+    with torch.no_grad():
+        oa, ov, orv, okept = orc.mprl_predict_batched(robot, humans, gio.oracle_params("trained", L), cfg)
+    act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
+    close(val.cpu().numpy(), ov.numpy(), tol=F16_TOL)
+    same = act.cpu().numpy().astype(np.int64) == oa.numpy()
+    for b in np.nonzero(~same)[0]:
+        assert abs(float(val[b]) - float(ov[b])) < F16_TOL
+    pol2 = make_mprl_policy("trained", 1, L=2, device=dev)
+    pol2.contraction_dtype = "f16"
+    with pytest.raises(nat.NativeLibraryError):
+        pol2.predict_batch(robot.to(dev), humans.to(dev))
 
 
 def test_unicycle_kinematics_both_paths(dev):

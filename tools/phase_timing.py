@@ -17,11 +17,19 @@ from relationalgraphlearning_amd import _native as nat  # noqa: E402
 
 
 class A:
-    layers, depth, width, humans = 2, 2, 2, 19
+    layers, depth, width, humans, contraction = 2, 2, 2, 19, "f32"
+
+
+DEEP_NAMES = ["loop top (end barrier)", "phase A: embeddings", "barrier", "phase B: relation block / S row+col",
+              "barrier + E load", "phase C: row scalars", "phase C': robot row", "per-child loop"]
 
 
 def main():
+    """usage: phase_timing.py [parents] [humans layers contraction]   (N > 32 or 3 layers -> the deep kernel's phases)"""
     P = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    if len(sys.argv) > 4:
+        A.humans, A.layers, A.contraction = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    deep = A.layers == 3 or A.humans + 1 > 32
     dev = torch.device("cuda:0")
     pol = bench.make_policy(A, dev)
     ts = pol.tree_search()
@@ -30,7 +38,8 @@ def main():
     lib = nat.lib()
     raw = C.CDLL(nat.LIB_PATH)
     buf = (C.c_ulonglong * 16)()
-    raw.rgl_debug_read_phase_cycles(buf, 1)
+    read = raw.rgl_debug_read_deep_phase_cycles if deep else raw.rgl_debug_read_phase_cycles
+    read(buf, 1)
     reps = 3
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -38,8 +47,8 @@ def main():
         ts.value_children(ex["child_robot"], ex["humans_next"])
     e1.record()
     torch.cuda.synchronize()
-    raw.rgl_debug_read_phase_cycles(buf, 1)
-    names = ["loop", "embed-1 / crowd-1 work", "mid barrier", "embed-2 / crowd-2 work", "barrier", "row phase work",
+    read(buf, 1)
+    names = DEEP_NAMES if deep else ["loop", "embed-1 / crowd-1 work", "mid barrier", "embed-2 / crowd-2 work", "barrier", "row phase work",
              "row barrier", "robot-row pass (+end barrier next loop)"]
     waves = 8 * P * reps          # per (wave, parent); rank-1 kernel, 8 waves per workgroup
     tot = sum(buf[i] for i in range(8))
