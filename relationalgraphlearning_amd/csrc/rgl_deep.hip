@@ -35,7 +35,7 @@ struct DeepArgs {
     int off_wh1, off_bh1, off_wh2, off_bh2, off_wa, off_wr1, off_br1, off_wr2, off_br2, off_w1, off_w2;   // weight image
     int off_xh, off_uw, off_gm, off_msh, off_zsh;       // crowd block
     int off_x0, off_y0, off_g0, off_s00;                // per-child rows; g0 is re-used for H1_0
-    int off_tp, off_ta, off_tb;                         // tables [A][TLD]: S0 -> p, Sc0 -> a, (E exchange) -> b
+    int off_tp, off_ta, off_tb;                         // tables [A][TLD]: p, S_c[.][0] -> a, (E exchange) -> b
 };
 
 constexpr int kDeepThreads = 512;
@@ -135,6 +135,14 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
             for (int e = 0; e < 8; ++e) w2h[gt][e] = (_Float16)w2[(8 * q + e) * WLD + 16 * gt + n];
     }
 
+    // Node order inside a 16-row MFMA tile whose rows feed the NEXT product's k index.  f32 path: A-operand row m holds
+    // node 16 jt + 4 (m & 3) + (m >> 2), so that the D rows 4q + r of a tile -- the k slots of lane group q in k step r --
+    // are the consecutive nodes 16 jt + 4 r + q: k step s = 4 jt + r covers nodes 4s .. 4s+3 and steps >= ceil(N / 4)
+    // are skipped.  f16 path (K = 32 per instruction, nothing to skip): plain order, node 16 jt + 4 q + r.
+    constexpr bool PERM = !F16;
+    const int jrow = PERM ? 4 * (n & 3) + (n >> 2) : n;
+    auto knode = [&](int jt, int r) { return PERM ? 16 * jt + 4 * r + q : 16 * jt + 4 * q + r; };
+    const int KS = (N + 3) >> 2;
     const bool crowd_wave = wave < NT;
     const int n_child_waves = kDeepWaves - NT;
 
@@ -269,13 +277,13 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                 f32x4 sacc = zero4();
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft) {
-                    const f32x4 xa = *reinterpret_cast<const f32x4*>(&Xh[(16 * jt + n) * XLD + 16 * ft + 4 * q]);
+                    const f32x4 xa = *reinterpret_cast<const f32x4*>(&Xh[(16 * jt + jrow) * XLD + 16 * ft + 4 * q]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sacc = mfma4(xa[r], pg[ft][r], sacc);      // [j = 16jt+4q+r][i = my node]
+                    for (int r = 0; r < 4; ++r) sacc = mfma4(xa[r], pg[ft][r], sacc);      // [j = 16jt+4r+q][i = my node]
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int j = 16 * jt + 4 * q + r;
+                    const int j = knode(jt, r);
                     if (j < 1 || j >= N) sacc[r] = NEG_INF;
                     mx = fmaxf(mx, sacc[r]);
                 }
@@ -305,8 +313,8 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                 load_fence();
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float a0 = Xh[(16 * jt + 4 * q + r) * XLD + n];
-                    const float a1 = Xh[(16 * jt + 4 * q + r) * XLD + 16 + n];
+                    const float a0 = Xh[knode(jt, r) * XLD + n];
+                    const float a1 = Xh[knode(jt, r) * XLD + 16 + n];
                     u[0] = mfma4(a0, e[jt][r], u[0]);                                         // U^T[f][i] = sum_j Xh[j][f] E[i][j]
                     u[1] = mfma4(a1, e[jt][r], u[1]);
                 }
@@ -335,6 +343,8 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                     gq[ot] = *reinterpret_cast<const f32x4*>(&G0[cc * XLD + 16 * ot + 4 * q]);
                 }
                 const float s00 = S00[cc];
+                f32x4 s0t[NT];
+                float mx0 = NEG_INF;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     load_fence();
@@ -354,11 +364,27 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                         const int nd = 16 * nt + 4 * q + r;
                         if (nd == 0) { sc[r] = s00; s0[r] = s00; }
                         if (nd >= N) { sc[r] = NEG_INF; s0[r] = NEG_INF; }
+                        mx0 = fmaxf(mx0, s0[r]);
                     }
-                    if (c < A && 16 * nt + 4 * q < TLD) {
-                        *reinterpret_cast<f32x4*>(&TA[c * TLD + 16 * nt + 4 * q]) = sc;
-                        *reinterpret_cast<f32x4*>(&TP[c * TLD + 16 * nt + 4 * q]) = s0;
+                    s0t[nt] = s0;
+                    if (c < A && 16 * nt + 4 * q < TLD) *reinterpret_cast<f32x4*>(&TA[c * TLD + 16 * nt + 4 * q]) = sc;
+                }
+                // p = softmax of the robot row, in the D layout: my lane holds nodes 16 nt + 4 q + r of child c
+                mx0 = kgroups_max(mx0);
+                float z0 = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s0t[nt][r] = __expf(s0t[nt][r] - mx0);
+                        z0 += s0t[nt][r];
                     }
+                const float iz0 = __builtin_amdgcn_rcpf(kgroups_sum(z0));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s0t[nt][r] *= iz0;
+                    if (c < A && 16 * nt + 4 * q < TLD) *reinterpret_cast<f32x4*>(&TP[c * TLD + 16 * nt + 4 * q]) = s0t[nt];
                 }
             }
         }
@@ -366,7 +392,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
         __syncthreads();
 
         // =========================== E fragments into registers (all waves) ====================================
-        // A operand of the E O product: lane (n, q) of fragment [it][jt] holds E[i = 16 it + n][j = 16 jt + 4 q + r].
+        // A operand of the E O product: lane (n, q) of fragment [it][jt] holds E[i = 16 it + n][j = knode(jt, r)].
         f32x4 Ef[F16 ? 1 : NT][F16 ? 1 : NT];
         f16x8 Eh[F16 ? NT : 1][F16 ? KT : 1];
         if (a.L == 3) {
@@ -391,42 +417,35 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
         }
         __syncthreads();
         PHASE_MARK(4);
-
-        // =========================== phase C: per-child row scalars p, a, b (lane = row) =======================
-        {
-            const int i = lane;
-            const bool row_h = i >= 1 && i < N;
-            const float my_msh = row_h ? MSH[i] : 0.f;
-            const float my_zsh = row_h ? ZSH[i] : 1.f;
-            for (int c = wave; c < A; c += kDeepWaves) {
-                const float s0v = i < N ? TP[c * TLD + i] : NEG_INF;
-                const float mx0 = wave_max(s0v);
-                const float e0 = __expf(s0v - mx0);
-                const float z0 = wave_sum(e0);
-                const float pv = e0 * __builtin_amdgcn_rcpf(z0);                  // A_c[0][i]
-                float av = i == 0 ? 1.f : 0.f, bv = 0.f;
-                if (row_h) {
-                    const float scv = TA[c * TLD + i];
-                    const float m = fmaxf(my_msh, scv);
-                    const float al = __expf(my_msh - m), be = __expf(scv - m);
-                    const float iz = __builtin_amdgcn_rcpf(fmaf(al, my_zsh, be));
-                    av = al * iz;
-                    bv = be * iz;
-                }
-                if (i < TLD) {
-                    TP[c * TLD + i] = i < N ? pv : 0.f;
-                    TA[c * TLD + i] = av;
-                    TB[c * TLD + i] = bv;
-                }
-            }
-        }
-        __syncthreads();
         PHASE_MARK(5);
 
-        // =========================== phase C': robot row of layer 0, 16 children per MFMA tile =================
+        // =========================== phase C': row scalars a, b; robot row of layer 0, 16 children per MFMA tile =================
         for (int ct = wave; ct < a.CT; ct += kDeepWaves) {
             const int c = 16 * ct + n;
             const int cc = c < A ? c : A - 1;
+            // row scalars a, b of my 16 children (D layout: nodes 16 nt + 4 q + r), over the raw S_c[node][0] left in TA
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (16 * nt + 4 * q >= TLD) continue;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(&TA[cc * TLD + 16 * nt + 4 * q]);
+                const f32x4 ms = *reinterpret_cast<const f32x4*>(&MSH[16 * nt + 4 * q]);
+                const f32x4 zs = *reinterpret_cast<const f32x4*>(&ZSH[16 * nt + 4 * q]);
+                f32x4 av, bv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nd = 16 * nt + 4 * q + r;
+                    const float m = fmaxf(ms[r], sc[r]);
+                    const float al = __expf(ms[r] - m), be = __expf(sc[r] - m);
+                    const float iz = __builtin_amdgcn_rcpf(fmaf(al, zs[r], be));
+                    const bool row_h = nd >= 1 && nd < N;
+                    av[r] = row_h ? al * iz : (nd == 0 ? 1.f : 0.f);
+                    bv[r] = row_h ? be * iz : 0.f;
+                }
+                if (c < A) {
+                    *reinterpret_cast<f32x4*>(&TA[c * TLD + 16 * nt + 4 * q]) = av;
+                    *reinterpret_cast<f32x4*>(&TB[c * TLD + 16 * nt + 4 * q]) = bv;
+                }
+            }
             f32x4 t0[2] = {zero4(), zero4()};                 // T0^T[f = 16 ft + 4q + r][c]
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
@@ -481,7 +500,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
             f32x4 tsk[2] = {zero4(), zero4()};
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
-                const int j = 16 * jt + n;
+                const int j = 16 * jt + jrow;
                 const bool jv = j < TLD;
                 const float aj = jv ? TA[c * TLD + j] : 0.f;
                 const float bj = jv ? TB[c * TLD + j] : 0.f;
@@ -519,7 +538,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                 }
                 continue;
             }
-            // ---- O = H1 W2 : tiles [jt][gt], lane (n, q) holds O[j = 16 jt + 4 q + r][g = 16 gt + n]
+            // ---- O = H1 W2 : tiles [jt][gt], lane (n, q) holds O[j = knode(jt, r)][g = 16 gt + n]
             f32x4 O[NT][2];
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) { O[jt][0] = zero4(); O[jt][1] = zero4(); }
@@ -550,16 +569,18 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                         }
                 }
             }
-            // row scalars in the D layout: i = 16 it + 4 q + r  (pq doubles as row 0 of E's first tile)
-            f32x4 pq[NT], aq[NT], bq[NT];
+            // row scalars in the D layout: i = 16 it + 4 q + r;  pn = p in k-slot order (row 0 of E's first tile)
+            f32x4 pn[NT];
 #pragma unroll
-            for (int it = 0; it < NT; ++it) {
-                const bool v = 16 * it + 4 * q < TLD;
-                pq[it] = v ? *reinterpret_cast<const f32x4*>(&TP[c * TLD + 16 * it + 4 * q]) : zero4();
-                aq[it] = v ? *reinterpret_cast<const f32x4*>(&TA[c * TLD + 16 * it + 4 * q]) : zero4();
-                bq[it] = v ? *reinterpret_cast<const f32x4*>(&TB[c * TLD + 16 * it + 4 * q]) : zero4();
+            for (int jt = 0; jt < NT; ++jt) {
+                if (PERM) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pn[jt][r] = knode(jt, r) < TLD ? TP[c * TLD + knode(jt, r)] : 0.f;
+                } else {
+                    pn[jt] = 16 * jt + 4 * q < TLD ? *reinterpret_cast<const f32x4*>(&TP[c * TLD + 16 * jt + 4 * q]) : zero4();
+                }
             }
-            // O_0[g]: held by the q == 0 lanes (r = 0 of tile jt = 0)
+            // O_0[g]: held by the q == 0 lanes (r = 0 of tile jt = 0: node 0)
             float o0[2];
 #pragma unroll
             for (int gt = 0; gt < 2; ++gt) o0[gt] = kgroups_sum(q == 0 ? O[0][gt][0] : 0.f);
@@ -575,11 +596,16 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                         ob[t][gt] = pack8(O[2 * t][gt], 2 * t + 1 < NT ? O[2 * t + 1 < NT ? 2 * t + 1 : 0][gt] : zero4());
 #pragma unroll
                 for (int it = 0; it < NT; ++it) {
+                    load_fence();
+                    const bool rv = 16 * it + 4 * q < TLD;
+                    const f32x4 pq = rv ? *reinterpret_cast<const f32x4*>(&TP[c * TLD + 16 * it + 4 * q]) : zero4();
+                    const f32x4 aq = rv ? *reinterpret_cast<const f32x4*>(&TA[c * TLD + 16 * it + 4 * q]) : zero4();
+                    const f32x4 bq = rv ? *reinterpret_cast<const f32x4*>(&TB[c * TLD + 16 * it + 4 * q]) : zero4();
                     f32x4 d[2] = {zero4(), zero4()};
 #pragma unroll
                     for (int t = 0; t < KT; ++t) {
                         f16x8 ea = Eh[F16 ? it : 0][F16 ? t : 0];
-                        if (it == 0 && n == 0) ea = pack8(pq[2 * t], 2 * t + 1 < NT ? pq[2 * t + 1 < NT ? 2 * t + 1 : 0] : zero4());
+                        if (it == 0 && n == 0) ea = pack8(pn[2 * t], 2 * t + 1 < NT ? pn[2 * t + 1 < NT ? 2 * t + 1 : 0] : zero4());
                         d[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ea, ob[t][0], d[0], 0, 0, 0);
                         d[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ea, ob[t][1], d[1], 0, 0, 0);
                     }
@@ -587,21 +613,27 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                     for (int gt = 0; gt < 2; ++gt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float v = relu1(fmaf(aq[it][r], d[gt][r], bq[it][r] * o0[gt]));
-                            tacc[gt] = fmaf(pq[it][r], v, tacc[gt]);
+                            const float v = relu1(fmaf(aq[r], d[gt][r], bq[r] * o0[gt]));
+                            tacc[gt] = fmaf(pq[r], v, tacc[gt]);
                             if (it == 0 && r == 0) hrow0[gt] = v;
                         }
                 }
             } else {
 #pragma unroll
                 for (int it = 0; it < NT; ++it) {
+                    load_fence();
+                    const bool rv = 16 * it + 4 * q < TLD;
+                    const f32x4 pq = rv ? *reinterpret_cast<const f32x4*>(&TP[c * TLD + 16 * it + 4 * q]) : zero4();
+                    const f32x4 aq = rv ? *reinterpret_cast<const f32x4*>(&TA[c * TLD + 16 * it + 4 * q]) : zero4();
+                    const f32x4 bq = rv ? *reinterpret_cast<const f32x4*>(&TB[c * TLD + 16 * it + 4 * q]) : zero4();
                     f32x4 d[2] = {zero4(), zero4()};
 #pragma unroll
                     for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
+                            if (jt == NT - 1 && 4 * jt + r >= KS) continue;       // k steps beyond the last node (uniform)
                             float ea = Ef[F16 ? 0 : it][F16 ? 0 : jt][r];
-                            if (it == 0 && n == 0) ea = pq[jt][r];
+                            if (it == 0 && n == 0) ea = pn[jt][r];
                             d[0] = mfma4(ea, O[jt][0][r], d[0]);
                             d[1] = mfma4(ea, O[jt][1][r], d[1]);
                         }
@@ -609,8 +641,8 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                     for (int gt = 0; gt < 2; ++gt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float v = relu1(fmaf(aq[it][r], d[gt][r], bq[it][r] * o0[gt]));
-                            tacc[gt] = fmaf(pq[it][r], v, tacc[gt]);
+                            const float v = relu1(fmaf(aq[r], d[gt][r], bq[r] * o0[gt]));
+                            tacc[gt] = fmaf(pq[r], v, tacc[gt]);
                             if (it == 0 && r == 0) hrow0[gt] = v;
                         }
                 }

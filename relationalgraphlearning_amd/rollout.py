@@ -312,14 +312,20 @@ class ShardedRollout:
     def run_local(self, robot_shard, humans_shard, total):
         """Same, when each rank already holds only its shard (`total` = global root count)."""
         per = -(-total // self.world)
-        packed = torch.zeros(per, 2, dtype=torch.float32, device=robot_shard.device)
         n = robot_shard.shape[0]
+        if not self.active:                      # one rank: nothing to exchange, hand the search's outputs through
+            if n == 0:
+                return (torch.zeros(0, dtype=torch.int64, device=robot_shard.device),
+                        torch.zeros(0, dtype=torch.float32, device=robot_shard.device))
+            act, val = self.search_fn(robot_shard, humans_shard)
+            return act.to(torch.int64), val
+        packed = torch.empty(per, 2, dtype=torch.float32, device=robot_shard.device)
+        if n < per:
+            packed[n:].zero_()
         if n > 0:
             act, val = self.search_fn(robot_shard, humans_shard)
-            packed[:n, 0] = act.to(torch.float32)
-            packed[:n, 1] = val
-        if not self.active:
-            return packed[:n, 0].to(torch.int64), packed[:n, 1].clone()
+            packed[:n, 0].copy_(act)             # int32 -> fp32 (exact: action indices < 2^24)
+            packed[:n, 1].copy_(val)
         gathered = torch.empty(self.world * per, 2, dtype=torch.float32, device=packed.device)
         self.dist.all_gather_into_tensor(gathered, packed, group=self.group)
         pieces_a, pieces_v = [], []

@@ -21,7 +21,7 @@ class A:
 
 
 DEEP_NAMES = ["loop top (end barrier)", "phase A: embeddings", "barrier", "phase B: relation block / S row+col",
-              "barrier + E load", "phase C: row scalars", "phase C': robot row", "per-child loop"]
+              "barrier + E load", "(unused)", "phase C: row scalars a, b + robot row", "per-child loop"]
 
 
 def main():
