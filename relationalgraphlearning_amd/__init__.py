@@ -8,8 +8,9 @@ from .nets import mlp, RGL, ValueEstimator, StatePredictor, LinearStatePredictor
 from .policy import Policy, ModelPredictiveRL, GCN, register
 from .state import FullState, ObservableState, JointState, tensor_to_joint_state
 from .rollout import TreeSearch, GcnSearch, ShardedRollout, rotate, shard_bounds
+from .vector_explorer import VectorExplorer, ReplayMemory
 
 __all__ = ["ActionXY", "ActionRot", "mlp", "RGL", "ValueEstimator", "StatePredictor", "LinearStatePredictor",
            "ValueNetwork", "Policy", "ModelPredictiveRL", "GCN", "register", "TreeSearch", "GcnSearch",
            "ShardedRollout", "rotate", "shard_bounds", "FullState", "ObservableState", "JointState",
-           "tensor_to_joint_state"]
+           "tensor_to_joint_state", "VectorExplorer", "ReplayMemory"]

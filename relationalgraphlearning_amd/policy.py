@@ -404,6 +404,14 @@ class GCN(Policy):
             self.last_state = self.transform(state)
         return max_action
 
+    def predict_batch(self, robot, humans, roots_are_joint_states=True):
+        """Additive API: robot (B,9), humans (B,H,5) device tensors -> (action index (B,), its value (B,))."""
+        if self.action_space is None:
+            self.build_action_space(float(robot[0, 7]))
+        with torch.no_grad():
+            vals, best = self.gcn_search().search(robot, humans)
+        return best, vals.gather(1, best.long().clamp(min=0)[:, None])[:, 0]
+
     def _refresh_adjacency(self, robot, humans):
         last = self.action_space[-1]
         nxt = self.propagate_robot(robot, last)
