@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
         }
         for (int i = tid; i < XD * XD; i += kDeepThreads) {
             const int r = i / XD, c = i - r * XD;
-            w[a.off_wa + r * WLD + c] = a.wa[i];
+            w[a.off_wa + r * WLD + c] = a.wa ? a.wa[i] : (r == c ? 1.f : 0.f);   // gaussian: Wa = I
             w[a.off_w1 + r * WLD + c] = a.w1[i];
             if (a.L == 3) w[a.off_w2 + r * WLD + c] = a.w2[i];
         }
@@ -679,7 +679,7 @@ inline DeepPlan plan_deep(const RglGraph& g, int P, int A, int H) {
     DeepPlan pl;
     pl.ok = false;
     if (!fast_path_enabled() || !rank1_enabled()) return pl;
-    if (g.similarity != RGL_SIM_EMBEDDED_GAUSSIAN || g.layerwise_graph || g.x_dim != XD) return pl;
+    if (!similarity_is_bilinear(g) || g.layerwise_graph || g.x_dim != XD) return pl;
     if (g.num_layer != 2 && g.num_layer != 3) return pl;
     if (!mlp_is(g.w_r, 9, HID, XD, true) || !mlp_is(g.w_h, 5, HID, XD, true)) return pl;
     const int N = H + 1;
@@ -706,7 +706,7 @@ inline DeepPlan plan_deep(const RglGraph& g, int P, int A, int H) {
     if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
     a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];
     a.wh1 = g.w_h.weight[0]; a.bh1 = g.w_h.bias[0]; a.wh2 = g.w_h.weight[1]; a.bh2 = g.w_h.bias[1];
-    a.wa = g.w_a; a.w1 = g.Ws[0]; a.w2 = g.num_layer == 3 ? g.Ws[1] : g.Ws[0];
+    a.wa = bilinear_wa(g); a.w1 = g.Ws[0]; a.w2 = g.num_layer == 3 ? g.Ws[1] : g.Ws[0];
     pl.ok = true;
     return pl;
 }

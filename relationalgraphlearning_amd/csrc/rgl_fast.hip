@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kThreads1, STAGE1_WAVES_PER_SIMD) void children_gra
         }
         for (int i = tid; i < XD * XD; i += nthreads) {
             const int r = i / XD, c = i - r * XD;
-            w[a.off_wa + r * WLD + c] = a.wa[i];
+            w[a.off_wa + r * WLD + c] = a.wa ? a.wa[i] : (r == c ? 1.f : 0.f);   // gaussian: Wa = I
         }
         for (int i = tid; i < 12 * HID; i += nthreads) {
             const int r = i / HID, c = i - r * HID;
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
         }
         for (int i = tid; i < XD * XD; i += nthreads) {
             const int r = i / XD, c = i - r * XD;
-            w[a.off_wa + r * WLD + c] = a.wa[i];
+            w[a.off_wa + r * WLD + c] = a.wa ? a.wa[i] : (r == c ? 1.f : 0.f);   // gaussian: Wa = I
             w[a.off_w1 + r * WLD + c] = a.w1[i];
         }
         for (int i = tid; i < 12 * HID; i += nthreads) {
@@ -1097,7 +1097,7 @@ inline ChildPlan plan_children(const RglGraph& g, int P, int A, int H) {
     ChildPlan pl;
     pl.ok = false;
     if (!fast_path_enabled()) return pl;
-    if (g.similarity != RGL_SIM_EMBEDDED_GAUSSIAN || g.layerwise_graph || g.x_dim != XD) return pl;
+    if (!similarity_is_bilinear(g) || g.layerwise_graph || g.x_dim != XD) return pl;
     if (g.num_layer < 1 || !mlp_is(g.w_r, 9, HID, XD, true) || !mlp_is(g.w_h, 5, HID, XD, true)) return pl;
     const int N = H + 1;
     if (N > 64 || A > 96 || A < 1) return pl;
@@ -1166,7 +1166,7 @@ inline ChildPlan plan_children(const RglGraph& g, int P, int A, int H) {
     if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
     a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];
     a.wh1 = g.w_h.weight[0]; a.bh1 = g.w_h.bias[0]; a.wh2 = g.w_h.weight[1]; a.bh2 = g.w_h.bias[1];
-    a.wa = g.w_a;
+    a.wa = bilinear_wa(g);
     for (int l = 0; l < RGL_MAX_GCN_LAYERS; ++l) a.Ws[l] = l < g.num_layer ? g.Ws[l] : nullptr;
     a.P = P; a.A = A; a.H = H;
     pl.ok = true;
@@ -1292,7 +1292,7 @@ __global__ __launch_bounds__(kThreads, 2) void scene_graph_kernel(const SceneArg
         float* w = lds;
         for (int i = tid; i < XD * XD; i += kThreads) {
             const int r = i / XD, c = i - r * XD;
-            w[a.off_wa + r * WLD + c] = a.wa[i];
+            w[a.off_wa + r * WLD + c] = a.wa ? a.wa[i] : (r == c ? 1.f : 0.f);   // gaussian: Wa = I
             for (int l = 0; l < a.L; ++l) w[a.off_ws + (l * XD + r) * WLD + c] = a.Ws[l][i];
         }
         for (int i = tid; i < XD * HID; i += kThreads) {
@@ -1496,7 +1496,7 @@ inline Rank1Plan plan_rank1(const RglGraph& g, int P, int A, int H) {
     Rank1Plan pl;
     pl.ok = false;
     if (!fast_path_enabled() || !rank1_enabled()) return pl;
-    if (g.similarity != RGL_SIM_EMBEDDED_GAUSSIAN || g.layerwise_graph || g.x_dim != XD || g.num_layer != 2) return pl;
+    if (!similarity_is_bilinear(g) || g.layerwise_graph || g.x_dim != XD || g.num_layer != 2) return pl;
     if (!mlp_is(g.w_r, 9, HID, XD, true) || !mlp_is(g.w_h, 5, HID, XD, true)) return pl;
     const int N = H + 1;
     if (N > 32 || A > 96 || A < 1) return pl;
@@ -1525,7 +1525,7 @@ inline Rank1Plan plan_rank1(const RglGraph& g, int P, int A, int H) {
     if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
     a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];
     a.wh1 = g.w_h.weight[0]; a.bh1 = g.w_h.bias[0]; a.wh2 = g.w_h.weight[1]; a.bh2 = g.w_h.bias[1];
-    a.wa = g.w_a; a.w1 = g.Ws[0];
+    a.wa = bilinear_wa(g); a.w1 = g.Ws[0];
     pl.ok = true;
     return pl;
 }
@@ -1579,7 +1579,7 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
     const RglGraph& g = pl->predictor_graph;
     const RglMlp& mh = pl->motion_head;
     const int N = H + 1;
-    const bool ok = fast_path_enabled() && g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN && !g.layerwise_graph && g.x_dim == XD &&
+    const bool ok = fast_path_enabled() && similarity_is_bilinear(g) && !g.layerwise_graph && g.x_dim == XD &&
                     g.num_layer >= 1 && g.num_layer <= 4 && mlp_is(g.w_r, 9, HID, XD, true) && mlp_is(g.w_h, 5, HID, XD, true) &&
                     mlp_is(mh, XD, HID, 5, false) && N <= 64 && workspace &&
                     workspace_bytes >= (size_t)P * N * XD * sizeof(float) && P % crowds_per == 0;
@@ -1595,7 +1595,7 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
     if (rc) return rc;
     SceneArgs sa;
     sa.xh_rows = xh_rows; sa.x0_rows = x0_rows; sa.crowds_per = crowds_per;
-    sa.wa = g.w_a;
+    sa.wa = bilinear_wa(g);
     for (int l = 0; l < RGL_MAX_GCN_LAYERS; ++l) sa.Ws[l] = l < g.num_layer ? g.Ws[l] : nullptr;
     sa.L = g.num_layer; sa.skip = g.skip_connection;
     sa.wm1 = mh.weight[0]; sa.bm1 = mh.bias[0]; sa.wm2 = mh.weight[1]; sa.bm2 = mh.bias[1];

@@ -104,6 +104,13 @@ inline bool mlp_is(const RglMlp& m, int d0, int d1, int d2, bool last_relu) {
     return m.n_layers == 2 && m.dims[0] == d0 && m.dims[1] == d1 && m.dims[2] == d2 && (m.last_relu != 0) == last_relu;
 }
 
+// The MFMA kernels compute S = X Wa X^T; `gaussian` (S = X X^T, graph_model.py:67-69) is the same with Wa = I, which the
+// kernels build in their LDS weight image when the pointer is null (x*1 + 0 is exact: same bits as X X^T).
+inline bool similarity_is_bilinear(const RglGraph& g) {
+    return g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN || g.similarity == RGL_SIM_GAUSSIAN;
+}
+inline const float* bilinear_wa(const RglGraph& g) { return g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN ? g.w_a : nullptr; }
+
 inline int head_variant(const RglMlp& h) {
     if (h.n_layers != 4 || h.last_relu || h.dims[0] != XD || h.dims[4] != 1) return -1;
     if (h.dims[1] == 32 && h.dims[2] == 100 && h.dims[3] == 100) return 0;     // ValueEstimator default

@@ -311,14 +311,20 @@ class ShardedRollout:
 
     def run_local(self, robot_shard, humans_shard, total):
         """Same, when each rank already holds only its shard (`total` = global root count)."""
+        return self.launch_local(robot_shard, humans_shard, total).result()
+
+    def launch_local(self, robot_shard, humans_shard, total):
+        """Enqueue this rank's search and the exchange WITHOUT waiting for the exchange: returns a handle whose
+        `.result()` gives (best_action, best_value) of all roots.  Calling `.result()` one step later lets the
+        (latency-bound) all-gather of step i run on RCCL's stream underneath the search of step i+1."""
         per = -(-total // self.world)
         n = robot_shard.shape[0]
         if not self.active:                      # one rank: nothing to exchange, hand the search's outputs through
             if n == 0:
-                return (torch.zeros(0, dtype=torch.int64, device=robot_shard.device),
-                        torch.zeros(0, dtype=torch.float32, device=robot_shard.device))
+                return _Exchange(None, None, total, 1, (torch.zeros(0, dtype=torch.int64, device=robot_shard.device),
+                                                        torch.zeros(0, dtype=torch.float32, device=robot_shard.device)))
             act, val = self.search_fn(robot_shard, humans_shard)
-            return act.to(torch.int64), val
+            return _Exchange(None, None, total, 1, (act.to(torch.int64), val))
         packed = torch.empty(per, 2, dtype=torch.float32, device=robot_shard.device)
         if n < per:
             packed[n:].zero_()
@@ -327,10 +333,29 @@ class ShardedRollout:
             packed[:n, 0].copy_(act)             # int32 -> fp32 (exact: action indices < 2^24)
             packed[:n, 1].copy_(val)
         gathered = torch.empty(self.world * per, 2, dtype=torch.float32, device=packed.device)
-        self.dist.all_gather_into_tensor(gathered, packed, group=self.group)
-        pieces_a, pieces_v = [], []
-        for r in range(self.world):
-            lo, hi = shard_bounds(total, self.world, r)
-            pieces_a.append(gathered[r * per:r * per + (hi - lo), 0])
-            pieces_v.append(gathered[r * per:r * per + (hi - lo), 1])
-        return torch.cat(pieces_a).to(torch.int64), torch.cat(pieces_v)
+        work = self.dist.all_gather_into_tensor(gathered, packed, group=self.group, async_op=True)
+        return _Exchange(work, gathered, total, self.world, None, keep=packed)
+
+
+class _Exchange:
+    """Handle of one sharded step: the pending all-gather and how to unpack it."""
+
+    def __init__(self, work, gathered, total, world, ready, keep=None):
+        self.work, self.gathered, self.total, self.world, self.ready, self.keep = work, gathered, total, world, ready, keep
+
+    def result(self):
+        if self.ready is None:
+            self.work.wait()                     # the caller's stream waits for the collective; the host does not block
+            per = self.gathered.shape[0] // self.world
+            if per * self.world == self.total:   # equal shards: rank r's rows are already at their global positions
+                acts, vals = self.gathered[:, 0], self.gathered[:, 1]
+            else:
+                rows = []
+                for r in range(self.world):
+                    lo, hi = shard_bounds(self.total, self.world, r)
+                    rows.append(self.gathered[r * per:r * per + (hi - lo)])
+                both = torch.cat(rows)
+                acts, vals = both[:, 0], both[:, 1]
+            self.ready = (acts.to(torch.int64), vals.contiguous())
+            self.work = self.keep = None
+        return self.ready

@@ -320,6 +320,35 @@ def test_tree_vs_batched_oracle(H, D, w, clip, B, L, dev):
     assert same.mean() > 0.95
 
 
+@pytest.mark.parametrize("H,L,D,B", [(19, 2, 2, 12), (5, 2, 1, 40), (49, 3, 2, 3), (40, 2, 1, 4), (19, 1, 1, 8)])
+def test_gaussian_similarity_on_the_mfma_path(H, L, D, B, dev):
+    """similarity_function = 'gaussian' (S = X X^T) runs on the same MFMA kernels with Wa = I built in LDS: children's values
+    (rank-1 / deep / tile kernel by shape), state predictor and the whole search against the oracle."""
+    pol = make_mprl_policy("trained", D, 2, D > 1, L=L, similarity="gaussian", device=dev)
+    pol.build_action_space(1.0)
+    cfg = orc.OracleConfig(num_layer=L, similarity="gaussian", planning_depth=D, planning_width=2, do_action_clip=D > 1)
+    Pm = gio.oracle_params("trained", L, similarity="gaussian")
+    robot, humans = seeded_scenes(500 + H + L, B, H)
+    ts = pol.tree_search()
+    A = ts.num_actions
+    acts, _ = orc.mprl_action_space(orc.OracleConfig(), 1.0)
+    cr = orc._children_robot(robot, acts, orc.OracleConfig())
+    got = ts.value_children(cr.to(dev), humans.to(dev)).cpu().numpy()
+    with torch.no_grad():
+        want = orc.value_estimator_forward(cr.reshape(B * A, 1, 9), humans[:, None].expand(B, A, H, 5).reshape(B * A, H, 5),
+                                           Pm.ve_graph, Pm.value_network, cfg).numpy().reshape(B, A)
+        hn = orc.state_predictor_humans(robot[:, None], humans, Pm.sp_graph, Pm.motion_predictor, cfg)
+        oa, ov, orv, okept = orc.mprl_predict_batched(robot, humans, Pm, cfg)
+    close(got, want)
+    ex = ts.expand(robot.to(dev), humans.to(dev), parents_are_joint_states=True)
+    close(ex["humans_next"].cpu().numpy(), hn.numpy())
+    act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
+    close(val.cpu().numpy(), ov.numpy())
+    same = act.cpu().numpy().astype(np.int64) == oa.numpy()
+    for b in np.nonzero(~same)[0]:
+        assert abs(float(val[b]) - float(ov[b])) < 1e-5
+
+
 F16_TOL = 1e-3      # BASELINE configs[4]: f16-input MFMA for the dense middle-layer products, f32 accumulate (measured ~1e-5)
 
 

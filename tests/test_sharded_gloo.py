@@ -41,6 +41,22 @@ def _worker(rank, world, port, total, out_dir):
         return a, v
     sr = ShardedRollout(search)
     act, val = sr.run(robot, humans)
+    # pipelined use (bench.py): two steps in flight, results collected one step late
+    from relationalgraphlearning_amd import shard_bounds
+    lo, hi = shard_bounds(total, world, rank)
+    h1 = sr.launch_local(robot[lo:hi], humans[lo:hi], total)
+    h2 = sr.launch_local(robot[lo:hi], humans[lo:hi], total)
+    a1, v1 = h1.result()
+    a2, v2 = h2.result()
+    assert torch.equal(a1, act) and torch.equal(v1, val) and torch.equal(a2, act) and torch.equal(v2, val)
+    assert h1.result()[0] is a1                          # idempotent
+    # equal shards take the no-copy unpacking path
+    even = total - total % world
+    he = sr.launch_local(robot[:even][rank * (even // world):(rank + 1) * (even // world)],
+                         humans[:even][rank * (even // world):(rank + 1) * (even // world)], even)
+    ae, ve = he.result()
+    assert torch.equal(ae, act[:even]) and torch.equal(ve, val[:even])
+    del calls[1:]
     torch.save({"act": act, "val": val, "calls": calls}, os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
