@@ -556,7 +556,7 @@ struct Rank1Args {
     float* rows_out;                      // [P*A][64]
     int off_wh1, off_bh1, off_wh2, off_bh2, off_wa, off_wr1, off_br1, off_wr2, off_br2, off_w1;   // weight image
     int off_crowd, crowd_stride;          // double-buffered crowd block: Xh | Gm | UW | msh | zsh
-    int off_s0, off_sc0, off_x0, off_y0, off_tp, off_p00, off_scal;
+    int off_s0, off_sc0, off_x0, off_y0, off_tp;
 };
 
 template <int HR, int NT, bool SKIP>      // HR >= N: human rows held in registers (padded rows contribute exactly 0)
@@ -578,12 +578,10 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
     const float* br2 = lds + a.off_br2;
     const float* w1 = lds + a.off_w1;     // [XD][WLD]
     float* S0 = lds + a.off_s0;           // [16*CT][SLD]
-    float* Sc0 = lds + a.off_sc0;         // [16*CT][SLD]
+    float* AB = lds + a.off_sc0;          // [16*CT][SLD][2]  per child and row: (a, b) of the rank-1 form, p folded in
     float* X0 = lds + a.off_x0;           // [16*CT][XLD]
     float* Y0 = lds + a.off_y0;           // [16*CT][XLD]  x0 W1, later T_0
     float* TP = lds + a.off_tp;           // [16*CT][XLD]  t_c without the robot-row term
-    float* P00 = lds + a.off_p00;         // [16*CT]
-    float* scal = lds + a.off_scal + wave * (2 * 32 * 4);   // [2][32][4] per wave
     const float NEG_INF = -INFINITY;
     // crowd block b: Xh[16*NT][XLD] | Gm[16*NT][XLD] | UW[16*NT][XLD] | msh[16*NT] | zsh[16*NT]
     auto crowd_xh = [&](int b) { return lds + a.off_crowd + b * a.crowd_stride; };
@@ -825,6 +823,11 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
         PHASE_MARK(2);
         // ---------------- embedding phase, second half: robot row / column of S  ||  prologue2(next parent) -------
         if (child_wave) {
+            // robot row and column of S for my 16 children, then -- still in the MFMA D layout, lane (n, q) = child
+            // 16 wave + n, nodes 16 nt + 4 q + r -- p = softmax(robot row) and the per-row scalars (a, b) of the rank-1
+            // form with p folded in.  Nothing here crosses lanes except two permlane butterflies per child tile.
+            f32x4 s0t[NT], sct[NT];
+            float mx0 = NEG_INF;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 load_fence();
@@ -842,10 +845,39 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int nd = 16 * nt + 4 * q + r;
-                    float vs = sc[r], v0 = s0[r];
-                    if (nd == 0) { vs = s00; v0 = s00; }
-                    if (nd >= N) { vs = NEG_INF; v0 = NEG_INF; }
-                    if (nd < SLD) { Sc0[c * SLD + nd] = vs; S0[c * SLD + nd] = v0; }
+                    if (nd == 0) { sc[r] = s00; s0[r] = s00; }
+                    if (nd >= N) { sc[r] = NEG_INF; s0[r] = NEG_INF; }
+                    mx0 = fmaxf(mx0, s0[r]);
+                }
+                s0t[nt] = s0;
+                sct[nt] = sc;
+            }
+            mx0 = kgroups_max(mx0);
+            float z0 = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s0t[nt][r] = __expf(s0t[nt][r] - mx0);
+                    z0 += s0t[nt][r];
+                }
+            const float iz0 = __builtin_amdgcn_rcpf(kgroups_sum(z0));
+            const float* mshp = crowd_msh(buf);
+            const float* zshp = crowd_zsh(buf);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 ms = *reinterpret_cast<const f32x4*>(&mshp[16 * nt + 4 * q]);
+                const f32x4 zs = *reinterpret_cast<const f32x4*>(&zshp[16 * nt + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nd = 16 * nt + 4 * q + r;
+                    const float pv = s0t[nt][r] * iz0;                               // A_c[0][nd]
+                    const float m = fmaxf(ms[r], sct[nt][r]);
+                    const float al = __expf(ms[r] - m), be = __expf(sct[nt][r] - m);
+                    const float piz = pv * __builtin_amdgcn_rcpf(fmaf(al, zs[r], be));
+                    const bool rh = nd >= 1 && nd < N;
+                    S0[c * SLD + nd] = pv;                                           // p row (0 beyond row N-1)
+                    *reinterpret_cast<f32x2*>(&AB[(c * SLD + nd) * 2]) = f32x2{rh ? al * piz : 0.f, rh ? be * piz : 0.f};
                 }
             }
         } else if (crowd_wave && pn < a.P) {
@@ -859,54 +891,54 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
         {
             const float* UW = crowd_uw(buf);
             const int hh = lane >> 5, f = lane & 31;
-            float uwr[HR], xhr[HR];
+            float uwr[HR];
 #pragma unroll
-            for (int i = 1; i < HR; ++i) {
-                uwr[i] = i < N ? UW[i * XLD + f] : 0.f;
-                xhr[i] = i < N ? Xh[i * XLD + f] : 0.f;
-            }
-            const float my_msh = (f >= 1 && f < N) ? crowd_msh(buf)[f] : 0.f;      // lane f doubles as row index i = f
-            const float my_zsh = (f >= 1 && f < N) ? crowd_zsh(buf)[f] : 1.f;
-            float* sc_mine = scal + (hh * 32) * 4;
+            for (int i = 1; i < HR; ++i) uwr[i] = i < N ? UW[i * XLD + f] : 0.f;
             const int n_pairs = (A + 1) / 2;
             for (int pair = wave; pair < n_pairs; pair += a.n_waves) {
                 const int ch = 2 * pair + hh;
                 const bool cv = ch < A;
                 const int cc = cv ? ch : A - 1;
-                // (1) per-row scalars; lane f = row i
-                const int i = f;
-                const float s0v = i < N ? S0[cc * SLD + i] : NEG_INF;
-                const float mx0 = half_max(s0v);
-                const float e0 = __expf(s0v - mx0);
-                const float z0 = half_sum(e0);
-                const float pv = e0 * __builtin_amdgcn_rcpf(z0);                  // A_c[0][i]
-                float av = 0.f, bv = 0.f;
-                if (i >= 1 && i < N) {
-                    const float scv = Sc0[cc * SLD + i];
-                    const float m = fmaxf(my_msh, scv);
-                    const float al = __expf(my_msh - m), be = __expf(scv - m);
-                    const float iz = __builtin_amdgcn_rcpf(fmaf(al, my_zsh, be));
-                    av = pv * al * iz;
-                    bv = pv * be * iz;
-                }
-                *reinterpret_cast<f32x4*>(&sc_mine[i * 4]) = f32x4{av, bv, i < N ? pv : 0.f, 0.f};
-                // (2) rows: racc = sum_i relu(a_i UW_i + b_i y) ; t0h = sum_i p_i Xh_i
+                const float* sc_mine = AB + cc * SLD * 2;       // (a_i, b_i) pairs of my child: the loop below is bound by
+                                                                // LDS broadcast bytes and issue, not by arithmetic
                 const float yv = Y0[cc * XLD + f];
-                const float x0v = X0[cc * XLD + f];
-                float racc = 0.f, t0h = 0.f;
+                // Written as stages over chunks of rows with scheduling barriers in between: left alone, hipcc emits one
+                // dependent mul -> fma -> max -> add chain for the whole loop, and with two waves per SIMD every
+                // instruction then waits out the previous one's latency (measured: ~8 cycles each).
+                constexpr int CH = 8;
+                constexpr int HRV = HR < 16 * NT ? HR : 16 * NT;      // the tables hold 16*NT rows per child
+                float racc = 0.f;
 #pragma unroll
-                for (int ii = 1; ii < HR; ++ii) {
-                    const f32x4 sv = *reinterpret_cast<const f32x4*>(&sc_mine[ii * 4]);
-                    t0h = fmaf(sv[2], xhr[ii], t0h);
-                    racc += relu1(fmaf(sv[0], uwr[ii], sv[1] * yv));
+                for (int i0 = 1; i0 < HRV; i0 += CH) {
+                    float t[CH];
+                    f32x2 sv[CH];
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+                        if (i0 + k < HRV) sv[k] = *reinterpret_cast<const f32x2*>(&sc_mine[(i0 + k) * 2]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+                        if (i0 + k < HRV) t[k] = sv[k][1] * yv;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+                        if (i0 + k < HRV) t[k] = fmaf(sv[k][0], uwr[i0 + k], t[k]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+                        if (i0 + k < HRV) t[k] = relu1(t[k]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+                        if (!(i0 + k < HRV)) t[k] = 0.f;
+#pragma unroll
+                    for (int w = CH / 2; w >= 1; w /= 2) {                  // pairwise tree
+#pragma unroll
+                        for (int k = 0; k < w; ++k) t[k] += t[k + w];
+                    }
+                    racc += t[0];
                 }
-                const float p00 = sc_mine[2];
-                // (3) hand the robot row to the batched MFMA pass
-                if (cv) {
-                    Y0[ch * XLD + f] = fmaf(p00, x0v, t0h);                    // T_0 = (A_c X_c)[0]
-                    TP[ch * XLD + f] = SKIP ? racc + t0h : racc;              // t_c without the robot-row term
-                    if (f == 0) P00[ch] = p00;
-                }
+                if (cv) TP[ch * XLD + f] = racc;                               // t_c without the robot-row / skip terms
             }
         }
         PHASE_MARK(5);
@@ -915,19 +947,35 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
 
         // ---------------- robot row: H1_0 = relu(T_0 W1)(+x0), t_c += p00 * H1_0, rows out ---------------------
         if (child_wave) {
+            // T_0^T[f][c] = sum_j Xh^T[f][j] p_c[j] (humans; Xh row 0 is zero) + p_c[0] x0_c, batched over my 16 children
+            const int cc = c < A ? c : A - 1;
+            f32x4 t0h[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * jt + 4 * q + r;
+                    const float pb = S0[cc * SLD + j];
+                    t0h[0] = mfma4(Xh[j * XLD + n], pb, t0h[0]);
+                    t0h[1] = mfma4(Xh[j * XLD + 16 + n], pb, t0h[1]);
+                }
+            }
+            const float p00 = S0[cc * SLD];
             f32x4 o[2] = {zero4(), zero4()};
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
                 load_fence();
-                const f32x4 tb = *reinterpret_cast<const f32x4*>(&Y0[c * XLD + 16 * ft + 4 * q]);
+                const f32x4 x0q = *reinterpret_cast<const f32x4*>(&X0[cc * XLD + 16 * ft + 4 * q]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
+                    const float tb = fmaf(p00, x0q[r], t0h[ft][r]);
 #pragma unroll
                     for (int ot = 0; ot < 2; ++ot)
-                        o[ot] = mfma4(w1[(16 * ft + 4 * q + r) * WLD + 16 * ot + n], tb[r], o[ot]);
+                        o[ot] = mfma4(w1[(16 * ft + 4 * q + r) * WLD + 16 * ot + n], tb, o[ot]);
+                }
             }
             if (c < A) {
-                const float p00 = P00[c];
                 float* out = a.rows_out + ((size_t)p * A + c) * 64;
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot) {
@@ -939,7 +987,7 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
                         float hv = relu1(o[ot][r]);
                         if (SKIP) hv += xv[r];
                         h[r] = hv;
-                        t[r] = fmaf(p00, hv, tp[r]);
+                        t[r] = fmaf(p00, hv, SKIP ? tp[r] + t0h[ot][r] : tp[r]);
                     }
                     *reinterpret_cast<f32x4*>(out + 16 * ot + 4 * q) = t;
                     *reinterpret_cast<f32x4*>(out + 32 + 16 * ot + 4 * q) = h;
@@ -1503,7 +1551,7 @@ inline Rank1Plan plan_rank1(const RglGraph& g, int P, int A, int H) {
     Rank1Args& a = pl.a;
     a.N = N; a.H = H; a.A = A; a.P = P;
     pl.hr = N <= 8 ? 8 : (N <= 20 ? 20 : 32);
-    a.SLD = N | 1;                              // odd row stride >= N
+    a.SLD = 16 * ((N + 15) / 16) + 1;           // rows padded to whole MFMA tiles (unconditional access), odd stride
     a.NT = (N + 15) / 16;
     a.CT = (A + 15) / 16;
     a.n_waves = 8;                              // CT (<= 6) child waves + NT (<= 2) crowd waves
@@ -1515,12 +1563,10 @@ inline Rank1Plan plan_rank1(const RglGraph& g, int P, int A, int H) {
     a.crowd_stride = 3 * 16 * a.NT * XLD + 2 * 16 * a.NT;
     a.off_crowd = take(2 * a.crowd_stride);
     a.off_s0 = take(16 * a.CT * a.SLD);
-    a.off_sc0 = take(16 * a.CT * a.SLD);
+    a.off_sc0 = take(2 * 16 * a.CT * a.SLD);
     a.off_x0 = take(16 * a.CT * XLD);
     a.off_y0 = take(16 * a.CT * XLD);
     a.off_tp = take(16 * a.CT * XLD);
-    a.off_p00 = take(16 * a.CT);
-    a.off_scal = take(a.n_waves * 2 * 32 * 4);
     pl.lds_bytes = (size_t)off * sizeof(float);
     if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
     a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];

@@ -7,6 +7,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int XD = 32;    // x_dim
 constexpr int HID = 64;   // embedding hidden width
