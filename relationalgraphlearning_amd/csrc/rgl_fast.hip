@@ -556,7 +556,7 @@ struct Rank1Args {
     float* rows_out;                      // [P*A][64]
     int off_wh1, off_bh1, off_wh2, off_bh2, off_wa, off_wr1, off_br1, off_wr2, off_br2, off_w1;   // weight image
     int off_crowd, crowd_stride;          // double-buffered crowd block: Xh | Gm | UW | msh | zsh
-    int off_s0, off_sc0, off_x0, off_y0, off_tp;
+    int off_sc0, off_y0, off_tp;
 };
 
 template <int HR, int NT, bool SKIP>      // HR >= N: human rows held in registers (padded rows contribute exactly 0)
@@ -577,9 +577,7 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
     const float* wr2 = lds + a.off_wr2;
     const float* br2 = lds + a.off_br2;
     const float* w1 = lds + a.off_w1;     // [XD][WLD]
-    float* S0 = lds + a.off_s0;           // [16*CT][SLD]
     float* AB = lds + a.off_sc0;          // [16*CT][SLD][2]  per child and row: (a, b) of the rank-1 form, p folded in
-    float* X0 = lds + a.off_x0;           // [16*CT][XLD]
     float* Y0 = lds + a.off_y0;           // [16*CT][XLD]  x0 W1, later T_0
     float* TP = lds + a.off_tp;           // [16*CT][XLD]  t_c without the robot-row term
     const float NEG_INF = -INFINITY;
@@ -759,6 +757,8 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
         const float* Gm = crowd_gm(buf);
         // ---------------- embedding phase, first half: x0, y = x0 W1, g0 = x0 Wa  ||  prologue1(next parent) -----
         f32x4 xacc[2] = {zero4(), zero4()}, gacc[2] = {zero4(), zero4()};
+        f32x4 t0h[2] = {zero4(), zero4()};        // child waves: (p_c Xh)^T of my 16 children, from embed-2 to the robot-row pass
+        float p00 = 0.f;                          // A_c[0][0]
         const int c = 16 * wave + n;              // meaningful for child waves only
         float s00 = 0.f;
         if (child_wave) {
@@ -793,7 +793,6 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(&br2[16 * ot + 4 * q]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xacc[ot][r] = relu1(xacc[ot][r] + bb[r]);
-                *reinterpret_cast<f32x4*>(&X0[c * XLD + 16 * ot + 4 * q]) = xacc[ot];
             }
             f32x4 yacc[2] = {zero4(), zero4()};
 #pragma unroll
@@ -862,6 +861,22 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
                     z0 += s0t[nt][r];
                 }
             const float iz0 = __builtin_amdgcn_rcpf(kgroups_sum(z0));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s0t[nt][r] *= iz0;                       // p = A_c[0][:] (0 beyond row N-1)
+            p00 = kgroups_sum(q == 0 ? s0t[0][0] : 0.f);
+            // (p_c Xh)^T[f][c] = sum_j Xh^T[f][j] p_c[j]: the D registers of the robot-row product are already the B operand
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * nt + 4 * q + r;
+                    t0h[0] = mfma4(Xh[j * XLD + n], s0t[nt][r], t0h[0]);
+                    t0h[1] = mfma4(Xh[j * XLD + 16 + n], s0t[nt][r], t0h[1]);
+                }
+            }
             const float* mshp = crowd_msh(buf);
             const float* zshp = crowd_zsh(buf);
 #pragma unroll
@@ -871,12 +886,11 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int nd = 16 * nt + 4 * q + r;
-                    const float pv = s0t[nt][r] * iz0;                               // A_c[0][nd]
+                    const float pv = s0t[nt][r];
                     const float m = fmaxf(ms[r], sct[nt][r]);
                     const float al = __expf(ms[r] - m), be = __expf(sct[nt][r] - m);
                     const float piz = pv * __builtin_amdgcn_rcpf(fmaf(al, zs[r], be));
                     const bool rh = nd >= 1 && nd < N;
-                    S0[c * SLD + nd] = pv;                                           // p row (0 beyond row N-1)
                     *reinterpret_cast<f32x2*>(&AB[(c * SLD + nd) * 2]) = f32x2{rh ? al * piz : 0.f, rh ? be * piz : 0.f};
                 }
             }
@@ -895,50 +909,21 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
 #pragma unroll
             for (int i = 1; i < HR; ++i) uwr[i] = i < N ? UW[i * XLD + f] : 0.f;
             const int n_pairs = (A + 1) / 2;
+            constexpr int HRV = HR < 16 * NT ? HR : 16 * NT;      // the tables hold 16*NT rows per child
             for (int pair = wave; pair < n_pairs; pair += a.n_waves) {
                 const int ch = 2 * pair + hh;
                 const bool cv = ch < A;
                 const int cc = cv ? ch : A - 1;
-                const float* sc_mine = AB + cc * SLD * 2;       // (a_i, b_i) pairs of my child: the loop below is bound by
-                                                                // LDS broadcast bytes and issue, not by arithmetic
+                const float* sc_mine = AB + cc * SLD * 2;       // (a_i, b_i) pairs of my child, broadcast reads: this loop is
+                                                                // bound by LDS bytes (64 lanes x 8 B per row), not by arithmetic
                 const float yv = Y0[cc * XLD + f];
-                // Written as stages over chunks of rows with scheduling barriers in between: left alone, hipcc emits one
-                // dependent mul -> fma -> max -> add chain for the whole loop, and with two waves per SIMD every
-                // instruction then waits out the previous one's latency (measured: ~8 cycles each).
-                constexpr int CH = 8;
-                constexpr int HRV = HR < 16 * NT ? HR : 16 * NT;      // the tables hold 16*NT rows per child
-                float racc = 0.f;
+                float rp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i0 = 1; i0 < HRV; i0 += CH) {
-                    float t[CH];
-                    f32x2 sv[CH];
-#pragma unroll
-                    for (int k = 0; k < CH; ++k)
-                        if (i0 + k < HRV) sv[k] = *reinterpret_cast<const f32x2*>(&sc_mine[(i0 + k) * 2]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int k = 0; k < CH; ++k)
-                        if (i0 + k < HRV) t[k] = sv[k][1] * yv;
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int k = 0; k < CH; ++k)
-                        if (i0 + k < HRV) t[k] = fmaf(sv[k][0], uwr[i0 + k], t[k]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int k = 0; k < CH; ++k)
-                        if (i0 + k < HRV) t[k] = relu1(t[k]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int k = 0; k < CH; ++k)
-                        if (!(i0 + k < HRV)) t[k] = 0.f;
-#pragma unroll
-                    for (int w = CH / 2; w >= 1; w /= 2) {                  // pairwise tree
-#pragma unroll
-                        for (int k = 0; k < w; ++k) t[k] += t[k + w];
-                    }
-                    racc += t[0];
+                for (int ii = 1; ii < HRV; ++ii) {
+                    const f32x2 sv = *reinterpret_cast<const f32x2*>(&sc_mine[ii * 2]);
+                    rp[ii & 3] += relu1(fmaf(sv[0], uwr[ii], sv[1] * yv));
                 }
-                if (cv) TP[ch * XLD + f] = racc;                               // t_c without the robot-row / skip terms
+                if (cv) TP[ch * XLD + f] = (rp[0] + rp[1]) + (rp[2] + rp[3]);   // t_c without the robot-row / skip terms
             }
         }
         PHASE_MARK(5);
@@ -947,29 +932,14 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
 
         // ---------------- robot row: H1_0 = relu(T_0 W1)(+x0), t_c += p00 * H1_0, rows out ---------------------
         if (child_wave) {
-            // T_0^T[f][c] = sum_j Xh^T[f][j] p_c[j] (humans; Xh row 0 is zero) + p_c[0] x0_c, batched over my 16 children
-            const int cc = c < A ? c : A - 1;
-            f32x4 t0h[2] = {zero4(), zero4()};
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt) {
-                load_fence();
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = 16 * jt + 4 * q + r;
-                    const float pb = S0[cc * SLD + j];
-                    t0h[0] = mfma4(Xh[j * XLD + n], pb, t0h[0]);
-                    t0h[1] = mfma4(Xh[j * XLD + 16 + n], pb, t0h[1]);
-                }
-            }
-            const float p00 = S0[cc * SLD];
+            // T_0 = (A_c X_c)[0] = p_c Xh + p_c[0] x0_c  (everything it needs is in this wave's registers)
             f32x4 o[2] = {zero4(), zero4()};
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
                 load_fence();
-                const f32x4 x0q = *reinterpret_cast<const f32x4*>(&X0[cc * XLD + 16 * ft + 4 * q]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float tb = fmaf(p00, x0q[r], t0h[ft][r]);
+                    const float tb = fmaf(p00, xacc[ft][r], t0h[ft][r]);
 #pragma unroll
                     for (int ot = 0; ot < 2; ++ot)
                         o[ot] = mfma4(w1[(16 * ft + 4 * q + r) * WLD + 16 * ot + n], tb, o[ot]);
@@ -979,13 +949,12 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
                 float* out = a.rows_out + ((size_t)p * A + c) * 64;
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot) {
-                    const f32x4 xv = *reinterpret_cast<const f32x4*>(&X0[c * XLD + 16 * ot + 4 * q]);
                     const f32x4 tp = *reinterpret_cast<const f32x4*>(&TP[c * XLD + 16 * ot + 4 * q]);
                     f32x4 h, t;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float hv = relu1(o[ot][r]);
-                        if (SKIP) hv += xv[r];
+                        if (SKIP) hv += xacc[ot][r];
                         h[r] = hv;
                         t[r] = fmaf(p00, hv, SKIP ? tp[r] + t0h[ot][r] : tp[r]);
                     }
@@ -995,7 +964,9 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
             }
         }
         PHASE_MARK(7);
-        __syncthreads();
+        // No barrier here: the robot-row pass of parent p and the first embedding half of the next parent touch only rows
+        // of the wave's own child tile (TP, Y0) and registers, and the crowd waves write the crowd buffer nobody reads
+        // any more; the mid barrier of the next iteration orders everything else.
         buf ^= 1;
     }
     PHASE_FLUSH();
@@ -1562,9 +1533,7 @@ inline Rank1Plan plan_rank1(const RglGraph& g, int P, int A, int H) {
     a.off_br2 = take(XD); a.off_w1 = take(XD * WLD);
     a.crowd_stride = 3 * 16 * a.NT * XLD + 2 * 16 * a.NT;
     a.off_crowd = take(2 * a.crowd_stride);
-    a.off_s0 = take(16 * a.CT * a.SLD);
     a.off_sc0 = take(2 * 16 * a.CT * a.SLD);
-    a.off_x0 = take(16 * a.CT * XLD);
     a.off_y0 = take(16 * a.CT * XLD);
     a.off_tp = take(16 * a.CT * XLD);
     pl.lds_bytes = (size_t)off * sizeof(float);
