@@ -103,9 +103,10 @@ class TreeSearch:
         return pl
 
     # -- device calls ----------------------------------------------------------------------------
-    def search(self, robot, humans, roots_are_joint_states=True, want_root_values=True):
+    def search(self, robot, humans, roots_are_joint_states=True, want_root_values=True, out=None):
         """robot (B,9), humans (B,H,5) fp32 device tensors -> dict of device tensors:
-        best_action (B,) int32, best_value (B,) fp32, root_values/root_kept (B,W0)."""
+        best_action (B,) int32, best_value (B,) fp32, root_values/root_kept (B,W0).
+        `out` = (int32 (B,), fp32 (B,)) contiguous device tensors to receive best_action / best_value in place."""
         robot = _require_device_tensor(robot, "robot states")
         humans = _require_device_tensor(humans, "human states")
         B, H = robot.shape[0], humans.shape[1]
@@ -118,8 +119,15 @@ class TreeSearch:
                 raise nat.NativeLibraryError("mprl_tree_workspace_bytes rejected the configuration")
             ws = self._ws.get(nbytes, dev)
             W0 = self.kept_per_node
-            out = {"best_action": torch.empty(B, dtype=torch.int32, device=dev),
-                   "best_value": torch.empty(B, dtype=torch.float32, device=dev)}
+            if out is not None:
+                act_out, val_out = out
+                if not (act_out.dtype == torch.int32 and val_out.dtype == torch.float32 and act_out.is_contiguous()
+                        and val_out.is_contiguous() and act_out.numel() == B and val_out.numel() == B):
+                    raise ValueError("out must be contiguous (int32 (B,), float32 (B,)) device tensors")
+                out = {"best_action": act_out, "best_value": val_out}
+            else:
+                out = {"best_action": torch.empty(B, dtype=torch.int32, device=dev),
+                       "best_value": torch.empty(B, dtype=torch.float32, device=dev)}
             rv = rk = None
             if want_root_values:
                 out["root_values"] = torch.empty(B, W0, dtype=torch.float32, device=dev)
@@ -293,10 +301,13 @@ class ShardedRollout:
     The only collective is one `all_gather_into_tensor` of (ceil(B/world), 2) fp32 per rank -- a few
     KB, latency-bound; on MI355X this is RCCL over xGMI (`backend="nccl"`), in the CPU tests gloo."""
 
-    def __init__(self, search_fn, group=None):
+    def __init__(self, search_fn, group=None, search_into=None):
+        """search_fn(robot, humans) -> (action (n,), value (n,));  optional search_into(robot, humans, act_out, val_out)
+        writes int32 actions / fp32 values straight into the exchange buffer (no packing kernels)."""
         import torch.distributed as dist
         self.dist = dist
         self.search_fn = search_fn
+        self.search_into = search_into
         self.group = group
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.active else 1
@@ -325,14 +336,19 @@ class ShardedRollout:
                                                         torch.zeros(0, dtype=torch.float32, device=robot_shard.device)))
             act, val = self.search_fn(robot_shard, humans_shard)
             return _Exchange(None, None, total, 1, (act.to(torch.int64), val))
-        packed = torch.empty(per, 2, dtype=torch.float32, device=robot_shard.device)
+        # exchange buffer: row 0 = action indices (int32 bit patterns), row 1 = values
+        packed = torch.empty(2, per, dtype=torch.float32, device=robot_shard.device)
         if n < per:
-            packed[n:].zero_()
+            packed[:, n:].zero_()
         if n > 0:
-            act, val = self.search_fn(robot_shard, humans_shard)
-            packed[:n, 0].copy_(act)             # int32 -> fp32 (exact: action indices < 2^24)
-            packed[:n, 1].copy_(val)
-        gathered = torch.empty(self.world * per, 2, dtype=torch.float32, device=packed.device)
+            act_out, val_out = packed[0, :n].view(torch.int32), packed[1, :n]
+            if self.search_into is not None:
+                self.search_into(robot_shard, humans_shard, act_out, val_out)
+            else:
+                act, val = self.search_fn(robot_shard, humans_shard)
+                act_out.copy_(act)
+                val_out.copy_(val)
+        gathered = torch.empty(self.world * 2, per, dtype=torch.float32, device=packed.device)   # rank-major concatenation
         work = self.dist.all_gather_into_tensor(gathered, packed, group=self.group, async_op=True)
         return _Exchange(work, gathered, total, self.world, None, keep=packed)
 
@@ -343,19 +359,23 @@ class _Exchange:
     def __init__(self, work, gathered, total, world, ready, keep=None):
         self.work, self.gathered, self.total, self.world, self.ready, self.keep = work, gathered, total, world, ready, keep
 
+    def wait(self):
+        """Order the caller's stream after the collective (the host does not block).  `result()` implies it."""
+        if self.work is not None:
+            self.work.wait()
+            self.work = self.keep = None
+        return self
+
     def result(self):
         if self.ready is None:
-            self.work.wait()                     # the caller's stream waits for the collective; the host does not block
-            per = self.gathered.shape[0] // self.world
-            if per * self.world == self.total:   # equal shards: rank r's rows are already at their global positions
-                acts, vals = self.gathered[:, 0], self.gathered[:, 1]
+            self.wait()
+            g = self.gathered.view(self.world, 2, -1)
+            per = g.shape[2]
+            if per * self.world == self.total:   # equal shards: rank r's block is already at its global position
+                acts, vals = g[:, 0, :].reshape(-1), g[:, 1, :].reshape(-1)
             else:
-                rows = []
-                for r in range(self.world):
-                    lo, hi = shard_bounds(self.total, self.world, r)
-                    rows.append(self.gathered[r * per:r * per + (hi - lo)])
-                both = torch.cat(rows)
-                acts, vals = both[:, 0], both[:, 1]
-            self.ready = (acts.to(torch.int64), vals.contiguous())
-            self.work = self.keep = None
+                sizes = [shard_bounds(self.total, self.world, r) for r in range(self.world)]
+                acts = torch.cat([g[r, 0, :hi - lo] for r, (lo, hi) in enumerate(sizes)])
+                vals = torch.cat([g[r, 1, :hi - lo] for r, (lo, hi) in enumerate(sizes)])
+            self.ready = (acts.contiguous().view(torch.int32).to(torch.int64), vals)
         return self.ready
