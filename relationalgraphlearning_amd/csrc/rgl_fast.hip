@@ -910,19 +910,37 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
             for (int i = 1; i < HR; ++i) uwr[i] = i < N ? UW[i * XLD + f] : 0.f;
             const int n_pairs = (A + 1) / 2;
             constexpr int HRV = HR < 16 * NT ? HR : 16 * NT;      // the tables hold 16*NT rows per child
+            // (a_i, b_i) of my child: ONE b64 read per 16 rows, lane k of every 16-lane DPP row holding row 16*chunk + k;
+            // each row's pair then reaches all lanes through row_newbcast operands of the mul / fmac themselves.
+            // (Reading the pairs as per-row LDS broadcasts made this loop LDS-bound: 64 lanes x 8 B per row.)
             for (int pair = wave; pair < n_pairs; pair += a.n_waves) {
                 const int ch = 2 * pair + hh;
                 const bool cv = ch < A;
                 const int cc = cv ? ch : A - 1;
-                const float* sc_mine = AB + cc * SLD * 2;       // (a_i, b_i) pairs of my child, broadcast reads: this loop is
-                                                                // bound by LDS bytes (64 lanes x 8 B per row), not by arithmetic
+                const float* sc_mine = AB + (cc * SLD + (lane & 15)) * 2;
+                f32x2 ab[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) ab[t] = *reinterpret_cast<const f32x2*>(&sc_mine[32 * t]);
                 const float yv = Y0[cc * XLD + f];
                 float rp[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ii = 1; ii < HRV; ++ii) {
-                    const f32x2 sv = *reinterpret_cast<const f32x2*>(&sc_mine[ii * 2]);
-                    rp[ii & 3] += relu1(fmaf(sv[0], uwr[ii], sv[1] * yv));
-                }
+                // four rows per step, stage by stage: each row is a mul -> fmac -> max -> add dependency chain, and with two
+                // waves per SIMD the chain latency is exposed unless independent rows are interleaved in program order
+                static_for<0, (HRV + 2) / 4>([&](auto gc) {
+                    constexpr int i0 = 1 + 4 * decltype(gc)::value;
+                    float t[4];
+                    static_for<0, 4>([&](auto kc) {
+                        constexpr int ii = i0 + decltype(kc)::value;
+                        if constexpr (ii < HRV) t[ii - i0] = dpp_rowbcast_mul<(ii & 15)>(ab[ii >> 4][1], yv);
+                    });
+                    static_for<0, 4>([&](auto kc) {
+                        constexpr int ii = i0 + decltype(kc)::value;
+                        if constexpr (ii < HRV) t[ii - i0] = dpp_rowbcast_fmac<(ii & 15)>(ab[ii >> 4][0], uwr[ii], t[ii - i0]);
+                    });
+                    static_for<0, 4>([&](auto kc) {
+                        constexpr int ii = i0 + decltype(kc)::value;
+                        if constexpr (ii < HRV) rp[ii - i0] += relu1(t[ii - i0]);
+                    });
+                });
                 if (cv) TP[ch * XLD + f] = (rp[0] + rp[1]) + (rp[2] + rp[3]);   // t_c without the robot-row / skip terms
             }
         }

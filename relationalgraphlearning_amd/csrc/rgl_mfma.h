@@ -3,6 +3,7 @@
 #include "rgl_common.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -80,6 +81,28 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
     return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xF, 0xF, false));
 }
+// gfx90a+ DPP row_newbcast:K -- every lane of a 16-lane DPP row reads lane K of its row -- fused into the consuming VOP2
+// instruction: a per-row scalar held once per DPP row reaches all lanes with no LDS traffic and no extra instruction.
+// (hipcc does not fold row_newbcast movs into their users, hence the asm.)
+template <int K>
+__device__ __forceinline__ float dpp_rowbcast_mul(float row_src, float other) {
+    float d;
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(row_src), "v"(other), "n"(K));
+    return d;
+}
+template <int K>
+__device__ __forceinline__ float dpp_rowbcast_fmac(float row_src, float other, float acc) {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(row_src), "v"(other), "n"(K));
+    return acc;
+}
+template <int I, int END, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < END) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, END>(f);
+    }
+}
+
 // all-reduce over the 32 lanes of a half-wave (lanes l and l^32 stay separate)
 __device__ __forceinline__ float half_max(float x) {
     x = fmaxf(x, dpp_mov<DPP_QUAD_XOR1>(x));
