@@ -545,8 +545,14 @@ __global__ __launch_bounds__(kThreads1, STAGE1_WAVES_PER_SIMD) void children_gra
 // msh_i = max_{j>=1} S_ij, and per child m = max(msh_i, S_c[i][0]), alpha = e^{msh_i - m}, beta = e^{S_c[i][0] - m},
 // Z = alpha*Zsh_i + beta (an exactly re-associated, overflow-safe softmax).  Because p >= 0,
 // p * relu(x) = relu(p * x), so the robot-row aggregation t_c = sum_i A_c[0][i] H_c[i] folds into the same pass:
-// ~5 VALU ops per (row, feature) instead of 26 MFMAs per 16 columns.  The robot row itself costs one batched
-// MFMA product (T_0 W1) per 16 children.
+// 4 VALU ops per (row, feature) instead of 26 MFMAs per 16 columns.  The robot row itself costs two batched
+// MFMA products (T_0 = p X_c, T_0 W1) per 16 children.
+//
+// Phases per parent (8 waves; waves 0..CT-1 own one 16-child MFMA tile each, waves CT..CT+NT-1 prepare the NEXT
+// parent's crowd block meanwhile):   [x0, y = x0 W1, g0 = x0 Wa]  barrier  [robot row/column of S, p = softmax,
+// p Xh, (a_i, b_i) table -- all in the MFMA D layout]  barrier  [row phase: all waves, lane = feature, the (a, b) pairs
+// arrive as DPP row_newbcast operands]  barrier  [robot row: T_0 W1, relu, t_c, rows out -- registers and own rows only,
+// so no barrier before the next parent].
 // ------------------------------------------------------------------------------------------------
 struct Rank1Args {
     const float *wr1, *br1, *wr2, *br2, *wh1, *bh1, *wh2, *bh2, *wa, *w1;
@@ -556,7 +562,7 @@ struct Rank1Args {
     float* rows_out;                      // [P*A][64]
     int off_wh1, off_bh1, off_wh2, off_bh2, off_wa, off_wr1, off_br1, off_wr2, off_br2, off_w1;   // weight image
     int off_crowd, crowd_stride;          // double-buffered crowd block: Xh | Gm | UW | msh | zsh
-    int off_sc0, off_y0, off_tp;
+    int off_sc0, off_y0, off_tp;          // (a, b) table [16*CT][SLD][2], y = x0 W1 [16*CT][XLD], partial t_c [16*CT][XLD]
 };
 
 template <int HR, int NT, bool SKIP>      // HR >= N: human rows held in registers (padded rows contribute exactly 0)

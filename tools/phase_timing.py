@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Per-phase cycle breakdown of children_graph_kernel (debug build: make -C relationalgraphlearning_amd/csrc timing).
+"""Per-phase cycle breakdown of the stage-1 kernels, children_rank1_kernel or children_deep_kernel (debug build:
+make -C relationalgraphlearning_amd/csrc timing; per-wave s_memtime deltas, i.e. core-clock cycles).
 
     RGL_HIP_LIBRARY=relationalgraphlearning_amd/lib/librgl_hip_timing.so python tools/phase_timing.py
 """
@@ -48,8 +49,9 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     read(buf, 1)
-    names = DEEP_NAMES if deep else ["loop", "embed-1 / crowd-1 work", "mid barrier", "embed-2 / crowd-2 work", "barrier", "row phase work",
-             "row barrier", "robot-row pass (+end barrier next loop)"]
+    names = DEEP_NAMES if deep else ["loop top", "embed-1 (x0, y, g0) / crowd-1 work", "mid barrier",
+                                     "embed-2 (S row+col, p, pXh, a/b) / crowd-2 work", "barrier", "row phase work",
+                                     "row barrier", "robot-row pass"]
     waves = 8 * P * reps          # per (wave, parent); rank-1 kernel, 8 waves per workgroup
     tot = sum(buf[i] for i in range(8))
     print("P=%d  %.3f ms per call (stage 1+2)" % (P, e0.elapsed_time(e1) / reps))
