@@ -99,6 +99,15 @@ __global__ void mprl_children_kernel(const float* __restrict__ robot, const floa
         }
         const double vx = (double)hu[2] - avx, vy = (double)hu[3] - avy;
         const double ex = px + vx * dt, ey = py + vy * dt;
+        // Exact shortcut: the outcome depends on this human only if its clearance d is < 0.2 (collision, or the minimum
+        // when that is below the discomfort distance).  dist(origin, segment) >= |p| - |e - p|, so with
+        // T = radii + 0.25 the test |p|^2 >= 2 (|e - p|^2 + T^2)  (=> |p| >= |e - p| + T) proves d >= 0.25 without the
+        // float64 division and square root of the general case; the 0.05 margin dwarfs every rounding involved.
+        {
+            const double T = (double)hu[4] + (double)r[4] + 0.25;
+            const double sx = ex - px, sy = ey - py;
+            if (px * px + py * py >= 2.0 * (sx * sx + sy * sy + T * T)) continue;
+        }
         const double d = seg_point_dist_origin(px, py, ex, ey, !joint, fpx, fpy) - (double)hu[4] - (double)r[4];
         if (d < 0.0) collision = true;
         if (d < dmin) dmin = d;
