@@ -149,7 +149,12 @@ __device__ __forceinline__ int bi_fallback(const int* kl, int k) { return k > 0 
 __global__ __launch_bounds__(256) void mprl_select_kernel(const float* __restrict__ reward, const float* __restrict__ child_value,
                                    const float* __restrict__ child_robot, const int* __restrict__ groups, int P,
                                    int A, int W, int clip, int sparse, float gamma_f, float* __restrict__ value1,
-                                   int* __restrict__ keep, float* __restrict__ next_robot) {
+                                   int* __restrict__ keep, float* __restrict__ next_robot,
+                                   // deepest level only (else null): leaf values V(kept child) and, below the root level,
+                                   // this parent's back-up step -- what mprl_leaf_kernel + mprl_backup_kernel compute
+                                   float* __restrict__ leaf_backup, const float* __restrict__ up_child_value,
+                                   const int* __restrict__ up_keep, int d, float* __restrict__ up_backup,
+                                   int* __restrict__ best_slot) {
     __shared__ int kept_lds[4][RGL_MAX_ACTIONS];         // per-wave copy of the kept indices for the gather below
     const int lane = threadIdx.x & 63;
     int* kl = kept_lds[threadIdx.x >> 6];
@@ -222,6 +227,29 @@ __global__ __launch_bounds__(256) void mprl_select_kernel(const float* __restric
             next_robot[((size_t)p * W + k) * 9 + i] = child_robot[((size_t)p * A + a) * 9 + i];
         }
     }
+    if (leaf_backup) {
+        for (int k = lane; k < W; k += 64) leaf_backup[(size_t)p * W + k] = cv[kl[k]];     // V_planning(child, 1) = V(child)
+        if (up_backup && lane == 0) {
+            // ret_k = v/d + (d-1)/d * (gamma*nv_k + r_k), first maximum (model_predictive_rl.py:293,298-302)
+            const int q = p / W, slot = p - q * W;
+            const float v = up_child_value[(size_t)q * A + up_keep[(size_t)q * W + slot]];
+            const float v_over_d = __fdiv_rn(v, (float)d);
+            const float c = (float)((double)(d - 1) / (double)d);
+            float best = 0.f;
+            int bk = -1;
+            for (int k = 0; k < W; ++k) {
+                const int a = kl[k];
+                const float inner = __fadd_rn(__fmul_rn(gamma_f, cv[a]), rw[a]);
+                const float ret = __fadd_rn(v_over_d, __fmul_rn(c, inner));
+                if (bk < 0 || ret > best) {
+                    best = ret;
+                    bk = k;
+                }
+            }
+            up_backup[(size_t)q * W + slot] = best;
+            best_slot[p] = bk;
+        }
+    }
 }
 
 // value1 = reward + gamma_bar * V(child), each op rounded to fp32 like the reference's tensor arithmetic
@@ -229,15 +257,6 @@ __global__ void one_step_value_kernel(const float* __restrict__ r, const float* 
                                       float* __restrict__ o) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) o[i] = __fadd_rn(r[i], __fmul_rn(g, v[i]));
-}
-
-// Deepest level: V_planning(child, 1) = V(child).
-__global__ void mprl_leaf_kernel(const float* __restrict__ child_value, const int* __restrict__ keep, int P, int A,
-                                 int W, float* __restrict__ backup) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)P * W) return;
-    const long long p = i / W;
-    backup[i] = child_value[p * A + keep[i]];
 }
 
 // Level l >= 1, one thread per parent p: ret_k = v/d + (d-1)/d * (gamma*nv_k + r_k); the max goes to
@@ -611,20 +630,20 @@ extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* rob
                           (float*)(ws + L.humans_next), (float*)(ws + L.child_robot), (float*)(ws + L.reward),
                           (float*)(ws + L.child_value), ws + scratch_off, (size_t)scratch_bytes, st);
         if (rc) return rc;
-        float* next_robot = l + 1 < D ? (float*)(ws + lv[l + 1].robot) : nullptr;
+        const bool deepest = l + 1 == D;
+        float* next_robot = deepest ? nullptr : (float*)(ws + lv[l + 1].robot);
+        // the deepest level's selection also writes the leaf values and (below the root) does its own back-up step
+        const bool up = deepest && l >= 1;
         hipLaunchKernelGGL(mprl_select_kernel, grid_for(P, 4), dim3(256), 0, st, (const float*)(ws + L.reward),
                            (const float*)(ws + L.child_value), (const float*)(ws + L.child_robot), pl.action_groups, P, A,
                            W, pl.do_action_clip, pl.sparse_search, gamma_f, (float*)(ws + L.value1), (int*)(ws + L.keep),
-                           next_robot);
+                           next_robot, deepest ? (float*)(ws + L.backup) : nullptr,
+                           up ? (const float*)(ws + lv[l - 1].child_value) : nullptr,
+                           up ? (const int*)(ws + lv[l - 1].keep) : nullptr, 2,
+                           up ? (float*)(ws + lv[l - 1].backup) : nullptr, up ? (int*)(ws + L.best_slot) : nullptr);
         RGL_LAUNCH_CHECK();
     }
-    {
-        const LevelLayout& L = lv[D - 1];
-        hipLaunchKernelGGL(mprl_leaf_kernel, grid_for(L.P * W), dim3(kBlock), 0, st, (const float*)(ws + L.child_value),
-                           (const int*)(ws + L.keep), (int)L.P, A, W, (float*)(ws + L.backup));
-        RGL_LAUNCH_CHECK();
-    }
-    for (int l = D - 1; l >= 1; --l) {
+    for (int l = D - 2; l >= 1; --l) {
         const LevelLayout& L = lv[l];
         const LevelLayout& U = lv[l - 1];
         hipLaunchKernelGGL(mprl_backup_kernel, grid_for(L.P, 64), dim3(64), 0, st, (const float*)(ws + L.reward),
