@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void mprl_select_kernel(const float* __restric
                                    int A, int W, int clip, int sparse, float gamma_f, float* __restrict__ value1,
                                    int* __restrict__ keep, float* __restrict__ next_robot,
                                    // deepest level only (else null): leaf values V(kept child) and, below the root level,
-                                   // this parent's back-up step -- what mprl_leaf_kernel + mprl_backup_kernel compute
+                                   // this parent's back-up step -- the leaf step and the first mprl_backup_kernel step
                                    float* __restrict__ leaf_backup, const float* __restrict__ up_child_value,
                                    const int* __restrict__ up_keep, int d, float* __restrict__ up_backup,
                                    int* __restrict__ best_slot) {
