@@ -56,6 +56,16 @@ def _worker(rank, world, port, total, out_dir):
                          humans[:even][rank * (even // world):(rank + 1) * (even // world)], even)
     ae, ve = he.result()
     assert torch.equal(ae, act[:even]) and torch.equal(ve, val[:even])
+    # search_into: the search writes int32 actions / fp32 values straight into the exchange buffer (what bench.py uses)
+    def search_into(r, h, act_out, val_out):
+        a, v = search(r, h)
+        assert act_out.dtype == torch.int32 and val_out.dtype == torch.float32 and act_out.is_contiguous()
+        act_out.copy_(a)
+        val_out.copy_(v)
+    sr2 = ShardedRollout(search, search_into=search_into)
+    hx = sr2.launch_local(robot[lo:hi], humans[lo:hi], total).wait()
+    ax, vx = hx.result()
+    assert torch.equal(ax, act) and torch.equal(vx, val)
     del calls[1:]
     torch.save({"act": act, "val": val, "calls": calls}, os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
