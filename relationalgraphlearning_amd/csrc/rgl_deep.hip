@@ -31,6 +31,7 @@ struct DeepArgs {
     const float* child_robot;             // [P][A][9]
     const float* humans;                  // [P][H][5]
     int P, A, H, N, L, CT, TLD;           // TLD: row stride of the per-child tables (multiple of 4, >= N)
+    int sim;                              // SIM_* row normalisation
     float* rows_out;                      // [P*A][64]
     int off_wh1, off_bh1, off_wh2, off_bh2, off_wa, off_wr1, off_br1, off_wr2, off_br2, off_w1, off_w2;   // weight image
     int off_xh, off_uw, off_gm, off_msh, off_zsh;       // crowd block
@@ -65,8 +66,9 @@ __device__ __forceinline__ f16x8 pack8(f32x4 lo, f32x4 hi) {
     return v;
 }
 
-template <int NT, bool F16, bool SKIP>
+template <int NT, bool F16, bool SKIP, bool SOFT>
 __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const DeepArgs a) {
+    const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int KT = (NT + 1) / 2;          // f16: k tiles of 32 nodes
     const int tid = threadIdx.x;
@@ -284,19 +286,21 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = knode(jt, r);
-                    if (j < 1 || j >= N) sacc[r] = NEG_INF;
+                    if (sim != SIM_SOFTMAX) sacc[r] = plain_weight(sim, sacc[r], node, j);
+                    if (j < 1 || j >= N) sacc[r] = sim == SIM_SOFTMAX ? NEG_INF : 0.f;
                     mx = fmaxf(mx, sacc[r]);
                 }
                 e[jt] = sacc;
             }
             mx = kgroups_max(mx);
-            if (!node_ok) mx = 0.f;
+            if (!node_ok || sim != SIM_SOFTMAX) mx = 0.f;
             float z = 0.f;
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    e[jt][r] = node_ok ? __expf(e[jt][r] - mx) : 0.f;
+                    if (sim == SIM_SOFTMAX) e[jt][r] = __expf(e[jt][r] - mx);
+                    if (!node_ok) e[jt][r] = 0.f;
                     z += e[jt][r];
                 }
             z = kgroups_sum(z);
@@ -363,7 +367,8 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                     for (int r = 0; r < 4; ++r) {
                         const int nd = 16 * nt + 4 * q + r;
                         if (nd == 0) { sc[r] = s00; s0[r] = s00; }
-                        if (nd >= N) { sc[r] = NEG_INF; s0[r] = NEG_INF; }
+                        if (sim != SIM_SOFTMAX) s0[r] = plain_weight(sim, s0[r], 0, nd);
+                        if (nd >= N) { sc[r] = NEG_INF; s0[r] = sim == SIM_SOFTMAX ? NEG_INF : 0.f; }
                         mx0 = fmaxf(mx0, s0[r]);
                     }
                     s0t[nt] = s0;
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        s0t[nt][r] = __expf(s0t[nt][r] - mx0);
+                        if (sim == SIM_SOFTMAX) s0t[nt][r] = __expf(s0t[nt][r] - mx0);
                         z0 += s0t[nt][r];
                     }
                 const float iz0 = __builtin_amdgcn_rcpf(kgroups_sum(z0));
@@ -434,8 +439,15 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int nd = 16 * nt + 4 * q + r;
-                    const float m = fmaxf(ms[r], sc[r]);
-                    const float al = __expf(ms[r] - m), be = __expf(sc[r] - m);
+                    float al, be;
+                    if (sim == SIM_SOFTMAX) {
+                        const float m = fmaxf(ms[r], sc[r]);
+                        al = __expf(ms[r] - m);
+                        be = __expf(sc[r] - m);
+                    } else {
+                        al = 1.f;
+                        be = plain_weight(sim, sc[r], nd, 0);
+                    }
                     const float iz = __builtin_amdgcn_rcpf(fmaf(al, zs[r], be));
                     const bool row_h = nd >= 1 && nd < N;
                     av[r] = row_h ? al * iz : (nd == 0 ? 1.f : 0.f);
@@ -679,13 +691,14 @@ inline DeepPlan plan_deep(const RglGraph& g, int P, int A, int H) {
     DeepPlan pl;
     pl.ok = false;
     if (!fast_path_enabled() || !rank1_enabled()) return pl;
-    if (!similarity_is_bilinear(g) || g.layerwise_graph || g.x_dim != XD) return pl;
+    if (fast_similarity_mode(g) < 0 || g.layerwise_graph || g.x_dim != XD) return pl;
     if (g.num_layer != 2 && g.num_layer != 3) return pl;
     if (!mlp_is(g.w_r, 9, HID, XD, true) || !mlp_is(g.w_h, 5, HID, XD, true)) return pl;
     const int N = H + 1;
     if (N > 64 || A > 96 || A < 1) return pl;
     DeepArgs& a = pl.a;
     a.N = N; a.H = H; a.A = A; a.P = P; a.L = g.num_layer;
+    a.sim = fast_similarity_mode(g);
     pl.NT = (N + 15) / 16;
     a.CT = (A + 15) / 16;
     a.TLD = (N + 3) & ~3;
@@ -711,9 +724,9 @@ inline DeepPlan plan_deep(const RglGraph& g, int P, int A, int H) {
     return pl;
 }
 
-template <int NT, bool F16, bool SKIP>
+template <int NT, bool F16, bool SKIP, bool SOFT>
 int launch_deep_t(const DeepPlan& pl, hipStream_t st) {
-    auto kern = children_deep_kernel<NT, F16, SKIP>;
+    auto kern = children_deep_kernel<NT, F16, SKIP, SOFT>;
     if (pl.lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)pl.lds_bytes));
@@ -726,8 +739,13 @@ int launch_deep_t(const DeepPlan& pl, hipStream_t st) {
 
 template <int NT>
 int launch_deep_nt(const DeepPlan& pl, bool f16, bool skip, hipStream_t st) {
-    if (f16) return skip ? launch_deep_t<NT, true, true>(pl, st) : launch_deep_t<NT, true, false>(pl, st);
-    return skip ? launch_deep_t<NT, false, true>(pl, st) : launch_deep_t<NT, false, false>(pl, st);
+    const bool soft = pl.a.sim == SIM_SOFTMAX;
+    if (f16) {
+        if (!soft) return 1;                      // f16 contractions are built for the softmax similarities only
+        return skip ? launch_deep_t<NT, true, true, true>(pl, st) : launch_deep_t<NT, true, false, true>(pl, st);
+    }
+    if (soft) return skip ? launch_deep_t<NT, false, true, true>(pl, st) : launch_deep_t<NT, false, false, true>(pl, st);
+    return skip ? launch_deep_t<NT, false, true, false>(pl, st) : launch_deep_t<NT, false, false, false>(pl, st);
 }
 
 }  // namespace

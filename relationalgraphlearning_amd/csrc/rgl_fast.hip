@@ -1,5 +1,6 @@
 // rgl_fast.hip -- f32-MFMA kernels for the shipped configuration of the relational graph
-// (embedded_gaussian similarity, one adjacency for all layers, x_dim 32, embedding MLPs
+// (embedded_gaussian similarity -- and the other per-row-sum normalisations: gaussian, squared, equal_attention,
+// diagonal, see rgl_mfma.h --, one adjacency for all layers, x_dim 32, embedding MLPs
 // 9->64->32 / 5->64->32, value head 32->D1->D2->D3->1), specialised for the shape the rollout
 // actually produces: the A sibling children of one parent share their crowd and differ only in
 // the robot row.
@@ -559,14 +560,17 @@ struct Rank1Args {
     const float* child_robot;             // [P][A][9]
     const float* humans;                  // [P][H][5]
     int P, A, H, N, CT, NT, SLD, n_waves;
+    int sim;                              // SIM_* row normalisation
     float* rows_out;                      // [P*A][64]
     int off_wh1, off_bh1, off_wh2, off_bh2, off_wa, off_wr1, off_br1, off_wr2, off_br2, off_w1;   // weight image
     int off_crowd, crowd_stride;          // double-buffered crowd block: Xh | Gm | UW | msh | zsh
     int off_sc0, off_y0, off_tp;          // (a, b) table [16*CT][SLD][2], y = x0 W1 [16*CT][XLD], partial t_c [16*CT][XLD]
 };
 
-template <int HR, int NT, bool SKIP>      // HR >= N: human rows held in registers (padded rows contribute exactly 0)
+// HR >= N: human rows held in registers (padded rows contribute exactly 0); SOFT: softmax row normalisation (else sim)
+template <int HR, int NT, bool SKIP, bool SOFT>
 __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args a) {
+    const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -701,19 +705,21 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int j = 16 * jt + 4 * q + r;
-                if (j < 1 || j >= N) sacc[r] = NEG_INF;
+                if (sim != SIM_SOFTMAX) sacc[r] = plain_weight(sim, sacc[r], node, j);
+                if (j < 1 || j >= N) sacc[r] = sim == SIM_SOFTMAX ? NEG_INF : 0.f;
                 mx = fmaxf(mx, sacc[r]);
             }
             e[jt] = sacc;
         }
         mx = kgroups_max(mx);
-        if (!node_ok) mx = 0.f;
+        if (!node_ok || sim != SIM_SOFTMAX) mx = 0.f;
         float z = 0.f;
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                e[jt][r] = node_ok ? __expf(e[jt][r] - mx) : 0.f;
+                if (sim == SIM_SOFTMAX) e[jt][r] = __expf(e[jt][r] - mx);
+                if (!node_ok) e[jt][r] = 0.f;
                 z += e[jt][r];
             }
         z = kgroups_sum(z);
@@ -851,7 +857,8 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
                 for (int r = 0; r < 4; ++r) {
                     const int nd = 16 * nt + 4 * q + r;
                     if (nd == 0) { sc[r] = s00; s0[r] = s00; }
-                    if (nd >= N) { sc[r] = NEG_INF; s0[r] = NEG_INF; }
+                    if (sim != SIM_SOFTMAX) s0[r] = plain_weight(sim, s0[r], 0, nd);
+                    if (nd >= N) { sc[r] = NEG_INF; s0[r] = sim == SIM_SOFTMAX ? NEG_INF : 0.f; }
                     mx0 = fmaxf(mx0, s0[r]);
                 }
                 s0t[nt] = s0;
@@ -863,7 +870,7 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    s0t[nt][r] = __expf(s0t[nt][r] - mx0);
+                    if (sim == SIM_SOFTMAX) s0t[nt][r] = __expf(s0t[nt][r] - mx0);
                     z0 += s0t[nt][r];
                 }
             const float iz0 = __builtin_amdgcn_rcpf(kgroups_sum(z0));
@@ -893,8 +900,15 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
                 for (int r = 0; r < 4; ++r) {
                     const int nd = 16 * nt + 4 * q + r;
                     const float pv = s0t[nt][r];
-                    const float m = fmaxf(ms[r], sct[nt][r]);
-                    const float al = __expf(ms[r] - m), be = __expf(sct[nt][r] - m);
+                    float al, be;
+                    if (sim == SIM_SOFTMAX) {
+                        const float m = fmaxf(ms[r], sct[nt][r]);
+                        al = __expf(ms[r] - m);
+                        be = __expf(sct[nt][r] - m);
+                    } else {
+                        al = 1.f;
+                        be = plain_weight(sim, sct[nt][r], nd, 0);        // diagonal: nd >= 1 here, so 0
+                    }
                     const float piz = pv * __builtin_amdgcn_rcpf(fmaf(al, zs[r], be));
                     const bool rh = nd >= 1 && nd < N;
                     *reinterpret_cast<f32x2*>(&AB[(c * SLD + nd) * 2]) = f32x2{rh ? al * piz : 0.f, rh ? be * piz : 0.f};
@@ -1158,7 +1172,7 @@ inline ChildPlan plan_children(const RglGraph& g, int P, int A, int H) {
     ChildPlan pl;
     pl.ok = false;
     if (!fast_path_enabled()) return pl;
-    if (!similarity_is_bilinear(g) || g.layerwise_graph || g.x_dim != XD) return pl;
+    if (fast_similarity_mode(g) != SIM_SOFTMAX || g.layerwise_graph || g.x_dim != XD) return pl;
     if (g.num_layer < 1 || !mlp_is(g.w_r, 9, HID, XD, true) || !mlp_is(g.w_h, 5, HID, XD, true)) return pl;
     const int N = H + 1;
     if (N > 64 || A > 96 || A < 1) return pl;
@@ -1331,6 +1345,7 @@ struct SceneArgs {
     const float* wa;                   // [32][32]
     const float* Ws[RGL_MAX_GCN_LAYERS];
     int L, skip;
+    int sim;                           // SIM_* row normalisation
     const float *wm1, *bm1, *wm2, *bm2;   // motion head, k-major [32][64], [64], [64][5], [5]
     float* humans_next;                // [P][H][5]
     int P, H, N;
@@ -1339,8 +1354,9 @@ struct SceneArgs {
 
 constexpr int M2LD = 20;   // LDS row stride of the [64][5 -> 16] motion output layer (4*M2LD % 32 == 16)
 
-template <int NT>
+template <int NT, bool SOFT>
 __global__ __launch_bounds__(kThreads, 2) void scene_graph_kernel(const SceneArgs a) {
+    const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
@@ -1416,7 +1432,9 @@ __global__ __launch_bounds__(kThreads, 2) void scene_graph_kernel(const SceneArg
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (16 * jt + 4 * q + r >= N) sacc[r] = -INFINITY;
+                    const int j = 16 * jt + 4 * q + r;
+                    if (sim != SIM_SOFTMAX) sacc[r] = plain_weight(sim, sacc[r], 16 * ct + n, j);
+                    if (j >= N) sacc[r] = sim == SIM_SOFTMAX ? -INFINITY : 0.f;
                     mx = fmaxf(mx, sacc[r]);
                 }
                 pr[ct][jt] = sacc;
@@ -1427,7 +1445,7 @@ __global__ __launch_bounds__(kThreads, 2) void scene_graph_kernel(const SceneArg
             for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pr[ct][jt][r] = __expf(pr[ct][jt][r] - mx);
+                    if (sim == SIM_SOFTMAX) pr[ct][jt][r] = __expf(pr[ct][jt][r] - mx);
                     sum += pr[ct][jt][r];
                 }
             sum = kgroups_sum(sum);
@@ -1536,7 +1554,7 @@ int launch_row_mlp2(const RglMlp& m, const float* rows, float* out, int M, hipSt
 
 template <int NT>
 int launch_scene(const SceneArgs& sa, size_t lds_bytes, hipStream_t st) {
-    auto kern = scene_graph_kernel<NT>;
+    auto kern = sa.sim == SIM_SOFTMAX ? scene_graph_kernel<NT, true> : scene_graph_kernel<NT, false>;
     if (lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_bytes));
@@ -1560,7 +1578,7 @@ inline Rank1Plan plan_rank1(const RglGraph& g, int P, int A, int H) {
     Rank1Plan pl;
     pl.ok = false;
     if (!fast_path_enabled() || !rank1_enabled()) return pl;
-    if (!similarity_is_bilinear(g) || g.layerwise_graph || g.x_dim != XD || g.num_layer != 2) return pl;
+    if (fast_similarity_mode(g) < 0 || g.layerwise_graph || g.x_dim != XD || g.num_layer != 2) return pl;
     if (!mlp_is(g.w_r, 9, HID, XD, true) || !mlp_is(g.w_h, 5, HID, XD, true)) return pl;
     const int N = H + 1;
     if (N > 32 || A > 96 || A < 1) return pl;
@@ -1586,13 +1604,14 @@ inline Rank1Plan plan_rank1(const RglGraph& g, int P, int A, int H) {
     a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];
     a.wh1 = g.w_h.weight[0]; a.bh1 = g.w_h.bias[0]; a.wh2 = g.w_h.weight[1]; a.bh2 = g.w_h.bias[1];
     a.wa = bilinear_wa(g); a.w1 = g.Ws[0];
+    a.sim = fast_similarity_mode(g);
     pl.ok = true;
     return pl;
 }
 
-template <int HR, int NT, bool SKIP>
-int launch_rank1_t(const Rank1Plan& pl, hipStream_t st) {
-    auto kern = children_rank1_kernel<HR, NT, SKIP>;
+template <int HR, int NT, bool SKIP, bool SOFT>
+int launch_rank1_ts(const Rank1Plan& pl, hipStream_t st) {
+    auto kern = children_rank1_kernel<HR, NT, SKIP, SOFT>;
     if (pl.lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)pl.lds_bytes));
@@ -1600,6 +1619,11 @@ int launch_rank1_t(const Rank1Plan& pl, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(pl.a.n_waves * 64), pl.lds_bytes, st, pl.a);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
+}
+
+template <int HR, int NT, bool SKIP>
+int launch_rank1_t(const Rank1Plan& pl, hipStream_t st) {
+    return pl.a.sim == SIM_SOFTMAX ? launch_rank1_ts<HR, NT, SKIP, true>(pl, st) : launch_rank1_ts<HR, NT, SKIP, false>(pl, st);
 }
 
 inline int launch_rank1(const Rank1Plan& pl, bool skip, hipStream_t st) {
@@ -1639,7 +1663,7 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
     const RglGraph& g = pl->predictor_graph;
     const RglMlp& mh = pl->motion_head;
     const int N = H + 1;
-    const bool ok = fast_path_enabled() && similarity_is_bilinear(g) && !g.layerwise_graph && g.x_dim == XD &&
+    const bool ok = fast_path_enabled() && fast_similarity_mode(g) >= 0 && !g.layerwise_graph && g.x_dim == XD &&
                     g.num_layer >= 1 && g.num_layer <= 4 && mlp_is(g.w_r, 9, HID, XD, true) && mlp_is(g.w_h, 5, HID, XD, true) &&
                     mlp_is(mh, XD, HID, 5, false) && N <= 64 && workspace &&
                     workspace_bytes >= (size_t)P * N * XD * sizeof(float) && P % crowds_per == 0;
@@ -1656,6 +1680,7 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
     SceneArgs sa;
     sa.xh_rows = xh_rows; sa.x0_rows = x0_rows; sa.crowds_per = crowds_per;
     sa.wa = bilinear_wa(g);
+    sa.sim = fast_similarity_mode(g);
     for (int l = 0; l < RGL_MAX_GCN_LAYERS; ++l) sa.Ws[l] = l < g.num_layer ? g.Ws[l] : nullptr;
     sa.L = g.num_layer; sa.skip = g.skip_connection;
     sa.wm1 = mh.weight[0]; sa.bm1 = mh.bias[0]; sa.wm2 = mh.weight[1]; sa.bm2 = mh.bias[1];
@@ -1685,41 +1710,45 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
 int launch_value_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
                           float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     const int A = pl->num_actions;
-    ChildPlan cp = plan_children(pl->value_graph, P, A, H);
     const int hv = head_variant(pl->value_head);
     const bool want_f16 = pl->contraction_dtype == RGL_CONTRACT_F16;
     if (pl->contraction_dtype != RGL_CONTRACT_F32 && !want_f16) return RGL_ERR_BAD_MODE;
-    if (want_f16 && (!cp.ok || hv < 0 || pl->value_graph.num_layer != 3 || !workspace ||
-                     workspace_bytes < value_children_workspace_bytes(pl, P, H)))
-        return RGL_ERR_BAD_MODE;
-    if (!cp.ok || hv < 0 || !workspace || workspace_bytes < value_children_workspace_bytes(pl, P, H)) {
+    const bool staged = hv >= 0 && workspace && workspace_bytes >= value_children_workspace_bytes(pl, P, H);
+    // stage 1, in order of preference: rank-1 (L = 2, N <= 32), shared-crowd deep (L in {2,3}, N <= 60), tiles (softmax
+    // similarities, any depth, N <= 64); everything else, or a head without a stage-2 kernel: the general kernel
+    int rc = 1;                                            // 1 = no stage-1 kernel launched yet
+    if (staged) {
+        Rank1Plan rp = plan_rank1(pl->value_graph, P, A, H);
+        if (rp.ok && !want_f16) {
+            rp.a.child_robot = child_robot;
+            rp.a.humans = humans_next;
+            rp.a.rows_out = (float*)workspace;
+            rc = launch_rank1(rp, pl->value_graph.skip_connection != 0, stream);
+        } else {
+            rc = launch_deep_children(&pl->value_graph, P, A, H, child_robot, humans_next, (float*)workspace,
+                                      want_f16 && pl->value_graph.num_layer == 3, stream);
+            if (want_f16 && (rc == 1 || pl->value_graph.num_layer != 3)) return RGL_ERR_BAD_MODE;
+        }
+        if (rc == 1) {
+            ChildPlan cp = plan_children(pl->value_graph, P, A, H);
+            if (cp.ok) {
+                cp.a.child_robot = child_robot;
+                cp.a.humans = humans_next;
+                cp.a.rows_out = (float*)workspace;
+                switch (cp.ks_bucket) {
+                    case 2: rc = launch_children<2>(cp, stream); break;
+                    case 5: rc = launch_children<5>(cp, stream); break;
+                    case 8: rc = launch_children<8>(cp, stream); break;
+                    case 13: rc = launch_children<13>(cp, stream); break;
+                    default: rc = launch_children<16>(cp, stream); break;
+                }
+            }
+        }
+    }
+    if (want_f16 && rc == 1) return RGL_ERR_BAD_MODE;
+    if (rc == 1)
         return launch_generic_forward(&pl->value_graph, &pl->value_head, nullptr, child_robot, humans_next, P * A, A, H,
                                       nullptr, nullptr, child_value, nullptr, stream);
-    }
-    cp.a.child_robot = child_robot;
-    cp.a.humans = humans_next;
-    cp.a.rows_out = (float*)workspace;
-    int rc = 1;
-    Rank1Plan rp = plan_rank1(pl->value_graph, P, A, H);
-    if (!rp.ok || want_f16) {
-        rc = launch_deep_children(&pl->value_graph, P, A, H, child_robot, humans_next, (float*)workspace, want_f16, stream);
-        if (rc == 1 && want_f16) return RGL_ERR_BAD_MODE;
-    }
-    if (rc != 1) {
-        // launched (or failed) above
-    } else if (rp.ok) {
-        rp.a.child_robot = child_robot;
-        rp.a.humans = humans_next;
-        rp.a.rows_out = (float*)workspace;
-        rc = launch_rank1(rp, pl->value_graph.skip_connection != 0, stream);
-    } else
-    switch (cp.ks_bucket) {
-        case 2: rc = launch_children<2>(cp, stream); break;
-        case 5: rc = launch_children<5>(cp, stream); break;
-        case 8: rc = launch_children<8>(cp, stream); break;
-        case 13: rc = launch_children<13>(cp, stream); break;
-        default: rc = launch_children<16>(cp, stream); break;
-    }
     if (rc) return rc;
     HeadArgs ha;
     const RglGraph& g = pl->value_graph;

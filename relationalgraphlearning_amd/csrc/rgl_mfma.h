@@ -128,12 +128,28 @@ inline bool mlp_is(const RglMlp& m, int d0, int d1, int d2, bool last_relu) {
     return m.n_layers == 2 && m.dims[0] == d0 && m.dims[1] == d1 && m.dims[2] == d2 && (m.last_relu != 0) == last_relu;
 }
 
-// The MFMA kernels compute S = X Wa X^T; `gaussian` (S = X X^T, graph_model.py:67-69) is the same with Wa = I, which the
-// kernels build in their LDS weight image when the pointer is null (x*1 + 0 is exact: same bits as X X^T).
-inline bool similarity_is_bilinear(const RglGraph& g) {
-    return g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN || g.similarity == RGL_SIM_GAUSSIAN;
+// The MFMA kernels compute S = X Wa X^T and normalise its rows.  `gaussian`, `squared` (S = X X^T, graph_model.py:67-69,
+// 86-89) are the same with Wa = I, which the kernels build in their LDS weight image when the pointer is null (x*1 + 0 is
+// exact: same bits as X X^T); `equal_attention` / `diagonal` (:90-93) ignore S.  Row normalisations the shared-crowd
+// kernels and the scene kernel implement: A_ij = w_ij / sum_j w_ij with
+//   SIM_SOFTMAX  w = e^{S_ij - max_j S_ij}      SIM_SQUARED  w = S_ij^2      SIM_EQUAL  w = 1      SIM_DIAGONAL  w = [i == j]
+// (`cosine*` scale every column by a child-dependent norm and `concatenation` is a pair MLP: general kernel.)
+enum { SIM_SOFTMAX = 0, SIM_SQUARED = 1, SIM_EQUAL = 2, SIM_DIAGONAL = 3 };
+inline int fast_similarity_mode(const RglGraph& g) {
+    switch (g.similarity) {
+        case RGL_SIM_EMBEDDED_GAUSSIAN:
+        case RGL_SIM_GAUSSIAN: return SIM_SOFTMAX;
+        case RGL_SIM_SQUARED: return SIM_SQUARED;
+        case RGL_SIM_EQUAL_ATTENTION: return SIM_EQUAL;
+        case RGL_SIM_DIAGONAL: return SIM_DIAGONAL;
+        default: return -1;
+    }
 }
 inline const float* bilinear_wa(const RglGraph& g) { return g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN ? g.w_a : nullptr; }
+// un-normalised weight of a VALID entry under the non-softmax modes (entry s of row i, column j)
+__device__ __forceinline__ float plain_weight(int sim, float s, int i, int j) {
+    return sim == SIM_SQUARED ? s * s : (sim == SIM_EQUAL ? 1.f : (i == j ? 1.f : 0.f));
+}
 
 inline int head_variant(const RglMlp& h) {
     if (h.n_layers != 4 || h.last_relu || h.dims[0] != XD || h.dims[4] != 1) return -1;

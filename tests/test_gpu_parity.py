@@ -320,14 +320,17 @@ def test_tree_vs_batched_oracle(H, D, w, clip, B, L, dev):
     assert same.mean() > 0.95
 
 
-@pytest.mark.parametrize("H,L,D,B", [(19, 2, 2, 12), (5, 2, 1, 40), (49, 3, 2, 3), (40, 2, 1, 4), (19, 1, 1, 8)])
-def test_gaussian_similarity_on_the_mfma_path(H, L, D, B, dev):
-    """similarity_function = 'gaussian' (S = X X^T) runs on the same MFMA kernels with Wa = I built in LDS: children's values
-    (rank-1 / deep / tile kernel by shape), state predictor and the whole search against the oracle."""
-    pol = make_mprl_policy("trained", D, 2, D > 1, L=L, similarity="gaussian", device=dev)
+@pytest.mark.parametrize("sim", ["gaussian", "squared", "equal_attention", "diagonal"])
+@pytest.mark.parametrize("H,L,D,B", [(19, 2, 2, 12), (5, 2, 1, 40), (49, 3, 2, 3), (40, 2, 1, 4), (19, 1, 1, 8), (12, 3, 1, 5)])
+def test_other_similarities_on_the_mfma_path(sim, H, L, D, B, dev):
+    """The similarity functions whose row normalisation is a per-row sum -- gaussian (S = X X^T, softmax), squared
+    (S^2 / sum S^2), equal_attention (1/N), diagonal (I) -- run on the shared-crowd MFMA kernels (Wa = I built in LDS):
+    children's values (rank-1 / deep kernel by shape; L = 1 goes to the tile kernel for gaussian and to the general kernel
+    otherwise), state predictor and the whole search against the oracle."""
+    pol = make_mprl_policy("trained", D, 2, D > 1, L=L, similarity=sim, device=dev)
     pol.build_action_space(1.0)
-    cfg = orc.OracleConfig(num_layer=L, similarity="gaussian", planning_depth=D, planning_width=2, do_action_clip=D > 1)
-    Pm = gio.oracle_params("trained", L, similarity="gaussian")
+    cfg = orc.OracleConfig(num_layer=L, similarity=sim, planning_depth=D, planning_width=2, do_action_clip=D > 1)
+    Pm = gio.oracle_params("trained", L, similarity=sim)
     robot, humans = seeded_scenes(500 + H + L, B, H)
     ts = pol.tree_search()
     A = ts.num_actions
