@@ -124,7 +124,8 @@ int rgl_graph_forward_f32(const RglGraph* graph, const RglMlp* value_head, const
  * parameter, summed over the n_scenes scenes (deterministic: per-scene slabs reduced in scene order).
  * Replaces: torch autograd through RGL.forward / ValueEstimator.forward / StatePredictor.forward /
  * gcn.ValueNetwork.forward as driven by MPRLTrainer / VNRLTrainer (crowd_nav/utils/trainer.py:110-161,
- * 199-250).  Supported: similarity embedded_gaussian | gaussian, layerwise_graph = 0 (else RGL_ERR_BAD_MODE).
+ * 199-250).  Supported: similarity embedded_gaussian | gaussian | squared | equal_attention | diagonal,
+ * layerwise_graph = 0 (else RGL_ERR_BAD_MODE).
  *   d_value [n_scenes], d_humans_next [n_scenes][H][out], d_H [n_scenes][N][x_dim]: upstream gradients of the
  *   corresponding forward outputs (device; NULL = zero).  detach_graph = 1 reproduces
  *   StatePredictor(..., detach=True): only the heads receive gradients.

@@ -5,7 +5,7 @@
 // writes its own gradient slab (every element exactly once, by one thread, as a fixed-order sum), and
 // reduce_slabs_kernel adds the slabs in scene order, so the result is deterministic.
 //
-// Supported structure: similarity embedded_gaussian or gaussian, one adjacency for all layers
+// Supported structure: similarity embedded_gaussian, gaussian, squared, equal_attention or diagonal; one adjacency for all layers
 // (layerwise_graph = 0), any depth / skip / MLP shapes within the ABI limits.  Anything else returns
 // RGL_ERR_BAD_MODE (the Python side raises; it never falls back to another device).
 //
@@ -152,6 +152,7 @@ __global__ __launch_bounds__(kThreads) void rgl_scene_backward_kernel(const Back
     float* d1 = lds + a.l_d1;
     const int a_ld = a.a_ld, d_ld = a.d_ld;
     const bool embedded = g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN;
+    const int sim = g.similarity;
 
     for (int s = blockIdx.x; s < a.n_scenes; s += gridDim.x) {
         float* slab = a.slabs + (size_t)s * a.n_params;
@@ -187,11 +188,21 @@ __global__ __launch_bounds__(kThreads) void rgl_scene_backward_kernel(const Back
         __syncthreads();
         for (int i = threadIdx.x; i < N; i += kThreads) {
             float* r = A + i * a_ld;
-            float mx = r[0];
-            for (int j = 1; j < N; ++j) mx = fmaxf(mx, r[j]);
-            float sum = 0.f;
-            for (int j = 0; j < N; ++j) { r[j] = expf(r[j] - mx); sum += r[j]; }
-            for (int j = 0; j < N; ++j) r[j] = r[j] / sum;
+            if (sim == RGL_SIM_SQUARED) {                       // S^2 / sum_j S^2   (graph_model.py:86-89)
+                float sum = 0.f;
+                for (int j = 0; j < N; ++j) { r[j] = r[j] * r[j]; sum += r[j]; }
+                for (int j = 0; j < N; ++j) r[j] = r[j] / sum;
+            } else if (sim == RGL_SIM_EQUAL_ATTENTION) {
+                for (int j = 0; j < N; ++j) r[j] = 1.f / (float)N;
+            } else if (sim == RGL_SIM_DIAGONAL) {
+                for (int j = 0; j < N; ++j) r[j] = i == j ? 1.f : 0.f;
+            } else {                                            // row softmax
+                float mx = r[0];
+                for (int j = 1; j < N; ++j) mx = fmaxf(mx, r[j]);
+                float sum = 0.f;
+                for (int j = 0; j < N; ++j) { r[j] = expf(r[j] - mx); sum += r[j]; }
+                for (int j = 0; j < N; ++j) r[j] = r[j] / sum;
+            }
         }
         __syncthreads();
         for (int l = 0; l < L; ++l) {
@@ -304,10 +315,28 @@ __global__ __launch_bounds__(kThreads) void rgl_scene_backward_kernel(const Back
             dnxt = t;
         }
         // dcur = dL/dX from the layers.  softmax: dS_ij = A_ij (dA_ij - sum_k dA_ik A_ik)   (in place in dA)
+        //                                  squared: dS_ij = (2 S_ij / sum_k S_ik^2) (dA_ij - sum_k dA_ik A_ik), S recomputed
+        //                                  equal_attention / diagonal: A is constant, dS = 0
         for (int i = threadIdx.x; i < N; i += kThreads) {
             float dot = 0.f;
             for (int j = 0; j < N; ++j) dot = fmaf(dA[i * a_ld + j], A[i * a_ld + j], dot);
-            for (int j = 0; j < N; ++j) dA[i * a_ld + j] = A[i * a_ld + j] * (dA[i * a_ld + j] - dot);
+            if (sim == RGL_SIM_SQUARED) {
+                float z = 0.f;
+                for (int j = 0; j < N; ++j) {
+                    float sij = 0.f;
+                    for (int k = 0; k < xd; ++k) sij = fmaf(G[i * xd + k], X[j * xd + k], sij);
+                    z = fmaf(sij, sij, z);
+                }
+                for (int j = 0; j < N; ++j) {
+                    float sij = 0.f;
+                    for (int k = 0; k < xd; ++k) sij = fmaf(G[i * xd + k], X[j * xd + k], sij);
+                    dA[i * a_ld + j] = 2.f * sij / z * (dA[i * a_ld + j] - dot);
+                }
+            } else if (sim == RGL_SIM_EQUAL_ATTENTION || sim == RGL_SIM_DIAGONAL) {
+                for (int j = 0; j < N; ++j) dA[i * a_ld + j] = 0.f;
+            } else {
+                for (int j = 0; j < N; ++j) dA[i * a_ld + j] = A[i * a_ld + j] * (dA[i * a_ld + j] - dot);
+            }
         }
         __syncthreads();
         // (X = H_0 is still addressed through the pointer set up in the forward part)
@@ -387,7 +416,10 @@ int plan_backward(const RglGraph* graph, const RglMlp* vh, const RglMlp* mh, int
     int rc = rgl::validate_graph(*graph, H);
     if (rc) return rc;
     if (graph->layerwise_graph) return RGL_ERR_BAD_MODE;
-    if (graph->similarity != RGL_SIM_EMBEDDED_GAUSSIAN && graph->similarity != RGL_SIM_GAUSSIAN) return RGL_ERR_BAD_MODE;
+    if (graph->similarity != RGL_SIM_EMBEDDED_GAUSSIAN && graph->similarity != RGL_SIM_GAUSSIAN &&
+        graph->similarity != RGL_SIM_SQUARED && graph->similarity != RGL_SIM_EQUAL_ATTENTION &&
+        graph->similarity != RGL_SIM_DIAGONAL)
+        return RGL_ERR_BAD_MODE;
     a.g = *graph;
     a.has_vhead = (vh && vh->n_layers > 0) ? 1 : 0;
     a.has_mhead = (mh && mh->n_layers > 0) ? 1 : 0;

@@ -56,8 +56,10 @@ class _Spec(object):
         self.value_desc, self.motion_desc = value_desc, motion_desc
         self.want_H, self.want_A, self.detach_graph = want_H, want_A, detach_graph
         gm = graph_module
-        if gm.similarity_function not in ("embedded_gaussian", "gaussian") or gm.layerwise_graph:
-            raise NotImplementedError("gradients on the HIP path cover similarity embedded_gaussian|gaussian with one "
+        if gm.similarity_function not in ("embedded_gaussian", "gaussian", "squared", "equal_attention",
+                                          "diagonal") or gm.layerwise_graph:
+            raise NotImplementedError("gradients on the HIP path cover similarity embedded_gaussian|gaussian|squared|"
+                                      "equal_attention|diagonal with one "
                                       "adjacency for all layers (the shipped configurations); got %s, layerwise=%s"
                                       % (gm.similarity_function, gm.layerwise_graph))
         self.params, self.param_shapes = [], []

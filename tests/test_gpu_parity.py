@@ -577,7 +577,11 @@ def _grad_close(got, want, name, tol=2e-4):
                                                      (19, 2, "embedded_gaussian", True, "trained", 4),
                                                      (5, 3, "embedded_gaussian", False, "trained", 5),
                                                      (3, 1, "gaussian", True, "trained", 6),
-                                                     (5, 2, "embedded_gaussian", True, "rand", 3)])
+                                                     (5, 2, "embedded_gaussian", True, "rand", 3),
+                                                     (5, 2, "squared", True, "trained", 5),
+                                                     (7, 3, "squared", False, "trained", 3),
+                                                     (5, 2, "equal_attention", True, "trained", 4),
+                                                     (4, 2, "diagonal", True, "trained", 4)])
 def test_gradients_value_estimator_and_state_predictor(H, L, sim, skip, flavour, B, dev):
     c = dict(L=L, sim=sim, layerwise=False, skip=skip, flavour=flavour)
     g1, ve, sp = build_modules(c, dev)
