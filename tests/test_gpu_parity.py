@@ -352,6 +352,34 @@ def test_other_similarities_on_the_mfma_path(sim, H, L, D, B, dev):
         assert abs(float(val[b]) - float(ov[b])) < 1e-5
 
 
+@pytest.mark.parametrize("speeds,rots,H,L", [(3, 8, 19, 2), (5, 19, 5, 2), (6, 16, 19, 2), (2, 4, 49, 3), (1, 1, 7, 2)])
+def test_non_default_action_spaces(speeds, rots, H, L, dev):
+    """Action tables other than 5 x 16 + 1: A = 25 (two child tiles), 96 (exactly six), 97 (beyond the MFMA kernels' 96:
+    general kernel), 9, 2 -- whole depth-2 search against the batched oracle."""
+    cfgp = policy_config("model_predictive_rl", gcn__num_layer=L, action_space__speed_samples=speeds,
+                         action_space__rotation_samples=rots, model_predictive_rl__planning_depth=2,
+                         model_predictive_rl__planning_width=2, model_predictive_rl__do_action_clip=True)
+    pol = rga.ModelPredictiveRL()
+    pol.time_step = 0.25
+    pol.configure(cfgp)
+    pol.load_state_dict(gio.checkpoint("trained", L))
+    pol.set_time_step(0.25)
+    pol.set_phase("test")
+    pol.set_device(dev)
+    B = 6
+    robot, humans = seeded_scenes(321 + speeds + rots, B, H)
+    cfg = orc.OracleConfig(num_layer=L, speed_samples=speeds, rotation_samples=rots, planning_depth=2, planning_width=2,
+                           do_action_clip=True)
+    with torch.no_grad():
+        oa, ov, orv, okept = orc.mprl_predict_batched(robot, humans, gio.oracle_params("trained", L), cfg)
+    act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
+    assert pol.tree_search().num_actions == speeds * rots + 1
+    close(val.cpu().numpy(), ov.numpy())
+    same = act.cpu().numpy().astype(np.int64) == oa.numpy()
+    for b in np.nonzero(~same)[0]:
+        assert abs(float(val[b]) - float(ov[b])) < 1e-5
+
+
 F16_TOL = 1e-3      # BASELINE configs[4]: f16-input MFMA for the dense middle-layer products, f32 accumulate (measured ~1e-5)
 
 
