@@ -565,6 +565,7 @@ struct Rank1Args {
     int off_wh1, off_bh1, off_wh2, off_bh2, off_wa, off_wr1, off_br1, off_wr2, off_br2, off_w1;   // weight image
     int off_crowd, crowd_stride;          // double-buffered crowd block: Xh | Gm | UW | msh | zsh
     int off_sc0, off_y0, off_tp;          // (a, b) table [16*CT][SLD][2], y = x0 W1 [16*CT][XLD], partial t_c [16*CT][XLD]
+    int off_flag;                         // [4] ints: crowd-wave epochs
 };
 
 // HR >= N: human rows held in registers (padded rows contribute exactly 0); SOFT: softmax row normalisation (else sim)
@@ -756,6 +757,9 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
 
     PHASE_START();
     int buf = 0;
+    int* crowd_flag = reinterpret_cast<int*>(lds + a.off_flag);      // [NT] epoch reached by each crowd wave's part 1
+    int crowd_epoch = 0;
+    if (tid < NT) crowd_flag[tid] = 0;
     if ((int)blockIdx.x < a.P) {               // prime the pipeline: crowd block of the first parent
         if (crowd_wave) prologue1(blockIdx.x, 0);
         __syncthreads();
@@ -830,7 +834,16 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
             prologue1(pn, buf ^ 1);
         }
         PHASE_MARK(1);
-        __syncthreads();
+        // No workgroup barrier here.  The child waves go straight on: their second half needs only their own registers and the
+        // CURRENT parent's crowd block, finished an iteration ago.  Only the crowd waves depend on each other (part 2 reads
+        // every Xh row of the block part 1 just wrote): they meet on a pair of LDS flags.
+        if (NT > 1 && crowd_wave && pn < a.P) {
+            ++crowd_epoch;
+            if (lane == 0) __hip_atomic_store(&crowd_flag[pct], crowd_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int w = 0; w < NT; ++w)
+                while (__hip_atomic_load(&crowd_flag[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < crowd_epoch)
+                    __builtin_amdgcn_s_sleep(2);
+        }
         PHASE_MARK(2);
         // ---------------- embedding phase, second half: robot row / column of S  ||  prologue2(next parent) -------
         if (child_wave) {
@@ -1599,6 +1612,7 @@ inline Rank1Plan plan_rank1(const RglGraph& g, int P, int A, int H) {
     a.off_sc0 = take(2 * 16 * a.CT * a.SLD);
     a.off_y0 = take(16 * a.CT * XLD);
     a.off_tp = take(16 * a.CT * XLD);
+    a.off_flag = take(4);
     pl.lds_bytes = (size_t)off * sizeof(float);
     if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
     a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];
