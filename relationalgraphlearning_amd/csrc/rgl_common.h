@@ -51,6 +51,24 @@ inline int validate_graph(const RglGraph& g, int H) {
     return RGL_OK;
 }
 
+// ---- internal launchers (one translation unit each; a return value of 1 means "outside this kernel's envelope") -------------
+int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
+                           const float* robot, const float* humans, int n_scenes, int scenes_per_crowd, int H,
+                           float* H_out, float* A_out, float* value_out, float* humans_next, hipStream_t stream);   // rgl_generic.hip
+int launch_rank1_children(const RglGraph* g, int P, int A, int H, const float* child_robot, const float* humans_next,
+                          float* rows_out, hipStream_t stream);                                                     // rgl_rank1.hip
+int launch_deep_children(const RglGraph* g, int P, int A, int H, const float* child_robot, const float* humans_next,
+                         float* rows_out, int f16, hipStream_t stream);                                             // rgl_deep.hip
+int launch_tile_children(const RglGraph* g, int P, int A, int H, const float* child_robot, const float* humans_next,
+                         float* rows_out, hipStream_t stream);                                                      // rgl_tile.hip
+int launch_head_rows(const RglGraph* g, const RglMlp* head, const float* rows, int M, float* value,
+                     hipStream_t stream);                                                                          // rgl_head.hip
+int launch_value_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
+                          float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream);         // rgl_fast.hip
+size_t value_children_workspace_bytes(const MprlPlanner* pl, int P, int H);                                        // rgl_fast.hip
+int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float* humans, int crowds_per, int P, int H,
+                          float* humans_next, void* workspace, size_t workspace_bytes, hipStream_t stream);         // rgl_scene.hip
+
 inline int mlp_max_hidden(const RglMlp& m) {
     int w = 0;
     for (int l = 1; l < m.n_layers; ++l) w = m.dims[l] > w ? m.dims[l] : w;

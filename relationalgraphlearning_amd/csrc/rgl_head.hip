@@ -1,0 +1,131 @@
+// rgl_head.hip -- stage 2 of "value of the sibling children": rows [t_c | H_{L-1}[robot]] -> value.
+//   h = relu(t W_last) (+skip), value head 32 -> D1 -> D2 -> D3 -> 1; one register-resident MFMA chain per 16 children,
+//   weights as pre-permuted A fragments in LDS.
+// Follows (reference paths): crowd_nav/policy/graph_model.py:124-127 (last layer), value_estimator.py:9,18-19.
+#include "rgl_mlp_chain.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// stage 2:  rows [t | hprev] -> value
+// ------------------------------------------------------------------------------------------------
+struct HeadArgs {
+    const float* w_last;          // [32][32] last GCN layer
+    const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;   // value head, k-major
+    int skip;
+    const float* rows;            // [M][64]
+    float* value;                 // [M]
+    int M, n_tiles;
+};
+
+template <int D1, int D2, int D3>
+struct HeadLds {
+    static constexpr int f_last = 0;
+    static constexpr int f1 = f_last + 2 * 2 * 4 * 64;
+    static constexpr int f2 = f1 + Tiles<D1>::v * 2 * 4 * 64;
+    static constexpr int f3 = f2 + Tiles<D2>::v * Tiles<D1>::v * 4 * 64;
+    static constexpr int b1 = f3 + Tiles<D3>::v * Tiles<D2>::v * 4 * 64;
+    static constexpr int b2 = b1 + Tiles<D1>::v * 16;
+    static constexpr int b3 = b2 + Tiles<D2>::v * 16;
+    static constexpr int w4 = b3 + Tiles<D3>::v * 16;
+    static constexpr int total = w4 + Tiles<D3>::v * 16;
+};
+
+constexpr int kHeadThreads = 512;     // 8 waves share one weight image; two workgroups per CU -> 4 waves/SIMD
+constexpr int kHeadWaves = kHeadThreads / 64;
+
+template <int D1, int D2, int D3>
+__global__ __launch_bounds__(kHeadThreads, 2) void robot_head_kernel(const HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using LO = HeadLds<D1, D2, D3>;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    fill_frags<XD, XD>(lds + LO::f_last, a.w_last, tid, kHeadThreads);
+    fill_frags<XD, D1>(lds + LO::f1, a.w1, tid, kHeadThreads);
+    fill_frags<D1, D2>(lds + LO::f2, a.w2, tid, kHeadThreads);
+    fill_frags<D2, D3>(lds + LO::f3, a.w3, tid, kHeadThreads);
+    fill_bias<D1>(lds + LO::b1, a.b1, tid, kHeadThreads);
+    fill_bias<D2>(lds + LO::b2, a.b2, tid, kHeadThreads);
+    fill_bias<D3>(lds + LO::b3, a.b3, tid, kHeadThreads);
+    fill_bias<D3>(lds + LO::w4, a.w4, tid, kHeadThreads);      // w4 is [D3][1]: same padded vector layout as a bias
+    __syncthreads();
+    const float b4 = a.b4[0];
+    for (int tile = blockIdx.x * kHeadWaves + wave; tile < a.n_tiles; tile += gridDim.x * kHeadWaves) {
+        const int row = 16 * tile + n;
+        const int rc = row < a.M ? row : a.M - 1;
+        const float* src = a.rows + (size_t)rc * 64;
+        f32x4 tin[2], hp[2];
+        tin[0] = *reinterpret_cast<const f32x4*>(src + 4 * q);
+        tin[1] = *reinterpret_cast<const f32x4*>(src + 16 + 4 * q);
+        hp[0] = *reinterpret_cast<const f32x4*>(src + 32 + 4 * q);
+        hp[1] = *reinterpret_cast<const f32x4*>(src + 48 + 4 * q);
+        f32x4 h[2];
+        layer_mfma<XD, XD>(lds + LO::f_last, tin, h, lane);
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = relu1(h[ot][r]);
+                if (a.skip) x += hp[ot][r];
+                h[ot][r] = x;
+            }
+        f32x4 a1[Tiles<D1>::v];
+        layer_mfma<XD, D1>(lds + LO::f1, h, a1, lane, lds + LO::b1);
+        relu_tiles<D1>(a1);
+        f32x4 a2[Tiles<D2>::v];
+        layer_mfma<D1, D2>(lds + LO::f2, a1, a2, lane, lds + LO::b2);
+        relu_tiles<D2>(a2);
+        f32x4 a3[Tiles<D3>::v];
+        layer_mfma<D2, D3>(lds + LO::f3, a2, a3, lane, lds + LO::b3);
+        relu_tiles<D3>(a3);
+        float v = 0.f;
+#pragma unroll
+        for (int ot = 0; ot < Tiles<D3>::v; ++ot) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(&lds[LO::w4 + 16 * ot + 4 * q]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v = fmaf(a3[ot][r], w[r], v);
+        }
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (q == 0 && row < a.M) a.value[row] = v + b4;
+    }
+}
+
+template <int D1, int D2, int D3>
+int launch_head(const HeadArgs& ha, hipStream_t st) {
+    auto kern = robot_head_kernel<D1, D2, D3>;
+    const size_t lds_bytes = (size_t)HeadLds<D1, D2, D3>::total * sizeof(float);
+    if (lds_bytes > 64 * 1024)
+        RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_bytes));
+    int grid = (ha.n_tiles + kHeadWaves - 1) / kHeadWaves;
+    const int cap = lds_bytes > 80 * 1024 ? 256 : 512;          // resident workgroups: 1 or 2 per CU
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kHeadThreads), lds_bytes, st, ha);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
+}  // namespace
+
+namespace rgl {
+
+// rows [M][64] (stage-1 hand-off) -> value [M];  1 = no kernel for this head (see head_variant)
+int launch_head_rows(const RglGraph* g, const RglMlp* h, const float* rows, int M, float* value, hipStream_t stream) {
+    const int hv = head_variant(*h);
+    if (hv < 0) return 1;
+    HeadArgs ha;
+    ha.w_last = g->Ws[g->num_layer - 1];
+    ha.w1 = h->weight[0]; ha.b1 = h->bias[0];
+    ha.w2 = h->weight[1]; ha.b2 = h->bias[1];
+    ha.w3 = h->weight[2]; ha.b3 = h->bias[2];
+    ha.w4 = h->weight[3]; ha.b4 = h->bias[3];
+    ha.skip = g->skip_connection;
+    ha.rows = rows;
+    ha.value = value;
+    ha.M = M;
+    ha.n_tiles = (M + 15) / 16;
+    return hv == 0 ? launch_head<32, 100, 100>(ha, stream) : launch_head<150, 100, 100>(ha, stream);
+}
+
+}  // namespace rgl

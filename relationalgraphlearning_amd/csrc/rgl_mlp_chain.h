@@ -1,0 +1,74 @@
+// MFMA chains for small MLPs in "transposed form" (activations = B operand, kept in registers; weights = pre-permuted A
+// fragments in LDS): shared by the stage-2 head kernel (rgl_head.hip) and the row-embedding kernel (rgl_scene.hip).
+#pragma once
+#include "rgl_mfma.h"
+
+namespace {
+
+template <int D>
+struct Tiles { static constexpr int v = (D + 15) / 16; };
+
+// A-fragment image of W (k-major [IN][OUT]) for the transposed product: fragment (ot, it, r), lane (i = l&15, q):
+//   W[in = 16*it + 4q + r][out = 16*ot + i]   (0 outside)
+// Feature held by D row (4q + r) of tile t of a D-wide activation.  Full tiles use the plain order 16t + 4q + r.  A partial
+// LAST tile uses 16t + 4r + q instead, so that as the next layer's k index its valid features sit in the first
+// ceil(valid / 4) k steps and the remaining steps (all-zero padding) are skipped: 25 k steps instead of 28 at D = 100.
+template <int D>
+__device__ __forceinline__ int tile_feature(int t, int q, int r) {
+    constexpr bool partial = (D % 16) != 0;
+    return (partial && t == Tiles<D>::v - 1) ? 16 * t + 4 * r + q : 16 * t + 4 * q + r;
+}
+template <int D>
+struct LastTileSteps { static constexpr int v = (D % 16) == 0 ? 4 : ((D % 16) + 3) / 4; };
+
+template <int IN, int OUT>
+__device__ __forceinline__ void fill_frags(float* dst, const float* __restrict__ W, int tid, int nthr = kThreads) {
+    constexpr int IT = Tiles<IN>::v, OT = Tiles<OUT>::v;
+    for (int idx = tid; idx < OT * IT * 4 * 64; idx += nthr) {
+        const int l = idx & 63, fr = idx >> 6;
+        const int r = fr & 3, it = (fr >> 2) % IT, ot = (fr >> 2) / IT;
+        const int m = l & 15;                                        // A-operand row = D row of the output tile
+        const int in = tile_feature<IN>(it, l >> 4, r), out = tile_feature<OUT>(ot, m >> 2, m & 3);
+        dst[idx] = (in < IN && out < OUT) ? W[in * OUT + out] : 0.f;
+    }
+}
+
+// per-feature vectors (bias, last-layer weights) in D-row order: dst[16 t + 4 q + r] belongs to tile_feature(t, q, r)
+template <int OUT>
+__device__ __forceinline__ void fill_bias(float* dst, const float* __restrict__ b, int tid, int nthr = kThreads) {
+    for (int idx = tid; idx < Tiles<OUT>::v * 16; idx += nthr) {
+        const int feat = tile_feature<OUT>(idx >> 4, (idx >> 2) & 3, idx & 3);
+        dst[idx] = feat < OUT ? b[feat] : 0.f;
+    }
+}
+
+// out = W^T in (+ bias): the accumulators START at the bias (no zero-init moves, no add afterwards).
+template <int IN, int OUT>
+__device__ __forceinline__ void layer_mfma(const float* frags, const f32x4 (&in)[Tiles<IN>::v], f32x4 (&out)[Tiles<OUT>::v],
+                                           int lane, const float* bias = nullptr) {
+    constexpr int IT = Tiles<IN>::v, OT = Tiles<OUT>::v;
+    const int q = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) out[ot] = bias ? *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * q]) : zero4();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        load_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (it == IT - 1 && r >= LastTileSteps<IN>::v) continue;          // k steps over padding only
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) out[ot] = mfma4(frags[((ot * IT + it) * 4 + r) * 64 + lane], in[it][r], out[ot]);
+        }
+    }
+    load_fence();
+}
+
+template <int OUT>
+__device__ __forceinline__ void relu_tiles(f32x4 (&x)[Tiles<OUT>::v]) {
+#pragma unroll
+    for (int ot = 0; ot < Tiles<OUT>::v; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[ot][r] = relu1(x[ot][r]);
+}
+
+}  // namespace

@@ -1,0 +1,335 @@
+// rgl_scene.hip -- state-predictor path of the rollout: scenes with their own crowds (one graph forward per tree node).
+// Follows (reference paths): crowd_nav/policy/state_predictor.py:20-39, graph_model.py:99-130.
+#include "rgl_mlp_chain.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// state-predictor path: scenes with their own crowds (one graph forward per tree node)
+//   row_mlp2_kernel   : batched 2-layer embedding MLP over rows (IN -> 64 -> 32, ReLU after both) as an MFMA chain
+//   scene_graph_kernel: one wave per scene: S = (X Wa) X^T, softmax, L x relu(A H W)(+H), motion head 32->64->5
+// ------------------------------------------------------------------------------------------------
+struct RowMlpArgs {
+    const float *w1, *b1, *w2, *b2;   // k-major [IN][64], [64], [64][32], [32]
+    const float* rows;                // [M][IN]
+    float* out;                       // [M][32]
+    int M, n_tiles;
+};
+
+template <int IN>
+__global__ __launch_bounds__(kThreads, 2) void row_mlp2_kernel(const RowMlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int F1 = 0, F2 = F1 + 4 * 1 * 4 * 64, B1 = F2 + 2 * 4 * 4 * 64, B2 = B1 + HID;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    fill_frags<IN, HID>(lds + F1, a.w1, tid);
+    fill_frags<HID, XD>(lds + F2, a.w2, tid);
+    fill_bias<HID>(lds + B1, a.b1, tid);
+    fill_bias<XD>(lds + B2, a.b2, tid);
+    __syncthreads();
+    for (int tile = blockIdx.x * kWaves + wave; tile < a.n_tiles; tile += gridDim.x * kWaves) {
+        const int row = 16 * tile + n;
+        const int rc = row < a.M ? row : a.M - 1;
+        const float* src = a.rows + (size_t)rc * IN;
+        f32x4 in[1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int feat = tile_feature<IN>(0, q, r);
+            in[0][r] = feat < IN ? src[feat] : 0.f;
+        }
+        f32x4 h[4];
+        layer_mfma<IN, HID>(lds + F1, in, h, lane, lds + B1);
+        relu_tiles<HID>(h);
+        f32x4 o[2];
+        layer_mfma<HID, XD>(lds + F2, h, o, lane, lds + B2);
+        relu_tiles<XD>(o);
+        if (row < a.M) {
+            float* dst = a.out + (size_t)row * XD;
+            *reinterpret_cast<f32x4*>(dst + 4 * q) = o[0];
+            *reinterpret_cast<f32x4*>(dst + 16 + 4 * q) = o[1];
+        }
+    }
+}
+
+struct SceneArgs {
+    const float* xh_rows;              // [n_crowds][H][32]  human embeddings
+    const float* x0_rows;              // [P][32]            robot embeddings
+    int crowds_per;                    // scene s uses crowd s / crowds_per
+    const float* wa;                   // [32][32]
+    const float* Ws[RGL_MAX_GCN_LAYERS];
+    int L, skip;
+    int sim;                           // SIM_* row normalisation
+    const float *wm1, *bm1, *wm2, *bm2;   // motion head, k-major [32][64], [64], [64][5], [5]
+    float* humans_next;                // [P][H][5]
+    int P, H, N;
+    int off_wa, off_ws, off_wm1, off_bm1, off_wm2, off_bm2, off_wave, wave_stride;
+};
+
+constexpr int M2LD = 20;   // LDS row stride of the [64][5 -> 16] motion output layer (4*M2LD % 32 == 16)
+
+template <int NT, bool SOFT>
+__global__ __launch_bounds__(kThreads, 2) void scene_graph_kernel(const SceneArgs a) {
+    const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int N = a.N, H = a.H;
+    const float* wa = lds + a.off_wa;       // [32][WLD]
+    const float* ws = lds + a.off_ws;       // [L][32][WLD]
+    const float* wm1 = lds + a.off_wm1;     // [32][W1LD]
+    const float* bm1 = lds + a.off_bm1;     // [64]
+    const float* wm2 = lds + a.off_wm2;     // [64][M2LD], columns >= 5 zero
+    const float* bm2 = lds + a.off_bm2;     // [16], entries >= 5 zero
+    float* Hs = lds + a.off_wave + wave * a.wave_stride;   // [16*NT][XLD] node features of the wave's current scene
+    {
+        float* w = lds;
+        for (int i = tid; i < XD * XD; i += kThreads) {
+            const int r = i / XD, c = i - r * XD;
+            w[a.off_wa + r * WLD + c] = a.wa ? a.wa[i] : (r == c ? 1.f : 0.f);   // gaussian: Wa = I
+            for (int l = 0; l < a.L; ++l) w[a.off_ws + (l * XD + r) * WLD + c] = a.Ws[l][i];
+        }
+        for (int i = tid; i < XD * HID; i += kThreads) {
+            const int r = i / HID, c = i - r * HID;
+            w[a.off_wm1 + r * W1LD + c] = a.wm1[i];
+        }
+        for (int i = tid; i < HID * 16; i += kThreads) {
+            const int r = i / 16, c = i - r * 16;
+            w[a.off_wm2 + r * M2LD + c] = c < 5 ? a.wm2[r * 5 + c] : 0.f;
+        }
+        for (int i = tid; i < HID; i += kThreads) w[a.off_bm1 + i] = a.bm1[i];
+        for (int i = tid; i < 16; i += kThreads) w[a.off_bm2 + i] = i < 5 ? a.bm2[i] : 0.f;
+    }
+    __syncthreads();
+    for (int sc = blockIdx.x * kWaves + wave; sc < a.P; sc += gridDim.x * kWaves) {
+        // node features of this scene: row 0 = robot, rows 1..H = its crowd, rows >= N zero
+        const float* xr = a.x0_rows + (size_t)sc * XD;
+        const float* xh = a.xh_rows + (size_t)(sc / a.crowds_per) * H * XD;
+        for (int idx = lane; idx < 16 * NT * (XD / 4); idx += 64) {
+            const int row = idx >> 3, c4 = (idx & 7) * 4;
+            f32x4 val = zero4();
+            if (row == 0) val = *reinterpret_cast<const f32x4*>(xr + c4);
+            else if (row < N) val = *reinterpret_cast<const f32x4*>(xh + (size_t)(row - 1) * XD + c4);
+            *reinterpret_cast<f32x4*>(&Hs[row * XLD + c4]) = val;
+        }
+        // G^T = Wa^T X^T   (per column tile: [g = 16gt+4q+r][col n])
+        f32x4 gt_[NT][2];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            gt_[ct][0] = zero4();
+            gt_[ct][1] = zero4();
+            load_fence();
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+                const f32x4 xb = *reinterpret_cast<const f32x4*>(&Hs[(16 * ct + n) * XLD + 16 * ft + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+                        gt_[ct][g] = mfma4(wa[(16 * ft + 4 * q + r) * WLD + 16 * g + n], xb[r], gt_[ct][g]);
+            }
+        }
+        // S^T[j][col] = X[j] . G[col]  -> softmax over j, kept in B-operand order (k <-> j = 16jt+4q+r)
+        f32x4 pr[NT][NT];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                load_fence();
+                f32x4 sacc = zero4();
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft) {
+                    const f32x4 xa = *reinterpret_cast<const f32x4*>(&Hs[(16 * jt + n) * XLD + 16 * ft + 4 * q]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc = mfma4(xa[r], gt_[ct][ft][r], sacc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * jt + 4 * q + r;
+                    if (sim != SIM_SOFTMAX) sacc[r] = plain_weight(sim, sacc[r], 16 * ct + n, j);
+                    if (j >= N) sacc[r] = sim == SIM_SOFTMAX ? -INFINITY : 0.f;
+                    mx = fmaxf(mx, sacc[r]);
+                }
+                pr[ct][jt] = sacc;
+            }
+            mx = kgroups_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (sim == SIM_SOFTMAX) pr[ct][jt][r] = __expf(pr[ct][jt][r] - mx);
+                    sum += pr[ct][jt][r];
+                }
+            sum = kgroups_sum(sum);
+            const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[ct][jt][r] *= inv;
+        }
+        // layers: H <- relu((A H) W_l) (+ H); every column tile's A*H is taken before any row is overwritten
+        for (int l = 0; l < a.L; ++l) {
+            f32x4 acc[NT][2];
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                acc[ct][0] = zero4();
+                acc[ct][1] = zero4();
+            }
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a0 = Hs[(16 * jt + 4 * q + r) * XLD + n];
+                    const float a1 = Hs[(16 * jt + 4 * q + r) * XLD + 16 + n];
+#pragma unroll
+                    for (int ct = 0; ct < NT; ++ct) {
+                        acc[ct][0] = mfma4(a0, pr[ct][jt][r], acc[ct][0]);
+                        acc[ct][1] = mfma4(a1, pr[ct][jt][r], acc[ct][1]);
+                    }
+                }
+            }
+            const float* wl = ws + l * XD * WLD;
+            const bool last = (l == a.L - 1);
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                load_fence();
+                f32x4 o[2] = {zero4(), zero4()};
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int ot = 0; ot < 2; ++ot)
+                            o[ot] = mfma4(wl[(16 * ft + 4 * q + r) * WLD + 16 * ot + n], acc[ct][ft][r], o[ot]);
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    const f32x4 sk = *reinterpret_cast<const f32x4*>(&Hs[(16 * ct + n) * XLD + 16 * ot + 4 * q]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float hv = fmaxf(o[ot][r], 0.f);
+                        if (a.skip) hv += sk[r];
+                        o[ot][r] = hv;
+                    }
+                    if (!last) *reinterpret_cast<f32x4*>(&Hs[(16 * ct + n) * XLD + 16 * ot + 4 * q]) = o[ot];
+                }
+                if (last) {
+                    // motion head on this tile's columns, straight from registers: 32 -> 64 (ReLU) -> 5
+                    f32x4 hm[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot) {
+                        load_fence();
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int ht = 0; ht < 4; ++ht)
+                                hm[ht] = mfma4(wm1[(16 * ot + 4 * q + r) * W1LD + 16 * ht + n], o[ot][r], hm[ht]);
+                    }
+                    f32x4 om = zero4();
+#pragma unroll
+                    for (int ht = 0; ht < 4; ++ht) {
+                        load_fence();
+                        const f32x4 bb = *reinterpret_cast<const f32x4*>(&bm1[16 * ht + 4 * q]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float hv = fmaxf(hm[ht][r] + bb[r], 0.f);
+                            om = mfma4(wm2[(16 * ht + 4 * q + r) * M2LD + n], hv, om);
+                        }
+                    }
+                    const int node = 16 * ct + n;
+                    if (node >= 1 && node < N) {
+                        float* dst = a.humans_next + ((size_t)sc * H + (node - 1)) * 5;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int oidx = 4 * q + r;
+                            if (oidx < 5) dst[oidx] = om[r] + bm2[oidx];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int IN>
+int launch_row_mlp2(const RglMlp& m, const float* rows, float* out, int M, hipStream_t st) {
+    RowMlpArgs ra;
+    ra.w1 = m.weight[0]; ra.b1 = m.bias[0]; ra.w2 = m.weight[1]; ra.b2 = m.bias[1];
+    ra.rows = rows; ra.out = out; ra.M = M; ra.n_tiles = (M + 15) / 16;
+    const size_t lds_bytes = (size_t)(4 * 4 * 64 + 2 * 4 * 4 * 64 + HID + XD) * sizeof(float);
+    int grid = (ra.n_tiles + kWaves - 1) / kWaves;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(row_mlp2_kernel<IN>, dim3(grid), dim3(kThreads), lds_bytes, st, ra);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
+template <int NT>
+int launch_scene(const SceneArgs& sa, size_t lds_bytes, hipStream_t st) {
+    auto kern = sa.sim == SIM_SOFTMAX ? scene_graph_kernel<NT, true> : scene_graph_kernel<NT, false>;
+    if (lds_bytes > 64 * 1024)
+        RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_bytes));
+    int grid = (sa.P + kWaves - 1) / kWaves;
+    const int cap = 256 * (lds_bytes * 2 <= (size_t)rgl::kLdsBytesPerCu ? 2 : 1) * 2;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, st, sa);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
+}  // namespace
+
+namespace rgl {
+
+// humans_next[s] = motion_head(RGL(robot[s], humans[s / crowds_per]))[1:]  for P scenes (StatePredictor.forward).
+int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float* humans, int crowds_per, int P, int H,
+                          float* humans_next, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const RglGraph& g = pl->predictor_graph;
+    const RglMlp& mh = pl->motion_head;
+    const int N = H + 1;
+    const bool ok = fast_path_enabled() && fast_similarity_mode(g) >= 0 && !g.layerwise_graph && g.x_dim == XD &&
+                    g.num_layer >= 1 && g.num_layer <= 4 && mlp_is(g.w_r, 9, HID, XD, true) && mlp_is(g.w_h, 5, HID, XD, true) &&
+                    mlp_is(mh, XD, HID, 5, false) && N <= 64 && workspace &&
+                    workspace_bytes >= (size_t)P * N * XD * sizeof(float) && P % crowds_per == 0;
+    if (!ok)
+        return launch_generic_forward(&g, nullptr, &mh, robot, humans, P, crowds_per, H, nullptr, nullptr, nullptr,
+                                      humans_next, stream);
+    const int n_crowds = P / crowds_per;
+    float* x0_rows = (float*)workspace;                      // [P][32]
+    float* xh_rows = x0_rows + (size_t)P * XD;               // [n_crowds][H][32]
+    int rc = launch_row_mlp2<9>(g.w_r, robot, x0_rows, P, stream);
+    if (rc) return rc;
+    rc = launch_row_mlp2<5>(g.w_h, humans, xh_rows, n_crowds * H, stream);
+    if (rc) return rc;
+    SceneArgs sa;
+    sa.xh_rows = xh_rows; sa.x0_rows = x0_rows; sa.crowds_per = crowds_per;
+    sa.wa = bilinear_wa(g);
+    sa.sim = fast_similarity_mode(g);
+    for (int l = 0; l < RGL_MAX_GCN_LAYERS; ++l) sa.Ws[l] = l < g.num_layer ? g.Ws[l] : nullptr;
+    sa.L = g.num_layer; sa.skip = g.skip_connection;
+    sa.wm1 = mh.weight[0]; sa.bm1 = mh.bias[0]; sa.wm2 = mh.weight[1]; sa.bm2 = mh.bias[1];
+    sa.humans_next = humans_next;
+    sa.P = P; sa.H = H; sa.N = N;
+    const int NT = (N + 15) / 16;
+    int off = 0;
+    auto take = [&](int nfl) { int o = off; off += (nfl + 3) & ~3; return o; };
+    sa.off_wa = take(XD * WLD);
+    sa.off_ws = take(g.num_layer * XD * WLD);
+    sa.off_wm1 = take(XD * W1LD);
+    sa.off_bm1 = take(HID);
+    sa.off_wm2 = take(HID * M2LD);
+    sa.off_bm2 = take(16);
+    sa.wave_stride = 16 * NT * XLD;
+    sa.off_wave = take(kWaves * sa.wave_stride);
+    const size_t lds_bytes = (size_t)off * sizeof(float);
+    switch (NT) {
+        case 1: return launch_scene<1>(sa, lds_bytes, stream);
+        case 2: return launch_scene<2>(sa, lds_bytes, stream);
+        case 3: return launch_scene<3>(sa, lds_bytes, stream);
+        default: return launch_scene<4>(sa, lds_bytes, stream);
+    }
+}
+
+}  // namespace rgl
