@@ -8,17 +8,6 @@
 // crowd_sim/envs/utils/utils.py:4-26, multi_human_rl.py:36-96, cadrl.py:113-138,241-276.
 #include "rgl_common.h"
 
-namespace rgl {
-int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
-                           const float* robot, const float* humans, int n_scenes, int scenes_per_crowd, int H,
-                           float* H_out, float* A_out, float* value_out, float* humans_next, hipStream_t stream);
-int launch_value_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
-                          float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream);   // rgl_fast.hip
-size_t value_children_workspace_bytes(const MprlPlanner* pl, int P, int H);
-int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float* humans, int crowds_per, int P, int H,
-                          float* humans_next, void* workspace, size_t workspace_bytes, hipStream_t stream);   // rgl_fast.hip
-}  // namespace rgl
-
 namespace {
 
 constexpr int kBlock = 256;
