@@ -104,23 +104,27 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
 
     {   // weight image, once per workgroup
         float* w = lds;
+#pragma unroll 4
         for (int i = tid; i < 8 * HID; i += kDeepThreads) {
             const int r = i / HID, c = i - r * HID;
             w[a.off_wh1 + r * W1LD + c] = r < 5 ? a.wh1[i] : 0.f;
         }
         for (int i = tid; i < HID; i += kDeepThreads) { w[a.off_bh1 + i] = a.bh1[i]; w[a.off_br1 + i] = a.br1[i]; }
         for (int i = tid; i < XD; i += kDeepThreads) { w[a.off_bh2 + i] = a.bh2[i]; w[a.off_br2 + i] = a.br2[i]; }
+#pragma unroll 4
         for (int i = tid; i < HID * XD; i += kDeepThreads) {
             const int r = i / XD, c = i - r * XD;
             w[a.off_wh2 + r * WLD + c] = a.wh2[i];
             w[a.off_wr2 + r * WLD + c] = a.wr2[i];
         }
+#pragma unroll 4
         for (int i = tid; i < XD * XD; i += kDeepThreads) {
             const int r = i / XD, c = i - r * XD;
             w[a.off_wa + r * WLD + c] = a.wa ? a.wa[i] : (r == c ? 1.f : 0.f);   // gaussian: Wa = I
             w[a.off_w1 + r * WLD + c] = a.w1[i];
             if (a.L == 3) w[a.off_w2 + r * WLD + c] = a.w2[i];
         }
+#pragma unroll 4
         for (int i = tid; i < 12 * HID; i += kDeepThreads) {
             const int r = i / HID, c = i - r * HID;
             w[a.off_wr1 + r * W1LD + c] = r < 9 ? a.wr1[i] : 0.f;

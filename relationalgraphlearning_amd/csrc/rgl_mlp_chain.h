@@ -24,21 +24,27 @@ struct LastTileSteps { static constexpr int v = (D % 16) == 0 ? 4 : ((D % 16) + 
 template <int IN, int OUT>
 __device__ __forceinline__ void fill_frags(float* dst, const float* __restrict__ W, int tid, int nthr = kThreads) {
     constexpr int IT = Tiles<IN>::v, OT = Tiles<OUT>::v;
+    // unrolled: the loads of several elements are in flight together (one L2 round trip per element otherwise: the
+    // 74 KB image of the value head took ~20 us per workgroup to build)
+#pragma unroll 8
     for (int idx = tid; idx < OT * IT * 4 * 64; idx += nthr) {
         const int l = idx & 63, fr = idx >> 6;
         const int r = fr & 3, it = (fr >> 2) % IT, ot = (fr >> 2) / IT;
         const int m = l & 15;                                        // A-operand row = D row of the output tile
         const int in = tile_feature<IN>(it, l >> 4, r), out = tile_feature<OUT>(ot, m >> 2, m & 3);
-        dst[idx] = (in < IN && out < OUT) ? W[in * OUT + out] : 0.f;
+        const float w = W[(in < IN ? in : IN - 1) * OUT + (out < OUT ? out : OUT - 1)];   // unconditional load (batched), then mask
+        dst[idx] = (in < IN && out < OUT) ? w : 0.f;
     }
 }
 
 // per-feature vectors (bias, last-layer weights) in D-row order: dst[16 t + 4 q + r] belongs to tile_feature(t, q, r)
 template <int OUT>
 __device__ __forceinline__ void fill_bias(float* dst, const float* __restrict__ b, int tid, int nthr = kThreads) {
+#pragma unroll 2
     for (int idx = tid; idx < Tiles<OUT>::v * 16; idx += nthr) {
         const int feat = tile_feature<OUT>(idx >> 4, (idx >> 2) & 3, idx & 3);
-        dst[idx] = feat < OUT ? b[feat] : 0.f;
+        const float v = b[feat < OUT ? feat : OUT - 1];
+        dst[idx] = feat < OUT ? v : 0.f;
     }
 }
 

@@ -71,22 +71,26 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
 
     {   // weight image, once per workgroup
         float* w = lds;
+#pragma unroll 4
         for (int i = tid; i < 8 * HID; i += nthreads) {
             const int r = i / HID, c = i - r * HID;
             w[a.off_wh1 + r * W1LD + c] = r < 5 ? a.wh1[i] : 0.f;
         }
         for (int i = tid; i < HID; i += nthreads) { w[a.off_bh1 + i] = a.bh1[i]; w[a.off_br1 + i] = a.br1[i]; }
         for (int i = tid; i < XD; i += nthreads) { w[a.off_bh2 + i] = a.bh2[i]; w[a.off_br2 + i] = a.br2[i]; }
+#pragma unroll 4
         for (int i = tid; i < HID * XD; i += nthreads) {
             const int r = i / XD, c = i - r * XD;
             w[a.off_wh2 + r * WLD + c] = a.wh2[i];
             w[a.off_wr2 + r * WLD + c] = a.wr2[i];
         }
+#pragma unroll 4
         for (int i = tid; i < XD * XD; i += nthreads) {
             const int r = i / XD, c = i - r * XD;
             w[a.off_wa + r * WLD + c] = a.wa ? a.wa[i] : (r == c ? 1.f : 0.f);   // gaussian: Wa = I
             w[a.off_w1 + r * WLD + c] = a.w1[i];
         }
+#pragma unroll 4
         for (int i = tid; i < 12 * HID; i += nthreads) {
             const int r = i / HID, c = i - r * HID;
             w[a.off_wr1 + r * W1LD + c] = r < 9 ? a.wr1[i] : 0.f;

@@ -83,15 +83,18 @@ __global__ __launch_bounds__(kThreads, 2) void scene_graph_kernel(const SceneArg
     float* Hs = lds + a.off_wave + wave * a.wave_stride;   // [16*NT][XLD] node features of the wave's current scene
     {
         float* w = lds;
+#pragma unroll 4
         for (int i = tid; i < XD * XD; i += kThreads) {
             const int r = i / XD, c = i - r * XD;
             w[a.off_wa + r * WLD + c] = a.wa ? a.wa[i] : (r == c ? 1.f : 0.f);   // gaussian: Wa = I
             for (int l = 0; l < a.L; ++l) w[a.off_ws + (l * XD + r) * WLD + c] = a.Ws[l][i];
         }
+#pragma unroll 4
         for (int i = tid; i < XD * HID; i += kThreads) {
             const int r = i / HID, c = i - r * HID;
             w[a.off_wm1 + r * W1LD + c] = a.wm1[i];
         }
+#pragma unroll 4
         for (int i = tid; i < HID * 16; i += kThreads) {
             const int r = i / 16, c = i - r * 16;
             w[a.off_wm2 + r * M2LD + c] = c < 5 ? a.wm2[r * 5 + c] : 0.f;

@@ -87,18 +87,22 @@ __global__ __launch_bounds__(kThreads1, STAGE1_WAVES_PER_SIMD) void children_gra
     // ---------------- once per workgroup: weight image ------------------------------------------------
     {
         float* w = lds;
+#pragma unroll 4
         for (int i = tid; i < 5 * HID; i += nthreads) w[a.off_wh1 + i] = a.wh1[i];
         for (int i = tid; i < HID; i += nthreads) { w[a.off_bh1 + i] = a.bh1[i]; w[a.off_br1 + i] = a.br1[i]; }
         for (int i = tid; i < XD; i += nthreads) { w[a.off_bh2 + i] = a.bh2[i]; w[a.off_br2 + i] = a.br2[i]; }
+#pragma unroll 4
         for (int i = tid; i < HID * XD; i += nthreads) {
             const int r = i / XD, c = i - r * XD;
             w[a.off_wh2 + r * WLD + c] = a.wh2[i];
             w[a.off_wr2 + r * WLD + c] = a.wr2[i];
         }
+#pragma unroll 4
         for (int i = tid; i < XD * XD; i += nthreads) {
             const int r = i / XD, c = i - r * XD;
             w[a.off_wa + r * WLD + c] = a.wa ? a.wa[i] : (r == c ? 1.f : 0.f);   // gaussian: Wa = I
         }
+#pragma unroll 4
         for (int i = tid; i < 12 * HID; i += nthreads) {
             const int r = i / HID, c = i - r * HID;
             w[a.off_wr1 + r * W1LD + c] = r < 9 ? a.wr1[i] : 0.f;
