@@ -352,10 +352,11 @@ def test_other_similarities_on_the_mfma_path(sim, H, L, D, B, dev):
         assert abs(float(val[b]) - float(ov[b])) < 1e-5
 
 
-@pytest.mark.parametrize("speeds,rots,H,L", [(3, 8, 19, 2), (5, 19, 5, 2), (6, 16, 19, 2), (2, 4, 49, 3), (1, 1, 7, 2)])
+@pytest.mark.parametrize("speeds,rots,H,L", [(3, 8, 19, 2), (5, 19, 5, 2), (6, 16, 19, 2), (2, 4, 49, 3), (1, 1, 7, 2),
+                                             (15, 17, 5, 2)])
 def test_non_default_action_spaces(speeds, rots, H, L, dev):
     """Action tables other than 5 x 16 + 1: A = 25 (two child tiles), 96 (exactly six), 97 (beyond the MFMA kernels' 96:
-    general kernel), 9, 2 -- whole depth-2 search against the batched oracle."""
+    general kernel), 9, 2, 256 (the ABI maximum) -- whole depth-2 search against the batched oracle."""
     cfgp = policy_config("model_predictive_rl", gcn__num_layer=L, action_space__speed_samples=speeds,
                          action_space__rotation_samples=rots, model_predictive_rl__planning_depth=2,
                          model_predictive_rl__planning_width=2, model_predictive_rl__do_action_clip=True)
@@ -375,6 +376,18 @@ def test_non_default_action_spaces(speeds, rots, H, L, dev):
     act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
     assert pol.tree_search().num_actions == speeds * rots + 1
     close(val.cpu().numpy(), ov.numpy())
+    if speeds * rots + 1 == nat.MAX_ACTIONS:                     # one more action is refused, not truncated
+        too_many = policy_config("model_predictive_rl", gcn__num_layer=L, action_space__speed_samples=speeds,
+                                 action_space__rotation_samples=rots + 1)
+        big = rga.ModelPredictiveRL()
+        big.time_step = 0.25
+        big.configure(too_many)
+        big.load_state_dict(gio.checkpoint("trained", L))
+        big.set_time_step(0.25)
+        big.set_phase("test")
+        big.set_device(dev)
+        with pytest.raises(nat.NativeLibraryError):
+            big.predict_batch(robot.to(dev), humans.to(dev))
     same = act.cpu().numpy().astype(np.int64) == oa.numpy()
     for b in np.nonzero(~same)[0]:
         assert abs(float(val[b]) - float(ov[b])) < 1e-5
