@@ -50,7 +50,10 @@ __global__ __launch_bounds__(kHeadThreads, 2) void robot_head_kernel(const HeadA
     fill_bias<D3>(lds + LO::w4, a.w4, tid, kHeadThreads);      // w4 is [D3][1]: same padded vector layout as a bias
     __syncthreads();
     const float b4 = a.b4[0];
-    for (int tile = blockIdx.x * kHeadWaves + wave; tile < a.n_tiles; tile += gridDim.x * kHeadWaves) {
+    // tile t -> workgroup t % grid, wave (t / grid) % 8: the tiles of the last, partial round land on DIFFERENT workgroups
+    // (one extra tile per CU) instead of filling whole workgroups -- the kernel is MFMA-paced per SIMD, so a SIMD whose
+    // four waves all carry an extra tile would set the kernel's time
+    for (int tile = blockIdx.x + gridDim.x * wave; tile < a.n_tiles; tile += gridDim.x * kHeadWaves) {
         const int row = 16 * tile + n;
         const int rc = row < a.M ? row : a.M - 1;
         const float* src = a.rows + (size_t)rc * 64;

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(kThreads, 2) void row_mlp2_kernel(const RowMlpArgs 
     fill_bias<HID>(lds + B1, a.b1, tid);
     fill_bias<XD>(lds + B2, a.b2, tid);
     __syncthreads();
-    for (int tile = blockIdx.x * kWaves + wave; tile < a.n_tiles; tile += gridDim.x * kWaves) {
+    for (int tile = blockIdx.x + gridDim.x * wave; tile < a.n_tiles; tile += gridDim.x * kWaves) {   // partial round: one per WG
         const int row = 16 * tile + n;
         const int rc = row < a.M ? row : a.M - 1;
         const float* src = a.rows + (size_t)rc * IN;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kThreads, 2) void scene_graph_kernel(const SceneArg
         for (int i = tid; i < 16; i += kThreads) w[a.off_bm2 + i] = i < 5 ? a.bm2[i] : 0.f;
     }
     __syncthreads();
-    for (int sc = blockIdx.x * kWaves + wave; sc < a.P; sc += gridDim.x * kWaves) {
+    for (int sc = blockIdx.x + gridDim.x * wave; sc < a.P; sc += gridDim.x * kWaves) {               // partial round: one per WG
         // node features of this scene: row 0 = robot, rows 1..H = its crowd, rows >= N zero
         const float* xr = a.x0_rows + (size_t)sc * XD;
         const float* xh = a.xh_rows + (size_t)(sc / a.crowds_per) * H * XD;
