@@ -16,18 +16,12 @@ struct RowMlpArgs {
     int M, n_tiles;
 };
 
+// One wave per 16-row tile: IN -> 64 -> 32 with ReLU after both layers.
 template <int IN>
-__global__ __launch_bounds__(kThreads, 2) void row_mlp2_kernel(const RowMlpArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void row_mlp2_tiles(const RowMlpArgs& a, const float* lds_set, int first, int stride, int lane) {
     constexpr int F1 = 0, F2 = F1 + 4 * 1 * 4 * 64, B1 = F2 + 2 * 4 * 4 * 64, B2 = B1 + HID;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
-    fill_frags<IN, HID>(lds + F1, a.w1, tid);
-    fill_frags<HID, XD>(lds + F2, a.w2, tid);
-    fill_bias<HID>(lds + B1, a.b1, tid);
-    fill_bias<XD>(lds + B2, a.b2, tid);
-    __syncthreads();
-    for (int tile = blockIdx.x + gridDim.x * wave; tile < a.n_tiles; tile += gridDim.x * kWaves) {   // partial round: one per WG
+    for (int tile = first; tile < a.n_tiles; tile += stride) {
         const int row = 16 * tile + n;
         const int rc = row < a.M ? row : a.M - 1;
         const float* src = a.rows + (size_t)rc * IN;
@@ -38,10 +32,10 @@ __global__ __launch_bounds__(kThreads, 2) void row_mlp2_kernel(const RowMlpArgs 
             in[0][r] = feat < IN ? src[feat] : 0.f;
         }
         f32x4 h[4];
-        layer_mfma<IN, HID>(lds + F1, in, h, lane, lds + B1);
+        layer_mfma<IN, HID>(lds_set + F1, in, h, lane, lds_set + B1);
         relu_tiles<HID>(h);
         f32x4 o[2];
-        layer_mfma<HID, XD>(lds + F2, h, o, lane, lds + B2);
+        layer_mfma<HID, XD>(lds_set + F2, h, o, lane, lds_set + B2);
         relu_tiles<XD>(o);
         if (row < a.M) {
             float* dst = a.out + (size_t)row * XD;
@@ -49,6 +43,26 @@ __global__ __launch_bounds__(kThreads, 2) void row_mlp2_kernel(const RowMlpArgs 
             *reinterpret_cast<f32x4*>(dst + 16 + 4 * q) = o[1];
         }
     }
+}
+
+constexpr int kRowMlpSetFloats = 4 * 1 * 4 * 64 + 2 * 4 * 4 * 64 + HID + XD;
+
+// Both embedding MLPs of a level in ONE launch (they are launch-latency sized): workgroups [0, grid_a) take the robot rows
+// (9 inputs), the others the human rows (5 inputs).
+__global__ __launch_bounds__(kThreads, 2) void row_mlp2_pair_kernel(const RowMlpArgs ra, const RowMlpArgs rb, int grid_a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int F1 = 0, F2 = F1 + 4 * 1 * 4 * 64, B1 = F2 + 2 * 4 * 4 * 64, B2 = B1 + HID;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool first = (int)blockIdx.x < grid_a;
+    const RowMlpArgs& a = first ? ra : rb;
+    if (first) fill_frags<9, HID>(lds + F1, a.w1, tid); else fill_frags<5, HID>(lds + F1, a.w1, tid);
+    fill_frags<HID, XD>(lds + F2, a.w2, tid);
+    fill_bias<HID>(lds + B1, a.b1, tid);
+    fill_bias<XD>(lds + B2, a.b2, tid);
+    __syncthreads();
+    const int b = first ? blockIdx.x : blockIdx.x - grid_a, g = first ? grid_a : gridDim.x - grid_a;
+    if (first) row_mlp2_tiles<9>(a, lds, b + g * wave, g * kWaves, lane);       // partial round: one tile per workgroup
+    else row_mlp2_tiles<5>(a, lds, b + g * wave, g * kWaves, lane);
 }
 
 struct SceneArgs {
@@ -255,15 +269,22 @@ __global__ __launch_bounds__(kThreads, 2) void scene_graph_kernel(const SceneArg
     }
 }
 
-template <int IN>
-int launch_row_mlp2(const RglMlp& m, const float* rows, float* out, int M, hipStream_t st) {
+inline RowMlpArgs row_mlp_args(const RglMlp& m, const float* rows, float* out, int M) {
     RowMlpArgs ra;
     ra.w1 = m.weight[0]; ra.b1 = m.bias[0]; ra.w2 = m.weight[1]; ra.b2 = m.bias[1];
     ra.rows = rows; ra.out = out; ra.M = M; ra.n_tiles = (M + 15) / 16;
-    const size_t lds_bytes = (size_t)(4 * 4 * 64 + 2 * 4 * 4 * 64 + HID + XD) * sizeof(float);
-    int grid = (ra.n_tiles + kWaves - 1) / kWaves;
-    if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(row_mlp2_kernel<IN>, dim3(grid), dim3(kThreads), lds_bytes, st, ra);
+    return ra;
+}
+
+// robot rows [Ma][9] -> [Ma][32] with w_r, human rows [Mb][5] -> [Mb][32] with w_h
+inline int launch_row_mlp2_pair(const RglMlp& wr, const float* robot_rows, float* x0_out, int Ma, const RglMlp& wh,
+                                const float* human_rows, float* xh_out, int Mb, hipStream_t st) {
+    const RowMlpArgs ra = row_mlp_args(wr, robot_rows, x0_out, Ma), rb = row_mlp_args(wh, human_rows, xh_out, Mb);
+    int grid_a = (ra.n_tiles + kWaves - 1) / kWaves, grid_b = (rb.n_tiles + kWaves - 1) / kWaves;
+    if (grid_a > 256) grid_a = 256;
+    if (grid_b > 1024) grid_b = 1024;
+    hipLaunchKernelGGL(row_mlp2_pair_kernel, dim3(grid_a + grid_b), dim3(kThreads), kRowMlpSetFloats * sizeof(float), st, ra,
+                       rb, grid_a);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }
@@ -302,9 +323,7 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
     const int n_crowds = P / crowds_per;
     float* x0_rows = (float*)workspace;                      // [P][32]
     float* xh_rows = x0_rows + (size_t)P * XD;               // [n_crowds][H][32]
-    int rc = launch_row_mlp2<9>(g.w_r, robot, x0_rows, P, stream);
-    if (rc) return rc;
-    rc = launch_row_mlp2<5>(g.w_h, humans, xh_rows, n_crowds * H, stream);
+    int rc = launch_row_mlp2_pair(g.w_r, robot, x0_rows, P, g.w_h, humans, xh_rows, n_crowds * H, stream);
     if (rc) return rc;
     SceneArgs sa;
     sa.xh_rows = xh_rows; sa.x0_rows = x0_rows; sa.crowds_per = crowds_per;
