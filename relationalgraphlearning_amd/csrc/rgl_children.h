@@ -1,0 +1,123 @@
+// Next robot state + estimate_reward for one (parent, action) pair: the body of mprl_children_kernel, shared with the scene
+// kernel, which runs it on extra workgroups beside the state predictor's graph forward (the two are independent).
+// Follows crowd_nav/policy/state_predictor.py:41-60, model_predictive_rl.py:304-357, crowd_sim/envs/utils/utils.py:4-26.
+#pragma once
+#include "rgl_common.h"
+
+namespace {
+
+struct ChildrenArgs {
+    const float* robot;        // [P][9]
+    const float* humans;       // [P / humans_per][H][5]
+    int humans_per;
+    const double* actions;     // [A][2]
+    int P, H, A, kinematics;
+    double dt;
+    int joint;                 // 1: position differences in float64 (JointState roots), 0: rounded to fp32 first
+    float* child_robot;        // [P][A][9]
+    float* reward;             // [P][A]
+};
+
+__device__ __forceinline__ double seg_point_dist_origin(double px, double py, double ex, double ey, bool f32_degenerate,
+                                                        float fpx, float fpy) {
+    // distance from the origin to the segment (px,py)-(ex,ey); utils.py:4-26 with (x3,y3) = 0
+    const double sx = ex - px, sy = ey - py;
+    if (sx == 0.0 && sy == 0.0) {
+        if (f32_degenerate) return (double)sqrtf(__fadd_rn(__fmul_rn(fpx, fpx), __fmul_rn(fpy, fpy)));
+        return sqrt(px * px + py * py);
+    }
+    double u = ((0.0 - px) * sx + (0.0 - py) * sy) / (sx * sx + sy * sy);
+    u = u > 1.0 ? 1.0 : (u < 0.0 ? 0.0 : u);
+    const double cx = px + u * sx, cy = py + u * sy;
+    return sqrt(cx * cx + cy * cy);
+}
+
+// One (parent, action) pair: next robot state + estimate_reward.
+__device__ __forceinline__ void children_thread(const ChildrenArgs& ca, long long idx) {
+    const float* __restrict__ robot = ca.robot;
+    const float* __restrict__ humans = ca.humans;
+    const double* __restrict__ actions = ca.actions;
+    float* __restrict__ child_robot = ca.child_robot;
+    float* __restrict__ reward = ca.reward;
+    const int humans_per = ca.humans_per, H = ca.H, A = ca.A, kinematics = ca.kinematics, joint = ca.joint;
+    const double dt = ca.dt;
+
+    const int p = (int)(idx / A), a = (int)(idx - (long long)p * A);
+    const float* r = robot + (size_t)p * 9;
+    const float* hs = humans + (size_t)(p / humans_per) * H * 5;
+    const double a0 = actions[2 * a], a1 = actions[2 * a + 1];
+    float c[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c[i] = r[i];
+    double avx, avy, nx, ny;
+    if (kinematics == RGL_HOLONOMIC) {
+        c[0] = __fadd_rn(r[0], (float)(a0 * dt));
+        c[1] = __fadd_rn(r[1], (float)(a1 * dt));
+        c[2] = (float)a0;
+        c[3] = (float)a1;
+        avx = a0;
+        avy = a1;
+        nx = (double)r[0] + a0 * dt;
+        ny = (double)r[1] + a1 * dt;
+    } else {
+        // the reference rotates slot 7 (v_pref), not slot 8 (theta): kept (state_predictor.py:53-58)
+        const float th7 = __fadd_rn(r[7], (float)a1);
+        const float cs = cosf(th7), sn = sinf(th7);
+        c[7] = th7;
+        c[0] = __fadd_rn(r[0], (float)((double)cs * a0 * dt));
+        c[1] = __fadd_rn(r[1], (float)((double)sn * a0 * dt));
+        c[2] = (float)((double)cs * a0);
+        c[3] = (float)((double)sn * a0);
+        // estimate_reward uses theta (slot 8) for the relative velocity and the goal test
+        const double th = a1 + (double)r[8];
+        avx = a0 * cos(th);
+        avy = a0 * sin(th);
+        const double th2 = (double)r[8] + a1;
+        nx = (double)r[0] + cos(th2) * a0 * dt;
+        ny = (double)r[1] + sin(th2) * a0 * dt;
+    }
+    float* co = child_robot + (size_t)idx * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) co[i] = c[i];
+
+    bool collision = false;
+    double dmin = INFINITY;
+    for (int h = 0; h < H; ++h) {
+        const float* hu = hs + h * 5;
+        double px, py;
+        float fpx = 0.f, fpy = 0.f;
+        if (joint) {
+            px = (double)hu[0] - (double)r[0];
+            py = (double)hu[1] - (double)r[1];
+        } else {
+            fpx = __fsub_rn(hu[0], r[0]);
+            fpy = __fsub_rn(hu[1], r[1]);
+            px = (double)fpx;
+            py = (double)fpy;
+        }
+        const double vx = (double)hu[2] - avx, vy = (double)hu[3] - avy;
+        const double ex = px + vx * dt, ey = py + vy * dt;
+        // Exact shortcut: the outcome depends on this human only if its clearance d is < 0.2 (collision, or the minimum
+        // when that is below the discomfort distance).  dist(origin, segment) >= |p| - |e - p|, so with
+        // T = radii + 0.25 the test |p|^2 >= 2 (|e - p|^2 + T^2)  (=> |p| >= |e - p| + T) proves d >= 0.25 without the
+        // float64 division and square root of the general case; the 0.05 margin dwarfs every rounding involved.
+        {
+            const double T = (double)hu[4] + (double)r[4] + 0.25;
+            const double sx = ex - px, sy = ey - py;
+            if (px * px + py * py >= 2.0 * (sx * sx + sy * sy + T * T)) continue;
+        }
+        const double d = seg_point_dist_origin(px, py, ex, ey, !joint, fpx, fpy) - (double)hu[4] - (double)r[4];
+        if (d < 0.0) collision = true;
+        if (d < dmin) dmin = d;
+    }
+    const double gx = nx - (double)r[5], gy = ny - (double)r[6];
+    const bool reaching = sqrt(gx * gx + gy * gy) < (double)r[4];
+    double rew;
+    if (collision) rew = -0.25;
+    else if (reaching) rew = 1.0;
+    else if (dmin < 0.2) rew = (dmin - 0.2) * 0.5 * dt;
+    else rew = 0.0;
+    reward[idx] = (float)rew;
+}
+
+}  // namespace

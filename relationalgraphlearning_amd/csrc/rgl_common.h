@@ -66,8 +66,12 @@ int launch_head_rows(const RglGraph* g, const RglMlp* head, const float* rows, i
 int launch_value_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
                           float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream);         // rgl_fast.hip
 size_t value_children_workspace_bytes(const MprlPlanner* pl, int P, int H);                                        // rgl_fast.hip
+// `children` (optional): a ChildrenArgs (rgl_children.h, passed opaquely with its size) describing the level's independent
+// next-state / reward work; when the MFMA scene kernel runs, it executes that work on extra workgroups of the same launch
+// and sets *children_done.
 int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float* humans, int crowds_per, int P, int H,
-                          float* humans_next, void* workspace, size_t workspace_bytes, hipStream_t stream);         // rgl_scene.hip
+                          float* humans_next, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                          const void* children = nullptr, size_t children_bytes = 0, int* children_done = nullptr);  // rgl_scene.hip
 
 inline int mlp_max_hidden(const RglMlp& m) {
     int w = 0;

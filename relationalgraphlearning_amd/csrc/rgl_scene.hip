@@ -1,5 +1,6 @@
 // rgl_scene.hip -- state-predictor path of the rollout: scenes with their own crowds (one graph forward per tree node).
 // Follows (reference paths): crowd_nav/policy/state_predictor.py:20-39, graph_model.py:99-130.
+#include "rgl_children.h"
 #include "rgl_mlp_chain.h"
 
 namespace {
@@ -81,8 +82,16 @@ struct SceneArgs {
 
 constexpr int M2LD = 20;   // LDS row stride of the [64][5 -> 16] motion output layer (4*M2LD % 32 == 16)
 
+// Workgroups [0, grid_scene) run the graph forward, one scene per wave; the remaining ones (if any) run the level's
+// independent next-robot-state / reward work (children_thread): different pipes (MFMA vs float64 VALU), one launch.
 template <int NT, bool SOFT>
-__global__ __launch_bounds__(kThreads, 2) void scene_graph_kernel(const SceneArgs a) {
+__global__ __launch_bounds__(kThreads, 2) void scene_graph_kernel(const SceneArgs a, const ChildrenArgs ca, int grid_scene) {
+    if ((int)blockIdx.x >= grid_scene) {
+        const long long total = (long long)ca.P * ca.A, stride = (long long)(gridDim.x - grid_scene) * kThreads;
+        for (long long idx = (long long)(blockIdx.x - grid_scene) * kThreads + threadIdx.x; idx < total; idx += stride)
+            children_thread(ca, idx);
+        return;
+    }
     const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(kThreads, 2) void scene_graph_kernel(const SceneArg
         for (int i = tid; i < 16; i += kThreads) w[a.off_bm2 + i] = i < 5 ? a.bm2[i] : 0.f;
     }
     __syncthreads();
-    for (int sc = blockIdx.x + gridDim.x * wave; sc < a.P; sc += gridDim.x * kWaves) {               // partial round: one per WG
+    for (int sc = blockIdx.x + grid_scene * wave; sc < a.P; sc += grid_scene * kWaves) {             // partial round: one per WG
         // node features of this scene: row 0 = robot, rows 1..H = its crowd, rows >= N zero
         const float* xr = a.x0_rows + (size_t)sc * XD;
         const float* xh = a.xh_rows + (size_t)(sc / a.crowds_per) * H * XD;
@@ -290,7 +299,7 @@ inline int launch_row_mlp2_pair(const RglMlp& wr, const float* robot_rows, float
 }
 
 template <int NT>
-int launch_scene(const SceneArgs& sa, size_t lds_bytes, hipStream_t st) {
+int launch_scene(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* children, hipStream_t st) {
     auto kern = sa.sim == SIM_SOFTMAX ? scene_graph_kernel<NT, true> : scene_graph_kernel<NT, false>;
     if (lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -298,7 +307,14 @@ int launch_scene(const SceneArgs& sa, size_t lds_bytes, hipStream_t st) {
     int grid = (sa.P + kWaves - 1) / kWaves;
     const int cap = 256 * (lds_bytes * 2 <= (size_t)rgl::kLdsBytesPerCu ? 2 : 1) * 2;
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, st, sa);
+    ChildrenArgs ca{};
+    int grid_children = 0;
+    if (children) {
+        ca = *children;
+        const long long blocks = ((long long)ca.P * ca.A + kThreads - 1) / kThreads;
+        grid_children = (int)(blocks < 2048 ? blocks : 2048);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid + grid_children), dim3(kThreads), lds_bytes, st, sa, ca, grid);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }
@@ -309,7 +325,10 @@ namespace rgl {
 
 // humans_next[s] = motion_head(RGL(robot[s], humans[s / crowds_per]))[1:]  for P scenes (StatePredictor.forward).
 int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float* humans, int crowds_per, int P, int H,
-                          float* humans_next, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                          float* humans_next, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                          const void* children, size_t children_bytes, int* children_done) {
+    const ChildrenArgs* ca = (children && children_bytes == sizeof(ChildrenArgs)) ? (const ChildrenArgs*)children : nullptr;
+    if (children_done) *children_done = 0;
     const RglGraph& g = pl->predictor_graph;
     const RglMlp& mh = pl->motion_head;
     const int N = H + 1;
@@ -347,11 +366,13 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
     sa.off_wave = take(kWaves * sa.wave_stride);
     const size_t lds_bytes = (size_t)off * sizeof(float);
     switch (NT) {
-        case 1: return launch_scene<1>(sa, lds_bytes, stream);
-        case 2: return launch_scene<2>(sa, lds_bytes, stream);
-        case 3: return launch_scene<3>(sa, lds_bytes, stream);
-        default: return launch_scene<4>(sa, lds_bytes, stream);
+        case 1: rc = launch_scene<1>(sa, lds_bytes, ca, stream); break;
+        case 2: rc = launch_scene<2>(sa, lds_bytes, ca, stream); break;
+        case 3: rc = launch_scene<3>(sa, lds_bytes, ca, stream); break;
+        default: rc = launch_scene<4>(sa, lds_bytes, ca, stream); break;
     }
+    if (rc == RGL_OK && ca && children_done) *children_done = 1;
+    return rc;
 }
 
 }  // namespace rgl
