@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kHeadThreads, 2) void robot_head_kernel(const HeadA
         hp[0] = *reinterpret_cast<const f32x4*>(src + 32 + 4 * q);
         hp[1] = *reinterpret_cast<const f32x4*>(src + 48 + 4 * q);
         f32x4 h[2];
-        layer_mfma<XD, XD>(lds + LO::f_last, tin, h, lane);
+        layer_mfma<XD, XD, false>(lds + LO::f_last, tin, h, lane);
 #pragma unroll
         for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -73,13 +73,13 @@ __global__ __launch_bounds__(kHeadThreads, 2) void robot_head_kernel(const HeadA
                 h[ot][r] = x;
             }
         f32x4 a1[Tiles<D1>::v];
-        layer_mfma<XD, D1>(lds + LO::f1, h, a1, lane, lds + LO::b1);
+        layer_mfma<XD, D1, true>(lds + LO::f1, h, a1, lane, lds + LO::b1);
         relu_tiles<D1>(a1);
         f32x4 a2[Tiles<D2>::v];
-        layer_mfma<D1, D2>(lds + LO::f2, a1, a2, lane, lds + LO::b2);
+        layer_mfma<D1, D2, true>(lds + LO::f2, a1, a2, lane, lds + LO::b2);
         relu_tiles<D2>(a2);
         f32x4 a3[Tiles<D3>::v];
-        layer_mfma<D2, D3>(lds + LO::f3, a2, a3, lane, lds + LO::b3);
+        layer_mfma<D2, D3, true>(lds + LO::f3, a2, a3, lane, lds + LO::b3);
         relu_tiles<D3>(a3);
         float v = 0.f;
 #pragma unroll

@@ -49,13 +49,17 @@ __device__ __forceinline__ void fill_bias(float* dst, const float* __restrict__ 
 }
 
 // out = W^T in (+ bias): the accumulators START at the bias (no zero-init moves, no add afterwards).
-template <int IN, int OUT>
+template <int IN, int OUT, bool BIAS>
 __device__ __forceinline__ void layer_mfma(const float* frags, const f32x4 (&in)[Tiles<IN>::v], f32x4 (&out)[Tiles<OUT>::v],
                                            int lane, const float* bias = nullptr) {
     constexpr int IT = Tiles<IN>::v, OT = Tiles<OUT>::v;
     const int q = lane >> 4;
+    // BIAS is a template flag, not a pointer test: with a run-time test hipcc zero-initialises every accumulator first
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) out[ot] = bias ? *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * q]) : zero4();
+    for (int ot = 0; ot < OT; ++ot) {
+        if constexpr (BIAS) out[ot] = *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * q]);
+        else out[ot] = zero4();
+    }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         load_fence();

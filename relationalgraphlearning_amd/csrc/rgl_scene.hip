@@ -33,10 +33,10 @@ __device__ __forceinline__ void row_mlp2_tiles(const RowMlpArgs& a, const float*
             in[0][r] = feat < IN ? src[feat] : 0.f;
         }
         f32x4 h[4];
-        layer_mfma<IN, HID>(lds_set + F1, in, h, lane, lds_set + B1);
+        layer_mfma<IN, HID, true>(lds_set + F1, in, h, lane, lds_set + B1);
         relu_tiles<HID>(h);
         f32x4 o[2];
-        layer_mfma<HID, XD>(lds_set + F2, h, o, lane, lds_set + B2);
+        layer_mfma<HID, XD, true>(lds_set + F2, h, o, lane, lds_set + B2);
         relu_tiles<XD>(o);
         if (row < a.M) {
             float* dst = a.out + (size_t)row * XD;
