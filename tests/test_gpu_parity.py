@@ -541,6 +541,32 @@ def test_properties_at_full_size(dev):
     close(v1[:16].cpu().numpy(), ov.numpy())
 
 
+def test_headline_workload_against_the_oracle_in_full(dev):
+    """All 2048 roots of BASELINE config 3 (the benchmarked workload: N=20, L=2, D=2, w=2, bench.py's own scenes and
+    weights) against the batched CPU oracle: every value within 1e-4, decisions identical except on numerical ties.
+    (~20 s of CPU time on the GPU box: 510 k value forwards.)"""
+    import bench
+
+    class Args:
+        layers, depth, width, humans, contraction = 2, 2, 2, 19, "f32"
+    pol = bench.make_policy(Args, dev)
+    robot, humans = bench.synth_scenes(1000, 2048, Args.humans)
+    act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
+    cfg = orc.OracleConfig(planning_depth=2, planning_width=2, do_action_clip=True)
+    oa, ov = [], []
+    with torch.no_grad():
+        for lo in range(0, 2048, 256):
+            a, v, _, _ = orc.mprl_predict_batched(robot[lo:lo + 256], humans[lo:lo + 256], gio.oracle_params("trained"), cfg)
+            oa.append(a)
+            ov.append(v)
+    oa, ov = torch.cat(oa).numpy(), torch.cat(ov).numpy()
+    close(val.cpu().numpy(), ov)
+    same = act.cpu().numpy().astype(np.int64) == oa
+    for b in np.nonzero(~same)[0]:
+        assert abs(float(val[b]) - float(ov[b])) < 1e-5
+    assert same.mean() > 0.995
+
+
 # ---------------------------------------------------------------------------------------------------
 # path G
 # ---------------------------------------------------------------------------------------------------
