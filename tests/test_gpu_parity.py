@@ -541,30 +541,37 @@ def test_properties_at_full_size(dev):
     close(v1[:16].cpu().numpy(), ov.numpy())
 
 
-def test_headline_workload_against_the_oracle_in_full(dev):
-    """All 2048 roots of BASELINE config 3 (the benchmarked workload: N=20, L=2, D=2, w=2, bench.py's own scenes and
-    weights) against the batched CPU oracle: every value within 1e-4, decisions identical except on numerical ties.
-    (~20 s of CPU time on the GPU box: 510 k value forwards.)"""
+@pytest.mark.parametrize("tag,H,L,D,B,contraction,tol", [
+    ("configs[2] in full", 19, 2, 2, 2048, "f32", TOL),
+    ("configs[3] per-GPU share", 19, 2, 3, 512, "f32", TOL),
+    ("configs[4] per-GPU share (256 roots), first 96", 49, 3, 2, 96, "f32", TOL),
+    ("configs[4] with f16 contractions, first 96", 49, 3, 2, 96, "f16", 1e-3)])
+def test_baseline_workloads_against_the_oracle_at_size(tag, H, L, D, B, contraction, tol, dev):
+    """The BASELINE workloads with bench.py's own scenes and weights against the batched CPU oracle: every value within
+    tolerance, decisions identical except on numerical ties.  configs[2] is checked in full (2048 roots, 510 k value
+    forwards, ~20 s of CPU time on the GPU box); configs[4] on the first 96 of its 256 roots per GPU (the oracle needs
+    1.3 MFLOP per forward there)."""
     import bench
 
     class Args:
-        layers, depth, width, humans, contraction = 2, 2, 2, 19, "f32"
+        pass
+    Args.layers, Args.depth, Args.width, Args.humans, Args.contraction = L, D, 2, H, contraction
     pol = bench.make_policy(Args, dev)
-    robot, humans = bench.synth_scenes(1000, 2048, Args.humans)
+    robot, humans = bench.synth_scenes(1000, B, H)
     act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
-    cfg = orc.OracleConfig(planning_depth=2, planning_width=2, do_action_clip=True)
+    cfg = orc.OracleConfig(num_layer=L, planning_depth=D, planning_width=2, do_action_clip=True)
     oa, ov = [], []
     with torch.no_grad():
-        for lo in range(0, 2048, 256):
-            a, v, _, _ = orc.mprl_predict_batched(robot[lo:lo + 256], humans[lo:lo + 256], gio.oracle_params("trained"), cfg)
+        for lo in range(0, B, 256):
+            a, v, _, _ = orc.mprl_predict_batched(robot[lo:lo + 256], humans[lo:lo + 256], gio.oracle_params("trained", L), cfg)
             oa.append(a)
             ov.append(v)
     oa, ov = torch.cat(oa).numpy(), torch.cat(ov).numpy()
-    close(val.cpu().numpy(), ov)
+    close(val.cpu().numpy(), ov, tol=tol)
     same = act.cpu().numpy().astype(np.int64) == oa
     for b in np.nonzero(~same)[0]:
-        assert abs(float(val[b]) - float(ov[b])) < 1e-5
-    assert same.mean() > 0.995
+        assert abs(float(val[b]) - float(ov[b])) < 10 * tol
+    assert same.mean() > 0.97
 
 
 # ---------------------------------------------------------------------------------------------------
