@@ -185,6 +185,19 @@ class _PackCache:
             self.key = key
         return self.value
 
+    # The cache holds ctypes descriptor structs (raw device pointers), which can be neither copied nor pickled and
+    # would be wrong for a copy anyway (its parameters live elsewhere).  A copied / unpickled module starts with an
+    # empty cache and repacks on its first forward: `copy.deepcopy(model)` (Trainer.update_target_model upstream,
+    # crowd_nav/utils/trainer.py:41,187) and `torch.save(model)` work after any number of forwards.
+    def __deepcopy__(self, memo):
+        return _PackCache()
+
+    def __copy__(self):
+        return _PackCache()
+
+    def __reduce__(self):
+        return (_PackCache, ())
+
 
 def graph_forward(graph, value_head, motion_head, robot, humans, scenes_per_crowd=1, want_H=False, want_A=False):
     """Thin wrapper over rgl_graph_forward_f32.  robot (S,rd), humans (S/spc,H,hd) -> dict of outputs."""

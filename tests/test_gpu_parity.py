@@ -764,5 +764,42 @@ def test_training_step_matches_cpu_autograd(dev):
         close(v.detach().cpu().numpy(), gsd[k].detach().numpy(), 5e-4)
 
 
+def test_target_model_deepcopy_after_forward(dev):
+    """copy.deepcopy(model) AFTER forwards (descriptor caches populated), then train against the copy as the frozen
+    target -- the order crowd_nav/train.py:161,206 + trainer.py:41,187 use (this used to raise)."""
+    import copy
+    c = dict(L=2, sim="embedded_gaussian", layerwise=False, skip=True, flavour="trained")
+    _, ve, sp = build_modules(c, dev)
+    robot, humans = seeded_scenes(41, 16, 5)
+    state = (robot.unsqueeze(1).to(dev), humans.to(dev))
+    with torch.no_grad():
+        v0 = ve(state).clone()
+        sp(state, None)
+    out = ve(state)                              # a forward under grad as well
+    out.sum().backward()
+    target, sp_copy = copy.deepcopy(ve), copy.deepcopy(sp)
+    with torch.no_grad():
+        assert torch.equal(target(state), v0)
+        assert torch.equal(sp_copy(state, None)[1], sp(state, None)[1])
+    opt = torch.optim.Adam(ve.parameters(), lr=1e-2)
+    for _ in range(2):
+        opt.zero_grad()
+        with torch.no_grad():
+            tgt = 0.1 + 0.9 * target(state)
+        loss = torch.nn.functional.mse_loss(ve(state), tgt)
+        loss.backward()
+        opt.step()
+    with torch.no_grad():
+        assert torch.equal(target(state), v0)                 # the copy owns its parameters and its own descriptors
+        assert not torch.equal(ve(state), v0)
+    pol = make_gcn_policy(device=dev)
+    rot = torch.randn(4, 5, 13, device=dev)
+    with torch.no_grad():
+        g0 = pol.model(rot).clone()
+    g2 = copy.deepcopy(pol.model)
+    with torch.no_grad():
+        assert torch.equal(g2(rot), g0)
+
+
 def test_library_reports_target():
     assert nat.lib().rgl_build_target() == b"gfx950"

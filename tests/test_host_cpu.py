@@ -149,3 +149,30 @@ def test_shard_bounds_cover_everything_once():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_modules_deepcopy_and_pickle_with_populated_descriptor_cache():
+    """Trainer.update_target_model deep-copies the model after forwards have run (crowd_nav/utils/trainer.py:41,187;
+    train.py:161,206): the descriptor caches hold ctypes structs with raw pointers, which must not travel with a copy."""
+    import copy
+    import io
+    pol = make_mprl_policy("trained", D=1)
+    ve, sp = pol.value_estimator, pol.state_predictor
+    for cache in (ve._cache, ve.graph_model._cache, sp._cache, sp.graph_model._cache):
+        cache.key, cache.value, cache.keep = ("stale",), nat.RglGraph(), [torch.zeros(3)]   # what a forward leaves behind
+    ve2, sp2 = copy.deepcopy(ve), copy.deepcopy(sp)
+    for cache in (ve2._cache, ve2.graph_model._cache, sp2._cache, sp2.graph_model._cache):
+        assert cache.key is None and cache.value is None and cache.keep is None
+    assert ve._cache.key == ("stale",)                                  # the original keeps its cache
+    for (k, a), (_, b) in zip(ve.state_dict().items(), ve2.state_dict().items()):
+        assert torch.equal(a, b) and a.data_ptr() != b.data_ptr(), k
+    buf = io.BytesIO()
+    torch.save(ve, buf)
+    buf.seek(0)
+    ve3 = torch.load(buf, weights_only=False)
+    assert ve3._cache.key is None and set(ve3.state_dict()) == set(ve.state_dict())
+    g = make_gcn_policy().model
+    g._cache.key, g._cache.value = ("stale",), nat.RglGraph()
+    g._head_cache.key, g._head_cache.value = ("stale",), nat.RglMlp()
+    g2 = copy.deepcopy(g)
+    assert g2._cache.key is None and g2._head_cache.key is None
