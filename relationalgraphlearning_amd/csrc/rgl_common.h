@@ -63,8 +63,19 @@ int launch_tile_children(const RglGraph* g, int P, int A, int H, const float* ch
                          float* rows_out, hipStream_t stream);                                                      // rgl_tile.hip
 int launch_head_rows(const RglGraph* g, const RglMlp* head, const float* rows, int M, float* value,
                      hipStream_t stream);                                                                          // rgl_head.hip
+int launch_head_rows_strided(const RglGraph* g, const RglMlp* head, const float* rows, int M, float* value, int out_group,
+                             int out_stride, int out_base, hipStream_t stream, const float* image);                 // rgl_head.hip
+// the fused tile kernel (rgl_fused.hip).  Its weight images are prepared in global memory by pack_children_images -- once per
+// tree search (image_ready = 1 on the per-level calls) or by the call itself -- at the END of the workspace it is given.
+int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, int H, const float* child_robot,
+                          const float* humans_next, float* child_value, void* workspace, size_t workspace_bytes,
+                          int image_ready, hipStream_t stream);
+int pack_children_images(const RglGraph* g, const RglMlp* head, int P, int A, int H, void* workspace, size_t workspace_bytes,
+                         hipStream_t stream);               // P = the largest launch; 1 = the fused kernel does not apply
+size_t fused_children_workspace_bytes(int P, int A, int H);
 int launch_value_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
-                          float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream);         // rgl_fast.hip
+                          float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                          int image_ready = 0);                                                                     // rgl_fast.hip
 size_t value_children_workspace_bytes(const MprlPlanner* pl, int P, int H);                                        // rgl_fast.hip
 // `children` (optional): a ChildrenArgs (rgl_children.h, passed opaquely with its size) describing the level's independent
 // next-state / reward work; when the MFMA scene kernel runs, it executes that work on extra workgroups of the same launch

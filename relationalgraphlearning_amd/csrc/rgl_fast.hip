@@ -15,12 +15,15 @@ namespace rgl {
 size_t value_children_workspace_bytes(const MprlPlanner* pl, int P, int H) {
     const size_t children = (size_t)P * pl->num_actions * 64 * sizeof(float);
     const size_t predictor = (size_t)P * (H + 1) * XD * sizeof(float);         // embeddings of launch_predict_humans
-    return children > predictor ? children : predictor;
+    const size_t fused = H + 1 <= 32 ? fused_children_workspace_bytes(P, pl->num_actions, H) : 0;
+    const size_t m = children > predictor ? children : predictor;
+    // the fused kernel keeps its weight images at the END of the workspace: room for them behind every other use
+    return H + 1 <= 32 ? ((m + 255) & ~(size_t)255) + fused_children_workspace_bytes(0, pl->num_actions, H) + (fused > m ? fused - m : 0) : m;
 }
 
 // V(child) for the A children of each of P parents; children of one parent share humans_next[p].
 int launch_value_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
-                          float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                          float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream, int image_ready) {
     const int A = pl->num_actions;
     const int hv = head_variant(pl->value_head);
     const bool want_f16 = pl->contraction_dtype == RGL_CONTRACT_F16;
@@ -29,6 +32,12 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
     // stage 1, in order of preference: rank-1 (L = 2, N <= 32), shared-crowd deep (L in {2,3}, N <= 60), tiles (softmax
     // similarities, any depth, N <= 64); everything else, or a head without a stage-2 kernel: the general kernel
     int rc = 1;                                            // 1 = no stage-1 kernel launched yet
+    if (staged && !want_f16) {
+        // one fused kernel over 16-child tiles (L = 2, N <= 32, default head): values come out directly, no stage 2
+        rc = launch_fused_children(&pl->value_graph, &pl->value_head, P, A, H, child_robot, humans_next, child_value, workspace,
+                                   workspace_bytes, image_ready, stream);
+        if (rc != 1) return rc;
+    }
     if (staged) {
         const RglGraph* g = &pl->value_graph;
         float* rows = (float*)workspace;

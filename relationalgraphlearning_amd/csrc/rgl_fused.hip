@@ -1,0 +1,834 @@
+// rgl_fused.hip -- "value of the sibling children" for the shipped shape (L = 2, N <= 32, value head 32-100-100-1) as ONE
+// kernel over a stream of 16-child tiles, plus the crowd-only prologue as a small kernel of its own.
+//
+// Follows (reference paths): crowd_nav/policy/graph_model.py:99-130 (RGL.forward), value_estimator.py:11-20,
+// model_predictive_rl.py:245-250 (the per-action loop whose iterations run side by side here).
+//
+// Algebra: the rank-1 (shared-crowd) form of rgl_rank1.hip -- siblings share every human row of X and of S except the
+// robot column, so a human row i of child c is (alpha_i UW_i + beta_i (x0_c W1)) / Z_i with crowd-only UW, msh, Zsh.
+// What changes is the organisation (round 2):
+//   * crowd_block_kernel computes the crowd-only block of every parent once (Xh, G = Xh Wa, UW, msh, Zsh -> 12.5 KB per
+//     parent in HBM/MALL), so the main kernel has no producer waves, no double buffer and no flag handshakes;
+//   * children_fused_kernel: every wave owns one 16-child tile from the robot embedding to the VALUE: embedding,
+//     robot row/column of S, softmax scalars, the VALU row pass, the robot row, the last GCN layer on the robot row and the
+//     value head all run on registers and a 6.5 KB wave-private LDS scratch.  No workgroup barrier after the weight image
+//     is built, no [P*A][64] fp32 hand-off through HBM, no second launch.  Tiles are dealt round-robin over all waves of
+//     the GPU (full tiles first, then the partial last tiles of the parents), so the four SIMDs of a CU carry the same
+//     number of tiles -- the imbalance that sank round 1's barrier-free experiment (6 tiles + 2 crowd waves on 4 SIMDs).
+//   * a parent's partial last tile (A % 16 children; the single `stop` action of the 81-action table) runs everything but
+//     the head and leaves its rows in a small buffer; robot_head_kernel scores those rows tile-packed over parents, so the
+//     head never multiplies 15 columns of padding.
+#include "rgl_mlp_chain.h"
+
+namespace {
+
+// crowd block of one parent in global memory (floats), NP = 16 NT node slots (slot 0 = robot, zero):
+//   Xh[NP][32] | G[NP][32]   node-major: MFMA A-operand rows of the robot row / column of S
+//   XhT[32][NP] | UWT[32][NP] feature-major: a lane's nodes are contiguous (one b128 load per 4 nodes)
+//   msh[NP] | zsh[NP]
+__host__ __device__ constexpr int crowd_block_floats(int NT) { return 4 * 16 * NT * XD + 2 * 16 * NT; }
+
+struct CrowdArgs {
+    const float *wh1, *bh1, *wh2, *bh2, *wa, *w1;
+    const float* humans;      // [P][H][5]
+    float* blocks;            // [P][crowd_block_floats(NT)]
+    const float* image;       // the weight image below, prepared in global memory by pack_images_kernel
+    int P, H, N, sim;
+};
+
+// LDS weight image of crowd_block_kernel (floats)
+struct CrowdLds {
+    static constexpr int wh1 = 0, bh1 = wh1 + 8 * W1LD, wh2 = bh1 + HID, bh2 = wh2 + HID * WLD, wa = bh2 + XD, w1 = wa + XD * WLD,
+                         total = w1 + XD * WLD;
+};
+
+template <int NTHR>
+__device__ __forceinline__ void fill_crowd_image(float* img, const CrowdArgs& a, int tid) {
+    fill_matrix<5, 8, HID, W1LD, NTHR>(img + CrowdLds::wh1, a.wh1, tid);
+    fill_matrix<HID, HID, XD, WLD, NTHR>(img + CrowdLds::wh2, a.wh2, tid);
+    fill_matrix<XD, XD, XD, WLD, NTHR>(img + CrowdLds::w1, a.w1, tid);
+    if (a.wa) fill_matrix<XD, XD, XD, WLD, NTHR>(img + CrowdLds::wa, a.wa, tid);
+    else
+        for (int i = tid; i < XD * XD; i += NTHR) img[CrowdLds::wa + (i / XD) * WLD + (i % XD)] = (i / XD) == (i % XD) ? 1.f : 0.f;   // gaussian: Wa = I
+    for (int i = tid; i < HID; i += NTHR) img[CrowdLds::bh1 + i] = a.bh1[i];
+    for (int i = tid; i < XD; i += NTHR) img[CrowdLds::bh2 + i] = a.bh2[i];
+}
+
+constexpr int kCrowdWaves = 8;
+
+// One wave per (parent, 16-node column tile); the NT waves of a parent meet at a workgroup barrier between the two parts.
+template <int NT, bool SOFT>
+__global__ __launch_bounds__(kCrowdWaves * 64) void crowd_block_kernel(const CrowdArgs a) {
+    const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NP = 16 * NT;
+    constexpr int PPW = kCrowdWaves / NT;            // parents per workgroup pass
+    constexpr int o_wh1 = CrowdLds::wh1, o_bh1 = CrowdLds::bh1, o_wh2 = CrowdLds::wh2, o_bh2 = CrowdLds::bh2, o_wa = CrowdLds::wa,
+                  o_w1 = CrowdLds::w1, o_xh = CrowdLds::total;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int N = a.N, H = a.H;
+    const float NEG_INF = -INFINITY;
+    copy_image<CrowdLds::total, kCrowdWaves * 64>(lds, a.image, tid);
+    __syncthreads();
+    const float* wh1 = lds + o_wh1;
+    const float* bh1 = lds + o_bh1;
+    const float* wh2 = lds + o_wh2;
+    const float* bh2 = lds + o_bh2;
+    const float* wa = lds + o_wa;
+    const float* w1 = lds + o_w1;
+    const int slot = wave / NT, pct = wave - slot * NT;
+    float* Xh = lds + o_xh + slot * NP * XLD;
+    const int node = 16 * pct + n;
+    const bool node_ok = node >= 1 && node < N;
+
+    float hin[2];                                    // my node's state row, loaded one pass ahead
+    auto human_rows = [&](int pp) {
+        const float* hsrc = a.humans + ((size_t)(pp < a.P ? pp : a.P - 1) * H + (node_ok ? node - 1 : 0)) * 5;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = 4 * s + q;
+            hin[s] = (node_ok && k < 5) ? hsrc[k] : 0.f;
+        }
+    };
+    human_rows(blockIdx.x * PPW + slot);
+    for (int base = blockIdx.x * PPW; base < a.P; base += gridDim.x * PPW) {
+        const int pp = base + slot;
+        const bool active = pp < a.P;
+        float* blk = a.blocks + (size_t)(active ? pp : 0) * crowd_block_floats(NT);
+        f32x4 pg[2] = {zero4(), zero4()};
+        if (active) {
+            // part 1: Xh = w_h(humans), G = Xh Wa   (transposed MFMA chain, 16 nodes per wave)
+            f32x4 hacc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int k = 4 * s + q;
+#pragma unroll
+                for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wh1[k * W1LD + 16 * ht + n], hin[s], hacc[ht]);
+            }
+            human_rows(pp + gridDim.x * PPW);
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&bh1[16 * ht + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hacc[ht][r] = relu1(hacc[ht][r] + bb[r]);
+            }
+            f32x4 xacc[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot)
+                        xacc[ot] = mfma4(wh2[(16 * ht + 4 * q + r) * WLD + 16 * ot + n], hacc[ht][r], xacc[ot]);
+            }
+            load_fence();
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&bh2[16 * ot + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xacc[ot][r] = node_ok ? relu1(xacc[ot][r] + bb[r]) : 0.f;   // robot slot / padding rows: 0
+                *reinterpret_cast<f32x4*>(&Xh[node * XLD + 16 * ot + 4 * q]) = xacc[ot];
+                *reinterpret_cast<f32x4*>(&blk[node * XD + 16 * ot + 4 * q]) = xacc[ot];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) blk[2 * NP * XD + (16 * ot + 4 * q + r) * NP + node] = xacc[ot][r];
+            }
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int gt = 0; gt < 2; ++gt)
+                        pg[gt] = mfma4(wa[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], pg[gt]);
+            }
+            load_fence();
+            *reinterpret_cast<f32x4*>(&blk[NP * XD + node * XD + 4 * q]) = pg[0];
+            *reinterpret_cast<f32x4*>(&blk[NP * XD + node * XD + 16 + 4 * q]) = pg[1];
+        }
+        __syncthreads();
+        if (active) {
+            // part 2 (needs every Xh row): S_ij = G_i . Xh_j over humans j, msh / E / Zsh, U = E Xh, UW = U W1
+            f32x4 e[NT];
+            float mx = NEG_INF;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                load_fence();
+                f32x4 sacc = zero4();
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft) {
+                    const f32x4 xa = *reinterpret_cast<const f32x4*>(&Xh[(16 * jt + n) * XLD + 16 * ft + 4 * q]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc = mfma4(xa[r], pg[ft][r], sacc);      // [j = 16jt+4q+r][i = my node]
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * jt + 4 * q + r;
+                    if (sim != SIM_SOFTMAX) sacc[r] = plain_weight(sim, sacc[r], node, j);
+                    if (j < 1 || j >= N) sacc[r] = sim == SIM_SOFTMAX ? NEG_INF : 0.f;
+                    mx = fmaxf(mx, sacc[r]);
+                }
+                e[jt] = sacc;
+            }
+            mx = kgroups_max(mx);
+            if (!node_ok || sim != SIM_SOFTMAX) mx = 0.f;
+            float z = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (sim == SIM_SOFTMAX) e[jt][r] = __expf(e[jt][r] - mx);
+                    if (!node_ok) e[jt][r] = 0.f;
+                    z += e[jt][r];
+                }
+            z = kgroups_sum(z);
+            if (q == 0) {
+                blk[4 * NP * XD + node] = mx;
+                blk[4 * NP * XD + NP + node] = node_ok ? z : 1.f;
+            }
+            f32x4 u[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a0 = Xh[(16 * jt + 4 * q + r) * XLD + n];
+                    const float a1 = Xh[(16 * jt + 4 * q + r) * XLD + 16 + n];
+                    u[0] = mfma4(a0, e[jt][r], u[0]);                                         // U^T[f][i] = sum_j Xh[j][f] E[i][j]
+                    u[1] = mfma4(a1, e[jt][r], u[1]);
+                }
+            }
+            f32x4 uw[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot)
+                        uw[ot] = mfma4(w1[(16 * ft + 4 * q + r) * WLD + 16 * ot + n], u[ft][r], uw[ot]);
+            }
+            load_fence();
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) blk[3 * NP * XD + (16 * ot + 4 * q + r) * NP + node] = uw[ot][r];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the fused tile kernel
+// ------------------------------------------------------------------------------------------------
+struct FusedArgs {
+    const float *wr1, *br1, *wr2, *br2, *wa, *w1;                       // child-side weights (k-major)
+    const float* w_last;                                                // [32][32] last GCN layer
+    const float *hw1, *hb1, *hw2, *hb2, *hw3, *hb3, *hw4, *hb4;         // value head, k-major
+    const float* child_robot;     // [P][A][9]
+    const float* blocks;          // [P][crowd_block_floats(NT)]
+    float* value;                 // [P][A]
+    float* rows_left;             // [P][A % 16][64]  rows [t_c | H1_0] of the partial last tiles (null when A % 16 == 0)
+    int P, A, N, SLD, sim;
+    int n_full;                   // full tiles per parent = A / 16
+    int rem;                      // A % 16
+    const float* image;           // FusedLds weight image [0, FusedLds::scratch) prepared in global memory by pack_images_kernel
+    int tiles_per_item;           // a work item = this many consecutive FULL tiles of one parent (crowd fragments loaded once)
+    int items_per_parent;         // = ceil(n_full / tiles_per_item)
+};
+
+constexpr int kFusedWaves = 8;
+
+template <int D1, int D2, int D3>
+struct FusedLds {
+    // child-side weight image
+    static constexpr int wr1 = 0;
+    static constexpr int br1 = wr1 + 12 * W1LD;
+    static constexpr int wr2 = br1 + HID;
+    static constexpr int br2 = wr2 + HID * WLD;
+    static constexpr int wa = br2 + XD;
+    static constexpr int w1 = wa + XD * WLD;
+    // head fragments (layout of rgl_head.hip)
+    static constexpr int f_last = w1 + XD * WLD;
+    static constexpr int f1 = f_last + 2 * 2 * 4 * 64;
+    static constexpr int f2 = f1 + Tiles<D1>::v * 2 * 4 * 64;
+    static constexpr int f3 = f2 + Tiles<D2>::v * Tiles<D1>::v * 4 * 64;
+    static constexpr int b1 = f3 + Tiles<D3>::v * Tiles<D2>::v * 4 * 64;
+    static constexpr int b2 = b1 + Tiles<D1>::v * 16;
+    static constexpr int b3 = b2 + Tiles<D2>::v * 16;
+    static constexpr int w4 = b3 + Tiles<D3>::v * 16;
+    static constexpr int scratch = w4 + Tiles<D3>::v * 16;       // per wave: AB[16][SLD][2] | Y[16][XLD]
+};
+
+// h = relu(t W_last)(+hprev), value head 32 -> D1 -> D2 -> D3 -> 1 for the 16 children of a tile (lane (n, q): child n, D-layout
+// registers); returns the value of child n in every lane of its column (without the last bias)
+template <class LO, int D1, int D2, int D3, bool SKIP>
+__device__ __forceinline__ float head_chain(const float* lds, const f32x4 (&tin)[2], const f32x4 (&hp)[2], int lane) {
+    const int q = lane >> 4;
+    f32x4 h[2];
+    layer_mfma<XD, XD, false>(lds + LO::f_last, tin, h, lane);
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = relu1(h[ot][r]);
+            if (SKIP) x += hp[ot][r];
+            h[ot][r] = x;
+        }
+    f32x4 a1[Tiles<D1>::v];
+    layer_mfma<XD, D1, true>(lds + LO::f1, h, a1, lane, lds + LO::b1);
+    relu_tiles<D1>(a1);
+    f32x4 a2[Tiles<D2>::v];
+    layer_mfma<D1, D2, true>(lds + LO::f2, a1, a2, lane, lds + LO::b2);
+    relu_tiles<D2>(a2);
+    f32x4 a3[Tiles<D3>::v];
+    layer_mfma<D2, D3, true>(lds + LO::f3, a2, a3, lane, lds + LO::b3);
+    relu_tiles<D3>(a3);
+    float v = 0.f;
+#pragma unroll
+    for (int ot = 0; ot < Tiles<D3>::v; ++ot) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(&lds[LO::w4 + 16 * ot + 4 * q]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v = fmaf(a3[ot][r], w[r], v);
+    }
+    return kgroups_sum(v);
+}
+
+// HR >= N: human rows of UW held in registers (padded rows contribute exactly 0); SOFT: softmax row normalisation
+template <int HR, int NT, bool SKIP, bool SOFT, int D1, int D2, int D3>
+__global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const FusedArgs a) {
+    const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using LO = FusedLds<D1, D2, D3>;
+    constexpr int NP = 16 * NT;
+    constexpr int nthreads = kFusedWaves * 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int N = a.N, A = a.A, SLD = a.SLD;
+    const float NEG_INF = -INFINITY;
+    copy_image<LO::scratch, nthreads>(lds, a.image, tid);      // weight image, once per workgroup
+    __syncthreads();
+    const float* wr1 = lds + LO::wr1;   // [12][W1LD], rows 9..11 zero
+    const float* br1 = lds + LO::br1;
+    const float* wr2 = lds + LO::wr2;   // [HID][WLD]
+    const float* br2 = lds + LO::br2;
+    const float* wa = lds + LO::wa;     // [XD][WLD]
+    const float* w1 = lds + LO::w1;     // [XD][WLD]
+    float* AB = lds + LO::scratch + wave * (2 * 16 * SLD + 16 * XLD);   // [16][SLD][2]: per child and row (a, b), p folded in
+    float* Y0 = AB + 2 * 16 * SLD;                                      // [16][XLD]: x0 W1, then t_c without the robot-row term
+    const float hb4 = a.hb4[0];
+
+    // Work items (each class dealt round-robin over all waves of the GPU, so every wave sees the same mix):
+    //   item (j, p), group-major (all first groups, then all second ...): G consecutive full tiles of parent p; the FIRST group
+    //   of a parent starts with its partial last tile (A % 16 children: everything but the head, rows -> rows_left; a launch of
+    //   robot_head_kernel scores those rows tile-packed over parents afterwards).
+    // Item wi -> (workgroup wi % grid, wave (wi / grid) % 8): consecutive items land on different CUs, then on different SIMDs.
+    // The crowd fragments of a parent are loaded once per item, and the NEXT item's loads are issued before the head of the
+    // current item's last tile: no item starts on a cold register file.
+    const int G = a.tiles_per_item;
+    const int n_group = a.P * a.items_per_parent;
+    const int n_items = n_group;
+    const int stride = gridDim.x * kFusedWaves;
+    constexpr int HRL = HR < NP ? HR : NP;              // rows of UW a lane holds (rows >= N are zero in the block)
+    float rin[3];
+    f32x4 gq[NT][2], xq[NT][2], ms[NT], zs[NT], xt[NT][2], uw4[HRL / 4];
+    auto item_tiles = [&](int wi, int& p, int& ts, int& t1) {      // tile sequence ts .. t1-1, where t < t0 means "the partial tile"
+        const int j = wi / a.P;
+        p = wi - j * a.P;
+        const int t0 = j * G;
+        t1 = t0 + G < a.n_full ? t0 + G : a.n_full;
+        ts = (j == 0 && a.rem) ? t0 - 1 : t0;
+    };
+    auto robot_rows = [&](int p, int t) {                          // rows of child 16 t + n of parent p -> rin
+        const int c0 = 16 * t + n;
+        const float* rr = a.child_robot + ((size_t)p * A + (c0 < A ? c0 : A - 1)) * 9;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int k = 4 * s + q;
+            rin[s] = k < 9 ? rr[k] : 0.f;
+        }
+    };
+    auto item_loads = [&](int wi) {                                // first robot rows + crowd fragments of item wi
+        int p, ts, t1;
+        item_tiles(wi, p, ts, t1);
+        robot_rows(p, ts < (wi / a.P) * G ? a.n_full : ts);
+        const float* blk = a.blocks + (size_t)p * crowd_block_floats(NT);
+        const float* gXh = blk;
+        const float* gGm = blk + NP * XD;
+        const float* gXhT = blk + 2 * NP * XD;
+        const float* gUWT = blk + 3 * NP * XD;
+        const float* gms = blk + 4 * NP * XD;
+        const float* gzs = gms + NP;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                gq[nt][ot] = *reinterpret_cast<const f32x4*>(&gGm[(16 * nt + n) * XD + 16 * ot + 4 * q]);
+                xq[nt][ot] = *reinterpret_cast<const f32x4*>(&gXh[(16 * nt + n) * XD + 16 * ot + 4 * q]);
+                xt[nt][ot] = *reinterpret_cast<const f32x4*>(&gXhT[(16 * ot + n) * NP + 16 * nt + 4 * q]);   // Xh[16nt+4q+r][16ot+n]
+            }
+            ms[nt] = *reinterpret_cast<const f32x4*>(&gms[16 * nt + 4 * q]);
+            zs[nt] = *reinterpret_cast<const f32x4*>(&gzs[16 * nt + 4 * q]);
+        }
+#pragma unroll
+        for (int i4 = 0; i4 < HRL / 4; ++i4) uw4[i4] = *reinterpret_cast<const f32x4*>(&gUWT[(lane & 31) * NP + 4 * i4]);
+    };
+    PHASE_START();
+    const int wi_first = wave * gridDim.x + blockIdx.x;
+    if (wi_first < n_group) item_loads(wi_first);
+    for (int wi = wi_first; wi < n_items; wi += stride) {
+        PHASE_MARK(0);
+        int p, ts, t1;
+        item_tiles(wi, p, ts, t1);
+        const int t0 = (wi / a.P) * G;
+        load_fence();
+        PHASE_MARK(1);
+
+      for (int ti = ts; ti < t1; ++ti) {
+        const int t = ti < t0 ? a.n_full : ti;             // the first group of a parent starts with the partial tile
+        const bool full = t < a.n_full;
+        const int c = 16 * t + n;                          // my child (column of the MFMA tiles)
+        const int n_valid = full ? 16 : a.rem;
+
+        // ---------------- embedding: x0 = w_r(robot'), y = x0 W1, g0 = x0 Wa (transposed MFMA chain) ----------------
+        f32x4 xacc[2] = {zero4(), zero4()}, gacc[2] = {zero4(), zero4()};
+        float s00 = 0.f;
+        {
+            f32x4 hacc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int k = 4 * s + q;
+#pragma unroll
+                for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wr1[k * W1LD + 16 * ht + n], rin[s], hacc[ht]);
+            }
+            if (ti + 1 < t1) robot_rows(p, ti + 1);      // robot rows of my next tile: in flight under this tile's work
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&br1[16 * ht + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hacc[ht][r] = relu1(hacc[ht][r] + bb[r]);
+            }
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot)
+                        xacc[ot] = mfma4(wr2[(16 * ht + 4 * q + r) * WLD + 16 * ot + n], hacc[ht][r], xacc[ot]);
+            }
+            load_fence();
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&br2[16 * ot + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xacc[ot][r] = relu1(xacc[ot][r] + bb[r]);
+            }
+            f32x4 yacc[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int gt = 0; gt < 2; ++gt) {
+                        gacc[gt] = mfma4(wa[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], gacc[gt]);
+                        yacc[gt] = mfma4(w1[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], yacc[gt]);
+                    }
+            }
+            load_fence();
+            *reinterpret_cast<f32x4*>(&Y0[n * XLD + 4 * q]) = yacc[0];
+            *reinterpret_cast<f32x4*>(&Y0[n * XLD + 16 + 4 * q]) = yacc[1];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s00 = fmaf(gacc[tt][r], xacc[tt][r], s00);
+            s00 = kgroups_sum(s00);
+        }
+
+        PHASE_MARK(2);
+        // ---------------- robot row / column of S, p = softmax(robot row), p Xh, the (a, b) table ---------------------
+        // all in the MFMA D layout: lane (n, q) = child 16 t + n, registers = nodes 16 nt + 4 q + r
+        f32x4 t0h[2] = {zero4(), zero4()};        // (p_c Xh)^T of my 16 children
+        float p00;                                // A_c[0][0]
+        {
+            f32x4 s0t[NT], sct[NT];
+            float mx0 = NEG_INF;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 sc = zero4(), s0 = zero4();
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sc = mfma4(gq[nt][ot][r], xacc[ot][r], sc);
+                        s0 = mfma4(xq[nt][ot][r], gacc[ot][r], s0);
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nd = 16 * nt + 4 * q + r;
+                    if (nd == 0) { sc[r] = s00; s0[r] = s00; }
+                    if (sim != SIM_SOFTMAX) s0[r] = plain_weight(sim, s0[r], 0, nd);
+                    if (nd >= N) { sc[r] = NEG_INF; s0[r] = sim == SIM_SOFTMAX ? NEG_INF : 0.f; }
+                    mx0 = fmaxf(mx0, s0[r]);
+                }
+                s0t[nt] = s0;
+                sct[nt] = sc;
+            }
+            mx0 = kgroups_max(mx0);
+            float z0 = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (sim == SIM_SOFTMAX) s0t[nt][r] = __expf(s0t[nt][r] - mx0);
+                    z0 += s0t[nt][r];
+                }
+            const float iz0 = __builtin_amdgcn_rcpf(kgroups_sum(z0));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s0t[nt][r] *= iz0;                       // p = A_c[0][:] (0 beyond row N-1)
+            p00 = kgroups_sum(q == 0 ? s0t[0][0] : 0.f);
+            // (p_c Xh)^T[f][c] = sum_j Xh^T[f][j] p_c[j]: the D registers of the robot-row product are already the B operand
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    t0h[0] = mfma4(xt[nt][0][r], s0t[nt][r], t0h[0]);
+                    t0h[1] = mfma4(xt[nt][1][r], s0t[nt][r], t0h[1]);
+                }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nd = 16 * nt + 4 * q + r;
+                    const float pv = s0t[nt][r];
+                    float al, be;
+                    if (sim == SIM_SOFTMAX) {
+                        const float m = fmaxf(ms[nt][r], sct[nt][r]);
+                        al = __expf(ms[nt][r] - m);
+                        be = __expf(sct[nt][r] - m);
+                    } else {
+                        al = 1.f;
+                        be = plain_weight(sim, sct[nt][r], nd, 0);        // diagonal: nd >= 1 here, so 0
+                    }
+                    const float piz = pv * __builtin_amdgcn_rcpf(fmaf(al, zs[nt][r], be));
+                    const bool rh = nd >= 1 && nd < N;
+                    *reinterpret_cast<f32x2*>(&AB[(n * SLD + nd) * 2]) = f32x2{rh ? al * piz : 0.f, rh ? be * piz : 0.f};
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+        load_fence();
+        PHASE_MARK(3);
+
+        // ---------------- row pass over my 16 children: two per step (half-wave each), lane = feature -----------------
+        {
+            const int hh = lane >> 5, f = lane & 31;
+            constexpr int HRV = HR < 16 * NT ? HR : 16 * NT;      // the table holds 16*NT rows per child
+            const int n_pairs = (n_valid + 1) >> 1;
+            for (int pair = 0; pair < n_pairs; ++pair) {
+                const int lc = 2 * pair + hh;                                      // child within the tile
+                const float* sc_mine = AB + (lc * SLD + (lane & 15)) * 2;
+                f32x2 ab[NT];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) ab[tt] = *reinterpret_cast<const f32x2*>(&sc_mine[32 * tt]);
+                const float yv = Y0[lc * XLD + f];
+                float rp[4] = {0.f, 0.f, 0.f, 0.f};
+                static_for<0, (HRV + 2) / 4>([&](auto gc) {
+                    constexpr int i0 = 1 + 4 * decltype(gc)::value;
+                    float tv[4];
+                    static_for<0, 4>([&](auto kc) {
+                        constexpr int ii = i0 + decltype(kc)::value;
+                        if constexpr (ii < HRV) tv[ii - i0] = dpp_rowbcast_mul<(ii & 15)>(ab[ii >> 4][1], yv);
+                    });
+                    static_for<0, 4>([&](auto kc) {
+                        constexpr int ii = i0 + decltype(kc)::value;
+                        if constexpr (ii < HRV) tv[ii - i0] = dpp_rowbcast_fmac<(ii & 15)>(ab[ii >> 4][0], uw4[ii >> 2][ii & 3], tv[ii - i0]);
+                    });
+                    static_for<0, 4>([&](auto kc) {
+                        constexpr int ii = i0 + decltype(kc)::value;
+                        if constexpr (ii < HRV) rp[ii - i0] += relu1(tv[ii - i0]);
+                    });
+                });
+                Y0[lc * XLD + f] = (rp[0] + rp[1]) + (rp[2] + rp[3]);             // t_c without the robot-row / skip terms
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        load_fence();
+        PHASE_MARK(4);
+
+        // ---------------- robot row: H1_0 = relu(T_0 W1)(+x0), t_c += p00 * H1_0 ---------------------------------------
+        f32x4 tin[2], hp[2];
+        {
+            f32x4 o[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float tb = fmaf(p00, xacc[ft][r], t0h[ft][r]);      // T_0 = p_c Xh + p_c[0] x0_c
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot)
+                        o[ot] = mfma4(w1[(16 * ft + 4 * q + r) * WLD + 16 * ot + n], tb, o[ot]);
+                }
+            }
+            load_fence();
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                const f32x4 tp = *reinterpret_cast<const f32x4*>(&Y0[n * XLD + 16 * ot + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float hv = relu1(o[ot][r]);
+                    if (SKIP) hv += xacc[ot][r];
+                    hp[ot][r] = hv;
+                    tin[ot][r] = fmaf(p00, hv, SKIP ? tp[r] + t0h[ot][r] : tp[r]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();      // the next tile's Y0 / AB writes stay behind this tile's reads
+        PHASE_MARK(5);
+        if (ti + 1 == t1 && wi + stride < n_group) item_loads(wi + stride);     // next item's loads fly under this tile's head
+
+        if (!full) {
+            // partial last tile: leave the rows [t_c | H1_0] for the tile-packed head pass
+            if (n < a.rem) {
+                float* out = a.rows_left + ((size_t)p * a.rem + n) * 64;
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    *reinterpret_cast<f32x4*>(out + 16 * ot + 4 * q) = tin[ot];
+                    *reinterpret_cast<f32x4*>(out + 32 + 16 * ot + 4 * q) = hp[ot];
+                }
+            }
+            continue;
+        }
+
+        // ---------------- last GCN layer on the robot row + value head: one register-resident MFMA chain -------------------
+        const float v = head_chain<LO, D1, D2, D3, SKIP>(lds, tin, hp, lane);
+        if (q == 0) a.value[(size_t)p * A + c] = v + hb4;
+        PHASE_MARK(6);
+      }
+    }
+    PHASE_FLUSH();
+}
+
+// Both weight images in global memory, in exactly the LDS layouts the kernels use: built ONCE per tree search (or per
+// stand-alone call) by a grid of threads, then every workgroup of every level copies its image with b128 loads that are all in
+// flight at once.  (Building the 97 KB image inside each persistent workgroup cost ~10 us of dependent L2 round trips per
+// launch -- most of a small-batch launch.)
+constexpr int kPackThreads = 256, kPackBlocks = 48;
+template <int D1, int D2, int D3>
+__global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedArgs a, const CrowdArgs c, float* img) {
+    using LO = FusedLds<D1, D2, D3>;
+    constexpr int NTHR = kPackThreads * kPackBlocks;
+    const int tid = blockIdx.x * kPackThreads + threadIdx.x;
+    float* w = img;
+    fill_matrix<9, 12, HID, W1LD, NTHR>(w + LO::wr1, a.wr1, tid);
+    fill_matrix<HID, HID, XD, WLD, NTHR>(w + LO::wr2, a.wr2, tid);
+    fill_matrix<XD, XD, XD, WLD, NTHR>(w + LO::w1, a.w1, tid);
+    if (a.wa) fill_matrix<XD, XD, XD, WLD, NTHR>(w + LO::wa, a.wa, tid);
+    else
+        for (int i = tid; i < XD * XD; i += NTHR) w[LO::wa + (i / XD) * WLD + (i % XD)] = (i / XD) == (i % XD) ? 1.f : 0.f;   // gaussian: Wa = I
+    for (int i = tid; i < HID; i += NTHR) w[LO::br1 + i] = a.br1[i];
+    for (int i = tid; i < XD; i += NTHR) w[LO::br2 + i] = a.br2[i];
+    // the image rows the matrices do not cover (padding columns of the strided rows) are never read
+    fill_frags<XD, XD, NTHR>(w + LO::f_last, a.w_last, tid);
+    fill_frags<XD, D1, NTHR>(w + LO::f1, a.hw1, tid);
+    fill_frags<D1, D2, NTHR>(w + LO::f2, a.hw2, tid);
+    fill_frags<D2, D3, NTHR>(w + LO::f3, a.hw3, tid);
+    fill_bias<D1>(w + LO::b1, a.hb1, tid, NTHR);
+    fill_bias<D2>(w + LO::b2, a.hb2, tid, NTHR);
+    fill_bias<D3>(w + LO::b3, a.hb3, tid, NTHR);
+    fill_bias<D3>(w + LO::w4, a.hw4, tid, NTHR);        // w4 is [D3][1]: same padded vector layout as a bias
+    fill_crowd_image<NTHR>(img + LO::scratch, c, tid);
+}
+
+constexpr size_t kImageFloats = FusedLds<32, 100, 100>::scratch + CrowdLds::total;
+constexpr size_t kImageBytes = (kImageFloats * sizeof(float) + 255) & ~(size_t)255;
+
+struct FusedPlan {
+    FusedArgs a;
+    CrowdArgs c;
+    size_t lds_bytes, crowd_lds_bytes;
+    int hr, nt;
+    bool ok;
+};
+
+// Which launches take the fused kernel.  Measured on MI355X (tools/kiter.py, profiles/r02_*): both organisations end up
+// pipe-bound (MFMA + VALU issue, no co-execution) at a shader clock that drops with utilisation, so the fused kernel wins
+// only where its per-tile latency (one wave carries a tile through ~400 MFMAs) is covered by many tiles per SIMD: from ~9 k
+// tiles (P ~ 1.5 k parents of 81 actions) upwards it is 2-5 % faster and moves 12x less HBM traffic; below, the two-stage
+// pair (8 waves share a parent, 4 waves per SIMD in the head) is faster.  RGL_CHILDREN_FUSED=1 / RGL_CHILDREN_TWO_STAGE=1
+// force one organisation (tests).
+inline int fused_policy() {
+    static const int pol = [] {
+        const char* f = getenv("RGL_CHILDREN_FUSED");
+        const char* t = getenv("RGL_CHILDREN_TWO_STAGE");
+        return (f && f[0] == '1') ? 1 : ((t && t[0] == '1') ? -1 : 0);
+    }();
+    return pol;
+}
+
+inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A, int H) {
+    FusedPlan pl;
+    pl.ok = false;
+    if (!fast_path_enabled() || !rank1_enabled() || fused_policy() < 0) return pl;
+    if (fused_policy() == 0 && (long)P * ((A + 15) / 16) < 9000) return pl;
+    if (fast_similarity_mode(g) < 0 || g.layerwise_graph || g.x_dim != XD || g.num_layer != 2) return pl;
+    if (!mlp_is(g.w_r, 9, HID, XD, true) || !mlp_is(g.w_h, 5, HID, XD, true)) return pl;
+    if (head_variant(head) != 0) return pl;
+    const int N = H + 1;
+    if (N > 32 || A < 1) return pl;
+    FusedArgs& a = pl.a;
+    a.N = N; a.A = A; a.P = P;
+    pl.nt = (N + 15) / 16;
+    pl.hr = N <= 8 ? 8 : (N <= 20 ? 20 : 32);
+    a.SLD = 16 * pl.nt + 1;                      // rows padded to whole MFMA tiles (unconditional access), odd stride
+    a.n_full = A / 16;
+    a.rem = A % 16;
+    a.sim = fast_similarity_mode(g);
+    {   // tiles per work item: as many as keeps >= 2 items on every SIMD of the GPU (256 CUs x 4) and the per-SIMD makespan minimal
+        const int CT = a.n_full > 0 ? a.n_full : 1;
+        int best_g = 1;
+        long best_cost = -1;
+        for (int G = CT; G >= 1; --G) {
+            const int ipp = (CT + G - 1) / G;
+            if (G > 1 && (ipp - 1) * G >= CT) continue;
+            const long items = (long)P * ipp;
+            if (G > 1 && items < 2048) continue;
+            const long cost = ((items + 1023) / 1024) * G;
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_g = G; }
+        }
+        a.tiles_per_item = best_g;
+        a.items_per_parent = (CT + best_g - 1) / best_g;      // n_full == 0: one item per parent, its partial tile alone
+    }
+    pl.lds_bytes = (size_t)(FusedLds<32, 100, 100>::scratch + kFusedWaves * (2 * 16 * a.SLD + 16 * XLD)) * sizeof(float);
+    if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
+    a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];
+    a.wa = bilinear_wa(g); a.w1 = g.Ws[0];
+    a.w_last = g.Ws[1];
+    a.hw1 = head.weight[0]; a.hb1 = head.bias[0]; a.hw2 = head.weight[1]; a.hb2 = head.bias[1];
+    a.hw3 = head.weight[2]; a.hb3 = head.bias[2]; a.hw4 = head.weight[3]; a.hb4 = head.bias[3];
+    CrowdArgs& c = pl.c;
+    c.wh1 = g.w_h.weight[0]; c.bh1 = g.w_h.bias[0]; c.wh2 = g.w_h.weight[1]; c.bh2 = g.w_h.bias[1];
+    c.wa = bilinear_wa(g); c.w1 = g.Ws[0];
+    c.P = P; c.H = H; c.N = N; c.sim = a.sim;
+    pl.crowd_lds_bytes = (size_t)(CrowdLds::total + kCrowdWaves * 16 * XLD) * sizeof(float);
+    pl.ok = true;
+    return pl;
+}
+
+template <int NT, bool SOFT>
+int launch_crowd(const FusedPlan& pl, hipStream_t st) {
+    auto kern = crowd_block_kernel<NT, SOFT>;
+    constexpr int PPW = kCrowdWaves / NT;
+    int grid = (pl.c.P + PPW - 1) / PPW;
+    if (grid > 768) grid = 768;                                   // 40 KB LDS: three workgroups per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kCrowdWaves * 64), pl.crowd_lds_bytes, st, pl.c);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
+template <int HR, int NT, bool SKIP, bool SOFT>
+int launch_fused_ts(const FusedPlan& pl, hipStream_t st) {
+    int rc = launch_crowd<NT, SOFT>(pl, st);
+    if (rc) return rc;
+    auto kern = children_fused_kernel<HR, NT, SKIP, SOFT, 32, 100, 100>;
+    RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)pl.lds_bytes));
+    const int n_items = pl.a.P * pl.a.items_per_parent;
+    int grid = (n_items + kFusedWaves - 1) / kFusedWaves;
+    // persistent, one 8-wave workgroup per CU (LDS-bound)
+    static const int n_cu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev);
+                                 (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    if (grid > n_cu) grid = n_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), pl.lds_bytes, st, pl.a);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
+template <int HR, int NT, bool SKIP>
+int launch_fused_t(const FusedPlan& pl, hipStream_t st) {
+    return pl.a.sim == SIM_SOFTMAX ? launch_fused_ts<HR, NT, SKIP, true>(pl, st) : launch_fused_ts<HR, NT, SKIP, false>(pl, st);
+}
+
+inline int launch_fused(const FusedPlan& pl, bool skip, hipStream_t st) {
+    switch (pl.hr) {
+        case 8: return skip ? launch_fused_t<8, 1, true>(pl, st) : launch_fused_t<8, 1, false>(pl, st);
+        case 20: return pl.nt == 1 ? (skip ? launch_fused_t<20, 1, true>(pl, st) : launch_fused_t<20, 1, false>(pl, st))
+                                   : (skip ? launch_fused_t<20, 2, true>(pl, st) : launch_fused_t<20, 2, false>(pl, st));
+        default: return skip ? launch_fused_t<32, 2, true>(pl, st) : launch_fused_t<32, 2, false>(pl, st);
+    }
+}
+
+}  // namespace
+
+#ifdef RGL_PHASE_TIMING
+extern "C" int rgl_debug_read_fused_phase_cycles(unsigned long long* out16, int reset) {
+    RGL_HIP_TRY(hipDeviceSynchronize());
+    RGL_HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        RGL_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)));
+    }
+    return 0;
+}
+#endif
+
+namespace rgl {
+
+// workspace: crowd blocks [P][crowd_block_floats] | rows of the partial tiles [P][A % 16][64] | ... | weight images (at the END)
+size_t fused_children_workspace_bytes(int P, int A, int H) {
+    const int nt = (H + 1 + 15) / 16;
+    const size_t main_bytes = ((size_t)P * crowd_block_floats(nt) + (size_t)P * (A % 16) * 64) * sizeof(float);
+    return ((main_bytes + 255) & ~(size_t)255) + kImageBytes;
+}
+
+static inline float* image_of(void* workspace, size_t workspace_bytes) {
+    return reinterpret_cast<float*>((char*)workspace + ((workspace_bytes - kImageBytes) & ~(size_t)255));
+}
+
+// 1 = the fused kernel does not apply (or the workspace cannot hold its images)
+int pack_children_images(const RglGraph* g, const RglMlp* head, int P, int A, int H, void* workspace, size_t workspace_bytes,
+                         hipStream_t stream) {
+    FusedPlan fp = plan_fused(*g, *head, P, A, H);
+    if (!fp.ok || !workspace || workspace_bytes < fused_children_workspace_bytes(P, A, H)) return 1;
+    hipLaunchKernelGGL((pack_images_kernel<32, 100, 100>), dim3(kPackBlocks), dim3(kPackThreads), 0, stream, fp.a, fp.c,
+                       image_of(workspace, workspace_bytes));
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
+// 1 = outside this kernel's envelope
+int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, int H, const float* child_robot,
+                          const float* humans_next, float* child_value, void* workspace, size_t workspace_bytes,
+                          int image_ready, hipStream_t stream) {
+    FusedPlan fp = plan_fused(*g, *head, P, A, H);
+    if (!fp.ok) return 1;
+    if (!workspace || workspace_bytes < fused_children_workspace_bytes(P, A, H)) return 1;
+    if (!image_ready) {
+        int rc = pack_children_images(g, head, P, A, H, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+    }
+    float* image = image_of(workspace, workspace_bytes);
+    float* blocks = (float*)workspace;
+    float* rows_left = blocks + (size_t)P * crowd_block_floats(fp.nt);
+    fp.c.humans = humans_next;
+    fp.c.blocks = blocks;
+    fp.c.image = image + FusedLds<32, 100, 100>::scratch;
+    fp.a.child_robot = child_robot;
+    fp.a.blocks = blocks;
+    fp.a.value = child_value;
+    fp.a.image = image;
+    fp.a.rows_left = rows_left;
+    int rc = launch_fused(fp, g->skip_connection != 0, stream);
+    if (rc) return rc;
+    if (fp.a.rem)      // rows of the partial tiles, tile-packed over parents: value[p*A + 16*n_full + j]
+        return launch_head_rows_strided(g, head, rows_left, P * fp.a.rem, child_value, fp.a.rem, A, 16 * fp.a.n_full, stream,
+                                        image + FusedLds<32, 100, 100>::f_last);
+    return RGL_OK;
+}
+
+}  // namespace rgl

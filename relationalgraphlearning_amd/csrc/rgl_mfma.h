@@ -49,6 +49,8 @@ __device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__fl
 __device__ unsigned long long g_phase_cycles[16];
 #define PHASE_START()                                                      \
     unsigned long long phase_acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0};          \
+    const unsigned long long phase_rt0__ = __builtin_amdgcn_s_memrealtime(); \
+    const unsigned long long phase_ct0__ = __builtin_amdgcn_s_memtime();   \
     unsigned long long phase_t0__ = __builtin_amdgcn_s_memtime()
 #define PHASE_MARK(idx)                                                    \
     do {                                                                   \
@@ -60,6 +62,10 @@ __device__ unsigned long long g_phase_cycles[16];
     do {                                                                   \
         if ((threadIdx.x & 63) == 0)                                       \
             for (int i__ = 0; i__ < 8; ++i__) atomicAdd(&g_phase_cycles[i__], phase_acc__[i__]); \
+        if (threadIdx.x == 0 && blockIdx.x == 0) { /* shader clock: s_memtime ticks per 100 MHz s_memrealtime tick */ \
+            atomicAdd(&g_phase_cycles[8], __builtin_amdgcn_s_memtime() - phase_ct0__);           \
+            atomicAdd(&g_phase_cycles[9], __builtin_amdgcn_s_memrealtime() - phase_rt0__);       \
+        }                                                                  \
     } while (0)
 #else
 #define PHASE_MARK(idx) do { } while (0)

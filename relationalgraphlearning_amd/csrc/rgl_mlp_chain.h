@@ -21,19 +21,43 @@ __device__ __forceinline__ int tile_feature(int t, int q, int r) {
 template <int D>
 struct LastTileSteps { static constexpr int v = (D % 16) == 0 ? 4 : ((D % 16) + 3) / 4; };
 
-template <int IN, int OUT>
+// NTHR > 0: the workgroup size as a compile-time constant -- the loops are fully unrolled and every global load of a thread is
+// in flight at once (one L2 round trip for the whole image instead of one per batch of 8: the 74 KB image of the value head
+// took ~10 us per workgroup to build, which is most of a small launch).
+template <int IN, int OUT, int NTHR = 0>
 __device__ __forceinline__ void fill_frags(float* dst, const float* __restrict__ W, int tid, int nthr = kThreads) {
     constexpr int IT = Tiles<IN>::v, OT = Tiles<OUT>::v;
-    // unrolled: the loads of several elements are in flight together (one L2 round trip per element otherwise: the
-    // 74 KB image of the value head took ~20 us per workgroup to build)
-#pragma unroll 8
-    for (int idx = tid; idx < OT * IT * 4 * 64; idx += nthr) {
+    constexpr int TOTAL = OT * IT * 4 * 64;
+    auto element = [&](int idx, float& w, bool& ok) {
         const int l = idx & 63, fr = idx >> 6;
         const int r = fr & 3, it = (fr >> 2) % IT, ot = (fr >> 2) / IT;
         const int m = l & 15;                                        // A-operand row = D row of the output tile
         const int in = tile_feature<IN>(it, l >> 4, r), out = tile_feature<OUT>(ot, m >> 2, m & 3);
-        const float w = W[(in < IN ? in : IN - 1) * OUT + (out < OUT ? out : OUT - 1)];   // unconditional load (batched), then mask
-        dst[idx] = (in < IN && out < OUT) ? w : 0.f;
+        w = W[(in < IN ? in : IN - 1) * OUT + (out < OUT ? out : OUT - 1)];   // unconditional load (batched), then mask
+        ok = in < IN && out < OUT;
+    };
+    if constexpr (NTHR > 0) {
+        constexpr int ITERS = (TOTAL + NTHR - 1) / NTHR;
+        float w[ITERS];
+        bool ok[ITERS];
+#pragma unroll
+        for (int k = 0; k < ITERS; ++k) {
+            const int idx = tid + k * NTHR;
+            element(idx < TOTAL ? idx : TOTAL - 1, w[k], ok[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < ITERS; ++k) {
+            const int idx = tid + k * NTHR;
+            if (idx < TOTAL) dst[idx] = ok[k] ? w[k] : 0.f;
+        }
+    } else {
+#pragma unroll 8
+        for (int idx = tid; idx < TOTAL; idx += nthr) {
+            float w;
+            bool ok;
+            element(idx, w, ok);
+            dst[idx] = ok ? w : 0.f;
+        }
     }
 }
 
@@ -45,6 +69,45 @@ __device__ __forceinline__ void fill_bias(float* dst, const float* __restrict__ 
         const int feat = tile_feature<OUT>(idx >> 4, (idx >> 2) & 3, idx & 3);
         const float v = b[feat < OUT ? feat : OUT - 1];
         dst[idx] = feat < OUT ? v : 0.f;
+    }
+}
+
+// k-major [ROWS][COLS] matrix -> LDS image with row stride LD (rows >= ROWS of the ROWS_PAD-row image are zero), all loads of a
+// thread in flight at once
+template <int ROWS, int ROWS_PAD, int COLS, int LD, int NTHR>
+__device__ __forceinline__ void fill_matrix(float* dst, const float* __restrict__ W, int tid) {
+    constexpr int TOTAL = ROWS_PAD * COLS;
+    constexpr int ITERS = (TOTAL + NTHR - 1) / NTHR;
+    float w[ITERS];
+#pragma unroll
+    for (int k = 0; k < ITERS; ++k) {
+        const int i = tid + k * NTHR;
+        w[k] = W[i < ROWS * COLS ? i : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < ITERS; ++k) {
+        const int i = tid + k * NTHR;
+        const int r = i / COLS, c = i - r * COLS;
+        if (i < TOTAL) dst[r * LD + c] = i < ROWS * COLS ? w[k] : 0.f;
+    }
+}
+
+// LDS image <- the same image prepared in global memory: b128 copies, every load of a thread in flight at once
+template <int NFLOATS, int NTHR>
+__device__ __forceinline__ void copy_image(float* dst, const float* __restrict__ src, int tid) {
+    static_assert(NFLOATS % 4 == 0, "images are whole float4s");
+    constexpr int TOTAL = NFLOATS / 4;
+    constexpr int ITERS = (TOTAL + NTHR - 1) / NTHR;
+    f32x4 v[ITERS];
+#pragma unroll
+    for (int k = 0; k < ITERS; ++k) {
+        const int i = tid + k * NTHR;
+        v[k] = reinterpret_cast<const f32x4*>(src)[i < TOTAL ? i : TOTAL - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < ITERS; ++k) {
+        const int i = tid + k * NTHR;
+        if (i < TOTAL) reinterpret_cast<f32x4*>(dst)[i] = v[k];
     }
 }
 

@@ -397,7 +397,7 @@ inline int validate_planner(const MprlPlanner& pl, int H) {
 // One level: steps 1-3 of the header comment of mprl_expand_f32.
 int expand_level(const MprlPlanner& pl, const float* robot, const float* humans, int humans_per, int P, int H, int joint,
                  float* humans_next, float* child_robot, float* reward, float* child_value, void* scratch,
-                 size_t scratch_bytes, hipStream_t st) {
+                 size_t scratch_bytes, hipStream_t st, int image_ready = 0) {
     const int A = pl.num_actions;
     ChildrenArgs ca;
     ca.robot = robot; ca.humans = humans; ca.humans_per = humans_per; ca.actions = pl.actions;
@@ -424,7 +424,7 @@ int expand_level(const MprlPlanner& pl, const float* robot, const float* humans,
         hipLaunchKernelGGL(mprl_children_kernel, grid_for((long long)P * A), dim3(kBlock), 0, st, ca);
         RGL_LAUNCH_CHECK();
     }
-    return rgl::launch_value_children(&pl, child_robot, humans_next, P, H, child_value, scratch, scratch_bytes, st);
+    return rgl::launch_value_children(&pl, child_robot, humans_next, P, H, child_value, scratch, scratch_bytes, st, image_ready);
 }
 
 }  // namespace
@@ -523,6 +523,10 @@ extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* rob
     hipStream_t st = (hipStream_t)stream;
     const float gamma_f = (float)pl.gamma_bar;
 
+    // weight images of the value-of-children kernels: prepared once, every level copies them into LDS (0 = prepared)
+    const int image_ready = pl.contraction_dtype == RGL_CONTRACT_F32 &&
+                            rgl::pack_children_images(&pl.value_graph, &pl.value_head, (int)lv[D - 1].P, A, H, ws + scratch_off,
+                                                      (size_t)scratch_bytes, st) == 0;
     for (int l = 0; l < D; ++l) {
         const LevelLayout& L = lv[l];
         const int P = (int)L.P;
@@ -531,7 +535,7 @@ extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* rob
         const int humans_per = l == 0 ? 1 : W;
         rc = expand_level(pl, pr, ph, humans_per, P, H, l == 0 ? roots_are_joint_states : 0,
                           (float*)(ws + L.humans_next), (float*)(ws + L.child_robot), (float*)(ws + L.reward),
-                          (float*)(ws + L.child_value), ws + scratch_off, (size_t)scratch_bytes, st);
+                          (float*)(ws + L.child_value), ws + scratch_off, (size_t)scratch_bytes, st, image_ready);
         if (rc) return rc;
         const bool deepest = l + 1 == D;
         float* next_robot = deepest ? nullptr : (float*)(ws + lv[l + 1].robot);

@@ -263,6 +263,84 @@ print("OK")
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_fused_tile_kernel_forced(dev):
+    """The fused tile-stream kernel (rgl_fused.hip) is picked for large launches only; RGL_CHILDREN_FUSED=1 forces it for the small,
+    odd-sized launches here (partial tiles, every register bucket, skip on/off, the plain-weight similarities, action tables whose
+    size is / is not a multiple of 16) -- against the oracle, and whole searches against the two-stage pair.  Child process: the
+    switch is read once."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+from oracle import rgl_oracle as orc
+from tests import golden_io as gio
+from tests.helpers import make_mprl_policy
+from tests.test_gpu_parity import seeded_scenes
+dev = torch.device("cuda:0")
+worst = 0.0
+for H, skip, P, sim, flavour in ((19, True, 5, "embedded_gaussian", "trained"), (19, True, 67, "embedded_gaussian", "rand"),
+                                 (5, True, 7, "embedded_gaussian", "trained"), (4, False, 33, "embedded_gaussian", "trained"),
+                                 (1, True, 3, "embedded_gaussian", "trained"), (15, False, 9, "embedded_gaussian", "rand"),
+                                 (16, True, 3, "embedded_gaussian", "trained"), (31, True, 21, "embedded_gaussian", "trained"),
+                                 (12, True, 130, "gaussian", "trained"), (19, False, 6, "squared", "trained"),
+                                 (7, True, 5, "equal_attention", "trained"), (23, True, 4, "diagonal", "trained")):
+    pol = make_mprl_policy(flavour, 1, L=2, skip=skip, similarity=sim, device=dev)
+    pol.build_action_space(1.0)
+    ts = pol.tree_search()
+    A = ts.num_actions
+    robot, humans = seeded_scenes(900 + H, P, H)
+    acts, _ = orc.mprl_action_space(orc.OracleConfig(), 1.0)
+    cr = orc._children_robot(robot, acts, orc.OracleConfig())
+    got = ts.value_children(cr.to(dev), humans.to(dev)).cpu().numpy()
+    Pm = gio.oracle_params(flavour, 2, similarity=sim)
+    with torch.no_grad():
+        want = orc.value_estimator_forward(cr.reshape(P * A, 1, 9), humans[:, None].expand(P, A, H, 5).reshape(P * A, H, 5),
+                                           Pm.ve_graph, Pm.value_network,
+                                           orc.OracleConfig(num_layer=2, skip_connection=skip, similarity=sim)).numpy().reshape(P, A)
+    err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
+    worst = max(worst, err)
+    assert err < 1e-4, (H, skip, P, sim, err)
+# whole depth-2 searches: action tables of 25 (1 full tile + 9), 96 (6 full tiles, no partial), 97 (6 + 1) and 5 (partial only)
+from relationalgraphlearning_amd.config import policy_config
+import relationalgraphlearning_amd as rga
+for speeds, rots, H in ((3, 8, 19), (5, 19, 5), (6, 16, 19), (1, 4, 9)):
+    cfgp = policy_config("model_predictive_rl", action_space__speed_samples=speeds, action_space__rotation_samples=rots,
+                         model_predictive_rl__planning_depth=2, model_predictive_rl__planning_width=2,
+                         model_predictive_rl__do_action_clip=True)
+    pol = rga.ModelPredictiveRL()
+    pol.time_step = 0.25
+    pol.configure(cfgp)
+    pol.load_state_dict(gio.checkpoint("trained", 2))
+    pol.set_time_step(0.25)
+    pol.set_phase("test")
+    pol.set_device(dev)
+    robot, humans = seeded_scenes(950 + speeds * rots, 11, H)
+    cfg = orc.OracleConfig(speed_samples=speeds, rotation_samples=rots, planning_depth=2, planning_width=2, do_action_clip=True)
+    with torch.no_grad():
+        oa, ov, _, _ = orc.mprl_predict_batched(robot, humans, gio.oracle_params("trained", 2), cfg)
+    a, v = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
+    assert pol.tree_search().num_actions == speeds * rots + 1
+    err = float((v.cpu() - ov).abs().max())
+    assert err < 1e-4, (speeds, rots, H, err)
+# a whole depth-3 search through the fused kernel (packed images once per search) vs the oracle
+pol = make_mprl_policy("trained", D=3, w=2, clip=True, device=dev)
+robot, humans = seeded_scenes(77, 24, 19)
+a, v = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
+cfg = orc.OracleConfig(planning_depth=3, planning_width=2, do_action_clip=True)
+with torch.no_grad():
+    oa, ov, _, _ = orc.mprl_predict_batched(robot, humans, gio.oracle_params("trained"), cfg)
+assert np.array_equal(a.cpu().numpy().astype(np.int64), oa.numpy()), (a, oa)
+assert float((v.cpu() - ov).abs().max()) < 1e-4
+print("OK worst relative error %.2e" % worst)
+'''
+    env = dict(os.environ, RGL_CHILDREN_FUSED="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+    print(out.stdout.strip())
+
+
 @pytest.mark.parametrize("H,L,flavour,skip,P", [(1, 2, "trained", True, 5), (15, 2, "trained", True, 4), (16, 2, "rand", True, 3),
                                                  (31, 1, "trained", True, 3), (49, 3, "trained", True, 2),
                                                  (63, 2, "trained", False, 2), (19, 3, "rand", True, 3), (7, 4, "trained", True, 3)])

@@ -39,7 +39,9 @@ def main():
     lib = nat.lib()
     raw = C.CDLL(nat.LIB_PATH)
     buf = (C.c_ulonglong * 16)()
-    read = raw.rgl_debug_read_deep_phase_cycles if deep else raw.rgl_debug_read_phase_cycles
+    fused = (not deep) and os.environ.get("RGL_CHILDREN_TWO_STAGE", "0") != "1"
+    read = raw.rgl_debug_read_deep_phase_cycles if deep else (raw.rgl_debug_read_fused_phase_cycles if fused
+                                                              else raw.rgl_debug_read_phase_cycles)
     read(buf, 1)
     reps = 3
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -53,11 +55,17 @@ def main():
                                      "embed-2 (S row+col, p, pXh, a/b) / crowd-2 work", "barrier", "row phase work",
                                      "row barrier", "robot-row pass"]
     waves = 8 * P * reps          # per (wave, parent); rank-1 kernel, 8 waves per workgroup
+    if fused:                     # per tile: one wave, 16 children
+        names = ["loop top / value store", "tile loads issued", "embedding (x0, y, g0)", "S row+col, p, pXh, a/b", "row pass",
+                 "robot row", "head", "(unused)"]
+        waves = P * 6 * reps
     tot = sum(buf[i] for i in range(8))
     print("P=%d  %.3f ms per call (stage 1+2)" % (P, e0.elapsed_time(e1) / reps))
     for i, nm in enumerate(names):
         print("  %-18s %9.0f cycles per wave per parent   %5.1f %%" % (nm, buf[i] / waves, 100.0 * buf[i] / tot))
     print("  total              %9.0f" % (tot / waves))
+    if buf[9]:
+        print("  s_memtime / s_memrealtime (100 MHz) over the kernel: %.1f -> counter clock %.0f MHz" % (buf[8] / buf[9], 100.0 * buf[8] / buf[9]))
 
 
 if __name__ == "__main__":
