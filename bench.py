@@ -12,8 +12,16 @@ configs[2]: N=20 agents (19 humans + robot), 2-layer GCN, depth-2 rollout (width
 
 Prints ONE JSON line on rank 0.  `value` counts reference-equivalent ValueEstimator forwards
 (249 per root for D=2,w=2) completed per second over all ranks.  Multi-GPU:
-roots are sharded (fixed roots per GPU -> weak scaling) and each step ends with the one real
-exchange of the path, an RCCL all-gather of the per-shard (action, value) rows.
+roots are sharded and each step ends with the one real exchange of the path, an RCCL all-gather
+of the per-shard (action, value) rows.  Two modes:
+
+    --scaling weak   (default)  --roots R roots PER GPU: per-GPU work fixed as N grows
+    --scaling strong --total-roots T   T roots in total, split contiguously over the ranks
+                     (BASELINE configs[3]: --scaling strong --total-roots 4096 --depth 3;
+                      configs[4]: --scaling strong --total-roots 2048 --humans 49 --layers 3 --contraction f16)
+
+With more than one rank the line also carries `multi_gpu`: the slowest rank's search time per step
+and the exchange time per step, measured separately (un-pipelined) after the timed region.
 """
 import argparse
 import json
@@ -51,7 +59,9 @@ def children_flops_per_scene(N, L, A):
                      + 4 * N * 32 + 5 * N + 12 * H                      # robot row/column of S, robot-row softmax, row scalars
                      + 7 * H * 32 + 2 * 32                              # rank-1 row pass, T_0
                      + 2 * 32 * 32 + 4 * 32)                            # T_0*W1, H1_0, t_c
-        return per_parent / A + per_child + last_layer + head, "rank-1 (children_rank1_kernel + robot_head_kernel)"
+        return (per_parent / A + per_child + last_layer + head,
+                "rank-1 form: crowd_block_kernel + children_fused_kernel (+ robot_head_kernel on the partial tiles' rows) from ~9k "
+                "child tiles per launch, children_rank1_kernel + robot_head_kernel below")
     if L in (2, 3) and N <= 60:
         # shared-crowd deep kernel (rgl_deep.hip): layer 0 in rank-1 form; for L == 3 one dense layer per child whose
         # aggregation is E*O with the crowd-only E shared by the siblings
@@ -75,10 +85,11 @@ def workload_name(N, args):
     key = (N, args.layers, args.depth, args.width)
     if key == (20, 2, 2, 2):
         return "BASELINE configs[2]"
+    share = "" if getattr(args, "scaling", "weak") == "strong" else "per-GPU share, "
     if key == (20, 2, 3, 2):
-        return "BASELINE configs[3] (per-GPU share)"
+        return "BASELINE configs[3]" + (" (per-GPU share)" if share else "")
     if key == (50, 3, 2, 2):
-        return "BASELINE configs[4] (per-GPU share, %s contractions)" % args.contraction
+        return "BASELINE configs[4] (%s%s contractions)" % (share, args.contraction)
     if args.depth == 1 and N in (5, 6):
         return "BASELINE configs[1]"
     return "custom"
@@ -188,7 +199,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--roots", type=int, default=2048, help="root scenes per GPU")
+    ap.add_argument("--roots", type=int, default=2048, help="root scenes per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--total-roots", type=int, default=None,
+                    help="strong scaling: root scenes in total, split contiguously over the ranks (default: --roots)")
     ap.add_argument("--humans", type=int, default=19)
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--depth", type=int, default=2)
@@ -205,6 +219,8 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    if os.environ.get("RGL_BENCH_SINGLE_DEVICE") == "1":      # world-size-1 RCCL smoke on a one-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -214,10 +230,20 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    B, H, N = args.roots, args.humans, args.humans + 1
+    H, N = args.humans, args.humans + 1
+    if args.scaling == "strong":
+        total_roots = args.total_roots if args.total_roots is not None else args.roots
+        lo, hi = rga.shard_bounds(total_roots, world, rank)
+        B = hi - lo                                   # this rank's contiguous share (first ranks take the remainder)
+    else:
+        B, total_roots = args.roots, args.roots * world
     pol = make_policy(args, device)
     ts = pol.tree_search()
-    robot_cpu, humans_cpu = synth_scenes(1000 + rank, B, H)
+    if args.scaling == "strong":                      # every rank slices the SAME global batch
+        robot_all, humans_all = synth_scenes(1000, total_roots, H)
+        robot_cpu, humans_cpu = robot_all[lo:hi].contiguous(), humans_all[lo:hi].contiguous()
+    else:
+        robot_cpu, humans_cpu = synth_scenes(1000 + rank, B, H)
     robot, humans = robot_cpu.to(device), humans_cpu.to(device)
     sharded = rga.ShardedRollout(
         lambda r, h: (lambda o: (o["best_action"], o["best_value"]))(
@@ -230,7 +256,7 @@ def main():
     pending = [None]
 
     def step():
-        nxt = sharded.launch_local(robot, humans, B * world)
+        nxt = sharded.launch_local(robot, humans, total_roots)
         if pending[0] is not None:
             pending[0].wait()                # exchange of the previous step complete (stream-ordered); .result() unpacks
         pending[0] = nxt
@@ -279,8 +305,34 @@ def main():
         elapsed = float(t.item())
 
     per_root = ts.logical_value_evals_per_root()
-    evals_per_step = per_root * B * world
+    evals_per_step = per_root * total_roots
     value = evals_per_step * args.steps / elapsed
+
+    # ---- multi-GPU: search and exchange timed SEPARATELY (no pipelining), slowest rank, a few steps after the timed region
+    multi = None
+    if dist is not None:
+        n_diag = 10
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_diag)]
+        for i in range(n_diag):
+            fence()
+            ev[i][0].record()
+            h = sharded.launch_local(robot, humans, total_roots)      # search enqueued, all-gather queued behind it
+            ev[i][1].record()                                         # end of this rank's search on the compute stream
+            h.wait()                                                  # compute stream waits for the collective
+            ev[i][2].record()
+        fence()
+        srch = sorted(ev[i][0].elapsed_time(ev[i][1]) for i in range(n_diag))[n_diag // 2]
+        exch = sorted(ev[i][1].elapsed_time(ev[i][2]) for i in range(n_diag))[n_diag // 2]
+        t = torch.tensor([srch, exch], dtype=torch.float64, device=device)
+        tmax, tmin = t.clone(), t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        multi = {"search_ms_per_step_slowest_rank": float(tmax[0]), "search_ms_per_step_fastest_rank": float(tmin[0]),
+                 "exchange_ms_per_step_slowest_rank": float(tmax[1]),
+                 "note": "median of %d un-pipelined steps after the timed region; exchange = from the end of the rank's own "
+                         "search to the completion of the all-gather on its stream (includes waiting for slower ranks)" % n_diag,
+                 "roots_per_rank": [rga.shard_bounds(total_roots, world, r)[1] - rga.shard_bounds(total_roots, world, r)[0]
+                                    for r in range(world)] if args.scaling == "strong" else [B] * world}
 
     # ---- roofline of the dominant kernels (value of the sibling children), HIP events on the launch stream.
     # Launched straight through the C ABI (prebuilt descriptor, no Python work between launches) on the inputs
@@ -339,17 +391,18 @@ def main():
     result = {
         "metric": "agent-graph forward evals/sec (N=%d, %d-layer GCN, depth-%d tree)" % (N, args.layers, args.depth),
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
         "step_ms_device": {"p10": step_ms[len(step_ms) // 10], "median": step_ms[len(step_ms) // 2],
                            "p90": step_ms[(len(step_ms) * 9) // 10], "note": "rank 0, HIP events between steps"},
         "vs_baseline": None, "dtype": "f32" if args.contraction == "f32" else "f16 inputs / f32 accumulate (middle-layer "
         "products only; everything else f32)", "data": "synthetic",
         "config": {"workload": "%s: N=%d agents (H=%d humans), %d-layer GCN, depth-%d width-%d "
-                               "action-tree rollout, %d root scenes per GPU" % (workload_name(N, args), N, H, args.layers,
-                                                                                 args.depth, args.width, B),
-                   "roots_per_gpu": B, "logical_value_evals_per_root": per_root, "init_steps": INIT_STEPS,
+                               "action-tree rollout, %s" % (workload_name(N, args), N, H, args.layers, args.depth, args.width,
+                                                            ("%d root scenes per GPU" % B) if args.scaling == "weak" else
+                                                            ("%d root scenes in total over %d GPU(s)" % (total_roots, world))),
+                   "roots_per_gpu": B, "total_roots": total_roots, "logical_value_evals_per_root": per_root, "init_steps": INIT_STEPS,
                    "executed_graph_forwards_per_root": sum(W ** l for l in range(args.depth)) * (A + 1),
-                   "decisions_per_s": B * world * args.steps / elapsed,
+                   "decisions_per_s": total_roots * args.steps / elapsed,
                    "weights": "fixture F1 trained-like (tests/golden/weights_trained.npz)",
                    "exchange": "all_gather_into_tensor of (roots_per_gpu,2) fp32 per rank" if world > 1 else "none"},
         "roofline": {"bound": "mfma", "kernel": "value of sibling children, mprl_value_children_f32: " + kernel_path,
@@ -359,6 +412,8 @@ def main():
                      "launch_ms": kern_ms, "scenes_per_launch": scenes_per_launch,
                      "flop_per_scene": flop_per_scene, "reference_flop_per_eval": {(20, 2): 328120, (50, 3): 1337660, (6, 2): 102300}.get((N, args.layers))},
     }
+    if multi is not None:
+        result["multi_gpu"] = multi
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         result["cpu_baseline"] = cpu_baseline(args, robot_cpu, humans_cpu, args.cpu_seconds)
     elif rank == 0:

@@ -879,5 +879,27 @@ def test_target_model_deepcopy_after_forward(dev):
         assert torch.equal(g2(rot), g0)
 
 
+def test_bench_runs_under_torchrun_over_rccl(dev):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, backend nccl = RCCL), with the one
+    rank a one-GPU box can host: RCCL refuses two ranks on one device ("Duplicate GPU detected"), so the world-size-2 exchange is
+    covered by the gloo test and this executes the RCCL all-gather / barrier / all-reduce path on hardware.  Strong-scaling flags."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RGL_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--scaling", "strong", "--total-roots", "96", "--depth", "3", "--cpu-seconds", "0"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    r = json.loads(lines[0])
+    assert r["scaling"] == "strong" and r["n_gpus"] == 1 and r["config"]["total_roots"] == 96
+    assert r["multi_gpu"]["roots_per_rank"] == [96] and r["multi_gpu"]["exchange_ms_per_step_slowest_rank"] >= 0.0
+    assert r["value"] > 0 and r["roofline"]["frac"] > 0
+
+
 def test_library_reports_target():
     assert nat.lib().rgl_build_target() == b"gfx950"
