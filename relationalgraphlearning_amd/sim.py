@@ -112,7 +112,8 @@ class BatchedCrowdSim(object):
         """Load seeded cases (one environment each).  Returns the fp32 observation (robot (B,9), humans (B,H,5))."""
         scenes = []
         for k in cases:                      # scene generation is sequential host work (seeded rejection sampling): memoise
-            key = (phase, int(k), self.cfg.scenario, self.cfg.human_num, self.cfg.randomize_attributes)
+            key = (phase, int(k), self.cfg.scenario, self.cfg.human_num, self.cfg.randomize_attributes, self.cfg.circle_radius,
+                   self.cfg.square_width)
             if key not in self._scene_cache:
                 self._scene_cache[key] = generate_scene(self.cfg, phase, int(k))
             scenes.append(self._scene_cache[key])

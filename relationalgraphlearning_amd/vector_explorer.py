@@ -147,13 +147,14 @@ class VectorExplorer(object):
         collision_cases, timeout_cases, min_dist = [], [], []
         cumulative_rewards, average_returns = [], []
         discomfort = 0
-        per_episode = {"case": [], "outcome": [], "time": [], "length": []}
+        per_episode = {"case": [], "outcome": [], "time": [], "length": [], "actions": []}
         for lo in range(0, k, self.max_batch):
             chunk = cases[lo:lo + self.max_batch]
             run = self._run_chunk(phase, chunk, keep_states=update_memory)
             if (run["outcome"] == 0).any():
                 raise ValueError('Invalid end signal from environment')
             cum, avg_ret = discounted_statistics(run["rewards"], run["lengths"], step_discount)
+            acts = torch.stack(run["actions"]).cpu().numpy() if run["actions"] else np.zeros((0, len(chunk)), np.int64)
             for b in range(len(chunk)):
                 i = lo + b
                 code = int(run["outcome"][b])
@@ -171,6 +172,7 @@ class VectorExplorer(object):
                 per_episode["outcome"].append(code)
                 per_episode["time"].append(float(run["time"][b]))
                 per_episode["length"].append(int(run["lengths"][b]))
+                per_episode["actions"].append([int(a) for a in acts[:int(run["lengths"][b]), b]])
             danger = run["info"] == 1
             discomfort += int(danger.sum())
             min_dist.extend(run["dmin"][danger].tolist())

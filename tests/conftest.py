@@ -9,3 +9,14 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+
+
+# Lines the parity tests want in the log even when they pass (mismatch counts, measured errors): printed once at the end.
+PARITY_REPORT = []
+
+
+def pytest_terminal_summary(terminalreporter):
+    if PARITY_REPORT:
+        terminalreporter.write_sep("-", "parity report")
+        for line in PARITY_REPORT:
+            terminalreporter.write_line(line)

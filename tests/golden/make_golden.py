@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+HERE_SRC = HERE
 sys.path.insert(0, HERE)
 import ref_loader  # noqa: E402
 
@@ -103,6 +104,12 @@ def make_master(seed, scale):
     master.update(flat("motion_predictor.", sp.human_motion_predictor.state_dict()))
     master.update({"concat_w_a." + k[len("w_a."):]: v.detach().numpy().astype(np.float32)
                    for k, v in gc.state_dict().items() if k.startswith("w_a.")})
+    # a fourth GCN layer for both graphs (round 2: L = 4 exercises the tile kernel's deep mode).  Drawn from its own seed
+    # AFTER everything above, so the arrays of the round-1 fixtures stay bit-identical.
+    torch.manual_seed(seed + 1000)
+    pc4 = policy_config(gcn__num_layer=4)
+    master["graph_model1.Ws.3"] = RGL(pc4, 9, 5).state_dict()["Ws.3"].numpy().astype(np.float32)
+    master["graph_model2.Ws.3"] = RGL(pc4, 9, 5).state_dict()["Ws.3"].numpy().astype(np.float32)
     if scale != 1.0:
         for k in list(master):
             if k.endswith(".w_a") or ".Ws." in k:
@@ -162,6 +169,34 @@ def gen_forward_kats(masters, out):
         for lw in (False, True):
             for sk in (False, True):
                 cases.append(dict(H=5, B=3, L=2, flavour="trained", sim=sim, layerwise=lw, skip=sk))
+    meta = []
+    for ci, c in enumerate(cases):
+        robot, humans = synth_scene(rng, c["B"], c["H"])
+        pc, g1, g2, ve, sp = build_ref_modules(masters[c["flavour"]], c["L"], c["sim"], c["layerwise"], c["skip"])
+        r = torch.tensor(robot).unsqueeze(1)
+        h = torch.tensor(humans)
+        with torch.no_grad():
+            HL = g1((r, h))
+            X = torch.cat([g1.w_r(r), g1.w_h(h)], dim=1)
+            A = g1.compute_similarity_matrix(X)
+            val = ve((r, h))
+            nh = sp((r, h), None)[1]
+        k = "f%02d." % ci
+        out[k + "robot"], out[k + "humans"] = robot, humans
+        out[k + "H_L"], out[k + "A"] = HL.numpy(), A.numpy().astype(np.float32)
+        out[k + "value"], out[k + "humans_next"] = val.numpy(), nh.numpy()
+        meta.append("%d|%d|%d|%s|%s|%d|%d" % (c["H"], c["B"], c["L"], c["flavour"], c["sim"],
+                                              int(c["layerwise"]), int(c["skip"])))
+    out["forward_cases"] = np.array(meta)
+
+
+def gen_forward_kats_l4(masters, out):
+    """Forward KATs with four GCN layers (same arrays per case as gen_forward_kats; own file so the round-1 file is unchanged)."""
+    rng = np.random.RandomState(21)
+    cases = [dict(H=7, B=3, L=4, flavour="trained", sim="embedded_gaussian", layerwise=False, skip=True),
+             dict(H=19, B=2, L=4, flavour="rand", sim="embedded_gaussian", layerwise=False, skip=True),
+             dict(H=5, B=2, L=4, flavour="trained", sim="embedded_gaussian", layerwise=False, skip=False),
+             dict(H=12, B=2, L=4, flavour="trained", sim="gaussian", layerwise=True, skip=True)]
     meta = []
     for ci, c in enumerate(cases):
         robot, humans = synth_scene(rng, c["B"], c["H"])
@@ -620,17 +655,150 @@ def gen_sim_kats(out):
         del JointState.self_state
 
 
+def make_goal_master(base):
+    """A weight set whose value estimator prefers states closer to the goal (so that episodes end in goals and collisions,
+    not only in time-outs): the reference ValueEstimator (trained-like start) regressed for 500 Adam steps onto
+    -0.25 * |position - goal| on seeded random states.  Single-threaded CPU training: reproducible bit for bit here."""
+    # (The regression runs on the repo's functional restatement of the forward, oracle/rgl_oracle.py: the reference's own
+    # RGL.forward adds the skip connection in place, which current torch autograd rejects.  The result is just a weight set;
+    # everything recorded with it below is produced by the reference.)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE_SRC)))
+    from oracle import rgl_oracle as orc
+    torch.manual_seed(7)
+    rng = np.random.RandomState(7)
+    gsd = {k: v.clone().requires_grad_(True) for k, v in graph_sd(base, "graph_model1", 2, "embedded_gaussian").items()}
+    vsd = {k: v.clone().requires_grad_(True) for k, v in sub_sd(base, "value_network").items()}
+    opt = torch.optim.Adam(list(gsd.values()) + list(vsd.values()), lr=2e-3)
+    cfg = orc.OracleConfig()
+    for it in range(500):
+        B = 256
+        robot = np.zeros((B, 9), np.float32)
+        robot[:, 0:2] = rng.uniform(-2.2, 2.2, (B, 2))
+        robot[:, 2:4] = rng.uniform(-1, 1, (B, 2)) * rng.uniform(0, 1, (B, 1))
+        ang = rng.uniform(0, 2 * np.pi, B)
+        robot[:, 4], robot[:, 5], robot[:, 6], robot[:, 7], robot[:, 8] = 0.3, 1.5 * np.cos(ang), 1.5 * np.sin(ang), 1.0, np.pi / 2
+        humans = np.zeros((B, 5, 5), np.float32)
+        humans[:, :, 0:2] = rng.uniform(-2.2, 2.2, (B, 5, 2))
+        humans[:, :, 2:4] = rng.uniform(-1, 1, (B, 5, 2))
+        humans[:, :, 4] = 0.3
+        target = torch.tensor(-0.25 * np.linalg.norm(robot[:, 0:2] - robot[:, 5:7], axis=1).astype(np.float32)).reshape(B, 1)
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(orc.value_estimator_forward(torch.tensor(robot).unsqueeze(1), torch.tensor(humans),
+                                                                        gsd, vsd, cfg), target)
+        loss.backward()
+        opt.step()
+    m = dict(base)
+    m.update(flat("graph_model1.", gsd))
+    m.update(flat("value_network.", vsd))
+    m["goal.final_loss"] = np.array(float(loss.detach()), np.float64)
+    return m
+
+
+def gen_explorer_kats(masters, out):
+    """The reference Explorer (crowd_nav/utils/explorer.py:21-140) driving the reference simulator with its `linear` humans and
+    the reference ModelPredictiveRL robot (trained-like weights, depth 1): statistics, per-episode outcomes, every decision, and
+    the experience tuples it pushes into the reference ReplayMemory.  Same in-memory JointState.self_state alias as gen_sim_kats."""
+    import gym
+    from crowd_sim.envs.utils.robot import Robot
+    from crowd_sim.envs.utils.info import ReachGoal, Collision, Timeout
+    from crowd_nav.utils.explorer import Explorer
+    from crowd_nav.utils.memory import ReplayMemory
+    JointState.self_state = property(lambda self_: self_.robot_state)
+    mod = importlib.import_module("crowd_nav.configs.icra_benchmark.mp_separate")
+    envc = mod.EnvConfig()
+    old_policy, old_central = envc.humans.policy, envc.sim.centralized_planning
+    old_radius, old_limit = envc.sim.circle_radius, envc.env.time_limit
+    envc.humans.policy = "linear"
+    envc.sim.centralized_planning = False
+    # a tight arena and a short clock: the weights are not a trained policy, so on the default 4 m circle every episode times
+    # out; at 1.5 m the same robot also reaches goals and collides, and the replay memory receives tuples
+    envc.sim.circle_radius, envc.env.time_limit = 1.5, 12
+    try:
+        env = gym.make("CrowdSim-v0")
+        env.configure(envc)
+        robot = Robot(envc, "robot")
+        robot.time_step = env.time_step
+        pol = policy_factory["model_predictive_rl"]()
+        pol.configure(policy_config())
+        m = masters["goal"]
+        pol.load_state_dict({"graph_model1": graph_sd(m, "graph_model1", 2, "embedded_gaussian"),
+                             "graph_model2": graph_sd(m, "graph_model2", 2, "embedded_gaussian"),
+                             "value_network": sub_sd(m, "value_network"),
+                             "motion_predictor": sub_sd(m, "motion_predictor")})
+        pol.set_device(torch.device("cpu"))
+        pol.set_time_step(env.time_step)
+        pol.set_epsilon(0.0)
+        ve_fwd = pol.value_estimator.forward
+        pol.value_estimator.forward = lambda state: ve_fwd(state).reshape(())        # scalar-shape shim (header)
+        robot.set_policy(pol)
+        env.set_robot(robot)
+        memory = ReplayMemory(100000)
+        explorer = Explorer(env, robot, torch.device("cpu"), None, memory, 0.9, target_policy=pol)
+        table = [(a.vx, a.vy) for a in pol.action_space] if pol.action_space else None
+        # record every decision and every episode end by wrapping robot.act / env.step (nothing in the reference changes)
+        log = {"actions": [], "ends": []}
+        act0, step0 = robot.act, env.step
+
+        def act(ob):
+            a = act0(ob)
+            tbl = [(x.vx, x.vy) for x in pol.action_space]
+            log["actions"].append(tbl.index((a.vx, a.vy)))
+            return a
+
+        def step(action, update=True):
+            ob, reward, done, info = step0(action, update)
+            if done and update:
+                code = 3 if isinstance(info, ReachGoal) else (2 if isinstance(info, Collision) else 4)
+                log["ends"].append((code, env.global_time, len(log["actions"])))
+            return ob, reward, done, info
+        robot.act, env.step = act, step
+        meta = []
+        with torch.no_grad():
+            for tag, phase, k, upd in (("val6", "val", 6, False), ("test4", "test", 4, False), ("train8", "train", 8, True)):
+                log["actions"], log["ends"] = [], []
+                n_before = len(memory.memory)
+                stats = explorer.run_k_episodes(k, phase, update_memory=upd, episode=3)
+                key = "ex.%s." % tag
+                out[key + "stats"] = np.array(stats, np.float64)
+                out[key + "actions"] = np.array(log["actions"], np.int64)
+                out[key + "outcome"] = np.array([e[0] for e in log["ends"]], np.int64)
+                out[key + "time"] = np.array([e[1] for e in log["ends"]], np.float64)
+                out[key + "steps_end"] = np.array([e[2] for e in log["ends"]], np.int64)     # cumulative decision count
+                if upd:
+                    new = memory.memory[n_before:]
+                    out[key + "n_tuples"] = np.array(len(new), np.int64)
+                    for name, col in (() if not new else (("robot", 0), ("humans", 1), ("value", 2), ("reward", 3), ("next_robot", 4),
+                                      ("next_humans", 5))):
+                        out[key + "mem_" + name] = np.stack([t[col].numpy() for t in new]).astype(np.float32)
+                meta.append("%s|%s|%d|%d" % (tag, phase, k, int(upd)))
+        out["explorer_cases"] = np.array(meta)
+        out["ex.circle_radius"], out["ex.time_limit"] = np.array(1.5), np.array(12.0)
+    finally:
+        envc.humans.policy, envc.sim.centralized_planning = old_policy, old_central
+        envc.sim.circle_radius, envc.env.time_limit = old_radius, old_limit
+        del JointState.self_state
+
+
 def main():
+    global HERE
+    if len(sys.argv) > 1:                       # optional output directory (regeneration checks write to a scratch dir)
+        HERE = os.path.abspath(sys.argv[1])
+        os.makedirs(HERE, exist_ok=True)
     torch.set_num_threads(1)
     masters = {"rand": make_master(1, 1.0), "trained": make_master(2, 1.0 / np.sqrt(32.0))}
     np.savez(os.path.join(HERE, "weights_rand.npz"), **masters["rand"])
     np.savez(os.path.join(HERE, "weights_trained.npz"), **masters["trained"])
+    masters["goal"] = make_goal_master(masters["trained"])
+    np.savez(os.path.join(HERE, "weights_goal.npz"), **masters["goal"])
     scenes = gen_env_scenes()
     np.savez(os.path.join(HERE, "scenes.npz"), **scenes)
     fw = {}
     gen_forward_kats(masters, fw)
     gen_state_predictor_kats(masters, fw)
     np.savez(os.path.join(HERE, "forward.npz"), **fw)
+    fw4 = {}
+    gen_forward_kats_l4(masters, fw4)
+    np.savez(os.path.join(HERE, "forward_l4.npz"), **fw4)
     misc = {}
     gen_action_spaces(misc)
     gen_reward_kats(misc)
@@ -644,6 +812,9 @@ def main():
     sim = {}
     gen_sim_kats(sim)
     np.savez(os.path.join(HERE, "sim.npz"), **sim)
+    ex = {}
+    gen_explorer_kats(masters, ex)
+    np.savez(os.path.join(HERE, "explorer.npz"), **ex)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-24s %8.1f KB" % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))

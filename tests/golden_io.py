@@ -65,12 +65,14 @@ def oracle_params(flavour, L=2, variant="separate", similarity="embedded_gaussia
 
 
 def forward_cases():
-    fw = load("forward")
+    """Forward KATs: file "forward" (round 1: L <= 3) and "forward_l4" (four GCN layers)."""
     out = []
-    for ci, line in enumerate(fw["forward_cases"]):
-        H, B, L, flavour, sim, lw, sk = str(line).split("|")
-        out.append(dict(idx=ci, H=int(H), B=int(B), L=int(L), flavour=flavour, sim=sim,
-                        layerwise=bool(int(lw)), skip=bool(int(sk))))
+    for name in ("forward", "forward_l4"):
+        fw = load(name)
+        for ci, line in enumerate(fw["forward_cases"]):
+            H, B, L, flavour, sim, lw, sk = str(line).split("|")
+            out.append(dict(file=name, idx=ci, H=int(H), B=int(B), L=int(L), flavour=flavour, sim=sim,
+                            layerwise=bool(int(lw)), skip=bool(int(sk))))
     return out
 
 

@@ -35,6 +35,36 @@ def close(a, b, tol=TOL):
     return err
 
 
+def report(line):
+    from tests.conftest import PARITY_REPORT
+    PARITY_REPORT.append(line)
+
+
+def check_decisions(tag, act, val, oracle_out, levels, tol=TOL):
+    """Decisions against the oracle.  A different root action is accepted only when it is a numerical tie IN THE ORACLE: the
+    action the GPU chose must be one the oracle kept at the root with an oracle root value within `tol` of the oracle's best,
+    or -- when the root clipping itself kept a different set -- its oracle one-step value must be within `tol` of the
+    weakest kept one AND the GPU's value for it within `tol` of the oracle's best.  Returns (and logs) the mismatch count."""
+    oa, ov, orv, okept = [x.numpy() if hasattr(x, "numpy") else np.asarray(x) for x in oracle_out]
+    act = act.cpu().numpy().astype(np.int64)
+    val = val.cpu().numpy().astype(np.float64)
+    mism = np.nonzero(act != oa)[0]
+    value1 = levels[0]["value1"].numpy() if levels is not None else None
+    for b in mism:
+        scale = max(1.0, abs(float(ov[b])))
+        slot = np.nonzero(okept[b] == act[b])[0]
+        if slot.size:
+            assert orv[b, slot[0]] >= ov[b] - tol * scale, (tag, int(b), "not a tie in the oracle", float(orv[b, slot[0]]), float(ov[b]))
+        else:
+            assert value1 is not None, (tag, int(b), "GPU action outside the oracle's kept set")
+            weakest = value1[b, okept[b]].min()
+            assert value1[b, act[b]] >= weakest - tol * scale, (tag, int(b), "clipping is not a tie in the oracle")
+            assert abs(val[b] - ov[b]) <= tol * scale, (tag, int(b))
+    report("%s: %d of %d decisions differ from the oracle (all verified as ties in the oracle, tol %.0e); max |dV| = %.2e"
+           % (tag, mism.size, act.size, tol, float(np.abs(val - ov).max())))
+    return mism.size
+
+
 def build_modules(c, dev):
     cfg = policy_config(gcn__num_layer=c["L"], gcn__similarity_function=c["sim"],
                         gcn__layerwise_graph=c["layerwise"], gcn__skip_connection=c["skip"])
@@ -53,7 +83,7 @@ def build_modules(c, dev):
 @pytest.mark.parametrize("c", gio.forward_cases(), ids=lambda c: "f%02d-%s-H%d-L%d-lw%d-sk%d" % (
     c["idx"], c["sim"], c["H"], c["L"], c["layerwise"], c["skip"]))
 def test_forward_kats(c, dev):
-    fw = gio.load("forward")
+    fw = gio.load(c["file"])
     k = "f%02d." % c["idx"]
     g1, ve, sp = build_modules(c, dev)
     robot = torch.tensor(fw[k + "robot"]).unsqueeze(1).to(dev)
@@ -223,6 +253,10 @@ def test_value_children_mfma_path_vs_general_kernel(H, L, flavour, skip, P, dev)
                                            Pm.ve_graph, Pm.value_network, cfg)
     close(general.cpu().numpy().reshape(P, A), want.numpy().reshape(P, A))
     close(got.numpy(), want.numpy().reshape(P, A))
+    if flavour == "rand":     # the tolerance is relative to max |V| for these weights: log what that is in absolute terms
+        report("value of children, raw random-init weights H=%d L=%d: max |dV| = %.2e absolute at max |V| = %.1f (north star: 1e-4 "
+               "absolute on trained-scale values)" % (H, L, float(np.abs(got.numpy() - want.numpy().reshape(P, A)).max()),
+                                                      float(want.abs().max())))
 
 
 def test_tile_kernel_variant_forced(dev):
@@ -346,8 +380,6 @@ print("OK worst relative error %.2e" % worst)
                                                  (63, 2, "trained", False, 2), (19, 3, "rand", True, 3), (7, 4, "trained", True, 3)])
 def test_state_predictor_mfma_path_vs_oracle(H, L, flavour, skip, P, dev):
     """mprl_expand_f32's predicted humans (row-MLP embeddings + scene_graph_kernel with the motion head fused)."""
-    if L > 3:
-        pytest.skip("fixtures hold three GCN layers")
     pol = make_mprl_policy(flavour, 1, L=L, skip=skip, device=dev)
     pol.build_action_space(1.0)
     robot, humans = seeded_scenes(500 + H + L, P, H)
@@ -386,16 +418,12 @@ def test_tree_vs_batched_oracle(H, D, w, clip, B, L, dev):
     pol = make_mprl_policy("trained", D, w, clip, L=L, device=dev)
     cfg = orc.OracleConfig(num_layer=L, planning_depth=D, planning_width=w, do_action_clip=clip)
     with torch.no_grad():
-        oa, ov, orv, okept = orc.mprl_predict_batched(robot, humans, gio.oracle_params("trained", L), cfg)
+        oa, ov, orv, okept, lv = orc.mprl_predict_batched(robot, humans, gio.oracle_params("trained", L), cfg, return_levels=True)
     act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
     out = pol.tree_search().last
     close(val.cpu().numpy(), ov.numpy())
     close(out["root_values"].cpu().numpy(), orv.numpy())
-    same = act.cpu().numpy().astype(np.int64) == oa.numpy()
-    # a different argmax is only acceptable on a numerical tie of the two candidates
-    for b in np.nonzero(~same)[0]:
-        assert abs(float(val[b]) - float(ov[b])) < 1e-5
-    assert same.mean() > 0.95
+    check_decisions("tree vs batched oracle H=%d D=%d w=%d B=%d" % (H, D, w, B), act, val, (oa, ov, orv, okept), lv)
 
 
 @pytest.mark.parametrize("sim", ["gaussian", "squared", "equal_attention", "diagonal"])
@@ -419,15 +447,13 @@ def test_other_similarities_on_the_mfma_path(sim, H, L, D, B, dev):
         want = orc.value_estimator_forward(cr.reshape(B * A, 1, 9), humans[:, None].expand(B, A, H, 5).reshape(B * A, H, 5),
                                            Pm.ve_graph, Pm.value_network, cfg).numpy().reshape(B, A)
         hn = orc.state_predictor_humans(robot[:, None], humans, Pm.sp_graph, Pm.motion_predictor, cfg)
-        oa, ov, orv, okept = orc.mprl_predict_batched(robot, humans, Pm, cfg)
+        oa, ov, orv, okept, lv = orc.mprl_predict_batched(robot, humans, Pm, cfg, return_levels=True)
     close(got, want)
     ex = ts.expand(robot.to(dev), humans.to(dev), parents_are_joint_states=True)
     close(ex["humans_next"].cpu().numpy(), hn.numpy())
     act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
     close(val.cpu().numpy(), ov.numpy())
-    same = act.cpu().numpy().astype(np.int64) == oa.numpy()
-    for b in np.nonzero(~same)[0]:
-        assert abs(float(val[b]) - float(ov[b])) < 1e-5
+    check_decisions("similarity %s H=%d L=%d D=%d" % (sim, H, L, D), act, val, (oa, ov, orv, okept), lv)
 
 
 @pytest.mark.parametrize("speeds,rots,H,L", [(3, 8, 19, 2), (5, 19, 5, 2), (6, 16, 19, 2), (2, 4, 49, 3), (1, 1, 7, 2),
@@ -450,7 +476,7 @@ def test_non_default_action_spaces(speeds, rots, H, L, dev):
     cfg = orc.OracleConfig(num_layer=L, speed_samples=speeds, rotation_samples=rots, planning_depth=2, planning_width=2,
                            do_action_clip=True)
     with torch.no_grad():
-        oa, ov, orv, okept = orc.mprl_predict_batched(robot, humans, gio.oracle_params("trained", L), cfg)
+        oa, ov, orv, okept, lv = orc.mprl_predict_batched(robot, humans, gio.oracle_params("trained", L), cfg, return_levels=True)
     act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
     assert pol.tree_search().num_actions == speeds * rots + 1
     close(val.cpu().numpy(), ov.numpy())
@@ -466,9 +492,7 @@ def test_non_default_action_spaces(speeds, rots, H, L, dev):
         big.set_device(dev)
         with pytest.raises(nat.NativeLibraryError):
             big.predict_batch(robot.to(dev), humans.to(dev))
-    same = act.cpu().numpy().astype(np.int64) == oa.numpy()
-    for b in np.nonzero(~same)[0]:
-        assert abs(float(val[b]) - float(ov[b])) < 1e-5
+    check_decisions("action table %dx%d+1, H=%d" % (speeds, rots, H), act, val, (oa, ov, orv, okept), lv)
 
 
 F16_TOL = 1e-3      # BASELINE configs[4]: f16-input MFMA for the dense middle-layer products, f32 accumulate (measured ~1e-5)
@@ -620,6 +644,8 @@ def test_properties_at_full_size(dev):
 
 
 @pytest.mark.parametrize("tag,H,L,D,B,contraction,tol", [
+    ("configs[1] in full (N=5)", 4, 2, 1, 512, "f32", TOL),
+    ("configs[1] in full (N=6)", 5, 2, 1, 512, "f32", TOL),
     ("configs[2] in full", 19, 2, 2, 2048, "f32", TOL),
     ("configs[3] per-GPU share", 19, 2, 3, 512, "f32", TOL),
     ("configs[4] per-GPU share (256 roots), first 96", 49, 3, 2, 96, "f32", TOL),
@@ -637,19 +663,18 @@ def test_baseline_workloads_against_the_oracle_at_size(tag, H, L, D, B, contract
     pol = bench.make_policy(Args, dev)
     robot, humans = bench.synth_scenes(1000, B, H)
     act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
-    cfg = orc.OracleConfig(num_layer=L, planning_depth=D, planning_width=2, do_action_clip=True)
-    oa, ov = [], []
+    cfg = orc.OracleConfig(num_layer=L, planning_depth=D, planning_width=2, do_action_clip=(D > 1))
+    outs, v1 = [], []
     with torch.no_grad():
         for lo in range(0, B, 256):
-            a, v, _, _ = orc.mprl_predict_batched(robot[lo:lo + 256], humans[lo:lo + 256], gio.oracle_params("trained", L), cfg)
-            oa.append(a)
-            ov.append(v)
-    oa, ov = torch.cat(oa).numpy(), torch.cat(ov).numpy()
-    close(val.cpu().numpy(), ov, tol=tol)
-    same = act.cpu().numpy().astype(np.int64) == oa
-    for b in np.nonzero(~same)[0]:
-        assert abs(float(val[b]) - float(ov[b])) < 10 * tol
-    assert same.mean() > 0.97
+            o = orc.mprl_predict_batched(robot[lo:lo + 256], humans[lo:lo + 256], gio.oracle_params("trained", L), cfg,
+                                         return_levels=True)
+            outs.append(o[:4])
+            v1.append(o[4][0]["value1"])
+    oracle_out = [torch.cat([o[i] for o in outs]) for i in range(4)]
+    err = close(val.cpu().numpy(), oracle_out[1].numpy(), tol=tol)
+    check_decisions("at size, %s" % tag, act, val, oracle_out, [{"value1": torch.cat(v1)}], tol)
+    report("at size, %s: max |dV| = %.2e absolute (max |V| = %.3f)" % (tag, err, float(oracle_out[1].abs().max())))
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ def close(a, b, tol):
 @pytest.mark.parametrize("c", gio.forward_cases(), ids=lambda c: "f%02d-%s-H%d-L%d-lw%d-sk%d" % (
     c["idx"], c["sim"], c["H"], c["L"], c["layerwise"], c["skip"]))
 def test_forward_kats(c):
-    fw = gio.load("forward")
+    fw = gio.load(c["file"])
     k = "f%02d." % c["idx"]
     m = gio.master(c["flavour"])
     cfg = cfg_of(c)

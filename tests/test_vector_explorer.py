@@ -160,3 +160,47 @@ def test_experience_tuples(which, dev):
             assert abs(float(value) - run["cumulative_reward"][first]) < 1e-5
     with pytest.raises(ValueError):
         VectorExplorer(BatchedCrowdSim(dev), pol, gamma=None).update_memory([], [], [])
+
+
+@pytest.mark.gpu
+def test_against_the_reference_explorer_fixture(dev):
+    """Fixture tests/golden/explorer.npz: the REFERENCE Explorer.run_k_episodes (crowd_nav/utils/explorer.py:21-140) driving the
+    reference CrowdSim (linear humans, 1.5 m circle, 12 s limit) with the reference ModelPredictiveRL robot (weights_goal.npz,
+    depth 1): six validation, four test and eight training episodes.  The vectorised explorer + batched simulator + HIP policy
+    must reproduce every decision, every outcome and end time, the five statistics, and the experience tuples the reference
+    pushed into its ReplayMemory (order included)."""
+    from relationalgraphlearning_amd.sim import BatchedCrowdSim, SimConfig
+    from tests import golden_io as gio
+    from tests.helpers import make_mprl_policy
+    fx = gio.load("explorer")
+    pol = make_mprl_policy("goal", 1, device=dev)
+    pol.set_epsilon(0.0)
+    cfg = SimConfig(circle_radius=float(fx["ex.circle_radius"]), time_limit=float(fx["ex.time_limit"]))
+    mem = ReplayMemory(100000)
+    ex = VectorExplorer(BatchedCrowdSim(dev, cfg), pol, memory=mem, gamma=0.9, target_policy=pol)
+    for line in fx["explorer_cases"]:
+        tag, phase, k, upd = str(line).split("|")
+        k, upd, key = int(k), bool(int(upd)), "ex.%s." % tag
+        n_before = len(mem)
+        stats = ex.run_k_episodes(k, phase, update_memory=upd, episode=3)
+        run = ex.last_run
+        ends = fx[key + "steps_end"]
+        want_actions = np.split(fx[key + "actions"], ends[:-1])
+        for i in range(k):
+            assert run["actions"][i] == [int(a) for a in want_actions[i]], (tag, i)
+        assert run["outcome"] == [int(o) for o in fx[key + "outcome"]]
+        finished = np.array(run["outcome"]) != 4                         # the reference reports global_time, also at a time-out
+        assert np.allclose(np.array(run["time"])[finished], fx[key + "time"][finished], rtol=0, atol=1e-12)
+        want = fx[key + "stats"]
+        assert stats[0] == want[0] and stats[1] == want[1]
+        assert abs(stats[2] - want[2]) < 1e-9 and abs(stats[3] - want[3]) < 1e-6 and abs(stats[4] - want[4]) < 1e-6, (stats, want)
+        if upd:
+            assert len(mem) - n_before == int(fx[key + "n_tuples"])
+            for j in range(int(fx[key + "n_tuples"])):
+                robot, humans, value, reward, nrobot, nhumans = mem[n_before + j]
+                assert np.allclose(robot.cpu().numpy(), fx[key + "mem_robot"][j], rtol=0, atol=1e-6)
+                assert np.allclose(humans.cpu().numpy(), fx[key + "mem_humans"][j], rtol=0, atol=1e-6)
+                assert np.allclose(nrobot.cpu().numpy(), fx[key + "mem_next_robot"][j], rtol=0, atol=1e-6)
+                assert np.allclose(nhumans.cpu().numpy(), fx[key + "mem_next_humans"][j], rtol=0, atol=1e-6)
+                assert abs(float(value) - float(fx[key + "mem_value"][j])) < 1e-6
+                assert abs(float(reward) - float(fx[key + "mem_reward"][j])) < 1e-6
