@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RGL_ABI_VERSION 1
+#define RGL_ABI_VERSION 2
 
 #define RGL_MAX_MLP_LAYERS 6
 #define RGL_MAX_GCN_LAYERS 8
@@ -172,6 +172,11 @@ typedef struct GcnPlanner {
     double time_step;
     double gamma;               /* raw gamma; discount is gamma^(time_step * v_pref)            */
     const double* actions;      /* device [A][2]                                                */
+    /* optional (NULL = absent): the float64 states robot[B][9] / humans[B][H][5] that the fp32 arrays passed to
+     * gcn_predict_f32 were rounded from.  When set, propagate / compute_reward start from them -- the reference
+     * works on the simulator's python floats (cadrl.py:113-138, multi_human_rl.py:73-96) and rounds once, at to_tensor. */
+    const double* root_robot_f64;
+    const double* root_humans_f64;
 } GcnPlanner;
 
 size_t gcn_predict_workspace_bytes(int B, int H, int A);
@@ -202,6 +207,12 @@ typedef struct MprlPlanner {
     double gamma_bar;           /* gamma^(time_step * v_pref), get_normalized_gamma (:104-105)  */
     const double* actions;      /* device [A][2] float64, table of build_action_space (:155-190)*/
     const int* action_groups;   /* device [A], action_group_index (sparse search); may be NULL  */
+    /* optional (NULL = absent): the float64 JointStates robot[B][9] / humans[B][H][5] that the fp32 ROOT arrays were
+     * rounded from.  When set and the roots are joint states, estimate_reward of the ROOT level reads them: the reference
+     * evaluates it on the simulator's python floats (model_predictive_rl.py:226,304-357) while the networks see the
+     * fp32 tensors.  Deeper levels are tensor-born in the reference too. */
+    const double* root_robot_f64;
+    const double* root_humans_f64;
 } MprlPlanner;
 
 /* One tree level for P parent states (the unit `action_clip` evaluates, :242-269):

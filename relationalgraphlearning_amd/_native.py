@@ -15,7 +15,7 @@ MAX_NODES = 64
 MAX_XDIM = 64
 MAX_WIDTH = 256
 MAX_ACTIONS = 256
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 SIMILARITY = {"embedded_gaussian": 0, "gaussian": 1, "cosine": 2, "cosine_softmax": 3, "concatenation": 4,
               "squared": 5, "equal_attention": 6, "diagonal": 7}
@@ -44,7 +44,8 @@ class RglGraph(C.Structure):
 
 class GcnPlanner(C.Structure):
     _fields_ = [("graph", RglGraph), ("value_head", RglMlp), ("kinematics", C.c_int), ("num_actions", C.c_int),
-                ("time_step", C.c_double), ("gamma", C.c_double), ("actions", C.c_void_p)]
+                ("time_step", C.c_double), ("gamma", C.c_double), ("actions", C.c_void_p),
+                ("root_robot_f64", C.c_void_p), ("root_humans_f64", C.c_void_p)]
 
 
 class MprlPlanner(C.Structure):
@@ -53,7 +54,7 @@ class MprlPlanner(C.Structure):
                 ("num_actions", C.c_int), ("planning_depth", C.c_int), ("planning_width", C.c_int),
                 ("do_action_clip", C.c_int), ("sparse_search", C.c_int), ("contraction_dtype", C.c_int),
                 ("time_step", C.c_double), ("gamma_bar", C.c_double), ("actions", C.c_void_p),
-                ("action_groups", C.c_void_p)]
+                ("action_groups", C.c_void_p), ("root_robot_f64", C.c_void_p), ("root_humans_f64", C.c_void_p)]
 
 
 class CrowdSimConfig(C.Structure):

@@ -29,11 +29,15 @@ class GraphFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, robot, humans, *params):
         from .nets import graph_forward
+        if robot.requires_grad or humans.requires_grad:
+            raise NotImplementedError("gradients with respect to the agent states are not provided by the HIP path "
+                                      "(the states of a replay batch are data): detach the inputs")
         out = graph_forward(spec.graph(), spec.value_head(), spec.motion_head(), robot, humans,
                             want_H=spec.want_H, want_A=spec.want_A)
         ctx.spec = spec
         ctx.save_for_backward(robot, humans)
         ctx.n_params = len(params)
+        ctx.param_versions = [(p.data_ptr(), p._version) for p in params]
         ctx.keys = [k for k in ("H", "value", "humans_next", "A") if k in out]
         for k in ("A",):
             if k in out:
@@ -44,6 +48,11 @@ class GraphFunction(torch.autograd.Function):
     def backward(ctx, *grads):
         spec = ctx.spec
         robot, humans = ctx.saved_tensors
+        # the backward kernel recomputes the forward from the CURRENT parameters: refuse if they changed since forward
+        # (torch raises for the same situation on its own saved tensors)
+        if [(p.data_ptr(), p._version) for p in spec.params] != ctx.param_versions:
+            raise RuntimeError("a parameter of the graph model was modified in place between forward and backward "
+                               "(e.g. an optimizer step before loss.backward()): gradients would belong to other weights")
         g = dict(zip(ctx.keys, grads))
         S, H = robot.shape[0], humans.shape[1]
         graph, vh, mh = spec.graph(), spec.value_head(), spec.motion_head()

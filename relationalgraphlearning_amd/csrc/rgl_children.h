@@ -16,6 +16,8 @@ struct ChildrenArgs {
     int joint;                 // 1: position differences in float64 (JointState roots), 0: rounded to fp32 first
     float* child_robot;        // [P][A][9]
     float* reward;             // [P][A]
+    const double* robot64;     // null, or the float64 states robot / humans were rounded from (joint roots): the reward reads these
+    const double* humans64;
 };
 
 __device__ __forceinline__ double seg_point_dist_origin(double px, double py, double ex, double ey, bool f32_degenerate,
@@ -45,6 +47,9 @@ __device__ __forceinline__ void children_thread(const ChildrenArgs& ca, long lon
     const int p = (int)(idx / A), a = (int)(idx - (long long)p * A);
     const float* r = robot + (size_t)p * 9;
     const float* hs = humans + (size_t)(p / humans_per) * H * 5;
+    const double* r64 = ca.robot64 ? ca.robot64 + (size_t)p * 9 : nullptr;          // float64 roots (humans_per == 1 there)
+    const double* hs64 = ca.humans64 ? ca.humans64 + (size_t)p * H * 5 : nullptr;
+    auto R = [&](int i) { return r64 ? r64[i] : (double)r[i]; };
     const double a0 = actions[2 * a], a1 = actions[2 * a + 1];
     float c[9];
 #pragma unroll
@@ -57,8 +62,8 @@ __device__ __forceinline__ void children_thread(const ChildrenArgs& ca, long lon
         c[3] = (float)a1;
         avx = a0;
         avy = a1;
-        nx = (double)r[0] + a0 * dt;
-        ny = (double)r[1] + a1 * dt;
+        nx = R(0) + a0 * dt;
+        ny = R(1) + a1 * dt;
     } else {
         // the reference rotates slot 7 (v_pref), not slot 8 (theta): kept (state_predictor.py:53-58)
         const float th7 = __fadd_rn(r[7], (float)a1);
@@ -69,12 +74,12 @@ __device__ __forceinline__ void children_thread(const ChildrenArgs& ca, long lon
         c[2] = (float)((double)cs * a0);
         c[3] = (float)((double)sn * a0);
         // estimate_reward uses theta (slot 8) for the relative velocity and the goal test
-        const double th = a1 + (double)r[8];
+        const double th = a1 + R(8);
         avx = a0 * cos(th);
         avy = a0 * sin(th);
-        const double th2 = (double)r[8] + a1;
-        nx = (double)r[0] + cos(th2) * a0 * dt;
-        ny = (double)r[1] + sin(th2) * a0 * dt;
+        const double th2 = R(8) + a1;
+        nx = R(0) + cos(th2) * a0 * dt;
+        ny = R(1) + sin(th2) * a0 * dt;
     }
     float* co = child_robot + (size_t)idx * 9;
 #pragma unroll
@@ -84,34 +89,36 @@ __device__ __forceinline__ void children_thread(const ChildrenArgs& ca, long lon
     double dmin = INFINITY;
     for (int h = 0; h < H; ++h) {
         const float* hu = hs + h * 5;
+        const double* hu64 = hs64 ? hs64 + h * 5 : nullptr;
+        auto HU = [&](int i) { return hu64 ? hu64[i] : (double)hu[i]; };
         double px, py;
         float fpx = 0.f, fpy = 0.f;
         if (joint) {
-            px = (double)hu[0] - (double)r[0];
-            py = (double)hu[1] - (double)r[1];
+            px = HU(0) - R(0);
+            py = HU(1) - R(1);
         } else {
             fpx = __fsub_rn(hu[0], r[0]);
             fpy = __fsub_rn(hu[1], r[1]);
             px = (double)fpx;
             py = (double)fpy;
         }
-        const double vx = (double)hu[2] - avx, vy = (double)hu[3] - avy;
+        const double vx = HU(2) - avx, vy = HU(3) - avy;
         const double ex = px + vx * dt, ey = py + vy * dt;
         // Exact shortcut: the outcome depends on this human only if its clearance d is < 0.2 (collision, or the minimum
         // when that is below the discomfort distance).  dist(origin, segment) >= |p| - |e - p|, so with
         // T = radii + 0.25 the test |p|^2 >= 2 (|e - p|^2 + T^2)  (=> |p| >= |e - p| + T) proves d >= 0.25 without the
         // float64 division and square root of the general case; the 0.05 margin dwarfs every rounding involved.
         {
-            const double T = (double)hu[4] + (double)r[4] + 0.25;
+            const double T = HU(4) + R(4) + 0.25;
             const double sx = ex - px, sy = ey - py;
             if (px * px + py * py >= 2.0 * (sx * sx + sy * sy + T * T)) continue;
         }
-        const double d = seg_point_dist_origin(px, py, ex, ey, !joint, fpx, fpy) - (double)hu[4] - (double)r[4];
+        const double d = seg_point_dist_origin(px, py, ex, ey, !joint, fpx, fpy) - HU(4) - R(4);
         if (d < 0.0) collision = true;
         if (d < dmin) dmin = d;
     }
-    const double gx = nx - (double)r[5], gy = ny - (double)r[6];
-    const bool reaching = sqrt(gx * gx + gy * gy) < (double)r[4];
+    const double gx = nx - R(5), gy = ny - R(6);
+    const bool reaching = sqrt(gx * gx + gy * gy) < R(4);
     double rew;
     if (collision) rew = -0.25;
     else if (reaching) rew = 1.0;

@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void mprl_select_kernel(const float* __restric
             for (int k = 0; k < 4; ++k)
                 if (lane + 64 * k == bi) avail[k] = false;
             if (sparse) {
-                const int gi = groups[bi];
+                const int gi = groups[bi] & 63;         // ids are validated to [0, 64) by the host wrapper (TreeSearch); masked so
+                                                        // that a stray id through the raw ABI cannot shift out of range
                 if (seen_groups & (1ull << gi)) continue;
                 seen_groups |= 1ull << gi;
             }
@@ -116,6 +117,9 @@ __global__ __launch_bounds__(256) void mprl_select_kernel(const float* __restric
         if (lane == 0)
             for (int k = nkept; k < W; ++k) { kp[k] = bi_fallback(kl, k); kl[k] = kp[k]; }   // unreachable for validated inputs
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // lane 0's kl[] writes are ordered before the wave's reads below
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (next_robot) {
         for (int idx = lane; idx < W * 9; idx += 64) {      // same wave wrote kl: LDS operations of a wave execute in order
             const int k = idx / 9, i = idx - k * 9;
@@ -244,6 +248,7 @@ __global__ void gcn_rotate_kernel(const float* __restrict__ in14, float* __restr
 
 // One thread per (scene, action, human): propagate, rotate; thread h == 0 also does compute_reward.
 __global__ void gcn_prepare_kernel(const float* __restrict__ robot, const float* __restrict__ humans,
+                                   const double* __restrict__ robot64, const double* __restrict__ humans64,
                                    const double* __restrict__ actions, int B, int H, int A, int kinematics, double dt,
                                    float* __restrict__ self6, float* __restrict__ hum7, float* __restrict__ reward) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -252,33 +257,37 @@ __global__ void gcn_prepare_kernel(const float* __restrict__ robot, const float*
     const long long sa = idx / H;
     const int a = (int)(sa % A), b = (int)(sa / A);
     const float* r = robot + (size_t)b * 9;
+    const double* r64 = robot64 ? robot64 + (size_t)b * 9 : nullptr;        // the float64 state the fp32 row was rounded from
+    auto R = [&](int i) { return r64 ? r64[i] : (double)r[i]; };
     const double a0 = actions[2 * a], a1 = actions[2 * a + 1];
     // CADRL.propagate in float64, as python floats
     double nr[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) nr[i] = (double)r[i];
+    for (int i = 0; i < 9; ++i) nr[i] = R(i);
     if (kinematics == RGL_HOLONOMIC) {
-        nr[0] = (double)r[0] + a0 * dt;
-        nr[1] = (double)r[1] + a1 * dt;
+        nr[0] = R(0) + a0 * dt;
+        nr[1] = R(1) + a1 * dt;
         nr[2] = a0;
         nr[3] = a1;
     } else {
-        const double th = (double)r[8] + a1;
+        const double th = R(8) + a1;
         nr[2] = a0 * cos(th);
         nr[3] = a0 * sin(th);
-        nr[0] = (double)r[0] + nr[2] * dt;
-        nr[1] = (double)r[1] + nr[3] * dt;
+        nr[0] = R(0) + nr[2] * dt;
+        nr[1] = R(1) + nr[3] * dt;
         nr[8] = th;
     }
     const float* hu = humans + ((size_t)b * H + h) * 5;
+    const double* hb64 = humans64 ? humans64 + (size_t)b * H * 5 : nullptr;
+    auto HB = [&](int j, int i) { return hb64 ? hb64[j * 5 + i] : (double)humans[((size_t)b * H + j) * 5 + i]; };
     float s[14], o[13];
 #pragma unroll
     for (int i = 0; i < 9; ++i) s[i] = (float)nr[i];
-    s[9] = (float)((double)hu[0] + (double)hu[2] * dt);
-    s[10] = (float)((double)hu[1] + (double)hu[3] * dt);
-    s[11] = hu[2];
-    s[12] = hu[3];
-    s[13] = hu[4];
+    s[9] = (float)(HB(h, 0) + HB(h, 2) * dt);
+    s[10] = (float)(HB(h, 1) + HB(h, 3) * dt);
+    s[11] = hb64 ? (float)HB(h, 2) : hu[2];
+    s[12] = hb64 ? (float)HB(h, 3) : hu[3];
+    s[13] = hb64 ? (float)HB(h, 4) : hu[4];
     rotate_row(s, kinematics == RGL_UNICYCLE, o);
     float* h7 = hum7 + ((size_t)sa * H + h) * 7;
 #pragma unroll
@@ -290,12 +299,11 @@ __global__ void gcn_prepare_kernel(const float* __restrict__ robot, const float*
         // compute_reward (multi_human_rl.py:73-96): END-point distances, float64
         bool collision = false;
         double dmin = INFINITY;
-        const float* hb = humans + (size_t)b * H * 5;
         for (int j = 0; j < H; ++j) {
-            const double hx = (double)hb[j * 5] + (double)hb[j * 5 + 2] * dt;
-            const double hy = (double)hb[j * 5 + 1] + (double)hb[j * 5 + 3] * dt;
+            const double hx = HB(j, 0) + HB(j, 2) * dt;
+            const double hy = HB(j, 1) + HB(j, 3) * dt;
             const double ddx = nr[0] - hx, ddy = nr[1] - hy;
-            const double d = sqrt(ddx * ddx + ddy * ddy) - nr[4] - (double)hb[j * 5 + 4];
+            const double d = sqrt(ddx * ddx + ddy * ddy) - nr[4] - HB(j, 4);
             if (d < 0.0) collision = true;
             if (d < dmin) dmin = d;
         }
@@ -403,6 +411,9 @@ int expand_level(const MprlPlanner& pl, const float* robot, const float* humans,
     ca.robot = robot; ca.humans = humans; ca.humans_per = humans_per; ca.actions = pl.actions;
     ca.P = P; ca.H = H; ca.A = A; ca.kinematics = pl.kinematics; ca.dt = pl.time_step; ca.joint = joint;
     ca.child_robot = child_robot; ca.reward = reward;
+    const bool roots64 = joint && humans_per == 1 && pl.root_robot_f64 && pl.root_humans_f64;
+    ca.robot64 = roots64 ? pl.root_robot_f64 : nullptr;
+    ca.humans64 = roots64 ? pl.root_humans_f64 : nullptr;
     int children_done = 0;              // set when the state predictor's scene kernel ran them on its extra workgroups
     if (pl.linear_state_predictor) {
         if (humans_per == 1) {
@@ -612,7 +623,9 @@ extern "C" int gcn_predict_f32(const GcnPlanner* planner, const float* robot, co
     float* reward = (float*)ws;             ws += align_up(S * 4);
     float* value = (float*)ws;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gcn_prepare_kernel, grid_for(S * H), dim3(kBlock), 0, st, robot, humans, pl.actions, B, H, A,
+    hipLaunchKernelGGL(gcn_prepare_kernel, grid_for(S * H), dim3(kBlock), 0, st, robot, humans,
+                       pl.root_robot_f64 && pl.root_humans_f64 ? pl.root_robot_f64 : nullptr,
+                       pl.root_robot_f64 && pl.root_humans_f64 ? pl.root_humans_f64 : nullptr, pl.actions, B, H, A,
                        pl.kinematics, pl.time_step, self6, hum7, reward);
     RGL_LAUNCH_CHECK();
     rc = rgl::launch_generic_forward(&pl.graph, &pl.value_head, nullptr, self6, hum7, (int)S, 1, H, nullptr, nullptr,

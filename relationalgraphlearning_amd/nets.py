@@ -112,8 +112,10 @@ def _seq_last_relu(seq):
     return len(mods) > 0 and isinstance(mods[-1], nn.ReLU)
 
 
-def pack_mlp(seq, keep):
-    """nn.Sequential[Linear, ReLU...] -> RglMlp; transposed weights are appended to `keep`."""
+def pack_mlp(seq, keep, reuse=None):
+    """nn.Sequential[Linear, ReLU...] -> RglMlp; transposed weights are appended to `keep`.  `reuse` (dict, optional) holds the
+    transposed buffers of an earlier pack: they are overwritten in place, so device pointers handed out earlier (descriptors
+    baked into a captured hipGraph) stay valid and see the new weights."""
     lins = _linears(seq)
     if not 1 <= len(lins) <= nat.MAX_MLP_LAYERS:
         raise ValueError("MLP depth %d outside 1..%d" % (len(lins), nat.MAX_MLP_LAYERS))
@@ -125,7 +127,12 @@ def pack_mlp(seq, keep):
     for l, lin in enumerate(lins):
         w = _require_device_tensor(lin.weight.detach(), "MLP weight")
         b = _require_device_tensor(lin.bias.detach(), "MLP bias")
-        wt = torch.empty(lin.in_features, lin.out_features, device=w.device, dtype=torch.float32)
+        rk = (id(lin), lin.in_features, lin.out_features, str(w.device))
+        wt = None if reuse is None else reuse.get(rk)
+        if wt is None:
+            wt = torch.empty(lin.in_features, lin.out_features, device=w.device, dtype=torch.float32)
+            if reuse is not None:
+                reuse[rk] = wt
         nat.check(lib.rgl_transpose_f32(w.data_ptr(), wt.data_ptr(), lin.out_features, lin.in_features, _stream()),
                   "rgl_transpose_f32")
         keep.extend([wt, b])
@@ -141,10 +148,10 @@ class _GraphCore(nn.Module):
     def _graph_weights(self):
         raise NotImplementedError
 
-    def _pack_graph(self, keep):
+    def _pack_graph(self, keep, reuse=None):
         g = nat.RglGraph()
-        g.w_r = pack_mlp(self.w_r, keep)
-        g.w_h = pack_mlp(self.w_h, keep)
+        g.w_r = pack_mlp(self.w_r, keep, reuse)
+        g.w_h = pack_mlp(self.w_h, keep, reuse)
         g.x_dim = self.X_dim
         ws = self._graph_weights()
         g.num_layer = len(ws)
@@ -158,7 +165,7 @@ class _GraphCore(nn.Module):
             keep.append(wa)
             g.w_a = wa.data_ptr()
         elif self.similarity_function == "concatenation":
-            g.w_a_mlp = pack_mlp(self.w_a, keep)
+            g.w_a_mlp = pack_mlp(self.w_a, keep, reuse)
         for l, w in enumerate(ws):
             wt = _require_device_tensor(w.detach(), "GCN weight")
             if tuple(wt.shape) != (self.X_dim, self.X_dim):
@@ -175,12 +182,13 @@ class _PackCache:
         self.key = None
         self.value = None
         self.keep = None
+        self.buffers = {}         # transposed Linear weights, refreshed IN PLACE when parameters change (stable device pointers)
 
     def get(self, modules, build):
         key = tuple((p.data_ptr(), p._version, p.device.index) for m in modules for p in m.parameters())
         if key != self.key:
             keep = []
-            self.value = build(keep)
+            self.value = build(keep, self.buffers)
             self.keep = keep
             self.key = key
         return self.value
@@ -293,7 +301,7 @@ class ValueEstimator(nn.Module):
         self._cache = _PackCache()
 
     def head_descriptor(self):
-        return self._cache.get([self.value_network], lambda keep: pack_mlp(self.value_network, keep))
+        return self._cache.get([self.value_network], lambda keep, reuse: pack_mlp(self.value_network, keep, reuse))
 
     def forward(self, state):
         robot, humans = state
@@ -318,7 +326,7 @@ class StatePredictor(nn.Module):
 
     def head_descriptor(self):
         return self._cache.get([self.human_motion_predictor],
-                               lambda keep: pack_mlp(self.human_motion_predictor, keep))
+                               lambda keep, reuse: pack_mlp(self.human_motion_predictor, keep, reuse))
 
     def forward(self, state, action, detach=False):
         robot, humans = state
@@ -410,8 +418,8 @@ class ValueNetwork(_GraphCore):
     def _graph_weights(self):
         return [self.w1] if self.num_layer == 1 else [self.w1, self.w2]
 
-    def _pack_graph(self, keep):
-        g = super()._pack_graph(keep)
+    def _pack_graph(self, keep, reuse=None):
+        g = super()._pack_graph(keep, reuse)
         if self.num_layer == 1:
             g.skip_connection = 0          # the one-layer variant never adds the skip (gcn.py:108-110)
         return g
@@ -420,7 +428,7 @@ class ValueNetwork(_GraphCore):
         return self._cache.get([self], self._pack_graph)
 
     def head_descriptor(self):
-        return self._head_cache.get([self.value_net], lambda keep: pack_mlp(self.value_net, keep))
+        return self._head_cache.get([self.value_net], lambda keep, reuse: pack_mlp(self.value_net, keep, reuse))
 
     @property
     def A(self):

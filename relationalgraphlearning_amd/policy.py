@@ -114,7 +114,8 @@ class ModelPredictiveRL(Policy):
         self.sparse_speed_samples = 2
         self.sparse_rotation_samples = 8
         self.action_group_index = []
-        self.traj = None
+        self._traj = None
+        self._traj_search = None            # the search whose best branch `traj` describes, read back on demand
         self.contraction_dtype = "f32"      # additive: "f16" = f16-input MFMA for the dense middle-layer products
         self._search = None
 
@@ -180,6 +181,21 @@ class ModelPredictiveRL(Policy):
 
     def get_model(self):
         return self.value_estimator
+
+    @property
+    def traj(self):
+        """[(state tensors, action, reward), ...] along the best branch of the last decision (model_predictive_rl.py:231,
+        298-302).  Read back from the device when somebody asks (CrowdSim.render does), not on every predict()."""
+        if self._traj is None and self._traj_search is not None:
+            ts, last = self._traj_search
+            ts.last = last
+            self._traj = [(s, None if a is None else self.action_space[a], r) for s, a, r in ts.best_trajectory(0)]
+            self._traj_search = None
+        return self._traj
+
+    @traj.setter
+    def traj(self, value):
+        self._traj, self._traj_search = value, None
 
     def get_traj(self):
         return self.traj
@@ -250,21 +266,18 @@ class ModelPredictiveRL(Policy):
             max_action = self.action_space[np.random.choice(len(self.action_space))]
             max_traj = None
         else:
-            robot_t, humans_t = self._root_tensors(state)
+            robot, humans = _state_rows(state)
             ts = self.tree_search()
             with torch.no_grad():
-                out = ts.search(robot_t, humans_t, roots_are_joint_states=True)
-            idx = int(out["best_action"][0])
+                idx = ts.decide(robot, humans)            # captured hipGraph of the whole search for this crowd size
             if idx < 0:
                 raise ValueError('Value network is not well trained.')
             max_action = self.action_space[idx]
-            max_traj = None
-            if self.phase != 'train':
-                max_traj = [(s, None if a is None else self.action_space[a], r) for s, a, r in ts.best_trajectory(0)]
+            max_traj = (ts, ts.last)
         if self.phase == 'train':
             self.last_state = self.transform(state)
         else:
-            self.traj = max_traj
+            self._traj, self._traj_search = None, max_traj
         return max_action
 
     def predict_batch(self, robot, humans, roots_are_joint_states=False):
@@ -381,20 +394,20 @@ class GCN(Policy):
         if not state.human_states:
             raise NotImplementedError("empty crowds fall back to CADRL's greedy action upstream, which is bit-rotted "
                                       "there (state.self_state) and outside the relational-graph path")
-        if self.query_env:
-            raise NotImplementedError("query_env=True needs the simulator's one-step lookahead per action; "
-                                      "the shipped configs use query_env=False")
         probability = np.random.random()
         if self.phase == 'train' and probability < self.epsilon:
             max_action = self.action_space[np.random.choice(len(self.action_space))]
         else:
             robot, humans = _state_rows(state)
-            robot_t = torch.tensor([robot], dtype=torch.float32, device=self.device)
-            humans_t = torch.tensor([humans], dtype=torch.float32, device=self.device)
+            r64 = torch.tensor([robot], dtype=torch.float64, device=self.device)
+            h64 = torch.tensor([humans], dtype=torch.float64, device=self.device)
             with torch.no_grad():
-                vals, best = self.gcn_search().search(robot_t, humans_t)
-                # keep the visual-debug hook: adjacency of the LAST action's graph, as the sequential loop leaves it
-                self._refresh_adjacency(robot, humans)
+                if self.query_env:
+                    vals, best = self._search_querying_env(robot, r64)
+                else:
+                    vals, best = self.gcn_search().search(r64.float(), h64.float(), roots64=(r64, h64))
+                    # keep the visual-debug hook: adjacency of the LAST action's graph, as the sequential loop leaves it
+                    self._refresh_adjacency(robot, humans)
             self.action_values = [float(v) for v in vals[0].cpu()]
             idx = int(best[0])
             if idx < 0:
@@ -411,6 +424,32 @@ class GCN(Policy):
         with torch.no_grad():
             vals, best = self.gcn_search().search(robot, humans)
         return best, vals.gather(1, best.long().clamp(min=0)[:, None])[:, 0]
+
+    def _search_querying_env(self, robot, r64):
+        """query_env=True (multi_human_rl.py:43-44): next human states and the reward of every action come from the simulator's
+        one-step lookahead instead of the constant-velocity guess.  `self.env` must offer
+        `onestep_lookahead_actions(actions (A,2) float64) -> (next_humans (A,H,5), reward (A,))` for the scene it holds
+        (BatchedCrowdSim does: A copies of the scene stepped once on the device)."""
+        if self.env is None or not hasattr(self.env, "onestep_lookahead_actions"):
+            raise AttributeError("query_env=True needs policy.set_env(sim) with a simulator offering onestep_lookahead_actions")
+        table = torch.tensor(act.as_array(self.action_space), dtype=torch.float64, device=self.device)
+        next_humans, reward = self.env.onestep_lookahead_actions(table)              # (A,H,5) float64, (A,) float32
+        A, H = table.shape[0], next_humans.shape[1]
+        dt = self.time_step
+        nr = r64.repeat(A, 1)                                                        # CADRL.propagate, float64
+        if self.kinematics == 'holonomic':
+            nr[:, 0], nr[:, 1] = r64[0, 0] + table[:, 0] * dt, r64[0, 1] + table[:, 1] * dt
+            nr[:, 2], nr[:, 3] = table[:, 0], table[:, 1]
+        else:
+            th = r64[0, 8] + table[:, 1]
+            nr[:, 2], nr[:, 3] = table[:, 0] * torch.cos(th), table[:, 0] * torch.sin(th)
+            nr[:, 0], nr[:, 1] = r64[0, 0] + nr[:, 2] * dt, r64[0, 1] + nr[:, 3] * dt
+            nr[:, 8] = th
+        joint = torch.cat([nr[:, None, :].expand(A, H, 9), next_humans.double()], dim=2).reshape(A * H, 14).float().contiguous()
+        v = self.model(rotate(joint, self.kinematics).reshape(A, H, 13))             # leaves .A at the last action, like upstream
+        disc = pow(self.gamma, dt * float(robot[7]))
+        vals = (reward.double() + disc * v[:, 0].double()).float().reshape(1, A)
+        return vals, vals.argmax(dim=1).int()
 
     def _refresh_adjacency(self, robot, humans):
         last = self.action_space[-1]

@@ -36,6 +36,8 @@ class TreeSearch:
         self.state_predictor = state_predictor            # StatePredictor module or LinearStatePredictor
         self.actions_np = np.ascontiguousarray(np.asarray(actions, dtype=np.float64))
         self.groups_np = None if action_groups is None else np.asarray(action_groups, dtype=np.int32)
+        if self.groups_np is not None and self.groups_np.size and (self.groups_np.min() < 0 or self.groups_np.max() > 63):
+            raise ValueError("action group ids must lie in [0, 64): the sparse search keeps them in a 64-bit set")
         self.kinematics = kinematics
         self.time_step = float(time_step)
         self.gamma_bar = float(gamma_bar)
@@ -48,6 +50,7 @@ class TreeSearch:
         self._ws = _Workspace()
         self._ws2 = _Workspace()    # hand-off buffer of the stand-alone expand / value_children calls
         self.last = None            # outputs of the most recent search (device tensors)
+        self._decisions = {}        # (H, device) -> captured single-scene search (decide())
 
     # -- descriptors -----------------------------------------------------------------------------
     @property
@@ -103,16 +106,25 @@ class TreeSearch:
         return pl
 
     # -- device calls ----------------------------------------------------------------------------
-    def search(self, robot, humans, roots_are_joint_states=True, want_root_values=True, out=None):
+    def search(self, robot, humans, roots_are_joint_states=True, want_root_values=True, out=None, roots64=None):
         """robot (B,9), humans (B,H,5) fp32 device tensors -> dict of device tensors:
         best_action (B,) int32, best_value (B,) fp32, root_values/root_kept (B,W0).
-        `out` = (int32 (B,), fp32 (B,)) contiguous device tensors to receive best_action / best_value in place."""
+        `out` = (int32 (B,), fp32 (B,)) contiguous device tensors to receive best_action / best_value in place.
+        `roots64` = (robot (B,9), humans (B,H,5)) float64 device tensors: the JointStates the fp32 roots were rounded from; the
+        root level's estimate_reward reads them, as the reference does (model_predictive_rl.py:226)."""
         robot = _require_device_tensor(robot, "robot states")
         humans = _require_device_tensor(humans, "human states")
         B, H = robot.shape[0], humans.shape[1]
         dev = robot.device
         with torch.cuda.device(dev):
             pl = self.planner(dev)
+            if roots64 is not None:
+                r64, h64 = roots64
+                if not (r64.dtype == torch.float64 and h64.dtype == torch.float64 and r64.is_cuda and h64.is_cuda
+                        and r64.is_contiguous() and h64.is_contiguous() and tuple(r64.shape) == (B, 9)
+                        and tuple(h64.shape) == (B, H, 5)):
+                    raise ValueError("roots64 must be contiguous float64 device tensors (B,9) / (B,H,5)")
+                pl.root_robot_f64, pl.root_humans_f64 = r64.data_ptr(), h64.data_ptr()
             lib = nat.lib()
             nbytes = lib.mprl_tree_workspace_bytes(C.byref(pl), B, H)
             if nbytes == 0:
@@ -137,13 +149,65 @@ class TreeSearch:
                                           int(roots_are_joint_states), ws.data_ptr(), ws.numel(),
                                           out["best_action"].data_ptr(), out["best_value"].data_ptr(), rv, rk, _stream())
         nat.check(rc, "mprl_tree_search_f32")
-        self.last = dict(out, B=B, H=H, robot=robot, humans=humans, planner=pl, workspace=ws)
+        self.last = dict(out, B=B, H=H, robot=robot, humans=humans, planner=pl, workspace=ws, roots64=roots64)
         return out
+
+    def decide(self, robot_row, human_rows):
+        """One decision for ONE scene given as python floats (robot: 9 numbers, humans: H rows of 5): the whole search replayed
+        from a hipGraph captured for this crowd size.  Returns the action index; `self.last` describes the search as after
+        `search()`.  What `ModelPredictiveRL.predict` (model_predictive_rl.py:192-240) costs per call is then one host-to-device
+        copy of the state, one graph launch and one 4-byte read-back instead of ~8 eager launches per tree level.
+        The descriptors are refreshed before every replay: parameters updated in place (optimizer steps, load_state_dict) are
+        re-transposed into the SAME device buffers the graph reads, and a parameter whose storage moved triggers a re-capture."""
+        dev = next(self.value_estimator.parameters()).device
+        if dev.type != "cuda":
+            raise nat.NativeLibraryError("the policy's networks are on %s: the search runs only on the MI355X kernels (no CPU path)" % dev)
+        H = len(human_rows)
+        key = (H, str(dev))
+        ent = self._decisions.get(key)
+        with torch.cuda.device(dev):
+            sig = bytes(self.planner(dev))                       # repacks (in place) if any parameter changed
+            if ent is None or ent["sig"] != sig:
+                ent = self._capture_decision(H, dev)
+                ent["sig"] = bytes(self.planner(dev))
+                self._decisions[key] = ent
+            ent["host64"][:9] = torch.as_tensor(robot_row, dtype=torch.float64)
+            ent["host64"][9:] = torch.as_tensor(human_rows, dtype=torch.float64).reshape(-1)
+            ent["dev64"].copy_(ent["host64"], non_blocking=True)
+            ent["robot"].copy_(ent["dev64"][:9].reshape(1, 9))                      # fp32 views the networks see (to_tensor)
+            ent["humans"].copy_(ent["dev64"][9:].reshape(1, H, 5))
+            ent["graph"].replay()
+            self.last = ent["last"]
+            return int(ent["last"]["best_action"][0])
+
+    def _capture_decision(self, H, dev):
+        host64 = torch.empty(9 + 5 * H, dtype=torch.float64).pin_memory()
+        dev64 = torch.zeros(9 + 5 * H, dtype=torch.float64, device=dev)
+        robot = torch.zeros(1, 9, dtype=torch.float32, device=dev)
+        humans = torch.zeros(1, H, 5, dtype=torch.float32, device=dev)
+        robot[0, 4], robot[0, 7], humans[0, :, 4] = 0.3, 1.0, 0.3                  # a harmless warm-up scene
+        humans[0, :, 0] = torch.arange(H, device=dev, dtype=torch.float32) + 2.0
+        dev64[:9], dev64[9:] = robot.reshape(-1).double(), humans.reshape(-1).double()
+        roots64 = (dev64[:9].reshape(1, 9), dev64[9:].reshape(1, H, 5))
+        shared_ws, self._ws = self._ws, _Workspace()                  # the graph bakes its workspace pointer: a private one
+        try:
+            self.search(robot, humans, True, roots64=roots64)       # warm-up: workspace, descriptors, function attributes
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self.search(robot, humans, True, roots64=roots64)
+            last = self.last
+        finally:
+            self._ws = shared_ws
+        return {"graph": graph, "host64": host64, "dev64": dev64, "robot": robot, "humans": humans, "last": last}
 
     def capture(self, robot, humans, roots_are_joint_states=True):
         """Capture one whole search into a hipGraph (torch.cuda.CUDAGraph).  Returns (graph, outputs): copy new root
         states into `robot` / `humans` in place, call graph.replay(), read `outputs` -- no Python or launch overhead
-        per decision.  The library allocates nothing and never synchronises, which is what makes this legal."""
+        per decision.  The library allocates nothing and never synchronises, which is what makes this legal.
+        The graph bakes device pointers: parameters may change IN PLACE (their transposed copies are refreshed in place by
+        the next `planner()` / `search()` call -- call one of them before replaying after an optimizer step), but a parameter
+        moved to new storage needs a new capture (`decide()` does both checks itself)."""
         self.search(robot, humans, roots_are_joint_states)          # warm-up: workspace, descriptors, function attributes
         torch.cuda.synchronize(robot.device)
         graph = torch.cuda.CUDAGraph()
@@ -245,8 +309,9 @@ class GcnSearch:
         self._dev_tables = {}
         self._ws = _Workspace()
 
-    def search(self, robot, humans):
-        """robot (B,9), humans (B,H,5) -> (action_values (B,A) fp32, best_action (B,) int32), device tensors."""
+    def search(self, robot, humans, roots64=None):
+        """robot (B,9), humans (B,H,5) -> (action_values (B,A) fp32, best_action (B,) int32), device tensors.
+        `roots64`: the float64 (robot, humans) the fp32 arrays were rounded from (propagate / compute_reward read them)."""
         robot = _require_device_tensor(robot, "robot states")
         humans = _require_device_tensor(humans, "human states")
         B, H, A = robot.shape[0], humans.shape[1], self.actions_np.shape[0]
@@ -263,6 +328,8 @@ class GcnSearch:
             pl.time_step = self.time_step
             pl.gamma = self.gamma
             pl.actions = self._dev_tables[key].data_ptr()
+            if roots64 is not None:
+                pl.root_robot_f64, pl.root_humans_f64 = roots64[0].data_ptr(), roots64[1].data_ptr()
             lib = nat.lib()
             ws = self._ws.get(lib.gcn_predict_workspace_bytes(B, H, A), dev)
             vals = torch.empty(B, A, dtype=torch.float32, device=dev)

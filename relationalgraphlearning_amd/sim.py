@@ -174,6 +174,34 @@ class BatchedCrowdSim(object):
     def onestep_lookahead(self, robot_actions, human_actions=None):
         return self.step(robot_actions, human_actions, update=False)
 
+    def onestep_lookahead_actions(self, actions, env_index=0):
+        """CrowdSim.onestep_lookahead (crowd_sim.py:249-250) for EVERY action of a table at once: A copies of environment
+        `env_index` are stepped once on the device (the environment itself is untouched).  actions (A,2) float64 ->
+        (next observable human states (A,H,5) float64, reward (A,) float32).  What path G's query_env=True asks per action
+        (multi_human_rl.py:43-44)."""
+        dev = self.device
+        act = torch.as_tensor(actions, dtype=torch.float64).to(dev).contiguous()
+        A = act.shape[0]
+        b = int(env_index)
+        robot = self.robot[b:b + 1].repeat(A, 1).contiguous()
+        humans = self.humans[b:b + 1].repeat(A, 1, 1).contiguous()
+        goals = None if self.human_goals is None else self.human_goals[b:b + 1].repeat(A, 1, 1).contiguous()
+        vpref = None if self.human_vpref is None else self.human_vpref[b:b + 1].repeat(A, 1).contiguous()
+        time = self.time[b:b + 1].repeat(A).contiguous()
+        done = torch.zeros(A, dtype=torch.int32, device=dev)
+        reward = torch.empty(A, dtype=torch.float32, device=dev)
+        info = torch.empty(A, dtype=torch.int32, device=dev)
+        dmin = torch.empty(A, dtype=torch.float64, device=dev)
+        cfg = self._config()
+        with torch.cuda.device(dev):
+            rc = nat.lib().crowd_step_f64(C.byref(cfg), robot.data_ptr(), humans.data_ptr(),
+                                          None if goals is None else goals.data_ptr(),
+                                          None if vpref is None else vpref.data_ptr(), act.data_ptr(), None,
+                                          time.data_ptr(), done.data_ptr(), A, self.H, 1, reward.data_ptr(),
+                                          info.data_ptr(), dmin.data_ptr(), _stream())
+        nat.check(rc, "crowd_step_f64")
+        return humans, reward
+
 
 def run_episodes(sim, policy, phase, cases, gamma=0.9, max_steps=None):
     """Explorer.run_k_episodes for len(cases) environments in lock-step: the policy decides for every live environment

@@ -202,6 +202,124 @@ def test_predict_joint_state_api(dev):
     assert pol.predict(at_goal) == rga.ActionXY(0, 0)
 
 
+def test_predict_replays_a_captured_search_and_follows_the_weights(dev):
+    """predict() replays a hipGraph of the whole search per crowd size (TreeSearch.decide).  The graph bakes device pointers, so:
+    parameters updated IN PLACE (optimizer step, load_state_dict) must show up in the next decision (transposed copies are
+    refreshed into the same buffers), and a parameter moved to new storage must trigger a re-capture."""
+    pl = gio.load("planning")
+    pol = make_mprl_policy("trained", 2, 2, True, device=dev)
+    ts = pol.tree_search()
+    scenes = [JS(pl["plan.scene.s5.robot"][b], pl["plan.scene.s5.humans"][b]) for b in range(3)]
+
+    def eager(js):
+        r = torch.tensor([[getattr(js.robot_state, k) for k in ("px", "py", "vx", "vy", "radius", "gx", "gy", "v_pref", "theta")]],
+                         dtype=torch.float64, device=dev)
+        h = torch.tensor([[[getattr(x, k) for k in ("px", "py", "vx", "vy", "radius")] for x in js.human_states]],
+                         dtype=torch.float64, device=dev)
+        o = rga.TreeSearch(pol.value_estimator, pol.state_predictor, rga.actions.as_array(pol.action_space), pol.action_group_index,
+                           planning_depth=2, planning_width=2, do_action_clip=True).search(r.float(), h.float(), True, roots64=(r, h))
+        return int(o["best_action"][0]), float(o["best_value"][0])
+    for js in scenes:
+        a = pol.predict(js)
+        ea, ev = eager(js)
+        assert a == pol.action_space[ea] and abs(float(ts.last["best_value"][0]) - ev) == 0.0
+    assert len(ts._decisions) == 1                                   # one capture served all three decisions
+    graph0 = next(iter(ts._decisions.values()))["graph"]
+    with torch.no_grad():                                            # in-place update: same storage, new version
+        for p_ in pol.value_estimator.value_network.parameters():
+            p_.mul_(1.5)
+        pol.value_estimator.graph_model.w_a.add_(0.01)
+    for js in scenes:
+        a = pol.predict(js)
+        ea, ev = eager(js)
+        assert a == pol.action_space[ea] and abs(float(ts.last["best_value"][0]) - ev) == 0.0
+    assert next(iter(ts._decisions.values()))["graph"] is graph0      # still the first capture
+    sd = pol.get_state_dict()
+    sd["value_network"] = {k: v * 0.5 for k, v in sd["value_network"].items()}
+    pol.load_state_dict(sd)                                          # copy_ into the same parameters
+    a = pol.predict(scenes[0])
+    assert a == pol.action_space[eager(scenes[0])[0]]
+    gm = pol.value_estimator.graph_model
+    gm.w_a = torch.nn.Parameter(gm.w_a.detach().clone() * 1.1)     # new storage: the captured pointers are stale
+    a = pol.predict(scenes[1])
+    ea, ev = eager(scenes[1])
+    assert a == pol.action_space[ea] and abs(float(ts.last["best_value"][0]) - ev) == 0.0
+    assert next(iter(ts._decisions.values()))["graph"] is not graph0
+    # a larger crowd gets its own capture; the trajectory is read back lazily and belongs to the latest decision
+    big = JS(pl["plan.scene.s5.robot"][0], np.concatenate([pl["plan.scene.s5.humans"][0], pl["plan.scene.s5.humans"][1] + 0.37]))
+    a = pol.predict(big)
+    assert len(ts._decisions) == 2 and pol._traj is None
+    traj = pol.get_traj()
+    assert len(traj) == 3 and traj[0][1] == a and traj[0][0][1].shape == (1, 10, 5) and pol.traj is traj
+
+
+def test_root_reward_reads_the_float64_joint_state(dev):
+    """estimate_reward of the ROOT is evaluated on the simulator's float64 state in the reference (model_predictive_rl.py:226);
+    rounding the root to fp32 first moves clearances by ~1e-7 and flips threshold cases.  A human placed so that its
+    clearance under action 0 is -2e-9 in float64 (a collision) but +3e-8 after fp32 rounding."""
+    pol = make_mprl_policy("trained", 1, device=dev)
+    pol.build_action_space(1.0)
+    ts = pol.tree_search()
+    acts = rga.actions.as_array(pol.action_space)
+    robot = np.array([[0.1, -0.2, 0.0, 0.0, 0.3, 0.0, 4.0, 1.0, np.pi / 2]], np.float64)
+    found = None
+    for k in range(2000):                                     # search a placement where fp32 rounding crosses the boundary
+        cand = np.array([[[robot[0, 0] + 0.6 - 2e-9, -0.2 + k * 1e-4, 0.0, 0.0, 0.3]]], np.float64)
+        cand[0, 0, 0] = robot[0, 0] + np.sqrt(max(0.0, (0.6 - 2e-9) ** 2 - (k * 1e-4) ** 2))
+        d64 = np.hypot(cand[0, 0, 0] - robot[0, 0], cand[0, 0, 1] - robot[0, 1]) - 0.6
+        r32, c32 = robot.astype(np.float32).astype(np.float64), cand.astype(np.float32).astype(np.float64)
+        d32 = np.hypot(c32[0, 0, 0] - r32[0, 0], c32[0, 0, 1] - r32[0, 1]) - np.float64(np.float32(0.3)) * 2
+        if d64 < 0 <= d32:
+            found = cand
+            break
+    assert found is not None
+    r64, h64 = torch.tensor(robot, device=dev), torch.tensor(found, device=dev)
+    cfg = orc.OracleConfig()
+    want = [orc.estimate_reward([float(x) for x in robot[0]], [[float(x) for x in found[0, 0]]], a, cfg) for a in acts]
+    ts.search(r64.float(), h64.float(), True, roots64=(r64, h64))
+    got64 = ts.level_arrays(0)["reward"][0].cpu().numpy()
+    assert np.abs(got64 - np.array(want, np.float64)).max() < 1e-7
+    ts.search(r64.float(), h64.float(), True)                 # without the float64 state the stop action looks collision-free
+    got32 = ts.level_arrays(0)["reward"][0].cpu().numpy()
+    assert want[0] == -0.25 and got64[0] == -0.25 and got32[0] != -0.25
+
+
+def test_path_g_query_env(dev):
+    """query_env=True (multi_human_rl.py:43-44): per action, the next human states and the reward come from the simulator's
+    one-step lookahead.  Against a plain restatement on the same simulator (one action at a time through onestep_lookahead)."""
+    from relationalgraphlearning_amd.sim import BatchedCrowdSim
+    pol = make_gcn_policy(device=dev)
+    pol.query_env = True
+    sim = BatchedCrowdSim(dev)
+    sim.reset("test", [3])
+    for _ in range(6):                                        # a few steps in, so humans move
+        sim.step(torch.tensor([[0.0, 0.8]], dtype=torch.float64))
+    pol.set_env(sim)
+    robot = sim.robot[0].cpu().numpy()
+    js = JS(robot, sim.humans[0].cpu().numpy())
+    with pytest.raises(AttributeError):
+        pol.set_env(None)
+        pol.predict(js)
+    pol.set_env(sim)
+    a = pol.predict(js)
+    assert len(pol.action_values) == len(pol.action_space)
+    # restatement: action by action
+    table = rga.actions.as_array(pol.action_space)
+    vals = []
+    for i in range(table.shape[0]):
+        nh, rew = sim.onestep_lookahead_actions(table[i:i + 1])
+        (obs_r, obs_h), r1, _, _ = sim.onestep_lookahead(torch.tensor(table[i:i + 1]))
+        assert abs(float(r1[0]) - float(rew[0])) == 0.0       # same reward as the simulator's own lookahead
+        nr = list(robot)
+        nr[0], nr[1], nr[2], nr[3] = robot[0] + table[i, 0] * 0.25, robot[1] + table[i, 1] * 0.25, table[i, 0], table[i, 1]
+        joint = torch.tensor([nr + [float(x) for x in row] for row in nh[0].cpu().numpy()], dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            v = pol.model(rga.rotate(joint).unsqueeze(0))
+        vals.append(float(rew[0]) + pow(0.9, 0.25 * robot[7]) * float(v[0, 0]))
+    assert np.abs(np.array(vals) - np.array(pol.action_values)).max() < 1e-5
+    assert a == pol.action_space[int(np.argmax(vals))]
+
+
 def test_checkpoint_roundtrip(dev, tmp_path):
     pol = make_mprl_policy("trained", 1, device=dev)
     f = str(tmp_path / "rl_model.pth")
@@ -924,6 +1042,24 @@ def test_bench_runs_under_torchrun_over_rccl(dev):
     assert r["scaling"] == "strong" and r["n_gpus"] == 1 and r["config"]["total_roots"] == 96
     assert r["multi_gpu"]["roots_per_rank"] == [96] and r["multi_gpu"]["exchange_ms_per_step_slowest_rank"] >= 0.0
     assert r["value"] > 0 and r["roofline"]["frac"] > 0
+
+
+def test_backward_refuses_stale_parameters_and_state_gradients(dev):
+    """the backward recomputes the forward from the current parameters -- an in-place update between forward and
+    backward must raise (as torch does for its saved tensors), and so must inputs that ask for gradients."""
+    c = dict(L=2, sim="embedded_gaussian", layerwise=False, skip=True, flavour="trained")
+    _, ve, _ = build_modules(c, dev)
+    robot, humans = seeded_scenes(61, 8, 5)
+    state = (robot.unsqueeze(1).to(dev), humans.to(dev))
+    out = ve(state).sum()
+    with torch.no_grad():
+        ve.value_network[0].weight.mul_(1.001)
+    with pytest.raises(RuntimeError):
+        out.backward()
+    with pytest.raises(NotImplementedError):
+        ve((state[0], state[1].clone().requires_grad_(True)))
+    with pytest.raises(ValueError):
+        rga.TreeSearch(ve, None, np.zeros((3, 2)), [0, 64, 1])
 
 
 def test_library_reports_target():

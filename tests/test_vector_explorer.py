@@ -202,5 +202,5 @@ def test_against_the_reference_explorer_fixture(dev):
                 assert np.allclose(humans.cpu().numpy(), fx[key + "mem_humans"][j], rtol=0, atol=1e-6)
                 assert np.allclose(nrobot.cpu().numpy(), fx[key + "mem_next_robot"][j], rtol=0, atol=1e-6)
                 assert np.allclose(nhumans.cpu().numpy(), fx[key + "mem_next_humans"][j], rtol=0, atol=1e-6)
-                assert abs(float(value) - float(fx[key + "mem_value"][j])) < 1e-6
-                assert abs(float(reward) - float(fx[key + "mem_reward"][j])) < 1e-6
+                assert abs(float(value) - float(fx[key + "mem_value"][j, 0])) < 1e-6
+                assert abs(float(reward) - float(fx[key + "mem_reward"][j, 0])) < 1e-6
