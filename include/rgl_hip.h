@@ -124,13 +124,14 @@ int rgl_graph_forward_f32(const RglGraph* graph, const RglMlp* value_head, const
  * parameter, summed over the n_scenes scenes (deterministic: per-scene slabs reduced in scene order).
  * Replaces: torch autograd through RGL.forward / ValueEstimator.forward / StatePredictor.forward /
  * gcn.ValueNetwork.forward as driven by MPRLTrainer / VNRLTrainer (crowd_nav/utils/trainer.py:110-161,
- * 199-250).  Supported: similarity embedded_gaussian | gaussian | squared | equal_attention | diagonal,
- * layerwise_graph = 0 (else RGL_ERR_BAD_MODE).
+ * 199-250).  Supported: all eight similarity functions, layerwise_graph 0 | 1 (RGL_ERR_LDS when a scene's
+ * activations exceed the 160 KB LDS of a CU: N = 64 with deep MLPs; the training batches have N = 6).
  *   d_value [n_scenes], d_humans_next [n_scenes][H][out], d_H [n_scenes][N][x_dim]: upstream gradients of the
  *   corresponding forward outputs (device; NULL = zero).  detach_graph = 1 reproduces
  *   StatePredictor(..., detach=True): only the heads receive gradients.
- *   grad_out device [rgl_graph_param_count()]: w_r (W0,b0,W1,b1,..), w_h, w_a (embedded_gaussian only),
- *   Ws[0..L-1], value head, motion head; Linear weights k-major [in][out] like the forward's.
+ *   grad_out device [rgl_graph_param_count()]: w_r (W0,b0,W1,b1,..), w_h, w_a (embedded_gaussian: the matrix;
+ *   concatenation: its pair MLP W0,b0,W1,b1), Ws[0..L-1], value head, motion head; Linear weights k-major
+ *   [in][out] like the forward's.
  *   workspace device, >= rgl_graph_backward_workspace_bytes().  Each scene has its own crowd here
  *   (scenes_per_crowd = 1: the training batches are independent transitions).
  * ------------------------------------------------------------------------------------------- */

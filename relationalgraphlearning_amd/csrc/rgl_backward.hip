@@ -5,13 +5,18 @@
 // writes its own gradient slab (every element exactly once, by one thread, as a fixed-order sum), and
 // reduce_slabs_kernel adds the slabs in scene order, so the result is deterministic.
 //
-// Supported structure: similarity embedded_gaussian, gaussian, squared, equal_attention or diagonal; one adjacency for all layers
-// (layerwise_graph = 0), any depth / skip / MLP shapes within the ABI limits.  Anything else returns
-// RGL_ERR_BAD_MODE (the Python side raises; it never falls back to another device).
+// Supported structure: all eight similarity functions of compute_similarity_matrix (graph_model.py:63-97), one adjacency for
+// all layers or one per layer (layerwise_graph), any depth / skip / MLP shapes within the ABI limits; a configuration whose
+// activations do not fit the 160 KB LDS of a CU returns RGL_ERR_LDS (the Python side raises; it never falls back to another
+// device).  The similarity block is a pair of device functions (sim_forward / sim_backward) applied to X once, or to every
+// H_l when the graph is layerwise; its internals (S, norms, pair-MLP halves) are recomputed from the saved H_l in the
+// backward pass instead of being stored per layer.
 //
 // Forward being differentiated (reference: crowd_nav/policy/graph_model.py:99-130, value_estimator.py:11-20,
 // state_predictor.py:28-36, gcn.py:95-128):
-//   X = [w_r(robot); w_h(humans)]      G = X Wa (or X)      S = G X^T      A = softmax_rows(S)
+//   X = [w_r(robot); w_h(humans)]      A = sim(X)   [layerwise: A_l = sim(H_l)]
+//   sim: softmax_rows(X Wa X^T) | softmax_rows(X X^T) | C = S / (m m^T), m_i = |S_i,:|_2 | softmax_rows(C) |
+//        relu(w2 . relu(W1a x_i + W1b x_j + b1) + b2) | S^2 / rowsum(S^2) | 1/N | I
 //   H_0 = X ;  T_l = A H_l ;  R_l = relu(T_l W_l) ;  H_{l+1} = R_l (+ H_l)
 //   value = value_head(H_L[0]) ;  humans_next = motion_head(H_L)[1:]
 #include "rgl_common.h"
@@ -36,14 +41,16 @@ struct BackwardArgs {
     const float* d_H;               // [S][N][xd] or null
     float* slabs;                   // [S][n_params]
     int n_params;
-    MlpOffsets o_wr, o_wh, o_vh, o_mh;
+    MlpOffsets o_wr, o_wh, o_vh, o_mh, o_wam;      // o_wam: the pair MLP of `concatenation`
     int o_wa, o_ws[RGL_MAX_GCN_LAYERS];
     // LDS layout (float offsets)
     int l_ar, ar_ld;                // robot MLP activations: [1][ar_ld]  (all layers' inputs/outputs back to back)
     int l_ah, ah_ld;                // human MLP activations: [H][ah_ld]
     int l_av, av_ld;                // value head activations: [1][av_ld]
     int l_am, am_ld;                // motion head activations: [H][am_ld]
-    int l_G, l_A, a_ld, l_H, l_T, l_R;   // G[N][xd], A[N][a_ld], H[L+1][N][xd], T[L][N][xd], R[L][N][xd]
+    int l_G, l_A, a_ld, l_H, l_T, l_R;   // G[N][xd], A[nA][N][a_ld] (nA = L if layerwise else 1), H[L+1][N][xd], T[L][N][xd], R[L][N][xd]
+    int l_S, l_C, l_m;                   // cosine*: S[N][a_ld], C[N][a_ld], m[N]          (scratch shared with G / the pair halves)
+    int l_P, l_Q, l_dP, l_dQ, hid;       // concatenation: P = X W1a, Q = X W1b, their deltas, [N][hid]
     int l_dH, l_dH2, l_dT, l_dA, l_dG, l_d0, l_d1, d_ld;   // deltas
     int total;
 };
@@ -129,6 +136,270 @@ __device__ void zero_mlp_grads(const RglMlp& m, const MlpOffsets& off, float* sl
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// similarity block:  A = sim(X)  and its backward.  All eight functions of graph_model.py:63-97.
+// ------------------------------------------------------------------------------------------------
+// scratch (LDS, per workgroup): G [N][xd] (embedded_gaussian) | S, C [N][a_ld] + m [N] (cosine, cosine_softmax) | P, Q [N][hid]
+// (concatenation).  On return A [N][a_ld] holds the adjacency; the scratch holds what sim_backward needs for THIS X.
+__device__ void sim_forward(const BackwardArgs& a, float* lds, const float* X, float* A) {
+    const RglGraph& g = a.g;
+    const int N = a.H + 1, xd = g.x_dim, a_ld = a.a_ld, sim = g.similarity;
+    float* G = lds + a.l_G;
+    if (sim == RGL_SIM_EQUAL_ATTENTION || sim == RGL_SIM_DIAGONAL) {
+        for (int idx = threadIdx.x; idx < N * N; idx += kThreads) {
+            const int i = idx / N, j = idx - i * N;
+            A[i * a_ld + j] = sim == RGL_SIM_EQUAL_ATTENTION ? 1.f / (float)N : (i == j ? 1.f : 0.f);
+        }
+        __syncthreads();
+        return;
+    }
+    if (sim == RGL_SIM_CONCATENATION) {
+        // pair MLP 2X -> hid -> 1 with ReLU after both layers; the first layer split into the halves acting on x_i and x_j
+        const RglMlp& m = g.w_a_mlp;
+        const int hid = a.hid;
+        float* P = lds + a.l_P;
+        float* Q = lds + a.l_Q;
+        const float* __restrict__ W1 = m.weight[0];      // [2 xd][hid], k-major
+        for (int idx = threadIdx.x; idx < N * hid; idx += kThreads) {
+            const int i = idx / hid, h = idx - i * hid;
+            float p = 0.f, q = 0.f;
+            for (int k = 0; k < xd; ++k) {
+                p = fmaf(X[i * xd + k], W1[k * hid + h], p);
+                q = fmaf(X[i * xd + k], W1[(xd + k) * hid + h], q);
+            }
+            P[idx] = p;
+            Q[idx] = q;
+        }
+        __syncthreads();
+        const float* __restrict__ b1 = m.bias[0];
+        const float* __restrict__ w2 = m.weight[1];      // [hid][1]
+        const float b2 = m.bias[1][0];
+        for (int idx = threadIdx.x; idx < N * N; idx += kThreads) {
+            const int i = idx / N, j = idx - i * N;
+            float acc = b2;
+            for (int h = 0; h < hid; ++h) acc = fmaf(fmaxf(P[i * hid + h] + Q[j * hid + h] + b1[h], 0.f), w2[h], acc);
+            A[i * a_ld + j] = fmaxf(acc, 0.f);
+        }
+        __syncthreads();
+        return;
+    }
+    const bool embedded = sim == RGL_SIM_EMBEDDED_GAUSSIAN;
+    const bool cosine = sim == RGL_SIM_COSINE || sim == RGL_SIM_COSINE_SOFTMAX;
+    if (embedded) {
+        for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {
+            const int i = idx / xd, c = idx - i * xd;
+            float acc = 0.f;
+            for (int k = 0; k < xd; ++k) acc = fmaf(X[i * xd + k], g.w_a[k * xd + c], acc);
+            G[idx] = acc;
+        }
+        __syncthreads();
+    }
+    const float* GX = embedded ? G : X;
+    float* S = cosine ? lds + a.l_S : A;
+    for (int idx = threadIdx.x; idx < N * N; idx += kThreads) {
+        const int i = idx / N, j = idx - i * N;
+        float acc = 0.f;
+        for (int k = 0; k < xd; ++k) acc = fmaf(GX[i * xd + k], X[j * xd + k], acc);
+        S[i * a_ld + j] = acc;
+    }
+    __syncthreads();
+    if (cosine) {
+        float* mnorm = lds + a.l_m;
+        float* Cm = lds + a.l_C;
+        for (int i = threadIdx.x; i < N; i += kThreads) {
+            float z = 0.f;
+            for (int j = 0; j < N; ++j) z = fmaf(S[i * a_ld + j], S[i * a_ld + j], z);
+            mnorm[i] = sqrtf(z);
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < N * N; idx += kThreads) {
+            const int i = idx / N, j = idx - i * N;
+            const float c = S[i * a_ld + j] / (mnorm[i] * mnorm[j]);
+            Cm[i * a_ld + j] = c;
+            A[i * a_ld + j] = c;
+        }
+        __syncthreads();
+        if (sim == RGL_SIM_COSINE) return;
+    }
+    for (int i = threadIdx.x; i < N; i += kThreads) {
+        float* r = A + i * a_ld;
+        if (sim == RGL_SIM_SQUARED) {                       // S^2 / sum_j S^2   (graph_model.py:86-89)
+            float sum = 0.f;
+            for (int j = 0; j < N; ++j) { r[j] = r[j] * r[j]; sum += r[j]; }
+            for (int j = 0; j < N; ++j) r[j] = r[j] / sum;
+        } else {                                            // row softmax
+            float mx = r[0];
+            for (int j = 1; j < N; ++j) mx = fmaxf(mx, r[j]);
+            float sum = 0.f;
+            for (int j = 0; j < N; ++j) { r[j] = expf(r[j] - mx); sum += r[j]; }
+            for (int j = 0; j < N; ++j) r[j] = r[j] / sum;
+        }
+    }
+    __syncthreads();
+}
+
+// dA [N][a_ld] = dL/dA on entry (destroyed).  dX [N][xd] += dL/dX through the similarity.  Parameter gradients of the block
+// (w_a, or the pair MLP) are written to the slab when `first`, added otherwise (layerwise graphs apply the block L times; the
+// order of the additions is fixed, so the result stays deterministic).  Requires sim_forward(X) to have run last.
+__device__ void sim_backward(const BackwardArgs& a, float* lds, const float* X, const float* A, float* dA, float* dX,
+                             float* slab, bool first) {
+    const RglGraph& g = a.g;
+    const int N = a.H + 1, xd = g.x_dim, a_ld = a.a_ld, sim = g.similarity;
+    if (sim == RGL_SIM_EQUAL_ATTENTION || sim == RGL_SIM_DIAGONAL) return;           // A is a constant
+    if (sim == RGL_SIM_CONCATENATION) {
+        const RglMlp& m = g.w_a_mlp;
+        const int hid = a.hid;
+        const float* P = lds + a.l_P;
+        const float* Q = lds + a.l_Q;
+        float* dP = lds + a.l_dP;
+        float* dQ = lds + a.l_dQ;
+        const float* __restrict__ W1 = m.weight[0];
+        const float* __restrict__ b1 = m.bias[0];
+        const float* __restrict__ w2 = m.weight[1];
+        // dz_ij = dA_ij where the output ReLU is open (A_ij > 0)
+        for (int idx = threadIdx.x; idx < N * N; idx += kThreads) {
+            const int i = idx / N, j = idx - i * N;
+            if (!(A[i * a_ld + j] > 0.f)) dA[i * a_ld + j] = 0.f;
+        }
+        __syncthreads();
+        // hidden_ij[h] = relu(P_i[h] + Q_j[h] + b1[h]);  d hidden = dz w2[h] where open
+        for (int idx = threadIdx.x; idx < N * hid; idx += kThreads) {
+            const int i = idx / hid, h = idx - i * hid;
+            float accp = 0.f, accq = 0.f;
+            for (int j = 0; j < N; ++j) {
+                if (P[i * hid + h] + Q[j * hid + h] + b1[h] > 0.f) accp = fmaf(dA[i * a_ld + j], w2[h], accp);     // row i, pair (i, j)
+                if (P[j * hid + h] + Q[i * hid + h] + b1[h] > 0.f) accq = fmaf(dA[j * a_ld + i], w2[h], accq);     // column i, pair (j, i)
+            }
+            dP[idx] = accp;
+            dQ[idx] = accq;
+        }
+        float* gW1 = slab + a.o_wam.w[0];
+        float* gb1 = slab + a.o_wam.b[0];
+        float* gw2 = slab + a.o_wam.w[1];
+        float* gb2 = slab + a.o_wam.b[1];
+        for (int h = threadIdx.x; h < hid; h += kThreads) {              // d w2[h] = sum_ij dz_ij hidden_ij[h]
+            float acc = 0.f;
+            for (int i = 0; i < N; ++i)
+                for (int j = 0; j < N; ++j)
+                    acc = fmaf(dA[i * a_ld + j], fmaxf(P[i * hid + h] + Q[j * hid + h] + b1[h], 0.f), acc);
+            gw2[h] = first ? acc : gw2[h] + acc;
+        }
+        if (threadIdx.x == 0) {
+            float acc = 0.f;
+            for (int i = 0; i < N; ++i)
+                for (int j = 0; j < N; ++j) acc += dA[i * a_ld + j];
+            gb2[0] = first ? acc : gb2[0] + acc;
+        }
+        __syncthreads();
+        for (int h = threadIdx.x; h < hid; h += kThreads) {              // d b1 = sum_i dP_i  (= sum_j dQ_j)
+            float acc = 0.f;
+            for (int i = 0; i < N; ++i) acc += dP[i * hid + h];
+            gb1[h] = first ? acc : gb1[h] + acc;
+        }
+        for (int idx = threadIdx.x; idx < 2 * xd * hid; idx += kThreads) {   // d W1a = X^T dP ; d W1b = X^T dQ
+            const int k = idx / hid, h = idx - k * hid;
+            const float* D = k < xd ? dP : dQ;
+            const int kk = k < xd ? k : k - xd;
+            float acc = 0.f;
+            for (int i = 0; i < N; ++i) acc = fmaf(X[i * xd + kk], D[i * hid + h], acc);
+            gW1[idx] = first ? acc : gW1[idx] + acc;
+        }
+        for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {     // dX_i += W1a dP_i + W1b dQ_i
+            const int i = idx / xd, k = idx - i * xd;
+            float acc = dX[idx];
+            for (int h = 0; h < hid; ++h) {
+                acc = fmaf(dP[i * hid + h], W1[k * hid + h], acc);
+                acc = fmaf(dQ[i * hid + h], W1[(xd + k) * hid + h], acc);
+            }
+            dX[idx] = acc;
+        }
+        __syncthreads();
+        return;
+    }
+    const bool embedded = sim == RGL_SIM_EMBEDDED_GAUSSIAN;
+    const bool cosine = sim == RGL_SIM_COSINE || sim == RGL_SIM_COSINE_SOFTMAX;
+    float* G = lds + a.l_G;
+    const float* GX = embedded ? G : X;
+    // ---- through the row normalisation: dA -> dS (or dC for the cosine family), in place
+    if (sim != RGL_SIM_COSINE) {
+        for (int i = threadIdx.x; i < N; i += kThreads) {
+            float dot = 0.f;
+            for (int j = 0; j < N; ++j) dot = fmaf(dA[i * a_ld + j], A[i * a_ld + j], dot);
+            if (sim == RGL_SIM_SQUARED) {       // dS_ij = (2 S_ij / sum_k S_ik^2) (dA_ij - sum_k dA_ik A_ik), S recomputed
+                float z = 0.f;
+                for (int j = 0; j < N; ++j) {
+                    float sij = 0.f;
+                    for (int k = 0; k < xd; ++k) sij = fmaf(GX[i * xd + k], X[j * xd + k], sij);
+                    z = fmaf(sij, sij, z);
+                }
+                for (int j = 0; j < N; ++j) {
+                    float sij = 0.f;
+                    for (int k = 0; k < xd; ++k) sij = fmaf(GX[i * xd + k], X[j * xd + k], sij);
+                    dA[i * a_ld + j] = 2.f * sij / z * (dA[i * a_ld + j] - dot);
+                }
+            } else {                            // softmax: dS_ij = A_ij (dA_ij - sum_k dA_ik A_ik)
+                for (int j = 0; j < N; ++j) dA[i * a_ld + j] = A[i * a_ld + j] * (dA[i * a_ld + j] - dot);
+            }
+        }
+        __syncthreads();
+    }
+    if (cosine) {
+        // C_ij = S_ij / (m_i m_j), m_i = |S_i,:|_2.  dA holds dC.  m_i enters row i and column i:
+        //   dm_i = -(1/m_i) (sum_j dC_ij C_ij + sum_j dC_ji C_ji) ;  dS_ij = dC_ij / (m_i m_j) + dm_i S_ij / m_i
+        const float* S = lds + a.l_S;
+        const float* Cm = lds + a.l_C;
+        float* mnorm = lds + a.l_m;
+        float* dm = lds + a.l_m + N;                        // [N] right behind m
+        for (int i = threadIdx.x; i < N; i += kThreads) {
+            float acc = 0.f;
+            for (int j = 0; j < N; ++j) {
+                acc = fmaf(dA[i * a_ld + j], Cm[i * a_ld + j], acc);
+                acc = fmaf(dA[j * a_ld + i], Cm[j * a_ld + i], acc);
+            }
+            dm[i] = -acc / mnorm[i];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < N * N; idx += kThreads) {
+            const int i = idx / N, j = idx - i * N;
+            dA[i * a_ld + j] = dA[i * a_ld + j] / (mnorm[i] * mnorm[j]) + dm[i] * S[i * a_ld + j] / mnorm[i];
+        }
+        __syncthreads();
+    }
+    // ---- S = G X^T :  dG = dS X ;  dX += dS^T G   (dG kept in the dG buffer)
+    float* dG = lds + a.l_dG;
+    for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {
+        const int i = idx / xd, k = idx - i * xd;
+        float acc = 0.f;
+        for (int j = 0; j < N; ++j) acc = fmaf(dA[i * a_ld + j], X[j * xd + k], acc);
+        dG[idx] = acc;
+    }
+    for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {
+        const int j = idx / xd, k = idx - j * xd;
+        float acc = dX[idx];
+        for (int i = 0; i < N; ++i) acc = fmaf(dA[i * a_ld + j], GX[i * xd + k], acc);
+        dX[idx] = acc;
+    }
+    __syncthreads();
+    if (embedded) {   // G = X Wa :  dWa = X^T dG ;  dX += dG Wa^T
+        float* gWa = slab + a.o_wa;
+        for (int idx = threadIdx.x; idx < xd * xd; idx += kThreads) {
+            const int k = idx / xd, c = idx - k * xd;
+            float acc = 0.f;
+            for (int i = 0; i < N; ++i) acc = fmaf(X[i * xd + k], dG[i * xd + c], acc);
+            gWa[idx] = first ? acc : gWa[idx] + acc;
+        }
+        for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {
+            const int i = idx / xd, k = idx - i * xd;
+            float acc = dX[idx];
+            for (int c = 0; c < xd; ++c) acc = fmaf(dG[i * xd + c], g.w_a[k * xd + c], acc);
+            dX[idx] = acc;
+        }
+    } else {          // G = X
+        for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) dX[idx] += dG[idx];
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(kThreads) void rgl_scene_backward_kernel(const BackwardArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const RglGraph& g = a.g;
@@ -138,8 +409,7 @@ __global__ __launch_bounds__(kThreads) void rgl_scene_backward_kernel(const Back
     float* AH = lds + a.l_ah;
     float* AV = lds + a.l_av;
     float* AM = lds + a.l_am;
-    float* G = lds + a.l_G;
-    float* A = lds + a.l_A;
+    float* Aall = lds + a.l_A;    // [nA][N][a_ld]
     float* Hs = lds + a.l_H;      // [L+1][N][xd]
     float* T = lds + a.l_T;       // [L][N][xd]
     float* R = lds + a.l_R;       // [L][N][xd]
@@ -151,8 +421,9 @@ __global__ __launch_bounds__(kThreads) void rgl_scene_backward_kernel(const Back
     float* d0 = lds + a.l_d0;
     float* d1 = lds + a.l_d1;
     const int a_ld = a.a_ld, d_ld = a.d_ld;
+    const bool layerwise = g.layerwise_graph != 0;
     const bool embedded = g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN;
-    const int sim = g.similarity;
+    const bool concat = g.similarity == RGL_SIM_CONCATENATION;
 
     for (int s = blockIdx.x; s < a.n_scenes; s += gridDim.x) {
         float* slab = a.slabs + (size_t)s * a.n_params;
@@ -169,47 +440,14 @@ __global__ __launch_bounds__(kThreads) void rgl_scene_backward_kernel(const Back
             X[idx] = i == 0 ? AR[xr_off + f] : AH[(i - 1) * a.ah_ld + xh_off + f];
         }
         __syncthreads();
-        for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {
-            const int i = idx / xd, c = idx - i * xd;
-            float acc;
-            if (embedded) {
-                acc = 0.f;
-                for (int k = 0; k < xd; ++k) acc = fmaf(X[i * xd + k], g.w_a[k * xd + c], acc);
-            } else acc = X[idx];
-            G[idx] = acc;
-        }
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < N * N; idx += kThreads) {
-            const int i = idx / N, j = idx - i * N;
-            float acc = 0.f;
-            for (int k = 0; k < xd; ++k) acc = fmaf(G[i * xd + k], X[j * xd + k], acc);
-            A[i * a_ld + j] = acc;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < N; i += kThreads) {
-            float* r = A + i * a_ld;
-            if (sim == RGL_SIM_SQUARED) {                       // S^2 / sum_j S^2   (graph_model.py:86-89)
-                float sum = 0.f;
-                for (int j = 0; j < N; ++j) { r[j] = r[j] * r[j]; sum += r[j]; }
-                for (int j = 0; j < N; ++j) r[j] = r[j] / sum;
-            } else if (sim == RGL_SIM_EQUAL_ATTENTION) {
-                for (int j = 0; j < N; ++j) r[j] = 1.f / (float)N;
-            } else if (sim == RGL_SIM_DIAGONAL) {
-                for (int j = 0; j < N; ++j) r[j] = i == j ? 1.f : 0.f;
-            } else {                                            // row softmax
-                float mx = r[0];
-                for (int j = 1; j < N; ++j) mx = fmaxf(mx, r[j]);
-                float sum = 0.f;
-                for (int j = 0; j < N; ++j) { r[j] = expf(r[j] - mx); sum += r[j]; }
-                for (int j = 0; j < N; ++j) r[j] = r[j] / sum;
-            }
-        }
-        __syncthreads();
+        if (!layerwise) sim_forward(a, lds, X, Aall);
         for (int l = 0; l < L; ++l) {
             const float* Hl = Hs + l * N * xd;
             float* Tl = T + l * N * xd;
             float* Rl = R + l * N * xd;
             float* Hn = Hs + (l + 1) * N * xd;
+            float* A = layerwise ? Aall + l * N * a_ld : Aall;
+            if (layerwise) sim_forward(a, lds, Hl, A);
             for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {
                 const int i = idx / xd, c = idx - i * xd;
                 float acc = 0.f;
@@ -262,23 +500,32 @@ __global__ __launch_bounds__(kThreads) void rgl_scene_backward_kernel(const Back
                 dH[(idx / xd + 1) * xd + (idx % xd)] += din[(idx / xd) * d_ld + (idx % xd)];
             __syncthreads();
         }
-        if (a.detach_graph) {
+        if (a.detach_graph || L == 0) {
             // StatePredictor(..., detach=True): the embedding is a constant; only the head learns
-            zero_mlp_grads(g.w_r, a.o_wr, slab);
-            zero_mlp_grads(g.w_h, a.o_wh, slab);
-            if (embedded) for (int i = threadIdx.x; i < xd * xd; i += kThreads) slab[a.o_wa + i] = 0.f;
-            for (int l = 0; l < L; ++l) for (int i = threadIdx.x; i < xd * xd; i += kThreads) slab[a.o_ws[l] + i] = 0.f;
-            __syncthreads();
-            continue;
+            if (a.detach_graph || L == 0) {
+                if (a.detach_graph) {
+                    zero_mlp_grads(g.w_r, a.o_wr, slab);
+                    zero_mlp_grads(g.w_h, a.o_wh, slab);
+                }
+                if (embedded) for (int i = threadIdx.x; i < xd * xd; i += kThreads) slab[a.o_wa + i] = 0.f;
+                if (concat) zero_mlp_grads(g.w_a_mlp, a.o_wam, slab);
+                for (int l = 0; l < L; ++l) for (int i = threadIdx.x; i < xd * xd; i += kThreads) slab[a.o_ws[l] + i] = 0.f;
+                __syncthreads();
+            }
+            if (a.detach_graph) continue;
         }
-        for (int idx = threadIdx.x; idx < N * a_ld; idx += kThreads) dA[idx] = 0.f;
-        __syncthreads();
+        if (!layerwise) {
+            for (int idx = threadIdx.x; idx < N * a_ld; idx += kThreads) dA[idx] = 0.f;
+            __syncthreads();
+        }
         float* dcur = dH;
         float* dnxt = dH2;
+        bool first_sim = true;
         for (int l = L - 1; l >= 0; --l) {
             const float* Hl = Hs + l * N * xd;
             const float* Tl = T + l * N * xd;
             const float* Rl = R + l * N * xd;
+            const float* A = layerwise ? Aall + l * N * a_ld : Aall;
             const float* __restrict__ W = g.Ws[l];
             // dZ = dH_{l+1} o (R_l > 0)   (kept in dG as scratch)
             for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) dG[idx] = Rl[idx] > 0.f ? dcur[idx] : 0.f;
@@ -297,9 +544,9 @@ __global__ __launch_bounds__(kThreads) void rgl_scene_backward_kernel(const Back
                 dT[idx] = acc;
             }
             __syncthreads();
-            for (int idx = threadIdx.x; idx < N * N; idx += kThreads) {       // dA += dT H_l^T
+            for (int idx = threadIdx.x; idx < N * N; idx += kThreads) {       // dA (+)= dT H_l^T
                 const int i = idx / N, j = idx - i * N;
-                float acc = dA[i * a_ld + j];
+                float acc = layerwise ? 0.f : dA[i * a_ld + j];
                 for (int k = 0; k < xd; ++k) acc = fmaf(dT[i * xd + k], Hl[j * xd + k], acc);
                 dA[i * a_ld + j] = acc;
             }
@@ -310,73 +557,22 @@ __global__ __launch_bounds__(kThreads) void rgl_scene_backward_kernel(const Back
                 dnxt[idx] = acc;
             }
             __syncthreads();
+            if (layerwise) {                  // A_l = sim(H_l): recompute the block's internals for this H_l, then go through it
+                sim_forward(a, lds, Hl, Aall + l * N * a_ld);
+                sim_backward(a, lds, Hl, A, dA, dnxt, slab, first_sim);
+                first_sim = false;
+            }
             float* t = dcur;
             dcur = dnxt;
             dnxt = t;
         }
-        // dcur = dL/dX from the layers.  softmax: dS_ij = A_ij (dA_ij - sum_k dA_ik A_ik)   (in place in dA)
-        //                                  squared: dS_ij = (2 S_ij / sum_k S_ik^2) (dA_ij - sum_k dA_ik A_ik), S recomputed
-        //                                  equal_attention / diagonal: A is constant, dS = 0
-        for (int i = threadIdx.x; i < N; i += kThreads) {
-            float dot = 0.f;
-            for (int j = 0; j < N; ++j) dot = fmaf(dA[i * a_ld + j], A[i * a_ld + j], dot);
-            if (sim == RGL_SIM_SQUARED) {
-                float z = 0.f;
-                for (int j = 0; j < N; ++j) {
-                    float sij = 0.f;
-                    for (int k = 0; k < xd; ++k) sij = fmaf(G[i * xd + k], X[j * xd + k], sij);
-                    z = fmaf(sij, sij, z);
-                }
-                for (int j = 0; j < N; ++j) {
-                    float sij = 0.f;
-                    for (int k = 0; k < xd; ++k) sij = fmaf(G[i * xd + k], X[j * xd + k], sij);
-                    dA[i * a_ld + j] = 2.f * sij / z * (dA[i * a_ld + j] - dot);
-                }
-            } else if (sim == RGL_SIM_EQUAL_ATTENTION || sim == RGL_SIM_DIAGONAL) {
-                for (int j = 0; j < N; ++j) dA[i * a_ld + j] = 0.f;
-            } else {
-                for (int j = 0; j < N; ++j) dA[i * a_ld + j] = A[i * a_ld + j] * (dA[i * a_ld + j] - dot);
-            }
-        }
-        __syncthreads();
-        // (X = H_0 is still addressed through the pointer set up in the forward part)
-        // S = G X^T :  dG = dS X ;  dX += dS^T G
-        for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {
-            const int i = idx / xd, k = idx - i * xd;
-            float acc = 0.f;
-            for (int j = 0; j < N; ++j) acc = fmaf(dA[i * a_ld + j], X[j * xd + k], acc);
-            dG[idx] = acc;
-        }
-        for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {
-            const int j = idx / xd, k = idx - j * xd;
-            float acc = dcur[idx];
-            for (int i = 0; i < N; ++i) acc = fmaf(dA[i * a_ld + j], G[i * xd + k], acc);
-            dnxt[idx] = acc;
-        }
-        __syncthreads();
-        if (embedded) {   // G = X Wa :  dWa = X^T dG ;  dX += dG Wa^T
-            float* gWa = slab + a.o_wa;
-            for (int idx = threadIdx.x; idx < xd * xd; idx += kThreads) {
-                const int k = idx / xd, c = idx - k * xd;
-                float acc = 0.f;
-                for (int i = 0; i < N; ++i) acc = fmaf(X[i * xd + k], dG[i * xd + c], acc);
-                gWa[idx] = acc;
-            }
-            for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {
-                const int i = idx / xd, k = idx - i * xd;
-                float acc = dnxt[idx];
-                for (int c = 0; c < xd; ++c) acc = fmaf(dG[i * xd + c], g.w_a[k * xd + c], acc);
-                dnxt[idx] = acc;
-            }
-        } else {          // G = X
-            for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) dnxt[idx] += dG[idx];
-        }
-        __syncthreads();
+        // dcur = dL/dX from the layers; one adjacency for all layers: its gradient was accumulated in dA
+        if (!layerwise) sim_backward(a, lds, X, Aall, dA, dcur, slab, true);
         // embeddings: row 0 -> w_r, rows 1..H -> w_h
-        for (int f = threadIdx.x; f < xd; f += kThreads) d0[f] = dnxt[f];
+        for (int f = threadIdx.x; f < xd; f += kThreads) d0[f] = dcur[f];
         __syncthreads();
         mlp_backward(g.w_r, a.o_wr, AR, a.ar_ld, 1, d0, d1, d_ld, slab, false);
-        for (int idx = threadIdx.x; idx < H * xd; idx += kThreads) d0[(idx / xd) * d_ld + (idx % xd)] = dnxt[(idx / xd + 1) * xd + (idx % xd)];
+        for (int idx = threadIdx.x; idx < H * xd; idx += kThreads) d0[(idx / xd) * d_ld + (idx % xd)] = dcur[(idx / xd + 1) * xd + (idx % xd)];
         __syncthreads();
         mlp_backward(g.w_h, a.o_wh, AH, a.ah_ld, H, d0, d1, d_ld, slab, false);
         __syncthreads();
@@ -415,11 +611,6 @@ int plan_backward(const RglGraph* graph, const RglMlp* vh, const RglMlp* mh, int
     if (!graph) return RGL_ERR_NULL;
     int rc = rgl::validate_graph(*graph, H);
     if (rc) return rc;
-    if (graph->layerwise_graph) return RGL_ERR_BAD_MODE;
-    if (graph->similarity != RGL_SIM_EMBEDDED_GAUSSIAN && graph->similarity != RGL_SIM_GAUSSIAN &&
-        graph->similarity != RGL_SIM_SQUARED && graph->similarity != RGL_SIM_EQUAL_ATTENTION &&
-        graph->similarity != RGL_SIM_DIAGONAL)
-        return RGL_ERR_BAD_MODE;
     a.g = *graph;
     a.has_vhead = (vh && vh->n_layers > 0) ? 1 : 0;
     a.has_mhead = (mh && mh->n_layers > 0) ? 1 : 0;
@@ -427,12 +618,14 @@ int plan_backward(const RglGraph* graph, const RglMlp* vh, const RglMlp* mh, int
     a.mhead = a.has_mhead ? *mh : RglMlp{};
     if (a.has_vhead && (rc = rgl::validate_mlp(a.vhead, graph->x_dim, 1))) return rc;
     if (a.has_mhead && (rc = rgl::validate_mlp(a.mhead, graph->x_dim, 0))) return rc;
-    // slab order: w_r (W0,b0,W1,b1,..), w_h, w_a (embedded_gaussian only), Ws[0..L-1], value head, motion head
+    // slab order: w_r (W0,b0,W1,b1,..), w_h, w_a (embedded_gaussian: matrix; concatenation: its pair MLP), Ws[0..L-1],
+    // value head, motion head
     int off = 0;
     off = assign_mlp(a.g.w_r, a.o_wr, off);
     off = assign_mlp(a.g.w_h, a.o_wh, off);
     a.o_wa = off;
     if (graph->similarity == RGL_SIM_EMBEDDED_GAUSSIAN) off += graph->x_dim * graph->x_dim;
+    if (graph->similarity == RGL_SIM_CONCATENATION) off = assign_mlp(a.g.w_a_mlp, a.o_wam, off);
     for (int l = 0; l < graph->num_layer; ++l) { a.o_ws[l] = off; off += graph->x_dim * graph->x_dim; }
     if (a.has_vhead) off = assign_mlp(a.vhead, a.o_vh, off);
     if (a.has_mhead) off = assign_mlp(a.mhead, a.o_mh, off);
@@ -445,8 +638,18 @@ int plan_backward(const RglGraph* graph, const RglMlp* vh, const RglMlp* mh, int
     a.ah_ld = mlp_act_width(a.g.w_h); a.l_ah = take(H * a.ah_ld);
     a.av_ld = a.has_vhead ? mlp_act_width(a.vhead) : 0; a.l_av = take(a.av_ld);
     a.am_ld = a.has_mhead ? mlp_act_width(a.mhead) : 0; a.l_am = take(H * a.am_ld);
-    a.l_G = take(N * xd);
-    a.a_ld = N + 1; a.l_A = take(N * a.a_ld);
+    a.a_ld = N + 1;
+    // scratch of the similarity block: what one mode needs, the modes never coexist
+    a.hid = graph->similarity == RGL_SIM_CONCATENATION ? graph->w_a_mlp.dims[1] : 0;
+    a.l_G = a.l_S = a.l_C = a.l_m = a.l_P = a.l_Q = a.l_dP = a.l_dQ = lo;
+    if (graph->similarity == RGL_SIM_CONCATENATION) {
+        a.l_P = take(N * a.hid); a.l_Q = take(N * a.hid); a.l_dP = take(N * a.hid); a.l_dQ = take(N * a.hid);
+    } else if (graph->similarity == RGL_SIM_COSINE || graph->similarity == RGL_SIM_COSINE_SOFTMAX) {
+        a.l_S = take(N * a.a_ld); a.l_C = take(N * a.a_ld); a.l_m = take(2 * N);
+    } else {
+        a.l_G = take(N * xd);
+    }
+    a.l_A = take((graph->layerwise_graph && L > 0 ? L : 1) * N * a.a_ld);
     a.l_H = take((L + 1) * N * xd);
     a.l_T = take((L > 0 ? L : 1) * N * xd);
     a.l_R = take((L > 0 ? L : 1) * N * xd);

@@ -56,12 +56,8 @@ class _Spec(object):
         self.value_desc, self.motion_desc = value_desc, motion_desc
         self.want_H, self.want_A, self.detach_graph = want_H, want_A, detach_graph
         gm = graph_module
-        if gm.similarity_function not in ("embedded_gaussian", "gaussian", "squared", "equal_attention",
-                                          "diagonal") or gm.layerwise_graph:
-            raise NotImplementedError("gradients on the HIP path cover similarity embedded_gaussian|gaussian|squared|"
-                                      "equal_attention|diagonal with one "
-                                      "adjacency for all layers (the shipped configurations); got %s, layerwise=%s"
-                                      % (gm.similarity_function, gm.layerwise_graph))
+        if gm.similarity_function not in nat.SIMILARITY:
+            raise NotImplementedError(gm.similarity_function)
         self.params, self.param_shapes = [], []
 
         def add_mlp(seq):
@@ -74,6 +70,8 @@ class _Spec(object):
         if gm.similarity_function == "embedded_gaussian":
             self.params.append(gm.w_a)
             self.param_shapes.append(("matrix", tuple(gm.w_a.shape)))
+        elif gm.similarity_function == "concatenation":
+            add_mlp(gm.w_a)                       # the pair MLP 2X -> 2X -> 1
         for w in gm._graph_weights():
             self.params.append(w)
             self.param_shapes.append(("matrix", tuple(w.shape)))

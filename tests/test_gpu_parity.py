@@ -847,9 +847,10 @@ def test_no_cpu_fallback_and_no_silent_autograd(dev):
     h = torch.zeros(1, 3, 5)
     with torch.no_grad(), pytest.raises(nat.NativeLibraryError):
         ve((r, h))                                            # CPU tensors
-    lw = build_modules(dict(L=2, sim="cosine", layerwise=True, skip=True, flavour="trained"), dev)[1]
-    with pytest.raises(NotImplementedError):
-        lw((r.to(dev), h.to(dev)))                            # gradients for a structure the backward does not cover
+    big = build_modules(dict(L=3, sim="concatenation", layerwise=True, skip=True, flavour="trained"), dev)[1]
+    out = big((r.to(dev), torch.zeros(1, 63, 5, device=dev)))           # forward under grad is fine ...
+    with pytest.raises(nat.NativeLibraryError):
+        out.sum().backward()                                  # ... but N = 64 activations of the backward exceed one CU's LDS: loud
     with torch.no_grad(), pytest.raises(nat.NativeLibraryError):
         ve((r.to(dev), torch.zeros(1, 64, 5, device=dev)))    # N = 65 > RGL_MAX_NODES
 
@@ -868,20 +869,35 @@ def _grad_close(got, want, name, tol=2e-4):
     assert err <= tol * scale, (name, err, scale)
 
 
-@pytest.mark.parametrize("H,L,sim,skip,flavour,B", [(5, 2, "embedded_gaussian", True, "trained", 7),
-                                                     (19, 2, "embedded_gaussian", True, "trained", 4),
-                                                     (5, 3, "embedded_gaussian", False, "trained", 5),
-                                                     (3, 1, "gaussian", True, "trained", 6),
-                                                     (5, 2, "embedded_gaussian", True, "rand", 3),
-                                                     (5, 2, "squared", True, "trained", 5),
-                                                     (7, 3, "squared", False, "trained", 3),
-                                                     (5, 2, "equal_attention", True, "trained", 4),
-                                                     (4, 2, "diagonal", True, "trained", 4)])
-def test_gradients_value_estimator_and_state_predictor(H, L, sim, skip, flavour, B, dev):
-    c = dict(L=L, sim=sim, layerwise=False, skip=skip, flavour=flavour)
+@pytest.mark.parametrize("H,L,sim,skip,flavour,B,layerwise", [
+    (5, 2, "embedded_gaussian", True, "trained", 7, False),
+    (19, 2, "embedded_gaussian", True, "trained", 4, False),
+    (5, 3, "embedded_gaussian", False, "trained", 5, False),
+    (3, 1, "gaussian", True, "trained", 6, False),
+    (5, 2, "embedded_gaussian", True, "rand", 3, False),
+    (5, 2, "squared", True, "trained", 5, False),
+    (7, 3, "squared", False, "trained", 3, False),
+    (5, 2, "equal_attention", True, "trained", 4, False),
+    (4, 2, "diagonal", True, "trained", 4, False),
+    (5, 2, "cosine", True, "trained", 5, False),
+    (7, 3, "cosine", False, "trained", 3, False),
+    (5, 2, "cosine_softmax", True, "trained", 5, False),
+    (5, 2, "concatenation", True, "trained", 4, False),
+    (9, 1, "concatenation", False, "rand", 3, False),
+    (5, 2, "embedded_gaussian", True, "trained", 5, True),
+    (6, 3, "embedded_gaussian", False, "trained", 3, True),
+    (5, 2, "gaussian", True, "trained", 4, True),
+    (5, 2, "cosine", True, "trained", 4, True),
+    (4, 3, "cosine_softmax", False, "trained", 3, True),
+    (5, 2, "concatenation", True, "trained", 4, True),
+    (5, 2, "squared", True, "trained", 4, True),
+    (19, 2, "concatenation", True, "trained", 2, True),
+    (19, 2, "cosine_softmax", True, "trained", 2, False),])
+def test_gradients_value_estimator_and_state_predictor(H, L, sim, skip, flavour, B, layerwise, dev):
+    c = dict(L=L, sim=sim, layerwise=layerwise, skip=skip, flavour=flavour)
     g1, ve, sp = build_modules(c, dev)
     robot, humans = seeded_scenes(900 + H + L, B, H)
-    cfg = orc.OracleConfig(num_layer=L, similarity=sim, skip_connection=skip)
+    cfg = orc.OracleConfig(num_layer=L, similarity=sim, skip_connection=skip, layerwise_graph=layerwise)
     wv = torch.linspace(-1.0, 1.5, B).reshape(B, 1)
     # value estimator
     for p_ in ve.parameters():
