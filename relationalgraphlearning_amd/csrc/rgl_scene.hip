@@ -81,17 +81,18 @@ struct SceneArgs {
 };
 
 constexpr int M2LD = 20;   // LDS row stride of the [64][5 -> 16] motion output layer (4*M2LD % 32 == 16)
+// 8 waves share one 30 KB weight image; two workgroups per CU = 4 waves per SIMD.  (Round 1 ran 4-wave workgroups, 2 waves per
+// SIMD: a scene is one serial chain of ~290 MFMAs with a softmax in the middle, and two waves did not cover its latencies --
+// MFMA-busy 29 % at 4096 scenes.)
+constexpr int kSceneThreads = 512, kSceneWaves = kSceneThreads / 64;
 
-// Workgroups [0, grid_scene) run the graph forward, one scene per wave; the remaining ones (if any) run the level's
-// independent next-robot-state / reward work (children_thread): different pipes (MFMA vs float64 VALU), one launch.
+// One scene per wave.  The level's independent next-robot-state / reward work (children_thread, float64 VALU) rides in the same
+// launch: scene s IS parent s of the level, so the wave that owns it first runs the parent's actions (lanes = actions; the
+// parent's rows are wave-uniform: scalar loads).  (Round 1 put that work on EXTRA workgroups of the launch; they reserve the
+// same dynamic LDS as the scene workgroups, so they could only start when a persistent scene workgroup retired -- the two halves
+// of the launch ran one after the other, and one thread per (parent, action) re-read the crowd through vector loads.)
 template <int NT, bool SOFT>
-__global__ __launch_bounds__(kThreads, 2) void scene_graph_kernel(const SceneArgs a, const ChildrenArgs ca, int grid_scene) {
-    if ((int)blockIdx.x >= grid_scene) {
-        const long long total = (long long)ca.P * ca.A, stride = (long long)(gridDim.x - grid_scene) * kThreads;
-        for (long long idx = (long long)(blockIdx.x - grid_scene) * kThreads + threadIdx.x; idx < total; idx += stride)
-            children_thread(ca, idx);
-        return;
-    }
+__global__ __launch_bounds__(kSceneThreads, 2) void scene_graph_kernel(const SceneArgs a, const ChildrenArgs ca, int grid_scene) {
     const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -104,29 +105,55 @@ __global__ __launch_bounds__(kThreads, 2) void scene_graph_kernel(const SceneArg
     const float* wm2 = lds + a.off_wm2;     // [64][M2LD], columns >= 5 zero
     const float* bm2 = lds + a.off_bm2;     // [16], entries >= 5 zero
     float* Hs = lds + a.off_wave + wave * a.wave_stride;   // [16*NT][XLD] node features of the wave's current scene
-    {
+    {   // weight image in two phases -- every global load of the thread first, then the LDS stores -- so that the whole
+        // 30 KB image costs ONE L2 round trip (filling matrix by matrix cost one per matrix: ~9 us of a ~35 us launch)
         float* w = lds;
-#pragma unroll 4
-        for (int i = tid; i < XD * XD; i += kThreads) {
-            const int r = i / XD, c = i - r * XD;
-            w[a.off_wa + r * WLD + c] = a.wa ? a.wa[i] : (r == c ? 1.f : 0.f);   // gaussian: Wa = I
-            for (int l = 0; l < a.L; ++l) w[a.off_ws + (l * XD + r) * WLD + c] = a.Ws[l][i];
+        constexpr int NT_ = kSceneThreads;
+        constexpr int KQ = XD * XD / NT_, KM1 = XD * HID / NT_, KM2 = HID * 16 / NT_;
+        float vq[5][KQ];                                       // wa + up to 4 layer matrices
+        float vm1[KM1], vm2[KM2], vb;
+        const int Lc = a.L < 4 ? a.L : 4;
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+            const int i = tid + k * NT_;
+            vq[0][k] = a.wa ? a.wa[i] : ((i / XD) == (i % XD) ? 1.f : 0.f);      // gaussian: Wa = I
+#pragma unroll
+            for (int l = 0; l < 4; ++l) vq[1 + l][k] = l < Lc ? a.Ws[l][i] : 0.f;
         }
-#pragma unroll 4
-        for (int i = tid; i < XD * HID; i += kThreads) {
-            const int r = i / HID, c = i - r * HID;
-            w[a.off_wm1 + r * W1LD + c] = a.wm1[i];
+#pragma unroll
+        for (int k = 0; k < KM1; ++k) vm1[k] = a.wm1[tid + k * NT_];
+#pragma unroll
+        for (int k = 0; k < KM2; ++k) {
+            const int i = tid + k * NT_, r = i / 16, c = i - r * 16;
+            vm2[k] = a.wm2[r * 5 + (c < 5 ? c : 0)];
         }
-#pragma unroll 4
-        for (int i = tid; i < HID * 16; i += kThreads) {
-            const int r = i / 16, c = i - r * 16;
-            w[a.off_wm2 + r * M2LD + c] = c < 5 ? a.wm2[r * 5 + c] : 0.f;
+        vb = tid < HID ? a.bm1[tid] : (tid < HID + 5 ? a.bm2[tid - HID] : 0.f);
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+            const int i = tid + k * NT_, r = i / XD, c = i - r * XD;
+            w[a.off_wa + r * WLD + c] = vq[0][k];
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                if (l < Lc) w[a.off_ws + (l * XD + r) * WLD + c] = vq[1 + l][k];
         }
-        for (int i = tid; i < HID; i += kThreads) w[a.off_bm1 + i] = a.bm1[i];
-        for (int i = tid; i < 16; i += kThreads) w[a.off_bm2 + i] = i < 5 ? a.bm2[i] : 0.f;
+#pragma unroll
+        for (int k = 0; k < KM1; ++k) {
+            const int i = tid + k * NT_, r = i / HID, c = i - r * HID;
+            w[a.off_wm1 + r * W1LD + c] = vm1[k];
+        }
+#pragma unroll
+        for (int k = 0; k < KM2; ++k) {
+            const int i = tid + k * NT_, r = i / 16, c = i - r * 16;
+            w[a.off_wm2 + r * M2LD + c] = c < 5 ? vm2[k] : 0.f;
+        }
+        if (tid < HID) w[a.off_bm1 + tid] = vb;
+        else if (tid < HID + 16) w[a.off_bm2 + tid - HID] = tid < HID + 5 ? vb : 0.f;
     }
     __syncthreads();
-    for (int sc = blockIdx.x + grid_scene * wave; sc < a.P; sc += grid_scene * kWaves) {             // partial round: one per WG
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    for (int sc = blockIdx.x + grid_scene * wave_u; sc < a.P; sc += grid_scene * kSceneWaves) {      // partial round: one per WG
+        if (ca.child_robot)
+            for (int act = lane; act < ca.A; act += 64) children_pa(ca, sc, act);
         // node features of this scene: row 0 = robot, rows 1..H = its crowd, rows >= N zero
         const float* xr = a.x0_rows + (size_t)sc * XD;
         const float* xh = a.xh_rows + (size_t)(sc / a.crowds_per) * H * XD;
@@ -304,17 +331,12 @@ int launch_scene(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* chil
     if (lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_bytes));
-    int grid = (sa.P + kWaves - 1) / kWaves;
-    const int cap = 256 * (lds_bytes * 2 <= (size_t)rgl::kLdsBytesPerCu ? 2 : 1) * 2;
+    int grid = (sa.P + kSceneWaves - 1) / kSceneWaves;
+    const int cap = 256 * (lds_bytes * 2 <= (size_t)rgl::kLdsBytesPerCu ? 2 : 1);      // resident workgroups: persistent
     if (grid > cap) grid = cap;
-    ChildrenArgs ca{};
-    int grid_children = 0;
-    if (children) {
-        ca = *children;
-        const long long blocks = ((long long)ca.P * ca.A + kThreads - 1) / kThreads;
-        grid_children = (int)(blocks < 2048 ? blocks : 2048);
-    }
-    hipLaunchKernelGGL(kern, dim3(grid + grid_children), dim3(kThreads), lds_bytes, st, sa, ca, grid);
+    ChildrenArgs ca{};                       // child_robot == nullptr: no such work in this launch
+    if (children) ca = *children;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSceneThreads), lds_bytes, st, sa, ca, grid);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }
@@ -363,7 +385,7 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
     sa.off_wm2 = take(HID * M2LD);
     sa.off_bm2 = take(16);
     sa.wave_stride = 16 * NT * XLD;
-    sa.off_wave = take(kWaves * sa.wave_stride);
+    sa.off_wave = take(kSceneWaves * sa.wave_stride);
     const size_t lds_bytes = (size_t)off * sizeof(float);
     switch (NT) {
         case 1: rc = launch_scene<1>(sa, lds_bytes, ca, stream); break;
