@@ -378,14 +378,18 @@ def main():
         peak = flop_per_scene / (dense / F16_MFMA_PEAK_TFLOPS + (flop_per_scene - dense) / FP32_PEAK_TFLOPS)
         peak_note = "blend: %.0f%% of the FLOPs at the dense f16 MFMA peak (%.0f), the rest at the fp32 peak (%.1f)" % (
             100.0 * dense / flop_per_scene, F16_MFMA_PEAK_TFLOPS, FP32_PEAK_TFLOPS)
-    # HBM bytes per launch from the PMC passes committed under profiles/ (counters cannot be read from inside this
-    # process); only quoted for the workload they were measured on
-    traffic, traffic_src = None, None
+    # HBM bytes per launch from the PMC passes committed under profiles/ (counters cannot be read from inside this process);
+    # only quoted for the workload they were measured on, and stamped with the source revision they were measured at -- a
+    # record from another revision of the kernels is stale by construction
+    traffic, traffic_src, traffic_rev = None, None, None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        import glob
+        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+        tj = json.load(open(latest))
         if (tj["workload"]["N"], tj["workload"]["L"], tj["workload"]["A"]) == (N, args.layers, A):
             traffic, traffic_src = tj["bytes_per_scene"] * scenes_per_launch, tj["source"]
-    except (OSError, KeyError, ValueError):
+            traffic_rev = tj.get("source_revision", "round 1 (unstamped)")
+    except (OSError, KeyError, ValueError, IndexError):
         pass
 
     result = {
@@ -408,7 +412,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "value of sibling children, mprl_value_children_f32: " + kernel_path,
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "peak_note": peak_note,
                      "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes/launch",
-                     "traffic_source": traffic_src, "algorithmic_bytes": scenes_per_launch * (9 * 4 + 4) + scenes_per_launch / A * H * 20,
+                     "traffic_source": traffic_src, "traffic_measured_at_revision": traffic_rev, "algorithmic_bytes": scenes_per_launch * (9 * 4 + 4) + scenes_per_launch / A * H * 20,
                      "launch_ms": kern_ms, "scenes_per_launch": scenes_per_launch,
                      "flop_per_scene": flop_per_scene, "reference_flop_per_eval": {(20, 2): 328120, (50, 3): 1337660, (6, 2): 102300}.get((N, args.layers))},
     }

@@ -58,7 +58,7 @@ constexpr int kCrowdWaves = 8;
 
 // One wave per (parent, 16-node column tile); the NT waves of a parent meet at a workgroup barrier between the two parts.
 template <int NT, bool SOFT>
-__global__ __launch_bounds__(kCrowdWaves * 64) void crowd_block_kernel(const CrowdArgs a) {
+__global__ __launch_bounds__(kCrowdWaves * 64, 4) void crowd_block_kernel(const CrowdArgs a) {
     const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NP = 16 * NT;
@@ -725,7 +725,7 @@ int launch_crowd(const FusedPlan& pl, hipStream_t st) {
     auto kern = crowd_block_kernel<NT, SOFT>;
     constexpr int PPW = kCrowdWaves / NT;
     int grid = (pl.c.P + PPW - 1) / PPW;
-    if (grid > 768) grid = 768;                                   // 40 KB LDS: three workgroups per CU
+    if (grid > 1024) grid = 1024;                                 // 40 KB LDS: four workgroups per CU (64 VGPRs)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kCrowdWaves * 64), pl.crowd_lds_bytes, st, pl.c);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
