@@ -84,6 +84,10 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
                           float* humans_next, void* workspace, size_t workspace_bytes, hipStream_t stream,
                           const void* children = nullptr, size_t children_bytes = 0, int* children_done = nullptr);  // rgl_scene.hip
 
+int launch_scene_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
+                          float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream);         // rgl_scene.hip
+size_t scene_children_workspace_bytes(int P, int A, int H);                                                        // rgl_scene.hip
+
 inline int mlp_max_hidden(const RglMlp& m) {
     int w = 0;
     for (int l = 1; l < m.n_layers; ++l) w = m.dims[l] > w ? m.dims[l] : w;

@@ -16,7 +16,9 @@ size_t value_children_workspace_bytes(const MprlPlanner* pl, int P, int H) {
     const size_t children = (size_t)P * pl->num_actions * 64 * sizeof(float);
     const size_t predictor = (size_t)P * (H + 1) * XD * sizeof(float);         // embeddings of launch_predict_humans
     const size_t fused = H + 1 <= 32 ? fused_children_workspace_bytes(P, pl->num_actions, H) : 0;
-    const size_t m = children > predictor ? children : predictor;
+    const size_t scene = scene_children_workspace_bytes(P, pl->num_actions, H);
+    const size_t m0 = children > predictor ? children : predictor;
+    const size_t m = m0 > scene ? m0 : scene;
     // the fused kernel keeps its weight images at the END of the workspace: room for them behind every other use
     return H + 1 <= 32 ? ((m + 255) & ~(size_t)255) + fused_children_workspace_bytes(0, pl->num_actions, H) + (fused > m ? fused - m : 0) : m;
 }
@@ -47,8 +49,18 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
             if (want_f16 && (rc == 1 || g->num_layer != 3)) return RGL_ERR_BAD_MODE;
         }
         if (rc == 1) rc = launch_tile_children(g, P, A, H, child_robot, humans_next, rows, stream);
+        if (rc == 1 && !want_f16) {
+            // every child's graph in full, one wave per child: the remaining similarity functions and layerwise graphs
+            rc = launch_scene_children(pl, child_robot, humans_next, P, H, child_value, workspace, workspace_bytes, stream);
+            if (rc != 1) return rc;
+        }
     }
     if (want_f16 && rc == 1) return RGL_ERR_BAD_MODE;
+    if (rc == 1) {
+        // RGL_REQUIRE_MFMA_CHILDREN=1 (tests): refuse instead of running the general VALU kernel
+        static const bool require = [] { const char* e = getenv("RGL_REQUIRE_MFMA_CHILDREN"); return e && e[0] == '1'; }();
+        if (require) return RGL_ERR_BAD_MODE;
+    }
     if (rc == 1)
         return launch_generic_forward(&pl->value_graph, &pl->value_head, nullptr, child_robot, humans_next, P * A, A, H,
                                       nullptr, nullptr, child_value, nullptr, stream);

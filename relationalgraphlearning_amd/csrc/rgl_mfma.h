@@ -97,6 +97,12 @@ __device__ __forceinline__ float dpp_rowbcast_mul(float row_src, float other) {
     return d;
 }
 template <int K>
+__device__ __forceinline__ float dpp_rowbcast_add(float row_src, float other) {
+    float d;
+    asm("v_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(row_src), "v"(other), "n"(K));
+    return d;
+}
+template <int K>
 __device__ __forceinline__ float dpp_rowbcast_fmac(float row_src, float other, float acc) {
     asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(row_src), "v"(other), "n"(K));
     return acc;
@@ -140,7 +146,8 @@ inline bool mlp_is(const RglMlp& m, int d0, int d1, int d2, bool last_relu) {
 // kernels and the scene kernel implement: A_ij = w_ij / sum_j w_ij with
 //   SIM_SOFTMAX  w = e^{S_ij - max_j S_ij}      SIM_SQUARED  w = S_ij^2      SIM_EQUAL  w = 1      SIM_DIAGONAL  w = [i == j]
 // (`cosine*` scale every column by a child-dependent norm and `concatenation` is a pair MLP: general kernel.)
-enum { SIM_SOFTMAX = 0, SIM_SQUARED = 1, SIM_EQUAL = 2, SIM_DIAGONAL = 3 };
+enum { SIM_SOFTMAX = 0, SIM_SQUARED = 1, SIM_EQUAL = 2, SIM_DIAGONAL = 3,
+       SIM_COSINE = 4, SIM_COSINE_SOFTMAX = 5, SIM_CONCAT = 6 };      // the scene kernel only (scene_similarity_mode)
 inline int fast_similarity_mode(const RglGraph& g) {
     switch (g.similarity) {
         case RGL_SIM_EMBEDDED_GAUSSIAN:
@@ -150,6 +157,15 @@ inline int fast_similarity_mode(const RglGraph& g) {
         case RGL_SIM_DIAGONAL: return SIM_DIAGONAL;
         default: return -1;
     }
+}
+// the one-wave-per-scene kernel (rgl_scene.hip) also normalises by the row norms of S: the cosine family
+inline int scene_similarity_mode(const RglGraph& g) {
+    if (g.similarity == RGL_SIM_COSINE) return SIM_COSINE;
+    if (g.similarity == RGL_SIM_COSINE_SOFTMAX) return SIM_COSINE_SOFTMAX;
+    if (g.similarity == RGL_SIM_CONCATENATION)      // pair MLP 2X -> 64 -> 1 with ReLU after both layers (graph_model.py:46-47)
+        return (g.w_a_mlp.n_layers == 2 && g.w_a_mlp.dims[0] == 2 * XD && g.w_a_mlp.dims[1] == HID && g.w_a_mlp.dims[2] == 1 &&
+                g.w_a_mlp.last_relu) ? (int)SIM_CONCAT : -1;
+    return fast_similarity_mode(g);
 }
 inline const float* bilinear_wa(const RglGraph& g) { return g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN ? g.w_a : nullptr; }
 // un-normalised weight of a VALID entry under the non-softmax modes (entry s of row i, column j)

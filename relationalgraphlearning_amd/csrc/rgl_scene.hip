@@ -75,7 +75,11 @@ struct SceneArgs {
     int L, skip;
     int sim;                           // SIM_* row normalisation
     const float *wm1, *bm1, *wm2, *bm2;   // motion head, k-major [32][64], [64], [64][5], [5]
-    float* humans_next;                // [P][H][5]
+    float* humans_next;                // [P][H][5]   (state predictor)
+    float* rows_out;                   // null, or [P][64]: value mode -- rows [ (A H_{L-1})[robot] | H_{L-1}[robot] ] for robot_head_kernel
+    int layerwise;                     // adjacency recomputed from H_l in every layer (graph_model.py:119-122)
+    const float *wc1, *bc1, *wc2, *bc2;   // concatenation: pair MLP, k-major [64][64], [64], [64][1], [1]
+    int off_wc1, off_bc1, off_wc2;
     int P, H, N;
     int off_wa, off_ws, off_wm1, off_bm1, off_wm2, off_bm2, off_wave, wave_stride;
 };
@@ -91,9 +95,11 @@ constexpr int kSceneThreads = 512, kSceneWaves = kSceneThreads / 64;
 // parent's rows are wave-uniform: scalar loads).  (Round 1 put that work on EXTRA workgroups of the launch; they reserve the
 // same dynamic LDS as the scene workgroups, so they could only start when a persistent scene workgroup retired -- the two halves
 // of the launch ran one after the other, and one thread per (parent, action) re-read the crowd through vector loads.)
-template <int NT, bool SOFT>
+// SK: 0 = softmax of S (embedded_gaussian / gaussian), 1 = plain weights over their row sum (squared / equal_attention /
+// diagonal), 2 = cosine family (cosine / cosine_softmax; graph_model.py:70-79), 3 = concatenation (pair MLP, :80-85)
+template <int NT, int SK>
 __global__ __launch_bounds__(kSceneThreads, 2) void scene_graph_kernel(const SceneArgs a, const ChildrenArgs ca, int grid_scene) {
-    const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
+    const int sim = SK == 0 ? (int)SIM_SOFTMAX : a.sim;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
@@ -121,13 +127,13 @@ __global__ __launch_bounds__(kSceneThreads, 2) void scene_graph_kernel(const Sce
             for (int l = 0; l < 4; ++l) vq[1 + l][k] = l < Lc ? a.Ws[l][i] : 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < KM1; ++k) vm1[k] = a.wm1[tid + k * NT_];
+        for (int k = 0; k < KM1; ++k) vm1[k] = a.wm1 ? a.wm1[tid + k * NT_] : 0.f;        // value mode: no motion head
 #pragma unroll
         for (int k = 0; k < KM2; ++k) {
             const int i = tid + k * NT_, r = i / 16, c = i - r * 16;
-            vm2[k] = a.wm2[r * 5 + (c < 5 ? c : 0)];
+            vm2[k] = a.wm2 ? a.wm2[r * 5 + (c < 5 ? c : 0)] : 0.f;
         }
-        vb = tid < HID ? a.bm1[tid] : (tid < HID + 5 ? a.bm2[tid - HID] : 0.f);
+        vb = !a.bm1 ? 0.f : (tid < HID ? a.bm1[tid] : (tid < HID + 5 ? a.bm2[tid - HID] : 0.f));
 #pragma unroll
         for (int k = 0; k < KQ; ++k) {
             const int i = tid + k * NT_, r = i / XD, c = i - r * XD;
@@ -148,6 +154,10 @@ __global__ __launch_bounds__(kSceneThreads, 2) void scene_graph_kernel(const Sce
         }
         if (tid < HID) w[a.off_bm1 + tid] = vb;
         else if (tid < HID + 16) w[a.off_bm2 + tid - HID] = tid < HID + 5 ? vb : 0.f;
+        if (SK == 3) {
+            fill_matrix<2 * XD, 2 * XD, HID, W1LD, kSceneThreads>(w + a.off_wc1, a.wc1, tid);
+            for (int i = tid; i < HID; i += kSceneThreads) { w[a.off_bc1 + i] = a.bc1[i]; w[a.off_wc2 + i] = a.wc2[i]; }
+        }
     }
     __syncthreads();
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -164,65 +174,166 @@ __global__ __launch_bounds__(kSceneThreads, 2) void scene_graph_kernel(const Sce
             else if (row < N) val = *reinterpret_cast<const f32x4*>(xh + (size_t)(row - 1) * XD + c4);
             *reinterpret_cast<f32x4*>(&Hs[row * XLD + c4]) = val;
         }
-        // G^T = Wa^T X^T   (per column tile: [g = 16gt+4q+r][col n])
-        f32x4 gt_[NT][2];
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-            gt_[ct][0] = zero4();
-            gt_[ct][1] = zero4();
-            load_fence();
-#pragma unroll
-            for (int ft = 0; ft < 2; ++ft) {
-                const f32x4 xb = *reinterpret_cast<const f32x4*>(&Hs[(16 * ct + n) * XLD + 16 * ft + 4 * q]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int g = 0; g < 2; ++g)
-                        gt_[ct][g] = mfma4(wa[(16 * ft + 4 * q + r) * WLD + 16 * g + n], xb[r], gt_[ct][g]);
-            }
-        }
-        // S^T[j][col] = X[j] . G[col]  -> softmax over j, kept in B-operand order (k <-> j = 16jt+4q+r)
+        // adjacency of the node features currently in Hs, transposed and in B-operand order: pr[ct][jt][r] = A[i][j] for
+        // column i = 16 ct + n, j = 16 jt + 4 q + r.  Once per scene, or once per layer for layerwise graphs.
         f32x4 pr[NT][NT];
+        auto adjacency = [&]() {
+            if constexpr (SK == 3) {
+                // concatenation: A_ij = relu(w2 . relu(W1a x_i + W1b x_j + b1) + b2).  P^T = W1a^T X^T and Q^T = W1b^T X^T by MFMA
+                // (lane (n, q) of column tile ct holds hidden units 16 ht + 4 q + r of node 16 ct + n); the pair sum over the 64
+                // hidden units: Q_j of the same q-group arrives as a DPP row_newbcast operand, the four q-groups add up at the end.
+                const float* wc1 = lds + a.off_wc1;      // [64][W1LD]: rows 0..31 act on x_i, rows 32..63 on x_j
+                const float* bc1 = lds + a.off_bc1;
+                const float* wc2 = lds + a.off_wc2;
+                const float bc2 = a.bc2[0];
+                f32x4 pt[NT][4], qt[NT][4];
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-            float mx = -INFINITY;
+                for (int ct = 0; ct < NT; ++ct) {
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt) {
+                    for (int ht = 0; ht < 4; ++ht) {
+                        pt[ct][ht] = *reinterpret_cast<const f32x4*>(&bc1[16 * ht + 4 * q]);      // P carries b1
+                        qt[ct][ht] = zero4();
+                    }
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft) {
+                        load_fence();
+                        const f32x4 xb = *reinterpret_cast<const f32x4*>(&Hs[(16 * ct + n) * XLD + 16 * ft + 4 * q]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int ht = 0; ht < 4; ++ht) {
+                                pt[ct][ht] = mfma4(wc1[(16 * ft + 4 * q + r) * W1LD + 16 * ht + n], xb[r], pt[ct][ht]);
+                                qt[ct][ht] = mfma4(wc1[(XD + 16 * ft + 4 * q + r) * W1LD + 16 * ht + n], xb[r], qt[ct][ht]);
+                            }
+                    }
+                }
+                f32x4 w2h[4];
+#pragma unroll
+                for (int ht = 0; ht < 4; ++ht) w2h[ht] = *reinterpret_cast<const f32x4*>(&wc2[16 * ht + 4 * q]);
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                    for (int jt = 0; jt < NT; ++jt) {
+                        f32x4 res = zero4();
+                        static_for<0, 16>([&](auto jc) {
+                            constexpr int jl = decltype(jc)::value;
+                            float acc = 0.f;
+#pragma unroll
+                            for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    acc = fmaf(fmaxf(dpp_rowbcast_add<jl>(qt[jt][ht][r], pt[ct][ht][r]), 0.f), w2h[ht][r], acc);
+                            acc = fmaxf(kgroups_sum(acc) + bc2, 0.f);
+                            const int j = 16 * jt + jl;
+                            if (j >= N || 16 * ct + n >= N) acc = 0.f;
+                            if ((jl >> 2) == q) res[jl & 3] = acc;
+                        });
+                        pr[ct][jt] = res;
+                    }
+                return;
+            }
+            // G^T = Wa^T X^T   (per column tile: [g = 16gt+4q+r][col n])
+            f32x4 gt_[NT][2];
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                gt_[ct][0] = zero4();
+                gt_[ct][1] = zero4();
                 load_fence();
-                f32x4 sacc = zero4();
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft) {
-                    const f32x4 xa = *reinterpret_cast<const f32x4*>(&Hs[(16 * jt + n) * XLD + 16 * ft + 4 * q]);
+                    const f32x4 xb = *reinterpret_cast<const f32x4*>(&Hs[(16 * ct + n) * XLD + 16 * ft + 4 * q]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sacc = mfma4(xa[r], gt_[ct][ft][r], sacc);
-                }
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = 16 * jt + 4 * q + r;
-                    if (sim != SIM_SOFTMAX) sacc[r] = plain_weight(sim, sacc[r], 16 * ct + n, j);
-                    if (j >= N) sacc[r] = sim == SIM_SOFTMAX ? -INFINITY : 0.f;
-                    mx = fmaxf(mx, sacc[r]);
+                        for (int g = 0; g < 2; ++g)
+                            gt_[ct][g] = mfma4(wa[(16 * ft + 4 * q + r) * WLD + 16 * g + n], xb[r], gt_[ct][g]);
                 }
-                pr[ct][jt] = sacc;
             }
-            mx = kgroups_max(mx);
-            float sum = 0.f;
+            // S^T[j][col] = X[j] . G[col]
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt)
+            for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (sim == SIM_SOFTMAX) pr[ct][jt][r] = __expf(pr[ct][jt][r] - mx);
-                    sum += pr[ct][jt][r];
+                for (int jt = 0; jt < NT; ++jt) {
+                    load_fence();
+                    f32x4 sacc = zero4();
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft) {
+                        const f32x4 xa = *reinterpret_cast<const f32x4*>(&Hs[(16 * jt + n) * XLD + 16 * ft + 4 * q]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sacc = mfma4(xa[r], gt_[ct][ft][r], sacc);
+                    }
+                    pr[ct][jt] = sacc;
                 }
-            sum = kgroups_sum(sum);
-            const float inv = __builtin_amdgcn_rcpf(sum);
+            if (SK == 2) {
+                // cosine family (graph_model.py:70-79): C_ij = S_ij / (m_i m_j), m_i = |S_i,:|_2 (rows of S itself).  Row norm of
+                // column i: over my registers and the four q-groups; m_j of the other index goes through the padding column
+                // 32 of the node-feature rows (XLD = 36).  Padded nodes get 1/m = 0: their rows and columns stay exactly 0.
+                load_fence();
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt)
+                for (int ct = 0; ct < NT; ++ct) {
+                    float z = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pr[ct][jt][r] *= inv;
-        }
+                    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) z = fmaf(pr[ct][jt][r], pr[ct][jt][r], z);
+                    z = kgroups_sum(z);
+                    const float im = (16 * ct + n < N && z > 0.f) ? 1.f / sqrtf(z) : 0.f;
+                    if (q == 0) Hs[(16 * ct + n) * XLD + 32] = im;
+#pragma unroll
+                    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pr[ct][jt][r] *= im;
+                }
+                __builtin_amdgcn_wave_barrier();
+                load_fence();
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float imj = Hs[(16 * jt + 4 * q + r) * XLD + 32];
+#pragma unroll
+                        for (int ct = 0; ct < NT; ++ct) pr[ct][jt][r] *= imj;
+                    }
+                if (sim == SIM_COSINE) return;                   // the cosine matrix itself is the adjacency (not normalised)
+            }
+            // row normalisation: softmax over j (kept in B-operand order), or the plain weights / their row sums
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = 16 * jt + 4 * q + r;
+                        float v = pr[ct][jt][r];
+                        if (SK == 1) v = plain_weight(sim, v, 16 * ct + n, j);
+                        if (j >= N) v = SK == 1 ? 0.f : -INFINITY;
+                        mx = fmaxf(mx, v);
+                        pr[ct][jt][r] = v;
+                    }
+                mx = kgroups_max(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (SK != 1) pr[ct][jt][r] = __expf(pr[ct][jt][r] - mx);
+                        sum += pr[ct][jt][r];
+                    }
+                sum = kgroups_sum(sum);
+                const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pr[ct][jt][r] *= inv;
+            }
+        };
+        if (!a.layerwise) adjacency();
         // layers: H <- relu((A H) W_l) (+ H); every column tile's A*H is taken before any row is overwritten
         for (int l = 0; l < a.L; ++l) {
+            if (a.layerwise) adjacency();
+            const bool last = (l == a.L - 1);
+            const bool rows_only = last && a.rows_out != nullptr;     // value rows: only (A H)[robot] of the last layer is needed
             f32x4 acc[NT][2];
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
@@ -238,13 +349,23 @@ __global__ __launch_bounds__(kSceneThreads, 2) void scene_graph_kernel(const Sce
                     const float a1 = Hs[(16 * jt + 4 * q + r) * XLD + 16 + n];
 #pragma unroll
                     for (int ct = 0; ct < NT; ++ct) {
+                        if (ct > 0 && rows_only) continue;
                         acc[ct][0] = mfma4(a0, pr[ct][jt][r], acc[ct][0]);
                         acc[ct][1] = mfma4(a1, pr[ct][jt][r], acc[ct][1]);
                     }
                 }
             }
+            if (rows_only) {
+                // hand-off row of stage 2 (robot_head_kernel): [ (A H_{L-1})[robot] | H_{L-1}[robot] ]; column 0 of tile 0 = robot
+                float* out = a.rows_out + (size_t)sc * 64;
+                if (n == 0) {
+                    *reinterpret_cast<f32x4*>(out + 4 * q) = acc[0][0];
+                    *reinterpret_cast<f32x4*>(out + 16 + 4 * q) = acc[0][1];
+                }
+                if (lane < 8) *reinterpret_cast<f32x4*>(out + 32 + 4 * lane) = *reinterpret_cast<const f32x4*>(&Hs[4 * lane]);
+                break;
+            }
             const float* wl = ws + l * XD * WLD;
-            const bool last = (l == a.L - 1);
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
                 load_fence();
@@ -263,8 +384,8 @@ __global__ __launch_bounds__(kSceneThreads, 2) void scene_graph_kernel(const Sce
                     for (int r = 0; r < 4; ++r) {
                         float hv = fmaxf(o[ot][r], 0.f);
                         if (a.skip) hv += sk[r];
-                        o[ot][r] = hv;
-                    }
+                        o[ot][r] = 16 * ct + n < N ? hv : 0.f;          // padded node rows stay exactly zero (a softmax row of a
+                    }                                                   // padded node is uniform, not zero; layerwise graphs re-read H)
                     if (!last) *reinterpret_cast<f32x4*>(&Hs[(16 * ct + n) * XLD + 16 * ot + 4 * q]) = o[ot];
                 }
                 if (last) {
@@ -301,6 +422,7 @@ __global__ __launch_bounds__(kSceneThreads, 2) void scene_graph_kernel(const Sce
                     }
                 }
             }
+            __builtin_amdgcn_wave_barrier();      // layerwise: the next adjacency reads the rows written above
         }
     }
 }
@@ -327,7 +449,9 @@ inline int launch_row_mlp2_pair(const RglMlp& wr, const float* robot_rows, float
 
 template <int NT>
 int launch_scene(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* children, hipStream_t st) {
-    auto kern = sa.sim == SIM_SOFTMAX ? scene_graph_kernel<NT, true> : scene_graph_kernel<NT, false>;
+    auto kern = sa.sim == SIM_SOFTMAX ? scene_graph_kernel<NT, 0>
+                : (sa.sim == SIM_COSINE || sa.sim == SIM_COSINE_SOFTMAX ? scene_graph_kernel<NT, 2>
+                   : (sa.sim == SIM_CONCAT ? scene_graph_kernel<NT, 3> : scene_graph_kernel<NT, 1>));
     if (lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_bytes));
@@ -339,6 +463,56 @@ int launch_scene(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* chil
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kSceneThreads), lds_bytes, st, sa, ca, grid);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
+}
+
+static bool scene_kernel_covers(const RglGraph& g, int N) {
+    return fast_path_enabled() && scene_similarity_mode(g) >= 0 && g.x_dim == XD && g.num_layer >= 1 && g.num_layer <= 4 &&
+           mlp_is(g.w_r, 9, HID, XD, true) && mlp_is(g.w_h, 5, HID, XD, true) && N <= 64;
+}
+
+// embeddings (one launch) + one-wave-per-scene graph forward; mh != null: motion head -> humans_next; rows_out != null: value rows
+static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* robot, const float* humans, int crowds_per, int P,
+                             int H, float* humans_next, float* rows_out, float* x0_rows, float* xh_rows,
+                             const ChildrenArgs* ca, hipStream_t stream) {
+    const int N = H + 1, n_crowds = P / crowds_per;
+    int rc = launch_row_mlp2_pair(g.w_r, robot, x0_rows, P, g.w_h, humans, xh_rows, n_crowds * H, stream);
+    if (rc) return rc;
+    SceneArgs sa;
+    sa.xh_rows = xh_rows; sa.x0_rows = x0_rows; sa.crowds_per = crowds_per;
+    sa.wa = bilinear_wa(g);
+    sa.sim = scene_similarity_mode(g);
+    sa.layerwise = g.layerwise_graph;
+    for (int l = 0; l < RGL_MAX_GCN_LAYERS; ++l) sa.Ws[l] = l < g.num_layer ? g.Ws[l] : nullptr;
+    sa.L = g.num_layer; sa.skip = g.skip_connection;
+    sa.wm1 = mh ? mh->weight[0] : nullptr; sa.bm1 = mh ? mh->bias[0] : nullptr;
+    sa.wm2 = mh ? mh->weight[1] : nullptr; sa.bm2 = mh ? mh->bias[1] : nullptr;
+    sa.humans_next = humans_next;
+    sa.rows_out = rows_out;
+    sa.P = P; sa.H = H; sa.N = N;
+    const int NT = (N + 15) / 16;
+    int off = 0;
+    auto take = [&](int nfl) { int o = off; off += (nfl + 3) & ~3; return o; };
+    sa.off_wa = take(XD * WLD);
+    sa.off_ws = take(g.num_layer * XD * WLD);
+    sa.off_wm1 = take(XD * W1LD);
+    sa.off_bm1 = take(HID);
+    sa.off_wm2 = take(HID * M2LD);
+    sa.off_bm2 = take(16);
+    sa.wc1 = sa.bc1 = sa.wc2 = sa.bc2 = nullptr;
+    sa.off_wc1 = sa.off_bc1 = sa.off_wc2 = 0;
+    if (sa.sim == SIM_CONCAT) {
+        sa.wc1 = g.w_a_mlp.weight[0]; sa.bc1 = g.w_a_mlp.bias[0]; sa.wc2 = g.w_a_mlp.weight[1]; sa.bc2 = g.w_a_mlp.bias[1];
+        sa.off_wc1 = take(2 * XD * W1LD); sa.off_bc1 = take(HID); sa.off_wc2 = take(HID);
+    }
+    sa.wave_stride = 16 * NT * XLD;
+    sa.off_wave = take(kSceneWaves * sa.wave_stride);
+    const size_t lds_bytes = (size_t)off * sizeof(float);
+    switch (NT) {
+        case 1: return launch_scene<1>(sa, lds_bytes, ca, stream);
+        case 2: return launch_scene<2>(sa, lds_bytes, ca, stream);
+        case 3: return launch_scene<3>(sa, lds_bytes, ca, stream);
+        default: return launch_scene<4>(sa, lds_bytes, ca, stream);
+    }
 }
 
 }  // namespace
@@ -354,47 +528,39 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
     const RglGraph& g = pl->predictor_graph;
     const RglMlp& mh = pl->motion_head;
     const int N = H + 1;
-    const bool ok = fast_path_enabled() && fast_similarity_mode(g) >= 0 && !g.layerwise_graph && g.x_dim == XD &&
-                    g.num_layer >= 1 && g.num_layer <= 4 && mlp_is(g.w_r, 9, HID, XD, true) && mlp_is(g.w_h, 5, HID, XD, true) &&
-                    mlp_is(mh, XD, HID, 5, false) && N <= 64 && workspace &&
+    const bool ok = scene_kernel_covers(g, N) && mlp_is(mh, XD, HID, 5, false) && workspace &&
                     workspace_bytes >= (size_t)P * N * XD * sizeof(float) && P % crowds_per == 0;
     if (!ok)
         return launch_generic_forward(&g, nullptr, &mh, robot, humans, P, crowds_per, H, nullptr, nullptr, nullptr,
                                       humans_next, stream);
-    const int n_crowds = P / crowds_per;
     float* x0_rows = (float*)workspace;                      // [P][32]
     float* xh_rows = x0_rows + (size_t)P * XD;               // [n_crowds][H][32]
-    int rc = launch_row_mlp2_pair(g.w_r, robot, x0_rows, P, g.w_h, humans, xh_rows, n_crowds * H, stream);
-    if (rc) return rc;
-    SceneArgs sa;
-    sa.xh_rows = xh_rows; sa.x0_rows = x0_rows; sa.crowds_per = crowds_per;
-    sa.wa = bilinear_wa(g);
-    sa.sim = fast_similarity_mode(g);
-    for (int l = 0; l < RGL_MAX_GCN_LAYERS; ++l) sa.Ws[l] = l < g.num_layer ? g.Ws[l] : nullptr;
-    sa.L = g.num_layer; sa.skip = g.skip_connection;
-    sa.wm1 = mh.weight[0]; sa.bm1 = mh.bias[0]; sa.wm2 = mh.weight[1]; sa.bm2 = mh.bias[1];
-    sa.humans_next = humans_next;
-    sa.P = P; sa.H = H; sa.N = N;
-    const int NT = (N + 15) / 16;
-    int off = 0;
-    auto take = [&](int nfl) { int o = off; off += (nfl + 3) & ~3; return o; };
-    sa.off_wa = take(XD * WLD);
-    sa.off_ws = take(g.num_layer * XD * WLD);
-    sa.off_wm1 = take(XD * W1LD);
-    sa.off_bm1 = take(HID);
-    sa.off_wm2 = take(HID * M2LD);
-    sa.off_bm2 = take(16);
-    sa.wave_stride = 16 * NT * XLD;
-    sa.off_wave = take(kSceneWaves * sa.wave_stride);
-    const size_t lds_bytes = (size_t)off * sizeof(float);
-    switch (NT) {
-        case 1: rc = launch_scene<1>(sa, lds_bytes, ca, stream); break;
-        case 2: rc = launch_scene<2>(sa, lds_bytes, ca, stream); break;
-        case 3: rc = launch_scene<3>(sa, lds_bytes, ca, stream); break;
-        default: rc = launch_scene<4>(sa, lds_bytes, ca, stream); break;
-    }
+    const int rc = run_scene_kernels(g, &mh, robot, humans, crowds_per, P, H, humans_next, nullptr, x0_rows, xh_rows, ca, stream);
     if (rc == RGL_OK && ca && children_done) *children_done = 1;
     return rc;
+}
+
+// Value of the children through the one-wave-per-scene kernel: every child's graph in full (no crowd sharing), any of the
+// similarity functions it implements, layerwise graphs, 1..4 layers -- the MFMA path of everything the shared-crowd kernels do
+// not cover (cosine / cosine_softmax scale the columns by child-dependent norms; layerwise graphs rebuild the adjacency from
+// every H_l).  workspace: x0 [P*A][32] | xh [P*H][32] | rows [P*A][64].  1 = outside this kernel's envelope.
+size_t scene_children_workspace_bytes(int P, int A, int H) {
+    return ((size_t)P * A * (XD + 64) + (size_t)P * H * XD) * sizeof(float);
+}
+
+int launch_scene_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
+                          float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const RglGraph& g = pl->value_graph;
+    const int A = pl->num_actions, N = H + 1;
+    if (!scene_kernel_covers(g, N) || head_variant(pl->value_head) < 0 || !workspace ||
+        workspace_bytes < scene_children_workspace_bytes(P, A, H))
+        return 1;
+    float* x0_rows = (float*)workspace;                      // [P*A][32]
+    float* xh_rows = x0_rows + (size_t)P * A * XD;           // [P][H][32]
+    float* rows = xh_rows + (size_t)P * H * XD;              // [P*A][64]
+    int rc = run_scene_kernels(g, nullptr, child_robot, humans_next, A, P * A, H, nullptr, rows, x0_rows, xh_rows, nullptr, stream);
+    if (rc) return rc;
+    return launch_head_rows(&g, &pl->value_head, rows, P * A, child_value, stream);
 }
 
 }  // namespace rgl

@@ -574,6 +574,65 @@ def test_other_similarities_on_the_mfma_path(sim, H, L, D, B, dev):
     check_decisions("similarity %s H=%d L=%d D=%d" % (sim, H, L, D), act, val, (oa, ov, orv, okept), lv)
 
 
+def test_cosine_concatenation_and_layerwise_rollouts_on_the_scene_kernel(dev):
+    """cosine / cosine_softmax / concatenation and layerwise graphs (graph_model.py:70-85,119-122) have no shared-crowd form; their children and
+    state predictor run on the one-wave-per-scene MFMA kernel (value rows + robot_head_kernel).  With RGL_REQUIRE_MFMA_CHILDREN=1 the
+    library refuses to fall back to the general VALU kernel, so passing here proves the MFMA path ran.  Values, predicted humans
+    and whole searches against the oracle."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+from oracle import rgl_oracle as orc
+from tests import golden_io as gio
+from tests.helpers import make_mprl_policy
+from tests.test_gpu_parity import seeded_scenes
+dev = torch.device("cuda:0")
+worst = 0.0
+for sim, layerwise, H, L, D, B, skip in (("cosine", False, 19, 2, 2, 6, True), ("cosine_softmax", False, 19, 2, 2, 6, True),
+                                         ("cosine", False, 5, 2, 1, 17, False), ("cosine_softmax", False, 40, 3, 1, 3, True),
+                                         ("cosine", True, 19, 2, 1, 5, True), ("cosine_softmax", True, 5, 3, 2, 7, True),
+                                         ("embedded_gaussian", True, 19, 2, 2, 6, True), ("gaussian", True, 5, 2, 1, 9, False),
+                                         ("squared", True, 19, 3, 1, 4, True), ("embedded_gaussian", True, 49, 2, 1, 2, True),
+                                         ("equal_attention", True, 7, 2, 1, 5, True), ("embedded_gaussian", True, 5, 1, 1, 8, True),
+                                         ("concatenation", False, 19, 2, 2, 5, True), ("concatenation", False, 5, 2, 1, 11, False),
+                                         ("concatenation", True, 19, 2, 1, 3, True), ("concatenation", True, 7, 3, 2, 4, True),
+                                         ("concatenation", False, 33, 2, 1, 2, True)):
+    pol = make_mprl_policy("trained", D, 2, D > 1, L=L, similarity=sim, layerwise=layerwise, skip=skip, device=dev)
+    pol.build_action_space(1.0)
+    cfg = orc.OracleConfig(num_layer=L, similarity=sim, layerwise_graph=layerwise, skip_connection=skip, planning_depth=D,
+                           planning_width=2, do_action_clip=D > 1)
+    Pm = gio.oracle_params("trained", L, similarity=sim)
+    robot, humans = seeded_scenes(640 + H + L, B, H)
+    ts = pol.tree_search()
+    A = ts.num_actions
+    acts, _ = orc.mprl_action_space(orc.OracleConfig(), 1.0)
+    cr = orc._children_robot(robot, acts, orc.OracleConfig())
+    got = ts.value_children(cr.to(dev), humans.to(dev)).cpu().numpy()
+    with torch.no_grad():
+        want = orc.value_estimator_forward(cr.reshape(B * A, 1, 9), humans[:, None].expand(B, A, H, 5).reshape(B * A, H, 5),
+                                           Pm.ve_graph, Pm.value_network, cfg).numpy().reshape(B, A)
+        hn = orc.state_predictor_humans(robot[:, None], humans, Pm.sp_graph, Pm.motion_predictor, cfg).numpy()
+        oa, ov, orv, okept = orc.mprl_predict_batched(robot, humans, Pm, cfg)
+    err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
+    assert err < 1e-4, (sim, layerwise, H, L, "children", err)
+    ex = ts.expand(robot.to(dev), humans.to(dev), parents_are_joint_states=True)
+    e2 = np.abs(ex["humans_next"].cpu().numpy() - hn).max() / max(1.0, np.abs(hn).max())
+    assert e2 < 1e-4, (sim, layerwise, H, L, "state predictor", e2)
+    act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
+    e3 = float((val.cpu() - ov).abs().max()) / max(1.0, float(ov.abs().max()))
+    assert e3 < 1e-4, (sim, layerwise, H, L, "search", e3)
+    worst = max(worst, err, e2, e3)
+print("OK worst relative error %.2e" % worst)
+'''
+    env = dict(os.environ, RGL_REQUIRE_MFMA_CHILDREN="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+    report("scene-kernel rollouts (cosine family, concatenation, layerwise): " + out.stdout.strip().splitlines()[-1])
+
+
 @pytest.mark.parametrize("speeds,rots,H,L", [(3, 8, 19, 2), (5, 19, 5, 2), (6, 16, 19, 2), (2, 4, 49, 3), (1, 1, 7, 2),
                                              (15, 17, 5, 2)])
 def test_non_default_action_spaces(speeds, rots, H, L, dev):
