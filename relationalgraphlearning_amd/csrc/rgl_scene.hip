@@ -85,20 +85,29 @@ struct SceneArgs {
 };
 
 constexpr int M2LD = 20;   // LDS row stride of the [64][5 -> 16] motion output layer (4*M2LD % 32 == 16)
-// 8 waves share one 30 KB weight image; two workgroups per CU = 4 waves per SIMD.  (Round 1 ran 4-wave workgroups, 2 waves per
-// SIMD: a scene is one serial chain of ~290 MFMAs with a softmax in the middle, and two waves did not cover its latencies --
-// MFMA-busy 29 % at 4096 scenes.)
-constexpr int kSceneThreads = 512, kSceneWaves = kSceneThreads / 64;
+// N <= 32: 8 waves share one 30 KB weight image, two workgroups per CU = 4 waves per SIMD (round 1 ran 4-wave workgroups, 2 waves
+// per SIMD: a scene is one serial chain of ~290 MFMAs with a softmax in the middle, and two waves did not cover its latencies).
+// Larger crowds (3-4 column tiles: 200+ VGPRs, 9 KB of node features per wave) keep 4-wave workgroups, two per CU.
 
-// One scene per wave.  The level's independent next-robot-state / reward work (children_thread, float64 VALU) rides in the same
-// launch: scene s IS parent s of the level, so the wave that owns it first runs the parent's actions (lanes = actions; the
-// parent's rows are wave-uniform: scalar loads).  (Round 1 put that work on EXTRA workgroups of the launch; they reserve the
-// same dynamic LDS as the scene workgroups, so they could only start when a persistent scene workgroup retired -- the two halves
-// of the launch ran one after the other, and one thread per (parent, action) re-read the crowd through vector loads.)
+// One scene per wave.  CH = true: the level's independent next-robot-state / reward work (float64 VALU) rides in this launch on
+// EXTRA workgroups [grid_scene, gridDim.x).  That pays while the scene workgroups leave LDS free (few scenes: the two halves
+// overlap and a launch is saved); with many scenes the extra workgroups -- which reserve the same dynamic LDS -- only start when
+// a scene workgroup retires, and the second code path costs the kernel a third of its occupancy in registers: the launcher then
+// uses CH = false and the caller launches mprl_children_kernel (measured cross-over ~3 k scenes; an in-wave variant, lanes =
+// actions with scalar crowd loads, was tried and was never better).
 // SK: 0 = softmax of S (embedded_gaussian / gaussian), 1 = plain weights over their row sum (squared / equal_attention /
 // diagonal), 2 = cosine family (cosine / cosine_softmax; graph_model.py:70-79), 3 = concatenation (pair MLP, :80-85)
-template <int NT, int SK>
-__global__ __launch_bounds__(kSceneThreads, 2) void scene_graph_kernel(const SceneArgs a, const ChildrenArgs ca, int grid_scene) {
+template <int NT, int SK, int WAVES, bool CH>
+__global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneArgs a, const ChildrenArgs ca, int grid_scene) {
+    constexpr int kSceneThreads = WAVES * 64, kSceneWaves = WAVES;
+    if constexpr (CH) {
+        if ((int)blockIdx.x >= grid_scene) {
+            const long long total = (long long)ca.P * ca.A, stride = (long long)(gridDim.x - grid_scene) * kSceneThreads;
+            for (long long idx = (long long)(blockIdx.x - grid_scene) * kSceneThreads + threadIdx.x; idx < total; idx += stride)
+                children_thread(ca, idx);
+            return;
+        }
+    }
     const int sim = SK == 0 ? (int)SIM_SOFTMAX : a.sim;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -162,8 +171,6 @@ __global__ __launch_bounds__(kSceneThreads, 2) void scene_graph_kernel(const Sce
     __syncthreads();
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     for (int sc = blockIdx.x + grid_scene * wave_u; sc < a.P; sc += grid_scene * kSceneWaves) {      // partial round: one per WG
-        if (ca.child_robot)
-            for (int act = lane; act < ca.A; act += 64) children_pa(ca, sc, act);
         // node features of this scene: row 0 = robot, rows 1..H = its crowd, rows >= N zero
         const float* xr = a.x0_rows + (size_t)sc * XD;
         const float* xh = a.xh_rows + (size_t)(sc / a.crowds_per) * H * XD;
@@ -447,23 +454,38 @@ inline int launch_row_mlp2_pair(const RglMlp& wr, const float* robot_rows, float
     return RGL_OK;
 }
 
-template <int NT>
-int launch_scene(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* children, hipStream_t st) {
-    auto kern = sa.sim == SIM_SOFTMAX ? scene_graph_kernel<NT, 0>
-                : (sa.sim == SIM_COSINE || sa.sim == SIM_COSINE_SOFTMAX ? scene_graph_kernel<NT, 2>
-                   : (sa.sim == SIM_CONCAT ? scene_graph_kernel<NT, 3> : scene_graph_kernel<NT, 1>));
+template <int NT, int SK, int WAVES>
+int launch_scene_k(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* children, hipStream_t st) {
+    int grid = (sa.P + WAVES - 1) / WAVES;
+    const int cap = 256 * (lds_bytes * 2 <= (size_t)rgl::kLdsBytesPerCu ? 2 : 1) * (WAVES == 4 ? 2 : 1);
+    if (grid > cap) grid = cap;
+    ChildrenArgs ca{};
+    int grid_children = 0;
+    if (children) {
+        ca = *children;
+        const long long blocks = ((long long)ca.P * ca.A + WAVES * 64 - 1) / (WAVES * 64);
+        grid_children = (int)(blocks < 2048 ? blocks : 2048);
+    }
+    auto kern = children ? scene_graph_kernel<NT, SK, WAVES, true> : scene_graph_kernel<NT, SK, WAVES, false>;
     if (lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_bytes));
-    int grid = (sa.P + kSceneWaves - 1) / kSceneWaves;
-    const int cap = 256 * (lds_bytes * 2 <= (size_t)rgl::kLdsBytesPerCu ? 2 : 1);      // resident workgroups: persistent
-    if (grid > cap) grid = cap;
-    ChildrenArgs ca{};                       // child_robot == nullptr: no such work in this launch
-    if (children) ca = *children;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSceneThreads), lds_bytes, st, sa, ca, grid);
+    hipLaunchKernelGGL(kern, dim3(grid + grid_children), dim3(WAVES * 64), lds_bytes, st, sa, ca, grid);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }
+
+template <int NT, int WAVES>
+int launch_scene(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* children, hipStream_t st) {
+    if (sa.sim == SIM_SOFTMAX) return launch_scene_k<NT, 0, WAVES>(sa, lds_bytes, children, st);
+    if (sa.sim == SIM_COSINE || sa.sim == SIM_COSINE_SOFTMAX) return launch_scene_k<NT, 2, WAVES>(sa, lds_bytes, children, st);
+    if (sa.sim == SIM_CONCAT) return launch_scene_k<NT, 3, WAVES>(sa, lds_bytes, children, st);
+    return launch_scene_k<NT, 1, WAVES>(sa, lds_bytes, children, st);
+}
+
+}  // namespace
+
+namespace {
 
 static bool scene_kernel_covers(const RglGraph& g, int N) {
     return fast_path_enabled() && scene_similarity_mode(g) >= 0 && g.x_dim == XD && g.num_layer >= 1 && g.num_layer <= 4 &&
@@ -505,13 +527,13 @@ static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* r
         sa.off_wc1 = take(2 * XD * W1LD); sa.off_bc1 = take(HID); sa.off_wc2 = take(HID);
     }
     sa.wave_stride = 16 * NT * XLD;
-    sa.off_wave = take(kSceneWaves * sa.wave_stride);
+    sa.off_wave = take((NT <= 2 ? 8 : 4) * sa.wave_stride);
     const size_t lds_bytes = (size_t)off * sizeof(float);
     switch (NT) {
-        case 1: return launch_scene<1>(sa, lds_bytes, ca, stream);
-        case 2: return launch_scene<2>(sa, lds_bytes, ca, stream);
-        case 3: return launch_scene<3>(sa, lds_bytes, ca, stream);
-        default: return launch_scene<4>(sa, lds_bytes, ca, stream);
+        case 1: return launch_scene<1, 8>(sa, lds_bytes, ca, stream);
+        case 2: return launch_scene<2, 8>(sa, lds_bytes, ca, stream);
+        case 3: return launch_scene<3, 4>(sa, lds_bytes, ca, stream);
+        default: return launch_scene<4, 4>(sa, lds_bytes, ca, stream);
     }
 }
 
@@ -535,6 +557,7 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
                                       humans_next, stream);
     float* x0_rows = (float*)workspace;                      // [P][32]
     float* xh_rows = x0_rows + (size_t)P * XD;               // [n_crowds][H][32]
+    if (ca && P >= 3072) ca = nullptr;     // many scenes: the caller launches mprl_children_kernel (see scene_graph_kernel)
     const int rc = run_scene_kernels(g, &mh, robot, humans, crowds_per, P, H, humans_next, nullptr, x0_rows, xh_rows, ca, stream);
     if (rc == RGL_OK && ca && children_done) *children_done = 1;
     return rc;
