@@ -1,8 +1,9 @@
 """GPU parity: the HIP path (through the C ABI) against the golden fixtures and the CPU oracle.
 
 Tolerance (north star): |value_gpu - value_ref| <= 1e-4 in fp32 on identical crowd states; written
-here as 1e-4 * max(1, max|ref|) so the random-init weight sets (values of order 10..100) are held to
-the same relative bar.  Integer results (actions, kept sets) and fp32-exact kinematics must be equal.
+here as 1e-4 * max(1, max|ref|): for VALUES the factor is 1 everywhere (|V| < 1 with both weight sets; the
+absolute error of the raw random-init set is logged in the parity report), the factor matters for the hidden
+features H_L of the raw random-init weights (order 10..100), held to the same relative bar.  Integer results (actions, kept sets) and fp32-exact kinematics must be equal.
 """
 import numpy as np
 import pytest
