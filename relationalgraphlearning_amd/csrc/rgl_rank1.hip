@@ -45,7 +45,6 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int nthreads = a.n_waves * 64;
     const int n = lane & 15, q = lane >> 4;
     const int N = a.N, H = a.H, A = a.A, SLD = a.SLD;
     const float* wh1 = lds + a.off_wh1;   // [8][W1LD], rows 5..7 zero
@@ -69,32 +68,45 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
     auto crowd_msh = [&](int b) { return lds + a.off_crowd + b * a.crowd_stride + 3 * 16 * NT * XLD; };
     auto crowd_zsh = [&](int b) { return lds + a.off_crowd + b * a.crowd_stride + 3 * 16 * NT * XLD + 16 * NT; };
 
-    {   // weight image, once per workgroup
+    {   // weight image, once per workgroup, in two phases -- every global load of the thread first, then the LDS stores -- so the
+        // 34 KB image costs ONE L2 round trip (matrix by matrix it cost one per matrix: several us of a small launch)
         float* w = lds;
-#pragma unroll 4
-        for (int i = tid; i < 8 * HID; i += nthreads) {
-            const int r = i / HID, c = i - r * HID;
-            w[a.off_wh1 + r * W1LD + c] = r < 5 ? a.wh1[i] : 0.f;
+        constexpr int NTHR = 512;                      // the kernel is always launched with 8 waves
+        constexpr int K2 = HID * XD / NTHR, KQ = XD * XD / NTHR;
+        float v_wh2[K2], v_wr2[K2], v_wa[KQ], v_w1[KQ], v_wh1, v_wr1[2], v_b[4];
+#pragma unroll
+        for (int k = 0; k < K2; ++k) { v_wh2[k] = a.wh2[tid + k * NTHR]; v_wr2[k] = a.wr2[tid + k * NTHR]; }
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+            const int i = tid + k * NTHR;
+            v_wa[k] = a.wa ? a.wa[i] : ((i / XD) == (i % XD) ? 1.f : 0.f);       // gaussian: Wa = I
+            v_w1[k] = a.w1[i];
         }
-        for (int i = tid; i < HID; i += nthreads) { w[a.off_bh1 + i] = a.bh1[i]; w[a.off_br1 + i] = a.br1[i]; }
-        for (int i = tid; i < XD; i += nthreads) { w[a.off_bh2 + i] = a.bh2[i]; w[a.off_br2 + i] = a.br2[i]; }
-#pragma unroll 4
-        for (int i = tid; i < HID * XD; i += nthreads) {
-            const int r = i / XD, c = i - r * XD;
-            w[a.off_wh2 + r * WLD + c] = a.wh2[i];
-            w[a.off_wr2 + r * WLD + c] = a.wr2[i];
+        v_wh1 = tid < 5 * HID ? a.wh1[tid] : 0.f;                                // [8][W1LD], rows 5..7 zero
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { const int i = tid + k * NTHR; v_wr1[k] = i < 9 * HID ? a.wr1[i] : 0.f; }   // [12][W1LD], rows 9..11 zero
+        v_b[0] = tid < HID ? a.bh1[tid] : 0.f; v_b[1] = tid < HID ? a.br1[tid] : 0.f;
+        v_b[2] = tid < XD ? a.bh2[tid] : 0.f;  v_b[3] = tid < XD ? a.br2[tid] : 0.f;
+#pragma unroll
+        for (int k = 0; k < K2; ++k) {
+            const int i = tid + k * NTHR, r = i / XD, c = i - r * XD;
+            w[a.off_wh2 + r * WLD + c] = v_wh2[k];
+            w[a.off_wr2 + r * WLD + c] = v_wr2[k];
         }
-#pragma unroll 4
-        for (int i = tid; i < XD * XD; i += nthreads) {
-            const int r = i / XD, c = i - r * XD;
-            w[a.off_wa + r * WLD + c] = a.wa ? a.wa[i] : (r == c ? 1.f : 0.f);   // gaussian: Wa = I
-            w[a.off_w1 + r * WLD + c] = a.w1[i];
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+            const int i = tid + k * NTHR, r = i / XD, c = i - r * XD;
+            w[a.off_wa + r * WLD + c] = v_wa[k];
+            w[a.off_w1 + r * WLD + c] = v_w1[k];
         }
-#pragma unroll 4
-        for (int i = tid; i < 12 * HID; i += nthreads) {
-            const int r = i / HID, c = i - r * HID;
-            w[a.off_wr1 + r * W1LD + c] = r < 9 ? a.wr1[i] : 0.f;
+        { const int r = tid / HID, c = tid - r * HID; w[a.off_wh1 + r * W1LD + c] = v_wh1; }             // 8 x 64 = 512 entries
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + k * NTHR, r = i / HID, c = i - r * HID;
+            if (i < 12 * HID) w[a.off_wr1 + r * W1LD + c] = v_wr1[k];
         }
+        if (tid < HID) { w[a.off_bh1 + tid] = v_b[0]; w[a.off_br1 + tid] = v_b[1]; }
+        if (tid < XD) { w[a.off_bh2 + tid] = v_b[2]; w[a.off_br2 + tid] = v_b[3]; }
     }
     __syncthreads();
 
@@ -229,13 +241,74 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
         *reinterpret_cast<f32x4*>(&UW[node * XLD + 16 + 4 * q]) = uw[1];
     };
 
+    // embedding of my 16 children of parent p: x0 = w_r(robot'), y = x0 W1 -> Y0, g0 = x0 Wa, s00 = g0 . x0  (registers of the wave)
+    f32x4 xacc[2], gacc[2];
+    float s00 = 0.f;
+    const int c = 16 * wave + n;              // meaningful for child waves only
+    auto embed1 = [&](int p) {
+        xacc[0] = xacc[1] = gacc[0] = gacc[1] = zero4();
+        s00 = 0.f;
+        const int cc = c < A ? c : A - 1;
+        const float* rr = a.child_robot + ((size_t)p * A + cc) * 9;
+        f32x4 hacc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int k = 4 * s + q;
+            const float b = k < 9 ? rr[k] : 0.f;
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wr1[k * W1LD + 16 * ht + n], b, hacc[ht]);
+        }
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(&br1[16 * ht + 4 * q]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hacc[ht][r] = relu1(hacc[ht][r] + bb[r]);
+        }
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            load_fence();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+                    xacc[ot] = mfma4(wr2[(16 * ht + 4 * q + r) * WLD + 16 * ot + n], hacc[ht][r], xacc[ot]);
+        }
+        load_fence();
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(&br2[16 * ot + 4 * q]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xacc[ot][r] = relu1(xacc[ot][r] + bb[r]);
+        }
+        f32x4 yacc[2] = {zero4(), zero4()};
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+            load_fence();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int gt = 0; gt < 2; ++gt) {
+                    gacc[gt] = mfma4(wa[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], gacc[gt]);
+                    yacc[gt] = mfma4(w1[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], yacc[gt]);
+                }
+        }
+        load_fence();
+        *reinterpret_cast<f32x4*>(&Y0[c * XLD + 4 * q]) = yacc[0];
+        *reinterpret_cast<f32x4*>(&Y0[c * XLD + 16 + 4 * q]) = yacc[1];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s00 = fmaf(gacc[t][r], xacc[t][r], s00);
+        s00 = kgroups_sum(s00);
+    };
     PHASE_START();
     int buf = 0;
     int* crowd_flag = reinterpret_cast<int*>(lds + a.off_flag);      // [NT] epoch reached by each crowd wave's part 1
     int crowd_epoch = 0;
     if (tid < NT) crowd_flag[tid] = 0;
-    if ((int)blockIdx.x < a.P) {               // prime the pipeline: crowd block of the first parent
+    if ((int)blockIdx.x < a.P) {               // prime the pipeline: crowd block of the first parent || its children's embedding
         if (crowd_wave) prologue1(blockIdx.x, 0);
+        else if (child_wave) embed1(blockIdx.x);
         __syncthreads();
         if (crowd_wave) prologue2(0);
         __syncthreads();
@@ -246,64 +319,10 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
         const float* Xh = crowd_xh(buf);
         const float* Gm = crowd_gm(buf);
         // ---------------- embedding phase, first half: x0, y = x0 W1, g0 = x0 Wa  ||  prologue1(next parent) -----
-        f32x4 xacc[2] = {zero4(), zero4()}, gacc[2] = {zero4(), zero4()};
         f32x4 t0h[2] = {zero4(), zero4()};        // child waves: (p_c Xh)^T of my 16 children, from embed-2 to the robot-row pass
         float p00 = 0.f;                          // A_c[0][0]
-        const int c = 16 * wave + n;              // meaningful for child waves only
-        float s00 = 0.f;
         if (child_wave) {
-            const int cc = c < A ? c : A - 1;
-            const float* rr = a.child_robot + ((size_t)p * A + cc) * 9;
-            f32x4 hacc[4] = {zero4(), zero4(), zero4(), zero4()};
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int k = 4 * s + q;
-                const float b = k < 9 ? rr[k] : 0.f;
-#pragma unroll
-                for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wr1[k * W1LD + 16 * ht + n], b, hacc[ht]);
-            }
-#pragma unroll
-            for (int ht = 0; ht < 4; ++ht) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(&br1[16 * ht + 4 * q]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) hacc[ht][r] = relu1(hacc[ht][r] + bb[r]);
-            }
-#pragma unroll
-            for (int ht = 0; ht < 4; ++ht) {
-                load_fence();
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int ot = 0; ot < 2; ++ot)
-                        xacc[ot] = mfma4(wr2[(16 * ht + 4 * q + r) * WLD + 16 * ot + n], hacc[ht][r], xacc[ot]);
-            }
-            load_fence();
-#pragma unroll
-            for (int ot = 0; ot < 2; ++ot) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(&br2[16 * ot + 4 * q]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xacc[ot][r] = relu1(xacc[ot][r] + bb[r]);
-            }
-            f32x4 yacc[2] = {zero4(), zero4()};
-#pragma unroll
-            for (int ot = 0; ot < 2; ++ot) {
-                load_fence();
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int gt = 0; gt < 2; ++gt) {
-                        gacc[gt] = mfma4(wa[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], gacc[gt]);
-                        yacc[gt] = mfma4(w1[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], yacc[gt]);
-                    }
-            }
-            load_fence();
-            *reinterpret_cast<f32x4*>(&Y0[c * XLD + 4 * q]) = yacc[0];
-            *reinterpret_cast<f32x4*>(&Y0[c * XLD + 16 + 4 * q]) = yacc[1];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s00 = fmaf(gacc[t][r], xacc[t][r], s00);
-            s00 = kgroups_sum(s00);
+            if (p != (int)blockIdx.x) embed1(p);       // the first parent's embedding ran under the crowd prologue that primed the pipeline
         } else if (crowd_wave && pn < a.P) {
             prologue1(pn, buf ^ 1);
         }

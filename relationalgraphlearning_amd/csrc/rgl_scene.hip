@@ -56,8 +56,8 @@ __global__ __launch_bounds__(kThreads, 2) void row_mlp2_pair_kernel(const RowMlp
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool first = (int)blockIdx.x < grid_a;
     const RowMlpArgs& a = first ? ra : rb;
-    if (first) fill_frags<9, HID>(lds + F1, a.w1, tid); else fill_frags<5, HID>(lds + F1, a.w1, tid);
-    fill_frags<HID, XD>(lds + F2, a.w2, tid);
+    if (first) fill_frags<9, HID, kThreads>(lds + F1, a.w1, tid); else fill_frags<5, HID, kThreads>(lds + F1, a.w1, tid);
+    fill_frags<HID, XD, kThreads>(lds + F2, a.w2, tid);
     fill_bias<HID>(lds + B1, a.b1, tid);
     fill_bias<XD>(lds + B2, a.b2, tid);
     __syncthreads();

@@ -92,14 +92,13 @@ class ModelPredictiveRL(Policy):
         self.kinematics = None
         self.epsilon = None
         self.gamma = None
-        self.sampling = None
         self.speed_samples = None
         self.rotation_samples = None
         self.action_space = None
         self.rotation_constraint = None
-        self.speeds = None
+        self.speeds = None                  # read by CrowdSim.render (crowd_sim.py:601-602), like rotations
         self.rotations = None
-        self.action_values = None
+        self.action_values = None           # crowd_sim.py:332
         self.robot_state_dim = 9
         self.human_state_dim = 5
         self.v_pref = 1
@@ -111,7 +110,6 @@ class ModelPredictiveRL(Policy):
         self.planning_width = None
         self.do_action_clip = None
         self.sparse_search = None
-        self.sparse_speed_samples = 2
         self.sparse_rotation_samples = 8
         self.action_group_index = []
         self._traj = None
@@ -157,7 +155,6 @@ class ModelPredictiveRL(Policy):
         self.gamma = config.rl.gamma
         a = config.action_space
         self.kinematics = a.kinematics
-        self.sampling = a.sampling
         self.speed_samples = a.speed_samples
         self.rotation_samples = a.rotation_samples
         self.rotation_constraint = a.rotation_constraint
@@ -311,7 +308,6 @@ class GCN(Policy):
         self.kinematics = None
         self.epsilon = None
         self.gamma = None
-        self.sampling = None
         self.speed_samples = None
         self.rotation_samples = None
         self.query_env = None
@@ -320,10 +316,6 @@ class GCN(Policy):
         self.speeds = None
         self.rotations = None
         self.action_values = None
-        self.with_om = None
-        self.cell_num = None
-        self.cell_size = None
-        self.om_channel_size = None
         self.self_state_dim = 6
         self.human_state_dim = 7
         self.joint_state_dim = self.self_state_dim + self.human_state_dim
@@ -344,17 +336,13 @@ class GCN(Policy):
         self.gamma = config.rl.gamma
         a = config.action_space
         self.kinematics = a.kinematics
-        self.sampling = a.sampling
         self.speed_samples = a.speed_samples
         self.rotation_samples = a.rotation_samples
         self.query_env = a.query_env
         self.rotation_constraint = a.rotation_constraint
-        self.cell_num = config.om.cell_num
-        self.cell_size = config.om.cell_size
-        self.om_channel_size = config.om.om_channel_size
 
     def input_dim(self):
-        return self.joint_state_dim        # occupancy maps are never enabled for this policy (with_om stays None)
+        return self.joint_state_dim        # occupancy maps are never enabled for this policy upstream (gcn.py:131-157)
 
     def set_device(self, device):
         self.device = device
