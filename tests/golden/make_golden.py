@@ -779,6 +779,103 @@ def gen_explorer_kats(masters, out):
         del JointState.self_state
 
 
+def gen_trainer_kats(masters, out):
+    """The reference MPRLTrainer.optimize_batch (crowd_nav/utils/trainer.py:110-161) on the reference modules: three batches of 16
+    seeded transitions, Adam, frozen target copy, with and without detach_state_predictor.  skip_connection=False: the reference's
+    RGL.forward adds the skip in place (`next_H += H`), which current torch autograd refuses, so upstream training only runs
+    without it.  The loader is injected un-shuffled so that the batch order is part of the fixture."""
+    from crowd_nav.utils.trainer import MPRLTrainer
+    from crowd_nav.utils.memory import ReplayMemory
+    from torch.utils.data import DataLoader
+
+    class Writer(object):
+        def add_scalar(self, *a, **k):
+            pass
+    rng = np.random.RandomState(31)
+    n = 48
+    robot, humans = synth_scene(rng, n, 5)
+    robot2, humans2 = synth_scene(rng, n, 5)
+    rewards = rng.uniform(-0.25, 1.0, (n, 1)).astype(np.float32)
+    out["tr.robot"], out["tr.humans"], out["tr.next_robot"], out["tr.next_humans"], out["tr.rewards"] = robot, humans, robot2, humans2, rewards
+    meta = []
+    for tag, detach in (("plain", False), ("detach", True)):
+        torch.manual_seed(0)
+        pc, g1, g2, ve, sp = build_ref_modules(masters["trained"], 2, "embedded_gaussian", False, False)
+        memory = ReplayMemory(1000)
+        for i in range(n):
+            memory.push((torch.tensor(robot[i:i + 1]), torch.tensor(humans[i]), torch.zeros(1), torch.tensor(rewards[i]),
+                         torch.tensor(robot2[i:i + 1]), torch.tensor(humans2[i])))
+        tr = MPRLTrainer(ve, sp, memory, torch.device("cpu"), None, Writer(), 16, "Adam", 5, False, False, detach, False)
+        tr.set_learning_rate(1e-3)
+        tr.update_target_model(ve)
+        tr.data_loader = DataLoader(memory, 16, shuffle=False)
+        with torch.enable_grad():
+            v_loss, s_loss = tr.optimize_batch(2, 0)            # batch_count > num_batches: three batches are consumed
+        out["tr.%s.losses" % tag] = np.array([v_loss, s_loss], np.float64)
+        for name, mod in (("graph_model1", ve.graph_model), ("value_network", ve.value_network), ("graph_model2", sp.graph_model),
+                          ("motion_predictor", sp.human_motion_predictor)):
+            out.update(flat("tr.%s.%s." % (tag, name), mod.state_dict()))
+        meta.append("%s|%d" % (tag, int(detach)))
+    out["trainer_cases"] = np.array(meta)
+    policy_config(gcn__skip_connection=True)                     # restore the class-level config attribute
+
+
+def gen_query_env_kats(pg_fixture, out):
+    """Path G with query_env=True (multi_human_rl.py:43-44) on the reference simulator with `linear` humans: per action the next
+    human states and the reward come from env.onestep_lookahead.  States a few steps into seeded test cases; recorded: the full
+    simulator state (float64), human goals and preferred speeds, the 81 action values and the chosen action."""
+    import gym
+    from crowd_sim.envs.utils.robot import Robot
+    JointState.self_state = property(lambda self_: self_.robot_state)
+    mod = importlib.import_module("crowd_nav.configs.icra_benchmark.mp_separate")
+    envc = mod.EnvConfig()
+    old_policy, old_central = envc.humans.policy, envc.sim.centralized_planning
+    envc.humans.policy = "linear"
+    envc.sim.centralized_planning = False
+    try:
+        env = gym.make("CrowdSim-v0")
+        env.configure(envc)
+        robot = Robot(envc, "robot")
+        robot.time_step = env.time_step
+        pol = policy_factory["gcn"]()
+        pc = policy_config("rgl")
+        pol.configure(pc)
+        pol.model.load_state_dict({k[len("g.weights."):]: torch.tensor(v) for k, v in pg_fixture.items() if k.startswith("g.weights.")})
+        pol.set_phase("test")
+        pol.set_device(torch.device("cpu"))
+        pol.time_step = env.time_step
+        pol.query_env = True
+        robot.set_policy(pol)
+        env.set_robot(robot)
+        pol.set_env(env)
+        R, Hs, goals, vpref, avals, acts, times = [], [], [], [], [], [], []
+        for case, steps in ((0, 0), (1, 6), (2, 14), (4, 9)):
+            ob = env.reset("test", case)
+            for _ in range(steps):
+                ob, _, done, _ = env.step(ActionXY(np.float64(0.0), np.float64(0.7)))
+            js = JointState(robot.get_full_state(), ob)
+            with torch.no_grad():
+                a = pol.predict(js)
+            R.append(robot.get_full_state().to_tuple())
+            Hs.append([h.get_full_state().to_tuple() for h in env.humans])
+            goals.append([(h.gx, h.gy) for h in env.humans])
+            vpref.append([h.v_pref for h in env.humans])
+            avals.append(pol.action_values)
+            acts.append([i for i, x in enumerate(pol.action_space) if x is a][0])
+            times.append(env.global_time)
+        out["qe.robot"] = np.array(R, np.float64)
+        out["qe.humans_full"] = np.array(Hs, np.float64)            # (cases, H, 9) FullState of every human
+        out["qe.human_goals"] = np.array(goals, np.float64)
+        out["qe.human_vpref"] = np.array(vpref, np.float64)
+        out["qe.action_values"] = np.array(avals, np.float64)
+        out["qe.action"] = np.array(acts, np.int64)
+        out["qe.time"] = np.array(times, np.float64)
+    finally:
+        envc.humans.policy, envc.sim.centralized_planning = old_policy, old_central
+        del JointState.self_state
+        policy_config("rgl", action_space__query_env=False)
+
+
 def main():
     global HERE
     if len(sys.argv) > 1:                       # optional output directory (regeneration checks write to a scratch dir)
@@ -815,6 +912,10 @@ def main():
     ex = {}
     gen_explorer_kats(masters, ex)
     np.savez(os.path.join(HERE, "explorer.npz"), **ex)
+    tq = {}
+    gen_trainer_kats(masters, tq)
+    gen_query_env_kats(pg, tq)
+    np.savez(os.path.join(HERE, "training_queryenv.npz"), **tq)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-24s %8.1f KB" % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))

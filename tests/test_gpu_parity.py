@@ -1138,5 +1138,78 @@ def test_backward_refuses_stale_parameters_and_state_gradients(dev):
         rga.TreeSearch(ve, None, np.zeros((3, 2)), [0, 64, 1])
 
 
+@pytest.mark.parametrize("tag", ["plain", "detach"])
+def test_training_against_the_reference_trainer_fixture(tag, dev):
+    """Fixture training_queryenv.npz: the REFERENCE MPRLTrainer.optimize_batch (crowd_nav/utils/trainer.py:110-161) ran three
+    un-shuffled batches of 16 transitions on the reference modules (Adam 1e-3, frozen target copy; skip_connection=False, the only
+    way upstream trains on current torch).  The same loop on the product's modules (forward + rgl_graph_backward_f32 on the GPU) must
+    end at the same parameters and report the same losses."""
+    import copy
+    fx = gio.load("training_queryenv")
+    c = dict(L=2, sim="embedded_gaussian", layerwise=False, skip=False, flavour="trained")
+    _, ve, sp = build_modules(c, dev)
+    detach = tag == "detach"
+    target = copy.deepcopy(ve)
+    v_opt = torch.optim.Adam(ve.parameters(), lr=1e-3)
+    s_opt = torch.optim.Adam(sp.parameters(), lr=1e-3)
+    crit = torch.nn.MSELoss()
+    gamma_bar = pow(0.9, 0.25 * 1)
+    v_losses = s_losses = 0.0
+    for b in range(3):
+        sl = slice(16 * b, 16 * b + 16)
+        r = torch.tensor(fx["tr.robot"][sl]).unsqueeze(1).to(dev)
+        h = torch.tensor(fx["tr.humans"][sl]).to(dev)
+        r2 = torch.tensor(fx["tr.next_robot"][sl]).unsqueeze(1).to(dev)
+        h2 = torch.tensor(fx["tr.next_humans"][sl]).to(dev)
+        rew = torch.tensor(fx["tr.rewards"][sl]).to(dev)
+        v_opt.zero_grad()
+        out = ve((r, h))
+        tgt = rew + gamma_bar * target((r2, h2))
+        loss = crit(out, tgt)
+        loss.backward()
+        v_opt.step()
+        v_losses += float(loss.detach())
+        s_opt.zero_grad()
+        _, nh = sp((r, h), None, detach=detach)
+        loss = crit(nh, h2)
+        loss.backward()
+        s_opt.step()
+        s_losses += float(loss.detach())
+    want_v, want_s = fx["tr.%s.losses" % tag]                       # the reference divides by num_batches = 2
+    assert abs(v_losses / 2 - want_v) <= 1e-5 * max(1.0, abs(want_v)) and abs(s_losses / 2 - want_s) <= 1e-5 * max(1.0, abs(want_s))
+    worst = 0.0
+    for name, mod in (("graph_model1", ve.graph_model), ("value_network", ve.value_network), ("graph_model2", sp.graph_model),
+                      ("motion_predictor", sp.human_motion_predictor)):
+        for k, v in mod.state_dict().items():
+            want = fx["tr.%s.%s.%s" % (tag, name, k)]
+            err = float(np.abs(v.cpu().numpy() - want).max())
+            worst = max(worst, err)
+            assert err <= 2e-5, (name, k, err)           # three Adam steps of 1e-3 move parameters by ~3e-3
+    report("reference MPRLTrainer.optimize_batch (%s): final parameters within %.1e of the reference's, losses %.6f / %.6f"
+           % (tag, worst, v_losses / 2, s_losses / 2))
+
+
+def test_path_g_query_env_against_the_reference_fixture(dev):
+    """Fixture training_queryenv.npz: the reference MultiHumanRL.predict with query_env=True on the reference CrowdSim (linear
+    humans), four states a few steps into seeded test cases: 81 action values and the chosen action."""
+    from relationalgraphlearning_amd.sim import BatchedCrowdSim
+    fx = gio.load("training_queryenv")
+    pol = make_gcn_policy(device=dev)
+    pol.query_env = True
+    sim = BatchedCrowdSim(dev)
+    worst = 0.0
+    for i in range(fx["qe.robot"].shape[0]):
+        full = fx["qe.humans_full"][i]                                   # (H, 9) FullStates of the humans
+        sim.load(fx["qe.robot"][i:i + 1], full[None, :, :5], fx["qe.human_goals"][i:i + 1], fx["qe.human_vpref"][i:i + 1])
+        sim.time[:] = float(fx["qe.time"][i])
+        pol.set_env(sim)
+        a = pol.predict(JS(fx["qe.robot"][i], full[:, :5]))
+        err = float(np.abs(np.array(pol.action_values) - fx["qe.action_values"][i]).max())
+        worst = max(worst, err)
+        assert err < 1e-5, (i, err)
+        assert a == pol.action_space[int(fx["qe.action"][i])], i
+    report("path G query_env=True vs the reference on its simulator: max |d action value| = %.2e" % worst)
+
+
 def test_library_reports_target():
     assert nat.lib().rgl_build_target() == b"gfx950"
