@@ -42,18 +42,6 @@ struct CrowdLds {
                          total = w1 + XD * WLD;
 };
 
-template <int NTHR>
-__device__ __forceinline__ void fill_crowd_image(float* img, const CrowdArgs& a, int tid) {
-    fill_matrix<5, 8, HID, W1LD, NTHR>(img + CrowdLds::wh1, a.wh1, tid);
-    fill_matrix<HID, HID, XD, WLD, NTHR>(img + CrowdLds::wh2, a.wh2, tid);
-    fill_matrix<XD, XD, XD, WLD, NTHR>(img + CrowdLds::w1, a.w1, tid);
-    if (a.wa) fill_matrix<XD, XD, XD, WLD, NTHR>(img + CrowdLds::wa, a.wa, tid);
-    else
-        for (int i = tid; i < XD * XD; i += NTHR) img[CrowdLds::wa + (i / XD) * WLD + (i % XD)] = (i / XD) == (i % XD) ? 1.f : 0.f;   // gaussian: Wa = I
-    for (int i = tid; i < HID; i += NTHR) img[CrowdLds::bh1 + i] = a.bh1[i];
-    for (int i = tid; i < XD; i += NTHR) img[CrowdLds::bh2 + i] = a.bh2[i];
-}
-
 constexpr int kCrowdWaves = 8;
 
 // One wave per (parent, 16-node column tile); the NT waves of a parent meet at a workgroup barrier between the two parts.
@@ -618,31 +606,67 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
 // stand-alone call) by a grid of threads, then every workgroup of every level copies its image with b128 loads that are all in
 // flight at once.  (Building the 97 KB image inside each persistent workgroup cost ~10 us of dependent L2 round trips per
 // launch -- most of a small-batch launch.)
-constexpr int kPackThreads = 256, kPackBlocks = 48;
+// One thread per image float (inverse map: which array, which element): every source load of the grid is in flight at once --
+// one L2 round trip for both images instead of one per array (the array-by-array version took 7 us).
+constexpr int kPackThreads = 256;
+
+// element `idx` of the A-fragment image of W (k-major [IN][OUT]); same map as fill_frags
+template <int IN, int OUT>
+__device__ __forceinline__ float frag_element(const float* __restrict__ W, int idx) {
+    constexpr int IT = Tiles<IN>::v;
+    const int l = idx & 63, fr = idx >> 6;
+    const int r = fr & 3, it = (fr >> 2) % IT, ot = (fr >> 2) / IT;
+    const int m = l & 15;
+    const int in = tile_feature<IN>(it, l >> 4, r), out = tile_feature<OUT>(ot, m >> 2, m & 3);
+    return (in < IN && out < OUT) ? W[in * OUT + out] : 0.f;
+}
+template <int OUT>
+__device__ __forceinline__ float bias_element(const float* __restrict__ b, int idx) {
+    const int feat = tile_feature<OUT>(idx >> 4, (idx >> 2) & 3, idx & 3);
+    return feat < OUT ? b[feat] : 0.f;
+}
+// element `e` of a [ROWS_PAD][LD] image of a k-major [ROWS][COLS] matrix (padding rows / columns: 0)
+template <int ROWS, int COLS, int LD>
+__device__ __forceinline__ float matrix_element(const float* __restrict__ W, int e) {
+    const int r = e / LD, c = e - r * LD;
+    return (r < ROWS && c < COLS) ? W[r * COLS + c] : 0.f;
+}
+
 template <int D1, int D2, int D3>
 __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedArgs a, const CrowdArgs c, float* img) {
     using LO = FusedLds<D1, D2, D3>;
-    constexpr int NTHR = kPackThreads * kPackBlocks;
-    const int tid = blockIdx.x * kPackThreads + threadIdx.x;
-    float* w = img;
-    fill_matrix<9, 12, HID, W1LD, NTHR>(w + LO::wr1, a.wr1, tid);
-    fill_matrix<HID, HID, XD, WLD, NTHR>(w + LO::wr2, a.wr2, tid);
-    fill_matrix<XD, XD, XD, WLD, NTHR>(w + LO::w1, a.w1, tid);
-    if (a.wa) fill_matrix<XD, XD, XD, WLD, NTHR>(w + LO::wa, a.wa, tid);
-    else
-        for (int i = tid; i < XD * XD; i += NTHR) w[LO::wa + (i / XD) * WLD + (i % XD)] = (i / XD) == (i % XD) ? 1.f : 0.f;   // gaussian: Wa = I
-    for (int i = tid; i < HID; i += NTHR) w[LO::br1 + i] = a.br1[i];
-    for (int i = tid; i < XD; i += NTHR) w[LO::br2 + i] = a.br2[i];
-    // the image rows the matrices do not cover (padding columns of the strided rows) are never read
-    fill_frags<XD, XD, NTHR>(w + LO::f_last, a.w_last, tid);
-    fill_frags<XD, D1, NTHR>(w + LO::f1, a.hw1, tid);
-    fill_frags<D1, D2, NTHR>(w + LO::f2, a.hw2, tid);
-    fill_frags<D2, D3, NTHR>(w + LO::f3, a.hw3, tid);
-    fill_bias<D1>(w + LO::b1, a.hb1, tid, NTHR);
-    fill_bias<D2>(w + LO::b2, a.hb2, tid, NTHR);
-    fill_bias<D3>(w + LO::b3, a.hb3, tid, NTHR);
-    fill_bias<D3>(w + LO::w4, a.hw4, tid, NTHR);        // w4 is [D3][1]: same padded vector layout as a bias
-    fill_crowd_image<NTHR>(img + LO::scratch, c, tid);
+    const int e = blockIdx.x * kPackThreads + threadIdx.x;
+    if (e >= LO::scratch + CrowdLds::total) return;
+    float v;
+    if (e < LO::scratch) {
+        if (e < LO::br1) v = matrix_element<9, HID, W1LD>(a.wr1, e - LO::wr1);
+        else if (e < LO::wr2) v = a.br1[e - LO::br1];
+        else if (e < LO::br2) v = matrix_element<HID, XD, WLD>(a.wr2, e - LO::wr2);
+        else if (e < LO::wa) v = a.br2[e - LO::br2];
+        else if (e < LO::w1) {
+            const int k = e - LO::wa, r = k / WLD, col = k - r * WLD;
+            v = a.wa ? matrix_element<XD, XD, WLD>(a.wa, k) : ((col < XD && r == col) ? 1.f : 0.f);      // gaussian: Wa = I
+        } else if (e < LO::f_last) v = matrix_element<XD, XD, WLD>(a.w1, e - LO::w1);
+        else if (e < LO::f1) v = frag_element<XD, XD>(a.w_last, e - LO::f_last);
+        else if (e < LO::f2) v = frag_element<XD, D1>(a.hw1, e - LO::f1);
+        else if (e < LO::f3) v = frag_element<D1, D2>(a.hw2, e - LO::f2);
+        else if (e < LO::b1) v = frag_element<D2, D3>(a.hw3, e - LO::f3);
+        else if (e < LO::b2) v = bias_element<D1>(a.hb1, e - LO::b1);
+        else if (e < LO::b3) v = bias_element<D2>(a.hb2, e - LO::b2);
+        else if (e < LO::w4) v = bias_element<D3>(a.hb3, e - LO::b3);
+        else v = bias_element<D3>(a.hw4, e - LO::w4);                    // w4 is [D3][1]: same padded vector layout as a bias
+    } else {
+        const int k = e - LO::scratch;
+        if (k < CrowdLds::bh1) v = matrix_element<5, HID, W1LD>(c.wh1, k - CrowdLds::wh1);
+        else if (k < CrowdLds::wh2) v = c.bh1[k - CrowdLds::bh1];
+        else if (k < CrowdLds::bh2) v = matrix_element<HID, XD, WLD>(c.wh2, k - CrowdLds::wh2);
+        else if (k < CrowdLds::wa) v = c.bh2[k - CrowdLds::bh2];
+        else if (k < CrowdLds::w1) {
+            const int kk = k - CrowdLds::wa, r = kk / WLD, col = kk - r * WLD;
+            v = c.wa ? matrix_element<XD, XD, WLD>(c.wa, kk) : ((col < XD && r == col) ? 1.f : 0.f);
+        } else v = matrix_element<XD, XD, WLD>(c.w1, k - CrowdLds::w1);
+    }
+    img[e] = v;
 }
 
 constexpr size_t kImageFloats = FusedLds<32, 100, 100>::scratch + CrowdLds::total;
@@ -725,7 +749,7 @@ int launch_crowd(const FusedPlan& pl, hipStream_t st) {
     auto kern = crowd_block_kernel<NT, SOFT>;
     constexpr int PPW = kCrowdWaves / NT;
     int grid = (pl.c.P + PPW - 1) / PPW;
-    if (grid > 1024) grid = 1024;                                 // 40 KB LDS: four workgroups per CU (64 VGPRs)
+    if (grid > 512) grid = 512;                                   // resident workgroups (two per CU at ~120 VGPRs): persistent, one image copy each
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kCrowdWaves * 64), pl.crowd_lds_bytes, st, pl.c);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
@@ -795,8 +819,8 @@ int pack_children_images(const RglGraph* g, const RglMlp* head, int P, int A, in
                          hipStream_t stream) {
     FusedPlan fp = plan_fused(*g, *head, P, A, H);
     if (!fp.ok || !workspace || workspace_bytes < fused_children_workspace_bytes(P, A, H)) return 1;
-    hipLaunchKernelGGL((pack_images_kernel<32, 100, 100>), dim3(kPackBlocks), dim3(kPackThreads), 0, stream, fp.a, fp.c,
-                       image_of(workspace, workspace_bytes));
+    hipLaunchKernelGGL((pack_images_kernel<32, 100, 100>), dim3((unsigned)((kImageFloats + kPackThreads - 1) / kPackThreads)),
+                       dim3(kPackThreads), 0, stream, fp.a, fp.c, image_of(workspace, workspace_bytes));
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }
