@@ -22,11 +22,13 @@
 
 namespace {
 
-// crowd block of one parent in global memory (floats), NP = 16 NT node slots (slot 0 = robot, zero):
-//   Xh[NP][32] | G[NP][32]   node-major: MFMA A-operand rows of the robot row / column of S
-//   XhT[32][NP] | UWT[32][NP] feature-major: a lane's nodes are contiguous (one b128 load per 4 nodes)
-//   msh[NP] | zsh[NP]
-__host__ __device__ constexpr int crowd_block_floats(int NT) { return 4 * 16 * NT * XD + 2 * 16 * NT; }
+// crowd block of one parent in global memory (floats), compact: N node rows (row 0 = robot slot, zero), N4 = N rounded up to 4:
+//   Xh[N][32] | G[N][32]   node-major: MFMA A-operand rows of the robot row / column of S (and, strided, Xh^T for p Xh)
+//   UWT[32][N4]            feature-major: the row pass' lane = feature holds its nodes contiguously (one b128 load per 4 nodes)
+//   msh[N4] | zsh[N4]
+// 7.8 KB per parent at N = 20 (the 32-slot layout with two transposed copies was 16.6 KB: HBM traffic of the path halved).
+__host__ __device__ constexpr int crowd_n4(int N) { return (N + 3) & ~3; }
+__host__ __device__ constexpr int crowd_block_floats(int N) { return 2 * N * XD + XD * crowd_n4(N) + 2 * crowd_n4(N); }
 
 struct CrowdArgs {
     const float *wh1, *bh1, *wh2, *bh2, *wa, *w1;
@@ -83,7 +85,8 @@ __global__ __launch_bounds__(kCrowdWaves * 64, 4) void crowd_block_kernel(const 
     for (int base = blockIdx.x * PPW; base < a.P; base += gridDim.x * PPW) {
         const int pp = base + slot;
         const bool active = pp < a.P;
-        float* blk = a.blocks + (size_t)(active ? pp : 0) * crowd_block_floats(NT);
+        const int N4 = crowd_n4(N);
+        float* blk = a.blocks + (size_t)(active ? pp : 0) * crowd_block_floats(N);
         f32x4 pg[2] = {zero4(), zero4()};
         if (active) {
             // part 1: Xh = w_h(humans), G = Xh Wa   (transposed MFMA chain, 16 nodes per wave)
@@ -118,9 +121,7 @@ __global__ __launch_bounds__(kCrowdWaves * 64, 4) void crowd_block_kernel(const 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xacc[ot][r] = node_ok ? relu1(xacc[ot][r] + bb[r]) : 0.f;   // robot slot / padding rows: 0
                 *reinterpret_cast<f32x4*>(&Xh[node * XLD + 16 * ot + 4 * q]) = xacc[ot];
-                *reinterpret_cast<f32x4*>(&blk[node * XD + 16 * ot + 4 * q]) = xacc[ot];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) blk[2 * NP * XD + (16 * ot + 4 * q + r) * NP + node] = xacc[ot][r];
+                if (node < N) *reinterpret_cast<f32x4*>(&blk[node * XD + 16 * ot + 4 * q]) = xacc[ot];
             }
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
@@ -132,8 +133,10 @@ __global__ __launch_bounds__(kCrowdWaves * 64, 4) void crowd_block_kernel(const 
                         pg[gt] = mfma4(wa[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], pg[gt]);
             }
             load_fence();
-            *reinterpret_cast<f32x4*>(&blk[NP * XD + node * XD + 4 * q]) = pg[0];
-            *reinterpret_cast<f32x4*>(&blk[NP * XD + node * XD + 16 + 4 * q]) = pg[1];
+            if (node < N) {
+                *reinterpret_cast<f32x4*>(&blk[N * XD + node * XD + 4 * q]) = pg[0];
+                *reinterpret_cast<f32x4*>(&blk[N * XD + node * XD + 16 + 4 * q]) = pg[1];
+            }
         }
         __syncthreads();
         if (active) {
@@ -172,8 +175,10 @@ __global__ __launch_bounds__(kCrowdWaves * 64, 4) void crowd_block_kernel(const 
                 }
             z = kgroups_sum(z);
             if (q == 0) {
-                blk[4 * NP * XD + node] = mx;
-                blk[4 * NP * XD + NP + node] = node_ok ? z : 1.f;
+                if (node < N4) {
+                    blk[2 * N * XD + XD * N4 + node] = mx;
+                    blk[2 * N * XD + XD * N4 + N4 + node] = node_ok ? z : 1.f;
+                }
             }
             f32x4 u[2] = {zero4(), zero4()};
 #pragma unroll
@@ -201,7 +206,8 @@ __global__ __launch_bounds__(kCrowdWaves * 64, 4) void crowd_block_kernel(const 
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) blk[3 * NP * XD + (16 * ot + 4 * q + r) * NP + node] = uw[ot][r];
+                for (int r = 0; r < 4; ++r)
+                    if (node < N4) blk[2 * N * XD + (16 * ot + 4 * q + r) * N4 + node] = uw[ot][r];
         }
         __syncthreads();
     }
@@ -342,26 +348,34 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         int p, ts, t1;
         item_tiles(wi, p, ts, t1);
         robot_rows(p, ts < (wi / a.P) * G ? a.n_full : ts);
-        const float* blk = a.blocks + (size_t)p * crowd_block_floats(NT);
+        const int N4 = crowd_n4(N);
+        const float* blk = a.blocks + (size_t)p * crowd_block_floats(N);
         const float* gXh = blk;
-        const float* gGm = blk + NP * XD;
-        const float* gXhT = blk + 2 * NP * XD;
-        const float* gUWT = blk + 3 * NP * XD;
-        const float* gms = blk + 4 * NP * XD;
-        const float* gzs = gms + NP;
+        const float* gGm = blk + N * XD;
+        const float* gUWT = blk + 2 * N * XD;
+        const float* gms = gUWT + XD * N4;
+        const float* gzs = gms + N4;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+            const int row = 16 * nt + n;                          // A-operand rows: nodes >= N are zero rows
+            const int rc = row < N ? row : 0;                     // (row 0 = robot slot = zeros)
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
-                gq[nt][ot] = *reinterpret_cast<const f32x4*>(&gGm[(16 * nt + n) * XD + 16 * ot + 4 * q]);
-                xq[nt][ot] = *reinterpret_cast<const f32x4*>(&gXh[(16 * nt + n) * XD + 16 * ot + 4 * q]);
-                xt[nt][ot] = *reinterpret_cast<const f32x4*>(&gXhT[(16 * ot + n) * NP + 16 * nt + 4 * q]);   // Xh[16nt+4q+r][16ot+n]
+                gq[nt][ot] = *reinterpret_cast<const f32x4*>(&gGm[rc * XD + 16 * ot + 4 * q]);
+                xq[nt][ot] = *reinterpret_cast<const f32x4*>(&gXh[rc * XD + 16 * ot + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                     // Xh^T for p Xh: Xh[16nt+4q+r][16ot+n], strided
+                    const int j = 16 * nt + 4 * q + r;
+                    xt[nt][ot][r] = gXh[(j < N ? j : 0) * XD + 16 * ot + n];
+                }
             }
-            ms[nt] = *reinterpret_cast<const f32x4*>(&gms[16 * nt + 4 * q]);
-            zs[nt] = *reinterpret_cast<const f32x4*>(&gzs[16 * nt + 4 * q]);
+            const int m4 = 16 * nt + 4 * q;                       // msh / zsh of nodes m4 .. m4+3 (N4 is a multiple of 4)
+            ms[nt] = *reinterpret_cast<const f32x4*>(&gms[m4 < N4 ? m4 : 0]);
+            zs[nt] = *reinterpret_cast<const f32x4*>(&gzs[m4 < N4 ? m4 : 0]);
         }
 #pragma unroll
-        for (int i4 = 0; i4 < HRL / 4; ++i4) uw4[i4] = *reinterpret_cast<const f32x4*>(&gUWT[(lane & 31) * NP + 4 * i4]);
+        for (int i4 = 0; i4 < HRL / 4; ++i4)
+            uw4[i4] = 4 * i4 < N4 ? *reinterpret_cast<const f32x4*>(&gUWT[(lane & 31) * N4 + 4 * i4]) : zero4();
     };
     PHASE_START();
     const int wi_first = wave * gridDim.x + blockIdx.x;
@@ -806,7 +820,8 @@ namespace rgl {
 // workspace: crowd blocks [P][crowd_block_floats] | rows of the partial tiles [P][A % 16][64] | ... | weight images (at the END)
 size_t fused_children_workspace_bytes(int P, int A, int H) {
     const int nt = (H + 1 + 15) / 16;
-    const size_t main_bytes = ((size_t)P * crowd_block_floats(nt) + (size_t)P * (A % 16) * 64) * sizeof(float);
+    (void)nt;
+    const size_t main_bytes = ((size_t)P * crowd_block_floats(H + 1) + (size_t)P * (A % 16) * 64) * sizeof(float);
     return ((main_bytes + 255) & ~(size_t)255) + kImageBytes;
 }
 
@@ -838,7 +853,7 @@ int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, i
     }
     float* image = image_of(workspace, workspace_bytes);
     float* blocks = (float*)workspace;
-    float* rows_left = blocks + (size_t)P * crowd_block_floats(fp.nt);
+    float* rows_left = blocks + (size_t)P * crowd_block_floats(H + 1);
     fp.c.humans = humans_next;
     fp.c.blocks = blocks;
     fp.c.image = image + FusedLds<32, 100, 100>::scratch;
