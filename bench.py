@@ -60,7 +60,7 @@ def children_flops_per_scene(N, L, A):
                      + 7 * H * 32 + 2 * 32                              # rank-1 row pass, T_0
                      + 2 * 32 * 32 + 4 * 32)                            # T_0*W1, H1_0, t_c
         return (per_parent / A + per_child + last_layer + head,
-                "rank-1 form: crowd_block_kernel + children_fused_kernel (+ robot_head_kernel on the partial tiles' rows) from ~9k "
+                "rank-1 form: children_fused_kernel (one launch: crowd quantities, 16-child tiles from embedding to value) from ~3k "
                 "child tiles per launch, children_rank1_kernel + robot_head_kernel below")
     if L in (2, 3) and N <= 60:
         # shared-crowd deep kernel (rgl_deep.hip): layer 0 in rank-1 form; for L == 3 one dense layer per child whose

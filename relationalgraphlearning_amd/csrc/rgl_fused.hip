@@ -1,5 +1,5 @@
 // rgl_fused.hip -- "value of the sibling children" for the shipped shape (L = 2, N <= 32, value head 32-100-100-1) as ONE
-// kernel over a stream of 16-child tiles, plus the crowd-only prologue as a small kernel of its own.
+// kernel over a stream of 16-child tiles.
 //
 // Follows (reference paths): crowd_nav/policy/graph_model.py:99-130 (RGL.forward), value_estimator.py:11-20,
 // model_predictive_rl.py:245-250 (the per-action loop whose iterations run side by side here).
@@ -7,229 +7,49 @@
 // Algebra: the rank-1 (shared-crowd) form of rgl_rank1.hip -- siblings share every human row of X and of S except the
 // robot column, so a human row i of child c is (alpha_i UW_i + beta_i (x0_c W1)) / Z_i with crowd-only UW, msh, Zsh.
 // What changes is the organisation (round 2):
-//   * crowd_block_kernel computes the crowd-only block of every parent once (Xh, G = Xh Wa, UW, msh, Zsh -> 12.5 KB per
-//     parent in HBM/MALL), so the main kernel has no producer waves, no double buffer and no flag handshakes;
 //   * children_fused_kernel: every wave owns one 16-child tile from the robot embedding to the VALUE: embedding,
 //     robot row/column of S, softmax scalars, the VALU row pass, the robot row, the last GCN layer on the robot row and the
 //     value head all run on registers and a 6.5 KB wave-private LDS scratch.  No workgroup barrier after the weight image
 //     is built, no [P*A][64] fp32 hand-off through HBM, no second launch.  Tiles are dealt round-robin over all waves of
-//     the GPU (full tiles first, then the partial last tiles of the parents), so the four SIMDs of a CU carry the same
-//     number of tiles -- the imbalance that sank round 1's barrier-free experiment (6 tiles + 2 crowd waves on 4 SIMDs).
+//     the GPU, so the four SIMDs of a CU carry the same number of tiles -- the imbalance that sank round 1's barrier-free
+//     experiment (6 tiles + 2 crowd waves on 4 SIMDs).
+//   * the crowd-only quantities of a parent (Xh, G = Xh Wa, UW, msh, Zsh: 208 MFMAs, ~9 % of a parent's work) are computed
+//     by the wave that owns the work item, at the item's start, straight into the registers the tiles read them from
+//     (the MFMA D layout of the crowd chain IS the A-operand layout of the robot row / column products; the two
+//     transposed views go through the wave's own scratch).  Nothing crowd-sized crosses HBM: the kernel reads the child
+//     robot rows and the parent's human rows and writes the values.  (Until the end of round 2 a crowd_block_kernel
+//     produced 7.8-16.6 KB blocks per parent in global memory: one more launch and 5-10x the algorithmic HBM bytes.)
 //   * a parent's partial last tile (A % 16 children; the single `stop` action of the 81-action table) runs everything but
-//     the head and leaves its rows in a small buffer; robot_head_kernel scores those rows tile-packed over parents, so the
-//     head never multiplies 15 columns of padding.
+//     the head and leaves its rows in a small buffer; the workgroup scores the rows of ITS partial tiles at the end of the
+//     kernel, tile-packed over parents (16 `stop` children = one head tile), so the head never multiplies 15 columns of
+//     padding and the whole path is one launch.
 #include "rgl_mlp_chain.h"
 
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
 namespace {
-
-// crowd block of one parent in global memory (floats), compact: N node rows (row 0 = robot slot, zero), N4 = N rounded up to 4:
-//   Xh[N][32] | G[N][32]   node-major: MFMA A-operand rows of the robot row / column of S (and, strided, Xh^T for p Xh)
-//   UWT[32][N4]            feature-major: the row pass' lane = feature holds its nodes contiguously (one b128 load per 4 nodes)
-//   msh[N4] | zsh[N4]
-// 7.8 KB per parent at N = 20 (the 32-slot layout with two transposed copies was 16.6 KB: HBM traffic of the path halved).
-__host__ __device__ constexpr int crowd_n4(int N) { return (N + 3) & ~3; }
-__host__ __device__ constexpr int crowd_block_floats(int N) { return 2 * N * XD + XD * crowd_n4(N) + 2 * crowd_n4(N); }
-
-struct CrowdArgs {
-    const float *wh1, *bh1, *wh2, *bh2, *wa, *w1;
-    const float* humans;      // [P][H][5]
-    float* blocks;            // [P][crowd_block_floats(NT)]
-    const float* image;       // the weight image below, prepared in global memory by pack_images_kernel
-    int P, H, N, sim;
-};
-
-// LDS weight image of crowd_block_kernel (floats)
-struct CrowdLds {
-    static constexpr int wh1 = 0, bh1 = wh1 + 8 * W1LD, wh2 = bh1 + HID, bh2 = wh2 + HID * WLD, wa = bh2 + XD, w1 = wa + XD * WLD,
-                         total = w1 + XD * WLD;
-};
-
-constexpr int kCrowdWaves = 8;
-
-// One wave per (parent, 16-node column tile); the NT waves of a parent meet at a workgroup barrier between the two parts.
-template <int NT, bool SOFT>
-__global__ __launch_bounds__(kCrowdWaves * 64, 4) void crowd_block_kernel(const CrowdArgs a) {
-    const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NP = 16 * NT;
-    constexpr int PPW = kCrowdWaves / NT;            // parents per workgroup pass
-    constexpr int o_wh1 = CrowdLds::wh1, o_bh1 = CrowdLds::bh1, o_wh2 = CrowdLds::wh2, o_bh2 = CrowdLds::bh2, o_wa = CrowdLds::wa,
-                  o_w1 = CrowdLds::w1, o_xh = CrowdLds::total;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = lane & 15, q = lane >> 4;
-    const int N = a.N, H = a.H;
-    const float NEG_INF = -INFINITY;
-    copy_image<CrowdLds::total, kCrowdWaves * 64>(lds, a.image, tid);
-    __syncthreads();
-    const float* wh1 = lds + o_wh1;
-    const float* bh1 = lds + o_bh1;
-    const float* wh2 = lds + o_wh2;
-    const float* bh2 = lds + o_bh2;
-    const float* wa = lds + o_wa;
-    const float* w1 = lds + o_w1;
-    const int slot = wave / NT, pct = wave - slot * NT;
-    float* Xh = lds + o_xh + slot * NP * XLD;
-    const int node = 16 * pct + n;
-    const bool node_ok = node >= 1 && node < N;
-
-    float hin[2];                                    // my node's state row, loaded one pass ahead
-    auto human_rows = [&](int pp) {
-        const float* hsrc = a.humans + ((size_t)(pp < a.P ? pp : a.P - 1) * H + (node_ok ? node - 1 : 0)) * 5;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int k = 4 * s + q;
-            hin[s] = (node_ok && k < 5) ? hsrc[k] : 0.f;
-        }
-    };
-    human_rows(blockIdx.x * PPW + slot);
-    for (int base = blockIdx.x * PPW; base < a.P; base += gridDim.x * PPW) {
-        const int pp = base + slot;
-        const bool active = pp < a.P;
-        const int N4 = crowd_n4(N);
-        float* blk = a.blocks + (size_t)(active ? pp : 0) * crowd_block_floats(N);
-        f32x4 pg[2] = {zero4(), zero4()};
-        if (active) {
-            // part 1: Xh = w_h(humans), G = Xh Wa   (transposed MFMA chain, 16 nodes per wave)
-            f32x4 hacc[4] = {zero4(), zero4(), zero4(), zero4()};
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int k = 4 * s + q;
-#pragma unroll
-                for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wh1[k * W1LD + 16 * ht + n], hin[s], hacc[ht]);
-            }
-            human_rows(pp + gridDim.x * PPW);
-#pragma unroll
-            for (int ht = 0; ht < 4; ++ht) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(&bh1[16 * ht + 4 * q]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) hacc[ht][r] = relu1(hacc[ht][r] + bb[r]);
-            }
-            f32x4 xacc[2] = {zero4(), zero4()};
-#pragma unroll
-            for (int ht = 0; ht < 4; ++ht) {
-                load_fence();
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int ot = 0; ot < 2; ++ot)
-                        xacc[ot] = mfma4(wh2[(16 * ht + 4 * q + r) * WLD + 16 * ot + n], hacc[ht][r], xacc[ot]);
-            }
-            load_fence();
-#pragma unroll
-            for (int ot = 0; ot < 2; ++ot) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(&bh2[16 * ot + 4 * q]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xacc[ot][r] = node_ok ? relu1(xacc[ot][r] + bb[r]) : 0.f;   // robot slot / padding rows: 0
-                *reinterpret_cast<f32x4*>(&Xh[node * XLD + 16 * ot + 4 * q]) = xacc[ot];
-                if (node < N) *reinterpret_cast<f32x4*>(&blk[node * XD + 16 * ot + 4 * q]) = xacc[ot];
-            }
-#pragma unroll
-            for (int ot = 0; ot < 2; ++ot) {
-                load_fence();
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int gt = 0; gt < 2; ++gt)
-                        pg[gt] = mfma4(wa[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], pg[gt]);
-            }
-            load_fence();
-            if (node < N) {
-                *reinterpret_cast<f32x4*>(&blk[N * XD + node * XD + 4 * q]) = pg[0];
-                *reinterpret_cast<f32x4*>(&blk[N * XD + node * XD + 16 + 4 * q]) = pg[1];
-            }
-        }
-        __syncthreads();
-        if (active) {
-            // part 2 (needs every Xh row): S_ij = G_i . Xh_j over humans j, msh / E / Zsh, U = E Xh, UW = U W1
-            f32x4 e[NT];
-            float mx = NEG_INF;
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt) {
-                load_fence();
-                f32x4 sacc = zero4();
-#pragma unroll
-                for (int ft = 0; ft < 2; ++ft) {
-                    const f32x4 xa = *reinterpret_cast<const f32x4*>(&Xh[(16 * jt + n) * XLD + 16 * ft + 4 * q]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sacc = mfma4(xa[r], pg[ft][r], sacc);      // [j = 16jt+4q+r][i = my node]
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = 16 * jt + 4 * q + r;
-                    if (sim != SIM_SOFTMAX) sacc[r] = plain_weight(sim, sacc[r], node, j);
-                    if (j < 1 || j >= N) sacc[r] = sim == SIM_SOFTMAX ? NEG_INF : 0.f;
-                    mx = fmaxf(mx, sacc[r]);
-                }
-                e[jt] = sacc;
-            }
-            mx = kgroups_max(mx);
-            if (!node_ok || sim != SIM_SOFTMAX) mx = 0.f;
-            float z = 0.f;
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (sim == SIM_SOFTMAX) e[jt][r] = __expf(e[jt][r] - mx);
-                    if (!node_ok) e[jt][r] = 0.f;
-                    z += e[jt][r];
-                }
-            z = kgroups_sum(z);
-            if (q == 0) {
-                if (node < N4) {
-                    blk[2 * N * XD + XD * N4 + node] = mx;
-                    blk[2 * N * XD + XD * N4 + N4 + node] = node_ok ? z : 1.f;
-                }
-            }
-            f32x4 u[2] = {zero4(), zero4()};
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt) {
-                load_fence();
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float a0 = Xh[(16 * jt + 4 * q + r) * XLD + n];
-                    const float a1 = Xh[(16 * jt + 4 * q + r) * XLD + 16 + n];
-                    u[0] = mfma4(a0, e[jt][r], u[0]);                                         // U^T[f][i] = sum_j Xh[j][f] E[i][j]
-                    u[1] = mfma4(a1, e[jt][r], u[1]);
-                }
-            }
-            f32x4 uw[2] = {zero4(), zero4()};
-#pragma unroll
-            for (int ft = 0; ft < 2; ++ft) {
-                load_fence();
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int ot = 0; ot < 2; ++ot)
-                        uw[ot] = mfma4(w1[(16 * ft + 4 * q + r) * WLD + 16 * ot + n], u[ft][r], uw[ot]);
-            }
-            load_fence();
-#pragma unroll
-            for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (node < N4) blk[2 * N * XD + (16 * ot + 4 * q + r) * N4 + node] = uw[ot][r];
-        }
-        __syncthreads();
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // the fused tile kernel
 // ------------------------------------------------------------------------------------------------
 struct FusedArgs {
     const float *wr1, *br1, *wr2, *br2, *wa, *w1;                       // child-side weights (k-major)
+    const float *wh1, *bh1, *wh2, *bh2;                                 // w_h (crowd side)
     const float* w_last;                                                // [32][32] last GCN layer
     const float *hw1, *hb1, *hw2, *hb2, *hw3, *hb3, *hw4, *hb4;         // value head, k-major
     const float* child_robot;     // [P][A][9]
-    const float* blocks;          // [P][crowd_block_floats(NT)]
+    const float* humans;          // [P][H][5] the parents' crowds
     float* value;                 // [P][A]
     float* rows_left;             // [P][A % 16][64]  rows [t_c | H1_0] of the partial last tiles (null when A % 16 == 0)
-    int P, A, N, SLD, sim;
+    int P, A, N, H, SLD, sim;
     int n_full;                   // full tiles per parent = A / 16
     int rem;                      // A % 16
     const float* image;           // FusedLds weight image [0, FusedLds::scratch) prepared in global memory by pack_images_kernel
-    int tiles_per_item;           // a work item = this many consecutive FULL tiles of one parent (crowd fragments loaded once)
-    int items_per_parent;         // = ceil(n_full / tiles_per_item)
+    int tiles_per_item;           // a work item = this many consecutive FULL tiles of one parent (crowd quantities computed once)
+    int items_per_parent;         // = ceil(n_full / tiles_per_item); the last group also carries the partial tile
+    int rot;                      // item order: group (o + rot) % items_per_parent at order position o (heaviest group first)
 };
 
 constexpr int kFusedWaves = 8;
@@ -243,8 +63,13 @@ struct FusedLds {
     static constexpr int br2 = wr2 + HID * WLD;
     static constexpr int wa = br2 + XD;
     static constexpr int w1 = wa + XD * WLD;
+    // crowd side: w_h
+    static constexpr int wh1 = w1 + XD * WLD;
+    static constexpr int bh1 = wh1 + 8 * W1LD;
+    static constexpr int wh2 = bh1 + HID;
+    static constexpr int bh2 = wh2 + HID * WLD;
     // head fragments (layout of rgl_head.hip)
-    static constexpr int f_last = w1 + XD * WLD;
+    static constexpr int f_last = bh2 + XD;
     static constexpr int f1 = f_last + 2 * 2 * 4 * 64;
     static constexpr int f2 = f1 + Tiles<D1>::v * 2 * 4 * 64;
     static constexpr int f3 = f2 + Tiles<D2>::v * Tiles<D1>::v * 4 * 64;
@@ -252,7 +77,7 @@ struct FusedLds {
     static constexpr int b2 = b1 + Tiles<D1>::v * 16;
     static constexpr int b3 = b2 + Tiles<D2>::v * 16;
     static constexpr int w4 = b3 + Tiles<D3>::v * 16;
-    static constexpr int scratch = w4 + Tiles<D3>::v * 16;       // per wave: AB[16][SLD][2] | Y[16][XLD]
+    static constexpr int scratch = w4 + Tiles<D3>::v * 16;       // per wave: AB[16][SLD][2] | Y[16][XLD]   (between items: Xh / UW [16 NT][XLD] | msh, Zsh [2][16 NT])
 };
 
 // h = relu(t W_last)(+hprev), value head 32 -> D1 -> D2 -> D3 -> 1 for the 16 children of a tile (lane (n, q): child n, D-layout
@@ -316,24 +141,34 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
 
     // Work items (each class dealt round-robin over all waves of the GPU, so every wave sees the same mix):
     //   item (j, p), group-major (all first groups, then all second ...): G consecutive full tiles of parent p; the FIRST group
-    //   of a parent starts with its partial last tile (A % 16 children: everything but the head, rows -> rows_left; a launch of
-    //   robot_head_kernel scores those rows tile-packed over parents afterwards).
-    // Item wi -> (workgroup wi % grid, wave (wi / grid) % 8): consecutive items land on different CUs, then on different SIMDs.
-    // The crowd fragments of a parent are loaded once per item, and the NEXT item's loads are issued before the head of the
-    // current item's last tile: no item starts on a cold register file.
+    //   of a parent starts with its partial last tile (A % 16 children: everything but the head, rows -> rows_left; scored at the
+    //   end of the kernel by the workgroup that wrote them, tile-packed over parents).
+    // Position wl of a dealing pass -> (workgroup wl % grid, wave wl / grid): consecutive items land on different CUs, then on
+    // different SIMDs.
+    // The crowd quantities of a parent are computed once per item, and the NEXT item's loads (robot rows, crowd state rows) are
+    // issued before the head of the current item's last tile: no item starts waiting on HBM.
     const int G = a.tiles_per_item;
-    const int n_group = a.P * a.items_per_parent;
-    const int n_items = n_group;
-    const int stride = gridDim.x * kFusedWaves;
-    constexpr int HRL = HR < NP ? HR : NP;              // rows of UW a lane holds (rows >= N are zero in the block)
-    float rin[3];
+    const int n_items = a.P * a.items_per_parent;
+    const int S = gridDim.x * kFusedWaves;              // waves of the launch
+    const int wl = wave * gridDim.x + blockIdx.x;       // my position in a dealing pass
+    const int n_pass = (n_items + S - 1) / S;
+    // pass k deals items k S .. k S + S - 1 over the waves, odd passes in reverse ("snake"): with the heavy items first in the
+    // order, the waves that got a heavy item in one pass get a light one (or none) in the next
+    auto item_at = [&](int k, int w_l) { return k * S + ((k & 1) ? S - 1 - w_l : w_l); };
+    constexpr int HRL = HR < NP ? HR : NP;              // rows of UW a lane holds (rows >= N are zero)
+    float rin[3], hin[NT][2];
     f32x4 gq[NT][2], xq[NT][2], ms[NT], zs[NT], xt[NT][2], uw4[HRL / 4];
-    auto item_tiles = [&](int wi, int& p, int& ts, int& t1) {      // tile sequence ts .. t1-1, where t < t0 means "the partial tile"
-        const int j = wi / a.P;
-        p = wi - j * a.P;
-        const int t0 = j * G;
+    // item wi = (order position o, parent p), o-major; group j = (o + rot) % items_per_parent covers the full tiles j G ..; the
+    // LAST group (the short one) also carries the parent's partial tile, which it runs first.  Tile sequence ts .. t1-1, where
+    // t < t0 means "the partial tile".
+    auto item_tiles = [&](int wi, int& p, int& t0, int& ts, int& t1) {
+        const int o = wi / a.P;
+        p = wi - o * a.P;
+        int j = o + a.rot;
+        if (j >= a.items_per_parent) j -= a.items_per_parent;
+        t0 = j * G;
         t1 = t0 + G < a.n_full ? t0 + G : a.n_full;
-        ts = (j == 0 && a.rem) ? t0 - 1 : t0;
+        ts = (j == a.items_per_parent - 1 && a.rem) ? t0 - 1 : t0;
     };
     auto robot_rows = [&](int p, int t) {                          // rows of child 16 t + n of parent p -> rin
         const int c0 = 16 * t + n;
@@ -344,48 +179,182 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
             rin[s] = k < 9 ? rr[k] : 0.f;
         }
     };
-    auto item_loads = [&](int wi) {                                // first robot rows + crowd fragments of item wi
-        int p, ts, t1;
-        item_tiles(wi, p, ts, t1);
-        robot_rows(p, ts < (wi / a.P) * G ? a.n_full : ts);
-        const int N4 = crowd_n4(N);
-        const float* blk = a.blocks + (size_t)p * crowd_block_floats(N);
-        const float* gXh = blk;
-        const float* gGm = blk + N * XD;
-        const float* gUWT = blk + 2 * N * XD;
-        const float* gms = gUWT + XD * N4;
-        const float* gzs = gms + N4;
+    auto human_rows = [&](int p) {                                 // state rows of the parent's crowd (node 16 pct + n) -> hin
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int row = 16 * nt + n;                          // A-operand rows: nodes >= N are zero rows
-            const int rc = row < N ? row : 0;                     // (row 0 = robot slot = zeros)
+        for (int pct = 0; pct < NT; ++pct) {
+            const int node = 16 * pct + n;
+            const bool ok = node >= 1 && node < N;
+            const float* hsrc = a.humans + ((size_t)p * a.H + (ok ? node - 1 : 0)) * 5;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int k = 4 * s + q;
+                hin[pct][s] = (ok && k < 5) ? hsrc[k] : 0.f;
+            }
+        }
+    };
+    auto item_loads = [&](int wi) {                                // first robot rows + crowd state rows of item wi
+        int p, t0, ts, t1;
+        item_tiles(wi, p, t0, ts, t1);
+        robot_rows(p, ts < t0 ? a.n_full : ts);
+        human_rows(p);
+    };
+    // Crowd-only quantities of the item's parent, from hin, into the registers the tiles read (row 0 = robot slot and rows >= N
+    // are zero rows / contribute nothing).  The MFMA D layout of the chain (lane (n, q): node 16 pct + n, features 16 ot + 4 q + r)
+    // is the A-operand layout of the S products; Xh^T and the feature-major UW go through the wave's scratch (free between items).
+    auto crowd_compute = [&]() {
+        const float* wh1 = lds + LO::wh1;   // [8][W1LD], rows 5..7 zero
+        const float* bh1 = lds + LO::bh1;
+        const float* wh2 = lds + LO::wh2;   // [HID][WLD]
+        const float* bh2 = lds + LO::bh2;
+        float* Xs = AB;                     // [NP][XLD]: Xh, later UW
+        float* msz = AB + NP * XLD;         // [2][NP]: msh | Zsh
+        // part 1: Xh = w_h(humans), G = Xh Wa   (transposed MFMA chain, 16 nodes per pass)
+#pragma unroll
+        for (int pct = 0; pct < NT; ++pct) {
+            const int node = 16 * pct + n;
+            const bool node_ok = node >= 1 && node < N;
+            f32x4 hacc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int k = 4 * s + q;
+#pragma unroll
+                for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wh1[k * W1LD + 16 * ht + n], hin[pct][s], hacc[ht]);
+            }
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&bh1[16 * ht + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hacc[ht][r] = relu1(hacc[ht][r] + bb[r]);
+            }
+            f32x4 xa[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot)
+                        xa[ot] = mfma4(wh2[(16 * ht + 4 * q + r) * WLD + 16 * ot + n], hacc[ht][r], xa[ot]);
+            }
+            load_fence();
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
-                gq[nt][ot] = *reinterpret_cast<const f32x4*>(&gGm[rc * XD + 16 * ot + 4 * q]);
-                xq[nt][ot] = *reinterpret_cast<const f32x4*>(&gXh[rc * XD + 16 * ot + 4 * q]);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&bh2[16 * ot + 4 * q]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {                     // Xh^T for p Xh: Xh[16nt+4q+r][16ot+n], strided
-                    const int j = 16 * nt + 4 * q + r;
-                    xt[nt][ot][r] = gXh[(j < N ? j : 0) * XD + 16 * ot + n];
-                }
+                for (int r = 0; r < 4; ++r) xa[ot][r] = node_ok ? relu1(xa[ot][r] + bb[r]) : 0.f;   // robot slot / padding rows: 0
+                *reinterpret_cast<f32x4*>(&Xs[node * XLD + 16 * ot + 4 * q]) = xa[ot];
+                xq[pct][ot] = xa[ot];
             }
-            const int m4 = 16 * nt + 4 * q;                       // msh / zsh of nodes m4 .. m4+3 (N4 is a multiple of 4)
-            ms[nt] = *reinterpret_cast<const f32x4*>(&gms[m4 < N4 ? m4 : 0]);
-            zs[nt] = *reinterpret_cast<const f32x4*>(&gzs[m4 < N4 ? m4 : 0]);
+            f32x4 pg[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int gt = 0; gt < 2; ++gt)
+                        pg[gt] = mfma4(wa[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xa[ot][r], pg[gt]);
+            }
+            load_fence();
+            gq[pct][0] = pg[0];
+            gq[pct][1] = pg[1];
+        }
+        __builtin_amdgcn_wave_barrier();
+        load_fence();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xt[nt][ot][r] = Xs[(16 * nt + 4 * q + r) * XLD + 16 * ot + n];      // Xh^T for p Xh and U
+        load_fence();
+        __builtin_amdgcn_wave_barrier();
+        // part 2 (every Xh row is in registers now): S_ij = G_i . Xh_j over humans j, msh / E / Zsh, U = E Xh, UW = U W1
+#pragma unroll
+        for (int pct = 0; pct < NT; ++pct) {
+            const int node = 16 * pct + n;
+            const bool node_ok = node >= 1 && node < N;
+            f32x4 e[NT];
+            float mx = NEG_INF;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                f32x4 sacc = zero4();
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc = mfma4(xq[jt][ft][r], gq[pct][ft][r], sacc);      // [j = 16jt+4q+r][i = my node]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * jt + 4 * q + r;
+                    if (sim != SIM_SOFTMAX) sacc[r] = plain_weight(sim, sacc[r], node, j);
+                    if (j < 1 || j >= N) sacc[r] = sim == SIM_SOFTMAX ? NEG_INF : 0.f;
+                    mx = fmaxf(mx, sacc[r]);
+                }
+                e[jt] = sacc;
+            }
+            mx = kgroups_max(mx);
+            if (!node_ok || sim != SIM_SOFTMAX) mx = 0.f;
+            float z = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (sim == SIM_SOFTMAX) e[jt][r] = __expf(e[jt][r] - mx);
+                    if (!node_ok) e[jt][r] = 0.f;
+                    z += e[jt][r];
+                }
+            z = kgroups_sum(z);
+            if (q == 0) {
+                msz[node] = mx;
+                msz[NP + node] = node_ok ? z : 1.f;
+            }
+            f32x4 u[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    u[0] = mfma4(xt[jt][0][r], e[jt][r], u[0]);                               // U^T[f][i] = sum_j Xh[j][f] E[i][j]
+                    u[1] = mfma4(xt[jt][1][r], e[jt][r], u[1]);
+                }
+            f32x4 uw[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot)
+                        uw[ot] = mfma4(w1[(16 * ft + 4 * q + r) * WLD + 16 * ot + n], u[ft][r], uw[ot]);
+            }
+            load_fence();
+            *reinterpret_cast<f32x4*>(&Xs[node * XLD + 4 * q]) = uw[0];                      // UW rows over the (consumed) Xh rows
+            *reinterpret_cast<f32x4*>(&Xs[node * XLD + 16 + 4 * q]) = uw[1];
+        }
+        __builtin_amdgcn_wave_barrier();
+        load_fence();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            ms[nt] = *reinterpret_cast<const f32x4*>(&msz[16 * nt + 4 * q]);
+            zs[nt] = *reinterpret_cast<const f32x4*>(&msz[NP + 16 * nt + 4 * q]);
         }
 #pragma unroll
         for (int i4 = 0; i4 < HRL / 4; ++i4)
-            uw4[i4] = 4 * i4 < N4 ? *reinterpret_cast<const f32x4*>(&gUWT[(lane & 31) * N4 + 4 * i4]) : zero4();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) uw4[i4][k] = Xs[(4 * i4 + k) * XLD + (lane & 31)];      // lane = feature holds its nodes
+        load_fence();
+        __builtin_amdgcn_wave_barrier();      // the tiles' AB / Y0 writes stay behind these reads
     };
     PHASE_START();
-    const int wi_first = wave * gridDim.x + blockIdx.x;
-    if (wi_first < n_group) item_loads(wi_first);
-    for (int wi = wi_first; wi < n_items; wi += stride) {
+    if (wl < n_items) item_loads(wl);
+    for (int pass = 0; pass < n_pass; ++pass) {
+        const int wi = item_at(pass, wl);
+        if (wi >= n_items) break;                          // only the last pass is short
+        const int wi_next = pass + 1 < n_pass ? item_at(pass + 1, wl) : n_items;
         PHASE_MARK(0);
-        int p, ts, t1;
-        item_tiles(wi, p, ts, t1);
-        const int t0 = (wi / a.P) * G;
+        int p, t0, ts, t1;
+        item_tiles(wi, p, t0, ts, t1);
         load_fence();
+        crowd_compute();
         PHASE_MARK(1);
 
       for (int ti = ts; ti < t1; ++ti) {
@@ -592,7 +561,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         }
         __builtin_amdgcn_wave_barrier();      // the next tile's Y0 / AB writes stay behind this tile's reads
         PHASE_MARK(5);
-        if (ti + 1 == t1 && wi + stride < n_group) item_loads(wi + stride);     // next item's loads fly under this tile's head
+        if (ti + 1 == t1 && wi_next < n_items) item_loads(wi_next);     // next item's loads fly under this tile's head
 
         if (!full) {
             // partial last tile: leave the rows [t_c | H1_0] for the tile-packed head pass
@@ -612,6 +581,33 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         if (q == 0) a.value[(size_t)p * A + c] = v + hb4;
         PHASE_MARK(6);
       }
+    }
+    if (a.rem) {
+        // Rows of this workgroup's partial tiles (parents p = blockIdx + s * grid, all written by waves of THIS workgroup):
+        // scored here, tile-packed over parents -- 16 parents' `stop` children fill one head tile exactly, so the head never
+        // multiplies padding columns and the path needs no second launch.
+        __syncthreads();
+        const int b = blockIdx.x;
+        const int o_p = a.rot ? 0 : a.items_per_parent - 1;          // order position of the group that carries the partial tile
+        const int lo = o_p * a.P;                                    // its items: lo .. lo + P - 1
+        const int k_lo = lo / S, k_hi = (lo + a.P - 1) / S;
+        const int n_rows = (k_hi - k_lo + 1) * kFusedWaves * a.rem;  // (pass, wave) slots of this workgroup x rows per partial tile
+        for (int tt = wave; 16 * tt < n_rows; tt += kFusedWaves) {
+            const int i = 16 * tt + n;
+            const int slot = i / a.rem, kr = i - slot * a.rem;
+            const int wi = item_at(k_lo + slot / kFusedWaves, (slot % kFusedWaves) * (int)gridDim.x + b);
+            const bool valid = i < n_rows && wi >= lo && wi < lo + a.P;
+            const int p = valid ? wi - lo : 0, k = kr;
+            const float* row = a.rows_left + ((size_t)p * a.rem + k) * 64;
+            f32x4 tin[2], hp[2];
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                tin[ot] = valid ? *reinterpret_cast<const f32x4*>(row + 16 * ot + 4 * q) : zero4();
+                hp[ot] = valid ? *reinterpret_cast<const f32x4*>(row + 32 + 16 * ot + 4 * q) : zero4();
+            }
+            const float v = head_chain<LO, D1, D2, D3, SKIP>(lds, tin, hp, lane);
+            if (valid && q == 0) a.value[(size_t)p * A + 16 * a.n_full + k] = v + hb4;
+        }
     }
     PHASE_FLUSH();
 }
@@ -647,59 +643,50 @@ __device__ __forceinline__ float matrix_element(const float* __restrict__ W, int
 }
 
 template <int D1, int D2, int D3>
-__global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedArgs a, const CrowdArgs c, float* img) {
+__global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedArgs a, float* img) {
     using LO = FusedLds<D1, D2, D3>;
     const int e = blockIdx.x * kPackThreads + threadIdx.x;
-    if (e >= LO::scratch + CrowdLds::total) return;
+    if (e >= LO::scratch) return;
     float v;
-    if (e < LO::scratch) {
-        if (e < LO::br1) v = matrix_element<9, HID, W1LD>(a.wr1, e - LO::wr1);
-        else if (e < LO::wr2) v = a.br1[e - LO::br1];
-        else if (e < LO::br2) v = matrix_element<HID, XD, WLD>(a.wr2, e - LO::wr2);
-        else if (e < LO::wa) v = a.br2[e - LO::br2];
-        else if (e < LO::w1) {
-            const int k = e - LO::wa, r = k / WLD, col = k - r * WLD;
-            v = a.wa ? matrix_element<XD, XD, WLD>(a.wa, k) : ((col < XD && r == col) ? 1.f : 0.f);      // gaussian: Wa = I
-        } else if (e < LO::f_last) v = matrix_element<XD, XD, WLD>(a.w1, e - LO::w1);
-        else if (e < LO::f1) v = frag_element<XD, XD>(a.w_last, e - LO::f_last);
-        else if (e < LO::f2) v = frag_element<XD, D1>(a.hw1, e - LO::f1);
-        else if (e < LO::f3) v = frag_element<D1, D2>(a.hw2, e - LO::f2);
-        else if (e < LO::b1) v = frag_element<D2, D3>(a.hw3, e - LO::f3);
-        else if (e < LO::b2) v = bias_element<D1>(a.hb1, e - LO::b1);
-        else if (e < LO::b3) v = bias_element<D2>(a.hb2, e - LO::b2);
-        else if (e < LO::w4) v = bias_element<D3>(a.hb3, e - LO::b3);
-        else v = bias_element<D3>(a.hw4, e - LO::w4);                    // w4 is [D3][1]: same padded vector layout as a bias
-    } else {
-        const int k = e - LO::scratch;
-        if (k < CrowdLds::bh1) v = matrix_element<5, HID, W1LD>(c.wh1, k - CrowdLds::wh1);
-        else if (k < CrowdLds::wh2) v = c.bh1[k - CrowdLds::bh1];
-        else if (k < CrowdLds::bh2) v = matrix_element<HID, XD, WLD>(c.wh2, k - CrowdLds::wh2);
-        else if (k < CrowdLds::wa) v = c.bh2[k - CrowdLds::bh2];
-        else if (k < CrowdLds::w1) {
-            const int kk = k - CrowdLds::wa, r = kk / WLD, col = kk - r * WLD;
-            v = c.wa ? matrix_element<XD, XD, WLD>(c.wa, kk) : ((col < XD && r == col) ? 1.f : 0.f);
-        } else v = matrix_element<XD, XD, WLD>(c.w1, k - CrowdLds::w1);
-    }
+    if (e < LO::br1) v = matrix_element<9, HID, W1LD>(a.wr1, e - LO::wr1);
+    else if (e < LO::wr2) v = a.br1[e - LO::br1];
+    else if (e < LO::br2) v = matrix_element<HID, XD, WLD>(a.wr2, e - LO::wr2);
+    else if (e < LO::wa) v = a.br2[e - LO::br2];
+    else if (e < LO::w1) {
+        const int k = e - LO::wa, r = k / WLD, col = k - r * WLD;
+        v = a.wa ? matrix_element<XD, XD, WLD>(a.wa, k) : ((col < XD && r == col) ? 1.f : 0.f);      // gaussian: Wa = I
+    } else if (e < LO::wh1) v = matrix_element<XD, XD, WLD>(a.w1, e - LO::w1);
+    else if (e < LO::bh1) v = matrix_element<5, HID, W1LD>(a.wh1, e - LO::wh1);
+    else if (e < LO::wh2) v = a.bh1[e - LO::bh1];
+    else if (e < LO::bh2) v = matrix_element<HID, XD, WLD>(a.wh2, e - LO::wh2);
+    else if (e < LO::f_last) v = a.bh2[e - LO::bh2];
+    else if (e < LO::f1) v = frag_element<XD, XD>(a.w_last, e - LO::f_last);
+    else if (e < LO::f2) v = frag_element<XD, D1>(a.hw1, e - LO::f1);
+    else if (e < LO::f3) v = frag_element<D1, D2>(a.hw2, e - LO::f2);
+    else if (e < LO::b1) v = frag_element<D2, D3>(a.hw3, e - LO::f3);
+    else if (e < LO::b2) v = bias_element<D1>(a.hb1, e - LO::b1);
+    else if (e < LO::b3) v = bias_element<D2>(a.hb2, e - LO::b2);
+    else if (e < LO::w4) v = bias_element<D3>(a.hb3, e - LO::b3);
+    else v = bias_element<D3>(a.hw4, e - LO::w4);                    // w4 is [D3][1]: same padded vector layout as a bias
     img[e] = v;
 }
 
-constexpr size_t kImageFloats = FusedLds<32, 100, 100>::scratch + CrowdLds::total;
+constexpr size_t kImageFloats = FusedLds<32, 100, 100>::scratch;
 constexpr size_t kImageBytes = (kImageFloats * sizeof(float) + 255) & ~(size_t)255;
 
 struct FusedPlan {
     FusedArgs a;
-    CrowdArgs c;
-    size_t lds_bytes, crowd_lds_bytes;
+    size_t lds_bytes;
+    int grid;
     int hr, nt;
     bool ok;
 };
 
 // Which launches take the fused kernel.  Measured on MI355X (tools/kiter.py, profiles/r02_*): both organisations end up
-// pipe-bound (MFMA + VALU issue, no co-execution) at a shader clock that drops with utilisation, so the fused kernel wins
-// only where its per-tile latency (one wave carries a tile through ~400 MFMAs) is covered by many tiles per SIMD: from ~9 k
-// tiles (P ~ 1.5 k parents of 81 actions) upwards it is 2-5 % faster and moves 12x less HBM traffic; below, the two-stage
-// pair (8 waves share a parent, 4 waves per SIMD in the head) is faster.  RGL_CHILDREN_FUSED=1 / RGL_CHILDREN_TWO_STAGE=1
-// force one organisation (tests).
+// pipe-bound (MFMA + VALU issue, no co-execution) at a shader clock that drops with utilisation.  The fused kernel is one launch
+// that reads the child rows and writes the values; from ~3 k tiles (P ~ 500 parents of 81 actions) upwards it is the faster one
+// (P = 1024: 76 vs 79 us, 2048: 114 vs 131, 4096: 205 vs 233); below, the two-stage pair (8 waves share a parent, 4 waves per
+// SIMD in the head) hides the per-tile latency better.  RGL_CHILDREN_FUSED=1 / RGL_CHILDREN_TWO_STAGE=1 force one (tests).
 inline int fused_policy() {
     static const int pol = [] {
         const char* f = getenv("RGL_CHILDREN_FUSED");
@@ -709,38 +696,88 @@ inline int fused_policy() {
     return pol;
 }
 
+// How the tiles of a launch are cut into work items.  A work item = G consecutive full tiles of one parent (the last group of a
+// parent may be shorter, and also carries the parent's partial tile); its wave computes the parent's crowd quantities first, so
+// small G repeats crowd work (~0.45 of a tile) while large G leaves waves idle when parents are few.  Items are dealt over the
+// S = 8 x grid waves in "snake" passes, heaviest group first; two waves share a SIMD (pipe-bound: their loads add).  The plan
+// minimises the per-SIMD makespan of that dealing, by direct simulation (cached per shape: launches repeat).
+struct ItemPlan { int G, ipp, rot, grid; };
+
+inline int fused_cu_count() {
+    static const int n_cu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev);
+                                 (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    return n_cu;
+}
+
+inline ItemPlan plan_items(int P, int n_full, int rem) {
+    static std::mutex mu;
+    static std::unordered_map<unsigned long long, ItemPlan> cache;
+    const unsigned long long key = ((unsigned long long)P << 24) ^ ((unsigned long long)n_full << 8) ^ (unsigned long long)rem;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
+    constexpr float kCrowd = 0.45f, kPartial = 0.45f;          // in full-tile units (instruction counts of the phases)
+    const int n_cu = fused_cu_count();
+    const int CT = n_full > 0 ? n_full : 1;
+    ItemPlan best{1, CT, 0, 1};
+    float best_cost = -1.f;
+    std::vector<float> load;
+    for (int G = CT; G >= 1; --G) {
+        const int ipp = (CT + G - 1) / G;
+        if (G > 1 && (ipp - 1) * G >= CT) continue;
+        const int last_tiles = n_full - (ipp - 1) * G;           // full tiles of the last group (n_full == 0: 0)
+        const float c_full = kCrowd + G, c_last = kCrowd + (last_tiles > 0 ? last_tiles : 0) + (rem ? kPartial : 0.f);
+        const int rot = (ipp > 1 && c_last > c_full) ? ipp - 1 : 0;
+        const long n_items = (long)P * ipp;
+        const int grid = n_items < n_cu ? (int)n_items : n_cu;   // few items: one per CU before a second wave of any CU gets one
+        const long S = (long)grid * kFusedWaves;
+        const int n_simd = grid * 4;
+        load.assign(n_simd, 0.f);
+        for (int o = 0; o < ipp; ++o) {
+            int j = o + rot;
+            if (j >= ipp) j -= ipp;
+            const float c = j == ipp - 1 ? c_last : c_full;
+            for (long wi = (long)o * P; wi < (long)(o + 1) * P; ++wi) {
+                const long k = wi / S, r = wi - k * S;
+                const long w_l = (k & 1) ? S - 1 - r : r;
+                load[w_l % n_simd] += c;                         // waves w and w + 4 of a workgroup share a SIMD
+            }
+        }
+        float mk = 0.f;
+        for (float v : load) mk = v > mk ? v : mk;
+        if (best_cost < 0.f || mk < best_cost - 1e-3f) { best_cost = mk; best = ItemPlan{G, ipp, rot, grid}; }
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    cache.emplace(key, best);
+    return best;
+}
+
 inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A, int H) {
     FusedPlan pl;
     pl.ok = false;
     if (!fast_path_enabled() || !rank1_enabled() || fused_policy() < 0) return pl;
-    if (fused_policy() == 0 && (long)P * ((A + 15) / 16) < 9000) return pl;
+    if (fused_policy() == 0 && (long)P * ((A + 15) / 16) < 3000) return pl;
     if (fast_similarity_mode(g) < 0 || g.layerwise_graph || g.x_dim != XD || g.num_layer != 2) return pl;
     if (!mlp_is(g.w_r, 9, HID, XD, true) || !mlp_is(g.w_h, 5, HID, XD, true)) return pl;
     if (head_variant(head) != 0) return pl;
     const int N = H + 1;
     if (N > 32 || A < 1) return pl;
     FusedArgs& a = pl.a;
-    a.N = N; a.A = A; a.P = P;
+    a.N = N; a.A = A; a.P = P; a.H = H;
     pl.nt = (N + 15) / 16;
     pl.hr = N <= 8 ? 8 : (N <= 20 ? 20 : 32);
     a.SLD = 16 * pl.nt + 1;                      // rows padded to whole MFMA tiles (unconditional access), odd stride
     a.n_full = A / 16;
     a.rem = A % 16;
     a.sim = fast_similarity_mode(g);
-    {   // tiles per work item: as many as keeps >= 2 items on every SIMD of the GPU (256 CUs x 4) and the per-SIMD makespan minimal
-        const int CT = a.n_full > 0 ? a.n_full : 1;
-        int best_g = 1;
-        long best_cost = -1;
-        for (int G = CT; G >= 1; --G) {
-            const int ipp = (CT + G - 1) / G;
-            if (G > 1 && (ipp - 1) * G >= CT) continue;
-            const long items = (long)P * ipp;
-            if (G > 1 && items < 2048) continue;
-            const long cost = ((items + 1023) / 1024) * G;
-            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_g = G; }
-        }
-        a.tiles_per_item = best_g;
-        a.items_per_parent = (CT + best_g - 1) / best_g;      // n_full == 0: one item per parent, its partial tile alone
+    {
+        const ItemPlan ip = plan_items(P, a.n_full, a.rem);
+        a.tiles_per_item = ip.G;
+        a.items_per_parent = ip.ipp;
+        a.rot = ip.rot;
+        pl.grid = ip.grid;
     }
     pl.lds_bytes = (size_t)(FusedLds<32, 100, 100>::scratch + kFusedWaves * (2 * 16 * a.SLD + 16 * XLD)) * sizeof(float);
     if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
@@ -749,39 +786,17 @@ inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A,
     a.w_last = g.Ws[1];
     a.hw1 = head.weight[0]; a.hb1 = head.bias[0]; a.hw2 = head.weight[1]; a.hb2 = head.bias[1];
     a.hw3 = head.weight[2]; a.hb3 = head.bias[2]; a.hw4 = head.weight[3]; a.hb4 = head.bias[3];
-    CrowdArgs& c = pl.c;
-    c.wh1 = g.w_h.weight[0]; c.bh1 = g.w_h.bias[0]; c.wh2 = g.w_h.weight[1]; c.bh2 = g.w_h.bias[1];
-    c.wa = bilinear_wa(g); c.w1 = g.Ws[0];
-    c.P = P; c.H = H; c.N = N; c.sim = a.sim;
-    pl.crowd_lds_bytes = (size_t)(CrowdLds::total + kCrowdWaves * 16 * XLD) * sizeof(float);
+    a.wh1 = g.w_h.weight[0]; a.bh1 = g.w_h.bias[0]; a.wh2 = g.w_h.weight[1]; a.bh2 = g.w_h.bias[1];
     pl.ok = true;
     return pl;
 }
 
-template <int NT, bool SOFT>
-int launch_crowd(const FusedPlan& pl, hipStream_t st) {
-    auto kern = crowd_block_kernel<NT, SOFT>;
-    constexpr int PPW = kCrowdWaves / NT;
-    int grid = (pl.c.P + PPW - 1) / PPW;
-    if (grid > 512) grid = 512;                                   // resident workgroups (two per CU at ~120 VGPRs): persistent, one image copy each
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kCrowdWaves * 64), pl.crowd_lds_bytes, st, pl.c);
-    RGL_LAUNCH_CHECK();
-    return RGL_OK;
-}
-
 template <int HR, int NT, bool SKIP, bool SOFT>
 int launch_fused_ts(const FusedPlan& pl, hipStream_t st) {
-    int rc = launch_crowd<NT, SOFT>(pl, st);
-    if (rc) return rc;
     auto kern = children_fused_kernel<HR, NT, SKIP, SOFT, 32, 100, 100>;
     RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)pl.lds_bytes));
-    const int n_items = pl.a.P * pl.a.items_per_parent;
-    int grid = (n_items + kFusedWaves - 1) / kFusedWaves;
-    // persistent, one 8-wave workgroup per CU (LDS-bound)
-    static const int n_cu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev);
-                                 (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    if (grid > n_cu) grid = n_cu;
+    const int grid = pl.grid;                        // persistent, one 8-wave workgroup per CU (LDS-bound)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), pl.lds_bytes, st, pl.a);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
@@ -817,11 +832,10 @@ extern "C" int rgl_debug_read_fused_phase_cycles(unsigned long long* out16, int 
 
 namespace rgl {
 
-// workspace: crowd blocks [P][crowd_block_floats] | rows of the partial tiles [P][A % 16][64] | ... | weight images (at the END)
+// workspace: rows of the partial tiles [P][A % 16][64] | ... | weight image (at the END)
 size_t fused_children_workspace_bytes(int P, int A, int H) {
-    const int nt = (H + 1 + 15) / 16;
-    (void)nt;
-    const size_t main_bytes = ((size_t)P * crowd_block_floats(H + 1) + (size_t)P * (A % 16) * 64) * sizeof(float);
+    (void)H;
+    const size_t main_bytes = (size_t)P * (A % 16) * 64 * sizeof(float);
     return ((main_bytes + 255) & ~(size_t)255) + kImageBytes;
 }
 
@@ -835,7 +849,7 @@ int pack_children_images(const RglGraph* g, const RglMlp* head, int P, int A, in
     FusedPlan fp = plan_fused(*g, *head, P, A, H);
     if (!fp.ok || !workspace || workspace_bytes < fused_children_workspace_bytes(P, A, H)) return 1;
     hipLaunchKernelGGL((pack_images_kernel<32, 100, 100>), dim3((unsigned)((kImageFloats + kPackThreads - 1) / kPackThreads)),
-                       dim3(kPackThreads), 0, stream, fp.a, fp.c, image_of(workspace, workspace_bytes));
+                       dim3(kPackThreads), 0, stream, fp.a, image_of(workspace, workspace_bytes));
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }
@@ -852,22 +866,13 @@ int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, i
         if (rc) return rc;
     }
     float* image = image_of(workspace, workspace_bytes);
-    float* blocks = (float*)workspace;
-    float* rows_left = blocks + (size_t)P * crowd_block_floats(H + 1);
-    fp.c.humans = humans_next;
-    fp.c.blocks = blocks;
-    fp.c.image = image + FusedLds<32, 100, 100>::scratch;
+    float* rows_left = (float*)workspace;
     fp.a.child_robot = child_robot;
-    fp.a.blocks = blocks;
+    fp.a.humans = humans_next;
     fp.a.value = child_value;
     fp.a.image = image;
     fp.a.rows_left = rows_left;
-    int rc = launch_fused(fp, g->skip_connection != 0, stream);
-    if (rc) return rc;
-    if (fp.a.rem)      // rows of the partial tiles, tile-packed over parents: value[p*A + 16*n_full + j]
-        return launch_head_rows_strided(g, head, rows_left, P * fp.a.rem, child_value, fp.a.rem, A, 16 * fp.a.n_full, stream,
-                                        image + FusedLds<32, 100, 100>::f_last);
-    return RGL_OK;
+    return launch_fused(fp, g->skip_connection != 0, stream);
 }
 
 }  // namespace rgl

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r02_x}; shift
-KERNELS=${@:-children_fused crowd_block robot_head}
+KERNELS=${@:-children_fused pack_images robot_head}
 O=$R/gpurun_out/${TAG}_pmc
 mkdir -p $O
 : > $O.txt

@@ -35,7 +35,7 @@ for grp in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_ACTIV
   rocprofv3 --kernel-trace --pmc $grp -d $O/pmc$i -o pmc -- python $R/tools/profile_children.py > $O/pmc$i.log 2>&1
   f=$(find $O/pmc$i -name "*results.db" | head -1)
   if [ -n "$f" ]; then
-    for k in children_fused crowd_block robot_head children_rank1; do python $R/tools/pmc_summary.py $f $k >> $O.md; done
+    for k in children_fused pack_images robot_head children_rank1; do python $R/tools/pmc_summary.py $f $k >> $O.md; done
     if [ "$grp" = "FETCH_SIZE" ]; then cp $f $O/fetch.db; fi
     if [ "$grp" = "WRITE_SIZE" ]; then cp $f $O/write.db; fi
   else echo "(pass $i: $grp -- no database)" >> $O.md; fi
@@ -57,7 +57,7 @@ def totals(path, sym):
     return {k: sum(v.values()) / len(v) for k, v in per.items()}
 try:
     f, w = totals("$O/fetch.db", "FETCH_SIZE"), totals("$O/write.db", "WRITE_SIZE")
-    keep = [k for k in f if any(s in k for s in ("children_fused", "crowd_block", "robot_head", "children_rank1"))]
+    keep = [k for k in f if any(s in k for s in ("children_fused", "pack_images", "robot_head", "children_rank1"))]
     scenes = 4096 * 81
     total_bytes = sum(2 * f[k] + w.get(k, 0.0) for k in keep) * 1024
     rec = {"source": "profiles/$TAG.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/profile_children.py, P = 4096 parents x 81 children, N = 20, L = 2)",
