@@ -34,6 +34,17 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // the fused tile kernel
 // ------------------------------------------------------------------------------------------------
+// Wave-private LDS scratch of children_fused_kernel (floats).  Packed row pass (softmax, HR <= 20): UW [HRL][32] of the item's parent
+// | (r, b) table [16][HRL + 2][2] of the tile; otherwise (a, b) table [16][16 NT + 1][2] | Y [16][XLD].  Between items the same
+// space holds Xh [16 NT][XLD] | msh, Zsh [2][16 NT] of the crowd computation.
+__host__ __device__ constexpr bool fused_packed_rows(int HR, bool SOFT) { return SOFT && HR <= 20; }
+__host__ __device__ constexpr int fused_scratch_floats(int HR, int NT, bool SOFT) {
+    const int NP = 16 * NT, HRL = HR < NP ? HR : NP;
+    const int main_fl = fused_packed_rows(HR, SOFT) ? HRL * 32 + 16 * (HRL + 2) * 2 : 2 * 16 * (NP + 1) + 16 * XLD;
+    const int crowd_fl = NP * XLD + 2 * NP;
+    return ((main_fl > crowd_fl ? main_fl : crowd_fl) + 3) & ~3;
+}
+
 struct FusedArgs {
     const float *wr1, *br1, *wr2, *br2, *wa, *w1;                       // child-side weights (k-major)
     const float *wh1, *bh1, *wh2, *bh2;                                 // w_h (crowd side)
@@ -68,16 +79,18 @@ struct FusedLds {
     static constexpr int bh1 = wh1 + 8 * W1LD;
     static constexpr int wh2 = bh1 + HID;
     static constexpr int bh2 = wh2 + HID * WLD;
-    // head fragments (layout of rgl_head.hip)
-    static constexpr int f_last = bh2 + XD;
-    static constexpr int f1 = f_last + 2 * 2 * 4 * 64;
-    static constexpr int f2 = f1 + Tiles<D1>::v * 2 * 4 * 64;
-    static constexpr int f3 = f2 + Tiles<D2>::v * Tiles<D1>::v * 4 * 64;
-    static constexpr int b1 = f3 + Tiles<D3>::v * Tiles<D2>::v * 4 * 64;
+    // value head: per-feature vectors, then the A fragments (layout of rgl_head.hip).  Everything addressed with many different
+    // lane patterns sits below 64 KB (the reach of a ds instruction's immediate offset from a shared base register); the large
+    // f3 image, addressed with one pattern, spans the boundary.
+    static constexpr int b1 = bh2 + XD;
     static constexpr int b2 = b1 + Tiles<D1>::v * 16;
     static constexpr int b3 = b2 + Tiles<D2>::v * 16;
     static constexpr int w4 = b3 + Tiles<D3>::v * 16;
-    static constexpr int scratch = w4 + Tiles<D3>::v * 16;       // per wave: AB[16][SLD][2] | Y[16][XLD]   (between items: Xh / UW [16 NT][XLD] | msh, Zsh [2][16 NT])
+    static constexpr int f_last = w4 + Tiles<D3>::v * 16;
+    static constexpr int f1 = f_last + 2 * 2 * 4 * 64;
+    static constexpr int f2 = f1 + Tiles<D1>::v * 2 * 4 * 64;
+    static constexpr int f3 = f2 + Tiles<D2>::v * Tiles<D1>::v * 4 * 64;
+    static constexpr int scratch = f3 + Tiles<D3>::v * Tiles<D2>::v * 4 * 64;       // per wave: fused_scratch_floats()
 };
 
 // h = relu(t W_last)(+hprev), value head 32 -> D1 -> D2 -> D3 -> 1 for the 16 children of a tile (lane (n, q): child n, D-layout
@@ -125,7 +138,10 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
-    const int N = a.N, A = a.A, SLD = a.SLD;
+    constexpr bool PK = fused_packed_rows(HR, SOFT);    // row pass in the D layout with packed fp32 math
+    constexpr int HRL = HR < NP ? HR : NP;              // rows of UW the row pass visits (rows >= N are zero)
+    constexpr int SLDK = HRL + 2;
+    const int N = a.N, A = a.A, SLD = PK ? SLDK : a.SLD;
     const float NEG_INF = -INFINITY;
     copy_image<LO::scratch, nthreads>(lds, a.image, tid);      // weight image, once per workgroup
     __syncthreads();
@@ -135,8 +151,10 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
     const float* br2 = lds + LO::br2;
     const float* wa = lds + LO::wa;     // [XD][WLD]
     const float* w1 = lds + LO::w1;     // [XD][WLD]
-    float* AB = lds + LO::scratch + wave * (2 * 16 * SLD + 16 * XLD);   // [16][SLD][2]: per child and row (a, b), p folded in
-    float* Y0 = AB + 2 * 16 * SLD;                                      // [16][XLD]: x0 W1, then t_c without the robot-row term
+    float* WS = lds + LO::scratch + wave * fused_scratch_floats(HR, NT, SOFT);
+    float* UWs = WS;                                                    // PK: [HRL][32] UW rows of the item's parent
+    float* AB = PK ? WS + HRL * 32 : WS;                                // [16][SLD][2]: per child and row (a, b) / (r, b), p folded in
+    float* Y0 = AB + 2 * 16 * SLD;                                      // !PK: [16][XLD]: x0 W1, then t_c without the robot-row term
     const float hb4 = a.hb4[0];
 
     // Work items (each class dealt round-robin over all waves of the GPU, so every wave sees the same mix):
@@ -155,7 +173,6 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
     // pass k deals items k S .. k S + S - 1 over the waves, odd passes in reverse ("snake"): with the heavy items first in the
     // order, the waves that got a heavy item in one pass get a light one (or none) in the next
     auto item_at = [&](int k, int w_l) { return k * S + ((k & 1) ? S - 1 - w_l : w_l); };
-    constexpr int HRL = HR < NP ? HR : NP;              // rows of UW a lane holds (rows >= N are zero)
     float rin[3], hin[NT][2];
     f32x4 gq[NT][2], xq[NT][2], ms[NT], zs[NT], xt[NT][2], uw4[HRL / 4];
     // item wi = (order position o, parent p), o-major; group j = (o + rot) % items_per_parent covers the full tiles j G ..; the
@@ -206,8 +223,8 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         const float* bh1 = lds + LO::bh1;
         const float* wh2 = lds + LO::wh2;   // [HID][WLD]
         const float* bh2 = lds + LO::bh2;
-        float* Xs = AB;                     // [NP][XLD]: Xh, later UW
-        float* msz = AB + NP * XLD;         // [2][NP]: msh | Zsh
+        float* Xs = WS;                     // [NP][XLD]: Xh, later UW
+        float* msz = WS + NP * XLD;         // [2][NP]: msh | Zsh
         // part 1: Xh = w_h(humans), G = Xh Wa   (transposed MFMA chain, 16 nodes per pass)
 #pragma unroll
         for (int pct = 0; pct < NT; ++pct) {
@@ -327,8 +344,15 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                         uw[ot] = mfma4(w1[(16 * ft + 4 * q + r) * WLD + 16 * ot + n], u[ft][r], uw[ot]);
             }
             load_fence();
-            *reinterpret_cast<f32x4*>(&Xs[node * XLD + 4 * q]) = uw[0];                      // UW rows over the (consumed) Xh rows
-            *reinterpret_cast<f32x4*>(&Xs[node * XLD + 16 + 4 * q]) = uw[1];
+            if constexpr (PK) {                                                              // UW rows over the (consumed) Xh rows
+                if (node < HRL) {
+                    *reinterpret_cast<f32x4*>(&UWs[node * 32 + 4 * q]) = uw[0];
+                    *reinterpret_cast<f32x4*>(&UWs[node * 32 + 16 + 4 * q]) = uw[1];
+                }
+            } else {
+                *reinterpret_cast<f32x4*>(&Xs[node * XLD + 4 * q]) = uw[0];
+                *reinterpret_cast<f32x4*>(&Xs[node * XLD + 16 + 4 * q]) = uw[1];
+            }
         }
         __builtin_amdgcn_wave_barrier();
         load_fence();
@@ -337,10 +361,12 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
             ms[nt] = *reinterpret_cast<const f32x4*>(&msz[16 * nt + 4 * q]);
             zs[nt] = *reinterpret_cast<const f32x4*>(&msz[NP + 16 * nt + 4 * q]);
         }
+        if constexpr (!PK) {
 #pragma unroll
-        for (int i4 = 0; i4 < HRL / 4; ++i4)
+            for (int i4 = 0; i4 < HRL / 4; ++i4)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) uw4[i4][k] = Xs[(4 * i4 + k) * XLD + (lane & 31)];      // lane = feature holds its nodes
+                for (int k = 0; k < 4; ++k) uw4[i4][k] = Xs[(4 * i4 + k) * XLD + (lane & 31)];  // lane = feature holds its nodes
+        }
         load_fence();
         __builtin_amdgcn_wave_barrier();      // the tiles' AB / Y0 writes stay behind these reads
     };
@@ -364,7 +390,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         const int n_valid = full ? 16 : a.rem;
 
         // ---------------- embedding: x0 = w_r(robot'), y = x0 W1, g0 = x0 Wa (transposed MFMA chain) ----------------
-        f32x4 xacc[2] = {zero4(), zero4()}, gacc[2] = {zero4(), zero4()};
+        f32x4 xacc[2] = {zero4(), zero4()}, gacc[2] = {zero4(), zero4()}, yacc[2] = {zero4(), zero4()};
         float s00 = 0.f;
         {
             f32x4 hacc[4] = {zero4(), zero4(), zero4(), zero4()};
@@ -397,7 +423,6 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xacc[ot][r] = relu1(xacc[ot][r] + bb[r]);
             }
-            f32x4 yacc[2] = {zero4(), zero4()};
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
                 load_fence();
@@ -410,8 +435,10 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                     }
             }
             load_fence();
-            *reinterpret_cast<f32x4*>(&Y0[n * XLD + 4 * q]) = yacc[0];
-            *reinterpret_cast<f32x4*>(&Y0[n * XLD + 16 + 4 * q]) = yacc[1];
+            if constexpr (!PK) {
+                *reinterpret_cast<f32x4*>(&Y0[n * XLD + 4 * q]) = yacc[0];
+                *reinterpret_cast<f32x4*>(&Y0[n * XLD + 16 + 4 * q]) = yacc[1];
+            }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -471,32 +498,93 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                     t0h[0] = mfma4(xt[nt][0][r], s0t[nt][r], t0h[0]);
                     t0h[1] = mfma4(xt[nt][1][r], s0t[nt][r], t0h[1]);
                 }
+            if constexpr (PK) {
+                // human row i of child c: relu((alpha UW_i + beta y_c) / Z) weighted by p_i = b_i relu(r_i UW_i + y_c) with
+                // r_i = alpha / beta = exp(msh_i - S_i0), b_i = p_i beta / Z = p_i / (r_i Zsh_i + 1); r is capped at e^60 (beyond,
+                // beta y is below fp32 resolution of the row and b r = p / Zsh is exact)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int nd = 16 * nt + 4 * q + r;
-                    const float pv = s0t[nt][r];
-                    float al, be;
-                    if (sim == SIM_SOFTMAX) {
-                        const float m = fmaxf(ms[nt][r], sct[nt][r]);
-                        al = __expf(ms[nt][r] - m);
-                        be = __expf(sct[nt][r] - m);
-                    } else {
-                        al = 1.f;
-                        be = plain_weight(sim, sct[nt][r], nd, 0);        // diagonal: nd >= 1 here, so 0
+                    for (int r = 0; r < 4; ++r) {
+                        const int nd = 16 * nt + 4 * q + r;
+                        const float rr = __expf(fminf(ms[nt][r] - sct[nt][r], 60.f));
+                        const float bb = s0t[nt][r] * __builtin_amdgcn_rcpf(fmaf(rr, zs[nt][r], 1.f));
+                        const bool rh = nd >= 1 && nd < N;
+                        if (nd < HRL) *reinterpret_cast<f32x2*>(&AB[(n * SLDK + nd) * 2]) = f32x2{rh ? rr : 0.f, rh ? bb : 0.f};
                     }
-                    const float piz = pv * __builtin_amdgcn_rcpf(fmaf(al, zs[nt][r], be));
-                    const bool rh = nd >= 1 && nd < N;
-                    *reinterpret_cast<f32x2*>(&AB[(n * SLD + nd) * 2]) = f32x2{rh ? al * piz : 0.f, rh ? be * piz : 0.f};
-                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int nd = 16 * nt + 4 * q + r;
+                        const float pv = s0t[nt][r];
+                        float al, be;
+                        if (sim == SIM_SOFTMAX) {
+                            const float m = fmaxf(ms[nt][r], sct[nt][r]);
+                            al = __expf(ms[nt][r] - m);
+                            be = __expf(sct[nt][r] - m);
+                        } else {
+                            al = 1.f;
+                            be = plain_weight(sim, sct[nt][r], nd, 0);        // diagonal: nd >= 1 here, so 0
+                        }
+                        const float piz = pv * __builtin_amdgcn_rcpf(fmaf(al, zs[nt][r], be));
+                        const bool rh = nd >= 1 && nd < N;
+                        *reinterpret_cast<f32x2*>(&AB[(n * SLD + nd) * 2]) = f32x2{rh ? al * piz : 0.f, rh ? be * piz : 0.f};
+                    }
+            }
         }
         __builtin_amdgcn_wave_barrier();
         load_fence();
         PHASE_MARK(3);
 
-        // ---------------- row pass over my 16 children: two per step (half-wave each), lane = feature -----------------
-        {
+        // ---------------- row pass over my 16 children -------------------------------------------------------------------
+        f32x4 tp4[2] = {zero4(), zero4()};           // PK: t_c without the robot-row / skip terms, D layout (child n, features)
+        if constexpr (PK) {
+            // D layout throughout: lane (n, q) = child n, features 4q..4q+3 and 16+4q..: y and the result stay in registers, the
+            // child's (r_i, b_i) come as broadcast b128 reads (two nodes each), UW_i as two broadcast b128 reads; per node and feature
+            // pair: v_pk_fma (r UW + y), two integer-max relus, v_pk_fma (acc += b relu) -- 4 instructions per 2 elements where
+            // the lane = feature form spends 8 (DPP broadcasts cannot feed packed operands).
+            f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+            const f32x2 y2[4] = {f32x2{yacc[0][0], yacc[0][1]}, f32x2{yacc[0][2], yacc[0][3]},
+                                 f32x2{yacc[1][0], yacc[1][1]}, f32x2{yacc[1][2], yacc[1][3]}};
+            const float* abrow = AB + n * SLDK * 2;
+            // software pipeline by node pair: the loads of pair j + 1 are issued before the arithmetic of pair j; the register
+            // fence after it keeps hipcc from stacking all 48 b128 loads (192 VGPRs) in front of the arithmetic
+            f32x4 ab[2], ua[2][2], ub[2][2];                          // [buffer][node of the pair]
+            auto load_pair = [&](int j2, int buf) {
+                ab[buf] = *reinterpret_cast<const f32x4*>(&abrow[4 * j2]);              // (r, b) of nodes 2 j2, 2 j2 + 1
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int i = 2 * j2 + e;
+                    ua[buf][e] = *reinterpret_cast<const f32x4*>(&UWs[i * 32 + 4 * q]);
+                    ub[buf][e] = *reinterpret_cast<const f32x4*>(&UWs[i * 32 + 16 + 4 * q]);
+                }
+            };
+            load_pair(0, 0);
+            static_for<0, HRL / 2>([&](auto jc) {
+                constexpr int j2 = decltype(jc)::value, buf = j2 & 1;
+                if constexpr (j2 + 1 < HRL / 2) load_pair(j2 + 1, buf ^ 1);
+                static_for<0, 2>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value, i = 2 * j2 + e;
+                    if constexpr (i >= 1) {                                             // node 0 is the robot slot
+                        const f32x2 r2 = f32x2{ab[buf][2 * e], ab[buf][2 * e]}, b2 = f32x2{ab[buf][2 * e + 1], ab[buf][2 * e + 1]};
+                        const f32x2 u2[4] = {f32x2{ua[buf][e][0], ua[buf][e][1]}, f32x2{ua[buf][e][2], ua[buf][e][3]},
+                                             f32x2{ub[buf][e][0], ub[buf][e][1]}, f32x2{ub[buf][e][2], ub[buf][e][3]}};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            f32x2 t = r2 * u2[k] + y2[k];
+                            t[0] = relu1(t[0]);
+                            t[1] = relu1(t[1]);
+                            acc[k] = b2 * t + acc[k];
+                        }
+                    }
+                });
+                asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) :: "memory");
+            });
+            tp4[0] = f32x4{acc[0][0], acc[0][1], acc[1][0], acc[1][1]};
+            tp4[1] = f32x4{acc[2][0], acc[2][1], acc[3][0], acc[3][1]};
+        } else {
             const int hh = lane >> 5, f = lane & 31;
             constexpr int HRV = HR < 16 * NT ? HR : 16 * NT;      // the table holds 16*NT rows per child
             const int n_pairs = (n_valid + 1) >> 1;
@@ -549,7 +637,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
             load_fence();
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
-                const f32x4 tp = *reinterpret_cast<const f32x4*>(&Y0[n * XLD + 16 * ot + 4 * q]);
+                const f32x4 tp = PK ? tp4[ot] : *reinterpret_cast<const f32x4*>(&Y0[n * XLD + 16 * ot + 4 * q]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float hv = relu1(o[ot][r]);
@@ -659,15 +747,15 @@ __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedAr
     else if (e < LO::bh1) v = matrix_element<5, HID, W1LD>(a.wh1, e - LO::wh1);
     else if (e < LO::wh2) v = a.bh1[e - LO::bh1];
     else if (e < LO::bh2) v = matrix_element<HID, XD, WLD>(a.wh2, e - LO::wh2);
-    else if (e < LO::f_last) v = a.bh2[e - LO::bh2];
-    else if (e < LO::f1) v = frag_element<XD, XD>(a.w_last, e - LO::f_last);
-    else if (e < LO::f2) v = frag_element<XD, D1>(a.hw1, e - LO::f1);
-    else if (e < LO::f3) v = frag_element<D1, D2>(a.hw2, e - LO::f2);
-    else if (e < LO::b1) v = frag_element<D2, D3>(a.hw3, e - LO::f3);
+    else if (e < LO::b1) v = a.bh2[e - LO::bh2];
     else if (e < LO::b2) v = bias_element<D1>(a.hb1, e - LO::b1);
     else if (e < LO::b3) v = bias_element<D2>(a.hb2, e - LO::b2);
     else if (e < LO::w4) v = bias_element<D3>(a.hb3, e - LO::b3);
-    else v = bias_element<D3>(a.hw4, e - LO::w4);                    // w4 is [D3][1]: same padded vector layout as a bias
+    else if (e < LO::f_last) v = bias_element<D3>(a.hw4, e - LO::w4);          // w4 is [D3][1]: same padded vector layout as a bias
+    else if (e < LO::f1) v = frag_element<XD, XD>(a.w_last, e - LO::f_last);
+    else if (e < LO::f2) v = frag_element<XD, D1>(a.hw1, e - LO::f1);
+    else if (e < LO::f3) v = frag_element<D1, D2>(a.hw2, e - LO::f2);
+    else v = frag_element<D2, D3>(a.hw3, e - LO::f3);
     img[e] = v;
 }
 
@@ -779,7 +867,8 @@ inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A,
         a.rot = ip.rot;
         pl.grid = ip.grid;
     }
-    pl.lds_bytes = (size_t)(FusedLds<32, 100, 100>::scratch + kFusedWaves * (2 * 16 * a.SLD + 16 * XLD)) * sizeof(float);
+    pl.lds_bytes = (size_t)(FusedLds<32, 100, 100>::scratch +
+                            kFusedWaves * fused_scratch_floats(pl.hr, pl.nt, a.sim == SIM_SOFTMAX)) * sizeof(float);
     if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
     a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];
     a.wa = bilinear_wa(g); a.w1 = g.Ws[0];

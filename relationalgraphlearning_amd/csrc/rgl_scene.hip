@@ -557,7 +557,7 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
                                       humans_next, stream);
     float* x0_rows = (float*)workspace;                      // [P][32]
     float* xh_rows = x0_rows + (size_t)P * XD;               // [n_crowds][H][32]
-    if (ca && P >= 3072) ca = nullptr;     // many scenes: the caller launches mprl_children_kernel (see scene_graph_kernel)
+    if (ca && P >= 3072) ca = nullptr;     // many scenes: the caller runs mprl_children_kernel beside this launch (expand_level)
     const int rc = run_scene_kernels(g, &mh, robot, humans, crowds_per, P, H, humans_next, nullptr, x0_rows, xh_rows, ca, stream);
     if (rc == RGL_OK && ca && children_done) *children_done = 1;
     return rc;
