@@ -437,7 +437,11 @@ for H, skip, P, sim, flavour in ((19, True, 5, "embedded_gaussian", "trained"), 
                                  (1, True, 3, "embedded_gaussian", "trained"), (15, False, 9, "embedded_gaussian", "rand"),
                                  (16, True, 3, "embedded_gaussian", "trained"), (31, True, 21, "embedded_gaussian", "trained"),
                                  (12, True, 130, "gaussian", "trained"), (19, False, 6, "squared", "trained"),
-                                 (7, True, 5, "equal_attention", "trained"), (23, True, 4, "diagonal", "trained")):
+                                 (7, True, 5, "equal_attention", "trained"), (23, True, 4, "diagonal", "trained"),
+                                 # mid-size odd parent counts: several tiles per work item, several dealing passes, the partial
+                                 # tiles' rows spread over all workgroups
+                                 (19, True, 701, "embedded_gaussian", "trained"), (5, False, 1501, "embedded_gaussian", "trained"),
+                                 (9, True, 2311, "embedded_gaussian", "trained")):
     pol = make_mprl_policy(flavour, 1, L=2, skip=skip, similarity=sim, device=dev)
     pol.build_action_space(1.0)
     ts = pol.tree_search()
