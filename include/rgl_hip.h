@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RGL_ABI_VERSION 2
+#define RGL_ABI_VERSION 3
 
 #define RGL_MAX_MLP_LAYERS 6
 #define RGL_MAX_GCN_LAYERS 8
@@ -214,7 +214,20 @@ typedef struct MprlPlanner {
      * fp32 tensors.  Deeper levels are tensor-born in the reference too. */
     const double* root_robot_f64;
     const double* root_humans_f64;
+    /* optional (NULL = absent; ABI 3): device buffer of mprl_children_image_bytes() bytes holding the value-of-children
+     * kernel's LDS weight image, prepared by mprl_pack_children_image_f32 from THIS planner's value_graph / value_head
+     * weights.  The image depends on the weights only, so a caller that keeps them fixed over many searches (inference,
+     * a captured decision graph) packs once and re-packs after a parameter update; without it every search (or
+     * stand-alone mprl_value_children_f32 call) packs the image into its workspace first (~5 us). */
+    const float* children_image;
 } MprlPlanner;
+
+/* Bytes of the weight image above; 0 when the configuration has no image-based children kernel (the searches then ignore
+ * `children_image`).  Depends on the architecture only (not on the weights, P, A or H <= 31). */
+size_t mprl_children_image_bytes(const MprlPlanner* planner);
+/* Builds the image from the planner's current value_graph / value_head weights on `stream` (planner->children_image is not
+ * read).  RGL_ERR_BAD_MODE when mprl_children_image_bytes() is 0, RGL_ERR_WORKSPACE when `image_bytes` is too small. */
+int mprl_pack_children_image_f32(const MprlPlanner* planner, float* image, size_t image_bytes, rgl_stream_t stream);
 
 /* One tree level for P parent states (the unit `action_clip` evaluates, :242-269):
  *   humans_next[p]      = StatePredictor humans of parent p (or the linear approximation)

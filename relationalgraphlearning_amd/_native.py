@@ -15,7 +15,7 @@ MAX_NODES = 64
 MAX_XDIM = 64
 MAX_WIDTH = 256
 MAX_ACTIONS = 256
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 SIMILARITY = {"embedded_gaussian": 0, "gaussian": 1, "cosine": 2, "cosine_softmax": 3, "concatenation": 4,
               "squared": 5, "equal_attention": 6, "diagonal": 7}
@@ -54,7 +54,8 @@ class MprlPlanner(C.Structure):
                 ("num_actions", C.c_int), ("planning_depth", C.c_int), ("planning_width", C.c_int),
                 ("do_action_clip", C.c_int), ("sparse_search", C.c_int), ("contraction_dtype", C.c_int),
                 ("time_step", C.c_double), ("gamma_bar", C.c_double), ("actions", C.c_void_p),
-                ("action_groups", C.c_void_p), ("root_robot_f64", C.c_void_p), ("root_humans_f64", C.c_void_p)]
+                ("action_groups", C.c_void_p), ("root_robot_f64", C.c_void_p), ("root_humans_f64", C.c_void_p),
+                ("children_image", C.c_void_p)]
 
 
 class CrowdSimConfig(C.Structure):
@@ -88,6 +89,8 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                   C.c_void_p]),
     "mprl_value_children_workspace_bytes": (C.c_size_t, [C.POINTER(MprlPlanner), C.c_int, C.c_int]),
+    "mprl_children_image_bytes": (C.c_size_t, [C.POINTER(MprlPlanner)]),
+    "mprl_pack_children_image_f32": (C.c_int, [C.POINTER(MprlPlanner), C.c_void_p, C.c_size_t, C.c_void_p]),
     "mprl_value_children_f32": (C.c_int, [C.POINTER(MprlPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_size_t, C.c_void_p]),
     "mprl_tree_workspace_bytes": (C.c_size_t, [C.POINTER(MprlPlanner), C.c_int, C.c_int]),

@@ -69,7 +69,7 @@ int launch_head_rows_strided(const RglGraph* g, const RglMlp* head, const float*
 // tree search (image_ready = 1 on the per-level calls) or by the call itself -- at the END of the workspace it is given.
 int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, int H, const float* child_robot,
                           const float* humans_next, float* child_value, void* workspace, size_t workspace_bytes,
-                          int image_ready, hipStream_t stream);
+                          int image_ready, hipStream_t stream, const float* caller_image = nullptr);
 int pack_children_images(const RglGraph* g, const RglMlp* head, int P, int A, int H, void* workspace, size_t workspace_bytes,
                          hipStream_t stream);               // P = the largest launch; 1 = the fused kernel does not apply
 size_t fused_children_workspace_bytes(int P, int A, int H);

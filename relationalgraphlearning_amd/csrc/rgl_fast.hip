@@ -37,7 +37,7 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
     if (staged && !want_f16) {
         // one fused kernel over 16-child tiles (L = 2, N <= 32, default head): values come out directly, no stage 2
         rc = launch_fused_children(&pl->value_graph, &pl->value_head, P, A, H, child_robot, humans_next, child_value, workspace,
-                                   workspace_bytes, image_ready, stream);
+                                   workspace_bytes, image_ready, stream, pl->children_image);
         if (rc != 1) return rc;
     }
     if (staged) {

@@ -946,15 +946,15 @@ int pack_children_images(const RglGraph* g, const RglMlp* head, int P, int A, in
 // 1 = outside this kernel's envelope
 int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, int H, const float* child_robot,
                           const float* humans_next, float* child_value, void* workspace, size_t workspace_bytes,
-                          int image_ready, hipStream_t stream) {
+                          int image_ready, hipStream_t stream, const float* caller_image) {
     FusedPlan fp = plan_fused(*g, *head, P, A, H);
     if (!fp.ok) return 1;
     if (!workspace || workspace_bytes < fused_children_workspace_bytes(P, A, H)) return 1;
-    if (!image_ready) {
+    if (!image_ready && !caller_image) {
         int rc = pack_children_images(g, head, P, A, H, workspace, workspace_bytes, stream);
         if (rc) return rc;
     }
-    float* image = image_of(workspace, workspace_bytes);
+    const float* image = caller_image ? caller_image : image_of(workspace, workspace_bytes);
     float* rows_left = (float*)workspace;
     fp.a.child_robot = child_robot;
     fp.a.humans = humans_next;
@@ -965,3 +965,20 @@ int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, i
 }
 
 }  // namespace rgl
+
+// The image depends on the weights only: a caller with fixed weights packs it once (MprlPlanner::children_image).
+extern "C" size_t mprl_children_image_bytes(const MprlPlanner* planner) {
+    if (!planner) return 0;
+    return plan_fused(planner->value_graph, planner->value_head, 4096, 16, 1).ok ? kImageBytes : 0;      // architecture test only
+}
+
+extern "C" int mprl_pack_children_image_f32(const MprlPlanner* planner, float* image, size_t image_bytes, rgl_stream_t stream) {
+    if (!planner || !image) return RGL_ERR_NULL;
+    FusedPlan fp = plan_fused(planner->value_graph, planner->value_head, 4096, 16, 1);
+    if (!fp.ok) return RGL_ERR_BAD_MODE;
+    if (image_bytes < kImageBytes) return RGL_ERR_WORKSPACE;
+    hipLaunchKernelGGL((pack_images_kernel<32, 100, 100>), dim3((unsigned)((kImageFloats + kPackThreads - 1) / kPackThreads)),
+                       dim3(kPackThreads), 0, (hipStream_t)stream, fp.a, image);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}

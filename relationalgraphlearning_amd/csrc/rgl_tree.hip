@@ -537,9 +537,11 @@ extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* rob
     const float gamma_f = (float)pl.gamma_bar;
 
     // weight images of the value-of-children kernels: prepared once, every level copies them into LDS (0 = prepared)
+    // (or handed in by the caller, packed once for fixed weights: MprlPlanner::children_image)
     const int image_ready = pl.contraction_dtype == RGL_CONTRACT_F32 &&
-                            rgl::pack_children_images(&pl.value_graph, &pl.value_head, (int)lv[D - 1].P, A, H, ws + scratch_off,
-                                                      (size_t)scratch_bytes, st) == 0;
+                            (pl.children_image != nullptr ||
+                             rgl::pack_children_images(&pl.value_graph, &pl.value_head, (int)lv[D - 1].P, A, H, ws + scratch_off,
+                                                       (size_t)scratch_bytes, st) == 0);
     for (int l = 0; l < D; ++l) {
         const LevelLayout& L = lv[l];
         const int P = (int)L.P;

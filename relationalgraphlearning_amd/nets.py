@@ -181,6 +181,7 @@ class _PackCache:
         self.value = None
         self.keep = None
         self.buffers = {}         # transposed Linear weights, refreshed IN PLACE when parameters change (stable device pointers)
+        self.epoch = 0            # number of (re)packs: lets dependants (TreeSearch's weight image) notice a refresh
 
     def get(self, modules, build):
         key = tuple((p.data_ptr(), p._version, p.device.index) for m in modules for p in m.parameters())
@@ -189,6 +190,7 @@ class _PackCache:
             self.value = build(keep, self.buffers)
             self.keep = keep
             self.key = key
+            self.epoch += 1
         return self.value
 
     # The cache holds ctypes descriptor structs (raw device pointers), which can be neither copied nor pickled and

@@ -51,6 +51,7 @@ class TreeSearch:
         self._ws2 = _Workspace()    # hand-off buffer of the stand-alone expand / value_children calls
         self.last = None            # outputs of the most recent search (device tensors)
         self._decisions = {}        # (H, device) -> captured single-scene search (decide())
+        self._images = {}           # device -> (parameter-state key, weight image of the value-of-children kernel)
 
     # -- descriptors -----------------------------------------------------------------------------
     @property
@@ -103,7 +104,32 @@ class TreeSearch:
         act, grp = self._tables(device)
         pl.actions = act.data_ptr()
         pl.action_groups = None if grp is None else grp.data_ptr()
+        image = self._children_image(pl, device)
+        pl.children_image = None if image is None else image.data_ptr()
         return pl
+
+    def _children_image(self, pl, device):
+        """The value-of-children kernel's weight image for the CURRENT parameters (MprlPlanner.children_image): packed when the
+        descriptors of the value estimator were (re)built, into the same device buffer every time (captured decision graphs keep
+        reading it), so searches with unchanged weights skip the per-search packing launch.  None when the configuration has no
+        image-based kernel."""
+        ve = self.value_estimator
+        gcache, hcache = ve.graph_model._cache, ve._cache
+        key = (id(gcache), gcache.epoch, id(hcache), hcache.epoch)
+        dkey = str(device)
+        ent = self._images.get(dkey)
+        if ent is not None and ent[0] == key:
+            return ent[1]
+        lib = nat.lib()
+        nbytes = lib.mprl_children_image_bytes(C.byref(pl))
+        buf = None
+        if nbytes:
+            buf = ent[1] if ent is not None and ent[1] is not None and ent[1].numel() == nbytes else \
+                torch.empty(nbytes, dtype=torch.uint8, device=device)
+            nat.check(lib.mprl_pack_children_image_f32(C.byref(pl), buf.data_ptr(), nbytes, _stream()),
+                      "mprl_pack_children_image_f32")
+        self._images[dkey] = (key, buf)
+        return buf
 
     # -- device calls ----------------------------------------------------------------------------
     def search(self, robot, humans, roots_are_joint_states=True, want_root_values=True, out=None, roots64=None):

@@ -203,6 +203,44 @@ def test_predict_joint_state_api(dev):
     assert pol.predict(at_goal) == rga.ActionXY(0, 0)
 
 
+def test_batched_search_keeps_its_weight_image_and_follows_the_weights(dev):
+    """ABI 3: TreeSearch hands the searches a weight image packed once per parameter state (MprlPlanner.children_image).  At a
+    size the fused children kernel takes (600 roots x 81 actions): unchanged weights -> no re-pack (same cache entry, same
+    buffer); weights updated in place -> re-packed into the SAME buffer and the values follow, exactly as a fresh TreeSearch
+    (which packs from scratch) computes them."""
+    pol = make_mprl_policy("trained", 1, 1, False, device=dev)
+    pol.build_action_space(1.0)
+    ts = pol.tree_search()
+    robot, humans = seeded_scenes(77, 600, 19)
+    r, h = robot.to(dev), humans.to(dev)
+
+    def fresh():
+        o = rga.TreeSearch(pol.value_estimator, pol.state_predictor, rga.actions.as_array(pol.action_space), pol.action_group_index,
+                           pol.kinematics, pol.time_step, pol.get_normalized_gamma(), pol.planning_depth, pol.planning_width,
+                           pol.do_action_clip, pol.sparse_search, pol.contraction_dtype).search(r, h, True)
+        return o["best_action"].clone(), o["best_value"].clone()
+    o1 = ts.search(r, h, True)
+    a1, v1 = o1["best_action"].clone(), o1["best_value"].clone()
+    ent1 = ts._images[str(dev)]
+    assert ent1[1] is not None and ts.last["planner"].children_image == ent1[1].data_ptr()
+    o2 = ts.search(r, h, True)
+    assert ts._images[str(dev)] is ent1                                  # unchanged weights: the image was not re-packed
+    assert torch.equal(o2["best_value"], v1) and torch.equal(o2["best_action"], a1)
+    fa, fv = fresh()
+    assert torch.equal(fv, v1) and torch.equal(fa, a1)
+    with torch.no_grad():                                                # optimizer-like in-place update
+        for p_ in pol.value_estimator.value_network.parameters():
+            p_.mul_(1.25)
+        pol.value_estimator.graph_model.w_a.add_(0.02)
+    o3 = ts.search(r, h, True)
+    ent3 = ts._images[str(dev)]
+    assert ent3 is not ent1 and ent3[1].data_ptr() == ent1[1].data_ptr()   # re-packed, into the same device buffer
+    fa, fv = fresh()
+    assert torch.equal(o3["best_value"], fv) and torch.equal(o3["best_action"], fa)
+    assert float((o3["best_value"] - v1).abs().max()) > 1e-3             # and the values did move
+    report("weight image: packed once per parameter state, %d bytes, values follow in-place updates" % ent3[1].numel())
+
+
 def test_predict_replays_a_captured_search_and_follows_the_weights(dev):
     """predict() replays a hipGraph of the whole search per crowd size (TreeSearch.decide).  The graph bakes device pointers, so:
     parameters updated IN PLACE (optimizer step, load_state_dict) must show up in the next decision (transposed copies are
@@ -809,8 +847,12 @@ def test_properties_at_full_size(dev):
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).to(dev)
     a3, v3 = pol.predict_batch(r[perm], h[perm])
     assert torch.equal(a3, a1[perm]) and torch.equal(v3, v1[perm])          # roots are independent
+    # batch-size independent: 64 roots take the two-stage kernels, 2048 the fused one (size-based dispatch) -- the
+    # same arithmetic in another summation order, so values agree to rounding and decisions wherever the values are not tied
     a4, v4 = pol.predict_batch(r[:64], h[:64])
-    assert torch.equal(a4, a1[:64]) and torch.equal(v4, v1[:64])            # batch-size independent
+    assert float((v4 - v1[:64]).abs().max()) < 1e-5
+    differ = a4 != a1[:64]
+    assert int(differ.sum()) <= 1 and float((v4 - v1[:64])[differ].abs().max() if differ.any() else 0.0) < 1e-5
     hp = torch.randperm(H, generator=torch.Generator().manual_seed(2)).to(dev)
     a5, v5 = pol.predict_batch(r, h[:, hp])                                 # humans are an unordered set
     assert float((v5 - v1).abs().max()) < 1e-4

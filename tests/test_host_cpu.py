@@ -37,7 +37,7 @@ def test_struct_layout_matches_header_sizes():
     graph = 2 * mlp + 6 * 4 + 8 + mlp + 8 * 8
     assert ctypes.sizeof(nat.RglGraph) == graph
     assert ctypes.sizeof(nat.MprlLevelView) == 11 * 8
-    assert ctypes.sizeof(nat.MprlPlanner) == 2 * graph + 2 * mlp + 8 * 4 + 2 * 8 + 2 * 8 + 2 * 8      # ABI 2: + float64 root pointers
+    assert ctypes.sizeof(nat.MprlPlanner) == 2 * graph + 2 * mlp + 8 * 4 + 2 * 8 + 2 * 8 + 2 * 8 + 8  # ABI 2: + float64 root pointers; ABI 3: + children_image
     assert ctypes.sizeof(nat.GcnPlanner) == graph + mlp + 2 * 4 + 2 * 8 + 8 + 2 * 8
 
 
@@ -58,6 +58,11 @@ def test_host_side_argument_checks_without_gpu():
     assert lib.mprl_tree_level_view(ctypes.byref(pl), 2048, 19, 2, ctypes.byref(view)) == 0
     assert view.n_parents == 2048 * 4
     assert lib.mprl_tree_level_view(ctypes.byref(pl), 2048, 19, 3, ctypes.byref(view)) == -1
+    # ABI 3: the caller-owned weight image -- no image for an architecture without the image-based kernel (empty descriptors)
+    assert lib.mprl_children_image_bytes(None) == 0
+    assert lib.mprl_children_image_bytes(ctypes.byref(pl)) == 0
+    assert lib.mprl_pack_children_image_f32(None, None, 0, None) == -3
+    assert lib.mprl_pack_children_image_f32(ctypes.byref(pl), ctypes.c_void_p(16), 0, None) != 0
 
 
 def test_product_refuses_cpu_tensors():
