@@ -408,7 +408,7 @@ class ShardedRollout:
 
     def run(self, robot, humans):
         """robot (B,9), humans (B,H,5): the FULL root batch (identical on every rank).
-        Returns (best_action (B,) int64, best_value (B,) fp32) on the device of the inputs."""
+        Returns (best_action (B,) int32, best_value (B,) fp32) on the device of the inputs (index with `.long()` where torch wants int64)."""
         B = robot.shape[0]
         lo, hi = shard_bounds(B, self.world, self.rank)
         return self.run_local(robot[lo:hi], humans[lo:hi], B)
@@ -425,10 +425,10 @@ class ShardedRollout:
         n = robot_shard.shape[0]
         if not self.active:                      # one rank: nothing to exchange, hand the search's outputs through
             if n == 0:
-                return _Exchange(None, None, total, 1, (torch.zeros(0, dtype=torch.int64, device=robot_shard.device),
+                return _Exchange(None, None, total, 1, (torch.zeros(0, dtype=torch.int32, device=robot_shard.device),
                                                         torch.zeros(0, dtype=torch.float32, device=robot_shard.device)))
             act, val = self.search_fn(robot_shard, humans_shard)
-            return _Exchange(None, None, total, 1, (act.to(torch.int64), val))
+            return _Exchange(None, None, total, 1, (act, val))          # the search's own int32 indices: no conversion kernel
         # exchange buffer: row 0 = action indices (int32 bit patterns), row 1 = values
         packed = torch.empty(2, per, dtype=torch.float32, device=robot_shard.device)
         if n < per:
@@ -470,5 +470,5 @@ class _Exchange:
                 sizes = [shard_bounds(self.total, self.world, r) for r in range(self.world)]
                 acts = torch.cat([g[r, 0, :hi - lo] for r, (lo, hi) in enumerate(sizes)])
                 vals = torch.cat([g[r, 1, :hi - lo] for r, (lo, hi) in enumerate(sizes)])
-            self.ready = (acts.contiguous().view(torch.int32).to(torch.int64), vals)
+            self.ready = (acts.contiguous().view(torch.int32), vals)
         return self.ready

@@ -496,6 +496,28 @@ for H, skip, P, sim, flavour in ((19, True, 5, "embedded_gaussian", "trained"), 
     err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
     worst = max(worst, err)
     assert err < 1e-4, (H, skip, P, sim, err)
+# sharp attention: w_a scaled so that the similarities span hundreds -- the row weights' exponent differences (msh_i - S_i0) run
+# past both ends of the fp32 exp range; the packed row pass caps r = alpha / beta at e^60 (rgl_fused.hip), the oracle softmax is plain
+import copy
+for scale, H, P in ((25.0, 19, 40), (-40.0, 9, 33), (300.0, 5, 17)):
+    ck = copy.deepcopy(gio.checkpoint("trained", 2))
+    ck["graph_model1"]["w_a"] = ck["graph_model1"]["w_a"] * scale
+    pol = make_mprl_policy("trained", 1, L=2, device=dev)
+    pol.load_state_dict(ck)
+    pol.build_action_space(1.0)
+    ts = pol.tree_search()
+    A = ts.num_actions
+    robot, humans = seeded_scenes(1200 + H, P, H)
+    acts, _ = orc.mprl_action_space(orc.OracleConfig(), 1.0)
+    cr = orc._children_robot(robot, acts, orc.OracleConfig())
+    got = ts.value_children(cr.to(dev), humans.to(dev)).cpu().numpy()
+    Pm = orc.MprlParams.from_checkpoint(ck)
+    with torch.no_grad():
+        want = orc.value_estimator_forward(cr.reshape(P * A, 1, 9), humans[:, None].expand(P, A, H, 5).reshape(P * A, H, 5),
+                                           Pm.ve_graph, Pm.value_network, orc.OracleConfig(num_layer=2)).numpy().reshape(P, A)
+    err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
+    worst = max(worst, err)
+    assert np.isfinite(got).all() and err < 1e-4, (scale, H, P, err)
 # whole depth-2 searches: action tables of 25 (1 full tile + 9), 96 (6 full tiles, no partial), 97 (6 + 1) and 5 (partial only)
 from relationalgraphlearning_amd.config import policy_config
 import relationalgraphlearning_amd as rga
