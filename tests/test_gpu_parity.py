@@ -416,6 +416,61 @@ def test_value_children_mfma_path_vs_general_kernel(H, L, flavour, skip, P, dev)
                                                       float(want.abs().max())))
 
 
+def test_fused_kernel_random_shapes_vs_general_kernel(dev):
+    """Differential test of the fused children kernel (forced: RGL_CHILDREN_FUSED=1, child process) against the general VALU kernel
+    (the module forward) over seeded random shapes: crowd size 2..32, 1..400 parents, action tables of 3..115 actions (full tiles
+    only, partial tile only, both), five similarity functions, skip on / off.  Exercises every register bucket, both row-pass forms,
+    the work-item plan (tiles per item, item order, snake passes) and the in-launch scoring of the partial tiles' rows."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+from tests import golden_io as gio
+from tests.test_gpu_parity import seeded_scenes
+from oracle import rgl_oracle as orc
+from relationalgraphlearning_amd.config import policy_config
+import relationalgraphlearning_amd as rga
+dev = torch.device("cuda:0")
+rng = np.random.RandomState(20260927)
+sims = ["embedded_gaussian", "embedded_gaussian", "embedded_gaussian", "gaussian", "squared", "equal_attention", "diagonal"]
+worst = 0.0
+for case in range(36):
+    H = int(rng.randint(1, 32)); P = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 100, 257, 400]))
+    speeds = int(rng.randint(1, 7)); rots = int(rng.randint(2, 20)); skip = bool(rng.randint(2)); sim = sims[rng.randint(len(sims))]
+    if case == 0: speeds, rots = 3, 5            # 16 actions: one full tile, no partial
+    if case == 1: speeds, rots = 1, 2            # 3 actions: partial tile only
+    cfgp = policy_config("model_predictive_rl", action_space__speed_samples=speeds, action_space__rotation_samples=rots,
+                         gcn__similarity_function=sim, gcn__skip_connection=skip)
+    pol = rga.ModelPredictiveRL()
+    pol.time_step = 0.25
+    pol.configure(cfgp)
+    pol.load_state_dict(gio.checkpoint("trained", 2, "separate", sim))
+    pol.set_time_step(0.25); pol.set_phase("test"); pol.set_device(dev)
+    pol.build_action_space(1.0)
+    ts = pol.tree_search()
+    A = ts.num_actions
+    assert A == speeds * rots + 1
+    robot, humans = seeded_scenes(5000 + case, P, H)
+    g = torch.Generator().manual_seed(case)
+    cr = robot[:, None, :].expand(P, A, 9).clone()
+    cr[:, :, :4] += 0.3 * torch.randn(P, A, 4, generator=g)            # children: perturbed position / velocity of the parent
+    got = ts.value_children(cr.to(dev), humans.to(dev)).cpu().numpy()
+    with torch.no_grad():
+        ref = pol.value_estimator((cr.reshape(P * A, 1, 9).to(dev),
+                                   humans[:, None].expand(P, A, H, 5).reshape(P * A, H, 5).contiguous().to(dev))).cpu().numpy().reshape(P, A)
+    err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+    worst = max(worst, err)
+    assert np.isfinite(got).all() and err < 2e-5, (case, H, P, A, sim, skip, err)
+print("OK worst %.2e" % worst)
+'''
+    env = dict(os.environ, RGL_CHILDREN_FUSED="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+    report("fused kernel vs general kernel over 36 random shapes: " + out.stdout.strip().splitlines()[-1])
+
+
 def test_tile_kernel_variant_forced(dev):
     """With RGL_CHILDREN_TILE_KERNEL=1 the MFMA tile kernel also handles what the shared-crowd kernels (rank-1: L=2,
     N<=32; deep: L in {2,3}, N<=56) take by default.  The switch is read once per process, so this runs in a child process."""
