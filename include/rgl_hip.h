@@ -111,13 +111,19 @@ typedef struct RglGraph {
  *   motion_head NULL or the MLP applied to every node; rows 1..H    -> humans_next[n_scenes][H][out]
  *   H_out      NULL or device [n_scenes][N][x_dim]   (last-layer node features)
  *   A_out      NULL or device [n_scenes][N][N]       (first adjacency computed)
+ *   workspace  NULL or device scratch of rgl_graph_forward_workspace_bytes(...) bytes (ABI 3).  With it, and with H_out = A_out =
+ *              NULL, models the one-wave-per-scene MFMA kernel covers (the shipped path-M shapes: w_r 9-64-32, w_h 5-64-32,
+ *              x_dim 32, <= 4 layers, N <= 64, every similarity function, layerwise graphs) run on it; everything else, and
+ *              every call without workspace, runs on the general kernel -- same numbers up to summation order.
  * Limits: N = H+1 <= RGL_MAX_NODES, x_dim <= RGL_MAX_XDIM, widths <= RGL_MAX_WIDTH.
  * ------------------------------------------------------------------------------------------- */
+size_t rgl_graph_forward_workspace_bytes(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
+                                         int n_scenes, int scenes_per_crowd, int H);   /* 0: no MFMA path for this call */
 int rgl_graph_forward_f32(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
                           const float* robot, const float* humans,
                           int n_scenes, int scenes_per_crowd, int H,
                           float* H_out, float* A_out, float* value_out, float* humans_next,
-                          rgl_stream_t stream);
+                          void* workspace, size_t workspace_bytes, rgl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * rgl_graph_backward_f32 -- gradients of rgl_graph_forward_f32's outputs with respect to every

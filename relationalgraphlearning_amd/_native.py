@@ -72,9 +72,11 @@ class MprlLevelView(C.Structure):
 
 # name -> (restype, argtypes); every symbol include/rgl_hip.h declares
 SIGNATURES = {
+    "rgl_graph_forward_workspace_bytes": (C.c_size_t, [C.POINTER(RglGraph), C.POINTER(RglMlp), C.POINTER(RglMlp), C.c_int,
+                                                       C.c_int, C.c_int]),
     "rgl_graph_forward_f32": (C.c_int, [C.POINTER(RglGraph), C.POINTER(RglMlp), C.POINTER(RglMlp), C.c_void_p,
                                         C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.c_void_p, C.c_void_p]),
+                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rgl_graph_param_count": (C.c_int, [C.POINTER(RglGraph), C.POINTER(RglMlp), C.POINTER(RglMlp)]),
     "rgl_graph_backward_workspace_bytes": (C.c_size_t, [C.POINTER(RglGraph), C.POINTER(RglMlp), C.POINTER(RglMlp), C.c_int]),
     "rgl_graph_backward_f32": (C.c_int, [C.POINTER(RglGraph), C.POINTER(RglMlp), C.POINTER(RglMlp), C.c_void_p, C.c_void_p,

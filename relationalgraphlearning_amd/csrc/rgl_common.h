@@ -52,6 +52,16 @@ inline int validate_graph(const RglGraph& g, int H) {
 }
 
 // ---- internal launchers (one translation unit each; a return value of 1 means "outside this kernel's envelope") -------------
+int validate_forward_call(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head, const float* robot,
+                          const float* humans, int n_scenes, int scenes_per_crowd, int H, const float* value_out,
+                          const float* humans_next);                                                                // rgl_generic.hip
+// module forwards (values and / or next humans of S scenes) through the one-wave-per-scene MFMA kernel; 0 bytes / 1 = the
+// kernel does not cover the configuration
+size_t scene_forward_workspace_bytes(const RglGraph* g, const RglMlp* value_head, const RglMlp* motion_head, int S, int crowds_per,
+                                     int H);                                                                        // rgl_scene.hip
+int launch_scene_forward(const RglGraph* g, const RglMlp* value_head, const RglMlp* motion_head, const float* robot,
+                         const float* humans, int S, int crowds_per, int H, float* value_out, float* humans_next, void* workspace,
+                         size_t workspace_bytes, hipStream_t stream);                                               // rgl_scene.hip
 int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
                            const float* robot, const float* humans, int n_scenes, int scenes_per_crowd, int H,
                            float* H_out, float* A_out, float* value_out, float* humans_next, hipStream_t stream);   // rgl_generic.hip

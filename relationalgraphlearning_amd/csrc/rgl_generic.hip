@@ -280,9 +280,10 @@ __global__ void transpose_kernel(const float* __restrict__ src, float* __restric
 
 namespace rgl {
 
-int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
-                           const float* robot, const float* humans, int n_scenes, int scenes_per_crowd, int H,
-                           float* H_out, float* A_out, float* value_out, float* humans_next, hipStream_t stream) {
+// argument checks shared by every forward path
+int validate_forward_call(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head, const float* robot,
+                          const float* humans, int n_scenes, int scenes_per_crowd, int H, const float* value_out,
+                          const float* humans_next) {
     if (!graph || !robot || !humans) return RGL_ERR_NULL;
     if (n_scenes < 0 || scenes_per_crowd < 1) return RGL_ERR_BAD_SHAPE;
     int rc = validate_graph(*graph, H);
@@ -297,6 +298,15 @@ int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, cons
         if (rc) return rc;
         if (!humans_next) return RGL_ERR_NULL;
     }
+    return RGL_OK;
+}
+
+int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
+                           const float* robot, const float* humans, int n_scenes, int scenes_per_crowd, int H,
+                           float* H_out, float* A_out, float* value_out, float* humans_next, hipStream_t stream) {
+    int rc = validate_forward_call(graph, value_head, motion_head, robot, humans, n_scenes, scenes_per_crowd, H, value_out,
+                                   humans_next);
+    if (rc) return rc;
     if (n_scenes == 0) return RGL_OK;
 
     ForwardArgs a;
@@ -362,10 +372,26 @@ int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, cons
 
 }  // namespace rgl
 
+extern "C" size_t rgl_graph_forward_workspace_bytes(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
+                                                    int n_scenes, int scenes_per_crowd, int H) {
+    if (!graph || n_scenes < 1 || scenes_per_crowd < 1 || H < 1) return 0;
+    return rgl::scene_forward_workspace_bytes(graph, value_head, motion_head, n_scenes, scenes_per_crowd, H);
+}
+
 extern "C" int rgl_graph_forward_f32(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
                                      const float* robot, const float* humans, int n_scenes, int scenes_per_crowd,
                                      int H, float* H_out, float* A_out, float* value_out, float* humans_next,
-                                     rgl_stream_t stream) {
+                                     void* workspace, size_t workspace_bytes, rgl_stream_t stream) {
+    // values / next humans only, and a workspace: the one-wave-per-scene MFMA kernel (rgl_scene.hip) where it covers the model
+    if (workspace && !H_out && !A_out) {
+        int rc = rgl::validate_forward_call(graph, value_head, motion_head, robot, humans, n_scenes, scenes_per_crowd, H, value_out,
+                                            humans_next);
+        if (rc) return rc;
+        if (n_scenes == 0) return RGL_OK;
+        rc = rgl::launch_scene_forward(graph, value_head, motion_head, robot, humans, n_scenes, scenes_per_crowd, H, value_out,
+                                       humans_next, workspace, workspace_bytes, (hipStream_t)stream);
+        if (rc != 1) return rc;
+    }
     return rgl::launch_generic_forward(graph, value_head, motion_head, robot, humans, n_scenes, scenes_per_crowd, H,
                                        H_out, A_out, value_out, humans_next, (hipStream_t)stream);
 }

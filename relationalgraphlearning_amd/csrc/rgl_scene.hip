@@ -563,6 +563,45 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
     return rc;
 }
 
+// Module forwards (ValueEstimator.forward / StatePredictor.forward on a batch: value_estimator.py:11-20, state_predictor.py:20-39)
+// through the same kernels: embeddings + one wave per scene; values via the value-rows mode + robot_head_kernel.
+// workspace: x0 [S][32] | xh [S / crowds_per][H][32] | rows [S][64] (value head only).
+static bool scene_forward_covers(const RglGraph& g, const RglMlp* vh, const RglMlp* mh, int S, int crowds_per, int H) {
+    const bool has_v = vh && vh->n_layers > 0, has_m = mh && mh->n_layers > 0;
+    if (!(has_v || has_m) || crowds_per < 1 || S % crowds_per != 0) return false;
+    if (!scene_kernel_covers(g, H + 1)) return false;
+    if (has_v && head_variant(*vh) < 0) return false;
+    if (has_m && !mlp_is(*mh, XD, HID, 5, false)) return false;
+    return true;
+}
+
+size_t scene_forward_workspace_bytes(const RglGraph* g, const RglMlp* vh, const RglMlp* mh, int S, int crowds_per, int H) {
+    if (!g || !scene_forward_covers(*g, vh, mh, S, crowds_per, H)) return 0;
+    const bool has_v = vh && vh->n_layers > 0;
+    return ((size_t)S * XD + (size_t)(S / crowds_per) * H * XD + (has_v ? (size_t)S * 64 : 0)) * sizeof(float);
+}
+
+int launch_scene_forward(const RglGraph* g, const RglMlp* vh, const RglMlp* mh, const float* robot, const float* humans, int S,
+                         int crowds_per, int H, float* value_out, float* humans_next, void* workspace, size_t workspace_bytes,
+                         hipStream_t stream) {
+    if (!scene_forward_covers(*g, vh, mh, S, crowds_per, H)) return 1;
+    if (!workspace || workspace_bytes < scene_forward_workspace_bytes(g, vh, mh, S, crowds_per, H)) return 1;
+    const bool has_v = vh && vh->n_layers > 0, has_m = mh && mh->n_layers > 0;
+    float* x0_rows = (float*)workspace;
+    float* xh_rows = x0_rows + (size_t)S * XD;
+    float* rows = xh_rows + (size_t)(S / crowds_per) * H * XD;
+    if (has_m) {
+        int rc = run_scene_kernels(*g, mh, robot, humans, crowds_per, S, H, humans_next, nullptr, x0_rows, xh_rows, nullptr, stream);
+        if (rc) return rc;
+    }
+    if (has_v) {
+        int rc = run_scene_kernels(*g, nullptr, robot, humans, crowds_per, S, H, nullptr, rows, x0_rows, xh_rows, nullptr, stream);
+        if (rc) return rc;
+        return launch_head_rows(g, vh, rows, S, value_out, stream);
+    }
+    return RGL_OK;
+}
+
 // Value of the children through the one-wave-per-scene kernel: every child's graph in full (no crowd sharing), any of the
 // similarity functions it implements, layerwise graphs, 1..4 layers -- the MFMA path of everything the shared-crowd kernels do
 // not cover (cosine / cosine_softmax scale the columns by child-dependent norms; layerwise graphs rebuild the adjacency from

@@ -235,8 +235,16 @@ def graph_forward(graph, value_head, motion_head, robot, humans, scenes_per_crow
         mp = out["humans_next"].data_ptr()
         mh = C.byref(motion_head)
     with torch.cuda.device(dev):
-        rc = nat.lib().rgl_graph_forward_f32(C.byref(graph), vh, mh, robot.data_ptr(), humans.data_ptr(), S,
-                                             scenes_per_crowd, H, Hp, Ap, vp, mp, _stream())
+        lib = nat.lib()
+        ws, wp, wbytes = None, None, 0
+        if not (want_H or want_A) and S > 0:
+            # values / next humans only: the one-wave-per-scene MFMA kernel where it covers the model (scratch for the embeddings)
+            wbytes = lib.rgl_graph_forward_workspace_bytes(C.byref(graph), vh, mh, S, scenes_per_crowd, H)
+            if wbytes:
+                ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+                wp = ws.data_ptr()
+        rc = lib.rgl_graph_forward_f32(C.byref(graph), vh, mh, robot.data_ptr(), humans.data_ptr(), S,
+                                       scenes_per_crowd, H, Hp, Ap, vp, mp, wp, wbytes, _stream())
     nat.check(rc, "rgl_graph_forward_f32")
     return out
 
