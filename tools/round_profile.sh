@@ -60,7 +60,7 @@ try:
     keep = [k for k in f if any(s in k for s in ("children_fused", "pack_images", "robot_head", "children_rank1"))]
     scenes = 4096 * 81
     total_bytes = sum(2 * f[k] + w.get(k, 0.0) for k in keep) * 1024
-    rec = {"source": "profiles/$TAG.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/profile_children.py, P = 4096 parents x 81 children, N = 20, L = 2)",
+    rec = {"source": "profiles/${TAG}_kernel_stats.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/profile_children.py, P = 4096 parents x 81 children, N = 20, L = 2)",
            "source_revision": "$HASH",
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced loads -> reads doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported; both in KiB",
            "workload": {"N": 20, "L": 2, "A": 81}, "scenes": scenes,
