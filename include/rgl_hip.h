@@ -254,8 +254,10 @@ int mprl_expand_f32(const MprlPlanner* planner, const float* robot, const float*
 /* The dominant kernel of the rollout on its own: child_value[p][a] = ValueEstimator(child_robot[p][a],
  * humans_next[p]) for the A sibling children of each of P parents (siblings share their crowd).
  * Same code path mprl_expand_f32 / mprl_tree_search_f32 use; exported so it can be timed and
- * tested in isolation.  `workspace` (device, mprl_value_children_workspace_bytes) carries the
- * [P*A][64] hand-off between the two MFMA stages; without it (NULL) the general kernel runs (value_estimator.py:11-20 applied to model_predictive_rl.py:245-250's loop). */
+ * tested in isolation.  `workspace` (device, mprl_value_children_workspace_bytes) is the MFMA kernels' scratch: the rows of
+ * the partial 16-child tiles and (unless planner->children_image is set) the weight image of the one-launch kernel, or the
+ * [P*A][64] hand-off between the two stages of the small-launch pair; without it (NULL) the general kernel runs
+ * (value_estimator.py:11-20 applied to model_predictive_rl.py:245-250's loop). */
 size_t mprl_value_children_workspace_bytes(const MprlPlanner* planner, int P, int H);
 int mprl_value_children_f32(const MprlPlanner* planner, const float* child_robot, const float* humans_next,
                             int P, int H, float* child_value, void* workspace, size_t workspace_bytes,
