@@ -73,10 +73,9 @@ int launch_tile_children(const RglGraph* g, int P, int A, int H, const float* ch
                          float* rows_out, hipStream_t stream);                                                      // rgl_tile.hip
 int launch_head_rows(const RglGraph* g, const RglMlp* head, const float* rows, int M, float* value,
                      hipStream_t stream);                                                                          // rgl_head.hip
-int launch_head_rows_strided(const RglGraph* g, const RglMlp* head, const float* rows, int M, float* value, int out_group,
-                             int out_stride, int out_base, hipStream_t stream, const float* image);                 // rgl_head.hip
-// the fused tile kernel (rgl_fused.hip).  Its weight images are prepared in global memory by pack_children_images -- once per
-// tree search (image_ready = 1 on the per-level calls) or by the call itself -- at the END of the workspace it is given.
+// the fused tile kernel (rgl_fused.hip).  Its weight image is prepared in global memory by pack_images_kernel: by the caller once per
+// parameter state (caller_image = MprlPlanner::children_image), else once per tree search (image_ready = 1 on the per-level calls)
+// or by the call itself, at the END of the workspace it is given.
 int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, int H, const float* child_robot,
                           const float* humans_next, float* child_value, void* workspace, size_t workspace_bytes,
                           int image_ready, hipStream_t stream, const float* caller_image = nullptr);

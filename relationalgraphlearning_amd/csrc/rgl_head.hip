@@ -16,8 +16,6 @@ struct HeadArgs {
     const float* rows;            // [M][64]
     float* value;                 // [M]
     int M, n_tiles;
-    const float* image;           // null, or HeadLds<D1,D2,D3> prepared in global memory (rgl_fused.hip packs it once per search)
-    int out_group, out_stride, out_base;   // value index of row r: out_group > 0 ? (r / out_group) * out_stride + out_base + r % out_group : r
 };
 
 template <int D1, int D2, int D3>
@@ -42,8 +40,6 @@ __global__ __launch_bounds__(kHeadThreads, 2) void robot_head_kernel(const HeadA
     using LO = HeadLds<D1, D2, D3>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
-    if (a.image) copy_image<LO::total, kHeadThreads>(lds, a.image, tid);
-    else {
     fill_frags<XD, XD, kHeadThreads>(lds + LO::f_last, a.w_last, tid);
     fill_frags<XD, D1, kHeadThreads>(lds + LO::f1, a.w1, tid);
     fill_frags<D1, D2, kHeadThreads>(lds + LO::f2, a.w2, tid);
@@ -52,7 +48,6 @@ __global__ __launch_bounds__(kHeadThreads, 2) void robot_head_kernel(const HeadA
     fill_bias<D2>(lds + LO::b2, a.b2, tid, kHeadThreads);
     fill_bias<D3>(lds + LO::b3, a.b3, tid, kHeadThreads);
     fill_bias<D3>(lds + LO::w4, a.w4, tid, kHeadThreads);      // w4 is [D3][1]: same padded vector layout as a bias
-    }
     __syncthreads();
     const float b4 = a.b4[0];
     // tile t -> workgroup t % grid, wave (t / grid) % 8: the tiles of the last, partial round land on DIFFERENT workgroups
@@ -95,10 +90,7 @@ __global__ __launch_bounds__(kHeadThreads, 2) void robot_head_kernel(const HeadA
         }
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
-        if (q == 0 && row < a.M) {
-            const int g = a.out_group > 0 ? row / a.out_group : 0;
-            a.value[a.out_group > 0 ? (size_t)g * a.out_stride + a.out_base + (row - g * a.out_group) : (size_t)row] = v + b4;
-        }
+        if (q == 0 && row < a.M) a.value[row] = v + b4;
     }
 }
 
@@ -121,10 +113,8 @@ int launch_head(const HeadArgs& ha, hipStream_t st) {
 
 namespace rgl {
 
-// rows [M][64] (stage-1 hand-off) -> value;  1 = no kernel for this head (see head_variant).  out_group > 0 scatters the
-// values: row r -> value[(r / out_group) * out_stride + out_base + r % out_group] (rows of the parents' partial tiles).
-int launch_head_rows_strided(const RglGraph* g, const RglMlp* h, const float* rows, int M, float* value, int out_group,
-                             int out_stride, int out_base, hipStream_t stream, const float* image) {
+// rows [M][64] (stage-1 hand-off) -> value;  1 = no kernel for this head (see head_variant)
+int launch_head_rows(const RglGraph* g, const RglMlp* h, const float* rows, int M, float* value, hipStream_t stream) {
     const int hv = head_variant(*h);
     if (hv < 0) return 1;
     HeadArgs ha;
@@ -138,13 +128,7 @@ int launch_head_rows_strided(const RglGraph* g, const RglMlp* h, const float* ro
     ha.value = value;
     ha.M = M;
     ha.n_tiles = (M + 15) / 16;
-    ha.out_group = out_group; ha.out_stride = out_stride; ha.out_base = out_base;
-    ha.image = hv == 0 ? image : nullptr;
     return hv == 0 ? launch_head<32, 100, 100>(ha, stream) : launch_head<150, 100, 100>(ha, stream);
-}
-
-int launch_head_rows(const RglGraph* g, const RglMlp* h, const float* rows, int M, float* value, hipStream_t stream) {
-    return launch_head_rows_strided(g, h, rows, M, value, 0, 0, 0, stream, nullptr);
 }
 
 }  // namespace rgl
