@@ -183,6 +183,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
         }
         // adjacency of the node features currently in Hs, transposed and in B-operand order: pr[ct][jt][r] = A[i][j] for
         // column i = 16 ct + n, j = 16 jt + 4 q + r.  Once per scene, or once per layer for layerwise graphs.
+        // Node order inside the LAST 16-node tile (PERM: every similarity but concatenation): D row 4q + r of an S^T tile holds node
+        // 16 jt + 4 r + q instead of 16 jt + 4 q + r, so that as the k index of A*H the valid nodes of a partial tile sit in its first
+        // ceil(valid / 4) k steps and the steps over padding nodes are skipped (N = 20: 5 of 8 steps per layer, N = 5: 2 of 4).
+        constexpr bool PERM = SK != 3;
+        auto jnode = [&](int jt, int r) { return 16 * jt + ((PERM && jt == NT - 1) ? 4 * r + q : 4 * q + r); };
+        const int last_steps = PERM ? (N - 16 * (NT - 1) + 3) >> 2 : 4;
         f32x4 pr[NT][NT];
         auto adjacency = [&]() {
             if constexpr (SK == 3) {
@@ -265,7 +271,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                     f32x4 sacc = zero4();
 #pragma unroll
                     for (int ft = 0; ft < 2; ++ft) {
-                        const f32x4 xa = *reinterpret_cast<const f32x4*>(&Hs[(16 * jt + n) * XLD + 16 * ft + 4 * q]);
+                        const int jrow = (PERM && jt == NT - 1) ? 4 * (n & 3) + (n >> 2) : n;       // D row m <-> node perm(m), see jnode
+                        const f32x4 xa = *reinterpret_cast<const f32x4*>(&Hs[(16 * jt + jrow) * XLD + 16 * ft + 4 * q]);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) sacc = mfma4(xa[r], gt_[ct][ft][r], sacc);
                     }
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                 for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float imj = Hs[(16 * jt + 4 * q + r) * XLD + 32];
+                        const float imj = Hs[jnode(jt, r) * XLD + 32];
 #pragma unroll
                         for (int ct = 0; ct < NT; ++ct) pr[ct][jt][r] *= imj;
                     }
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                 for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int j = 16 * jt + 4 * q + r;
+                        const int j = jnode(jt, r);
                         float v = pr[ct][jt][r];
                         if (SK == 1) v = plain_weight(sim, v, 16 * ct + n, j);
                         if (j >= N) v = SK == 1 ? 0.f : -INFINITY;
@@ -352,8 +359,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                 load_fence();
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float a0 = Hs[(16 * jt + 4 * q + r) * XLD + n];
-                    const float a1 = Hs[(16 * jt + 4 * q + r) * XLD + 16 + n];
+                    if (PERM && jt == NT - 1 && r >= last_steps) continue;      // k steps over padding nodes only
+                    const float a0 = Hs[jnode(jt, r) * XLD + n];
+                    const float a1 = Hs[jnode(jt, r) * XLD + 16 + n];
 #pragma unroll
                     for (int ct = 0; ct < NT; ++ct) {
                         if (ct > 0 && rows_only) continue;
