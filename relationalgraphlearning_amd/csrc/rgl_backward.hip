@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 1024;
 
 struct MlpOffsets {                 // float offsets of W_l / b_l inside a gradient slab
     int w[RGL_MAX_MLP_LAYERS], b[RGL_MAX_MLP_LAYERS];
@@ -74,6 +74,7 @@ __device__ void mlp_forward_saved(const RglMlp& m, float* acts, int ld, int rows
             const int r = idx / out, j = idx - r * out;
             float acc = b[j];
             const float* a = acts + r * ld + in_off;
+#pragma unroll 16
             for (int k = 0; k < in; ++k) acc = fmaf(a[k], W[k * out + j], acc);
             acts[r * ld + out_off + j] = relu ? fmaxf(acc, 0.f) : acc;
         }
@@ -104,11 +105,13 @@ __device__ float* mlp_backward(const RglMlp& m, const MlpOffsets& off, const flo
         for (int idx = threadIdx.x; idx < in * out; idx += kThreads) {
             const int k = idx / out, j = idx - k * out;
             float acc = 0.f;
+#pragma unroll 16
             for (int r = 0; r < rows; ++r) acc = fmaf(acts[r * ld + in_off + k], cur[r * d_ld + j], acc);
             gW[idx] = acc;
         }
         for (int j = threadIdx.x; j < out; j += kThreads) {
             float acc = 0.f;
+#pragma unroll 16
             for (int r = 0; r < rows; ++r) acc += cur[r * d_ld + j];
             gb[j] = acc;
         }
@@ -117,6 +120,7 @@ __device__ float* mlp_backward(const RglMlp& m, const MlpOffsets& off, const flo
             for (int idx = threadIdx.x; idx < rows * in; idx += kThreads) {
                 const int r = idx / in, k = idx - r * in;
                 float acc = 0.f;
+#pragma unroll 16
                 for (int j = 0; j < out; ++j) acc = fmaf(cur[r * d_ld + j], W[k * out + j], acc);
                 nxt[r * d_ld + k] = acc;
             }
@@ -177,6 +181,7 @@ __device__ void sim_forward(const BackwardArgs& a, float* lds, const float* X, f
         for (int idx = threadIdx.x; idx < N * N; idx += kThreads) {
             const int i = idx / N, j = idx - i * N;
             float acc = b2;
+#pragma unroll 16
             for (int h = 0; h < hid; ++h) acc = fmaf(fmaxf(P[i * hid + h] + Q[j * hid + h] + b1[h], 0.f), w2[h], acc);
             A[i * a_ld + j] = fmaxf(acc, 0.f);
         }
@@ -189,6 +194,7 @@ __device__ void sim_forward(const BackwardArgs& a, float* lds, const float* X, f
         for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {
             const int i = idx / xd, c = idx - i * xd;
             float acc = 0.f;
+#pragma unroll 16
             for (int k = 0; k < xd; ++k) acc = fmaf(X[i * xd + k], g.w_a[k * xd + c], acc);
             G[idx] = acc;
         }
@@ -199,6 +205,7 @@ __device__ void sim_forward(const BackwardArgs& a, float* lds, const float* X, f
     for (int idx = threadIdx.x; idx < N * N; idx += kThreads) {
         const int i = idx / N, j = idx - i * N;
         float acc = 0.f;
+#pragma unroll 16
         for (int k = 0; k < xd; ++k) acc = fmaf(GX[i * xd + k], X[j * xd + k], acc);
         S[i * a_ld + j] = acc;
     }
@@ -287,12 +294,14 @@ __device__ void sim_backward(const BackwardArgs& a, float* lds, const float* X, 
         if (threadIdx.x == 0) {
             float acc = 0.f;
             for (int i = 0; i < N; ++i)
+#pragma unroll 16
                 for (int j = 0; j < N; ++j) acc += dA[i * a_ld + j];
             gb2[0] = first ? acc : gb2[0] + acc;
         }
         __syncthreads();
         for (int h = threadIdx.x; h < hid; h += kThreads) {              // d b1 = sum_i dP_i  (= sum_j dQ_j)
             float acc = 0.f;
+#pragma unroll 16
             for (int i = 0; i < N; ++i) acc += dP[i * hid + h];
             gb1[h] = first ? acc : gb1[h] + acc;
         }
@@ -301,6 +310,7 @@ __device__ void sim_backward(const BackwardArgs& a, float* lds, const float* X, 
             const float* D = k < xd ? dP : dQ;
             const int kk = k < xd ? k : k - xd;
             float acc = 0.f;
+#pragma unroll 16
             for (int i = 0; i < N; ++i) acc = fmaf(X[i * xd + kk], D[i * hid + h], acc);
             gW1[idx] = first ? acc : gW1[idx] + acc;
         }
@@ -370,12 +380,14 @@ __device__ void sim_backward(const BackwardArgs& a, float* lds, const float* X, 
     for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {
         const int i = idx / xd, k = idx - i * xd;
         float acc = 0.f;
+#pragma unroll 16
         for (int j = 0; j < N; ++j) acc = fmaf(dA[i * a_ld + j], X[j * xd + k], acc);
         dG[idx] = acc;
     }
     for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {
         const int j = idx / xd, k = idx - j * xd;
         float acc = dX[idx];
+#pragma unroll 16
         for (int i = 0; i < N; ++i) acc = fmaf(dA[i * a_ld + j], GX[i * xd + k], acc);
         dX[idx] = acc;
     }
@@ -385,12 +397,14 @@ __device__ void sim_backward(const BackwardArgs& a, float* lds, const float* X, 
         for (int idx = threadIdx.x; idx < xd * xd; idx += kThreads) {
             const int k = idx / xd, c = idx - k * xd;
             float acc = 0.f;
+#pragma unroll 16
             for (int i = 0; i < N; ++i) acc = fmaf(X[i * xd + k], dG[i * xd + c], acc);
             gWa[idx] = first ? acc : gWa[idx] + acc;
         }
         for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {
             const int i = idx / xd, k = idx - i * xd;
             float acc = dX[idx];
+#pragma unroll 16
             for (int c = 0; c < xd; ++c) acc = fmaf(dG[i * xd + c], g.w_a[k * xd + c], acc);
             dX[idx] = acc;
         }
@@ -451,6 +465,7 @@ __global__ __launch_bounds__(kThreads) void rgl_scene_backward_kernel(const Back
             for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {
                 const int i = idx / xd, c = idx - i * xd;
                 float acc = 0.f;
+#pragma unroll 16
                 for (int j = 0; j < N; ++j) acc = fmaf(A[i * a_ld + j], Hl[j * xd + c], acc);
                 Tl[idx] = acc;
             }
@@ -459,6 +474,7 @@ __global__ __launch_bounds__(kThreads) void rgl_scene_backward_kernel(const Back
             for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {
                 const int i = idx / xd, c = idx - i * xd;
                 float acc = 0.f;
+#pragma unroll 16
                 for (int k = 0; k < xd; ++k) acc = fmaf(Tl[i * xd + k], W[k * xd + c], acc);
                 acc = fmaxf(acc, 0.f);
                 Rl[idx] = acc;
@@ -534,12 +550,14 @@ __global__ __launch_bounds__(kThreads) void rgl_scene_backward_kernel(const Back
             for (int idx = threadIdx.x; idx < xd * xd; idx += kThreads) {
                 const int k = idx / xd, c = idx - k * xd;
                 float acc = 0.f;
+#pragma unroll 16
                 for (int i = 0; i < N; ++i) acc = fmaf(Tl[i * xd + k], dG[i * xd + c], acc);
                 gW[idx] = acc;
             }
             for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {      // dT = dZ W^T
                 const int i = idx / xd, k = idx - i * xd;
                 float acc = 0.f;
+#pragma unroll 16
                 for (int c = 0; c < xd; ++c) acc = fmaf(dG[i * xd + c], W[k * xd + c], acc);
                 dT[idx] = acc;
             }
@@ -547,12 +565,14 @@ __global__ __launch_bounds__(kThreads) void rgl_scene_backward_kernel(const Back
             for (int idx = threadIdx.x; idx < N * N; idx += kThreads) {       // dA (+)= dT H_l^T
                 const int i = idx / N, j = idx - i * N;
                 float acc = layerwise ? 0.f : dA[i * a_ld + j];
+#pragma unroll 16
                 for (int k = 0; k < xd; ++k) acc = fmaf(dT[i * xd + k], Hl[j * xd + k], acc);
                 dA[i * a_ld + j] = acc;
             }
             for (int idx = threadIdx.x; idx < N * xd; idx += kThreads) {      // dH_l = A^T dT (+ dH_{l+1})
                 const int j = idx / xd, k = idx - j * xd;
                 float acc = g.skip_connection ? dcur[idx] : 0.f;
+#pragma unroll 16
                 for (int i = 0; i < N; ++i) acc = fmaf(A[i * a_ld + j], dT[i * xd + k], acc);
                 dnxt[idx] = acc;
             }
@@ -582,8 +602,18 @@ __global__ __launch_bounds__(kThreads) void rgl_scene_backward_kernel(const Back
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int n_scenes, int n_params, float* __restrict__ out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_params) return;
+    // fixed order (deterministic), but 16 loads in flight at a time: a plain loop is one dependent-latency chain per scene
+    // (25 us for 100 scenes)
     float acc = 0.f;
-    for (int s = 0; s < n_scenes; ++s) acc += slabs[(size_t)s * n_params + k];     // fixed order: deterministic
+    int s = 0;
+    for (; s + 16 <= n_scenes; s += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = slabs[(size_t)(s + u) * n_params + k];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    for (; s < n_scenes; ++s) acc += slabs[(size_t)s * n_params + k];
     out[k] = acc;
 }
 
