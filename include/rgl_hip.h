@@ -136,8 +136,8 @@ int rgl_graph_forward_f32(const RglGraph* graph, const RglMlp* value_head, const
  *   corresponding forward outputs (device; NULL = zero).  detach_graph = 1 reproduces
  *   StatePredictor(..., detach=True): only the heads receive gradients.
  *   grad_out device [rgl_graph_param_count()]: w_r (W0,b0,W1,b1,..), w_h, w_a (embedded_gaussian: the matrix;
- *   concatenation: its pair MLP W0,b0,W1,b1), Ws[0..L-1], value head, motion head; Linear weights k-major
- *   [in][out] like the forward's.
+ *   concatenation: its pair MLP W0,b0,W1,b1), Ws[0..L-1], value head, motion head; Linear weight gradients in
+ *   torch's nn.Linear layout [out][in] (ABI 3; the forward's RglMlp weights stay k-major [in][out]).
  *   workspace device, >= rgl_graph_backward_workspace_bytes().  Each scene has its own crowd here
  *   (scenes_per_crowd = 1: the training batches are independent transitions).
  * ------------------------------------------------------------------------------------------- */

@@ -87,10 +87,8 @@ class GraphFunction(torch.autograd.Function):
                 cnt *= d
             piece = flat[off:off + cnt]
             off += cnt
-            # views into the freshly allocated slab (no copy kernels: ~20 small launches per backward otherwise)
-            if kind == "linear_w":           # slab holds k-major [in][out]; torch wants (out, in)
-                grads_out.append(piece.view(shape[1], shape[0]).t())
-            else:
-                grads_out.append(piece.view(*shape))
+            # contiguous views into the freshly allocated slab (no copy kernels, and the optimizers' fused kernels take contiguous
+            # gradients: transposed views sent them down torch's strided slow path); Linear weights come in torch layout (out, in)
+            grads_out.append(piece.view(*shape))
         assert off == n, (off, n)
         return (None, None, None) + tuple(grads_out)

@@ -84,7 +84,7 @@ __device__ void mlp_forward_saved(const RglMlp& m, float* acts, int ld, int rows
 }
 
 // backward of the same MLP.  d0 holds dL/d(output) [rows][d_ld] on entry; on exit the buffer returned holds
-// dL/d(input) [rows][d_ld].  Weight/bias gradients go to the slab (k-major [in][out], like the forward weights).
+// dL/d(input) [rows][d_ld].  Weight/bias gradients go to the slab, weights in torch's Linear layout [out][in].
 __device__ float* mlp_backward(const RglMlp& m, const MlpOffsets& off, const float* acts, int ld, int rows, float* d0,
                                float* d1, int d_ld, float* slab, bool need_input_grad) {
     float* cur = d0;
@@ -102,8 +102,8 @@ __device__ float* mlp_backward(const RglMlp& m, const MlpOffsets& off, const flo
         }
         float* gW = slab + off.w[l];
         float* gb = slab + off.b[l];
-        for (int idx = threadIdx.x; idx < in * out; idx += kThreads) {
-            const int k = idx / out, j = idx - k * out;
+        for (int idx = threadIdx.x; idx < in * out; idx += kThreads) {     // torch layout [out][in]: autograd hands out contiguous views
+            const int j = idx / in, k = idx - j * in;
             float acc = 0.f;
 #pragma unroll 16
             for (int r = 0; r < rows; ++r) acc = fmaf(acts[r * ld + in_off + k], cur[r * d_ld + j], acc);
@@ -305,8 +305,8 @@ __device__ void sim_backward(const BackwardArgs& a, float* lds, const float* X, 
             for (int i = 0; i < N; ++i) acc += dP[i * hid + h];
             gb1[h] = first ? acc : gb1[h] + acc;
         }
-        for (int idx = threadIdx.x; idx < 2 * xd * hid; idx += kThreads) {   // d W1a = X^T dP ; d W1b = X^T dQ
-            const int k = idx / hid, h = idx - k * hid;
+        for (int idx = threadIdx.x; idx < 2 * xd * hid; idx += kThreads) {   // d W1a = X^T dP ; d W1b = X^T dQ   (torch layout [hid][2 xd])
+            const int h = idx / (2 * xd), k = idx - h * (2 * xd);
             const float* D = k < xd ? dP : dQ;
             const int kk = k < xd ? k : k - xd;
             float acc = 0.f;
