@@ -49,21 +49,23 @@ __device__ __forceinline__ void row_mlp2_tiles(const RowMlpArgs& a, const float*
 constexpr int kRowMlpSetFloats = 4 * 1 * 4 * 64 + 2 * 4 * 4 * 64 + HID + XD;
 
 // Both embedding MLPs of a level in ONE launch (they are launch-latency sized): workgroups [0, grid_a) take the robot rows
-// (9 inputs), the others the human rows (5 inputs).
+// (INA inputs), the others the human rows (INB inputs).  (9, 5): path M's full / observable states; (6, 7): path G's rotated
+// self / human features (gcn.py:34-47).
+template <int INA, int INB>
 __global__ __launch_bounds__(kThreads, 2) void row_mlp2_pair_kernel(const RowMlpArgs ra, const RowMlpArgs rb, int grid_a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int F1 = 0, F2 = F1 + 4 * 1 * 4 * 64, B1 = F2 + 2 * 4 * 4 * 64, B2 = B1 + HID;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool first = (int)blockIdx.x < grid_a;
     const RowMlpArgs& a = first ? ra : rb;
-    if (first) fill_frags<9, HID, kThreads>(lds + F1, a.w1, tid); else fill_frags<5, HID, kThreads>(lds + F1, a.w1, tid);
+    if (first) fill_frags<INA, HID, kThreads>(lds + F1, a.w1, tid); else fill_frags<INB, HID, kThreads>(lds + F1, a.w1, tid);
     fill_frags<HID, XD, kThreads>(lds + F2, a.w2, tid);
     fill_bias<HID>(lds + B1, a.b1, tid);
     fill_bias<XD>(lds + B2, a.b2, tid);
     __syncthreads();
     const int b = first ? blockIdx.x : blockIdx.x - grid_a, g = first ? grid_a : gridDim.x - grid_a;
-    if (first) row_mlp2_tiles<9>(a, lds, b + g * wave, g * kWaves, lane);       // partial round: one tile per workgroup
-    else row_mlp2_tiles<5>(a, lds, b + g * wave, g * kWaves, lane);
+    if (first) row_mlp2_tiles<INA>(a, lds, b + g * wave, g * kWaves, lane);       // partial round: one tile per workgroup
+    else row_mlp2_tiles<INB>(a, lds, b + g * wave, g * kWaves, lane);
 }
 
 struct SceneArgs {
@@ -456,8 +458,12 @@ inline int launch_row_mlp2_pair(const RglMlp& wr, const float* robot_rows, float
     int grid_a = (ra.n_tiles + kWaves - 1) / kWaves, grid_b = (rb.n_tiles + kWaves - 1) / kWaves;
     if (grid_a > 256) grid_a = 256;
     if (grid_b > 1024) grid_b = 1024;
-    hipLaunchKernelGGL(row_mlp2_pair_kernel, dim3(grid_a + grid_b), dim3(kThreads), kRowMlpSetFloats * sizeof(float), st, ra,
-                       rb, grid_a);
+    if (wr.dims[0] == 9)
+        hipLaunchKernelGGL((row_mlp2_pair_kernel<9, 5>), dim3(grid_a + grid_b), dim3(kThreads), kRowMlpSetFloats * sizeof(float), st, ra,
+                           rb, grid_a);
+    else
+        hipLaunchKernelGGL((row_mlp2_pair_kernel<6, 7>), dim3(grid_a + grid_b), dim3(kThreads), kRowMlpSetFloats * sizeof(float), st, ra,
+                           rb, grid_a);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }
@@ -496,8 +502,10 @@ int launch_scene(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* chil
 namespace {
 
 static bool scene_kernel_covers(const RglGraph& g, int N) {
+    const bool path_m = mlp_is(g.w_r, 9, HID, XD, true) && mlp_is(g.w_h, 5, HID, XD, true);
+    const bool path_g = mlp_is(g.w_r, 6, HID, XD, true) && mlp_is(g.w_h, 7, HID, XD, true);        // gcn.ValueNetwork's inputs
     return fast_path_enabled() && scene_similarity_mode(g) >= 0 && g.x_dim == XD && g.num_layer >= 1 && g.num_layer <= 4 &&
-           mlp_is(g.w_r, 9, HID, XD, true) && mlp_is(g.w_h, 5, HID, XD, true) && N <= 64;
+           (path_m || path_g) && N <= 64;
 }
 
 // embeddings (one launch) + one-wave-per-scene graph forward; mh != null: motion head -> humans_next; rows_out != null: value rows

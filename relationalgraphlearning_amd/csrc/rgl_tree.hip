@@ -337,23 +337,38 @@ __global__ void gcn_prepare_kernel(const float* __restrict__ robot, const float*
     }
 }
 
+// 16 lanes per root (kRootLanes): the A action values side by side, then a first-maximum reduction -- one thread walking 81 actions
+// cost 25 us per call
 __global__ void gcn_argmax_kernel(const float* __restrict__ robot, const float* __restrict__ reward,
                                   const float* __restrict__ value, int B, int A, double gamma, double dt,
                                   float* __restrict__ action_values, int* __restrict__ best_action) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const double disc = pow(gamma, dt * (double)robot[(size_t)b * 9 + 7]);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = t / kRootLanes, sub = t % kRootLanes;
+    const bool live = b < B;
     double best = -INFINITY;
     int ba = -1;
-    for (int a = 0; a < A; ++a) {
-        const double v = (double)reward[(size_t)b * A + a] + disc * (double)value[(size_t)b * A + a];
-        action_values[(size_t)b * A + a] = (float)v;
-        if (v > best) {
-            best = v;
-            ba = a;
+    if (live) {
+        const double disc = pow(gamma, dt * (double)robot[(size_t)b * 9 + 7]);
+        for (int a = sub; a < A; a += kRootLanes) {
+            const double v = (double)reward[(size_t)b * A + a] + disc * (double)value[(size_t)b * A + a];
+            action_values[(size_t)b * A + a] = (float)v;
+            if (v > best) {
+                best = v;
+                ba = a;
+            }
         }
     }
-    best_action[b] = ba;
+#pragma unroll
+    for (int m = kRootLanes / 2; m >= 1; m >>= 1) {
+        const double ov = __shfl_xor(best, m);
+        const int oa = __shfl_xor(ba, m);
+        const bool take = oa >= 0 && (ba < 0 || ov > best || (ov == best && oa < ba));
+        if (take) {
+            best = ov;
+            ba = oa;
+        }
+    }
+    if (live && sub == 0) best_action[b] = ba;
 }
 
 inline dim3 grid_for(long long n, int block = kBlock) { return dim3((unsigned)((n + block - 1) / block)); }
@@ -621,7 +636,9 @@ extern "C" int gcn_rotate_f32(const float* joint14, float* rotated13, int n_rows
 extern "C" size_t gcn_predict_workspace_bytes(int B, int H, int A) {
     if (B < 1 || H < 1 || A < 1) return 0;
     const long long S = (long long)B * A;
-    return (size_t)(align_up(S * 6 * 4) + align_up(S * H * 7 * 4) + align_up(S * 4) + align_up(S * 4));
+    // rotated features, rewards, values + the scratch of the MFMA forward (embeddings [S][32], [S][H][32], value rows [S][64])
+    return (size_t)(align_up(S * 6 * 4) + align_up(S * H * 7 * 4) + align_up(S * 4) + align_up(S * 4) +
+                    align_up(S * (32 + (long long)H * 32 + 64) * 4));
 }
 
 extern "C" int gcn_predict_f32(const GcnPlanner* planner, const float* robot, const float* humans, int B, int H,
@@ -644,17 +661,24 @@ extern "C" int gcn_predict_f32(const GcnPlanner* planner, const float* robot, co
     float* self6 = (float*)ws;              ws += align_up(S * 6 * 4);
     float* hum7 = (float*)ws;               ws += align_up(S * H * 7 * 4);
     float* reward = (float*)ws;             ws += align_up(S * 4);
-    float* value = (float*)ws;
+    float* value = (float*)ws;              ws += align_up(S * 4);
+    void* fwd_ws = ws;
+    const size_t fwd_bytes = (size_t)align_up(S * (32 + (long long)H * 32 + 64) * 4);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gcn_prepare_kernel, grid_for(S * H), dim3(kBlock), 0, st, robot, humans,
                        pl.root_robot_f64 && pl.root_humans_f64 ? pl.root_robot_f64 : nullptr,
                        pl.root_robot_f64 && pl.root_humans_f64 ? pl.root_humans_f64 : nullptr, pl.actions, B, H, A,
                        pl.kinematics, pl.time_step, self6, hum7, reward);
     RGL_LAUNCH_CHECK();
-    rc = rgl::launch_generic_forward(&pl.graph, &pl.value_head, nullptr, self6, hum7, (int)S, 1, H, nullptr, nullptr,
-                                     value, nullptr, st);
+    // the B x A rotated scenes: one wave per scene on the MFMA kernel where it covers the model (the shipped ValueNetwork: 6 / 7
+    // inputs, 64-32 embeddings, head 150-100-100-1), else the general kernel
+    rc = rgl::launch_scene_forward(&pl.graph, &pl.value_head, nullptr, self6, hum7, (int)S, 1, H, value, nullptr, fwd_ws, fwd_bytes,
+                                   st);
+    if (rc == 1)
+        rc = rgl::launch_generic_forward(&pl.graph, &pl.value_head, nullptr, self6, hum7, (int)S, 1, H, nullptr, nullptr, value,
+                                         nullptr, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(gcn_argmax_kernel, grid_for(B, 64), dim3(64), 0, st, robot, reward, value, B, A, pl.gamma,
+    hipLaunchKernelGGL(gcn_argmax_kernel, grid_for((long long)B * kRootLanes, 256), dim3(256), 0, st, robot, reward, value, B, A, pl.gamma,
                        pl.time_step, action_values, best_action);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
