@@ -270,10 +270,14 @@ __global__ void gcn_prepare_kernel(const float* __restrict__ robot, const float*
                                    const double* __restrict__ robot64, const double* __restrict__ humans64,
                                    const double* __restrict__ actions, int B, int H, int A, int kinematics, double dt,
                                    float* __restrict__ self6, float* __restrict__ hum7, float* __restrict__ reward) {
+    // blockDim.x is a multiple of H: the H threads of a (root, action) pair sit in one workgroup, each contributes ITS human's
+    // end-point clearance (one float64 sqrt per thread) and thread h == 0 takes the minimum -- it used to walk all H itself
+    extern __shared__ double clearance[];
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)B * A * H) return;
-    const int h = (int)(idx % H);
-    const long long sa = idx / H;
+    const bool live = idx < (long long)B * A * H;
+    const long long cidx = live ? idx : 0;
+    const int h = (int)(cidx % H);
+    const long long sa = cidx / H;
     const int a = (int)(sa % A), b = (int)(sa / A);
     const float* r = robot + (size_t)b * 9;
     const double* r64 = robot64 ? robot64 + (size_t)b * 9 : nullptr;        // the float64 state the fp32 row was rounded from
@@ -308,21 +312,26 @@ __global__ void gcn_prepare_kernel(const float* __restrict__ robot, const float*
     s[12] = hb64 ? (float)HB(h, 3) : hu[3];
     s[13] = hb64 ? (float)HB(h, 4) : hu[4];
     rotate_row(s, kinematics == RGL_UNICYCLE, o);
-    float* h7 = hum7 + ((size_t)sa * H + h) * 7;
+    if (live) {
+        float* h7 = hum7 + ((size_t)sa * H + h) * 7;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) h7[i] = o[6 + i];
-    if (h == 0) {
+        for (int i = 0; i < 7; ++i) h7[i] = o[6 + i];
+    }
+    {   // compute_reward (multi_human_rl.py:73-96): END-point distance of my human, float64
+        const double hx = HB(h, 0) + HB(h, 2) * dt;
+        const double hy = HB(h, 1) + HB(h, 3) * dt;
+        const double ddx = nr[0] - hx, ddy = nr[1] - hy;
+        clearance[threadIdx.x] = sqrt(ddx * ddx + ddy * ddy) - nr[4] - HB(h, 4);
+    }
+    __syncthreads();
+    if (live && h == 0) {
         float* s6 = self6 + (size_t)sa * 6;
 #pragma unroll
         for (int i = 0; i < 6; ++i) s6[i] = o[i];
-        // compute_reward (multi_human_rl.py:73-96): END-point distances, float64
         bool collision = false;
         double dmin = INFINITY;
         for (int j = 0; j < H; ++j) {
-            const double hx = HB(j, 0) + HB(j, 2) * dt;
-            const double hy = HB(j, 1) + HB(j, 3) * dt;
-            const double ddx = nr[0] - hx, ddy = nr[1] - hy;
-            const double d = sqrt(ddx * ddx + ddy * ddy) - nr[4] - HB(j, 4);
+            const double d = clearance[threadIdx.x + j];
             if (d < 0.0) collision = true;
             if (d < dmin) dmin = d;
         }
@@ -665,7 +674,8 @@ extern "C" int gcn_predict_f32(const GcnPlanner* planner, const float* robot, co
     void* fwd_ws = ws;
     const size_t fwd_bytes = (size_t)align_up(S * (32 + (long long)H * 32 + 64) * 4);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gcn_prepare_kernel, grid_for(S * H), dim3(kBlock), 0, st, robot, humans,
+    const int prep_threads = (H >= kBlock ? 1 : kBlock / H) * H;        // whole (root, action) groups per workgroup
+    hipLaunchKernelGGL(gcn_prepare_kernel, grid_for(S * H, prep_threads), dim3(prep_threads), prep_threads * sizeof(double), st, robot, humans,
                        pl.root_robot_f64 && pl.root_humans_f64 ? pl.root_robot_f64 : nullptr,
                        pl.root_robot_f64 && pl.root_humans_f64 ? pl.root_humans_f64 : nullptr, pl.actions, B, H, A,
                        pl.kinematics, pl.time_step, self6, hum7, reward);
