@@ -99,9 +99,16 @@ constexpr int M2LD = 20;   // LDS row stride of the [64][5 -> 16] motion output 
 // actions with scalar crowd loads, was tried and was never better).
 // SK: 0 = softmax of S (embedded_gaussian / gaussian), 1 = plain weights over their row sum (squared / equal_attention /
 // diagonal), 2 = cosine family (cosine / cosine_softmax; graph_model.py:70-79), 3 = concatenation (pair MLP, :80-85)
-template <int NT, int SK, int WAVES, bool CH>
+// SPLIT: the NT column tiles of a scene go to NT waves (WAVES / NT scenes per workgroup pass, node features shared in LDS,
+// workgroup barriers where a phase needs every row): a scene is one serial chain of ~70 MFMAs per column tile with a softmax in
+// the middle, and with few scenes (the upper tree levels, dense crowds: 256-512 scenes of 50 agents on 256 CUs) nothing else hides
+// that chain.  With thousands of scenes the unsplit form -- no barriers, the same MFMA count -- is as fast or faster.
+template <int NT, int SK, int WAVES, bool CH, bool SPLIT>
 __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneArgs a, const ChildrenArgs ca, int grid_scene) {
-    constexpr int kSceneThreads = WAVES * 64, kSceneWaves = WAVES;
+    static_assert(!SPLIT || (SK != 3 && NT > 1 && WAVES % NT == 0), "split scenes: whole scenes per workgroup, no pair-MLP similarity");
+    constexpr int kSceneThreads = WAVES * 64;
+    constexpr int kSlots = SPLIT ? WAVES / NT : WAVES;      // scenes in flight per workgroup
+    constexpr int NCT = SPLIT ? 1 : NT;                     // column tiles of a scene this wave owns
     if constexpr (CH) {
         if ((int)blockIdx.x >= grid_scene) {
             const long long total = (long long)ca.P * ca.A, stride = (long long)(gridDim.x - grid_scene) * kSceneThreads;
@@ -121,7 +128,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
     const float* bm1 = lds + a.off_bm1;     // [64]
     const float* wm2 = lds + a.off_wm2;     // [64][M2LD], columns >= 5 zero
     const float* bm2 = lds + a.off_bm2;     // [16], entries >= 5 zero
-    float* Hs = lds + a.off_wave + wave * a.wave_stride;   // [16*NT][XLD] node features of the wave's current scene
+    const int slot = __builtin_amdgcn_readfirstlane(SPLIT ? wave / NT : wave);
+    const int ctb = SPLIT ? __builtin_amdgcn_readfirstlane(wave % NT) : 0;      // my first (SPLIT: only) column tile
+    float* Hs = lds + a.off_wave + slot * a.wave_stride;   // [16*NT][XLD] node features of the slot's current scene
     {   // weight image in two phases -- every global load of the thread first, then the LDS stores -- so that the whole
         // 30 KB image costs ONE L2 round trip (filling matrix by matrix cost one per matrix: ~9 us of a ~35 us launch)
         float* w = lds;
@@ -171,18 +180,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
         }
     }
     __syncthreads();
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    for (int sc = blockIdx.x + grid_scene * wave_u; sc < a.P; sc += grid_scene * kSceneWaves) {      // partial round: one per WG
+    // scene of slot k in pass i: blockIdx + grid_scene * k + i * grid_scene * kSlots (partial round: one scene per workgroup).  SPLIT:
+    // the loop is uniform over the workgroup (barriers inside); a slot past the end recomputes the last scene and writes nothing.
+    for (int it = blockIdx.x + (SPLIT ? 0 : grid_scene * slot); it < a.P; it += grid_scene * kSlots) {
+        const int sc_raw = SPLIT ? it + grid_scene * slot : it;
+        const bool active = sc_raw < a.P;
+        const int sc = active ? sc_raw : a.P - 1;
         // node features of this scene: row 0 = robot, rows 1..H = its crowd, rows >= N zero
         const float* xr = a.x0_rows + (size_t)sc * XD;
         const float* xh = a.xh_rows + (size_t)(sc / a.crowds_per) * H * XD;
-        for (int idx = lane; idx < 16 * NT * (XD / 4); idx += 64) {
-            const int row = idx >> 3, c4 = (idx & 7) * 4;
+        for (int idx = lane; idx < 16 * NCT * (XD / 4); idx += 64) {
+            const int row = (idx >> 3) + 16 * ctb, c4 = (idx & 7) * 4;
             f32x4 val = zero4();
             if (row == 0) val = *reinterpret_cast<const f32x4*>(xr + c4);
             else if (row < N) val = *reinterpret_cast<const f32x4*>(xh + (size_t)(row - 1) * XD + c4);
             *reinterpret_cast<f32x4*>(&Hs[row * XLD + c4]) = val;
         }
+        if (SPLIT) __syncthreads();
         // adjacency of the node features currently in Hs, transposed and in B-operand order: pr[ct][jt][r] = A[i][j] for
         // column i = 16 ct + n, j = 16 jt + 4 q + r.  Once per scene, or once per layer for layerwise graphs.
         // Node order inside the LAST 16-node tile (PERM: every similarity but concatenation): D row 4q + r of an S^T tile holds node
@@ -250,13 +264,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
             // G^T = Wa^T X^T   (per column tile: [g = 16gt+4q+r][col n])
             f32x4 gt_[NT][2];
 #pragma unroll
-            for (int ct = 0; ct < NT; ++ct) {
+            for (int ct = 0; ct < NCT; ++ct) {
                 gt_[ct][0] = zero4();
                 gt_[ct][1] = zero4();
                 load_fence();
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft) {
-                    const f32x4 xb = *reinterpret_cast<const f32x4*>(&Hs[(16 * ct + n) * XLD + 16 * ft + 4 * q]);
+                    const f32x4 xb = *reinterpret_cast<const f32x4*>(&Hs[(16 * (ct + ctb) + n) * XLD + 16 * ft + 4 * q]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -266,7 +280,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
             }
             // S^T[j][col] = X[j] . G[col]
 #pragma unroll
-            for (int ct = 0; ct < NT; ++ct)
+            for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int jt = 0; jt < NT; ++jt) {
                     load_fence();
@@ -286,21 +300,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                 // 32 of the node-feature rows (XLD = 36).  Padded nodes get 1/m = 0: their rows and columns stay exactly 0.
                 load_fence();
 #pragma unroll
-                for (int ct = 0; ct < NT; ++ct) {
+                for (int ct = 0; ct < NCT; ++ct) {
                     float z = 0.f;
 #pragma unroll
                     for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) z = fmaf(pr[ct][jt][r], pr[ct][jt][r], z);
                     z = kgroups_sum(z);
-                    const float im = (16 * ct + n < N && z > 0.f) ? 1.f / sqrtf(z) : 0.f;
-                    if (q == 0) Hs[(16 * ct + n) * XLD + 32] = im;
+                    const float im = (16 * (ct + ctb) + n < N && z > 0.f) ? 1.f / sqrtf(z) : 0.f;
+                    if (q == 0) Hs[(16 * (ct + ctb) + n) * XLD + 32] = im;
 #pragma unroll
                     for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) pr[ct][jt][r] *= im;
                 }
-                __builtin_amdgcn_wave_barrier();
+                if (SPLIT) __syncthreads(); else __builtin_amdgcn_wave_barrier();      // every column's 1/m is in place
                 load_fence();
 #pragma unroll
                 for (int jt = 0; jt < NT; ++jt)
@@ -308,13 +322,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                     for (int r = 0; r < 4; ++r) {
                         const float imj = Hs[jnode(jt, r) * XLD + 32];
 #pragma unroll
-                        for (int ct = 0; ct < NT; ++ct) pr[ct][jt][r] *= imj;
+                        for (int ct = 0; ct < NCT; ++ct) pr[ct][jt][r] *= imj;
                     }
                 if (sim == SIM_COSINE) return;                   // the cosine matrix itself is the adjacency (not normalised)
             }
             // row normalisation: softmax over j (kept in B-operand order), or the plain weights / their row sums
 #pragma unroll
-            for (int ct = 0; ct < NT; ++ct) {
+            for (int ct = 0; ct < NCT; ++ct) {
                 float mx = -INFINITY;
 #pragma unroll
                 for (int jt = 0; jt < NT; ++jt)
@@ -322,7 +336,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                     for (int r = 0; r < 4; ++r) {
                         const int j = jnode(jt, r);
                         float v = pr[ct][jt][r];
-                        if (SK == 1) v = plain_weight(sim, v, 16 * ct + n, j);
+                        if (SK == 1) v = plain_weight(sim, v, 16 * (ct + ctb) + n, j);
                         if (j >= N) v = SK == 1 ? 0.f : -INFINITY;
                         mx = fmaxf(mx, v);
                         pr[ct][jt][r] = v;
@@ -352,7 +366,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
             const bool rows_only = last && a.rows_out != nullptr;     // value rows: only (A H)[robot] of the last layer is needed
             f32x4 acc[NT][2];
 #pragma unroll
-            for (int ct = 0; ct < NT; ++ct) {
+            for (int ct = 0; ct < NCT; ++ct) {
                 acc[ct][0] = zero4();
                 acc[ct][1] = zero4();
             }
@@ -365,26 +379,29 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                     const float a0 = Hs[jnode(jt, r) * XLD + n];
                     const float a1 = Hs[jnode(jt, r) * XLD + 16 + n];
 #pragma unroll
-                    for (int ct = 0; ct < NT; ++ct) {
-                        if (ct > 0 && rows_only) continue;
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        if (rows_only && ct + ctb > 0) continue;
                         acc[ct][0] = mfma4(a0, pr[ct][jt][r], acc[ct][0]);
                         acc[ct][1] = mfma4(a1, pr[ct][jt][r], acc[ct][1]);
                     }
                 }
             }
+            if (SPLIT) __syncthreads();      // every wave of the scene has taken its A*H: rows may be overwritten
             if (rows_only) {
                 // hand-off row of stage 2 (robot_head_kernel): [ (A H_{L-1})[robot] | H_{L-1}[robot] ]; column 0 of tile 0 = robot
-                float* out = a.rows_out + (size_t)sc * 64;
-                if (n == 0) {
-                    *reinterpret_cast<f32x4*>(out + 4 * q) = acc[0][0];
-                    *reinterpret_cast<f32x4*>(out + 16 + 4 * q) = acc[0][1];
+                if (active && ctb == 0) {
+                    float* out = a.rows_out + (size_t)sc * 64;
+                    if (n == 0) {
+                        *reinterpret_cast<f32x4*>(out + 4 * q) = acc[0][0];
+                        *reinterpret_cast<f32x4*>(out + 16 + 4 * q) = acc[0][1];
+                    }
+                    if (lane < 8) *reinterpret_cast<f32x4*>(out + 32 + 4 * lane) = *reinterpret_cast<const f32x4*>(&Hs[4 * lane]);
                 }
-                if (lane < 8) *reinterpret_cast<f32x4*>(out + 32 + 4 * lane) = *reinterpret_cast<const f32x4*>(&Hs[4 * lane]);
                 break;
             }
             const float* wl = ws + l * XD * WLD;
 #pragma unroll
-            for (int ct = 0; ct < NT; ++ct) {
+            for (int ct = 0; ct < NCT; ++ct) {
                 load_fence();
                 f32x4 o[2] = {zero4(), zero4()};
 #pragma unroll
@@ -396,14 +413,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                             o[ot] = mfma4(wl[(16 * ft + 4 * q + r) * WLD + 16 * ot + n], acc[ct][ft][r], o[ot]);
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot) {
-                    const f32x4 sk = *reinterpret_cast<const f32x4*>(&Hs[(16 * ct + n) * XLD + 16 * ot + 4 * q]);
+                    const f32x4 sk = *reinterpret_cast<const f32x4*>(&Hs[(16 * (ct + ctb) + n) * XLD + 16 * ot + 4 * q]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float hv = fmaxf(o[ot][r], 0.f);
                         if (a.skip) hv += sk[r];
-                        o[ot][r] = 16 * ct + n < N ? hv : 0.f;          // padded node rows stay exactly zero (a softmax row of a
+                        o[ot][r] = 16 * (ct + ctb) + n < N ? hv : 0.f;          // padded node rows stay exactly zero (a softmax row of a
                     }                                                   // padded node is uniform, not zero; layerwise graphs re-read H)
-                    if (!last) *reinterpret_cast<f32x4*>(&Hs[(16 * ct + n) * XLD + 16 * ot + 4 * q]) = o[ot];
+                    if (!last) *reinterpret_cast<f32x4*>(&Hs[(16 * (ct + ctb) + n) * XLD + 16 * ot + 4 * q]) = o[ot];
                 }
                 if (last) {
                     // motion head on this tile's columns, straight from registers: 32 -> 64 (ReLU) -> 5
@@ -428,8 +445,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                             om = mfma4(wm2[(16 * ht + 4 * q + r) * M2LD + n], hv, om);
                         }
                     }
-                    const int node = 16 * ct + n;
-                    if (node >= 1 && node < N) {
+                    const int node = 16 * (ct + ctb) + n;
+                    if (active && node >= 1 && node < N) {
                         float* dst = a.humans_next + ((size_t)sc * H + (node - 1)) * 5;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -439,8 +456,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                     }
                 }
             }
-            __builtin_amdgcn_wave_barrier();      // layerwise: the next adjacency reads the rows written above
+            if (SPLIT) __syncthreads(); else __builtin_amdgcn_wave_barrier();      // the next layer / adjacency reads the rows written above
         }
+        if (SPLIT) __syncthreads();      // the slot's rows are free for the next scene
     }
 }
 
@@ -468,9 +486,20 @@ inline int launch_row_mlp2_pair(const RglMlp& wr, const float* robot_rows, float
     return RGL_OK;
 }
 
-template <int NT, int SK, int WAVES>
+// Split scenes (NT waves per scene) below this many scenes: env RGL_SCENE_SPLIT_BELOW overrides (0 = never, tests / measurements)
+inline int scene_split_below(int nt) {
+    static const int env = [] { const char* e = getenv("RGL_SCENE_SPLIT_BELOW"); return e ? atoi(e) : -1; }();
+    if (env >= 0) return env;
+    return nt == 2 ? 3072 : 4096;
+}
+
+template <int NT, int SK, int WAVES, bool SPLIT = false>
 int launch_scene_k(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* children, hipStream_t st) {
-    int grid = (sa.P + WAVES - 1) / WAVES;
+    if constexpr (!SPLIT && SK != 3 && (NT == 2 || NT == 4)) {
+        if (sa.P < scene_split_below(NT)) return launch_scene_k<NT, SK, 8, true>(sa, lds_bytes, children, st);
+    }
+    constexpr int kSlots = SPLIT ? WAVES / NT : WAVES;
+    int grid = (sa.P + kSlots - 1) / kSlots;
     const int cap = 256 * (lds_bytes * 2 <= (size_t)rgl::kLdsBytesPerCu ? 2 : 1) * (WAVES == 4 ? 2 : 1);
     if (grid > cap) grid = cap;
     ChildrenArgs ca{};
@@ -480,7 +509,7 @@ int launch_scene_k(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* ch
         const long long blocks = ((long long)ca.P * ca.A + WAVES * 64 - 1) / (WAVES * 64);
         grid_children = (int)(blocks < 2048 ? blocks : 2048);
     }
-    auto kern = children ? scene_graph_kernel<NT, SK, WAVES, true> : scene_graph_kernel<NT, SK, WAVES, false>;
+    auto kern = children ? scene_graph_kernel<NT, SK, WAVES, true, SPLIT> : scene_graph_kernel<NT, SK, WAVES, false, SPLIT>;
     if (lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_bytes));
