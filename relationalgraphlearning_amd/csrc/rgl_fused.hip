@@ -812,7 +812,9 @@ inline ItemPlan plan_items(int P, int n_full, int rem) {
     ItemPlan best{1, CT, 0, 1};
     float best_cost = -1.f;
     std::vector<float> load;
-    for (int G = CT; G >= 1; --G) {
+    // many parents: every SIMD gets dozens of items whatever the cut -- one item per parent (least crowd work), no simulation
+    const bool plenty = (long)P >= 16L * n_cu * kFusedWaves;
+    for (int G = CT; G >= (plenty ? CT : 1); --G) {
         const int ipp = (CT + G - 1) / G;
         if (G > 1 && (ipp - 1) * G >= CT) continue;
         const int last_tiles = n_full - (ipp - 1) * G;           // full tiles of the last group (n_full == 0: 0)
@@ -838,6 +840,7 @@ inline ItemPlan plan_items(int P, int n_full, int rem) {
         if (best_cost < 0.f || mk < best_cost - 1e-3f) { best_cost = mk; best = ItemPlan{G, ipp, rot, grid}; }
     }
     std::lock_guard<std::mutex> lk(mu);
+    if (cache.size() > 8192) cache.clear();                    // callers with ever-changing parent counts: bounded memory
     cache.emplace(key, best);
     return best;
 }
