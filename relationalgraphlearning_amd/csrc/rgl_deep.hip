@@ -42,11 +42,16 @@ struct DeepArgs {
 constexpr int kDeepThreads = 512;
 constexpr int kDeepWaves = 8;
 
-__device__ __forceinline__ float row16_sum(float x) {          // all-reduce over the 16 lanes of a DPP row
-    x += dpp_mov<DPP_QUAD_XOR1>(x);
-    x += dpp_mov<DPP_QUAD_XOR2>(x);
-    x += dpp_mov<DPP_ROW_HALF_MIRROR>(x);
-    x += dpp_mov<DPP_ROW_MIRROR>(x);
+// all-reduce over the 16 lanes of a DPP row.  The DPP operand rides in the add itself: through the update_dpp builtin every step was
+// v_mov 0 + v_mov_dpp + v_add (96 of the ~520 VALU instructions of the f16 per-child loop went into the eight sums of t_c)
+__device__ __forceinline__ float row16_sum(float x) {
+    // (s_nop 1: a DPP read of a VGPR needs two wait states after the VALU write of it, and the compiler's hazard recognizer does
+    // not look inside inline assembly)
+    float y;
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(y));
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(y));
     return x;
 }
 __device__ __forceinline__ float wave_max(float x) {
