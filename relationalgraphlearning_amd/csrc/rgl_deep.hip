@@ -531,13 +531,20 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                     const int fo = fh ? fo1 : fo0;
                     const f32x4 uw = *reinterpret_cast<const f32x4*>(&UW[j * XLD + fo]);
                     const f32x4 xh = *reinterpret_cast<const f32x4*>(&Xh[j * XLD + fo]);
+                    // two features per instruction (v_pk_mul / v_pk_fma / v_pk_add: same roundings as the scalar chain)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = relu1(fmaf(aj, uw[r], bj * yv[fh][r]));
-                        if (SKIP) v += xh[r];
-                        if (jt == 0 && n == 0) v = h10v[fh][r];
-                        h1[jt][fh][r] = v;
-                        tsk[fh][r] = fmaf(pj, v, tsk[fh][r]);
+                    for (int hp = 0; hp < 2; ++hp) {
+                        const f32x2 y2{yv[fh][2 * hp], yv[fh][2 * hp + 1]}, u2{uw[2 * hp], uw[2 * hp + 1]};
+                        f32x2 v = __builtin_elementwise_fma(f32x2{aj, aj}, u2, f32x2{bj, bj} * y2);      // fma(a, uw, round(b y))
+                        v[0] = relu1(v[0]);
+                        v[1] = relu1(v[1]);
+                        if (SKIP) v += f32x2{xh[2 * hp], xh[2 * hp + 1]};
+                        if (jt == 0 && n == 0) v = f32x2{h10v[fh][2 * hp], h10v[fh][2 * hp + 1]};
+                        h1[jt][fh][2 * hp] = v[0];
+                        h1[jt][fh][2 * hp + 1] = v[1];
+                        const f32x2 t2 = __builtin_elementwise_fma(f32x2{pj, pj}, v, f32x2{tsk[fh][2 * hp], tsk[fh][2 * hp + 1]});
+                        tsk[fh][2 * hp] = t2[0];
+                        tsk[fh][2 * hp + 1] = t2[1];
                     }
                 }
             }
@@ -607,6 +614,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
             for (int gt = 0; gt < 2; ++gt) o0[gt] = kgroups_sum(q == 0 ? O[0][gt][0] : 0.f);
             // ---- D2 = E O (+ robot row p O), then H2 = relu(a D2 + b O_0), t_c = sum_i p_i H2_i
             float tacc[2] = {0.f, 0.f};
+            f32x2 tacc2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};      // F16 branch: two rows per packed instruction
             float hrow0[2] = {0.f, 0.f};
             if (F16) {
                 f16x8 ob[KT][2];
@@ -630,15 +638,21 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                         d[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ea, ob[t][0], d[0], 0, 0, 0);
                         d[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ea, ob[t][1], d[1], 0, 0, 0);
                     }
+                    // two rows per instruction; the two partial sums of t_c meet after the loop
 #pragma unroll
                     for (int gt = 0; gt < 2; ++gt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float v = relu1(fmaf(aq[r], d[gt][r], bq[r] * o0[gt]));
-                            tacc[gt] = fmaf(pq[r], v, tacc[gt]);
-                            if (it == 0 && r == 0) hrow0[gt] = v;
+                        for (int hp = 0; hp < 2; ++hp) {
+                            const f32x2 a2{aq[2 * hp], aq[2 * hp + 1]}, b2{bq[2 * hp], bq[2 * hp + 1]}, p2{pq[2 * hp], pq[2 * hp + 1]};
+                            f32x2 v = __builtin_elementwise_fma(a2, f32x2{d[gt][2 * hp], d[gt][2 * hp + 1]}, b2 * f32x2{o0[gt], o0[gt]});
+                            v[0] = relu1(v[0]);
+                            v[1] = relu1(v[1]);
+                            tacc2[gt] = __builtin_elementwise_fma(p2, v, tacc2[gt]);
+                            if (it == 0 && hp == 0) hrow0[gt] = v[0];
                         }
                 }
+                tacc[0] = tacc2[0][0] + tacc2[0][1];
+                tacc[1] = tacc2[1][0] + tacc2[1][1];
             } else {
 #pragma unroll
                 for (int it = 0; it < NT; ++it) {
