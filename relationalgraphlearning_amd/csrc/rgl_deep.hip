@@ -54,16 +54,6 @@ __device__ __forceinline__ float row16_sum(float x) {
     asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(y));
     return x;
 }
-__device__ __forceinline__ float wave_max(float x) {
-    x = half_max(x);
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float wave_sum(float x) {
-    x = half_sum(x);
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 __device__ __forceinline__ f16x8 pack8(f32x4 lo, f32x4 hi) {
     f16x8 v;
 #pragma unroll

@@ -78,15 +78,6 @@ constexpr int WLD = 36;    // LDS row stride of the 32-column weight images (k-m
 constexpr int W1LD = 80;   // same for the 64-column image of wr1 (rows differ by 1 between k-groups)
 
 
-#define DPP_QUAD_XOR1 0xB1
-#define DPP_QUAD_XOR2 0x4E
-#define DPP_ROW_HALF_MIRROR 0x141
-#define DPP_ROW_MIRROR 0x140
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float x) {
-    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xF, 0xF, false));
-}
 // gfx90a+ DPP row_newbcast:K -- every lane of a 16-lane DPP row reads lane K of its row -- fused into the consuming VOP2
 // instruction: a per-row scalar held once per DPP row reaches all lanes with no LDS traffic and no extra instruction.
 // (hipcc does not fold row_newbcast movs into their users, hence the asm.)
@@ -115,23 +106,6 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-// all-reduce over the 32 lanes of a half-wave (lanes l and l^32 stay separate)
-__device__ __forceinline__ float half_max(float x) {
-    x = fmaxf(x, dpp_mov<DPP_QUAD_XOR1>(x));
-    x = fmaxf(x, dpp_mov<DPP_QUAD_XOR2>(x));
-    x = fmaxf(x, dpp_mov<DPP_ROW_HALF_MIRROR>(x));
-    x = fmaxf(x, dpp_mov<DPP_ROW_MIRROR>(x));
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float half_sum(float x) {
-    x += dpp_mov<DPP_QUAD_XOR1>(x);
-    x += dpp_mov<DPP_QUAD_XOR2>(x);
-    x += dpp_mov<DPP_ROW_HALF_MIRROR>(x);
-    x += dpp_mov<DPP_ROW_MIRROR>(x);
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 
 // ------------------------------------------------------------------------------------------------
 // host side
