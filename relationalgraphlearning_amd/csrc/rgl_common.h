@@ -65,14 +65,16 @@ int launch_scene_forward(const RglGraph* g, const RglMlp* value_head, const RglM
 int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
                            const float* robot, const float* humans, int n_scenes, int scenes_per_crowd, int H,
                            float* H_out, float* A_out, float* value_out, float* humans_next, hipStream_t stream);   // rgl_generic.hip
+// `image` (both launchers of the two-stage pair): null, or the packed weight image of these weights (FusedLds layout,
+// pack_images_kernel) -- the kernels then copy their weight images instead of building them from the raw matrices
 int launch_rank1_children(const RglGraph* g, int P, int A, int H, const float* child_robot, const float* humans_next,
-                          float* rows_out, hipStream_t stream);                                                     // rgl_rank1.hip
+                          float* rows_out, hipStream_t stream, const float* image = nullptr);                       // rgl_rank1.hip
 int launch_deep_children(const RglGraph* g, int P, int A, int H, const float* child_robot, const float* humans_next,
                          float* rows_out, int f16, hipStream_t stream);                                             // rgl_deep.hip
 int launch_tile_children(const RglGraph* g, int P, int A, int H, const float* child_robot, const float* humans_next,
                          float* rows_out, hipStream_t stream);                                                      // rgl_tile.hip
 int launch_head_rows(const RglGraph* g, const RglMlp* head, const float* rows, int M, float* value,
-                     hipStream_t stream);                                                                          // rgl_head.hip
+                     hipStream_t stream, const float* image = nullptr);                                                                          // rgl_head.hip
 // the fused tile kernel (rgl_fused.hip).  Its weight image is prepared in global memory by pack_images_kernel: by the caller once per
 // parameter state (caller_image = MprlPlanner::children_image), else once per tree search (image_ready = 1 on the per-level calls)
 // or by the call itself, at the END of the workspace it is given.
@@ -82,6 +84,7 @@ int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, i
 int pack_children_images(const RglGraph* g, const RglMlp* head, int P, int A, int H, void* workspace, size_t workspace_bytes,
                          hipStream_t stream);               // P = the largest launch; 1 = the fused kernel does not apply
 size_t fused_children_workspace_bytes(int P, int A, int H);
+const float* fused_workspace_image(const void* workspace, size_t workspace_bytes);   // where pack_children_images put the image
 int launch_value_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
                           float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream,
                           int image_ready = 0);                                                                     // rgl_fast.hip

@@ -40,10 +40,15 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
                                    workspace_bytes, image_ready, stream, pl->children_image);
         if (rc != 1) return rc;
     }
+    // packed weight image of the value estimator (the caller's, or this search's at the end of the workspace): the two-stage pair
+    // copies its weight images from it instead of building them from the raw matrices (most of a small launch)
+    const float* image = !staged ? nullptr
+                         : pl->children_image ? pl->children_image
+                         : image_ready ? fused_workspace_image(workspace, workspace_bytes) : nullptr;
     if (staged) {
         const RglGraph* g = &pl->value_graph;
         float* rows = (float*)workspace;
-        if (!want_f16) rc = launch_rank1_children(g, P, A, H, child_robot, humans_next, rows, stream);
+        if (!want_f16) rc = launch_rank1_children(g, P, A, H, child_robot, humans_next, rows, stream, image);
         if (rc == 1) {
             rc = launch_deep_children(g, P, A, H, child_robot, humans_next, rows, want_f16 && g->num_layer == 3, stream);
             if (want_f16 && (rc == 1 || g->num_layer != 3)) return RGL_ERR_BAD_MODE;
@@ -65,7 +70,7 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
         return launch_generic_forward(&pl->value_graph, &pl->value_head, nullptr, child_robot, humans_next, P * A, A, H,
                                       nullptr, nullptr, child_value, nullptr, stream);
     if (rc) return rc;
-    return launch_head_rows(&pl->value_graph, &pl->value_head, (const float*)workspace, P * A, child_value, stream);
+    return launch_head_rows(&pl->value_graph, &pl->value_head, (const float*)workspace, P * A, child_value, stream, image);
 }
 
 }  // namespace rgl

@@ -65,33 +65,6 @@ struct FusedArgs {
 
 constexpr int kFusedWaves = 8;
 
-template <int D1, int D2, int D3>
-struct FusedLds {
-    // child-side weight image
-    static constexpr int wr1 = 0;
-    static constexpr int br1 = wr1 + 12 * W1LD;
-    static constexpr int wr2 = br1 + HID;
-    static constexpr int br2 = wr2 + HID * WLD;
-    static constexpr int wa = br2 + XD;
-    static constexpr int w1 = wa + XD * WLD;
-    // crowd side: w_h
-    static constexpr int wh1 = w1 + XD * WLD;
-    static constexpr int bh1 = wh1 + 8 * W1LD;
-    static constexpr int wh2 = bh1 + HID;
-    static constexpr int bh2 = wh2 + HID * WLD;
-    // value head: per-feature vectors, then the A fragments (layout of rgl_head.hip).  Everything addressed with many different
-    // lane patterns sits below 64 KB (the reach of a ds instruction's immediate offset from a shared base register); the large
-    // f3 image, addressed with one pattern, spans the boundary.
-    static constexpr int b1 = bh2 + XD;
-    static constexpr int b2 = b1 + Tiles<D1>::v * 16;
-    static constexpr int b3 = b2 + Tiles<D2>::v * 16;
-    static constexpr int w4 = b3 + Tiles<D3>::v * 16;
-    static constexpr int f_last = w4 + Tiles<D3>::v * 16;
-    static constexpr int f1 = f_last + 2 * 2 * 4 * 64;
-    static constexpr int f2 = f1 + Tiles<D1>::v * 2 * 4 * 64;
-    static constexpr int f3 = f2 + Tiles<D2>::v * Tiles<D1>::v * 4 * 64;
-    static constexpr int scratch = f3 + Tiles<D3>::v * Tiles<D2>::v * 4 * 64;       // per wave: fused_scratch_floats()
-};
 
 // h = relu(t W_last)(+hprev), value head 32 -> D1 -> D2 -> D3 -> 1 for the 16 children of a tile (lane (n, q): child n, D-layout
 // registers); returns the value of child n in every lane of its column (without the last bias)
@@ -933,6 +906,10 @@ size_t fused_children_workspace_bytes(int P, int A, int H) {
 
 static inline float* image_of(void* workspace, size_t workspace_bytes) {
     return reinterpret_cast<float*>((char*)workspace + ((workspace_bytes - kImageBytes) & ~(size_t)255));
+}
+
+const float* fused_workspace_image(const void* workspace, size_t workspace_bytes) {
+    return image_of(const_cast<void*>(workspace), workspace_bytes);
 }
 
 // 1 = the fused kernel does not apply (or the workspace cannot hold its images)

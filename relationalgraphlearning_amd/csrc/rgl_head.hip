@@ -16,6 +16,7 @@ struct HeadArgs {
     const float* rows;            // [M][64]
     float* value;                 // [M]
     int M, n_tiles;
+    const float* image;           // null, or the packed weight image (FusedLds<32,100,100> layout): its head vectors and fragments
 };
 
 template <int D1, int D2, int D3>
@@ -40,6 +41,16 @@ __global__ __launch_bounds__(kHeadThreads, 2) void robot_head_kernel(const HeadA
     using LO = HeadLds<D1, D2, D3>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
+    if constexpr (D1 == 32 && D2 == 100 && D3 == 100) {
+        if (a.image) {
+            // fragments and vectors are two contiguous blocks of the packed image, in this kernel's own order
+            using FL = FusedLds<32, 100, 100>;
+            static_assert(FL::scratch - FL::f_last == LO::b1 && FL::f_last - FL::b1 == LO::total - LO::b1, "same blocks in both layouts");
+            copy_image<FL::scratch - FL::f_last, kHeadThreads>(lds + LO::f_last, a.image + FL::f_last, tid);
+            copy_image<FL::f_last - FL::b1, kHeadThreads>(lds + LO::b1, a.image + FL::b1, tid);
+        }
+    }
+    if (!(D1 == 32 && D2 == 100 && D3 == 100 && a.image)) {
     fill_frags<XD, XD, kHeadThreads>(lds + LO::f_last, a.w_last, tid);
     fill_frags<XD, D1, kHeadThreads>(lds + LO::f1, a.w1, tid);
     fill_frags<D1, D2, kHeadThreads>(lds + LO::f2, a.w2, tid);
@@ -48,6 +59,7 @@ __global__ __launch_bounds__(kHeadThreads, 2) void robot_head_kernel(const HeadA
     fill_bias<D2>(lds + LO::b2, a.b2, tid, kHeadThreads);
     fill_bias<D3>(lds + LO::b3, a.b3, tid, kHeadThreads);
     fill_bias<D3>(lds + LO::w4, a.w4, tid, kHeadThreads);      // w4 is [D3][1]: same padded vector layout as a bias
+    }
     __syncthreads();
     const float b4 = a.b4[0];
     // tile t -> workgroup t % grid, wave (t / grid) % 8: the tiles of the last, partial round land on DIFFERENT workgroups
@@ -114,10 +126,12 @@ int launch_head(const HeadArgs& ha, hipStream_t st) {
 namespace rgl {
 
 // rows [M][64] (stage-1 hand-off) -> value;  1 = no kernel for this head (see head_variant)
-int launch_head_rows(const RglGraph* g, const RglMlp* h, const float* rows, int M, float* value, hipStream_t stream) {
+int launch_head_rows(const RglGraph* g, const RglMlp* h, const float* rows, int M, float* value, hipStream_t stream,
+                     const float* image) {
     const int hv = head_variant(*h);
     if (hv < 0) return 1;
     HeadArgs ha;
+    ha.image = hv == 0 ? image : nullptr;
     ha.w_last = g->Ws[g->num_layer - 1];
     ha.w1 = h->weight[0]; ha.b1 = h->bias[0];
     ha.w2 = h->weight[1]; ha.b2 = h->bias[1];

@@ -92,6 +92,37 @@ __device__ __forceinline__ void fill_matrix(float* dst, const float* __restrict_
     }
 }
 
+// The weight image of the shipped value estimator (w_r, w_h, Wa, W1, value-head vectors and A fragments) in the LDS layout of
+// children_fused_kernel (rgl_fused.hip); pack_images_kernel writes it to global memory once per parameter state.  The two-stage pair
+// takes its parts from the same image when one is at hand: children_rank1_kernel the first `b1` floats, robot_head_kernel the rest.
+template <int D1, int D2, int D3>
+struct FusedLds {
+    // child-side weight image
+    static constexpr int wr1 = 0;
+    static constexpr int br1 = wr1 + 12 * W1LD;
+    static constexpr int wr2 = br1 + HID;
+    static constexpr int br2 = wr2 + HID * WLD;
+    static constexpr int wa = br2 + XD;
+    static constexpr int w1 = wa + XD * WLD;
+    // crowd side: w_h
+    static constexpr int wh1 = w1 + XD * WLD;
+    static constexpr int bh1 = wh1 + 8 * W1LD;
+    static constexpr int wh2 = bh1 + HID;
+    static constexpr int bh2 = wh2 + HID * WLD;
+    // value head: per-feature vectors, then the A fragments (layout of rgl_head.hip).  Everything addressed with many different
+    // lane patterns sits below 64 KB (the reach of a ds instruction's immediate offset from a shared base register); the large
+    // f3 image, addressed with one pattern, spans the boundary.
+    static constexpr int b1 = bh2 + XD;
+    static constexpr int b2 = b1 + Tiles<D1>::v * 16;
+    static constexpr int b3 = b2 + Tiles<D2>::v * 16;
+    static constexpr int w4 = b3 + Tiles<D3>::v * 16;
+    static constexpr int f_last = w4 + Tiles<D3>::v * 16;
+    static constexpr int f1 = f_last + 2 * 2 * 4 * 64;
+    static constexpr int f2 = f1 + Tiles<D1>::v * 2 * 4 * 64;
+    static constexpr int f3 = f2 + Tiles<D2>::v * Tiles<D1>::v * 4 * 64;
+    static constexpr int scratch = f3 + Tiles<D3>::v * Tiles<D2>::v * 4 * 64;       // per wave: fused_scratch_floats()
+};
+
 // LDS image <- the same image prepared in global memory: b128 copies, every load of a thread in flight at once
 template <int NFLOATS, int NTHR>
 __device__ __forceinline__ void copy_image(float* dst, const float* __restrict__ src, int tid) {

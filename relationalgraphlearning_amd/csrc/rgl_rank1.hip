@@ -3,7 +3,7 @@
 //
 // Follows (reference paths): crowd_nav/policy/graph_model.py:99-130, value_estimator.py:11-20,
 // model_predictive_rl.py:245-250 (the loop whose iterations this kernel runs side by side).
-#include "rgl_mfma.h"
+#include "rgl_mlp_chain.h"
 
 namespace {
 
@@ -33,6 +33,7 @@ struct Rank1Args {
     int sim;                              // SIM_* row normalisation
     float* rows_out;                      // [P*A][64]
     int off_wh1, off_bh1, off_wh2, off_bh2, off_wa, off_wr1, off_br1, off_wr2, off_br2, off_w1;   // weight image
+    const float* image;                   // null, or the packed weight image (FusedLds layout, rgl_mlp_chain.h): its first FusedLds::b1 floats
     int off_crowd, crowd_stride;          // double-buffered crowd block: Xh | Gm | UW | msh | zsh
     int off_sc0, off_y0, off_tp;          // (a, b) table [16*CT][SLD][2], y = x0 W1 [16*CT][XLD], partial t_c [16*CT][XLD]
     int off_flag;                         // [4] ints: crowd-wave epochs
@@ -68,7 +69,11 @@ __global__ __launch_bounds__(512, 2) void children_rank1_kernel(const Rank1Args 
     auto crowd_msh = [&](int b) { return lds + a.off_crowd + b * a.crowd_stride + 3 * 16 * NT * XLD; };
     auto crowd_zsh = [&](int b) { return lds + a.off_crowd + b * a.crowd_stride + 3 * 16 * NT * XLD + 16 * NT; };
 
-    {   // weight image, once per workgroup, in two phases -- every global load of the thread first, then the LDS stores -- so the
+    if (a.image) {
+        // the caller has the packed image of these weights (once per parameter state): straight b128 copies, no index arithmetic
+        copy_image<FusedLds<32, 100, 100>::b1, 512>(lds, a.image, tid);
+    } else {
+        // weight image, once per workgroup, in two phases -- every global load of the thread first, then the LDS stores -- so the
         // 34 KB image costs ONE L2 round trip (matrix by matrix it cost one per matrix: several us of a small launch)
         float* w = lds;
         constexpr int NTHR = 512;                      // the kernel is always launched with 8 waves
@@ -521,6 +526,7 @@ struct Rank1Plan {
     size_t lds_bytes;
     int hr;
     bool ok;
+    bool image_layout;                    // the LDS offsets coincide with FusedLds: a packed image can be copied in
 };
 
 inline Rank1Plan plan_rank1(const RglGraph& g, int P, int A, int H) {
@@ -540,9 +546,15 @@ inline Rank1Plan plan_rank1(const RglGraph& g, int P, int A, int H) {
     a.n_waves = 8;                              // CT (<= 6) child waves + NT (<= 2) crowd waves
     int off = 0;
     auto take = [&](int nfl) { int o = off; off += (nfl + 3) & ~3; return o; };
+    // weight image in the order (and with the strides) of FusedLds: one copy from the packed image when the caller has one
+    a.off_wr1 = take(12 * W1LD); a.off_br1 = take(HID); a.off_wr2 = take(HID * WLD); a.off_br2 = take(XD);
+    a.off_wa = take(XD * WLD); a.off_w1 = take(XD * WLD);
     a.off_wh1 = take(8 * W1LD); a.off_bh1 = take(HID); a.off_wh2 = take(HID * WLD); a.off_bh2 = take(XD);
-    a.off_wa = take(XD * WLD); a.off_wr1 = take(12 * W1LD); a.off_br1 = take(HID); a.off_wr2 = take(HID * WLD);
-    a.off_br2 = take(XD); a.off_w1 = take(XD * WLD);
+    using FL = FusedLds<32, 100, 100>;
+    static_assert(FL::wr1 == 0, "image starts at the robot embedding");
+    a.image = nullptr;
+    pl.image_layout = a.off_wr1 == FL::wr1 && a.off_br1 == FL::br1 && a.off_wr2 == FL::wr2 && a.off_br2 == FL::br2 && a.off_wa == FL::wa &&
+                      a.off_w1 == FL::w1 && a.off_wh1 == FL::wh1 && a.off_bh1 == FL::bh1 && a.off_wh2 == FL::wh2 && a.off_bh2 == FL::bh2;
     a.crowd_stride = 3 * 16 * a.NT * XLD + 2 * 16 * a.NT;
     a.off_crowd = take(2 * a.crowd_stride);
     a.off_sc0 = take(2 * 16 * a.CT * a.SLD);
@@ -603,9 +615,10 @@ namespace rgl {
 
 // 1 = outside this kernel's envelope
 int launch_rank1_children(const RglGraph* g, int P, int A, int H, const float* child_robot, const float* humans_next,
-                          float* rows_out, hipStream_t stream) {
+                          float* rows_out, hipStream_t stream, const float* image) {
     Rank1Plan rp = plan_rank1(*g, P, A, H);
     if (!rp.ok) return 1;
+    rp.a.image = rp.image_layout ? image : nullptr;
     rp.a.child_robot = child_robot;
     rp.a.humans = humans_next;
     rp.a.rows_out = rows_out;
