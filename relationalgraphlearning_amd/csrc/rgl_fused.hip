@@ -9,10 +9,11 @@
 // What changes is the organisation (round 2):
 //   * children_fused_kernel: every wave owns one 16-child tile from the robot embedding to the VALUE: embedding,
 //     robot row/column of S, softmax scalars, the VALU row pass, the robot row, the last GCN layer on the robot row and the
-//     value head all run on registers and a 6.5 KB wave-private LDS scratch.  No workgroup barrier after the weight image
-//     is built, no [P*A][64] fp32 hand-off through HBM, no second launch.  Tiles are dealt round-robin over all waves of
-//     the GPU, so the four SIMDs of a CU carry the same number of tiles -- the imbalance that sank round 1's barrier-free
-//     experiment (6 tiles + 2 crowd waves on 4 SIMDs).
+//     value head all run on registers and a 5-6.5 KB wave-private LDS scratch.  No workgroup barrier after the weight image
+//     is built, no [P*A][64] fp32 hand-off through HBM, no second launch.  Work items (groups of tiles of one parent,
+//     plan_items) are dealt over all waves of the GPU in snake passes, heaviest first, so the four SIMDs of a CU carry the
+//     same load -- the imbalance that sank round 1's barrier-free experiment (6 tiles + 2 crowd waves on 4 SIMDs).
+//   * row pass (softmax similarity, N <= 20) in the MFMA D layout with packed fp32 math: 4 instructions per 2 elements.
 //   * the crowd-only quantities of a parent (Xh, G = Xh Wa, UW, msh, Zsh: 208 MFMAs, ~9 % of a parent's work) are computed
 //     by the wave that owns the work item, at the item's start, straight into the registers the tiles read them from
 //     (the MFMA D layout of the crowd chain IS the A-operand layout of the robot row / column products; the two
