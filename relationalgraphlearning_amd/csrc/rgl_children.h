@@ -34,9 +34,9 @@ __device__ __forceinline__ double seg_point_dist_origin(double px, double py, do
     return sqrt(cx * cx + cy * cy);
 }
 
-// One (parent, action) pair: next robot state + estimate_reward.  When `p` is wave-uniform (one wave per parent, lanes =
-// actions) the parent's robot row and its crowd come through scalar loads, once per wave instead of once per lane.
-__device__ __forceinline__ void children_pa(const ChildrenArgs& ca, int p, int a) {
+// One (parent, action) pair: next robot state + estimate_reward.  `near_mask`: bit h clear = human h provably cannot influence
+// any child of this parent (children_wave), skipped outright.
+__device__ __forceinline__ void children_pa(const ChildrenArgs& ca, int p, int a, unsigned int near_mask = ~0u) {
     const long long idx = (long long)p * ca.A + a;
     const float* __restrict__ robot = ca.robot;
     const float* __restrict__ humans = ca.humans;
@@ -90,6 +90,7 @@ __device__ __forceinline__ void children_pa(const ChildrenArgs& ca, int p, int a
     double dmin = INFINITY;
     const float favx = (float)avx, favy = (float)avy, fdt = (float)dt;
     for (int h = 0; h < H; ++h) {
+        if (h < 32 && !((near_mask >> h) & 1u)) continue;
         const float* hu = hs + h * 5;
         {
             // fp32 pre-test of the exact shortcut below: with T = radii + 0.25, |p|^2 >= 2 (|e - p|^2 + T^2) proves that this
@@ -142,6 +143,50 @@ __device__ __forceinline__ void children_pa(const ChildrenArgs& ca, int p, int a
 __device__ __forceinline__ void children_thread(const ChildrenArgs& ca, long long idx) {
     const int p = (int)(idx / ca.A);
     children_pa(ca, p, (int)(idx - (long long)p * ca.A));
+}
+
+// 64 consecutive pairs idx0 .. idx0 + 63 by one WHOLE wave (every lane must call it: lanes past `total` only help with the masks).
+// With A >= 64 actions the pairs belong to at most two parents, pA and pA + 1.  Most humans of a crowd spread over an arena are far
+// from the robot for EVERY action: with v_max >= |v_a| over the table, the relative displacement of human h over the step obeys
+// |s| <= (|v_h| + v_max) dt, so |p|^2 >= 2 ((|v_h| + v_max)^2 dt^2 + T^2) (T = radii + 0.25) proves clearance >= 0.25 for all
+// children of the parent -- the per-child pre-test of children_pa would pass for each of them.  Lanes 0..31 evaluate that test
+// for the humans of pA, lanes 32..63 for pA + 1 (fp32, 1 % margin; the per-child test it implies keeps 0.1 %), one ballot makes the
+// two masks, and every pair skips its parent's far humans outright instead of pre-testing them one by one: same results,
+// H pre-tests per parent instead of per child.  (H <= 32; float64 roots and larger crowds take children_thread.)
+__device__ __forceinline__ void children_wave(const ChildrenArgs& ca, long long idx0, long long total, float v_max) {
+    const int lane = threadIdx.x & 63;
+    const int A = ca.A, H = ca.H;
+    const int pA = (int)(idx0 / A);
+    const int half = lane >> 5, h = lane & 31;
+    const int pm = pA + half;                                        // the parent whose human h this lane examines
+    bool near = false;
+    if (h < H && pm < ca.P) {
+        const float* r = ca.robot + (size_t)pm * 9;
+        const float* hu = ca.humans + ((size_t)(pm / ca.humans_per) * H + h) * 5;
+        const float qx = hu[0] - r[0], qy = hu[1] - r[1];
+        const float sm = (sqrtf(hu[2] * hu[2] + hu[3] * hu[3]) + v_max) * (float)ca.dt;
+        const float Tf = hu[4] + r[4] + 0.25f;
+        near = !(qx * qx + qy * qy >= 2.02f * (sm * sm + Tf * Tf));
+    }
+    const unsigned long long bal = __ballot(near);
+    const long long idx = idx0 + lane;
+    if (idx < total) {
+        const int p = (int)(idx / A);
+        children_pa(ca, p, (int)(idx - (long long)p * A), p == pA ? (unsigned int)bal : (unsigned int)(bal >> 32));
+    }
+}
+
+// largest action speed of the table (holonomic: |(vx, vy)|, unicycle: |v|), by one whole wave; slightly rounded up
+__device__ __forceinline__ float table_speed_bound(const ChildrenArgs& ca) {
+    const int lane = threadIdx.x & 63;
+    float m = 0.f;
+    for (int k = lane; k < ca.A; k += 64) {
+        const double a0 = ca.actions[2 * k], a1 = ca.actions[2 * k + 1];
+        m = fmaxf(m, ca.kinematics == RGL_HOLONOMIC ? (float)sqrt(a0 * a0 + a1 * a1) : (float)fabs(a0));
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+    return m * 1.0001f;
 }
 
 }  // namespace

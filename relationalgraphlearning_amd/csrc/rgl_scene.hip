@@ -112,8 +112,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
     if constexpr (CH) {
         if ((int)blockIdx.x >= grid_scene) {
             const long long total = (long long)ca.P * ca.A, stride = (long long)(gridDim.x - grid_scene) * kSceneThreads;
-            for (long long idx = (long long)(blockIdx.x - grid_scene) * kSceneThreads + threadIdx.x; idx < total; idx += stride)
-                children_thread(ca, idx);
+            const long long first = (long long)(blockIdx.x - grid_scene) * kSceneThreads + threadIdx.x;
+            if (ca.A >= 64 && ca.H <= 32 && !ca.robot64) {       // whole waves: far-human masks per parent (children_wave)
+                const float v_max = table_speed_bound(ca);
+                for (long long base = first & ~63LL; base < total; base += stride) children_wave(ca, base, total, v_max);
+            } else {
+                for (long long idx = first; idx < total; idx += stride) children_thread(ca, idx);
+            }
             return;
         }
     }

@@ -12,10 +12,17 @@ namespace {
 
 constexpr int kBlock = 256;
 
-// One thread per (parent, action): next robot state + estimate_reward (rgl_children.h).
+// One thread per (parent, action): next robot state + estimate_reward (rgl_children.h); a wave's 64 pairs share the far-human
+// masks of their (at most two) parents when the table and the crowd allow it (children_wave).
 __global__ void mprl_children_kernel(const ChildrenArgs ca) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (long long)ca.P * ca.A) children_thread(ca, idx);
+    const long long total = (long long)ca.P * ca.A;
+    const long long idx0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) & ~63LL;      // my wave's first pair
+    if (ca.A >= 64 && ca.H <= 32 && !ca.robot64) {
+        if (idx0 < total) children_wave(ca, idx0, total, table_speed_bound(ca));
+    } else {
+        const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx < total) children_thread(ca, idx);
+    }
 }
 
 __global__ void linear_humans_kernel(const float* __restrict__ humans, float* __restrict__ out, long long n_rows) {
