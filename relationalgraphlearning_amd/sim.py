@@ -52,8 +52,17 @@ def generate_scene(cfg, phase, case):
     rs = np.random.RandomState(BASE_SEED[phase] + case)
     R = cfg.circle_radius
     robot = np.array([0.0, -R, 0.0, 0.0, cfg.robot_radius, 0.0, R, cfg.robot_v_pref, np.pi / 2])
-    agents = [(robot[0], robot[1], robot[5], robot[6], cfg.robot_radius)]      # (px, py, gx, gy, radius)
+    # agents placed so far as columns (px, py, gx, gy, radius): the rejection tests below run as one vector expression per
+    # attempt -- sqrt(dx*dx + dy*dy) element by element, the arithmetic of np.linalg.norm on a pair -- instead of two
+    # np.linalg.norm calls per placed agent (20 ms per 19-human scene that way, almost all of it call overhead)
+    ag = np.empty((cfg.human_num + 1, 5))
+    ag[0] = (robot[0], robot[1], robot[5], robot[6], cfg.robot_radius)
+    n = 1
     humans, goals, vprefs = [], [], []
+
+    def clear_of(x, y, cx, cy, radius):        # every distance from (x, y) to the points (cx, cy) at least the margin
+        dx, dy = x - cx, y - cy
+        return not bool((np.sqrt(dx * dx + dy * dy) < radius + ag[:n, 4] + cfg.discomfort_dist).any())
     for _ in range(cfg.human_num):
         v_pref, radius = cfg.human_v_pref, cfg.human_radius
         if cfg.randomize_attributes:
@@ -66,13 +75,7 @@ def generate_scene(cfg, phase, case):
                 py_noise = (rs.random_sample() - 0.5) * v_pref
                 px = R * np.cos(angle) + px_noise
                 py = R * np.sin(angle) + py_noise
-                ok = True
-                for (ax, ay, agx, agy, ar) in agents:
-                    min_dist = radius + ar + cfg.discomfort_dist
-                    if np.linalg.norm((px - ax, py - ay)) < min_dist or np.linalg.norm((px - agx, py - agy)) < min_dist:
-                        ok = False
-                        break
-                if ok:
+                if clear_of(px, py, ag[:n, 0], ag[:n, 1], radius) and clear_of(px, py, ag[:n, 2], ag[:n, 3], radius):
                     break
             gx, gy = -px, -py
         elif cfg.scenario == "square_crossing":
@@ -80,18 +83,17 @@ def generate_scene(cfg, phase, case):
             while True:
                 px = rs.random_sample() * cfg.square_width * 0.5 * sign
                 py = (rs.random_sample() - 0.5) * cfg.square_width
-                if all(np.linalg.norm((px - ax, py - ay)) >= radius + ar + cfg.discomfort_dist
-                       for (ax, ay, _, _, ar) in agents):
+                if clear_of(px, py, ag[:n, 0], ag[:n, 1], radius):
                     break
             while True:
                 gx = rs.random_sample() * cfg.square_width * 0.5 * -sign
                 gy = (rs.random_sample() - 0.5) * cfg.square_width
-                if all(np.linalg.norm((gx - agx, gy - agy)) >= radius + ar + cfg.discomfort_dist
-                       for (_, _, agx, agy, ar) in agents):
+                if clear_of(gx, gy, ag[:n, 2], ag[:n, 3], radius):
                     break
         else:
             raise NotImplementedError(cfg.scenario)
-        agents.append((px, py, gx, gy, radius))
+        ag[n] = (px, py, gx, gy, radius)
+        n += 1
         humans.append([px, py, 0.0, 0.0, radius])
         goals.append([gx, gy])
         vprefs.append(v_pref)
