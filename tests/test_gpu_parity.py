@@ -480,6 +480,22 @@ print("OK worst %.2e" % worst)
     report("fused kernel vs general kernel over 36 random shapes: " + out.stdout.strip().splitlines()[-1])
 
 
+def test_scene_kernel_split_and_unsplit_forced(dev):
+    """The one-wave-per-scene kernel splits a scene over its column tiles' waves below a size threshold (rgl_scene.hip, SPLIT).  Both
+    organisations over the state-predictor, similarity / layerwise and forward-KAT tests, whatever their batch sizes: the threshold is
+    forced to "always" and to "never" in child processes (the switch is read once per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for below in ("1000000", "0"):
+        env = dict(os.environ, RGL_SCENE_SPLIT_BELOW=below)
+        out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                              "-k", "state_predictor or cosine_concatenation or forward_kats or path_g_value_network"],
+                             cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    report("scene kernel: split / unsplit forced over the predictor, similarity and forward-KAT tests: green")
+
+
 def test_tile_kernel_variant_forced(dev):
     """With RGL_CHILDREN_TILE_KERNEL=1 the MFMA tile kernel also handles what the shared-crowd kernels (rank-1: L=2,
     N<=32; deep: L in {2,3}, N<=56) take by default.  The switch is read once per process, so this runs in a child process."""
