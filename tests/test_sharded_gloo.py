@@ -41,6 +41,7 @@ def _worker(rank, world, port, total, out_dir):
         return a, v
     sr = ShardedRollout(search)
     act, val = sr.run(robot, humans)
+    assert act.dtype == torch.int32 and val.dtype == torch.float32        # the search's own index type, no conversion kernel
     # pipelined use (bench.py): two steps in flight, results collected one step late
     from relationalgraphlearning_amd import shard_bounds
     lo, hi = shard_bounds(total, world, rank)
