@@ -51,9 +51,24 @@ constexpr int kRowMlpSetFloats = 4 * 1 * 4 * 64 + 2 * 4 * 4 * 64 + HID + XD;
 // Both embedding MLPs of a level in ONE launch (they are launch-latency sized): workgroups [0, grid_a) take the robot rows
 // (INA inputs), the others the human rows (INB inputs).  (9, 5): path M's full / observable states; (6, 7): path G's rotated
 // self / human features (gcn.py:34-47).
+// `grid_mlp` < gridDim.x: the workgroups past the two MLPs run the level's independent next-robot-state / reward work (rgl_children.h)
+// in the same launch -- with many scenes that work does not ride in the scene kernel (see scene_graph_kernel) and was a launch of its
+// own between this one and the scene kernel.
 template <int INA, int INB>
-__global__ __launch_bounds__(kThreads, 2) void row_mlp2_pair_kernel(const RowMlpArgs ra, const RowMlpArgs rb, int grid_a) {
+__global__ __launch_bounds__(kThreads, 2) void row_mlp2_pair_kernel(const RowMlpArgs ra, const RowMlpArgs rb, int grid_a, int grid_mlp,
+                                                                    const ChildrenArgs ca) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x >= grid_mlp) {
+        const long long total = (long long)ca.P * ca.A, stride = (long long)(gridDim.x - grid_mlp) * kThreads;
+        const long long first_pair = (long long)(blockIdx.x - grid_mlp) * kThreads + threadIdx.x;
+        if (ca.A >= 64 && ca.H <= 32 && !ca.robot64) {
+            const float v_max = table_speed_bound(ca);
+            for (long long base = first_pair & ~63LL; base < total; base += stride) children_wave(ca, base, total, v_max);
+        } else {
+            for (long long idx = first_pair; idx < total; idx += stride) children_thread(ca, idx);
+        }
+        return;
+    }
     constexpr int F1 = 0, F2 = F1 + 4 * 1 * 4 * 64, B1 = F2 + 2 * 4 * 4 * 64, B2 = B1 + HID;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool first = (int)blockIdx.x < grid_a;
@@ -63,7 +78,7 @@ __global__ __launch_bounds__(kThreads, 2) void row_mlp2_pair_kernel(const RowMlp
     fill_bias<HID>(lds + B1, a.b1, tid);
     fill_bias<XD>(lds + B2, a.b2, tid);
     __syncthreads();
-    const int b = first ? blockIdx.x : blockIdx.x - grid_a, g = first ? grid_a : gridDim.x - grid_a;
+    const int b = first ? blockIdx.x : blockIdx.x - grid_a, g = first ? grid_a : grid_mlp - grid_a;
     if (first) row_mlp2_tiles<INA>(a, lds, b + g * wave, g * kWaves, lane);       // partial round: one tile per workgroup
     else row_mlp2_tiles<INB>(a, lds, b + g * wave, g * kWaves, lane);
 }
@@ -475,18 +490,27 @@ inline RowMlpArgs row_mlp_args(const RglMlp& m, const float* rows, float* out, i
 }
 
 // robot rows [Ma][9] -> [Ma][32] with w_r, human rows [Mb][5] -> [Mb][32] with w_h
+// `children` (optional): the level's reward / next-state work on extra workgroups of this launch
 inline int launch_row_mlp2_pair(const RglMlp& wr, const float* robot_rows, float* x0_out, int Ma, const RglMlp& wh,
-                                const float* human_rows, float* xh_out, int Mb, hipStream_t st) {
+                                const float* human_rows, float* xh_out, int Mb, hipStream_t st, const ChildrenArgs* children = nullptr) {
     const RowMlpArgs ra = row_mlp_args(wr, robot_rows, x0_out, Ma), rb = row_mlp_args(wh, human_rows, xh_out, Mb);
     int grid_a = (ra.n_tiles + kWaves - 1) / kWaves, grid_b = (rb.n_tiles + kWaves - 1) / kWaves;
     if (grid_a > 256) grid_a = 256;
     if (grid_b > 1024) grid_b = 1024;
+    ChildrenArgs ca{};
+    int grid_c = 0;
+    if (children) {
+        ca = *children;
+        const long long blocks = ((long long)ca.P * ca.A + kThreads - 1) / kThreads;
+        grid_c = (int)(blocks < 4096 ? blocks : 4096);
+    }
+    const int grid_mlp = grid_a + grid_b;
     if (wr.dims[0] == 9)
-        hipLaunchKernelGGL((row_mlp2_pair_kernel<9, 5>), dim3(grid_a + grid_b), dim3(kThreads), kRowMlpSetFloats * sizeof(float), st, ra,
-                           rb, grid_a);
+        hipLaunchKernelGGL((row_mlp2_pair_kernel<9, 5>), dim3(grid_mlp + grid_c), dim3(kThreads), kRowMlpSetFloats * sizeof(float), st, ra,
+                           rb, grid_a, grid_mlp, ca);
     else
-        hipLaunchKernelGGL((row_mlp2_pair_kernel<6, 7>), dim3(grid_a + grid_b), dim3(kThreads), kRowMlpSetFloats * sizeof(float), st, ra,
-                           rb, grid_a);
+        hipLaunchKernelGGL((row_mlp2_pair_kernel<6, 7>), dim3(grid_mlp + grid_c), dim3(kThreads), kRowMlpSetFloats * sizeof(float), st, ra,
+                           rb, grid_a, grid_mlp, ca);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }
@@ -545,9 +569,9 @@ static bool scene_kernel_covers(const RglGraph& g, int N) {
 // embeddings (one launch) + one-wave-per-scene graph forward; mh != null: motion head -> humans_next; rows_out != null: value rows
 static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* robot, const float* humans, int crowds_per, int P,
                              int H, float* humans_next, float* rows_out, float* x0_rows, float* xh_rows,
-                             const ChildrenArgs* ca, hipStream_t stream) {
+                             const ChildrenArgs* ca, hipStream_t stream, const ChildrenArgs* embed_children = nullptr) {
     const int N = H + 1, n_crowds = P / crowds_per;
-    int rc = launch_row_mlp2_pair(g.w_r, robot, x0_rows, P, g.w_h, humans, xh_rows, n_crowds * H, stream);
+    int rc = launch_row_mlp2_pair(g.w_r, robot, x0_rows, P, g.w_h, humans, xh_rows, n_crowds * H, stream, embed_children);
     if (rc) return rc;
     SceneArgs sa;
     sa.xh_rows = xh_rows; sa.x0_rows = x0_rows; sa.crowds_per = crowds_per;
@@ -607,8 +631,12 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
                                       humans_next, stream);
     float* x0_rows = (float*)workspace;                      // [P][32]
     float* xh_rows = x0_rows + (size_t)P * XD;               // [n_crowds][H][32]
-    if (ca && P >= 3072) ca = nullptr;     // many scenes: the caller runs mprl_children_kernel beside this launch (expand_level)
-    const int rc = run_scene_kernels(g, &mh, robot, humans, crowds_per, P, H, humans_next, nullptr, x0_rows, xh_rows, ca, stream);
+    // the level's reward / next-state work rides in the scene kernel's launch while the scene workgroups leave LDS free (few scenes),
+    // in the embedding launch otherwise: never a launch of its own on this path
+    const ChildrenArgs* in_scene = (ca && P < 3072) ? ca : nullptr;
+    const ChildrenArgs* in_embed = (ca && !in_scene) ? ca : nullptr;
+    const int rc = run_scene_kernels(g, &mh, robot, humans, crowds_per, P, H, humans_next, nullptr, x0_rows, xh_rows, in_scene, stream,
+                                     in_embed);
     if (rc == RGL_OK && ca && children_done) *children_done = 1;
     return rc;
 }
