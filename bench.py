@@ -3,25 +3,38 @@
 
 One "step" = one complete depth-D, width-w action-tree search (state predictor, 81-action
 expansion, rewards, value estimator, top-w clipping, V_planning back-up, argmax) for a batch of
-B synthetic root scenes per GPU, inputs resident in HBM.  Workload at N=1 = BASELINE.json
-configs[2]: N=20 agents (19 humans + robot), 2-layer GCN, depth-2 rollout (width 2), batch 2048.
+synthetic root scenes, inputs resident in HBM.  Workload = BASELINE.json configs[2]: N=20 agents
+(19 humans + robot), 2-layer GCN, depth-2 rollout (width 2), 2048 root scenes.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 8 --steps 50 --warmup 10          # launches its own 8 ranks (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port 29500 bench.py --gpus 8 --steps 50 --warmup 10
+        --master-port 29500 bench.py --gpus 8 --steps 50 --warmup 10        # what the driver does; same line
 
 Prints ONE JSON line on rank 0.  `value` counts reference-equivalent ValueEstimator forwards
 (249 per root for D=2,w=2) completed per second over all ranks.  Multi-GPU:
 roots are sharded and each step ends with the one real exchange of the path, an RCCL all-gather
-of the per-shard (action, value) rows.  Two modes:
+of the per-shard (action, value) rows.  Scaling readings (`--scaling`):
 
-    --scaling weak   (default)  --roots R roots PER GPU: per-GPU work fixed as N grows
-    --scaling strong --total-roots T   T roots in total, split contiguously over the ranks
-                     (BASELINE configs[3]: --scaling strong --total-roots 4096 --depth 3;
-                      configs[4]: --scaling strong --total-roots 2048 --humans 49 --layers 3 --contraction f16)
+    both   (default)  N = 1: the workload as is (reported as "weak": nothing is split).  N > 1: `value` is the
+                      FIXED-TOTAL reading SURVEY.md §8(d) prescribes (--roots roots in total, split contiguously over
+                      the ranks: "scaling": "strong"), and the same invocation also times --roots roots PER GPU and
+                      reports it as `weak_value` / `weak_ms_per_step`.
+    weak              --roots R roots PER GPU: per-GPU work fixed as N grows
+    strong            --total-roots T roots in total, split contiguously over the ranks
+                      (BASELINE configs[3]: --scaling strong --total-roots 4096 --depth 3;
+                       configs[4]: --scaling strong --total-roots 2048 --humans 49 --layers 3 --contraction f16)
 
-With more than one rank the line also carries `multi_gpu`: the slowest rank's search time per step
-and the exchange time per step, measured separately (un-pipelined) after the timed region.
+With more than one rank the line also carries `multi_gpu`: every rank's search time per step and the exchange time per
+step, measured separately (un-pipelined) after the timed region, and `ranks_seen` = dist.get_world_size().
+
+`--graph auto|on|off`: replay the rank's whole search from a captured hipGraph (auto: when the rank holds <= 512 roots,
+where a step is short enough for the host's ~12 launches to matter); `step_ms_device` (HIP events between steps) against
+`ms_per_step` (wall clock) shows whether the host is the limiter.
+
+RGL_BENCH_STUB_SEARCH=1 replaces the device search by a trivial CPU function over gloo: a test switch for the launcher
+and the exchange logic on machines without GPUs (tests/test_bench_launcher.py).  The line it prints says so and is not a
+measurement of anything.
 """
 import argparse
 import json
@@ -35,6 +48,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+STUB = os.environ.get("RGL_BENCH_STUB_SEARCH") == "1"       # launcher / exchange test switch: no device, no kernels, no measurement
 
 import relationalgraphlearning_amd as rga  # noqa: E402
 from relationalgraphlearning_amd.config import policy_config  # noqa: E402
@@ -81,11 +96,11 @@ def children_flops_per_scene(N, L, A):
             "tiles (children_graph_kernel + robot_head_kernel)")
 
 
-def workload_name(N, args):
+def workload_name(N, args, reading=None):
     key = (N, args.layers, args.depth, args.width)
     if key == (20, 2, 2, 2):
         return "BASELINE configs[2]"
-    share = "" if getattr(args, "scaling", "weak") == "strong" else "per-GPU share, "
+    share = "" if (reading or getattr(args, "scaling", "weak")) == "strong" else "per-GPU share, "
     if key == (20, 2, 3, 2):
         return "BASELINE configs[3]" + (" (per-GPU share)" if share else "")
     if key == (50, 3, 2, 2):
@@ -114,9 +129,15 @@ def load_weights(flavour, L, device):
             "value_network": sub("value_network"), "motion_predictor": sub("motion_predictor")}
 
 
-def synth_scenes(seed, B, H):
-    """Seeded synthetic crowd states: robot on the radius-4 circle heading to the antipode,
-    humans uniform in [-5,5]^2 with velocities in [-1,1]^2, radius 0.3."""
+CLEARANCE = 0.3 + 0.3 + 0.2        # radius + radius + discomfort distance (crowd_sim.py:131-139 re-draws below it)
+
+
+def synth_scenes(seed, B, H, placement="clearance"):
+    """Seeded synthetic crowd states: robot on the radius-4 circle heading to the antipode, humans in
+    [-5,5]^2 with velocities in [-1,1]^2, radius 0.3.  placement="clearance" (default since round 3) places the humans
+    one after the other and re-draws a position until it keeps 0.3 + 0.3 + 0.2 from the robot and from every human placed
+    before it -- the rejection rule of the reference's scene generator (crowd_sim.py:131-139), vectorised over the B scenes;
+    "uniform" is the round-1/2 generator (no re-draw; kept for one round so that r02 numbers stay reproducible)."""
     rng = np.random.RandomState(seed)
     robot = np.zeros((B, 9), np.float32)
     ang = rng.uniform(0, 2 * np.pi, B)
@@ -129,7 +150,22 @@ def synth_scenes(seed, B, H):
     robot[:, 7] = 1.0
     robot[:, 8] = np.pi / 2
     humans = np.zeros((B, H, 5), np.float32)
-    humans[:, :, 0:2] = rng.uniform(-5, 5, (B, H, 2))
+    if placement == "uniform":
+        humans[:, :, 0:2] = rng.uniform(-5, 5, (B, H, 2))
+    elif placement == "clearance":
+        pos = np.zeros((B, H, 2))
+        placed = np.concatenate([robot[:, None, 0:2].astype(np.float64), pos], axis=1)      # [robot, humans placed so far]
+        for i in range(H):
+            todo = np.arange(B)
+            while todo.size:
+                cand = rng.uniform(-5, 5, (todo.size, 2))
+                d = np.linalg.norm(placed[todo, :i + 1] - cand[:, None, :], axis=2)
+                ok = (d >= CLEARANCE).all(axis=1)
+                placed[todo[ok], i + 1] = cand[ok]
+                todo = todo[~ok]
+        humans[:, :, 0:2] = placed[:, 1:]
+    else:
+        raise ValueError("placement must be 'clearance' or 'uniform'")
     humans[:, :, 2:4] = rng.uniform(-1, 1, (B, H, 2))
     humans[:, :, 4] = 0.3
     return torch.tensor(robot), torch.tensor(humans)
@@ -194,13 +230,15 @@ def cpu_baseline(args, robot, humans, budget_s):
             "host_cpus": os.cpu_count()}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--roots", type=int, default=2048, help="root scenes per GPU (weak scaling)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--roots", type=int, default=2048,
+                    help="root scenes of the workload: per GPU in the weak reading, in total in the fixed-total reading of "
+                         "--scaling both")
+    ap.add_argument("--scaling", choices=("both", "weak", "strong"), default="both")
     ap.add_argument("--total-roots", type=int, default=None,
                     help="strong scaling: root scenes in total, split contiguously over the ranks (default: --roots)")
     ap.add_argument("--humans", type=int, default=19)
@@ -209,137 +247,200 @@ def main():
     ap.add_argument("--width", type=int, default=2)
     ap.add_argument("--contraction", choices=("f32", "f16"), default="f32",
                     help="f16: f16-input MFMA for the dense middle-layer products (BASELINE configs[4]; needs --layers 3)")
+    ap.add_argument("--scenes", choices=("clearance", "uniform"), default="clearance",
+                    help="human placement of the synthetic scenes: SURVEY 8(d)'s clearance re-draw (default) or the round-1/2 "
+                         "uniform draw")
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
+                    help="replay the rank's search from a captured hipGraph (auto: when the rank holds <= 512 roots)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 = skip)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
-    if os.environ.get("RGL_BENCH_SINGLE_DEVICE") == "1":      # world-size-1 RCCL smoke on a one-GPU box
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one process per GPU over RCCL
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    H, N = args.humans, args.humans + 1
-    if args.scaling == "strong":
-        total_roots = args.total_roots if args.total_roots is not None else args.roots
-        lo, hi = rga.shard_bounds(total_roots, world, rank)
-        B = hi - lo                                   # this rank's contiguous share (first ranks take the remainder)
-    else:
-        B, total_roots = args.roots, args.roots * world
-    pol = make_policy(args, device)
-    ts = pol.tree_search()
-    if args.scaling == "strong":                      # every rank slices the SAME global batch
-        robot_all, humans_all = synth_scenes(1000, total_roots, H)
-        robot_cpu, humans_cpu = robot_all[lo:hi].contiguous(), humans_all[lo:hi].contiguous()
-    else:
-        robot_cpu, humans_cpu = synth_scenes(1000 + rank, B, H)
-    robot, humans = robot_cpu.to(device), humans_cpu.to(device)
-    sharded = rga.ShardedRollout(
-        lambda r, h: (lambda o: (o["best_action"], o["best_value"]))(
-            ts.search(r, h, roots_are_joint_states=False, want_root_values=False)),
-        search_into=lambda r, h, a, v: ts.search(r, h, roots_are_joint_states=False, want_root_values=False, out=(a, v)))
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed.run environment: start the N ranks ourselves (one process
+    per GPU, rendezvous on 127.0.0.1) and pass their output through -- rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # the host driver only supports dmabuf IPC (RCCL needs it)
+    return subprocess.call(cmd, env=env)
+
+
+class _StubSearch:
+    """RGL_BENCH_STUB_SEARCH=1: a stand-in with the TreeSearch surface bench.py touches.  No arithmetic of the path -- it
+    exists so that the launcher, the sharding and the exchange can be run end to end on gloo without a GPU."""
+    num_actions, kept_per_node = 81, 2
+
+    def __init__(self, depth):
+        self.depth = depth
+
+    def logical_value_evals_per_root(self):
+        return {1: 81, 2: 249, 3: 581}.get(self.depth, 81)
+
+    def search(self, robot, humans, roots_are_joint_states=False, want_root_values=False, out=None):
+        act = (robot[:, 0].abs() * 1000).to(torch.int32) % self.num_actions
+        val = robot.sum(dim=1) + humans.sum(dim=(1, 2))
+        if out is not None:
+            out[0].copy_(act)
+            out[1].copy_(val)
+            return {"best_action": out[0], "best_value": out[1]}
+        return {"best_action": act, "best_value": val}
+
+
+class Leg:
+    """One timed reading: this rank's share of `total_roots` root scenes, its search (direct C-ABI call or replay of a
+    captured hipGraph) and the pipelined exchange."""
+
+    def __init__(self, args, ts, device, world, rank, total_roots, split, dist):
+        self.args, self.ts, self.device, self.world, self.rank, self.dist = args, ts, device, world, rank, dist
+        H = args.humans
+        if split:                                         # every rank slices the SAME seeded global batch
+            lo, hi = rga.shard_bounds(total_roots, world, rank)
+            robot_all, humans_all = synth_scenes(1000, total_roots, H, args.scenes)
+            self.robot_cpu, self.humans_cpu = robot_all[lo:hi].contiguous(), humans_all[lo:hi].contiguous()
+            self.roots_per_rank = [rga.shard_bounds(total_roots, world, r)[1] - rga.shard_bounds(total_roots, world, r)[0]
+                                   for r in range(world)]
+        else:
+            per = total_roots // world
+            self.robot_cpu, self.humans_cpu = synth_scenes(1000 + rank, per, H, args.scenes)
+            self.roots_per_rank = [per] * world
+        self.B, self.total_roots = self.robot_cpu.shape[0], total_roots
+        self.robot, self.humans = self.robot_cpu.to(device), self.humans_cpu.to(device)
+        self.use_graph = (not STUB) and (args.graph == "on" or (args.graph == "auto" and 0 < max(self.roots_per_rank) <= 512))
+        self.sharded = rga.ShardedRollout(self._search_fn, search_into=self._search_into)
+        self.graphs, self.graph_last = {}, None
+        if self.use_graph and self.B > 0:                 # capture BEFORE the first collective of this leg is enqueued
+            if self.sharded.active:
+                targets = self.sharded.use_static_buffers(total_roots, device)
+            else:
+                targets = [(torch.empty(self.B, dtype=torch.int32, device=device),
+                            torch.empty(self.B, dtype=torch.float32, device=device))]
+            for a, v in targets:
+                g, out = ts.capture(self.robot, self.humans, roots_are_joint_states=False, want_root_values=False, out=(a, v),
+                                    private_workspace=True)
+                self.graphs[a.data_ptr()] = (g, out)
+            self.single = targets[0]
+            self.graph_last = self.graphs[targets[0][0].data_ptr()][1]["last"]
+        self.pending = None
+
+    # the two shapes ShardedRollout calls the rank's search in
+    def _search_fn(self, r, h):
+        if self.graphs:
+            self.graphs[self.single[0].data_ptr()][0].replay()
+            return self.single
+        o = self.ts.search(r, h, roots_are_joint_states=False, want_root_values=False)
+        return o["best_action"], o["best_value"]
+
+    def _search_into(self, r, h, a, v):
+        if self.graphs:
+            self.graphs[a.data_ptr()][0].replay()
+        else:
+            self.ts.search(r, h, roots_are_joint_states=False, want_root_values=False, out=(a, v))
 
     # One exchange per step, pipelined by one step: the all-gather of step i is waited for after the search of step
     # i+1 has been enqueued, so it runs on RCCL's stream underneath that search.  drain() completes the last one;
     # every timed step's exchange finishes inside the timed region.
-    pending = [None]
+    def step(self):
+        nxt = self.sharded.launch_local(self.robot, self.humans, self.total_roots)
+        if self.pending is not None:
+            self.pending.wait()              # exchange of the previous step complete (stream-ordered); .result() unpacks
+        self.pending = nxt
 
-    def step():
-        nxt = sharded.launch_local(robot, humans, total_roots)
-        if pending[0] is not None:
-            pending[0].wait()                # exchange of the previous step complete (stream-ordered); .result() unpacks
-        pending[0] = nxt
+    def drain(self):
+        if self.pending is not None:
+            self.pending.wait()
+            self.pending = None
 
-    def drain():
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
+    def fence(self):
+        if not STUB:
+            torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        if not STUB:
+            torch.cuda.synchronize()
 
-    # Host hygiene: a generation-2 pass of CPython's cyclic GC over the heap torch leaves behind takes ~40 ms (measured:
-    # it landed inside the timed region and starved the GPU for 60 steps' worth of time).  Freeze the set-up objects so
-    # later collections only look at what the steps themselves allocate.
-    import gc
-    gc.collect()
-    gc.freeze()
+    def timed(self, steps, warmup, init_steps):
+        """`init_steps` set-up steps (code objects, workspace, RCCL channels), `warmup` untimed steps, then exactly `steps`
+        timed steps between fences; returns (wall seconds MAX over ranks, sorted per-step device ms of this rank)."""
+        for _ in range(init_steps):
+            self.step()
+        self.drain()
+        self.fence()
+        for _ in range(warmup):
+            self.step()
+        self.drain()
+        self.fence()
+        marks = None if STUB else [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if marks:
+                marks[i].record()
+            self.step()
+        self.drain()
+        if marks:
+            marks[steps].record()
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps)) if marks else [elapsed / steps * 1e3] * steps
+        if self.dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, step_ms
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def diagnose(self, n_diag=10):
+        """Search and exchange timed SEPARATELY (no pipelining) after the timed region, every rank's medians gathered."""
+        dist, dev = self.dist, self.device
+        if STUB:
+            srch = exch = 0.0
+            for _ in range(2):
+                self.fence()
+                t0 = time.perf_counter()
+                h = self.sharded.launch_local(self.robot, self.humans, self.total_roots)
+                t1 = time.perf_counter()
+                h.result()
+                srch, exch = (t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3
+        else:
+            ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_diag)]
+            for i in range(n_diag):
+                self.fence()
+                ev[i][0].record()
+                h = self.sharded.launch_local(self.robot, self.humans, self.total_roots)   # search enqueued, all-gather behind it
+                ev[i][1].record()                                     # end of this rank's search on the compute stream
+                h.wait()                                              # compute stream waits for the collective
+                ev[i][2].record()
+            self.fence()
+            srch = sorted(ev[i][0].elapsed_time(ev[i][1]) for i in range(n_diag))[n_diag // 2]
+            exch = sorted(ev[i][1].elapsed_time(ev[i][2]) for i in range(n_diag))[n_diag // 2]
+        mine = torch.tensor([srch, exch], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(every, mine)
+        per_rank = [[float(x[0]), float(x[1])] for x in every]
+        return {"ranks_seen": dist.get_world_size(),
+                "search_ms_per_step_by_rank": [p[0] for p in per_rank], "exchange_ms_per_step_by_rank": [p[1] for p in per_rank],
+                "search_ms_per_step_slowest_rank": max(p[0] for p in per_rank),
+                "search_ms_per_step_fastest_rank": min(p[0] for p in per_rank),
+                "exchange_ms_per_step_slowest_rank": max(p[1] for p in per_rank),
+                "note": "median of %d un-pipelined steps after the timed region; exchange = from the end of the rank's own "
+                        "search to the completion of the all-gather on its stream (includes waiting for slower ranks)" % n_diag,
+                "roots_per_rank": self.roots_per_rank}
 
-    # set-up, not warm-up: the first calls load the code objects, size the workspace and (N > 1) open the RCCL channels
-    INIT_STEPS = 3
-    for _ in range(INIT_STEPS):
-        step()
-    drain()
-    fence()
-    for _ in range(args.warmup):
-        step()
-    drain()
-    fence()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step spread (device clock)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        marks[i].record()
-        step()
-    drain()
-    marks[args.steps].record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    per_root = ts.logical_value_evals_per_root()
-    evals_per_step = per_root * total_roots
-    value = evals_per_step * args.steps / elapsed
-
-    # ---- multi-GPU: search and exchange timed SEPARATELY (no pipelining), slowest rank, a few steps after the timed region
-    multi = None
-    if dist is not None:
-        n_diag = 10
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_diag)]
-        for i in range(n_diag):
-            fence()
-            ev[i][0].record()
-            h = sharded.launch_local(robot, humans, total_roots)      # search enqueued, all-gather queued behind it
-            ev[i][1].record()                                         # end of this rank's search on the compute stream
-            h.wait()                                                  # compute stream waits for the collective
-            ev[i][2].record()
-        fence()
-        srch = sorted(ev[i][0].elapsed_time(ev[i][1]) for i in range(n_diag))[n_diag // 2]
-        exch = sorted(ev[i][1].elapsed_time(ev[i][2]) for i in range(n_diag))[n_diag // 2]
-        t = torch.tensor([srch, exch], dtype=torch.float64, device=device)
-        tmax, tmin = t.clone(), t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
-        multi = {"search_ms_per_step_slowest_rank": float(tmax[0]), "search_ms_per_step_fastest_rank": float(tmin[0]),
-                 "exchange_ms_per_step_slowest_rank": float(tmax[1]),
-                 "note": "median of %d un-pipelined steps after the timed region; exchange = from the end of the rank's own "
-                         "search to the completion of the all-gather on its stream (includes waiting for slower ranks)" % n_diag,
-                 "roots_per_rank": [rga.shard_bounds(total_roots, world, r)[1] - rga.shard_bounds(total_roots, world, r)[0]
-                                    for r in range(world)] if args.scaling == "strong" else [B] * world}
-
-    # ---- roofline of the dominant kernels (value of the sibling children), HIP events on the launch stream.
-    # Launched straight through the C ABI (prebuilt descriptor, no Python work between launches) on the inputs
-    # the last search left in its workspace, one launch per tree level, in the same mix as inside a step.
+def children_roofline(args, ts, device, N, H, last):
+    """Roofline of the dominant kernels (value of the sibling children), HIP events on the launch stream.  Launched straight
+    through the C ABI (prebuilt descriptor, no Python work between launches) on the inputs the last search left in its
+    workspace, one launch per tree level, in the same mix as inside a step."""
     import ctypes as C
     from relationalgraphlearning_amd import _native as nat
-    A, W = ts.num_actions, ts.kept_per_node
+    if last is not None:
+        ts.last = last
+    A = ts.num_actions
     levels = [ts.level_arrays(l) for l in range(args.depth)]
     outs = [torch.empty(lv["n_parents"], A, device=device) for lv in levels]
     lib = nat.lib()
@@ -380,8 +481,8 @@ def main():
             100.0 * dense / flop_per_scene, F16_MFMA_PEAK_TFLOPS, FP32_PEAK_TFLOPS)
     # HBM bytes per launch from the PMC passes committed under profiles/ (counters cannot be read from inside this process);
     # only quoted for the workload they were measured on, and stamped with the source revision they were measured at -- a
-    # record from another revision of the kernels is stale by construction
-    traffic, traffic_src, traffic_rev = None, None, None
+    # record from another revision of the kernels is stale by construction, and the line says so (`traffic_stale`)
+    traffic, traffic_src, traffic_rev, stale = None, None, None, None
     try:
         import glob
         latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
@@ -389,41 +490,151 @@ def main():
         if (tj["workload"]["N"], tj["workload"]["L"], tj["workload"]["A"]) == (N, args.layers, A):
             traffic, traffic_src = tj["bytes_per_scene"] * scenes_per_launch, tj["source"]
             traffic_rev = tj.get("source_revision", "round 1 (unstamped)")
+            now = kernel_sources_digest()
+            stale = None if tj.get("kernel_sources_sha256") is None else (tj["kernel_sources_sha256"] != now)
     except (OSError, KeyError, ValueError, IndexError):
         pass
+    return {"bound": "mfma", "kernel": "value of sibling children, mprl_value_children_f32: " + kernel_path,
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "peak_note": peak_note,
+            "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes/launch",
+            "traffic_source": traffic_src, "traffic_measured_at_revision": traffic_rev,
+            "traffic_stale": stale,
+            "algorithmic_bytes": scenes_per_launch * (9 * 4 + 4) + scenes_per_launch / A * H * 20,
+            "launch_ms": kern_ms, "scenes_per_launch": scenes_per_launch,
+            "flop_per_scene": flop_per_scene,
+            "reference_flop_per_eval": {(20, 2): 328120, (50, 3): 1337660, (6, 2): 102300}.get((N, args.layers))}
 
+
+def kernel_sources_digest():
+    """sha256 over the HIP sources and headers the library is built from (sorted by name): what `profiles/r*_traffic.json`
+    is stamped with, so that a counter record from another state of the kernels is recognisable without git."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "relationalgraphlearning_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))
+                    + [os.path.join(ROOT, "include", "rgl_hip.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.gpus != world:
+        sys.exit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    dist = None
+    if STUB:
+        device = torch.device("cpu")
+        backend = "gloo"
+    else:
+        assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+        if os.environ.get("RGL_BENCH_SINGLE_DEVICE") == "1":      # world-size-1 RCCL smoke on a one-GPU box
+            local_rank = 0
+        if local_rank >= torch.cuda.device_count():
+            sys.exit("rank %d: --gpus %d needs %d GPUs on this node, found %d" % (rank, args.gpus, args.gpus,
+                                                                                  torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        backend = "nccl"
+    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one process per GPU over RCCL
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if STUB:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=device)
+
+    H, N = args.humans, args.humans + 1
+    if STUB:
+        ts = _StubSearch(args.depth)
+    else:
+        pol = make_policy(args, device)
+        ts = pol.tree_search()
+
+    # which readings: (label, total roots, split one global batch?)
+    if args.scaling == "strong":
+        main_leg = ("strong", args.total_roots if args.total_roots is not None else args.roots, True)
+        extra_leg = None
+    elif args.scaling == "weak" or world == 1:
+        main_leg = ("weak", args.roots * world, False)
+        extra_leg = None
+    else:                                             # both, N > 1: fixed total is `value` (SURVEY 8d), per-GPU fixed rides along
+        main_leg = ("strong", args.roots, True)
+        extra_leg = ("weak", args.roots * world, False)
+
+    # Host hygiene: a generation-2 pass of CPython's cyclic GC over the heap torch leaves behind takes ~40 ms (measured:
+    # it landed inside the timed region and starved the GPU for 60 steps' worth of time).  Freeze the set-up objects so
+    # later collections only look at what the steps themselves allocate.
+    import gc
+    INIT_STEPS = 3      # set-up, not warm-up: the first calls load the code objects, size the workspace and (N > 1) open the RCCL channels
+    leg = Leg(args, ts, device, world, rank, main_leg[1], main_leg[2], dist)
+    gc.collect()
+    gc.freeze()
+    elapsed, step_ms = leg.timed(args.steps, args.warmup, INIT_STEPS)
+    per_root = ts.logical_value_evals_per_root()
+    total_roots, B = leg.total_roots, leg.B
+    value = per_root * total_roots * args.steps / elapsed
+    multi = leg.diagnose() if dist is not None else None
+
+    weak = None
+    if extra_leg is not None:
+        leg2 = Leg(args, ts, device, world, rank, extra_leg[1], extra_leg[2], dist)
+        e2, s2 = leg2.timed(args.steps, args.warmup, INIT_STEPS)
+        weak = {"weak_value": per_root * leg2.total_roots * args.steps / e2, "weak_ms_per_step": e2 / args.steps * 1e3,
+                "weak_total_roots": leg2.total_roots, "weak_roots_per_gpu": leg2.B,
+                "weak_step_ms_device_median": s2[len(s2) // 2], "weak_graph_replay": bool(leg2.graphs),
+                "weak_multi_gpu": leg2.diagnose()}
+        del leg2
+
+    A, W = ts.num_actions, ts.kept_per_node
+    roofline = None
+    if not STUB and B > 0:
+        if not leg.graphs:                                   # leave the main leg's levels in the shared workspace
+            ts.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
+        roofline = children_roofline(args, ts, device, N, H, leg.graph_last)
+
+    metric = "agent-graph forward evals/sec (N=%d, %d-layer GCN, depth-%d tree)" % (N, args.layers, args.depth)
     result = {
-        "metric": "agent-graph forward evals/sec (N=%d, %d-layer GCN, depth-%d tree)" % (N, args.layers, args.depth),
+        "metric": ("STUB SEARCH, NOT A MEASUREMENT: " if STUB else "") + metric,
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": main_leg[0],
         "step_ms_device": {"p10": step_ms[len(step_ms) // 10], "median": step_ms[len(step_ms) // 2],
                            "p90": step_ms[(len(step_ms) * 9) // 10], "note": "rank 0, HIP events between steps"},
         "vs_baseline": None, "dtype": "f32" if args.contraction == "f32" else "f16 inputs / f32 accumulate (middle-layer "
         "products only; everything else f32)", "data": "synthetic",
         "config": {"workload": "%s: N=%d agents (H=%d humans), %d-layer GCN, depth-%d width-%d "
-                               "action-tree rollout, %s" % (workload_name(N, args), N, H, args.layers, args.depth, args.width,
-                                                            ("%d root scenes per GPU" % B) if args.scaling == "weak" else
+                               "action-tree rollout, %s" % (workload_name(N, args, main_leg[0]), N, H, args.layers, args.depth, args.width,
+                                                            ("%d root scenes per GPU" % B) if main_leg[0] == "weak" else
                                                             ("%d root scenes in total over %d GPU(s)" % (total_roots, world))),
                    "roots_per_gpu": B, "total_roots": total_roots, "logical_value_evals_per_root": per_root, "init_steps": INIT_STEPS,
                    "executed_graph_forwards_per_root": sum(W ** l for l in range(args.depth)) * (A + 1),
                    "decisions_per_s": total_roots * args.steps / elapsed,
                    "weights": "fixture F1 trained-like (tests/golden/weights_trained.npz)",
+                   "scenes": "human placement: " + args.scenes,
+                   "graph_replay": bool(leg.graphs),
                    "exchange": "all_gather_into_tensor of (roots_per_gpu,2) fp32 per rank" if world > 1 else "none"},
-        "roofline": {"bound": "mfma", "kernel": "value of sibling children, mprl_value_children_f32: " + kernel_path,
-                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "peak_note": peak_note,
-                     "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes/launch",
-                     "traffic_source": traffic_src, "traffic_measured_at_revision": traffic_rev, "algorithmic_bytes": scenes_per_launch * (9 * 4 + 4) + scenes_per_launch / A * H * 20,
-                     "launch_ms": kern_ms, "scenes_per_launch": scenes_per_launch,
-                     "flop_per_scene": flop_per_scene, "reference_flop_per_eval": {(20, 2): 328120, (50, 3): 1337660, (6, 2): 102300}.get((N, args.layers))},
+        "roofline": roofline,
     }
+    if STUB:
+        result["stub_search"] = True
+    if weak is not None:
+        result.update(weak)
     if multi is not None:
         result["multi_gpu"] = multi
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        result["cpu_baseline"] = cpu_baseline(args, robot_cpu, humans_cpu, args.cpu_seconds)
+        result["ranks_seen"] = multi["ranks_seen"]
+    if rank == 0 and world == 1 and args.cpu_seconds > 0 and not STUB:
+        result["cpu_baseline"] = cpu_baseline(args, leg.robot_cpu, leg.humans_cpu, args.cpu_seconds)
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

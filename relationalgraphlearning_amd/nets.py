@@ -9,6 +9,7 @@ value_estimator.py:5-20 (`ValueEstimator`), state_predictor.py:7-118 (`StatePred
 library or a request for gradients raise -- there is no eager/CPU fallback to hide behind.
 """
 import ctypes as C
+import itertools
 
 import torch
 import torch.nn as nn
@@ -173,6 +174,9 @@ class _GraphCore(nn.Module):
         return g
 
 
+_PACK_SERIAL = itertools.count(1)   # process-wide: a pack serial is never shared by two caches or two parameter states
+
+
 class _PackCache:
     """Descriptor cache keyed on (storage pointer, version) of every parameter involved."""
 
@@ -181,7 +185,8 @@ class _PackCache:
         self.value = None
         self.keep = None
         self.buffers = {}         # transposed Linear weights, refreshed IN PLACE when parameters change (stable device pointers)
-        self.epoch = 0            # number of (re)packs: lets dependants (TreeSearch's weight image) notice a refresh
+        self.epoch = 0            # serial of the latest (re)pack, unique in the process: dependants (TreeSearch's weight image)
+                                  # compare it to notice a refresh -- or another module put in this one's place
 
     def get(self, modules, build):
         key = tuple((p.data_ptr(), p._version, p.device.index) for m in modules for p in m.parameters())
@@ -190,7 +195,7 @@ class _PackCache:
             self.value = build(keep, self.buffers)
             self.keep = keep
             self.key = key
-            self.epoch += 1
+            self.epoch = next(_PACK_SERIAL)
         return self.value
 
     # The cache holds ctypes descriptor structs (raw device pointers), which can be neither copied nor pickled and

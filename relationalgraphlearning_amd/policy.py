@@ -240,7 +240,8 @@ class ModelPredictiveRL(Policy):
     def tree_search(self):
         """The device search object for the current configuration (rebuilt when settings change)."""
         key = (self.planning_depth, self.planning_width, bool(self.do_action_clip), bool(self.sparse_search),
-               self.kinematics, self.time_step, self.gamma, id(self.state_predictor), self.contraction_dtype)
+               self.kinematics, self.time_step, self.gamma, id(self.state_predictor), id(self.value_estimator),
+               self.contraction_dtype)
         if self._search is None or self._search[0] != key:
             if self.action_space is None:
                 self.build_action_space(self.v_pref)
@@ -437,7 +438,7 @@ class GCN(Policy):
         v = self.model(rotate(joint, self.kinematics).reshape(A, H, 13))             # leaves .A at the last action, like upstream
         disc = pow(self.gamma, dt * float(robot[7]))
         vals = (reward.double() + disc * v[:, 0].double()).float().reshape(1, A)
-        return vals, vals.argmax(dim=1).int()
+        return vals, _first_strict_maximum(vals)
 
     def _refresh_adjacency(self, robot, humans):
         last = self.action_space[-1]
@@ -461,6 +462,17 @@ class GCN(Policy):
         robot, humans = _state_rows(state)
         joint = torch.tensor([robot + h for h in humans], dtype=torch.float32, device=self.device)
         return rotate(joint, self.kinematics)
+
+
+def _first_strict_maximum(vals):
+    """Index of the FIRST maximum of every row, -1 when no value beats -inf (all NaN / -inf): the strict `>` walk of
+    multi_human_rl.py:38-64 that leaves max_action None ("Value network is not well trained"), as gcn_argmax_kernel and
+    mprl_root_kernel do it.  torch.argmax guarantees neither the first index on ties nor a refusal of NaN rows."""
+    clean = torch.where(torch.isnan(vals), torch.full_like(vals, float("-inf")), vals)
+    m = clean.max(dim=1, keepdim=True).values
+    cols = torch.arange(vals.shape[1], device=vals.device).expand_as(vals)
+    first = torch.where(clean == m, cols, torch.full_like(cols, vals.shape[1])).min(dim=1).values
+    return torch.where(m[:, 0] > float("-inf"), first, torch.full_like(first, -1)).int()
 
 
 def register(policy_factory):

@@ -16,6 +16,16 @@ from . import _native as nat
 from .nets import _require_device_tensor, _stream
 
 
+def _check_roots64(roots64, B, H):
+    """The float64 JointStates the fp32 roots were rounded from: contiguous float64 device tensors (B,9) / (B,H,5)."""
+    r64, h64 = roots64
+    if not (torch.is_tensor(r64) and torch.is_tensor(h64) and r64.dtype == torch.float64 and h64.dtype == torch.float64
+            and r64.is_cuda and h64.is_cuda and r64.is_contiguous() and h64.is_contiguous()
+            and tuple(r64.shape) == (B, 9) and tuple(h64.shape) == (B, H, 5)):
+        raise ValueError("roots64 must be contiguous float64 device tensors (B,9) / (B,H,5)")
+    return r64, h64
+
+
 class _Workspace:
     def __init__(self):
         self.buf = None
@@ -115,7 +125,7 @@ class TreeSearch:
         image-based kernel."""
         ve = self.value_estimator
         gcache, hcache = ve.graph_model._cache, ve._cache
-        key = (id(gcache), gcache.epoch, id(hcache), hcache.epoch)
+        key = (gcache.epoch, hcache.epoch)        # process-wide pack serials (nets._PACK_SERIAL): identify the parameter state
         dkey = str(device)
         ent = self._images.get(dkey)
         if ent is not None and ent[0] == key:
@@ -145,11 +155,7 @@ class TreeSearch:
         with torch.cuda.device(dev):
             pl = self.planner(dev)
             if roots64 is not None:
-                r64, h64 = roots64
-                if not (r64.dtype == torch.float64 and h64.dtype == torch.float64 and r64.is_cuda and h64.is_cuda
-                        and r64.is_contiguous() and h64.is_contiguous() and tuple(r64.shape) == (B, 9)
-                        and tuple(h64.shape) == (B, H, 5)):
-                    raise ValueError("roots64 must be contiguous float64 device tensors (B,9) / (B,H,5)")
+                r64, h64 = _check_roots64(roots64, B, H)
                 pl.root_robot_f64, pl.root_humans_f64 = r64.data_ptr(), h64.data_ptr()
             lib = nat.lib()
             nbytes = lib.mprl_tree_workspace_bytes(C.byref(pl), B, H)
@@ -227,19 +233,28 @@ class TreeSearch:
             self._ws = shared_ws
         return {"graph": graph, "host64": host64, "dev64": dev64, "robot": robot, "humans": humans, "last": last}
 
-    def capture(self, robot, humans, roots_are_joint_states=True):
+    def capture(self, robot, humans, roots_are_joint_states=True, want_root_values=True, out=None, private_workspace=False):
         """Capture one whole search into a hipGraph (torch.cuda.CUDAGraph).  Returns (graph, outputs): copy new root
         states into `robot` / `humans` in place, call graph.replay(), read `outputs` -- no Python or launch overhead
         per decision.  The library allocates nothing and never synchronises, which is what makes this legal.
         The graph bakes device pointers: parameters may change IN PLACE (their transposed copies are refreshed in place by
         the next `planner()` / `search()` call -- call one of them before replaying after an optimizer step), but a parameter
-        moved to new storage needs a new capture (`decide()` does both checks itself)."""
-        self.search(robot, humans, roots_are_joint_states)          # warm-up: workspace, descriptors, function attributes
-        torch.cuda.synchronize(robot.device)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = self.search(robot, humans, roots_are_joint_states)
-        return graph, out
+        moved to new storage needs a new capture (`decide()` does both checks itself).  The workspace pointer is baked too:
+        with `private_workspace` the graph owns its workspace (returned as outputs["workspace"]), so later searches of other
+        sizes through this object cannot free it underneath the graph; `out` as in `search()`."""
+        shared_ws = self._ws
+        if private_workspace:
+            self._ws = _Workspace()
+        try:
+            self.search(robot, humans, roots_are_joint_states, want_root_values, out=out)   # warm-up: workspace, descriptors
+            torch.cuda.synchronize(robot.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                res = self.search(robot, humans, roots_are_joint_states, want_root_values, out=out)
+            res = dict(res, workspace=self._ws.buf, last=self.last)
+        finally:
+            self._ws = shared_ws
+        return graph, res
 
     def expand(self, robot, humans, parents_are_joint_states=True):
         """One tree level for P parents (what `action_clip` evaluates); all outputs device tensors."""
@@ -355,7 +370,8 @@ class GcnSearch:
             pl.gamma = self.gamma
             pl.actions = self._dev_tables[key].data_ptr()
             if roots64 is not None:
-                pl.root_robot_f64, pl.root_humans_f64 = roots64[0].data_ptr(), roots64[1].data_ptr()
+                r64, h64 = _check_roots64(roots64, B, H)
+                pl.root_robot_f64, pl.root_humans_f64 = r64.data_ptr(), h64.data_ptr()
             lib = nat.lib()
             ws = self._ws.get(lib.gcn_predict_workspace_bytes(B, H, A), dev)
             vals = torch.empty(B, A, dtype=torch.float32, device=dev)
@@ -405,13 +421,30 @@ class ShardedRollout:
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.active else 1
         self.rank = dist.get_rank(group) if self.active else 0
+        self._static = None
+
+    def use_static_buffers(self, total, device, depth=2):
+        """Pre-allocate `depth` exchange buffers for steps of `total` roots and hand them out in turn, instead of a fresh
+        buffer per step: a search captured in a hipGraph writes its results to FIXED addresses, so a pipelined loop (one
+        exchange in flight under the next search) needs the buffers to exist before the capture.  Returns the list of
+        (act_out (n,) int32, val_out (n,) fp32) views this rank's search must fill, in the order of use."""
+        per = -(-total // self.world)
+        lo, hi = shard_bounds(total, self.world, self.rank)
+        n = hi - lo
+        packed = [torch.zeros(2, per, dtype=torch.float32, device=device) for _ in range(depth)]
+        gathered = [torch.empty(self.world * 2, per, dtype=torch.float32, device=device) for _ in range(depth)]
+        self._static = {"total": total, "packed": packed, "gathered": gathered, "turn": 0}
+        return [(p[0, :n].view(torch.int32), p[1, :n]) for p in packed]
 
     def run(self, robot, humans):
         """robot (B,9), humans (B,H,5): the FULL root batch (identical on every rank).
-        Returns (best_action (B,) int32, best_value (B,) fp32) on the device of the inputs (index with `.long()` where torch wants int64)."""
+        Returns (best_action (B,) int64, best_value (B,) fp32) on the device of the inputs.  This convenience entry converts the
+        indices once to torch's index type (gather / fancy indexing want int64); `run_local` / `launch_local` keep the search's
+        own int32 indices, which is what travels through the exchange."""
         B = robot.shape[0]
         lo, hi = shard_bounds(B, self.world, self.rank)
-        return self.run_local(robot[lo:hi], humans[lo:hi], B)
+        act, val = self.run_local(robot[lo:hi], humans[lo:hi], B)
+        return act.long(), val
 
     def run_local(self, robot_shard, humans_shard, total):
         """Same, when each rank already holds only its shard (`total` = global root count)."""
@@ -430,9 +463,15 @@ class ShardedRollout:
             act, val = self.search_fn(robot_shard, humans_shard)
             return _Exchange(None, None, total, 1, (act, val))          # the search's own int32 indices: no conversion kernel
         # exchange buffer: row 0 = action indices (int32 bit patterns), row 1 = values
-        packed = torch.empty(2, per, dtype=torch.float32, device=robot_shard.device)
-        if n < per:
-            packed[:, n:].zero_()
+        st = self._static if self._static is not None and self._static["total"] == total else None
+        if st is not None:
+            turn = st["turn"]
+            st["turn"] = (turn + 1) % len(st["packed"])
+            packed = st["packed"][turn]                      # tail beyond n stays zero from allocation
+        else:
+            packed = torch.empty(2, per, dtype=torch.float32, device=robot_shard.device)
+            if n < per:
+                packed[:, n:].zero_()
         if n > 0:
             act_out, val_out = packed[0, :n].view(torch.int32), packed[1, :n]
             if self.search_into is not None:
@@ -441,7 +480,8 @@ class ShardedRollout:
                 act, val = self.search_fn(robot_shard, humans_shard)
                 act_out.copy_(act)
                 val_out.copy_(val)
-        gathered = torch.empty(self.world * 2, per, dtype=torch.float32, device=packed.device)   # rank-major concatenation
+        gathered = st["gathered"][turn] if st is not None else \
+            torch.empty(self.world * 2, per, dtype=torch.float32, device=packed.device)           # rank-major concatenation
         work = self.dist.all_gather_into_tensor(gathered, packed, group=self.group, async_op=True)
         return _Exchange(work, gathered, total, self.world, None, keep=packed)
 

@@ -1,0 +1,80 @@
+"""bench.py's own launcher and its multi-rank bookkeeping, end to end on CPU.
+
+`python bench.py --gpus 2` (no torch.distributed.run environment) must start its two ranks itself, shard the roots, run the
+pipelined exchange and print ONE JSON line from rank 0 carrying both scaling readings.  The device search
+is replaced by bench.py's stub (RGL_BENCH_STUB_SEARCH=1: gloo, CPU tensors, no kernels) -- this covers the launcher, not the
+path; the line it prints is marked as not being a measurement."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, extra_env=None, launcher=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RGL_BENCH_STUB_SEARCH="1", OMP_NUM_THREADS="1")
+    env.update(extra_env or {})
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + argv
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-3000:] + out.stderr[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks_and_reports_both_readings():
+    r = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--roots", "11"])
+    assert r["stub_search"] is True and r["metric"].startswith("STUB SEARCH")
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["steps"] == 4 and r["warmup"] == 1
+    # `value`: the fixed-total reading -- 11 roots split 6 + 5
+    assert r["scaling"] == "strong" and r["config"]["total_roots"] == 11 and r["config"]["roots_per_gpu"] == 6
+    assert r["multi_gpu"]["roots_per_rank"] == [6, 5]
+    assert len(r["multi_gpu"]["search_ms_per_step_by_rank"]) == 2 and len(r["multi_gpu"]["exchange_ms_per_step_by_rank"]) == 2
+    assert abs(r["value"] - 249 * 11 * 4 / (r["ms_per_step"] * 4e-3)) < 1e-6 * r["value"]
+    # ... and the per-GPU-fixed reading from the same invocation
+    assert r["weak_total_roots"] == 22 and r["weak_roots_per_gpu"] == 11 and r["weak_value"] > 0
+    assert r["weak_multi_gpu"]["roots_per_rank"] == [11, 11] and r["weak_multi_gpu"]["ranks_seen"] == 2
+    assert r["cpu_baseline"] is None and r["roofline"] is None
+
+
+def test_single_rank_line_keeps_its_shape():
+    r = _run(["--steps", "3", "--warmup", "1", "--roots", "7"])
+    assert r["n_gpus"] == 1 and r["scaling"] == "weak" and r["config"]["total_roots"] == 7 and "weak_value" not in r
+    assert "multi_gpu" not in r and "ranks_seen" not in r
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "step_ms_device", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in r, key
+
+
+def test_the_drivers_torchrun_command_gives_the_same_multi_rank_line():
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", "29541"]
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--roots", "8", "--scaling", "strong", "--total-roots", "9"],
+             launcher=launcher)
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["multi_gpu"]["roots_per_rank"] == [5, 4] and "weak_value" not in r
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--roots", "8", "--scaling", "weak"], launcher=launcher)
+    assert r["scaling"] == "weak" and r["config"]["total_roots"] == 16 and r["multi_gpu"]["roots_per_rank"] == [8, 8]
+
+
+def test_gpu_count_mismatch_is_an_error_not_a_silent_single_rank_run():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(RGL_BENCH_STUB_SEARCH="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29542")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "--gpus 4" in (out.stderr + out.stdout)
+
+
+def test_clearance_scenes():
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    robot, humans = bench.synth_scenes(1000, 64, 19)
+    p = humans[:, :, :2].numpy().astype(np.float64)
+    d = np.linalg.norm(p[:, :, None] - p[:, None], axis=3) + np.eye(19) * 99
+    assert d.min() >= bench.CLEARANCE - 1e-6
+    assert np.linalg.norm(p - robot[:, None, :2].numpy(), axis=2).min() >= bench.CLEARANCE - 1e-6
+    r2, h2 = bench.synth_scenes(1000, 64, 19)
+    assert (r2 == robot).all() and (h2 == humans).all()                       # seeded
+    r3, h3 = bench.synth_scenes(1000, 64, 19, "uniform")                      # the round-1/2 generator: same robots
+    assert (r3 == robot).all() and not (h3 == humans).all()

@@ -41,7 +41,8 @@ def _worker(rank, world, port, total, out_dir):
         return a, v
     sr = ShardedRollout(search)
     act, val = sr.run(robot, humans)
-    assert act.dtype == torch.int32 and val.dtype == torch.float32        # the search's own index type, no conversion kernel
+    assert act.dtype == torch.int64 and val.dtype == torch.float32        # run(): torch's index type
+    act = act.int()                                                       # launch_local / run_local: the search's own int32
     # pipelined use (bench.py): two steps in flight, results collected one step late
     from relationalgraphlearning_amd import shard_bounds
     lo, hi = shard_bounds(total, world, rank)
@@ -67,6 +68,22 @@ def _worker(rank, world, port, total, out_dir):
     hx = sr2.launch_local(robot[lo:hi], humans[lo:hi], total).wait()
     ax, vx = hx.result()
     assert torch.equal(ax, act) and torch.equal(vx, val)
+    # static exchange buffers (what a hipGraph-captured search needs): fixed addresses handed out in turn, same results
+    sr3 = ShardedRollout(search, search_into=search_into)
+    views = sr3.use_static_buffers(total, robot.device)
+    seen = []
+
+    def search_into_static(r, h, act_out, val_out):
+        seen.append(act_out.data_ptr())
+        search_into(r, h, act_out, val_out)
+    sr3.search_into = search_into_static
+    hs = [sr3.launch_local(robot[lo:hi], humans[lo:hi], total) for _ in range(3)]
+    for hnd in hs[:2]:
+        hnd.wait()
+    for hnd in hs[2:]:
+        ay, vy = hnd.result()
+        assert torch.equal(ay, act) and torch.equal(vy, val)
+    assert seen == [views[0][0].data_ptr(), views[1][0].data_ptr(), views[0][0].data_ptr()]
     del calls[1:]
     torch.save({"act": act, "val": val, "calls": calls}, os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
