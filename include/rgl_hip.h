@@ -213,7 +213,9 @@ typedef struct MprlPlanner {
     double time_step;
     double gamma_bar;           /* gamma^(time_step * v_pref), get_normalized_gamma (:104-105)  */
     const double* actions;      /* device [A][2] float64, table of build_action_space (:155-190)*/
-    const int* action_groups;   /* device [A], action_group_index (sparse search); may be NULL  */
+    const int* action_groups;   /* device [A], action_group_index (sparse search); may be NULL.  Any int32 ids: the
+                                 * kernel compares ids (no range to validate); a sparse search supports planning_width
+                                 * <= 16, wider requests return RGL_ERR_BAD_MODE                                  */
     /* optional (NULL = absent): the float64 JointStates robot[B][9] / humans[B][H][5] that the fp32 ROOT arrays were
      * rounded from.  When set and the roots are joint states, estimate_reward of the ROOT level reads them: the reference
      * evaluates it on the simulator's python floats (model_predictive_rl.py:226,304-357) while the networks see the

@@ -645,3 +645,64 @@ def gcn_predict_sequential(robot9, humans, sd, cfg):
         if val > best_v:
             best_v, best = val, ai
     return best, vals
+
+
+def gcn_predict_batched(robot, humans, sd, cfg, chunk=4096):
+    """Batched restatement of gcn_predict_sequential (the loop of multi_human_rl.py:36-64 for B root scenes at once).
+    robot (B,9), humans (B,H,5): arrays / tensors of the ROOT states (float32 values as the fixtures hold them; all arithmetic
+    of propagate / compute_reward in float64 like the python floats of the sequential walk, the joint rows rounded to float32
+    exactly where it builds its tensor).  Returns (best action (B,) int64, action_values (B,A) float64).
+    Pinned against fixture F7 (`path_g.npz`) in tests/test_oracle_golden.py next to the sequential form."""
+    robot = np.asarray(robot, dtype=np.float64)
+    humans = np.asarray(humans, dtype=np.float64)
+    B, H = humans.shape[0], humans.shape[1]
+    dt = cfg.time_step
+    # the action table depends on v_pref (robot[7]); scenes are grouped by it (the benchmarks and fixtures use one value)
+    out_vals, out_best = None, np.zeros(B, dtype=np.int64)
+    for vp in np.unique(robot[:, 7]):
+        sel = np.nonzero(robot[:, 7] == vp)[0]
+        actions = np.asarray(cadrl_action_space(cfg, float(vp)), dtype=np.float64)              # (A,2)
+        A = actions.shape[0]
+        r = robot[sel]                                                                          # (b,9)
+        nr = np.repeat(r[:, None, :], A, axis=1)                                                # (b,A,9)
+        if cfg.kinematics == "holonomic":
+            nr[:, :, 0] = r[:, None, 0] + actions[None, :, 0] * dt
+            nr[:, :, 1] = r[:, None, 1] + actions[None, :, 1] * dt
+            nr[:, :, 2] = actions[None, :, 0]
+            nr[:, :, 3] = actions[None, :, 1]
+        else:
+            th = r[:, None, 8] + actions[None, :, 1]
+            nr[:, :, 2] = actions[None, :, 0] * np.cos(th)
+            nr[:, :, 3] = actions[None, :, 0] * np.sin(th)
+            nr[:, :, 0] = r[:, None, 0] + nr[:, :, 2] * dt
+            nr[:, :, 1] = r[:, None, 1] + nr[:, :, 3] * dt
+            nr[:, :, 8] = th
+        h = humans[sel]
+        nh = h.copy()
+        nh[:, :, 0] = h[:, :, 0] + h[:, :, 2] * dt
+        nh[:, :, 1] = h[:, :, 1] + h[:, :, 3] * dt
+        # compute_reward (multi_human_rl.py:73-96): END-point clearance; a collision with ANY human wins (the sequential walk
+        # breaks at the first one, which gives the same reward), dmin over all humans otherwise
+        dx = nr[:, :, None, 0] - nh[:, None, :, 0]
+        dy = nr[:, :, None, 1] - nh[:, None, :, 1]
+        clear = np.sqrt(dx * dx + dy * dy) - nr[:, :, None, 4] - nh[:, None, :, 4]               # (b,A,H)
+        collision = (clear < 0).any(axis=2)
+        dmin = clear.min(axis=2)
+        reaching = np.sqrt((nr[:, :, 0] - nr[:, :, 5]) ** 2 + (nr[:, :, 1] - nr[:, :, 6]) ** 2) < nr[:, :, 4]
+        rew = np.where(collision, -0.25, np.where(reaching, 1.0, np.where(dmin < 0.2, (dmin - 0.2) * 0.5 * dt, 0.0)))
+        joint = np.concatenate([np.repeat(nr[:, :, None, :], H, axis=2),
+                                np.repeat(nh[:, None, :, :], A, axis=1)], axis=3).astype(np.float32)   # (b,A,H,14)
+        joint = torch.tensor(joint.reshape(-1, 14))
+        v = np.zeros(len(sel) * A)
+        with torch.no_grad():
+            for lo in range(0, len(sel) * A, chunk):
+                hi = min(len(sel) * A, lo + chunk)
+                rot = rotate_pairwise(joint[lo * H:hi * H], cfg.kinematics).reshape(hi - lo, H, 13)
+                v[lo:hi] = gcn_value_forward(rot, sd, cfg)[0][:, 0].double().numpy()
+        gam = pow(cfg.gamma, dt * float(vp))
+        val = rew + gam * v.reshape(len(sel), A)
+        if out_vals is None:
+            out_vals = np.zeros((B, A))
+        out_vals[sel] = val
+        out_best[sel] = np.argmax(val, axis=1)          # first maximum, like the strict '>' walk
+    return out_best, out_vals

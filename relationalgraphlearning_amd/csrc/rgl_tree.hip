@@ -45,6 +45,8 @@ __global__ void gather_parent_humans_kernel(const float* __restrict__ humans, in
     out[i] = humans[(p / humans_per) * H * 5 + rest];
 }
 
+constexpr int kMaxSparseWidth = 16;     // sparse (one action per group) searches: widest clipping the select kernel supports
+
 __device__ __forceinline__ int bi_fallback(const int* kl, int k) { return k > 0 ? kl[k - 1] : 0; }
 
 // One WAVE per parent: one-step values, top-w clipping (argpartition semantics; sparse: one action per group in
@@ -82,7 +84,10 @@ __global__ __launch_bounds__(256) void mprl_select_kernel(const float* __restric
     if (!clip) {
         for (int a = lane; a < A; a += 64) { kp[a] = a; kl[a] = a; }
     } else {
-        unsigned long long seen_groups = 0ull;          // sparse search: <= 64 groups (wave-uniform)
+        // sparse search: one action per group.  The groups taken so far are kept BY ID (any int32, as in the reference's python
+        // set, model_predictive_rl.py:252-263) -- the width of a sparse search is at most kMaxSparseWidth (checked by the entry
+        // point), so the set is a handful of wave-uniform registers and no id range has to be imposed on the caller.
+        int seen[kMaxSparseWidth];
         int nkept = 0;
         while (nkept < W) {
             // lane-local best: larger value first, then lower index; a NaN is only taken when nothing else is left
@@ -113,10 +118,14 @@ __global__ __launch_bounds__(256) void mprl_select_kernel(const float* __restric
             for (int k = 0; k < 4; ++k)
                 if (lane + 64 * k == bi) avail[k] = false;
             if (sparse) {
-                const int gi = groups[bi] & 63;         // ids are validated to [0, 64) by the host wrapper (TreeSearch); masked so
-                                                        // that a stray id through the raw ABI cannot shift out of range
-                if (seen_groups & (1ull << gi)) continue;
-                seen_groups |= 1ull << gi;
+                const int gi = groups[bi];
+                bool dup = false;
+#pragma unroll
+                for (int k = 0; k < kMaxSparseWidth; ++k) dup = dup || (k < nkept && seen[k] == gi);
+                if (dup) continue;
+#pragma unroll
+                for (int k = 0; k < kMaxSparseWidth; ++k)
+                    if (k == nkept) seen[k] = gi;
             }
             if (lane == 0) { kp[nkept] = bi; kl[nkept] = bi; }
             ++nkept;
@@ -574,8 +583,8 @@ extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* rob
     const int A = pl.num_actions, D = pl.planning_depth;
     const int W = pl.do_action_clip ? pl.planning_width : A;
     if (pl.do_action_clip && pl.sparse_search) {
-        // the grouped walk can only ever keep one action per group: refuse widths it cannot fill
-        if (W > 16) return RGL_ERR_BAD_MODE;
+        // the select kernel keeps the ids of the groups taken so far in kMaxSparseWidth registers
+        if (W > kMaxSparseWidth) return RGL_ERR_BAD_MODE;
     }
     LevelLayout lv[8];
     long long total = 0, scratch_off = 0, scratch_bytes = 0;

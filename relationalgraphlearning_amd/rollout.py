@@ -46,8 +46,7 @@ class TreeSearch:
         self.state_predictor = state_predictor            # StatePredictor module or LinearStatePredictor
         self.actions_np = np.ascontiguousarray(np.asarray(actions, dtype=np.float64))
         self.groups_np = None if action_groups is None else np.asarray(action_groups, dtype=np.int32)
-        if self.groups_np is not None and self.groups_np.size and (self.groups_np.min() < 0 or self.groups_np.max() > 63):
-            raise ValueError("action group ids must lie in [0, 64): the sparse search keeps them in a 64-bit set")
+        # group ids are arbitrary int32 values, as in the reference's python set (the select kernel compares ids, round 3)
         self.kinematics = kinematics
         self.time_step = float(time_step)
         self.gamma_bar = float(gamma_bar)

@@ -820,6 +820,47 @@ def gen_trainer_kats(masters, out):
     policy_config(gcn__skip_connection=True)                     # restore the class-level config attribute
 
 
+def gen_vnrl_trainer_kats(pg_fixture, out):
+    """The reference VNRLTrainer.optimize_batch (crowd_nav/utils/trainer.py:199-250; path G's trainer) on the reference
+    gcn.ValueNetwork with the weights of fixture path_g.npz: three un-shuffled batches of 16 seeded transitions
+    (rotated states (5,13), reward, next rotated states), Adam 1e-3, frozen target copy, the reference's own pad_batch collate.
+    gcn.ValueNetwork adds its skip connections out of place, so the shipped skip_connection=True configuration trains."""
+    from crowd_nav.utils.trainer import VNRLTrainer, pad_batch
+    from crowd_nav.utils.memory import ReplayMemory
+    from torch.utils.data import DataLoader
+
+    class Writer(object):
+        def add_scalar(self, *a, **k):
+            pass
+    rng = np.random.RandomState(41)
+    n = 48
+    states = rng.uniform(-2, 2, (n, 5, 13)).astype(np.float32)
+    next_states = rng.uniform(-2, 2, (n, 5, 13)).astype(np.float32)
+    rewards = rng.uniform(-0.25, 1.0, (n,)).astype(np.float32)
+    out["vn.states"], out["vn.next_states"], out["vn.rewards"] = states, next_states, rewards
+    meta = []
+    for tag, L, lw, sk in (("shipped", 2, False, True), ("layerwise_noskip", 2, True, False)):
+        pc = policy_config("rgl", gcn__num_layer=L, gcn__layerwise_graph=lw, gcn__skip_connection=sk)
+        pol = policy_factory["gcn"]()
+        pol.configure(pc)
+        pol.model.load_state_dict({k[len("g.weights."):]: torch.tensor(v) for k, v in pg_fixture.items()
+                                   if k.startswith("g.weights.")})
+        memory = ReplayMemory(1000)
+        for i in range(n):
+            memory.push((torch.tensor(states[i]), torch.zeros(1), torch.tensor(rewards[i:i + 1]), torch.tensor(next_states[i])))
+        tr = VNRLTrainer(pol.model, memory, torch.device("cpu"), pol, 16, "Adam", Writer())
+        tr.set_learning_rate(1e-3)
+        tr.update_target_model(pol.model)
+        tr.data_loader = DataLoader(memory, 16, shuffle=False, collate_fn=pad_batch)
+        with torch.enable_grad():
+            loss = tr.optimize_batch(2, 0)                       # batch_count > num_batches: three batches are consumed
+        out["vn.%s.loss" % tag] = np.array([loss], np.float64)
+        out.update(flat("vn.%s.model." % tag, pol.model.state_dict()))
+        meta.append("%s|%d|%d|%d" % (tag, L, int(lw), int(sk)))
+    out["vnrl_cases"] = np.array(meta)
+    policy_config("rgl", gcn__num_layer=2, gcn__layerwise_graph=False, gcn__skip_connection=True)
+
+
 def gen_query_env_kats(pg_fixture, out):
     """Path G with query_env=True (multi_human_rl.py:43-44) on the reference simulator with `linear` humans: per action the next
     human states and the reward come from env.onestep_lookahead.  States a few steps into seeded test cases; recorded: the full
@@ -916,6 +957,9 @@ def main():
     gen_trainer_kats(masters, tq)
     gen_query_env_kats(pg, tq)
     np.savez(os.path.join(HERE, "training_queryenv.npz"), **tq)
+    vt = {}
+    gen_vnrl_trainer_kats(pg, vt)
+    np.savez(os.path.join(HERE, "vnrl_trainer.npz"), **vt)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-24s %8.1f KB" % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))

@@ -191,6 +191,58 @@ def test_path_g_predict():
         close(np.array(vals), g["g.pred_action_values"][b], 2e-6)
 
 
+def test_path_g_predict_batched_restatement():
+    """The batched form the at-size GPU tests compare with: pinned against the reference's own outputs (fixture
+    F7) and against the sequential restatement, holonomic and unicycle."""
+    g = gio.load("path_g")
+    sd = gio.path_g_sd()
+    best, vals = orc.gcn_predict_batched(g["g.pred_robot"], g["g.pred_humans"], sd, orc.OracleConfig())
+    assert np.array_equal(best, g["g.pred_action"].astype(np.int64))
+    close(vals, g["g.pred_action_values"], 2e-6)
+    cfg_u = orc.OracleConfig(kinematics="unicycle")
+    rng = np.random.RandomState(3)
+    robot = g["g.pred_robot"].astype(np.float64).copy()
+    humans = np.concatenate([g["g.pred_humans"], g["g.pred_humans"] + rng.uniform(-0.5, 0.5, g["g.pred_humans"].shape)], axis=1)
+    humans[:, :, 4] = 0.3
+    for cfg in (orc.OracleConfig(), cfg_u):
+        bb, bv = orc.gcn_predict_batched(robot, humans, sd, cfg, chunk=100)
+        for b in range(robot.shape[0]):
+            a, v = orc.gcn_predict_sequential([float(x) for x in robot[b]], [[float(x) for x in row] for row in humans[b]], sd, cfg)
+            assert a == int(bb[b])
+            close(bv[b], np.array(v), 2e-6)
+
+
+def test_vnrl_trainer_fixture_with_autograd_on_the_oracle():
+    """Fixture vnrl_trainer.npz (the reference VNRLTrainer.optimize_batch, trainer.py:199-250): torch autograd over the oracle's
+    path-G forward + Adam reproduces the reference's parameters -- which pins the oracle as the gradient reference the GPU
+    backward tests of path G compare with."""
+    import torch
+    fx = gio.load("vnrl_trainer")
+    for case in fx["vnrl_cases"]:
+        tag, L, lw, sk = str(case).split("|")
+        cfg = orc.OracleConfig(num_layer=int(L), layerwise_graph=bool(int(lw)), skip_connection=bool(int(sk)))
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in gio.path_g_sd().items()}
+        target = {k: v.detach().clone() for k, v in sd.items()}
+        opt = torch.optim.Adam(list(sd.values()), lr=1e-3)
+        gamma_bar = pow(0.9, 0.25)
+        losses = 0.0
+        for b in range(3):
+            sl = slice(16 * b, 16 * b + 16)
+            x, x2 = torch.tensor(fx["vn.states"][sl]), torch.tensor(fx["vn.next_states"][sl])
+            rew = torch.tensor(fx["vn.rewards"][sl]).unsqueeze(1)
+            opt.zero_grad()
+            out = orc.gcn_value_forward(x, sd, cfg)[0]
+            with torch.no_grad():
+                tgt = rew + gamma_bar * orc.gcn_value_forward(x2, target, cfg)[0]
+            loss = torch.nn.functional.mse_loss(out, tgt)
+            loss.backward()
+            opt.step()
+            losses += float(loss.detach())
+        assert abs(losses / 2 - float(fx["vn.%s.loss" % tag][0])) < 1e-6
+        for k, v in sd.items():
+            close(v.detach().numpy(), fx["vn.%s.model.%s" % (tag, k)], 2e-6)
+
+
 def test_env_scene_fixture_matches_survey_probe():
     sc = gio.load("scenes")
     assert np.allclose(sc["test_robot"][0], [0, -4, 0, 0, 0.3, 0, 4, 1, np.pi / 2])
