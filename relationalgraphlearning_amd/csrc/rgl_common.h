@@ -78,16 +78,21 @@ int launch_head_rows(const RglGraph* g, const RglMlp* head, const float* rows, i
 // the fused tile kernel (rgl_fused.hip).  Its weight image is prepared in global memory by pack_images_kernel: by the caller once per
 // parameter state (caller_image = MprlPlanner::children_image), else once per tree search (image_ready = 1 on the per-level calls)
 // or by the call itself, at the END of the workspace it is given.
+// `tail` (optional): a TailArgs (rgl_tail.h, passed opaquely with its size) -- the search's select / back-up / root steps for the
+// parents of this launch; the kernel runs them in its tail and reports *tail_done = 1 (selection done) or 2 (the deepest level:
+// back-up steps and root decision done as well).  0 = the caller launches the stand-alone kernels.
 int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, int H, const float* child_robot,
                           const float* humans_next, float* child_value, void* workspace, size_t workspace_bytes,
-                          int image_ready, hipStream_t stream, const float* caller_image = nullptr);
+                          int image_ready, hipStream_t stream, const float* caller_image = nullptr,
+                          const void* tail = nullptr, size_t tail_bytes = 0, int* tail_done = nullptr);
 int pack_children_images(const RglGraph* g, const RglMlp* head, int P, int A, int H, void* workspace, size_t workspace_bytes,
                          hipStream_t stream);               // P = the largest launch; 1 = the fused kernel does not apply
 size_t fused_children_workspace_bytes(int P, int A, int H);
 const float* fused_workspace_image(const void* workspace, size_t workspace_bytes);   // where pack_children_images put the image
 int launch_value_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
                           float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream,
-                          int image_ready = 0);                                                                     // rgl_fast.hip
+                          int image_ready = 0, const void* tail = nullptr, size_t tail_bytes = 0,
+                          int* tail_done = nullptr);                                                                // rgl_fast.hip
 size_t value_children_workspace_bytes(const MprlPlanner* pl, int P, int H);                                        // rgl_fast.hip
 // `children` (optional): a ChildrenArgs (rgl_children.h, passed opaquely with its size) describing the level's independent
 // next-state / reward work; when the MFMA scene kernel runs, it executes that work on extra workgroups of the same launch

@@ -25,7 +25,9 @@ size_t value_children_workspace_bytes(const MprlPlanner* pl, int P, int H) {
 
 // V(child) for the A children of each of P parents; children of one parent share humans_next[p].
 int launch_value_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
-                          float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream, int image_ready) {
+                          float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream, int image_ready,
+                          const void* tail, size_t tail_bytes, int* tail_done) {
+    if (tail_done) *tail_done = 0;
     const int A = pl->num_actions;
     const int hv = head_variant(pl->value_head);
     const bool want_f16 = pl->contraction_dtype == RGL_CONTRACT_F16;
@@ -37,7 +39,7 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
     if (staged && !want_f16) {
         // one fused kernel over 16-child tiles (L = 2, N <= 32, default head): values come out directly, no stage 2
         rc = launch_fused_children(&pl->value_graph, &pl->value_head, P, A, H, child_robot, humans_next, child_value, workspace,
-                                   workspace_bytes, image_ready, stream, pl->children_image);
+                                   workspace_bytes, image_ready, stream, pl->children_image, tail, tail_bytes, tail_done);
         if (rc != 1) return rc;
     }
     // packed weight image of the value estimator (the caller's, or this search's at the end of the workspace): the two-stage pair

@@ -10,9 +10,12 @@
 //   * children_fused_kernel: every wave owns one 16-child tile from the robot embedding to the VALUE: embedding,
 //     robot row/column of S, softmax scalars, the VALU row pass, the robot row, the last GCN layer on the robot row and the
 //     value head all run on registers and a 5-6.5 KB wave-private LDS scratch.  No workgroup barrier after the weight image
-//     is built, no [P*A][64] fp32 hand-off through HBM, no second launch.  Work items (groups of tiles of one parent,
-//     plan_items) are dealt over all waves of the GPU in snake passes, heaviest first, so the four SIMDs of a CU carry the
-//     same load -- the imbalance that sank round 1's barrier-free experiment (6 tiles + 2 crowd waves on 4 SIMDs).
+//     is built, no [P*A][64] fp32 hand-off through HBM, no second launch.  Round 3: every workgroup OWNS a contiguous block
+//     of parents; their work items (groups of tiles of one parent, plan_items) are dealt over the workgroup's 8 waves in
+//     snake passes, heaviest first, so the four SIMDs of a CU carry the same load.  Because all 81 values of a parent are
+//     produced inside one workgroup, the search's bookkeeping for that parent -- one-step values, top-w clipping, gather of the
+//     next level's robot rows, and at the deepest level the whole back-up chain and the root decision (rgl_tail.h) -- runs in
+//     the TAIL of this kernel behind a workgroup barrier: mprl_select / mprl_backup / mprl_root are no launches of their own.
 //   * row pass (softmax similarity, N <= 20) in the MFMA D layout with packed fp32 math: 4 instructions per 2 elements.
 //   * the crowd-only quantities of a parent (Xh, G = Xh Wa, UW, msh, Zsh: 208 MFMAs, ~9 % of a parent's work) are computed
 //     by the wave that owns the work item, at the item's start, straight into the registers the tiles read them from
@@ -25,6 +28,7 @@
 //     kernel, tile-packed over parents (16 `stop` children = one head tile), so the head never multiplies 15 columns of
 //     padding and the whole path is one launch.
 #include "rgl_mlp_chain.h"
+#include "rgl_tail.h"
 
 #include <mutex>
 #include <unordered_map>
@@ -43,7 +47,8 @@ __host__ __device__ constexpr int fused_scratch_floats(int HR, int NT, bool SOFT
     const int NP = 16 * NT, HRL = HR < NP ? HR : NP;
     const int main_fl = fused_packed_rows(HR, SOFT) ? HRL * 32 + 16 * (HRL + 2) * 2 : 2 * 16 * (NP + 1) + 16 * XLD;
     const int crowd_fl = NP * XLD + 2 * NP;
-    return ((main_fl > crowd_fl ? main_fl : crowd_fl) + 3) & ~3;
+    const int fl = main_fl > crowd_fl ? main_fl : crowd_fl;
+    return ((fl > kTailLdsInts ? fl : kTailLdsInts) + 3) & ~3;      // ... and, after the last item, the tables of the select step
 }
 
 struct FusedArgs {
@@ -62,6 +67,10 @@ struct FusedArgs {
     int tiles_per_item;           // a work item = this many consecutive FULL tiles of one parent (crowd quantities computed once)
     int items_per_parent;         // = ceil(n_full / tiles_per_item); the last group also carries the partial tile
     int rot;                      // item order: group (o + rot) % items_per_parent at order position o (heaviest group first)
+    int parents_per_wg;           // workgroup b owns parents [b k, (b + 1) k): every item of a parent runs on that workgroup's waves
+    int inline_partial;           // few parents per workgroup: the partial tile is an ordinary (padded) tile with its own head
+                                  // instead of a row hand-off to the tile-packed pass at the end (a barrier + a serial head)
+    TailArgs tail;                // tail.enabled: select (+ back-up chain + root step) for the owned parents at the end
 };
 
 constexpr int kFusedWaves = 8;
@@ -131,35 +140,36 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
     float* Y0 = AB + 2 * 16 * SLD;                                      // !PK: [16][XLD]: x0 W1, then t_c without the robot-row term
     const float hb4 = a.hb4[0];
 
-    // Work items (each class dealt round-robin over all waves of the GPU, so every wave sees the same mix):
-    //   item (j, p), group-major (all first groups, then all second ...): G consecutive full tiles of parent p; the FIRST group
-    //   of a parent starts with its partial last tile (A % 16 children: everything but the head, rows -> rows_left; scored at the
-    //   end of the kernel by the workgroup that wrote them, tile-packed over parents).
-    // Position wl of a dealing pass -> (workgroup wl % grid, wave wl / grid): consecutive items land on different CUs, then on
-    // different SIMDs.
+    // Work items of the parents this workgroup owns, dealt over its 8 waves:
+    //   item (j, p), group-major (all first groups, then all second ...): G consecutive full tiles of parent p; the LAST (short)
+    //   group of a parent starts with its partial tile (A % 16 children: everything but the head, rows -> rows_left; scored at the
+    //   end of the kernel, tile-packed over the workgroup's parents) -- or, with few parents per workgroup (inline_partial), the
+    //   partial tile is one more ordinary tile with its own head.
     // The crowd quantities of a parent are computed once per item, and the NEXT item's loads (robot rows, crowd state rows) are
     // issued before the head of the current item's last tile: no item starts waiting on HBM.
     const int G = a.tiles_per_item;
-    const int n_items = a.P * a.items_per_parent;
-    const int S = gridDim.x * kFusedWaves;              // waves of the launch
-    const int wl = wave * gridDim.x + blockIdx.x;       // my position in a dealing pass
-    const int n_pass = (n_items + S - 1) / S;
-    // pass k deals items k S .. k S + S - 1 over the waves, odd passes in reverse ("snake"): with the heavy items first in the
-    // order, the waves that got a heavy item in one pass get a light one (or none) in the next
-    auto item_at = [&](int k, int w_l) { return k * S + ((k & 1) ? S - 1 - w_l : w_l); };
+    const int p_first = blockIdx.x * a.parents_per_wg;          // my workgroup's parents: p_first .. p_first + k_b - 1
+    const int k_b = a.P - p_first < a.parents_per_wg ? a.P - p_first : a.parents_per_wg;
+    const int n_items = k_b * a.items_per_parent;
+    const int n_pass = (n_items + kFusedWaves - 1) / kFusedWaves;
+    // pass k deals the workgroup's items 8 k .. 8 k + 7 over its waves, odd passes in reverse ("snake"): with the heavy items
+    // first in the order, the waves that got a heavy item in one pass get a light one (or none) in the next; waves w and w + 4
+    // share a SIMD
+    auto item_at = [&](int k) { return k * kFusedWaves + ((k & 1) ? kFusedWaves - 1 - wave : wave); };
+    const int n_tiles_inl = a.n_full + (a.inline_partial ? 1 : 0);      // tiles that run their own head
     float rin[3], hin[NT][2];
     f32x4 gq[NT][2], xq[NT][2], ms[NT], zs[NT], xt[NT][2], uw4[HRL / 4];
-    // item wi = (order position o, parent p), o-major; group j = (o + rot) % items_per_parent covers the full tiles j G ..; the
+    // item wi = (order position o, local parent), o-major; group j = (o + rot) % items_per_parent covers the full tiles j G ..; the
     // LAST group (the short one) also carries the parent's partial tile, which it runs first.  Tile sequence ts .. t1-1, where
     // t < t0 means "the partial tile".
     auto item_tiles = [&](int wi, int& p, int& t0, int& ts, int& t1) {
-        const int o = wi / a.P;
-        p = wi - o * a.P;
+        const int o = wi / k_b;
+        p = p_first + (wi - o * k_b);
         int j = o + a.rot;
         if (j >= a.items_per_parent) j -= a.items_per_parent;
         t0 = j * G;
-        t1 = t0 + G < a.n_full ? t0 + G : a.n_full;
-        ts = (j == a.items_per_parent - 1 && a.rem) ? t0 - 1 : t0;
+        t1 = t0 + G < n_tiles_inl ? t0 + G : n_tiles_inl;
+        ts = (j == a.items_per_parent - 1 && a.rem && !a.inline_partial) ? t0 - 1 : t0;
     };
     auto robot_rows = [&](int p, int t) {                          // rows of child 16 t + n of parent p -> rin
         const int c0 = 16 * t + n;
@@ -345,11 +355,11 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         __builtin_amdgcn_wave_barrier();      // the tiles' AB / Y0 writes stay behind these reads
     };
     PHASE_START();
-    if (wl < n_items) item_loads(wl);
+    if (wave < n_items) item_loads(item_at(0));
     for (int pass = 0; pass < n_pass; ++pass) {
-        const int wi = item_at(pass, wl);
+        const int wi = item_at(pass);
         if (wi >= n_items) break;                          // only the last pass is short
-        const int wi_next = pass + 1 < n_pass ? item_at(pass + 1, wl) : n_items;
+        const int wi_next = pass + 1 < n_pass ? item_at(pass + 1) : n_items;
         PHASE_MARK(0);
         int p, t0, ts, t1;
         item_tiles(wi, p, t0, ts, t1);
@@ -625,7 +635,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         PHASE_MARK(5);
         if (ti + 1 == t1 && wi_next < n_items) item_loads(wi_next);     // next item's loads fly under this tile's head
 
-        if (!full) {
+        if (!full && !a.inline_partial) {
             // partial last tile: leave the rows [t_c | H1_0] for the tile-packed head pass
             if (n < a.rem) {
                 float* out = a.rows_left + ((size_t)p * a.rem + n) * 64;
@@ -640,26 +650,21 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
 
         // ---------------- last GCN layer on the robot row + value head: one register-resident MFMA chain -------------------
         const float v = head_chain<LO, D1, D2, D3, SKIP>(lds, tin, hp, lane);
-        if (q == 0) a.value[(size_t)p * A + c] = v + hb4;
+        if (q == 0 && c < A) a.value[(size_t)p * A + c] = v + hb4;
         PHASE_MARK(6);
       }
     }
-    if (a.rem) {
-        // Rows of this workgroup's partial tiles (parents p = blockIdx + s * grid, all written by waves of THIS workgroup):
-        // scored here, tile-packed over parents -- 16 parents' `stop` children fill one head tile exactly, so the head never
-        // multiplies padding columns and the path needs no second launch.
+    if (a.rem && !a.inline_partial) {
+        // Rows of this workgroup's partial tiles (its own parents, all written by waves of THIS workgroup): scored here,
+        // tile-packed over parents -- 16 parents' `stop` children fill one head tile exactly, so the head never multiplies
+        // padding columns and the path needs no second launch.
         __syncthreads();
-        const int b = blockIdx.x;
-        const int o_p = a.rot ? 0 : a.items_per_parent - 1;          // order position of the group that carries the partial tile
-        const int lo = o_p * a.P;                                    // its items: lo .. lo + P - 1
-        const int k_lo = lo / S, k_hi = (lo + a.P - 1) / S;
-        const int n_rows = (k_hi - k_lo + 1) * kFusedWaves * a.rem;  // (pass, wave) slots of this workgroup x rows per partial tile
+        const int n_rows = k_b * a.rem;
         for (int tt = wave; 16 * tt < n_rows; tt += kFusedWaves) {
             const int i = 16 * tt + n;
-            const int slot = i / a.rem, kr = i - slot * a.rem;
-            const int wi = item_at(k_lo + slot / kFusedWaves, (slot % kFusedWaves) * (int)gridDim.x + b);
-            const bool valid = i < n_rows && wi >= lo && wi < lo + a.P;
-            const int p = valid ? wi - lo : 0, k = kr;
+            const bool valid = i < n_rows;
+            const int lp = valid ? i / a.rem : 0, k = valid ? i - lp * a.rem : 0;
+            const int p = p_first + lp;
             const float* row = a.rows_left + ((size_t)p * a.rem + k) * 64;
             f32x4 tin[2], hp[2];
 #pragma unroll
@@ -669,6 +674,32 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
             }
             const float v = head_chain<LO, D1, D2, D3, SKIP>(lds, tin, hp, lane);
             if (valid && q == 0) a.value[(size_t)p * A + 16 * a.n_full + k] = v + hb4;
+        }
+    }
+    if (a.tail.enabled) {
+        // The search's bookkeeping for the parents this workgroup owns (rgl_tail.h): every value of theirs was written by a wave
+        // of this workgroup, so a workgroup barrier is all the synchronisation there is.  One wave per parent selects; at the
+        // deepest level the workgroup owns the parents of whole roots and walks the back-up chain up to the root decision.
+        __syncthreads();
+        static_assert(fused_scratch_floats(HR, NT, SOFT) >= kTailLdsInts, "the wave's scratch holds the select step's tables");
+        int* kl = reinterpret_cast<int*>(WS);                    // the wave's scratch is free now
+        for (int lp = wave; lp < k_b; lp += kFusedWaves) tail_select(a.tail, p_first + lp, kl);
+        if (a.tail.chain) {
+            const int W = a.tail.W, lvl = a.tail.level;
+            int per_deep = 1;
+            for (int l = 0; l < lvl; ++l) per_deep *= W;        // parents of one root at this (the deepest) level
+            const int r_first = p_first / per_deep, n_roots = k_b / per_deep;
+            int per_l = per_deep;
+            for (int l = lvl - 1; l >= 1; --l) {
+                per_l /= W;
+                __syncthreads();                                 // level l + 1's back-up values are in place
+                for (int i = tid; i < n_roots * per_l; i += nthreads) tail_backup(a.tail, l, r_first * per_l + i);
+            }
+            __syncthreads();
+            for (int base = 0; base < n_roots * kRootLanes; base += nthreads) {
+                const int i = base + tid, bl = i / kRootLanes;
+                tail_root(a.tail, r_first + bl, i % kRootLanes, bl < n_roots);
+            }
         }
     }
     PHASE_FLUSH();
@@ -760,10 +791,9 @@ inline int fused_policy() {
 
 // How the tiles of a launch are cut into work items.  A work item = G consecutive full tiles of one parent (the last group of a
 // parent may be shorter, and also carries the parent's partial tile); its wave computes the parent's crowd quantities first, so
-// small G repeats crowd work (~0.45 of a tile) while large G leaves waves idle when parents are few.  Items are dealt over the
-// S = 8 x grid waves in "snake" passes, heaviest group first; two waves share a SIMD (pipe-bound: their loads add).  The plan
-// minimises the per-SIMD makespan of that dealing, by direct simulation (cached per shape: launches repeat).
-struct ItemPlan { int G, ipp, rot, grid; };
+// small G repeats crowd work (~0.45 of a tile) while large G leaves waves idle when parents are few.  Two waves share a SIMD
+// (pipe-bound: their loads add).
+struct ItemPlan { int G, ipp, rot, grid, k_wg, inline_partial; };
 
 inline int fused_cu_count() {
     static const int n_cu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev);
@@ -771,47 +801,71 @@ inline int fused_cu_count() {
     return n_cu;
 }
 
-inline ItemPlan plan_items(int P, int n_full, int rem) {
+inline int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e && e[0] ? atoi(e) : dflt;
+}
+
+// `unit`: parents are handed to workgroups in blocks that are multiples of this (the parents of one root at the deepest level when
+// the kernel's tail walks the back-up chain; 1 otherwise).  Workgroup b owns parents [b k, (b + 1) k), k = the smallest multiple of
+// `unit` that covers P with one workgroup per CU.  Within a workgroup the items are dealt over the 8 waves in snake passes (waves w
+// and w + 4 share a SIMD); the plan simulates that dealing for one full workgroup and takes the cut with the smallest per-SIMD
+// makespan (cached per shape: launches repeat).
+inline ItemPlan plan_items(int P, int n_full, int rem, int unit) {
     static std::mutex mu;
     static std::unordered_map<unsigned long long, ItemPlan> cache;
-    const unsigned long long key = ((unsigned long long)P << 24) ^ ((unsigned long long)n_full << 8) ^ (unsigned long long)rem;
+    const unsigned long long key = ((unsigned long long)P << 32) ^ ((unsigned long long)unit << 16) ^
+                                   ((unsigned long long)n_full << 8) ^ (unsigned long long)rem;
     {
         std::lock_guard<std::mutex> lk(mu);
         auto it = cache.find(key);
         if (it != cache.end()) return it->second;
     }
-    constexpr float kCrowd = 0.45f, kPartial = 0.45f;          // in full-tile units (instruction counts of the phases)
+    // in full-tile units (instruction counts of the phases); a tile whose SIMD has no second wave to overlap with runs slower
+    constexpr float kCrowd = 0.45f, kPartial = 0.45f, kHead = 0.65f, kSolo = 1.12f;
     const int n_cu = fused_cu_count();
-    const int CT = n_full > 0 ? n_full : 1;
-    ItemPlan best{1, CT, 0, 1};
+    int k = (P + n_cu - 1) / n_cu;
+    if (k < 1) k = 1;
+    k = ((k + unit - 1) / unit) * unit;
+    const int grid = (P + k - 1) / k;
+    static const int force_g = env_int("RGL_FUSED_G", 0), force_inline = env_int("RGL_FUSED_INLINE_PARTIAL", -1);   // measurements
+    ItemPlan best{1, n_full > 0 ? n_full : 1, 0, grid, k, 0};
     float best_cost = -1.f;
-    std::vector<float> load;
-    // many parents: every SIMD gets dozens of items whatever the cut -- one item per parent (least crowd work), no simulation
-    const bool plenty = (long)P >= 16L * n_cu * kFusedWaves;
-    for (int G = CT; G >= (plenty ? CT : 1); --G) {
-        const int ipp = (CT + G - 1) / G;
-        if (G > 1 && (ipp - 1) * G >= CT) continue;
-        const int last_tiles = n_full - (ipp - 1) * G;           // full tiles of the last group (n_full == 0: 0)
-        const float c_full = kCrowd + G, c_last = kCrowd + (last_tiles > 0 ? last_tiles : 0) + (rem ? kPartial : 0.f);
-        const int rot = (ipp > 1 && c_last > c_full) ? ipp - 1 : 0;
-        const long n_items = (long)P * ipp;
-        const int grid = n_items < n_cu ? (int)n_items : n_cu;   // few items: one per CU before a second wave of any CU gets one
-        const long S = (long)grid * kFusedWaves;
-        const int n_simd = grid * 4;
-        load.assign(n_simd, 0.f);
-        for (int o = 0; o < ipp; ++o) {
-            int j = o + rot;
-            if (j >= ipp) j -= ipp;
-            const float c = j == ipp - 1 ? c_last : c_full;
-            for (long wi = (long)o * P; wi < (long)(o + 1) * P; ++wi) {
-                const long k = wi / S, r = wi - k * S;
-                const long w_l = (k & 1) ? S - 1 - r : r;
-                load[w_l % n_simd] += c;                         // waves w and w + 4 of a workgroup share a SIMD
+    for (int inl = 0; inl <= 1; ++inl) {
+        if (inl && !rem) continue;
+        if (force_inline >= 0 ? (inl != (force_inline && rem ? 1 : 0)) : (inl && (long)k * rem > 8)) continue;
+        const int n_tiles = n_full + inl;                        // tiles that run their own head
+        const int CT = n_tiles > 0 ? n_tiles : 1;
+        for (int G = CT; G >= 1; --G) {
+            if (force_g > 0 && G != (force_g < CT ? force_g : CT)) continue;
+            const int ipp = (CT + G - 1) / G;
+            if (G > 1 && (ipp - 1) * G >= CT) continue;
+            const int last_tiles = n_tiles - (ipp - 1) * G;      // tiles of the last group (n_tiles == 0: 0)
+            const float c_full = kCrowd + G;
+            const float c_last = kCrowd + (last_tiles > 0 ? last_tiles : 0) + ((rem && !inl) ? kPartial : 0.f);
+            const int rot = (ipp > 1 && c_last > c_full) ? ipp - 1 : 0;
+            float load[4] = {0.f, 0.f, 0.f, 0.f};
+            int busy[kFusedWaves] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const long n_items = (long)k * ipp;
+            for (long i = 0; i < n_items; ++i) {
+                int j = (int)(i / k) + rot;
+                if (j >= ipp) j -= ipp;
+                const long pass = i / kFusedWaves, r = i - pass * kFusedWaves;
+                const int w = (int)((pass & 1) ? kFusedWaves - 1 - r : r);
+                load[w & 3] += j == ipp - 1 ? c_last : c_full;
+                busy[w] = 1;
             }
+            float mk = 0.f;
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const float v = load[sidx] * ((busy[sidx] + busy[sidx + 4] == 1) ? kSolo : 1.f);
+                mk = v > mk ? v : mk;
+            }
+            if (rem && !inl) {                                   // the tile-packed pass behind the barrier
+                const long head_tiles = ((long)k * rem + 15) / 16;
+                mk += kHead * (float)((head_tiles + kFusedWaves - 1) / kFusedWaves) * (head_tiles > 4 ? 2.f : 1.f) + 0.05f;
+            }
+            if (best_cost < 0.f || mk < best_cost - 1e-3f) { best_cost = mk; best = ItemPlan{G, ipp, rot, grid, k, inl}; }
         }
-        float mk = 0.f;
-        for (float v : load) mk = v > mk ? v : mk;
-        if (best_cost < 0.f || mk < best_cost - 1e-3f) { best_cost = mk; best = ItemPlan{G, ipp, rot, grid}; }
     }
     std::lock_guard<std::mutex> lk(mu);
     if (cache.size() > 8192) cache.clear();                    // callers with ever-changing parent counts: bounded memory
@@ -819,11 +873,12 @@ inline ItemPlan plan_items(int P, int n_full, int rem) {
     return best;
 }
 
-inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A, int H) {
+inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A, int H, int unit = 1) {
     FusedPlan pl;
     pl.ok = false;
     if (!fast_path_enabled() || !rank1_enabled() || fused_policy() < 0) return pl;
-    if (fused_policy() == 0 && (long)P * ((A + 15) / 16) < 3000) return pl;
+    static const int min_tiles = env_int("RGL_FUSED_MIN_TILES", 1200);
+    if (fused_policy() == 0 && (long)P * ((A + 15) / 16) < min_tiles) return pl;
     if (fast_similarity_mode(g) < 0 || g.layerwise_graph || g.x_dim != XD || g.num_layer != 2) return pl;
     if (!mlp_is(g.w_r, 9, HID, XD, true) || !mlp_is(g.w_h, 5, HID, XD, true)) return pl;
     if (head_variant(head) != 0) return pl;
@@ -838,10 +893,13 @@ inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A,
     a.rem = A % 16;
     a.sim = fast_similarity_mode(g);
     {
-        const ItemPlan ip = plan_items(P, a.n_full, a.rem);
+        const ItemPlan ip = plan_items(P, a.n_full, a.rem, unit);
         a.tiles_per_item = ip.G;
         a.items_per_parent = ip.ipp;
         a.rot = ip.rot;
+        a.parents_per_wg = ip.k_wg;
+        a.inline_partial = ip.inline_partial;
+        a.tail = TailArgs{};
         pl.grid = ip.grid;
     }
     pl.lds_bytes = (size_t)(FusedLds<32, 100, 100>::scratch +
@@ -927,8 +985,26 @@ int pack_children_images(const RglGraph* g, const RglMlp* head, int P, int A, in
 // 1 = outside this kernel's envelope
 int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, int H, const float* child_robot,
                           const float* humans_next, float* child_value, void* workspace, size_t workspace_bytes,
-                          int image_ready, hipStream_t stream, const float* caller_image) {
-    FusedPlan fp = plan_fused(*g, *head, P, A, H);
+                          int image_ready, hipStream_t stream, const float* caller_image, const void* tail, size_t tail_bytes,
+                          int* tail_done) {
+    if (tail_done) *tail_done = 0;
+    // the search's tail: selection always; the back-up chain + root step at the deepest level when handing whole roots to
+    // workgroups does not starve the GPU (few roots with many parents each -- unclipped deep searches -- keep unit = 1)
+    const TailArgs* ta = (tail && tail_bytes == sizeof(TailArgs) && ((const TailArgs*)tail)->enabled) ? (const TailArgs*)tail : nullptr;
+    static const bool tail_off = env_int("RGL_FUSED_NO_TAIL", 0) != 0;          // measurements / tests: stand-alone kernels
+    if (tail_off) ta = nullptr;
+    int unit = 1, chain = 0;
+    if (ta && ta->chain) {
+        long u = 1;
+        for (int l = 0; l < ta->level && u <= P; ++l) u *= ta->W;
+        if (u <= P && P % u == 0 && P / u >= fused_cu_count() / 2) {
+            unit = (int)u;
+            chain = 1;
+        } else if (u == 1) {
+            chain = 1;
+        }
+    }
+    FusedPlan fp = plan_fused(*g, *head, P, A, H, unit);
     if (!fp.ok) return 1;
     if (!workspace || workspace_bytes < fused_children_workspace_bytes(P, A, H)) return 1;
     if (!image_ready && !caller_image) {
@@ -942,7 +1018,13 @@ int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, i
     fp.a.value = child_value;
     fp.a.image = image;
     fp.a.rows_left = rows_left;
-    return launch_fused(fp, g->skip_connection != 0, stream);
+    if (ta) {
+        fp.a.tail = *ta;
+        fp.a.tail.chain = chain;
+    }
+    const int rc = launch_fused(fp, g->skip_connection != 0, stream);
+    if (rc == RGL_OK && ta && tail_done) *tail_done = chain ? 2 : 1;
+    return rc;
 }
 
 }  // namespace rgl

@@ -7,6 +7,7 @@
 // action_clip, V_planning, estimate_reward), state_predictor.py:41-60,109-118,
 // crowd_sim/envs/utils/utils.py:4-26, multi_human_rl.py:36-96, cadrl.py:113-138,241-276.
 #include "rgl_children.h"
+#include "rgl_tail.h"
 
 namespace {
 
@@ -45,127 +46,13 @@ __global__ void gather_parent_humans_kernel(const float* __restrict__ humans, in
     out[i] = humans[(p / humans_per) * H * 5 + rest];
 }
 
-constexpr int kMaxSparseWidth = 16;     // sparse (one action per group) searches: widest clipping the select kernel supports
-
-__device__ __forceinline__ int bi_fallback(const int* kl, int k) { return k > 0 ? kl[k - 1] : 0; }
-
-// One WAVE per parent: one-step values, top-w clipping (argpartition semantics; sparse: one action per group in
-// descending value order), next level's robot states.  Lane l owns actions l, l+64, l+128, l+192.
-__global__ __launch_bounds__(256) void mprl_select_kernel(const float* __restrict__ reward, const float* __restrict__ child_value,
-                                   const float* __restrict__ child_robot, const int* __restrict__ groups, int P,
-                                   int A, int W, int clip, int sparse, float gamma_f, float* __restrict__ value1,
-                                   int* __restrict__ keep, float* __restrict__ next_robot,
-                                   // deepest level only (else null): leaf values V(kept child) and, below the root level,
-                                   // this parent's back-up step -- the leaf step and the first mprl_backup_kernel step
-                                   float* __restrict__ leaf_backup, const float* __restrict__ up_child_value,
-                                   const int* __restrict__ up_keep, int d, float* __restrict__ up_backup,
-                                   int* __restrict__ best_slot) {
-    __shared__ int kept_lds[4][RGL_MAX_ACTIONS];         // per-wave copy of the kept indices for the gather below
-    const int lane = threadIdx.x & 63;
-    int* kl = kept_lds[threadIdx.x >> 6];
+// One WAVE per parent (tail_select, rgl_tail.h): one-step values, top-w clipping, next level's robot states; at the deepest
+// level also the leaf values and the parent's own back-up step.
+__global__ __launch_bounds__(256) void mprl_select_kernel(const TailArgs t) {
+    __shared__ int kept_lds[4][kTailLdsInts];            // per wave: kept indices | V(child) | rewards (tail_select)
     const int p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (p >= P) return;
-    const float* rw = reward + (size_t)p * A;
-    const float* cv = child_value + (size_t)p * A;
-    float* v1 = value1 + (size_t)p * A;
-    float val[4];
-    bool avail[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int a = lane + 64 * k;
-        avail[k] = a < A;
-        val[k] = 0.f;
-        if (avail[k]) {
-            val[k] = __fadd_rn(rw[a], __fmul_rn(gamma_f, cv[a]));
-            v1[a] = val[k];
-        }
-    }
-    int* kp = keep + (size_t)p * W;
-    if (!clip) {
-        for (int a = lane; a < A; a += 64) { kp[a] = a; kl[a] = a; }
-    } else {
-        // sparse search: one action per group.  The groups taken so far are kept BY ID (any int32, as in the reference's python
-        // set, model_predictive_rl.py:252-263) -- the width of a sparse search is at most kMaxSparseWidth (checked by the entry
-        // point), so the set is a handful of wave-uniform registers and no id range has to be imposed on the caller.
-        int seen[kMaxSparseWidth];
-        int nkept = 0;
-        while (nkept < W) {
-            // lane-local best: larger value first, then lower index; a NaN is only taken when nothing else is left
-            int bi = -1;
-            float bv = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!avail[k]) continue;
-                const float v = val[k];
-                if (bi < 0 || v > bv || (bv != bv && v == v)) {
-                    bi = lane + 64 * k;
-                    bv = v;
-                }
-            }
-            // wave argmax over (value, index)
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float ov = __shfl_xor(bv, off);
-                const int oi = __shfl_xor(bi, off);
-                const bool take = oi >= 0 && (bi < 0 || ov > bv || (bv != bv && ov == ov) || (ov == bv && oi < bi));
-                if (take) {
-                    bv = ov;
-                    bi = oi;
-                }
-            }
-            if (bi < 0) break;                          // nothing left (wave-uniform)
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (lane + 64 * k == bi) avail[k] = false;
-            if (sparse) {
-                const int gi = groups[bi];
-                bool dup = false;
-#pragma unroll
-                for (int k = 0; k < kMaxSparseWidth; ++k) dup = dup || (k < nkept && seen[k] == gi);
-                if (dup) continue;
-#pragma unroll
-                for (int k = 0; k < kMaxSparseWidth; ++k)
-                    if (k == nkept) seen[k] = gi;
-            }
-            if (lane == 0) { kp[nkept] = bi; kl[nkept] = bi; }
-            ++nkept;
-        }
-        if (lane == 0)
-            for (int k = nkept; k < W; ++k) { kp[k] = bi_fallback(kl, k); kl[k] = kp[k]; }   // unreachable for validated inputs
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // lane 0's kl[] writes are ordered before the wave's reads below
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (next_robot) {
-        for (int idx = lane; idx < W * 9; idx += 64) {      // same wave wrote kl: LDS operations of a wave execute in order
-            const int k = idx / 9, i = idx - k * 9;
-            const int a = kl[k];
-            next_robot[((size_t)p * W + k) * 9 + i] = child_robot[((size_t)p * A + a) * 9 + i];
-        }
-    }
-    if (leaf_backup) {
-        for (int k = lane; k < W; k += 64) leaf_backup[(size_t)p * W + k] = cv[kl[k]];     // V_planning(child, 1) = V(child)
-        if (up_backup && lane == 0) {
-            // ret_k = v/d + (d-1)/d * (gamma*nv_k + r_k), first maximum (model_predictive_rl.py:293,298-302)
-            const int q = p / W, slot = p - q * W;
-            const float v = up_child_value[(size_t)q * A + up_keep[(size_t)q * W + slot]];
-            const float v_over_d = __fdiv_rn(v, (float)d);
-            const float c = (float)((double)(d - 1) / (double)d);
-            float best = 0.f;
-            int bk = -1;
-            for (int k = 0; k < W; ++k) {
-                const int a = kl[k];
-                const float inner = __fadd_rn(__fmul_rn(gamma_f, cv[a]), rw[a]);
-                const float ret = __fadd_rn(v_over_d, __fmul_rn(c, inner));
-                if (bk < 0 || ret > best) {
-                    best = ret;
-                    bk = k;
-                }
-            }
-            up_backup[(size_t)q * W + slot] = best;
-            best_slot[p] = bk;
-        }
-    }
+    if (p >= t.lv[t.level].P) return;
+    tail_select(t, p, kept_lds[threadIdx.x >> 6]);
 }
 
 // value1 = reward + gamma_bar * V(child), each op rounded to fp32 like the reference's tensor arithmetic
@@ -175,74 +62,16 @@ __global__ void one_step_value_kernel(const float* __restrict__ r, const float* 
     if (i < n) o[i] = __fadd_rn(r[i], __fmul_rn(g, v[i]));
 }
 
-// Level l >= 1, one thread per parent p: ret_k = v/d + (d-1)/d * (gamma*nv_k + r_k); the max goes to
-// the slot of p in its own parent's backup row (model_predictive_rl.py:293,298-302).
-__global__ void mprl_backup_kernel(const float* __restrict__ reward, const int* __restrict__ keep,
-                                   const float* __restrict__ backup, const float* __restrict__ up_child_value,
-                                   const int* __restrict__ up_keep, int P, int A, int W, int d, float gamma_f,
-                                   float* __restrict__ up_backup, int* __restrict__ best_slot) {
+// Level l >= 1, one thread per parent (tail_backup); 16 lanes per root (tail_root).
+__global__ void mprl_backup_kernel(const TailArgs t, int l) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    const int q = p / W, slot = p - q * W;
-    const float v = up_child_value[(size_t)q * A + up_keep[(size_t)q * W + slot]];
-    const float v_over_d = __fdiv_rn(v, (float)d);
-    const float c = (float)((double)(d - 1) / (double)d);
-    float best = 0.f;
-    int bk = -1;
-    for (int k = 0; k < W; ++k) {
-        const float r = reward[(size_t)p * A + keep[(size_t)p * W + k]];
-        const float inner = __fadd_rn(__fmul_rn(gamma_f, backup[(size_t)p * W + k]), r);
-        const float ret = __fadd_rn(v_over_d, __fmul_rn(c, inner));
-        if (bk < 0 || ret > best) {
-            best = ret;
-            bk = k;
-        }
-    }
-    up_backup[(size_t)q * W + slot] = best;
-    best_slot[p] = bk;
+    if (p < t.lv[l].P) tail_backup(t, l, p);
 }
 
-// 16 lanes per root: the W kept actions of a root are scored side by side (W = A = 81 without action clipping: a single thread
-// walking them paid 81 dependent gather latencies, 38 us of a 0.1 ms depth-1 search), then a first-maximum reduction.
-constexpr int kRootLanes = 16;
-__global__ void mprl_root_kernel(const float* __restrict__ reward, const int* __restrict__ keep,
-                                 const float* __restrict__ backup, int B, int A, int W, float gamma_f,
-                                 int* __restrict__ best_action, float* __restrict__ best_value,
-                                 float* __restrict__ root_values, int* __restrict__ root_kept,
-                                 int* __restrict__ best_slot) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = t / kRootLanes, sub = t % kRootLanes;
-    const bool live = b < B;
-    float best = -INFINITY;
-    int bk = -1;
-    if (live) {
-        for (int k = sub; k < W; k += kRootLanes) {
-            const int a = keep[(size_t)b * W + k];
-            const float val = __fadd_rn(reward[(size_t)b * A + a], __fmul_rn(gamma_f, backup[(size_t)b * W + k]));
-            if (root_values) root_values[(size_t)b * W + k] = val;
-            if (root_kept) root_kept[(size_t)b * W + k] = a;
-            if (val > best) {                  // strict '>' keeps the first maximum (:228)
-                best = val;
-                bk = k;
-            }
-        }
-    }
-    // first maximum over the 16 lanes: a slot beats no slot, then the larger value, then the smaller slot index
-#pragma unroll
-    for (int m = kRootLanes / 2; m >= 1; m >>= 1) {
-        const float ov = __shfl_xor(best, m);
-        const int ok = __shfl_xor(bk, m);
-        const bool take = ok >= 0 && (bk < 0 || ov > best || (ov == best && ok < bk));
-        if (take) {
-            best = ov;
-            bk = ok;
-        }
-    }
-    if (live && sub == 0) {
-        best_action[b] = bk >= 0 ? keep[(size_t)b * W + bk] : -1;   // -1 <=> 'Value network is not well trained'
-        best_value[b] = best;
-        best_slot[b] = bk;
-    }
+__global__ void mprl_root_kernel(const TailArgs t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = i / kRootLanes;
+    tail_root(t, b, i % kRootLanes, b < t.B);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -464,7 +293,8 @@ inline int validate_planner(const MprlPlanner& pl, int H) {
 // One level: steps 1-3 of the header comment of mprl_expand_f32.
 int expand_level(const MprlPlanner& pl, const float* robot, const float* humans, int humans_per, int P, int H, int joint,
                  float* humans_next, float* child_robot, float* reward, float* child_value, void* scratch,
-                 size_t scratch_bytes, hipStream_t st, int image_ready = 0) {
+                 size_t scratch_bytes, hipStream_t st, int image_ready = 0, const TailArgs* tail = nullptr,
+                 int* tail_done = nullptr) {
     const int A = pl.num_actions;
     ChildrenArgs ca;
     ca.robot = robot; ca.humans = humans; ca.humans_per = humans_per; ca.actions = pl.actions;
@@ -496,7 +326,8 @@ int expand_level(const MprlPlanner& pl, const float* robot, const float* humans,
         hipLaunchKernelGGL(mprl_children_kernel, grid_for((long long)P * A), dim3(kBlock), 0, st, ca);
         RGL_LAUNCH_CHECK();
     }
-    return rgl::launch_value_children(&pl, child_robot, humans_next, P, H, child_value, scratch, scratch_bytes, st, image_ready);
+    return rgl::launch_value_children(&pl, child_robot, humans_next, P, H, child_value, scratch, scratch_bytes, st, image_ready,
+                                      tail, tail ? sizeof(TailArgs) : 0, tail_done);
 }
 
 }  // namespace
@@ -601,43 +432,49 @@ extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* rob
                             (pl.children_image != nullptr ||
                              rgl::pack_children_images(&pl.value_graph, &pl.value_head, (int)lv[D - 1].P, A, H, ws + scratch_off,
                                                        (size_t)scratch_bytes, st) == 0);
+    TailArgs tail{};
+    tail.enabled = 1;
+    tail.D = D; tail.A = A; tail.W = W; tail.clip = pl.do_action_clip; tail.sparse = pl.sparse_search;
+    tail.gamma_f = gamma_f;
+    tail.groups = pl.action_groups;
+    for (int l = 0; l < D; ++l) {
+        const LevelLayout& L = lv[l];
+        tail.lv[l] = TailLevel{(const float*)(ws + L.reward), (const float*)(ws + L.child_value), (int*)(ws + L.keep),
+                               (float*)(ws + L.backup), (int*)(ws + L.best_slot), (int)L.P};
+    }
+    tail.B = B;
+    tail.best_action = best_action; tail.best_value = best_value; tail.root_values = root_values; tail.root_kept = root_kept;
+    int chain_done = 0;              // the deepest level's children kernel also ran the back-up steps and the root step
     for (int l = 0; l < D; ++l) {
         const LevelLayout& L = lv[l];
         const int P = (int)L.P;
         const float* pr = l == 0 ? robot : (const float*)(ws + L.robot);
         const float* ph = l == 0 ? humans : (const float*)(ws + L.humans);
         const int humans_per = l == 0 ? 1 : W;
+        const bool deepest = l + 1 == D;
+        tail.level = l;
+        tail.child_robot = (const float*)(ws + L.child_robot);
+        tail.value1 = (float*)(ws + L.value1);
+        tail.next_robot = deepest ? nullptr : (float*)(ws + lv[l + 1].robot);
+        tail.chain = deepest;
+        int tail_done = 0;           // 1: the children kernel selected for its parents; 2: ... and finished the search (deepest level)
         rc = expand_level(pl, pr, ph, humans_per, P, H, l == 0 ? roots_are_joint_states : 0,
                           (float*)(ws + L.humans_next), (float*)(ws + L.child_robot), (float*)(ws + L.reward),
-                          (float*)(ws + L.child_value), ws + scratch_off, (size_t)scratch_bytes, st, image_ready);
+                          (float*)(ws + L.child_value), ws + scratch_off, (size_t)scratch_bytes, st, image_ready, &tail, &tail_done);
         if (rc) return rc;
-        const bool deepest = l + 1 == D;
-        float* next_robot = deepest ? nullptr : (float*)(ws + lv[l + 1].robot);
-        // the deepest level's selection also writes the leaf values and (below the root) does its own back-up step
-        const bool up = deepest && l >= 1;
-        hipLaunchKernelGGL(mprl_select_kernel, grid_for(P, 4), dim3(256), 0, st, (const float*)(ws + L.reward),
-                           (const float*)(ws + L.child_value), (const float*)(ws + L.child_robot), pl.action_groups, P, A,
-                           W, pl.do_action_clip, pl.sparse_search, gamma_f, (float*)(ws + L.value1), (int*)(ws + L.keep),
-                           next_robot, deepest ? (float*)(ws + L.backup) : nullptr,
-                           up ? (const float*)(ws + lv[l - 1].child_value) : nullptr,
-                           up ? (const int*)(ws + lv[l - 1].keep) : nullptr, 2,
-                           up ? (float*)(ws + lv[l - 1].backup) : nullptr, up ? (int*)(ws + L.best_slot) : nullptr);
-        RGL_LAUNCH_CHECK();
+        if (!tail_done) {
+            // the deepest level's selection also writes the leaf values and (below the root) does its own back-up step
+            hipLaunchKernelGGL(mprl_select_kernel, grid_for(P, 4), dim3(256), 0, st, tail);
+            RGL_LAUNCH_CHECK();
+        }
+        if (deepest && tail_done == 2) chain_done = 1;
     }
-    for (int l = D - 2; l >= 1; --l) {
-        const LevelLayout& L = lv[l];
-        const LevelLayout& U = lv[l - 1];
-        hipLaunchKernelGGL(mprl_backup_kernel, grid_for(L.P, 64), dim3(64), 0, st, (const float*)(ws + L.reward),
-                           (const int*)(ws + L.keep), (const float*)(ws + L.backup), (const float*)(ws + U.child_value),
-                           (const int*)(ws + U.keep), (int)L.P, A, W, D - l + 1, gamma_f, (float*)(ws + U.backup),
-                           (int*)(ws + L.best_slot));
-        RGL_LAUNCH_CHECK();
-    }
-    {
-        const LevelLayout& L = lv[0];
-        hipLaunchKernelGGL(mprl_root_kernel, grid_for((long long)B * kRootLanes, 256), dim3(256), 0, st, (const float*)(ws + L.reward),
-                           (const int*)(ws + L.keep), (const float*)(ws + L.backup), B, A, W, gamma_f, best_action,
-                           best_value, root_values, root_kept, (int*)(ws + L.best_slot));
+    if (!chain_done) {
+        for (int l = D - 2; l >= 1; --l) {
+            hipLaunchKernelGGL(mprl_backup_kernel, grid_for(lv[l].P, 64), dim3(64), 0, st, tail, l);
+            RGL_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(mprl_root_kernel, grid_for((long long)B * kRootLanes, 256), dim3(256), 0, st, tail);
         RGL_LAUNCH_CHECK();
     }
     return RGL_OK;
