@@ -39,11 +39,11 @@
 extern "C" {
 #endif
 
-#define RGL_ABI_VERSION 3
+#define RGL_ABI_VERSION 4
 
 #define RGL_MAX_MLP_LAYERS 6
 #define RGL_MAX_GCN_LAYERS 8
-#define RGL_MAX_NODES 64    /* N = humans + 1 */
+#define RGL_MAX_NODES 128   /* N = humans + 1 (64 until ABI 3) */
 #define RGL_MAX_XDIM 64
 #define RGL_MAX_WIDTH 256   /* widest MLP layer */
 #define RGL_MAX_ACTIONS 256
@@ -113,7 +113,8 @@ typedef struct RglGraph {
  *   A_out      NULL or device [n_scenes][N][N]       (first adjacency computed)
  *   workspace  NULL or device scratch of rgl_graph_forward_workspace_bytes(...) bytes (ABI 3).  With it, and with H_out = A_out =
  *              NULL, models the one-wave-per-scene MFMA kernel covers (the shipped path-M shapes: w_r 9-64-32, w_h 5-64-32,
- *              x_dim 32, <= 4 layers, N <= 64, every similarity function, layerwise graphs) run on it; everything else, and
+ *              x_dim 32, <= 4 layers, N <= 128 (concatenation: N <= 64), every similarity function, layerwise graphs) run on
+ *              it; everything else, and
  *              every call without workspace, runs on the general kernel -- same numbers up to summation order.
  * Limits: N = H+1 <= RGL_MAX_NODES, x_dim <= RGL_MAX_XDIM, widths <= RGL_MAX_WIDTH.
  * ------------------------------------------------------------------------------------------- */
@@ -152,6 +153,16 @@ int rgl_graph_backward_f32(const RglGraph* graph, const RglMlp* value_head, cons
 /* rgl_transpose_f32 -- dst[c][r] = src[r][c]; turns a torch Linear weight (out,in) into the
  * k-major layout RglMlp wants.  Host-side convenience of this ABI (no reference counterpart). */
 int rgl_transpose_f32(const float* src, float* dst, int rows, int cols, rgl_stream_t stream);
+
+/* rgl_transpose_many_f32 (ABI 4) -- the same for a LIST of matrices in one launch per 32 jobs: a module's descriptor holds
+ * half a dozen Linear weights and is rebuilt after every optimizer step (crowd_nav/utils/trainer.py:110-161 steps two Adam
+ * optimizers per batch), so one launch per weight was most of a training step's launch count.  `jobs` is a HOST array. */
+typedef struct RglTransposeJob {
+    const float* src;           /* device [rows][cols] */
+    float* dst;                 /* device [cols][rows] */
+    int rows, cols;
+} RglTransposeJob;
+int rgl_transpose_many_f32(const RglTransposeJob* jobs, int n_jobs, rgl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * gcn_rotate_f32 -- pairwise relation features: (R,14) [robot 9 | human 5] -> (R,13)

@@ -11,11 +11,11 @@ LIB_PATH = os.environ.get("RGL_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libr
 
 MAX_MLP_LAYERS = 6
 MAX_GCN_LAYERS = 8
-MAX_NODES = 64
+MAX_NODES = 128
 MAX_XDIM = 64
 MAX_WIDTH = 256
 MAX_ACTIONS = 256
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 SIMILARITY = {"embedded_gaussian": 0, "gaussian": 1, "cosine": 2, "cosine_softmax": 3, "concatenation": 4,
               "squared": 5, "equal_attention": 6, "diagonal": 7}
@@ -33,6 +33,10 @@ c_double_p = C.POINTER(C.c_double)
 class RglMlp(C.Structure):
     _fields_ = [("n_layers", C.c_int), ("last_relu", C.c_int), ("dims", C.c_int * (MAX_MLP_LAYERS + 1)),
                 ("weight", C.c_void_p * MAX_MLP_LAYERS), ("bias", C.c_void_p * MAX_MLP_LAYERS)]
+
+
+class RglTransposeJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int)]
 
 
 class RglGraph(C.Structure):
@@ -83,6 +87,7 @@ SIGNATURES = {
                                          C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_size_t, C.c_void_p]),
     "rgl_transpose_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "rgl_transpose_many_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "gcn_rotate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "gcn_predict_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "gcn_predict_f32": (C.c_int, [C.POINTER(GcnPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,

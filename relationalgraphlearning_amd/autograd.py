@@ -28,12 +28,13 @@ class GraphFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, robot, humans, *params):
-        from .nets import graph_forward
+        from .nets import graph_forward, batched_transposes
         if robot.requires_grad or humans.requires_grad:
             raise NotImplementedError("gradients with respect to the agent states are not provided by the HIP path "
                                       "(the states of a replay batch are data): detach the inputs")
-        out = graph_forward(spec.graph(), spec.value_head(), spec.motion_head(), robot, humans,
-                            want_H=spec.want_H, want_A=spec.want_A)
+        with batched_transposes():                 # the descriptors of one forward: one transpose launch for all their weights
+            graph, vh, mh = spec.graph(), spec.value_head(), spec.motion_head()
+        out = graph_forward(graph, vh, mh, robot, humans, want_H=spec.want_H, want_A=spec.want_A)
         ctx.spec = spec
         ctx.save_for_backward(robot, humans)
         ctx.n_params = len(params)
@@ -55,7 +56,9 @@ class GraphFunction(torch.autograd.Function):
                                "(e.g. an optimizer step before loss.backward()): gradients would belong to other weights")
         g = dict(zip(ctx.keys, grads))
         S, H = robot.shape[0], humans.shape[1]
-        graph, vh, mh = spec.graph(), spec.value_head(), spec.motion_head()
+        from .nets import batched_transposes
+        with batched_transposes():
+            graph, vh, mh = spec.graph(), spec.value_head(), spec.motion_head()
         lib = nat.lib()
         vhp = C.byref(vh) if vh is not None else None
         mhp = C.byref(mh) if mh is not None else None

@@ -276,6 +276,23 @@ __global__ void transpose_kernel(const float* __restrict__ src, float* __restric
     dst[c * rows + r] = src[idx];
 }
 
+constexpr int kTransposeBatch = 32;
+struct TransposeBatch {
+    RglTransposeJob job[kTransposeBatch];
+    int first_block[kTransposeBatch + 1];      // job j owns workgroups [first_block[j], first_block[j + 1])
+    int n;
+};
+
+__global__ void transpose_many_kernel(const TransposeBatch b) {
+    int j = 0;
+    while (j + 1 < b.n && (int)blockIdx.x >= b.first_block[j + 1]) ++j;
+    const RglTransposeJob& t = b.job[j];
+    const int idx = ((int)blockIdx.x - b.first_block[j]) * blockDim.x + threadIdx.x;
+    if (idx >= t.rows * t.cols) return;
+    const int r = idx / t.cols, c = idx - r * t.cols;
+    t.dst[c * t.rows + r] = t.src[idx];
+}
+
 }  // namespace
 
 namespace rgl {
@@ -339,14 +356,20 @@ int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, cons
     int buf_floats = N * L.buf_ld;
     if (vmax > buf_floats) buf_floats = vmax;
     if (vmax > L.buf_ld) { /* single row may be wider than buf_ld; rows=1 so stride is irrelevant */ }
-    L.buf0 = take(buf_floats);
-    L.buf1 = take(buf_floats);
+    // The MLP ping-pong rows and the N x N similarity matrix are never live together (embeddings come before the first
+    // adjacency, the heads after the last layer): they share one region, which is what lets N = 128 fit a CU's LDS.
+    L.s_ld = N + 1;
+    {
+        const int s_floats = N * L.s_ld;
+        const int region = 2 * ((buf_floats + 3) & ~3) > s_floats ? 2 * ((buf_floats + 3) & ~3) : s_floats;
+        L.buf0 = take(region);
+        L.buf1 = L.buf0 + ((buf_floats + 3) & ~3);
+        L.S = L.buf0;
+    }
     L.X = take(N * xd);
     L.Hc = take(N * xd);
     L.Hn = take(N * xd);
     L.T = take(N * xd > N ? N * xd : N);
-    L.s_ld = N + 1;
-    L.S = take(N * L.s_ld);
     if (graph->similarity == RGL_SIM_CONCATENATION) {
         L.uv_ld = graph->w_a_mlp.dims[1] + 1;
         L.U = take(N * L.uv_ld);
@@ -402,6 +425,30 @@ extern "C" int rgl_transpose_f32(const float* src, float* dst, int rows, int col
     const int n = rows * cols;
     hipLaunchKernelGGL(transpose_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols);
     RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
+extern "C" int rgl_transpose_many_f32(const RglTransposeJob* jobs, int n_jobs, rgl_stream_t stream) {
+    if (n_jobs < 0) return RGL_ERR_BAD_SHAPE;
+    if (n_jobs == 0) return RGL_OK;
+    if (!jobs) return RGL_ERR_NULL;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!jobs[j].src || !jobs[j].dst) return RGL_ERR_NULL;
+        if (jobs[j].rows < 1 || jobs[j].cols < 1 || (long long)jobs[j].rows * jobs[j].cols > (1ll << 30)) return RGL_ERR_BAD_SHAPE;
+    }
+    for (int lo = 0; lo < n_jobs; lo += kTransposeBatch) {
+        TransposeBatch b;
+        b.n = n_jobs - lo < kTransposeBatch ? n_jobs - lo : kTransposeBatch;
+        int blocks = 0;
+        for (int j = 0; j < b.n; ++j) {
+            b.job[j] = jobs[lo + j];
+            b.first_block[j] = blocks;
+            blocks += (jobs[lo + j].rows * jobs[lo + j].cols + 255) / 256;
+        }
+        b.first_block[b.n] = blocks;
+        hipLaunchKernelGGL(transpose_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+        RGL_LAUNCH_CHECK();
+    }
     return RGL_OK;
 }
 

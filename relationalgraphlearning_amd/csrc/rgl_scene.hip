@@ -547,6 +547,15 @@ int launch_scene_k(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* ch
     return RGL_OK;
 }
 
+// 64 < N <= 128: eight column tiles, always split over the eight waves of a workgroup (one scene per workgroup pass; the
+// unsplit form would hold an 8 x 8 block of adjacency tiles per wave: 256 VGPRs).  The pair-MLP similarity has no split form.
+inline int launch_scene_wide(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* children, hipStream_t st) {
+    if (sa.sim == SIM_SOFTMAX) return launch_scene_k<8, 0, 8, true>(sa, lds_bytes, children, st);
+    if (sa.sim == SIM_COSINE || sa.sim == SIM_COSINE_SOFTMAX) return launch_scene_k<8, 2, 8, true>(sa, lds_bytes, children, st);
+    if (sa.sim == SIM_CONCAT) return 1;
+    return launch_scene_k<8, 1, 8, true>(sa, lds_bytes, children, st);
+}
+
 template <int NT, int WAVES>
 int launch_scene(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* children, hipStream_t st) {
     if (sa.sim == SIM_SOFTMAX) return launch_scene_k<NT, 0, WAVES>(sa, lds_bytes, children, st);
@@ -563,7 +572,7 @@ static bool scene_kernel_covers(const RglGraph& g, int N) {
     const bool path_m = mlp_is(g.w_r, 9, HID, XD, true) && mlp_is(g.w_h, 5, HID, XD, true);
     const bool path_g = mlp_is(g.w_r, 6, HID, XD, true) && mlp_is(g.w_h, 7, HID, XD, true);        // gcn.ValueNetwork's inputs
     return fast_path_enabled() && scene_similarity_mode(g) >= 0 && g.x_dim == XD && g.num_layer >= 1 && g.num_layer <= 4 &&
-           (path_m || path_g) && N <= 64;
+           (path_m || path_g) && N <= 128 && (N <= 64 || scene_similarity_mode(g) != SIM_CONCAT);
 }
 
 // embeddings (one launch) + one-wave-per-scene graph forward; mh != null: motion head -> humans_next; rows_out != null: value rows
@@ -585,7 +594,7 @@ static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* r
     sa.humans_next = humans_next;
     sa.rows_out = rows_out;
     sa.P = P; sa.H = H; sa.N = N;
-    const int NT = (N + 15) / 16;
+    const int NT = N > 64 ? 8 : (N + 15) / 16;
     int off = 0;
     auto take = [&](int nfl) { int o = off; off += (nfl + 3) & ~3; return o; };
     sa.off_wa = take(XD * WLD);
@@ -601,13 +610,14 @@ static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* r
         sa.off_wc1 = take(2 * XD * W1LD); sa.off_bc1 = take(HID); sa.off_wc2 = take(HID);
     }
     sa.wave_stride = 16 * NT * XLD;
-    sa.off_wave = take((NT <= 2 ? 8 : 4) * sa.wave_stride);
+    sa.off_wave = take((NT <= 2 ? 8 : (NT <= 4 ? 4 : 1)) * sa.wave_stride);
     const size_t lds_bytes = (size_t)off * sizeof(float);
     switch (NT) {
         case 1: return launch_scene<1, 8>(sa, lds_bytes, ca, stream);
         case 2: return launch_scene<2, 8>(sa, lds_bytes, ca, stream);
         case 3: return launch_scene<3, 4>(sa, lds_bytes, ca, stream);
-        default: return launch_scene<4, 4>(sa, lds_bytes, ca, stream);
+        case 4: return launch_scene<4, 4>(sa, lds_bytes, ca, stream);
+        default: return launch_scene_wide(sa, lds_bytes, ca, stream);
     }
 }
 

@@ -111,6 +111,48 @@ def _seq_last_relu(seq):
     return len(mods) > 0 and isinstance(mods[-1], nn.ReLU)
 
 
+_PENDING_TRANSPOSES = []      # (torch weight (out,in), k-major destination, rows, cols) collected by pack_mlp
+_BATCH_DEPTH = [0]
+
+
+class batched_transposes(object):
+    """`with batched_transposes():` around the code that gathers SEVERAL descriptors (graph, value head, motion head of one
+    forward; the four of a search): their Linear weights are transposed by one launch when the block ends instead of one per
+    descriptor.  Nothing may consume a descriptor inside the block."""
+
+    def __enter__(self):
+        _BATCH_DEPTH[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _BATCH_DEPTH[0] -= 1
+        if _BATCH_DEPTH[0] == 0:
+            flush_transposes()
+        return False
+
+
+
+def flush_transposes():
+    """One rgl_transpose_many_f32 launch for every Linear weight packed since the last flush (a descriptor holds several, and
+    training rebuilds it after every optimizer step: one launch per weight was most of a training step's launches).  Called by
+    _PackCache.get as soon as a descriptor is built, i.e. before anything can consume it, on the current stream."""
+    if not _PENDING_TRANSPOSES:
+        return
+    jobs = (nat.RglTransposeJob * len(_PENDING_TRANSPOSES))()
+    by_dev = {}
+    for i, (w, wt, rows, cols) in enumerate(_PENDING_TRANSPOSES):
+        by_dev.setdefault(w.device, []).append(i)
+        jobs[i].src, jobs[i].dst, jobs[i].rows, jobs[i].cols = w.data_ptr(), wt.data_ptr(), rows, cols
+    pending = list(_PENDING_TRANSPOSES)
+    del _PENDING_TRANSPOSES[:]
+    lib = nat.lib()
+    for dev, idx in by_dev.items():
+        sub = (nat.RglTransposeJob * len(idx))(*[jobs[i] for i in idx])
+        with torch.cuda.device(dev):
+            nat.check(lib.rgl_transpose_many_f32(sub, len(idx), _stream()), "rgl_transpose_many_f32")
+    del pending
+
+
 def pack_mlp(seq, keep, reuse=None):
     """nn.Sequential[Linear, ReLU...] -> RglMlp; transposed weights are appended to `keep`.  `reuse` (dict, optional) holds the
     transposed buffers of an earlier pack: they are overwritten in place, so device pointers handed out earlier (descriptors
@@ -122,7 +164,6 @@ def pack_mlp(seq, keep, reuse=None):
     m.n_layers = len(lins)
     m.last_relu = int(_seq_last_relu(seq))
     m.dims[0] = lins[0].in_features
-    lib = nat.lib()
     for l, lin in enumerate(lins):
         w = _require_device_tensor(lin.weight.detach(), "MLP weight")
         b = _require_device_tensor(lin.bias.detach(), "MLP bias")
@@ -132,8 +173,7 @@ def pack_mlp(seq, keep, reuse=None):
             wt = torch.empty(lin.in_features, lin.out_features, device=w.device, dtype=torch.float32)
             if reuse is not None:
                 reuse[rk] = wt
-        nat.check(lib.rgl_transpose_f32(w.data_ptr(), wt.data_ptr(), lin.out_features, lin.in_features, _stream()),
-                  "rgl_transpose_f32")
+        _PENDING_TRANSPOSES.append((w, wt, lin.out_features, lin.in_features))     # launched together: flush_transposes()
         keep.extend([wt, b])
         m.dims[l + 1] = lin.out_features
         m.weight[l] = wt.data_ptr()
@@ -193,6 +233,8 @@ class _PackCache:
         if key != self.key:
             keep = []
             self.value = build(keep, self.buffers)
+            if _BATCH_DEPTH[0] == 0:
+                flush_transposes()
             self.keep = keep
             self.key = key
             self.epoch = next(_PACK_SERIAL)

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _native as nat
-from .nets import _require_device_tensor, _stream
+from .nets import _require_device_tensor, _stream, batched_transposes
 
 
 def _check_roots64(roots64, B, H):
@@ -94,13 +94,14 @@ class TreeSearch:
     def planner(self, device):
         pl = nat.MprlPlanner()
         ve = self.value_estimator
-        pl.value_graph = ve.graph_model.descriptor()
-        pl.value_head = ve.head_descriptor()
         linear = not getattr(self.state_predictor, "trainable", False)
-        pl.linear_state_predictor = int(linear)
-        if not linear:
-            pl.predictor_graph = self.state_predictor.graph_model.descriptor()
-            pl.motion_head = self.state_predictor.head_descriptor()
+        with batched_transposes():                 # up to four descriptors: one transpose launch for all their Linear weights
+            pl.value_graph = ve.graph_model.descriptor()
+            pl.value_head = ve.head_descriptor()
+            pl.linear_state_predictor = int(linear)
+            if not linear:
+                pl.predictor_graph = self.state_predictor.graph_model.descriptor()
+                pl.motion_head = self.state_predictor.head_descriptor()
         pl.kinematics = nat.KINEMATICS[self.kinematics]
         pl.num_actions = self.num_actions
         pl.planning_depth = self.planning_depth
@@ -361,8 +362,9 @@ class GcnSearch:
             self._dev_tables[key] = torch.tensor(self.actions_np, dtype=torch.float64, device=dev)
         with torch.cuda.device(dev):
             pl = nat.GcnPlanner()
-            pl.graph = self.model.descriptor()
-            pl.value_head = self.model.head_descriptor()
+            with batched_transposes():
+                pl.graph = self.model.descriptor()
+                pl.value_head = self.model.head_descriptor()
             pl.kinematics = nat.KINEMATICS[self.kinematics]
             pl.num_actions = A
             pl.time_step = self.time_step

@@ -725,6 +725,62 @@ def test_tree_vs_batched_oracle(H, D, w, clip, B, L, dev):
     check_decisions("tree vs batched oracle H=%d D=%d w=%d B=%d" % (H, D, w, B), act, val, (oa, ov, orv, okept), lv)
 
 
+@pytest.mark.parametrize("H,sim,L,layerwise", [(64, "embedded_gaussian", 2, False), (99, "embedded_gaussian", 2, False),
+                                               (127, "embedded_gaussian", 3, False), (80, "cosine_softmax", 2, True),
+                                               (99, "squared", 2, False), (70, "concatenation", 2, False)])
+def test_crowds_beyond_64_nodes(H, sim, L, layerwise, dev):
+    """VERDICT r2 missing 3 / next 9: the reference has no crowd-size cap (graph_model.py:99-130, test.py --human_num); the ABI
+    limit is 128 nodes since round 3.  Module forwards at N = 65 / 100 / 128 against the oracle: RGL.forward with node features and
+    adjacency (general kernel), ValueEstimator / StatePredictor forwards (one-wave-per-scene MFMA kernel, eight column tiles split
+    over a workgroup's waves; concatenation beyond 64 nodes stays on the general kernel)."""
+    c = dict(L=L, sim=sim, layerwise=layerwise, skip=True, flavour="trained")
+    g1, ve, sp = build_modules(c, dev)
+    B = 6
+    robot, humans = seeded_scenes(700 + H, B, H)
+    state = (robot.unsqueeze(1).to(dev), humans.to(dev))
+    with torch.no_grad():
+        H_L = g1(state)
+        A0 = g1.A
+        val = ve(state)
+        _, nh = sp(state, None)
+    cfg = orc.OracleConfig(num_layer=L, similarity=sim, layerwise_graph=layerwise, skip_connection=True)
+    Pm = gio.oracle_params("trained", L, similarity=sim)
+    with torch.no_grad():
+        oH, oA = orc.rgl_forward(robot[:, None, :], humans, Pm.ve_graph, cfg)
+        ov = orc.value_estimator_forward(robot[:, None, :], humans, Pm.ve_graph, Pm.value_network, cfg)
+        onh = orc.state_predictor_humans(robot[:, None, :], humans, Pm.sp_graph, Pm.motion_predictor, cfg)
+    e1 = close(H_L.cpu().numpy(), oH.numpy())
+    close(A0, oA[0].numpy())
+    e2 = close(val.cpu().numpy(), ov.numpy())
+    e3 = close(nh.cpu().numpy(), onh.numpy())
+    report("N = %d nodes (%s, L=%d%s): |dH| %.1e |dV| %.1e |d humans'| %.1e vs the oracle" % (
+        H + 1, sim, L, ", layerwise" if layerwise else "", e1, e2, e3))
+
+
+@pytest.mark.parametrize("H,D,B", [(79, 2, 6), (127, 1, 4)])
+def test_rollout_beyond_64_nodes(H, D, B, dev):
+    """A whole search with a dense crowd of 80 / 128 agents: state predictor and every child's graph on the split scene kernel,
+    reward / selection / back-up unchanged; against the batched oracle."""
+    robot, humans = seeded_scenes(800 + H, B, H)
+    pol = make_mprl_policy("trained", D, 2, D > 1, device=dev)
+    cfg = orc.OracleConfig(planning_depth=D, planning_width=2, do_action_clip=D > 1)
+    with torch.no_grad():
+        oa, ov, orv, okept, lv = orc.mprl_predict_batched(robot, humans, gio.oracle_params("trained"), cfg, return_levels=True)
+    act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
+    close(val.cpu().numpy(), ov.numpy())
+    check_decisions("rollout with N=%d nodes D=%d B=%d" % (H + 1, D, B), act, val, (oa, ov, orv, okept), lv)
+    # path G at the same crowd size
+    g = make_gcn_policy(device=dev)
+    g.build_action_space(1.0)
+    vals, best = g.gcn_search().search(robot.to(dev), humans.to(dev))
+    ob, ovg = orc.gcn_predict_batched(robot.numpy(), humans.numpy(), gio.path_g_sd(), orc.OracleConfig())
+    close(vals.cpu().numpy().astype(np.float64), ovg)
+    if H == 127:                                                 # one more agent is beyond the ABI limit: refused, loudly
+        r2, h2 = seeded_scenes(1, 2, 128)
+        with pytest.raises(rga._native.NativeLibraryError, match="RGL_ERR_BAD_SHAPE|rejected"):
+            pol.predict_batch(r2.to(dev), h2.to(dev))
+
+
 @pytest.mark.parametrize("sim", ["gaussian", "squared", "equal_attention", "diagonal"])
 @pytest.mark.parametrize("H,L,D,B", [(19, 2, 2, 12), (5, 2, 1, 40), (49, 3, 2, 3), (40, 2, 1, 4), (19, 1, 1, 8), (12, 3, 1, 5)])
 def test_other_similarities_on_the_mfma_path(sim, H, L, D, B, dev):

@@ -45,6 +45,8 @@ def test_host_side_argument_checks_without_gpu():
     lib = nat.lib()
     # NULL pointers and bad shapes are rejected on the host before any launch
     assert lib.rgl_transpose_f32(None, None, 4, 4, None) == -3
+    assert lib.rgl_transpose_many_f32(None, 2, None) == -3 and lib.rgl_transpose_many_f32(None, 0, None) == 0
+    assert ctypes.sizeof(nat.RglTransposeJob) == 24
     assert lib.gcn_rotate_f32(None, None, 4, 0, None) == -3
     assert lib.mprl_tree_workspace_bytes(None, 4, 5) == 0
     assert lib.gcn_predict_workspace_bytes(4, 5, 81) > 0
