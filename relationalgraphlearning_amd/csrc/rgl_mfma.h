@@ -147,11 +147,15 @@ __device__ __forceinline__ float plain_weight(int sim, float s, int i, int j) {
     return sim == SIM_SQUARED ? s * s : (sim == SIM_EQUAL ? 1.f : (i == j ? 1.f : 0.f));
 }
 
+// 0 / 1: the two shipped value heads (register-resident MFMA chains, robot_head_kernel<D1,D2,D3>); 2: any other head
+// x_dim -> ... -> 1 within the ABI limits (robot_head_any_kernel: MFMA with run-time tile loops, activations in LDS)
 inline int head_variant(const RglMlp& h) {
-    if (h.n_layers != 4 || h.last_relu || h.dims[0] != XD || h.dims[4] != 1) return -1;
-    if (h.dims[1] == 32 && h.dims[2] == 100 && h.dims[3] == 100) return 0;     // ValueEstimator default
-    if (h.dims[1] == 150 && h.dims[2] == 100 && h.dims[3] == 100) return 1;    // gcn.ValueNetwork default
-    return -1;
+    if (h.n_layers < 1 || h.n_layers > RGL_MAX_MLP_LAYERS || h.last_relu || h.dims[0] != XD || h.dims[h.n_layers] != 1) return -1;
+    if (h.n_layers == 4 && h.dims[1] == 32 && h.dims[2] == 100 && h.dims[3] == 100) return 0;     // ValueEstimator default
+    if (h.n_layers == 4 && h.dims[1] == 150 && h.dims[2] == 100 && h.dims[3] == 100) return 1;    // gcn.ValueNetwork default
+    for (int l = 1; l < h.n_layers; ++l)
+        if (h.dims[l] < 1 || h.dims[l] > RGL_MAX_WIDTH) return -1;
+    return 2;
 }
 
 inline bool fast_path_enabled() {
