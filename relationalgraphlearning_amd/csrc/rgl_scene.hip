@@ -84,6 +84,12 @@ __global__ __launch_bounds__(kThreads, 2) void row_mlp2_pair_kernel(const RowMlp
 }
 
 struct SceneArgs {
+    // EMB kernels (few scenes: the embedding launch would cost more than its work): raw state rows + the two embedding MLPs
+    const float* robot_rows;           // [P][9]
+    const float* human_rows;           // [n_crowds][H][5]
+    const float *er_w1, *er_b1, *er_w2, *er_b2;      // w_r, k-major [9][64], [64], [64][32], [32]
+    const float *eh_w1, *eh_b1, *eh_w2, *eh_b2;      // w_h
+    int off_er, off_eh;                // LDS: fragment sets of the two MLPs (kRowMlpSetFloats each)
     const float* xh_rows;              // [n_crowds][H][32]  human embeddings
     const float* x0_rows;              // [P][32]            robot embeddings
     int crowds_per;                    // scene s uses crowd s / crowds_per
@@ -118,7 +124,11 @@ constexpr int M2LD = 20;   // LDS row stride of the [64][5 -> 16] motion output 
 // workgroup barriers where a phase needs every row): a scene is one serial chain of ~70 MFMAs per column tile with a softmax in
 // the middle, and with few scenes (the upper tree levels, dense crowds: 256-512 scenes of 50 agents on 256 CUs) nothing else hides
 // that chain.  With thousands of scenes the unsplit form -- no barriers, the same MFMA count -- is as fast or faster.
-template <int NT, int SK, int WAVES, bool CH, bool SPLIT>
+// EMB: the wave computes the embeddings of its node tiles itself (w_r on the robot row, w_h on the human rows: the MFMA chains of
+// row_mlp2_tiles) instead of reading rows a separate launch prepared -- with few scenes that launch is ~5 us of latency for ~1 us
+// of work (and a round trip through HBM); sibling scenes repeat their crowd's human embeddings, which only matters when the
+// kernel is throughput-bound (many scenes: the launcher keeps the two-launch form there).
+template <int NT, int SK, int WAVES, bool CH, bool SPLIT, bool EMB = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneArgs a, const ChildrenArgs ca, int grid_scene) {
     static_assert(!SPLIT || (SK != 3 && NT > 1 && WAVES % NT == 0), "split scenes: whole scenes per workgroup, no pair-MLP similarity");
     constexpr int kSceneThreads = WAVES * 64;
@@ -198,6 +208,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
             fill_matrix<2 * XD, 2 * XD, HID, W1LD, kSceneThreads>(w + a.off_wc1, a.wc1, tid);
             for (int i = tid; i < HID; i += kSceneThreads) { w[a.off_bc1 + i] = a.bc1[i]; w[a.off_wc2 + i] = a.wc2[i]; }
         }
+        if constexpr (EMB) {
+            constexpr int F1 = 0, F2 = F1 + 4 * 1 * 4 * 64, B1 = F2 + 2 * 4 * 4 * 64, B2 = B1 + HID;
+            fill_frags<9, HID, kSceneThreads>(w + a.off_er + F1, a.er_w1, tid);
+            fill_frags<HID, XD, kSceneThreads>(w + a.off_er + F2, a.er_w2, tid);
+            fill_bias<HID>(w + a.off_er + B1, a.er_b1, tid, kSceneThreads);
+            fill_bias<XD>(w + a.off_er + B2, a.er_b2, tid, kSceneThreads);
+            fill_frags<5, HID, kSceneThreads>(w + a.off_eh + F1, a.eh_w1, tid);
+            fill_frags<HID, XD, kSceneThreads>(w + a.off_eh + F2, a.eh_w2, tid);
+            fill_bias<HID>(w + a.off_eh + B1, a.eh_b1, tid, kSceneThreads);
+            fill_bias<XD>(w + a.off_eh + B2, a.eh_b2, tid, kSceneThreads);
+        }
     }
     __syncthreads();
     // scene of slot k in pass i: blockIdx + grid_scene * k + i * grid_scene * kSlots (partial round: one scene per workgroup).  SPLIT:
@@ -207,6 +228,46 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
         const bool active = sc_raw < a.P;
         const int sc = active ? sc_raw : a.P - 1;
         // node features of this scene: row 0 = robot, rows 1..H = its crowd, rows >= N zero
+        if constexpr (EMB) {
+            constexpr int F1 = 0, F2 = F1 + 4 * 1 * 4 * 64, B1 = F2 + 2 * 4 * 4 * 64, B2 = B1 + HID;
+            const float* er = lds + a.off_er;
+            const float* eh = lds + a.off_eh;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int node = 16 * (ct + ctb) + n;
+                const bool human = node >= 1 && node < N;
+                const float* hsrc = a.human_rows + ((size_t)(sc / a.crowds_per) * H + (human ? node - 1 : 0)) * 5;
+                f32x4 in[1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int feat = tile_feature<5>(0, q, r);
+                    in[0][r] = (human && feat < 5) ? hsrc[feat] : 0.f;
+                }
+                f32x4 hh[4], oh[2];
+                layer_mfma<5, HID, true>(eh + F1, in, hh, lane, eh + B1);
+                relu_tiles<HID>(hh);
+                layer_mfma<HID, XD, true>(eh + F2, hh, oh, lane, eh + B2);
+                relu_tiles<XD>(oh);
+                if (ct + ctb == 0) {                              // the tile that holds the robot: its row through w_r
+                    const float* rsrc = a.robot_rows + (size_t)sc * 9;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int feat = tile_feature<9>(0, q, r);
+                        in[0][r] = (n == 0 && feat < 9) ? rsrc[feat] : 0.f;
+                    }
+                    f32x4 orr[2];
+                    layer_mfma<9, HID, true>(er + F1, in, hh, lane, er + B1);
+                    relu_tiles<HID>(hh);
+                    layer_mfma<HID, XD, true>(er + F2, hh, orr, lane, er + B2);
+                    relu_tiles<XD>(orr);
+                    if (n == 0) { oh[0] = orr[0]; oh[1] = orr[1]; }
+                }
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+                    *reinterpret_cast<f32x4*>(&Hs[node * XLD + 16 * ot + 4 * q]) = node < N ? oh[ot] : zero4();
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
         const float* xr = a.x0_rows + (size_t)sc * XD;
         const float* xh = a.xh_rows + (size_t)(sc / a.crowds_per) * H * XD;
         for (int idx = lane; idx < 16 * NCT * (XD / 4); idx += 64) {
@@ -215,6 +276,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
             if (row == 0) val = *reinterpret_cast<const f32x4*>(xr + c4);
             else if (row < N) val = *reinterpret_cast<const f32x4*>(xh + (size_t)(row - 1) * XD + c4);
             *reinterpret_cast<f32x4*>(&Hs[row * XLD + c4]) = val;
+        }
         }
         if (SPLIT) __syncthreads();
         // adjacency of the node features currently in Hs, transposed and in B-operand order: pr[ct][jt][r] = A[i][j] for
@@ -522,10 +584,10 @@ inline int scene_split_below(int nt) {
     return nt == 2 ? 3072 : 4096;
 }
 
-template <int NT, int SK, int WAVES, bool SPLIT = false>
+template <int NT, int SK, int WAVES, bool SPLIT = false, bool EMB = false>
 int launch_scene_k(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* children, hipStream_t st) {
     if constexpr (!SPLIT && SK != 3 && (NT == 2 || NT == 4)) {
-        if (sa.P < scene_split_below(NT)) return launch_scene_k<NT, SK, 8, true>(sa, lds_bytes, children, st);
+        if (sa.P < scene_split_below(NT)) return launch_scene_k<NT, SK, 8, true, EMB>(sa, lds_bytes, children, st);
     }
     constexpr int kSlots = SPLIT ? WAVES / NT : WAVES;
     int grid = (sa.P + kSlots - 1) / kSlots;
@@ -538,7 +600,7 @@ int launch_scene_k(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* ch
         const long long blocks = ((long long)ca.P * ca.A + WAVES * 64 - 1) / (WAVES * 64);
         grid_children = (int)(blocks < 2048 ? blocks : 2048);
     }
-    auto kern = children ? scene_graph_kernel<NT, SK, WAVES, true, SPLIT> : scene_graph_kernel<NT, SK, WAVES, false, SPLIT>;
+    auto kern = children ? scene_graph_kernel<NT, SK, WAVES, true, SPLIT, EMB> : scene_graph_kernel<NT, SK, WAVES, false, SPLIT, EMB>;
     if (lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_bytes));
@@ -558,6 +620,12 @@ inline int launch_scene_wide(const SceneArgs& sa, size_t lds_bytes, const Childr
 
 template <int NT, int WAVES>
 int launch_scene(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* children, hipStream_t st) {
+    if constexpr (NT == 1) {
+        if (sa.robot_rows) return launch_scene_k<1, 0, 8, false, true>(sa, lds_bytes, children, st);           // embeddings inside
+    }
+    if constexpr (NT == 2 || NT == 4) {
+        if (sa.robot_rows) return launch_scene_k<NT, 0, 8, true, true>(sa, lds_bytes, children, st);          // ... and split scenes
+    }
     if (sa.sim == SIM_SOFTMAX) return launch_scene_k<NT, 0, WAVES>(sa, lds_bytes, children, st);
     if (sa.sim == SIM_COSINE || sa.sim == SIM_COSINE_SOFTMAX) return launch_scene_k<NT, 2, WAVES>(sa, lds_bytes, children, st);
     if (sa.sim == SIM_CONCAT) return launch_scene_k<NT, 3, WAVES>(sa, lds_bytes, children, st);
@@ -580,9 +648,22 @@ static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* r
                              int H, float* humans_next, float* rows_out, float* x0_rows, float* xh_rows,
                              const ChildrenArgs* ca, hipStream_t stream, const ChildrenArgs* embed_children = nullptr) {
     const int N = H + 1, n_crowds = P / crowds_per;
-    int rc = launch_row_mlp2_pair(g.w_r, robot, x0_rows, P, g.w_h, humans, xh_rows, n_crowds * H, stream, embed_children);
-    if (rc) return rc;
+    const int NT0 = N > 64 ? 8 : (N + 15) / 16;
+    // few scenes of the shipped shape: the scene kernel embeds its own node tiles (one launch for the level instead of two)
+    static const bool emb_off = [] { const char* e = getenv("RGL_SCENE_EMBED_INSIDE"); return e && e[0] == '0'; }();
+    const bool embed_inside = !emb_off && !embed_children && g.w_r.dims[0] == 9 && scene_similarity_mode(g) == SIM_SOFTMAX &&
+                              (NT0 == 1 || NT0 == 2 || NT0 == 4) && P <= 512 &&     // measured: +1.5-3 % up to 512 scenes, -2 % at 1-2 k (sibling scenes repeat their crowd's rows)
+                              (NT0 == 1 || P < scene_split_below(NT0));       // the split form (see launch_scene)
+    if (!embed_inside) {
+        int rc = launch_row_mlp2_pair(g.w_r, robot, x0_rows, P, g.w_h, humans, xh_rows, n_crowds * H, stream, embed_children);
+        if (rc) return rc;
+    }
     SceneArgs sa;
+    sa.robot_rows = embed_inside ? robot : nullptr;
+    sa.human_rows = embed_inside ? humans : nullptr;
+    sa.er_w1 = g.w_r.weight[0]; sa.er_b1 = g.w_r.bias[0]; sa.er_w2 = g.w_r.weight[1]; sa.er_b2 = g.w_r.bias[1];
+    sa.eh_w1 = g.w_h.weight[0]; sa.eh_b1 = g.w_h.bias[0]; sa.eh_w2 = g.w_h.weight[1]; sa.eh_b2 = g.w_h.bias[1];
+    sa.off_er = sa.off_eh = 0;
     sa.xh_rows = xh_rows; sa.x0_rows = x0_rows; sa.crowds_per = crowds_per;
     sa.wa = bilinear_wa(g);
     sa.sim = scene_similarity_mode(g);
@@ -608,6 +689,10 @@ static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* r
     if (sa.sim == SIM_CONCAT) {
         sa.wc1 = g.w_a_mlp.weight[0]; sa.bc1 = g.w_a_mlp.bias[0]; sa.wc2 = g.w_a_mlp.weight[1]; sa.bc2 = g.w_a_mlp.bias[1];
         sa.off_wc1 = take(2 * XD * W1LD); sa.off_bc1 = take(HID); sa.off_wc2 = take(HID);
+    }
+    if (embed_inside) {
+        sa.off_er = take(kRowMlpSetFloats);
+        sa.off_eh = take(kRowMlpSetFloats);
     }
     sa.wave_stride = 16 * NT * XLD;
     sa.off_wave = take((NT <= 2 ? 8 : (NT <= 4 ? 4 : 1)) * sa.wave_stride);

@@ -1274,7 +1274,7 @@ def test_no_cpu_fallback_and_no_silent_autograd(dev):
     with pytest.raises(nat.NativeLibraryError):
         out.sum().backward()                                  # ... but N = 64 activations of the backward exceed one CU's LDS: loud
     with torch.no_grad(), pytest.raises(nat.NativeLibraryError):
-        ve((r.to(dev), torch.zeros(1, 64, 5, device=dev)))    # N = 65 > RGL_MAX_NODES
+        ve((r.to(dev), torch.zeros(1, 128, 5, device=dev)))   # N = 129 > RGL_MAX_NODES (128 since round 3)
 
 
 # ---------------------------------------------------------------------------------------------------
