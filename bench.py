@@ -28,9 +28,9 @@ of the per-shard (action, value) rows.  Scaling readings (`--scaling`):
 With more than one rank the line also carries `multi_gpu`: every rank's search time per step and the exchange time per
 step, measured separately (un-pipelined) after the timed region, and `ranks_seen` = dist.get_world_size().
 
-`--graph auto|on|off`: replay the rank's whole search from a captured hipGraph (auto: when the rank holds <= 512 roots,
-where a step is short enough for the host's ~12 launches to matter); `step_ms_device` (HIP events between steps) against
-`ms_per_step` (wall clock) shows whether the host is the limiter.
+`--graph auto|on|off`: replay the rank's whole search from a captured hipGraph (auto: depth-1 searches of <= 512 roots per rank,
+the one case where it measured faster); `step_ms_device` (HIP events between steps) against `ms_per_step` (wall clock) shows
+whether the host is the limiter.
 
 RGL_BENCH_STUB_SEARCH=1 replaces the device search by a trivial CPU function over gloo: a test switch for the launcher
 and the exchange logic on machines without GPUs (tests/test_bench_launcher.py).  The line it prints says so and is not a
@@ -245,13 +245,14 @@ def parse_args(argv=None):
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--depth", type=int, default=2)
     ap.add_argument("--width", type=int, default=2)
-    ap.add_argument("--contraction", choices=("f32", "f16"), default="f32",
-                    help="f16: f16-input MFMA for the dense middle-layer products (BASELINE configs[4]; needs --layers 3)")
+    ap.add_argument("--contraction", choices=("f32", "f16", "f16x3"), default="f32",
+                    help="f16: f16-input MFMA for the dense middle-layer products (BASELINE configs[4]; needs --layers 3); "
+                         "f16x3: the value head's products as three split-f16 MFMA terms (f32-equivalent to ~2^-21, L = 2, N <= 32)")
     ap.add_argument("--scenes", choices=("clearance", "uniform"), default="clearance",
                     help="human placement of the synthetic scenes: SURVEY 8(d)'s clearance re-draw (default) or the round-1/2 "
                          "uniform draw")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
-                    help="replay the rank's search from a captured hipGraph (auto: when the rank holds <= 512 roots)")
+                    help="replay the rank's search from a captured hipGraph (auto: depth-1 searches of <= 512 roots per rank)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 = skip)")
     return ap.parse_args(argv)
 
@@ -312,7 +313,11 @@ class Leg:
             self.roots_per_rank = [per] * world
         self.B, self.total_roots = self.robot_cpu.shape[0], total_roots
         self.robot, self.humans = self.robot_cpu.to(device), self.humans_cpu.to(device)
-        self.use_graph = (not STUB) and (args.graph == "on" or (args.graph == "auto" and 0 < max(self.roots_per_rank) <= 512))
+        # measured (profiles/r03_a_share_regime.jsonl): a replayed search is 3-5 % SLOWER than the direct C-ABI call at depth 2 / 3
+        # (0.116 vs 0.111 ms at 256 roots -- the host is not the limiter: wall = device time in both forms) and 7 % faster only
+        # for the depth-1 search (0.0645 vs 0.0693 ms at 512 roots): auto = depth 1 with <= 512 roots per rank
+        self.use_graph = (not STUB) and (args.graph == "on" or (args.graph == "auto" and args.depth == 1
+                                                                and 0 < max(self.roots_per_rank) <= 512))
         self.sharded = rga.ShardedRollout(self._search_fn, search_into=self._search_into)
         self.graphs, self.graph_last = {}, None
         if self.use_graph and self.B > 0:                 # capture BEFORE the first collective of this leg is enqueued
@@ -473,6 +478,14 @@ def children_roofline(args, ts, device, N, H, last):
     flop_per_scene, kernel_path = children_flops_per_scene(N, args.layers, A)
     achieved = scenes_per_launch * flop_per_scene / (kern_ms * 1e-3) / 1e12
     peak, peak_note = FP32_PEAK_TFLOPS, "fp32 vector == f32-MFMA peak (the two do not co-execute on gfx950)"
+    if args.contraction == "f16x3":
+        # the value head's products (last GCN layer on the robot row + 32-32-100-100) run on the f16 matrix pipe as THREE split
+        # terms each, i.e. at a third of the dense f16 MFMA peak; the rest at the fp32 rate: time-weighted peak
+        dense = 2 * 32 * 32 + 2 * (32 * 32 + 32 * 100 + 100 * 100)
+        x3_peak = F16_MFMA_PEAK_TFLOPS / 3.0
+        peak = flop_per_scene / (dense / x3_peak + (flop_per_scene - dense) / FP32_PEAK_TFLOPS)
+        peak_note = "blend: %.0f%% of the FLOPs as 3 split-f16 MFMA terms (a third of the dense f16 MFMA peak = %.0f), the rest at the fp32 peak (%.1f)" % (
+            100.0 * dense / flop_per_scene, x3_peak, FP32_PEAK_TFLOPS)
     if args.contraction == "f16":
         # the two dense middle-layer products run on the f16 matrix pipe, the rest at the fp32 rate: time-weighted peak
         dense = 2 * N * 32 * 32 + 2 * N * N * 32
@@ -600,6 +613,33 @@ def main():
             ts.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
         roofline = children_roofline(args, ts, device, N, H, leg.graph_last)
 
+    # ---- auxiliary reading (never `value`): the same workload with the value head's dense products as three split-f16 MFMA terms
+    # (contraction_dtype "f16x3": f32-equivalent to ~2^-21 per product, on the f16 matrix pipe), timed the same way, with its
+    # deviation from the f32 kernels measured on this very batch
+    x3 = None
+    if (not STUB and world == 1 and args.contraction == "f32" and args.layers == 2 and N <= 32 and B > 0
+            and os.environ.get("RGL_BENCH_NO_F16X3") != "1"):
+        import copy
+        a3 = copy.copy(args)
+        a3.contraction = "f16x3"
+        pol3 = make_policy(a3, device)
+        ts3 = pol3.tree_search()
+        leg3 = Leg(a3, ts3, device, world, rank, main_leg[1], main_leg[2], None)
+        e3, s3 = leg3.timed(args.steps, args.warmup, INIT_STEPS)
+        o32 = ts.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
+        o3 = ts3.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
+        r3 = children_roofline(a3, ts3, device, N, H, None)
+        x3 = {"value": per_root * total_roots * args.steps / e3, "ms_per_step": e3 / args.steps * 1e3,
+              "step_ms_device_median": s3[len(s3) // 2],
+              "max_abs_dV_vs_f32_kernels": float((o3["best_value"] - o32["best_value"]).abs().max()),
+              "identical_decisions": float((o3["best_action"] == o32["best_action"]).float().mean()),
+              "roofline": {k: r3[k] for k in ("achieved", "peak", "frac", "peak_note", "launch_ms", "unit")},
+              "note": "contraction_dtype f16x3 (MprlPlanner.contraction_dtype = RGL_CONTRACT_F16X3): same search, the value head's "
+                      "products W^T a = W_hi a_hi + W_hi a_lo + W_lo a_hi on v_mfma_f32_16x16x32_f16 with f32 accumulation over "
+                      "power-of-two-scaled operands; reported beside the f32 line, never as `value`"}
+        del leg3
+        ts.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
+
     metric = "agent-graph forward evals/sec (N=%d, %d-layer GCN, depth-%d tree)" % (N, args.layers, args.depth)
     result = {
         "metric": ("STUB SEARCH, NOT A MEASUREMENT: " if STUB else "") + metric,
@@ -607,8 +647,10 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": main_leg[0],
         "step_ms_device": {"p10": step_ms[len(step_ms) // 10], "median": step_ms[len(step_ms) // 2],
                            "p90": step_ms[(len(step_ms) * 9) // 10], "note": "rank 0, HIP events between steps"},
-        "vs_baseline": None, "dtype": "f32" if args.contraction == "f32" else "f16 inputs / f32 accumulate (middle-layer "
-        "products only; everything else f32)", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"f32": "f32", "f16": "f16 inputs / f32 accumulate (middle-layer products only; everything else f32)",
+                                       "f16x3": "f32 (value-head products as three split-f16 MFMA terms with f32 accumulate, ~2^-21 "
+                                                "relative per product; everything else f32)"}[args.contraction],
+        "data": "synthetic",
         "config": {"workload": "%s: N=%d agents (H=%d humans), %d-layer GCN, depth-%d width-%d "
                                "action-tree rollout, %s" % (workload_name(N, args, main_leg[0]), N, H, args.layers, args.depth, args.width,
                                                             ("%d root scenes per GPU" % B) if main_leg[0] == "weak" else
@@ -622,6 +664,8 @@ def main():
                    "exchange": "all_gather_into_tensor of (roots_per_gpu,2) fp32 per rank" if world > 1 else "none"},
         "roofline": roofline,
     }
+    if x3 is not None:
+        result["f16x3"] = x3
     if STUB:
         result["stub_search"] = True
     if weak is not None:

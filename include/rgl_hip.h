@@ -55,6 +55,7 @@ extern "C" {
 #define RGL_ERR_WORKSPACE (-4)      /* workspace too small (see mprl_tree_workspace_bytes)     */
 #define RGL_CONTRACT_F32 0
 #define RGL_CONTRACT_F16 1
+#define RGL_CONTRACT_F16X3 2        /* ABI 4: f32-equivalent dense products as three split-f16 MFMA terms */
 
 #define RGL_ERR_LDS (-5)            /* configuration does not fit the 160 KiB LDS of one CU    */
 
@@ -220,7 +221,13 @@ typedef struct MprlPlanner {
     int contraction_dtype;      /* RGL_CONTRACT_F32 (reference arithmetic) | RGL_CONTRACT_F16: f16 inputs, f32   *
                                  * accumulate for the dense products of the middle GCN layer of the children's  *
                                  * value graph (BASELINE configs[4]); RGL_ERR_BAD_MODE when the configuration   *
-                                 * has no such kernel (needs embedded_gaussian, L = 3, N <= 64)                 */
+                                 * has no such kernel (needs embedded_gaussian, L = 3, N <= 64)                 *
+                                 * | RGL_CONTRACT_F16X3 (ABI 4): the value head's dense products of the shipped *
+                                 * shape (L = 2, N <= 32, head 32-100-100-1, softmax similarities) computed as   *
+                                 * W_hi a_hi + W_hi a_lo + W_lo a_hi with f16 halves of power-of-two-scaled      *
+                                 * operands and f32 accumulation: ~2^-21 relative per product (f32 rounding is   *
+                                 * 2^-24), 5x the MFMA rate of the f32 form, any finite input.  Where no kernel   *
+                                 * offers it, plain f32 runs (never less accurate), nothing is refused.           */
     double time_step;
     double gamma_bar;           /* gamma^(time_step * v_pref), get_normalized_gamma (:104-105)  */
     const double* actions;      /* device [A][2] float64, table of build_action_space (:155-190)*/

@@ -84,9 +84,10 @@ int launch_head_rows(const RglGraph* g, const RglMlp* head, const float* rows, i
 int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, int H, const float* child_robot,
                           const float* humans_next, float* child_value, void* workspace, size_t workspace_bytes,
                           int image_ready, hipStream_t stream, const float* caller_image = nullptr,
-                          const void* tail = nullptr, size_t tail_bytes = 0, int* tail_done = nullptr);
+                          const void* tail = nullptr, size_t tail_bytes = 0, int* tail_done = nullptr, int hx = 0);
+// hx: the value head as f16-split MFMAs (RGL_CONTRACT_F16X3): the image then holds f16 (hi, lo) fragments for that kernel only
 int pack_children_images(const RglGraph* g, const RglMlp* head, int P, int A, int H, void* workspace, size_t workspace_bytes,
-                         hipStream_t stream);               // P = the largest launch; 1 = the fused kernel does not apply
+                         hipStream_t stream, int hx = 0);   // P = the largest launch; 1 = the fused kernel does not apply
 size_t fused_children_workspace_bytes(int P, int A, int H);
 const float* fused_workspace_image(const void* workspace, size_t workspace_bytes);   // where pack_children_images put the image
 int launch_value_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,

@@ -31,7 +31,10 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
     const int A = pl->num_actions;
     const int hv = head_variant(pl->value_head);
     const bool want_f16 = pl->contraction_dtype == RGL_CONTRACT_F16;
-    if (pl->contraction_dtype != RGL_CONTRACT_F32 && !want_f16) return RGL_ERR_BAD_MODE;
+    // RGL_CONTRACT_F16X3: f32-equivalent products on the f16 matrix pipe (three split-f16 terms) where a kernel offers them -- the
+    // fused kernel's value head; every other kernel computes plain f32, which is at least as accurate, so nothing is refused
+    const bool want_x3 = pl->contraction_dtype == RGL_CONTRACT_F16X3;
+    if (pl->contraction_dtype != RGL_CONTRACT_F32 && !want_f16 && !want_x3) return RGL_ERR_BAD_MODE;
     const bool staged = hv >= 0 && workspace && workspace_bytes >= value_children_workspace_bytes(pl, P, H);
     // stage 1, in order of preference: rank-1 (L = 2, N <= 32), shared-crowd deep (L in {2,3}, N <= 60), tiles (softmax
     // similarities, any depth, N <= 64); everything else, or a head without a stage-2 kernel: the general kernel
@@ -39,12 +42,12 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
     if (staged && !want_f16) {
         // one fused kernel over 16-child tiles (L = 2, N <= 32, default head): values come out directly, no stage 2
         rc = launch_fused_children(&pl->value_graph, &pl->value_head, P, A, H, child_robot, humans_next, child_value, workspace,
-                                   workspace_bytes, image_ready, stream, pl->children_image, tail, tail_bytes, tail_done);
+                                   workspace_bytes, image_ready, stream, pl->children_image, tail, tail_bytes, tail_done, want_x3);
         if (rc != 1) return rc;
     }
     // packed weight image of the value estimator (the caller's, or this search's at the end of the workspace): the two-stage pair
     // copies its weight images from it instead of building them from the raw matrices (most of a small launch)
-    const float* image = !staged ? nullptr
+    const float* image = (!staged || want_x3) ? nullptr          // (an f16-split image is in the fused kernel's layout only)
                          : pl->children_image ? pl->children_image
                          : image_ready ? fused_workspace_image(workspace, workspace_bytes) : nullptr;
     if (staged) {

@@ -78,11 +78,12 @@ constexpr int kFusedWaves = 8;
 
 // h = relu(t W_last)(+hprev), value head 32 -> D1 -> D2 -> D3 -> 1 for the 16 children of a tile (lane (n, q): child n, D-layout
 // registers); returns the value of child n in every lane of its column (without the last bias)
-template <class LO, int D1, int D2, int D3, bool SKIP>
+template <class LO, int D1, int D2, int D3, bool SKIP, bool HX = false>
 __device__ __forceinline__ float head_chain(const float* lds, const f32x4 (&tin)[2], const f32x4 (&hp)[2], int lane) {
     const int q = lane >> 4;
     f32x4 h[2];
-    layer_mfma<XD, XD, false>(lds + LO::f_last, tin, h, lane);
+    if constexpr (HX) layer_mfma_h<XD, XD, false>(lds + LO::f_last, tin, h, lane, nullptr, lds[LO::hs + 0]);
+    else layer_mfma<XD, XD, false>(lds + LO::f_last, tin, h, lane);
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -92,13 +93,16 @@ __device__ __forceinline__ float head_chain(const float* lds, const f32x4 (&tin)
             h[ot][r] = x;
         }
     f32x4 a1[Tiles<D1>::v];
-    layer_mfma<XD, D1, true>(lds + LO::f1, h, a1, lane, lds + LO::b1);
+    if constexpr (HX) layer_mfma_h<XD, D1, true>(lds + LO::f1, h, a1, lane, lds + LO::b1, lds[LO::hs + 1]);
+    else layer_mfma<XD, D1, true>(lds + LO::f1, h, a1, lane, lds + LO::b1);
     relu_tiles<D1>(a1);
     f32x4 a2[Tiles<D2>::v];
-    layer_mfma<D1, D2, true>(lds + LO::f2, a1, a2, lane, lds + LO::b2);
+    if constexpr (HX) layer_mfma_h<D1, D2, true>(lds + LO::f2, a1, a2, lane, lds + LO::b2, lds[LO::hs + 2]);
+    else layer_mfma<D1, D2, true>(lds + LO::f2, a1, a2, lane, lds + LO::b2);
     relu_tiles<D2>(a2);
     f32x4 a3[Tiles<D3>::v];
-    layer_mfma<D2, D3, true>(lds + LO::f3, a2, a3, lane, lds + LO::b3);
+    if constexpr (HX) layer_mfma_h<D2, D3, true>(lds + LO::f3, a2, a3, lane, lds + LO::b3, lds[LO::hs + 3]);
+    else layer_mfma<D2, D3, true>(lds + LO::f3, a2, a3, lane, lds + LO::b3);
     relu_tiles<D3>(a3);
     float v = 0.f;
 #pragma unroll
@@ -111,11 +115,12 @@ __device__ __forceinline__ float head_chain(const float* lds, const f32x4 (&tin)
 }
 
 // HR >= N: human rows of UW held in registers (padded rows contribute exactly 0); SOFT: softmax row normalisation
-template <int HR, int NT, bool SKIP, bool SOFT, int D1, int D2, int D3>
+// HX: the value head's dense products as f16-split MFMAs (layer_mfma_h; MprlPlanner::contraction_dtype = RGL_CONTRACT_F16X3)
+template <int HR, int NT, bool SKIP, bool SOFT, int D1, int D2, int D3, bool HX = false>
 __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const FusedArgs a) {
     const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    using LO = FusedLds<D1, D2, D3>;
+    using LO = FusedLds<D1, D2, D3, HX>;
     constexpr int NP = 16 * NT;
     constexpr int nthreads = kFusedWaves * 64;
     const int tid = threadIdx.x;
@@ -649,7 +654,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         }
 
         // ---------------- last GCN layer on the robot row + value head: one register-resident MFMA chain -------------------
-        const float v = head_chain<LO, D1, D2, D3, SKIP>(lds, tin, hp, lane);
+        const float v = head_chain<LO, D1, D2, D3, SKIP, HX>(lds, tin, hp, lane);
         if (q == 0 && c < A) a.value[(size_t)p * A + c] = v + hb4;
         PHASE_MARK(6);
       }
@@ -672,7 +677,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                 tin[ot] = valid ? *reinterpret_cast<const f32x4*>(row + 16 * ot + 4 * q) : zero4();
                 hp[ot] = valid ? *reinterpret_cast<const f32x4*>(row + 32 + 16 * ot + 4 * q) : zero4();
             }
-            const float v = head_chain<LO, D1, D2, D3, SKIP>(lds, tin, hp, lane);
+            const float v = head_chain<LO, D1, D2, D3, SKIP, HX>(lds, tin, hp, lane);
             if (valid && q == 0) a.value[(size_t)p * A + 16 * a.n_full + k] = v + hb4;
         }
     }
@@ -735,11 +740,55 @@ __device__ __forceinline__ float matrix_element(const float* __restrict__ W, int
     return (r < ROWS && c < COLS) ? W[r * COLS + c] : 0.f;
 }
 
-template <int D1, int D2, int D3>
+// float slot `idx` of the f16 (hi, lo) fragment image of W (k-major [IN][OUT]) scaled by sw: two halves.  Unit u = idx / 4 is one
+// lane's 8-half fragment: u = ((ot NC + c) 2 + hl) 64 + lane; half e of it is W[in = tile_feature<IN>(2c + e / 4, q, e % 4)][out of
+// A-operand row lane % 16] -- hi = f16(w sw), lo = f16(w sw - hi).
+template <int IN, int OUT>
+__device__ __forceinline__ float frag_half2(const float* __restrict__ W, int idx, float sw) {
+    constexpr int IT = Tiles<IN>::v, NC = (IT + 1) / 2;
+    const int u = idx >> 2, p = idx & 3;
+    const int l = u & 63, rest = u >> 6;
+    const int hl = rest & 1, c = (rest >> 1) % NC, ot = (rest >> 1) / NC;
+    const int m = l & 15, q = l >> 4;
+    const int out = tile_feature<OUT>(ot, m >> 2, m & 3);
+    f16x2 hv;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = 2 * p + k, t = 2 * c + (e >> 2);
+        const int in = t < IT ? tile_feature<IN>(t, q, e & 3) : IN;
+        const float w = (in < IN && out < OUT) ? W[in * OUT + out] * sw : 0.f;
+        const _Float16 hi = (_Float16)w;
+        hv[k] = hl ? (_Float16)(w - (float)hi) : hi;
+    }
+    return __builtin_bit_cast(float, hv);
+}
+
+// 1 / scale of the four head matrices (HX images): scale = the power of two that brings max |W| into [512, 1024)
+__global__ __launch_bounds__(256) void head_scales_kernel(const FusedArgs a, float* img, int hs_off, int d1, int d2, int d3) {
+    __shared__ float red[256];
+    const float* W = blockIdx.x == 0 ? a.w_last : (blockIdx.x == 1 ? a.hw1 : (blockIdx.x == 2 ? a.hw2 : a.hw3));
+    const int n = blockIdx.x == 0 ? XD * XD : (blockIdx.x == 1 ? XD * d1 : (blockIdx.x == 2 ? d1 * d2 : d2 * d3));
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(W[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const unsigned E = __float_as_uint(red[0]) >> 23;
+        img[hs_off + blockIdx.x] = (E < 32u || E > 254u) ? 1.f : __uint_as_float((E - 9u) << 23);      // 1 / 2^(136 - E)
+        img[hs_off + 4 + blockIdx.x] = 0.f;
+    }
+}
+
+template <int D1, int D2, int D3, bool HX>
 __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedArgs a, float* img) {
-    using LO = FusedLds<D1, D2, D3>;
+    using LO = FusedLds<D1, D2, D3, HX>;
     const int e = blockIdx.x * kPackThreads + threadIdx.x;
     if (e >= LO::scratch) return;
+    if (HX && e >= LO::hs) return;                     // the scales: written by head_scales_kernel before this launch
     float v;
     if (e < LO::br1) v = matrix_element<9, HID, W1LD>(a.wr1, e - LO::wr1);
     else if (e < LO::wr2) v = a.br1[e - LO::br1];
@@ -757,14 +806,41 @@ __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedAr
     else if (e < LO::b3) v = bias_element<D2>(a.hb2, e - LO::b2);
     else if (e < LO::w4) v = bias_element<D3>(a.hb3, e - LO::b3);
     else if (e < LO::f_last) v = bias_element<D3>(a.hw4, e - LO::w4);          // w4 is [D3][1]: same padded vector layout as a bias
-    else if (e < LO::f1) v = frag_element<XD, XD>(a.w_last, e - LO::f_last);
-    else if (e < LO::f2) v = frag_element<XD, D1>(a.hw1, e - LO::f1);
-    else if (e < LO::f3) v = frag_element<D1, D2>(a.hw2, e - LO::f2);
-    else v = frag_element<D2, D3>(a.hw3, e - LO::f3);
+    else if constexpr (HX) {
+        // scale of matrix l = 1 / img[hs + l] (a power of two, so the reciprocal is exact)
+        if (e < LO::f1) v = frag_half2<XD, XD>(a.w_last, e - LO::f_last, 1.f / img[LO::hs + 0]);
+        else if (e < LO::f2) v = frag_half2<XD, D1>(a.hw1, e - LO::f1, 1.f / img[LO::hs + 1]);
+        else if (e < LO::f3) v = frag_half2<D1, D2>(a.hw2, e - LO::f2, 1.f / img[LO::hs + 2]);
+        else v = frag_half2<D2, D3>(a.hw3, e - LO::f3, 1.f / img[LO::hs + 3]);
+    } else {
+        if (e < LO::f1) v = frag_element<XD, XD>(a.w_last, e - LO::f_last);
+        else if (e < LO::f2) v = frag_element<XD, D1>(a.hw1, e - LO::f1);
+        else if (e < LO::f3) v = frag_element<D1, D2>(a.hw2, e - LO::f2);
+        else v = frag_element<D2, D3>(a.hw3, e - LO::f3);
+    }
     img[e] = v;
 }
 
-constexpr size_t kImageFloats = FusedLds<32, 100, 100>::scratch;
+// one packed image, in the layout of the kernel that will read it (hx: f16-split head fragments + scales)
+inline int launch_pack_image(const FusedArgs& a, float* img, bool hx, hipStream_t stream) {
+    if (hx) {
+        using LO = FusedLds<32, 100, 100, true>;
+        hipLaunchKernelGGL(head_scales_kernel, dim3(4), dim3(256), 0, stream, a, img, (int)LO::hs, 32, 100, 100);
+        RGL_LAUNCH_CHECK();
+        hipLaunchKernelGGL((pack_images_kernel<32, 100, 100, true>), dim3((unsigned)((LO::scratch + kPackThreads - 1) / kPackThreads)),
+                           dim3(kPackThreads), 0, stream, a, img);
+    } else {
+        using LO = FusedLds<32, 100, 100, false>;
+        hipLaunchKernelGGL((pack_images_kernel<32, 100, 100, false>), dim3((unsigned)((LO::scratch + kPackThreads - 1) / kPackThreads)),
+                           dim3(kPackThreads), 0, stream, a, img);
+    }
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
+// sized for the larger (f16-split) layout: one buffer size whatever the contraction mode
+constexpr size_t kImageFloats = FusedLds<32, 100, 100, true>::scratch > FusedLds<32, 100, 100, false>::scratch
+                                    ? FusedLds<32, 100, 100, true>::scratch : FusedLds<32, 100, 100, false>::scratch;
 constexpr size_t kImageBytes = (kImageFloats * sizeof(float) + 255) & ~(size_t)255;
 
 struct FusedPlan {
@@ -772,6 +848,7 @@ struct FusedPlan {
     size_t lds_bytes;
     int grid;
     int hr, nt;
+    bool hx;                       // f16-split head (RGL_CONTRACT_F16X3)
     bool ok;
 };
 
@@ -873,12 +950,15 @@ inline ItemPlan plan_items(int P, int n_full, int rem, int unit) {
     return best;
 }
 
-inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A, int H, int unit = 1) {
+// hx: the f16-split head is wanted (RGL_CONTRACT_F16X3).  It exists for the softmax similarities; such a plan takes every launch
+// size (the two-stage pair has no f16-split head, and the packed image is in this kernel's layout only).
+inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A, int H, int unit = 1, bool hx = false) {
     FusedPlan pl;
     pl.ok = false;
+    pl.hx = hx && fast_similarity_mode(g) == SIM_SOFTMAX;
     if (!fast_path_enabled() || !rank1_enabled() || fused_policy() < 0) return pl;
     static const int min_tiles = env_int("RGL_FUSED_MIN_TILES", 1200);
-    if (fused_policy() == 0 && (long)P * ((A + 15) / 16) < min_tiles) return pl;
+    if (!pl.hx && fused_policy() == 0 && (long)P * ((A + 15) / 16) < min_tiles) return pl;
     if (fast_similarity_mode(g) < 0 || g.layerwise_graph || g.x_dim != XD || g.num_layer != 2) return pl;
     if (!mlp_is(g.w_r, 9, HID, XD, true) || !mlp_is(g.w_h, 5, HID, XD, true)) return pl;
     if (head_variant(head) != 0) return pl;
@@ -902,7 +982,7 @@ inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A,
         a.tail = TailArgs{};
         pl.grid = ip.grid;
     }
-    pl.lds_bytes = (size_t)(FusedLds<32, 100, 100>::scratch +
+    pl.lds_bytes = (size_t)((pl.hx ? FusedLds<32, 100, 100, true>::scratch : FusedLds<32, 100, 100, false>::scratch) +
                             kFusedWaves * fused_scratch_floats(pl.hr, pl.nt, a.sim == SIM_SOFTMAX)) * sizeof(float);
     if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
     a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];
@@ -915,9 +995,9 @@ inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A,
     return pl;
 }
 
-template <int HR, int NT, bool SKIP, bool SOFT>
+template <int HR, int NT, bool SKIP, bool SOFT, bool HX = false>
 int launch_fused_ts(const FusedPlan& pl, hipStream_t st) {
-    auto kern = children_fused_kernel<HR, NT, SKIP, SOFT, 32, 100, 100>;
+    auto kern = children_fused_kernel<HR, NT, SKIP, SOFT, 32, 100, 100, HX>;
     RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)pl.lds_bytes));
     const int grid = pl.grid;                        // persistent, one 8-wave workgroup per CU (LDS-bound)
@@ -928,6 +1008,7 @@ int launch_fused_ts(const FusedPlan& pl, hipStream_t st) {
 
 template <int HR, int NT, bool SKIP>
 int launch_fused_t(const FusedPlan& pl, hipStream_t st) {
+    if (pl.hx) return launch_fused_ts<HR, NT, SKIP, true, true>(pl, st);          // plan_fused: softmax similarities only
     return pl.a.sim == SIM_SOFTMAX ? launch_fused_ts<HR, NT, SKIP, true>(pl, st) : launch_fused_ts<HR, NT, SKIP, false>(pl, st);
 }
 
@@ -973,20 +1054,17 @@ const float* fused_workspace_image(const void* workspace, size_t workspace_bytes
 
 // 1 = the fused kernel does not apply (or the workspace cannot hold its images)
 int pack_children_images(const RglGraph* g, const RglMlp* head, int P, int A, int H, void* workspace, size_t workspace_bytes,
-                         hipStream_t stream) {
-    FusedPlan fp = plan_fused(*g, *head, P, A, H);
+                         hipStream_t stream, int hx) {
+    FusedPlan fp = plan_fused(*g, *head, P, A, H, 1, hx != 0);
     if (!fp.ok || !workspace || workspace_bytes < fused_children_workspace_bytes(P, A, H)) return 1;
-    hipLaunchKernelGGL((pack_images_kernel<32, 100, 100>), dim3((unsigned)((kImageFloats + kPackThreads - 1) / kPackThreads)),
-                       dim3(kPackThreads), 0, stream, fp.a, image_of(workspace, workspace_bytes));
-    RGL_LAUNCH_CHECK();
-    return RGL_OK;
+    return launch_pack_image(fp.a, image_of(workspace, workspace_bytes), fp.hx, stream);
 }
 
 // 1 = outside this kernel's envelope
 int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, int H, const float* child_robot,
                           const float* humans_next, float* child_value, void* workspace, size_t workspace_bytes,
                           int image_ready, hipStream_t stream, const float* caller_image, const void* tail, size_t tail_bytes,
-                          int* tail_done) {
+                          int* tail_done, int hx) {
     if (tail_done) *tail_done = 0;
     // the search's tail: selection always; the back-up chain + root step at the deepest level when handing whole roots to
     // workgroups does not starve the GPU (few roots with many parents each -- unclipped deep searches -- keep unit = 1)
@@ -1004,11 +1082,11 @@ int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, i
             chain = 1;
         }
     }
-    FusedPlan fp = plan_fused(*g, *head, P, A, H, unit);
+    FusedPlan fp = plan_fused(*g, *head, P, A, H, unit, hx != 0);
     if (!fp.ok) return 1;
     if (!workspace || workspace_bytes < fused_children_workspace_bytes(P, A, H)) return 1;
     if (!image_ready && !caller_image) {
-        int rc = pack_children_images(g, head, P, A, H, workspace, workspace_bytes, stream);
+        int rc = pack_children_images(g, head, P, A, H, workspace, workspace_bytes, stream, hx);
         if (rc) return rc;
     }
     const float* image = caller_image ? caller_image : image_of(workspace, workspace_bytes);
@@ -1029,19 +1107,19 @@ int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, i
 
 }  // namespace rgl
 
-// The image depends on the weights only: a caller with fixed weights packs it once (MprlPlanner::children_image).
+// The image depends on the weights (and on the contraction mode: f16-split head fragments for RGL_CONTRACT_F16X3) only: a caller
+// with fixed weights packs it once (MprlPlanner::children_image).
 extern "C" size_t mprl_children_image_bytes(const MprlPlanner* planner) {
     if (!planner) return 0;
-    return plan_fused(planner->value_graph, planner->value_head, 4096, 16, 1).ok ? kImageBytes : 0;      // architecture test only
+    const bool hx = planner->contraction_dtype == RGL_CONTRACT_F16X3;
+    return plan_fused(planner->value_graph, planner->value_head, 4096, 16, 1, 1, hx).ok ? kImageBytes : 0;      // architecture test only
 }
 
 extern "C" int mprl_pack_children_image_f32(const MprlPlanner* planner, float* image, size_t image_bytes, rgl_stream_t stream) {
     if (!planner || !image) return RGL_ERR_NULL;
-    FusedPlan fp = plan_fused(planner->value_graph, planner->value_head, 4096, 16, 1);
+    const bool hx = planner->contraction_dtype == RGL_CONTRACT_F16X3;
+    FusedPlan fp = plan_fused(planner->value_graph, planner->value_head, 4096, 16, 1, 1, hx);
     if (!fp.ok) return RGL_ERR_BAD_MODE;
     if (image_bytes < kImageBytes) return RGL_ERR_WORKSPACE;
-    hipLaunchKernelGGL((pack_images_kernel<32, 100, 100>), dim3((unsigned)((kImageFloats + kPackThreads - 1) / kPackThreads)),
-                       dim3(kPackThreads), 0, (hipStream_t)stream, fp.a, image);
-    RGL_LAUNCH_CHECK();
-    return RGL_OK;
+    return launch_pack_image(fp.a, image, fp.hx, (hipStream_t)stream);
 }

@@ -9,6 +9,8 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int XD = 32;    // x_dim
 constexpr int HID = 64;   // embedding hidden width
@@ -37,6 +39,17 @@ __device__ __forceinline__ float kgroups_sum(float x) {
     x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// max over the 16 lanes of a DPP row (every lane gets it); the DPP operand rides in the v_max itself
+// (s_nop 1: a DPP read of a VGPR needs two wait states after the VALU write of it, and the compiler's hazard recognizer does
+// not look inside inline assembly)
+__device__ __forceinline__ float row16_max(float x) {
+    float y;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(y));
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(y));
+    return x;
 }
 // m / N for 0 <= m < 65536 and 1 <= N <= 64 with magic = floor(2^32 / N) + 1
 __device__ __forceinline__ int div_small(int m, unsigned magic) { return (int)__umulhi((unsigned)m, magic); }

@@ -428,10 +428,10 @@ extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* rob
 
     // weight images of the value-of-children kernels: prepared once, every level copies them into LDS (0 = prepared)
     // (or handed in by the caller, packed once for fixed weights: MprlPlanner::children_image)
-    const int image_ready = pl.contraction_dtype == RGL_CONTRACT_F32 &&
+    const int image_ready = (pl.contraction_dtype == RGL_CONTRACT_F32 || pl.contraction_dtype == RGL_CONTRACT_F16X3) &&
                             (pl.children_image != nullptr ||
                              rgl::pack_children_images(&pl.value_graph, &pl.value_head, (int)lv[D - 1].P, A, H, ws + scratch_off,
-                                                       (size_t)scratch_bytes, st) == 0);
+                                                       (size_t)scratch_bytes, st, pl.contraction_dtype == RGL_CONTRACT_F16X3) == 0);
     TailArgs tail{};
     tail.enabled = 1;
     tail.D = D; tail.A = A; tail.W = W; tail.clip = pl.do_action_clip; tail.sparse = pl.sparse_search;

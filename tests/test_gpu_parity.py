@@ -1148,6 +1148,63 @@ def test_properties_of_the_other_baseline_workloads(tag, H, L, D, B, contraction
            % (tag, float((v4 - v1).abs().max())))
 
 
+def test_f16x3_value_head_at_size_and_at_extreme_magnitudes(dev):
+    """RGL_CONTRACT_F16X3 (ABI 4): the value head's dense products as three split-f16 MFMA terms over power-of-two-scaled operands
+    (layer_mfma_h).  (1) configs[2] in full -- 2048 roots, bench.py's scenes and weights -- against the batched oracle at the
+    f32 tolerance 1e-4 (measured ~1e-7), decisions as for the f32 path; (2) against the library's own f32 path; (3) the scaling: the
+    head's weights multiplied by 3e4 / 2e-5 per layer (activations far outside f16's range) still match a float64 evaluation of
+    the same head to 1e-5 RELATIVE -- any finite input is handled."""
+    import bench
+
+    class Args:
+        pass
+    Args.layers, Args.depth, Args.width, Args.humans, Args.contraction = 2, 2, 2, 19, "f16x3"
+    pol = bench.make_policy(Args, dev)
+    B, H = 2048, 19
+    robot, humans = bench.synth_scenes(1000, B, H)
+    act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
+    assert pol.tree_search().last["planner"].contraction_dtype == nat.CONTRACTION_DTYPES["f16x3"]
+    oracle_out, v1 = _oracle_at_size(H, 2, 2, B, robot, humans)
+    err = close(val.cpu().numpy(), oracle_out[1].numpy())
+    check_decisions("at size, configs[2] in full, f16x3 value head", act, val, oracle_out, [{"value1": v1}], TOL)
+    Args.contraction = "f32"
+    pol32 = bench.make_policy(Args, dev)
+    a32, v32 = pol32.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
+    d32 = float((val - v32).abs().max())
+    same = float((act == a32).float().mean())
+    assert d32 < 1e-5 and same > 0.995, (d32, same)
+    report("f16x3 value head, configs[2] in full: max |dV| vs the oracle %.2e, vs the f32 kernels %.2e, %.2f %% identical decisions"
+           % (err, d32, 100 * same))
+    # (3) magnitudes: children's values with a head whose layers are scaled up / down
+    ts = pol.tree_search()
+    r, h = robot[:64].to(dev), humans[:64].to(dev)
+    ex = ts.expand(r, h, parents_are_joint_states=False)
+    worst = 0.0
+    for scales in ((3e4, 1.0, 1.0, 1.0), (1.0, 2e-5, 3e4, 1.0), (3e4, 3e4, 3e4, 1e-9), (1e-6, 1e-6, 1.0, 1e6)):
+        lins = [m for m in pol.value_estimator.value_network if isinstance(m, torch.nn.Linear)]
+        saved = [(m.weight.detach().clone(), m.bias.detach().clone()) for m in lins]
+        with torch.no_grad():
+            for m, sc in zip(lins, scales):
+                m.weight.mul_(sc)
+                m.bias.mul_(sc)
+        got = ts.value_children(ex["child_robot"], ex["humans_next"]).double().cpu()
+        with torch.no_grad():
+            Pm = orc.MprlParams.from_checkpoint({k: {kk: vv.double().cpu() for kk, vv in v.items()} for k, v in pol.get_state_dict().items()})
+            cfg = orc.OracleConfig()
+            A = ts.num_actions
+            want = orc.value_estimator_forward(ex["child_robot"].double().cpu().reshape(64 * A, 1, 9),
+                                               ex["humans_next"].double().cpu()[:, None].expand(64, A, H, 5).reshape(64 * A, H, 5),
+                                               Pm.ve_graph, Pm.value_network, cfg).reshape(64, A)
+        rel = float((got - want).abs().max() / want.abs().max())
+        worst = max(worst, rel)
+        assert rel < 1e-5, (scales, rel)
+        with torch.no_grad():
+            for m, (w, b) in zip(lins, saved):
+                m.weight.copy_(w)
+                m.bias.copy_(b)
+    report("f16x3 value head under extreme layer scales (3e4 / 2e-5 / 1e-9 per layer): worst relative error vs float64 %.1e" % worst)
+
+
 _ORACLE_AT_SIZE = {}
 
 
