@@ -381,8 +381,8 @@ class GCN(Policy):
         if self.action_space is None:
             self.build_action_space(state.robot_state.v_pref)
         if not state.human_states:
-            raise NotImplementedError("empty crowds fall back to CADRL's greedy action upstream, which is bit-rotted "
-                                      "there (state.self_state) and outside the relational-graph path")
+            assert self.phase != 'train'                       # multi_human_rl.py:27-31
+            return self.select_greedy_action(state.robot_state)
         probability = np.random.random()
         if self.phase == 'train' and probability < self.epsilon:
             max_action = self.action_space[np.random.choice(len(self.action_space))]
@@ -439,6 +439,28 @@ class GCN(Policy):
         disc = pow(self.gamma, dt * float(robot[7]))
         vals = (reward.double() + disc * v[:, 0].double()).float().reshape(1, A)
         return vals, _first_strict_maximum(vals)
+
+    def select_greedy_action(self, self_state):
+        """Empty crowd (multi_human_rl.py:27-31 -> cadrl.py:193-228): no graph to evaluate -- the table action closest to the
+        straight-to-goal velocity, first minimum.  Host arithmetic in float64 like upstream.  Unicycle: the two out-of-view cases;
+        the in-view case raises upstream (a misplaced parenthesis hands np.array a float as dtype), so it raises here too."""
+        direction = np.arctan2(self_state.gy - self_state.py, self_state.gx - self_state.px)
+        distance = np.linalg.norm((self_state.gy - self_state.py, self_state.gx - self_state.px))
+        if self.kinematics == 'holonomic':
+            speed = min(distance / self.time_step, self_state.v_pref)
+            target = np.array((np.cos(direction) * speed, np.sin(direction) * speed))
+            min_diff, closest = float('inf'), None
+            for action in self.action_space:
+                diff = np.linalg.norm(np.array(action) - target)
+                if diff < min_diff:
+                    min_diff, closest = diff, action
+            return closest
+        rotation = direction - self_state.theta
+        if rotation < self.rotations[0]:
+            return act.ActionRot(self.speeds[0], self.rotations[0])
+        if rotation > self.rotations[-1]:
+            return act.ActionRot(self.speeds[0], self.rotations[-1])
+        raise TypeError("select_greedy_action: the in-view unicycle case raises upstream (cadrl.py:222-223)")
 
     def _refresh_adjacency(self, robot, humans):
         last = self.action_space[-1]

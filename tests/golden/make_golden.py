@@ -861,6 +861,31 @@ def gen_vnrl_trainer_kats(pg_fixture, out):
     policy_config("rgl", gcn__num_layer=2, gcn__layerwise_graph=False, gcn__skip_connection=True)
 
 
+def gen_greedy_kats(out):
+    """MultiHumanRL.predict with an EMPTY crowd (multi_human_rl.py:27-31) -> CADRL.select_greedy_action (cadrl.py:193-228): the
+    table action closest to the straight-to-goal velocity.  Holonomic (the unicycle branch's last case raises upstream: a
+    misplaced parenthesis makes np.array take a float as dtype)."""
+    pc = policy_config("rgl")
+    pol = policy_factory["gcn"]()
+    pol.configure(pc)
+    pol.set_phase("test")
+    pol.set_device(torch.device("cpu"))
+    pol.time_step = 0.25
+    rng = np.random.RandomState(51)
+    rows, acts = [], []
+    for i in range(24):
+        px, py, gx, gy = rng.uniform(-4, 4, 4)
+        if i % 6 == 0:
+            gx, gy = px + rng.uniform(-0.1, 0.1), py + rng.uniform(0.31, 0.4)      # close to the goal: speed = distance / dt
+        row = [px, py, rng.uniform(-1, 1), rng.uniform(-1, 1), 0.3, gx, gy, 1.0, rng.uniform(-3, 3)]
+        js = JointState(FullState(*row), [])
+        a = pol.predict(js)
+        rows.append(row)
+        acts.append([k for k, x in enumerate(pol.action_space) if x is a][0])
+    out["greedy.robot"] = np.array(rows, np.float64)
+    out["greedy.action"] = np.array(acts, np.int64)
+
+
 def gen_query_env_kats(pg_fixture, out):
     """Path G with query_env=True (multi_human_rl.py:43-44) on the reference simulator with `linear` humans: per action the next
     human states and the reward come from env.onestep_lookahead.  States a few steps into seeded test cases; recorded: the full
@@ -958,6 +983,7 @@ def main():
     gen_query_env_kats(pg, tq)
     np.savez(os.path.join(HERE, "training_queryenv.npz"), **tq)
     vt = {}
+    gen_greedy_kats(vt)
     gen_vnrl_trainer_kats(pg, vt)
     np.savez(os.path.join(HERE, "vnrl_trainer.npz"), **vt)
     for f in sorted(os.listdir(HERE)):

@@ -183,3 +183,16 @@ def test_modules_deepcopy_and_pickle_with_populated_descriptor_cache():
     g._head_cache.key, g._head_cache.value = ("stale",), nat.RglMlp()
     g2 = copy.deepcopy(g)
     assert g2._cache.key is None and g2._head_cache.key is None
+
+
+def test_empty_crowd_takes_the_reference_greedy_action():
+    """Fixture vnrl_trainer.npz (greedy.*): the reference MultiHumanRL.predict on JointStates without humans (multi_human_rl.py:27-31 ->
+    CADRL.select_greedy_action).  No network is involved, so this runs without a GPU."""
+    from tests import golden_io as gio
+    from tests.helpers import make_gcn_policy, JS
+    fx = gio.load("vnrl_trainer")
+    pol = make_gcn_policy()
+    pol.device = "cpu"                                   # only marks the policy as configured: nothing is evaluated on it
+    for row, want in zip(fx["greedy.robot"], fx["greedy.action"]):
+        a = pol.predict(JS(row, []))
+        assert a == pol.action_space[int(want)]

@@ -44,6 +44,7 @@ echo '```' >> $O.md
 python - <<PY
 import json, sqlite3, sys
 sys.path.insert(0, "$R/tools")
+sys.path.insert(0, "$R")
 def totals(path, sym):
     db = sqlite3.connect(path)
     t = {r[0].split("_0000")[0]: r[0] for r in db.execute("select name from sqlite_master where type='table'")}
@@ -62,6 +63,7 @@ try:
     total_bytes = sum(2 * f[k] + w.get(k, 0.0) for k in keep) * 1024
     rec = {"source": "profiles/${TAG}_kernel_stats.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/profile_children.py, P = 4096 parents x 81 children, N = 20, L = 2)",
            "source_revision": "$HASH",
+           "kernel_sources_sha256": __import__("bench").kernel_sources_digest(),
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced loads -> reads doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported; both in KiB",
            "workload": {"N": 20, "L": 2, "A": 81}, "scenes": scenes,
            "kernels": {k: {"FETCH_SIZE_KiB": f[k], "WRITE_SIZE_KiB": w.get(k, 0.0)} for k in keep},
