@@ -5,7 +5,7 @@
 #   gpurun -- 'bash tools/round_profile.sh <tag> <git-hash>'   -> gpurun_out/<tag>.md, gpurun_out/<tag>_traffic.json  (copy to profiles/)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02_x}
+TAG=${1:-r03_x}
 HASH=${2:-unknown}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -41,6 +41,28 @@ for grp in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_ACTIV
   else echo "(pass $i: $grp -- no database)" >> $O.md; fi
 done
 echo '```' >> $O.md
+{
+  echo
+  echo "## Split-f16 value head (contraction f16x3), same launch: co-execution of the f16 MFMAs with the VALU"
+  echo
+  echo '`rocprofv3 --kernel-trace --pmc <list> -- python tools/profile_children.py --contraction f16x3`'
+  echo
+  echo '```'
+} >> $O.md
+for grp in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_ANY"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $grp -d $O/pmc$i -o pmc -- python $R/tools/profile_children.py --contraction f16x3 > $O/pmc$i.log 2>&1
+  f=$(find $O/pmc$i -name "*results.db" | head -1)
+  if [ -n "$f" ]; then python $R/tools/pmc_summary.py $f children_fused >> $O.md; else echo "(pass $i: $grp -- no database)" >> $O.md; fi
+done
+{
+  echo '```'
+  echo
+  echo "kernel durations of that mode (rocprofv3 --kernel-trace --stats -- python tools/profile_children.py --contraction f16x3):"
+  echo
+} >> $O.md
+rocprofv3 --kernel-trace --stats -d $O/x3trace -o x3 -- python $R/tools/profile_children.py --contraction f16x3 > $O/x3.log 2>&1
+python $R/tools/rocpd_summary.py $(find $O/x3trace -name "*results.db" | head -1) | head -6 >> $O.md
 python - <<PY
 import json, sqlite3, sys
 sys.path.insert(0, "$R/tools")
