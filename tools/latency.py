@@ -19,6 +19,14 @@ class A:
 
 def main():
     dev = torch.device("cuda:0")
+    # wake the device first: the first configuration measured straight after process start read 0.9-1.0 ms per decision in rounds
+    # 2 and 3 (profiles/r02_u_latency.txt) against 0.13 ms for every later one -- a fresh process's first ~0.3 s of GPU work
+    # (code-object loads, clocks leaving the idle state) is not decision latency
+    x = torch.randn(2048, 2048, device=dev)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.5:
+        x = (x @ x).clamp_(-1, 1)
+    torch.cuda.synchronize()
     for H, D in ((5, 1), (5, 2), (19, 2), (19, 3)):
         A.humans, A.depth = H, D
         pol = bench.make_policy(A, dev)
