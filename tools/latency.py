@@ -33,8 +33,8 @@ def main():
         robot, humans = bench.synth_scenes(3, 1, H)
         js = rga.JointState(rga.FullState(*[float(x) for x in robot[0]]),
                             [rga.ObservableState(*[float(x) for x in row]) for row in humans[0]])
-        for _ in range(5):
-            pol.predict(js)
+        for _ in range(40):                    # incl. the capture and the first replays of the fresh graph (they ran at ~1 ms
+            pol.predict(js)                    # each for the first configuration of a process: the r02 / r03 "outlier")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n = 50
