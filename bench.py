@@ -247,7 +247,7 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=2)
     ap.add_argument("--contraction", choices=("f32", "f16", "f16x3"), default="f32",
                     help="f16: f16-input MFMA for the dense middle-layer products (BASELINE configs[4]; needs --layers 3); "
-                         "f16x3: the value head's products as three split-f16 MFMA terms (f32-equivalent to ~2^-21, L = 2, N <= 32)")
+                         "f16x3: the children kernel's dense products as three split-f16 MFMA terms (f32-equivalent to ~2^-21, L = 2, N <= 20)")
     ap.add_argument("--scenes", choices=("clearance", "uniform"), default="clearance",
                     help="human placement of the synthetic scenes: SURVEY 8(d)'s clearance re-draw (default) or the round-1/2 "
                          "uniform draw")
@@ -479,9 +479,14 @@ def children_roofline(args, ts, device, N, H, last):
     achieved = scenes_per_launch * flop_per_scene / (kern_ms * 1e-3) / 1e12
     peak, peak_note = FP32_PEAK_TFLOPS, "fp32 vector == f32-MFMA peak (the two do not co-execute on gfx950)"
     if args.contraction == "f16x3":
-        # the value head's products (last GCN layer on the robot row + 32-32-100-100) run on the f16 matrix pipe as THREE split
-        # terms each, i.e. at a third of the dense f16 MFMA peak; the rest at the fp32 rate: time-weighted peak
-        dense = 2 * 32 * 32 + 2 * (32 * 32 + 32 * 100 + 100 * 100)
+        # every dense product of the fused kernel but the two input layers (K = 9 / 5) runs on the f16 matrix pipe as THREE split
+        # terms, i.e. at a third of the dense f16 MFMA peak; the rest (input layers, softmax scalars, the row pass) at the fp32 rate:
+        # time-weighted peak
+        Hh = N - 1
+        crowd_dense = (Hh * (4736 - 2 * 5 * 64) + 2 * Hh * 32 * 32 + 2 * Hh * Hh * 32 + 2 * Hh * Hh * 32 + 2 * Hh * 32 * 32) / A
+        dense = ((5248 - 2 * 9 * 64) + 2 * 2 * 32 * 32 + 4 * N * 32 + 2 * N * 32 + 2 * 32 * 32      # embedding, x0 Wa / W1, S row + column, p Xh, T_0 W1
+                 + 2 * 32 * 32 + 2 * (32 * 32 + 32 * 100 + 100 * 100) + crowd_dense)                 # last layer, value head, crowd quantities
+        dense = min(dense, flop_per_scene)
         x3_peak = F16_MFMA_PEAK_TFLOPS / 3.0
         peak = flop_per_scene / (dense / x3_peak + (flop_per_scene - dense) / FP32_PEAK_TFLOPS)
         peak_note = "blend: %.0f%% of the FLOPs as 3 split-f16 MFMA terms (a third of the dense f16 MFMA peak = %.0f), the rest at the fp32 peak (%.1f)" % (
@@ -613,9 +618,9 @@ def main():
             ts.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
         roofline = children_roofline(args, ts, device, N, H, leg.graph_last)
 
-    # ---- auxiliary reading (never `value`): the same workload with the value head's dense products as three split-f16 MFMA terms
-    # (contraction_dtype "f16x3": f32-equivalent to ~2^-21 per product, on the f16 matrix pipe), timed the same way, with its
-    # deviation from the f32 kernels measured on this very batch
+    # ---- auxiliary reading (never `value`): the same workload with the children kernel's dense products as three split-f16 MFMA
+    # terms (contraction_dtype "f16x3": f32-equivalent to ~2^-21 per product, on the f16 matrix pipe), timed the same way, with
+    # its deviation from the f32 kernels measured on this very batch
     x3 = None
     if (not STUB and world == 1 and args.contraction == "f32" and args.layers == 2 and N <= 32 and B > 0
             and os.environ.get("RGL_BENCH_NO_F16X3") != "1"):
@@ -634,8 +639,9 @@ def main():
               "max_abs_dV_vs_f32_kernels": float((o3["best_value"] - o32["best_value"]).abs().max()),
               "identical_decisions": float((o3["best_action"] == o32["best_action"]).float().mean()),
               "roofline": {k: r3[k] for k in ("achieved", "peak", "frac", "peak_note", "launch_ms", "unit")},
-              "note": "contraction_dtype f16x3 (MprlPlanner.contraction_dtype = RGL_CONTRACT_F16X3): same search, the value head's "
-                      "products W^T a = W_hi a_hi + W_hi a_lo + W_lo a_hi on v_mfma_f32_16x16x32_f16 with f32 accumulation over "
+              "note": "contraction_dtype f16x3 (MprlPlanner.contraction_dtype = RGL_CONTRACT_F16X3): same search, the dense "
+                      "products of the value-of-children kernel (value head, embedding chains, robot row / column of S, p Xh, crowd "
+                      "quantities) as W^T a = W_hi a_hi + W_hi a_lo + W_lo a_hi on v_mfma_f32_16x16x32_f16 with f32 accumulation over "
                       "power-of-two-scaled operands; reported beside the f32 line, never as `value`"}
         del leg3
         ts.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
@@ -648,8 +654,8 @@ def main():
         "step_ms_device": {"p10": step_ms[len(step_ms) // 10], "median": step_ms[len(step_ms) // 2],
                            "p90": step_ms[(len(step_ms) * 9) // 10], "note": "rank 0, HIP events between steps"},
         "vs_baseline": None, "dtype": {"f32": "f32", "f16": "f16 inputs / f32 accumulate (middle-layer products only; everything else f32)",
-                                       "f16x3": "f32 (value-head products as three split-f16 MFMA terms with f32 accumulate, ~2^-21 "
-                                                "relative per product; everything else f32)"}[args.contraction],
+                                       "f16x3": "f32 (dense products of the children kernel as three split-f16 MFMA terms with f32 accumulate, "
+                                                "~2^-21 relative per product; everything else f32)"}[args.contraction],
         "data": "synthetic",
         "config": {"workload": "%s: N=%d agents (H=%d humans), %d-layer GCN, depth-%d width-%d "
                                "action-tree rollout, %s" % (workload_name(N, args, main_leg[0]), N, H, args.layers, args.depth, args.width,

@@ -222,8 +222,9 @@ typedef struct MprlPlanner {
                                  * accumulate for the dense products of the middle GCN layer of the children's  *
                                  * value graph (BASELINE configs[4]); RGL_ERR_BAD_MODE when the configuration   *
                                  * has no such kernel (needs embedded_gaussian, L = 3, N <= 64)                 *
-                                 * | RGL_CONTRACT_F16X3 (ABI 4): the value head's dense products of the shipped *
-                                 * shape (L = 2, N <= 32, head 32-100-100-1, softmax similarities) computed as   *
+                                 * | RGL_CONTRACT_F16X3 (ABI 4): the dense products of the value-of-children    *
+                                 * kernel of the shipped shape (L = 2, N <= 20, head 32-100-100-1, softmax        *
+                                 * similarities: value head, embedding chains, S row / column, crowd) computed as *
                                  * W_hi a_hi + W_hi a_lo + W_lo a_hi with f16 halves of power-of-two-scaled      *
                                  * operands and f32 accumulation: ~2^-21 relative per product (f32 rounding is   *
                                  * 2^-24), 5x the MFMA rate of the f32 form, any finite input.  Where no kernel   *

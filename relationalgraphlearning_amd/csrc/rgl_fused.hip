@@ -164,6 +164,10 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
     const int n_tiles_inl = a.n_full + (a.inline_partial ? 1 : 0);      // tiles that run their own head
     float rin[3], hin[NT][2];
     f32x4 gq[NT][2], xq[NT][2], ms[NT], zs[NT], xt[NT][2], uw4[HRL / 4];
+    // HX: the crowd operands as split-f16 halves.  gqs / xqs [node tile]: rows = nodes, k = features (the D layout of the crowd chain,
+    // packed pairwise); xts [feature tile]: rows = features, k = nodes.  One power-of-two scale per family (they serve as A operands).
+    SplitOperand<2> gqs[NT], xqs[NT];
+    SplitOperand<NT> xts[2];
     // item wi = (order position o, local parent), o-major; group j = (o + rot) % items_per_parent covers the full tiles j G ..; the
     // LAST group (the short one) also carries the parent's partial tile, which it runs first.  Tile sequence ts .. t1-1, where
     // t < t0 means "the partial tile".
@@ -233,6 +237,21 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                 for (int r = 0; r < 4; ++r) hacc[ht][r] = relu1(hacc[ht][r] + bb[r]);
             }
             f32x4 xa[2] = {zero4(), zero4()};
+            if constexpr (HX) {
+                SplitOperand<4> sh;
+                make_split<4>(hacc, sh);
+                layer_mfma_hs<HID, XD, true>(lds + LO::wh2, sh, xa, lane, bh2, lds[LO::hs + 7]);
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xa[ot][r] = node_ok ? relu1(xa[ot][r]) : 0.f;
+                    *reinterpret_cast<f32x4*>(&Xs[node * XLD + 16 * ot + 4 * q]) = xa[ot];
+                    xq[pct][ot] = xa[ot];
+                }
+                SplitOperand<2> sxa;
+                make_split<2>(xa, sxa);
+                layer_mfma_hs<XD, XD, false>(lds + LO::wa, sxa, gq[pct], lane, nullptr, lds[LO::hs + 5]);
+            } else {
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) {
                 load_fence();
@@ -264,6 +283,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
             load_fence();
             gq[pct][0] = pg[0];
             gq[pct][1] = pg[1];
+            }
         }
         __builtin_amdgcn_wave_barrier();
         load_fence();
@@ -275,6 +295,37 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                 for (int r = 0; r < 4; ++r) xt[nt][ot][r] = Xs[(16 * nt + 4 * q + r) * XLD + 16 * ot + n];      // Xh^T for p Xh and U
         load_fence();
         __builtin_amdgcn_wave_barrier();
+        if constexpr (HX) {
+            // one scale for every Xh operand (xqs, xts) and one for G: they are A operands of the products below and of the tiles'
+            float mx_x = 0.f, mx_g = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        mx_x = fmaxf(mx_x, fabsf(xq[nt][ot][r]));
+                        mx_g = fmaxf(mx_g, fabsf(gq[nt][ot][r]));
+                    }
+            float sc_x, inv_x, sc_g, inv_g;
+            pow2_scale(row16_max(kgroups_max(mx_x)), sc_x, inv_x);
+            pow2_scale(row16_max(kgroups_max(mx_g)), sc_g, inv_g);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                split_tiles<2>(xq[nt], sc_x, xqs[nt]);
+                xqs[nt].inv = inv_x;
+                split_tiles<2>(gq[nt], sc_g, gqs[nt]);
+                gqs[nt].inv = inv_g;
+            }
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                f32x4 col[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) col[nt] = xt[nt][ot];
+                split_tiles<NT>(col, sc_x, xts[ot]);
+                xts[ot].inv = inv_x;
+            }
+        }
         // part 2 (every Xh row is in registers now): S_ij = G_i . Xh_j over humans j, msh / E / Zsh, U = E Xh, UW = U W1
 #pragma unroll
         for (int pct = 0; pct < NT; ++pct) {
@@ -285,10 +336,17 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
                 f32x4 sacc = zero4();
+                if constexpr (HX) {
+                    sacc = mfma_h3(xqs[jt].hi[0], xqs[jt].lo[0], gqs[pct].hi[0], gqs[pct].lo[0], sacc);
+                    const float post = xqs[jt].inv * gqs[pct].inv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[r] *= post;
+                } else {
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sacc = mfma4(xq[jt][ft][r], gq[pct][ft][r], sacc);      // [j = 16jt+4q+r][i = my node]
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = 16 * jt + 4 * q + r;
@@ -315,6 +373,22 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                 msz[NP + node] = node_ok ? z : 1.f;
             }
             f32x4 u[2] = {zero4(), zero4()};
+            f32x4 uw[2] = {zero4(), zero4()};
+            if constexpr (HX) {
+                SplitOperand<NT> se;
+                make_split<NT>(e, se);
+                const float post = xts[0].inv * se.inv;
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+                    for (int c = 0; c < (NT + 1) / 2; ++c) u[ot] = mfma_h3(xts[ot].hi[c], xts[ot].lo[c], se.hi[c], se.lo[c], u[ot]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) u[ot][r] *= post;
+                }
+                SplitOperand<2> su;
+                make_split<2>(u, su);
+                layer_mfma_hs<XD, XD, false>(lds + LO::w1, su, uw, lane, nullptr, lds[LO::hs + 6]);
+            } else {
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -322,7 +396,6 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                     u[0] = mfma4(xt[jt][0][r], e[jt][r], u[0]);                               // U^T[f][i] = sum_j Xh[j][f] E[i][j]
                     u[1] = mfma4(xt[jt][1][r], e[jt][r], u[1]);
                 }
-            f32x4 uw[2] = {zero4(), zero4()};
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
                 load_fence();
@@ -333,6 +406,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                         uw[ot] = mfma4(w1[(16 * ft + 4 * q + r) * WLD + 16 * ot + n], u[ft][r], uw[ot]);
             }
             load_fence();
+            }
             if constexpr (PK) {                                                              // UW rows over the (consumed) Xh rows
                 if (node < HRL) {
                     *reinterpret_cast<f32x4*>(&UWs[node * 32 + 4 * q]) = uw[0];
@@ -380,6 +454,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
 
         // ---------------- embedding: x0 = w_r(robot'), y = x0 W1, g0 = x0 Wa (transposed MFMA chain) ----------------
         f32x4 xacc[2] = {zero4(), zero4()}, gacc[2] = {zero4(), zero4()}, yacc[2] = {zero4(), zero4()};
+        SplitOperand<2> sxs;                   // HX: x0 of my 16 children as split-f16 operand (embedding products, column of S)
         float s00 = 0.f;
         {
             f32x4 hacc[4] = {zero4(), zero4(), zero4(), zero4()};
@@ -396,6 +471,18 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hacc[ht][r] = relu1(hacc[ht][r] + bb[r]);
             }
+            if constexpr (HX) {
+                SplitOperand<4> sh;
+                make_split<4>(hacc, sh);
+                layer_mfma_hs<HID, XD, true>(lds + LO::wr2, sh, xacc, lane, br2, lds[LO::hs + 4]);
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xacc[ot][r] = relu1(xacc[ot][r]);
+                make_split<2>(xacc, sxs);
+                layer_mfma_hs<XD, XD, false>(lds + LO::wa, sxs, gacc, lane, nullptr, lds[LO::hs + 5]);
+                layer_mfma_hs<XD, XD, false>(lds + LO::w1, sxs, yacc, lane, nullptr, lds[LO::hs + 6]);
+            } else {
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) {
                 load_fence();
@@ -424,6 +511,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                     }
             }
             load_fence();
+            }
             if constexpr (!PK) {
                 *reinterpret_cast<f32x4*>(&Y0[n * XLD + 4 * q]) = yacc[0];
                 *reinterpret_cast<f32x4*>(&Y0[n * XLD + 16 + 4 * q]) = yacc[1];
@@ -443,9 +531,18 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         {
             f32x4 s0t[NT], sct[NT];
             float mx0 = NEG_INF;
+            SplitOperand<2> sgs;
+            if constexpr (HX) make_split<2>(gacc, sgs);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 f32x4 sc = zero4(), s0 = zero4();
+                if constexpr (HX) {
+                    sc = mfma_h3(gqs[nt].hi[0], gqs[nt].lo[0], sxs.hi[0], sxs.lo[0], sc);
+                    s0 = mfma_h3(xqs[nt].hi[0], xqs[nt].lo[0], sgs.hi[0], sgs.lo[0], s0);
+                    const float pc = gqs[nt].inv * sxs.inv, p0 = xqs[nt].inv * sgs.inv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sc[r] *= pc; s0[r] *= p0; }
+                } else {
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -453,6 +550,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                         sc = mfma4(gq[nt][ot][r], xacc[ot][r], sc);
                         s0 = mfma4(xq[nt][ot][r], gacc[ot][r], s0);
                     }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int nd = 16 * nt + 4 * q + r;
@@ -480,6 +578,18 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                 for (int r = 0; r < 4; ++r) s0t[nt][r] *= iz0;                       // p = A_c[0][:] (0 beyond row N-1)
             p00 = kgroups_sum(q == 0 ? s0t[0][0] : 0.f);
             // (p_c Xh)^T[f][c] = sum_j Xh^T[f][j] p_c[j]: the D registers of the robot-row product are already the B operand
+            if constexpr (HX) {
+                SplitOperand<NT> sp;                             // p in [0, 1]: a fixed scale
+                split_tiles<NT>(s0t, 512.f, sp);
+                const float post = xts[0].inv * (1.f / 512.f);
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+                    for (int c = 0; c < (NT + 1) / 2; ++c) t0h[ot] = mfma_h3(xts[ot].hi[c], xts[ot].lo[c], sp.hi[c], sp.lo[c], t0h[ot]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t0h[ot][r] *= post;
+                }
+            } else {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -487,6 +597,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                     t0h[0] = mfma4(xt[nt][0][r], s0t[nt][r], t0h[0]);
                     t0h[1] = mfma4(xt[nt][1][r], s0t[nt][r], t0h[1]);
                 }
+            }
             if constexpr (PK) {
                 // human row i of child c: relu((alpha UW_i + beta y_c) / Z) weighted by p_i = b_i relu(r_i UW_i + y_c) with
                 // r_i = alpha / beta = exp(msh_i - S_i0), b_i = p_i beta / Z = p_i / (r_i Zsh_i + 1); r is capped at e^60 (beyond,
@@ -612,6 +723,16 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         f32x4 tin[2], hp[2];
         {
             f32x4 o[2] = {zero4(), zero4()};
+            if constexpr (HX) {
+                f32x4 tb[2];
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tb[ft][r] = fmaf(p00, xacc[ft][r], t0h[ft][r]);      // T_0 = p_c Xh + p_c[0] x0_c
+                SplitOperand<2> stb;
+                make_split<2>(tb, stb);
+                layer_mfma_hs<XD, XD, false>(lds + LO::w1, stb, o, lane, nullptr, lds[LO::hs + 6]);
+            } else {
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
                 load_fence();
@@ -624,6 +745,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                 }
             }
             load_fence();
+            }
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
                 const f32x4 tp = PK ? tp4[ot] : *reinterpret_cast<const f32x4*>(&Y0[n * XLD + 16 * ot + 4 * q]);
@@ -756,7 +878,7 @@ __device__ __forceinline__ float frag_half2(const float* __restrict__ W, int idx
     for (int k = 0; k < 2; ++k) {
         const int e = 2 * p + k, t = 2 * c + (e >> 2);
         const int in = t < IT ? tile_feature<IN>(t, q, e & 3) : IN;
-        const float w = (in < IN && out < OUT) ? W[in * OUT + out] * sw : 0.f;
+        const float w = (in < IN && out < OUT) ? (W ? W[in * OUT + out] * sw : (in == out ? sw : 0.f)) : 0.f;      // W == null: identity
         const _Float16 hi = (_Float16)w;
         hv[k] = hl ? (_Float16)(w - (float)hi) : hi;
     }
@@ -766,10 +888,15 @@ __device__ __forceinline__ float frag_half2(const float* __restrict__ W, int idx
 // 1 / scale of the four head matrices (HX images): scale = the power of two that brings max |W| into [512, 1024)
 __global__ __launch_bounds__(256) void head_scales_kernel(const FusedArgs a, float* img, int hs_off, int d1, int d2, int d3) {
     __shared__ float red[256];
-    const float* W = blockIdx.x == 0 ? a.w_last : (blockIdx.x == 1 ? a.hw1 : (blockIdx.x == 2 ? a.hw2 : a.hw3));
-    const int n = blockIdx.x == 0 ? XD * XD : (blockIdx.x == 1 ? XD * d1 : (blockIdx.x == 2 ? d1 * d2 : d2 * d3));
+    // blocks 0..3: W_last, hw1, hw2, hw3 (value head); 4..7: wr2, wa, w1, wh2 (embedding / graph matrices of the tile and crowd chains)
+    const float* Ws[8] = {a.w_last, a.hw1, a.hw2, a.hw3, a.wr2, a.wa, a.w1, a.wh2};
+    const int ns[8] = {XD * XD, XD * d1, d1 * d2, d2 * d3, HID * XD, XD * XD, XD * XD, HID * XD};
+    const float* W = Ws[blockIdx.x];
+    const int n = ns[blockIdx.x];
     float m = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(W[i]));
+    if (W)
+        for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(W[i]));
+    else m = 1.f;                                                  // the identity (gaussian: Wa = I)
     red[threadIdx.x] = m;
     __syncthreads();
     for (int s = 128; s >= 1; s >>= 1) {
@@ -779,7 +906,6 @@ __global__ __launch_bounds__(256) void head_scales_kernel(const FusedArgs a, flo
     if (threadIdx.x == 0) {
         const unsigned E = __float_as_uint(red[0]) >> 23;
         img[hs_off + blockIdx.x] = (E < 32u || E > 254u) ? 1.f : __uint_as_float((E - 9u) << 23);      // 1 / 2^(136 - E)
-        img[hs_off + 4 + blockIdx.x] = 0.f;
     }
 }
 
@@ -792,15 +918,23 @@ __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedAr
     float v;
     if (e < LO::br1) v = matrix_element<9, HID, W1LD>(a.wr1, e - LO::wr1);
     else if (e < LO::wr2) v = a.br1[e - LO::br1];
-    else if (e < LO::br2) v = matrix_element<HID, XD, WLD>(a.wr2, e - LO::wr2);
-    else if (e < LO::wa) v = a.br2[e - LO::br2];
+    else if (e < LO::br2) {
+        if constexpr (HX) v = e - LO::wr2 < HeadFragFloats<HID, XD, true>::v ? frag_half2<HID, XD>(a.wr2, e - LO::wr2, 1.f / img[LO::hs + 4]) : 0.f;
+        else v = matrix_element<HID, XD, WLD>(a.wr2, e - LO::wr2);
+    } else if (e < LO::wa) v = a.br2[e - LO::br2];
     else if (e < LO::w1) {
         const int k = e - LO::wa, r = k / WLD, col = k - r * WLD;
-        v = a.wa ? matrix_element<XD, XD, WLD>(a.wa, k) : ((col < XD && r == col) ? 1.f : 0.f);      // gaussian: Wa = I
-    } else if (e < LO::wh1) v = matrix_element<XD, XD, WLD>(a.w1, e - LO::w1);
-    else if (e < LO::bh1) v = matrix_element<5, HID, W1LD>(a.wh1, e - LO::wh1);
+        if constexpr (HX) v = k < HeadFragFloats<XD, XD, true>::v ? frag_half2<XD, XD>(a.wa, k, 1.f / img[LO::hs + 5]) : 0.f;   // null: Wa = I
+        else v = a.wa ? matrix_element<XD, XD, WLD>(a.wa, k) : ((col < XD && r == col) ? 1.f : 0.f);      // gaussian: Wa = I
+    } else if (e < LO::wh1) {
+        if constexpr (HX) v = e - LO::w1 < HeadFragFloats<XD, XD, true>::v ? frag_half2<XD, XD>(a.w1, e - LO::w1, 1.f / img[LO::hs + 6]) : 0.f;
+        else v = matrix_element<XD, XD, WLD>(a.w1, e - LO::w1);
+    } else if (e < LO::bh1) v = matrix_element<5, HID, W1LD>(a.wh1, e - LO::wh1);
     else if (e < LO::wh2) v = a.bh1[e - LO::bh1];
-    else if (e < LO::bh2) v = matrix_element<HID, XD, WLD>(a.wh2, e - LO::wh2);
+    else if (e < LO::bh2) {
+        if constexpr (HX) v = e - LO::wh2 < HeadFragFloats<HID, XD, true>::v ? frag_half2<HID, XD>(a.wh2, e - LO::wh2, 1.f / img[LO::hs + 7]) : 0.f;
+        else v = matrix_element<HID, XD, WLD>(a.wh2, e - LO::wh2);
+    }
     else if (e < LO::b1) v = a.bh2[e - LO::bh2];
     else if (e < LO::b2) v = bias_element<D1>(a.hb1, e - LO::b1);
     else if (e < LO::b3) v = bias_element<D2>(a.hb2, e - LO::b2);
@@ -825,7 +959,7 @@ __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedAr
 inline int launch_pack_image(const FusedArgs& a, float* img, bool hx, hipStream_t stream) {
     if (hx) {
         using LO = FusedLds<32, 100, 100, true>;
-        hipLaunchKernelGGL(head_scales_kernel, dim3(4), dim3(256), 0, stream, a, img, (int)LO::hs, 32, 100, 100);
+        hipLaunchKernelGGL(head_scales_kernel, dim3(8), dim3(256), 0, stream, a, img, (int)LO::hs, 32, 100, 100);
         RGL_LAUNCH_CHECK();
         hipLaunchKernelGGL((pack_images_kernel<32, 100, 100, true>), dim3((unsigned)((LO::scratch + kPackThreads - 1) / kPackThreads)),
                            dim3(kPackThreads), 0, stream, a, img);
@@ -1083,13 +1217,20 @@ int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, i
         }
     }
     FusedPlan fp = plan_fused(*g, *head, P, A, H, unit, hx != 0);
+    // the split-f16 image is 7 KB larger: crowds of 21..32 agents (lane = feature row pass, larger wave scratch) do not fit a CU
+    // with it -- they run the f32 form of this kernel on an f32 image packed here (the caller's image is in the other layout)
+    bool own_image = false;
+    if (!fp.ok && hx) {
+        fp = plan_fused(*g, *head, P, A, H, unit, false);
+        own_image = fp.ok;
+    }
     if (!fp.ok) return 1;
     if (!workspace || workspace_bytes < fused_children_workspace_bytes(P, A, H)) return 1;
-    if (!image_ready && !caller_image) {
-        int rc = pack_children_images(g, head, P, A, H, workspace, workspace_bytes, stream, hx);
+    if (own_image || (!image_ready && !caller_image)) {
+        int rc = launch_pack_image(fp.a, image_of(workspace, workspace_bytes), fp.hx, stream);
         if (rc) return rc;
     }
-    const float* image = caller_image ? caller_image : image_of(workspace, workspace_bytes);
+    const float* image = (caller_image && !own_image) ? caller_image : image_of(workspace, workspace_bytes);
     float* rows_left = (float*)workspace;
     fp.a.child_robot = child_robot;
     fp.a.humans = humans_next;

@@ -1149,8 +1149,8 @@ def test_properties_of_the_other_baseline_workloads(tag, H, L, D, B, contraction
 
 
 def test_f16x3_value_head_at_size_and_at_extreme_magnitudes(dev):
-    """RGL_CONTRACT_F16X3 (ABI 4): the value head's dense products as three split-f16 MFMA terms over power-of-two-scaled operands
-    (layer_mfma_h).  (1) configs[2] in full -- 2048 roots, bench.py's scenes and weights -- against the batched oracle at the
+    """RGL_CONTRACT_F16X3 (ABI 4): the dense products of the fused children kernel -- value head, embedding chains, robot row / column
+    of S, p Xh, the crowd quantities -- as three split-f16 MFMA terms over power-of-two-scaled operands (layer_mfma_hs, mfma_h3).  (1) configs[2] in full -- 2048 roots, bench.py's scenes and weights -- against the batched oracle at the
     f32 tolerance 1e-4 (measured ~1e-7), decisions as for the f32 path; (2) against the library's own f32 path; (3) the scaling: the
     head's weights multiplied by 3e4 / 2e-5 per layer (activations far outside f16's range) still match a float64 evaluation of
     the same head to 1e-5 RELATIVE -- any finite input is handled."""
@@ -1203,6 +1203,18 @@ def test_f16x3_value_head_at_size_and_at_extreme_magnitudes(dev):
                 m.weight.copy_(w)
                 m.bias.copy_(b)
     report("f16x3 value head under extreme layer scales (3e4 / 2e-5 / 1e-9 per layer): worst relative error vs float64 %.1e" % worst)
+    # other shapes of the mode: one node tile (N = 6), a depth-3 search, and N = 31 (its split-f16 image does not fit a CU beside
+    # the larger wave scratch: the f32 form of the kernel runs on an image it packs itself) -- against the oracle
+    for Hh, D, Bb in ((5, 1, 64), (19, 3, 24), (30, 2, 12), (12, 2, 300)):
+        Args.layers, Args.depth, Args.width, Args.humans, Args.contraction = 2, D, 2, Hh, "f16x3"
+        p3 = bench.make_policy(Args, dev)
+        rb, hb = bench.synth_scenes(77 + Hh, Bb, Hh)
+        a3, v3 = p3.predict_batch(rb.to(dev), hb.to(dev), roots_are_joint_states=True)
+        cfg = orc.OracleConfig(planning_depth=D, planning_width=2, do_action_clip=D > 1)
+        with torch.no_grad():
+            oa, ov, orv, okept, lv = orc.mprl_predict_batched(rb, hb, gio.oracle_params("trained"), cfg, return_levels=True)
+        close(v3.cpu().numpy(), ov.numpy())
+        check_decisions("f16x3, H=%d D=%d B=%d" % (Hh, D, Bb), a3, v3, (oa, ov, orv, okept), lv)
 
 
 _ORACLE_AT_SIZE = {}
