@@ -8,6 +8,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R
 bash tools/round_profile.sh $TAG $HASH > $O/${TAG}_round_profile.log 2>&1
+cp $O/${TAG}_traffic.json $R/profiles/${TAG}_traffic.json 2>/dev/null      # the bench lines below quote the record just measured
 python bench.py --steps 50 --warmup 10 2>/dev/null | grep "^{" > $O/${TAG}_bench_default.json
 bash tools/other_configs.sh $TAG > $O/${TAG}_other_configs.log 2>&1
 bash tools/share_regime.sh $TAG > $O/${TAG}_share_regime.txt 2>&1
