@@ -254,6 +254,19 @@ class _PackCache:
         return (_PackCache, ())
 
 
+def invalidate_packed_weights(*modules):
+    """Forget the packed descriptors (k-major weight copies, weight images) of `modules` and their sub-modules: the next forward
+    repacks from the current parameters.  Needed after parameters were changed WITHOUT autograd's version counters noticing --
+    i.e. after replaying a hipGraph that contains an optimizer step (a captured training step, tools/train_step_time.py --graph):
+    replays mutate the parameters in place but do not bump `tensor._version`, which is what the caches key on."""
+    for top in modules:
+        for m in top.modules():
+            for name in ("_cache", "_head_cache"):
+                c = getattr(m, name, None)
+                if isinstance(c, _PackCache):
+                    c.key = None
+
+
 def graph_forward(graph, value_head, motion_head, robot, humans, scenes_per_crowd=1, want_H=False, want_A=False):
     """Thin wrapper over rgl_graph_forward_f32.  robot (S,rd), humans (S/spc,H,hd) -> dict of outputs."""
     robot = _require_device_tensor(robot, "robot states")

@@ -1659,6 +1659,67 @@ def test_training_against_the_reference_vnrl_trainer_fixture(case, dev):
            % (tag, worst, losses / 2))
 
 
+def test_training_step_replayed_from_a_captured_graph(dev):
+    """A whole MPRLTrainer-style optimisation step (value forward, frozen-target forward, backward, Adam; state-predictor forward,
+    backward, Adam: crowd_nav/utils/trainer.py:110-161) captured once into a hipGraph and replayed: the library allocates nothing
+    outside torch's allocator, never synchronises, and repacks its descriptors on the capture stream, so the capture is legal -- and
+    four replays must leave the parameters where four eager steps leave them.  (Batch 100: 1.2-1.5 ms eager, 0.40-0.45 ms replayed,
+    profiles/r03_final_train_step_graph.jsonl.)  Replays do not bump autograd's version counters: invalidate_packed_weights()
+    afterwards, then an eager forward sees the trained weights."""
+    import copy
+    c = dict(L=2, sim="embedded_gaussian", layerwise=False, skip=True, flavour="trained")
+    robot, humans = seeded_scenes(31, 100, 5)
+    robot2, humans2 = seeded_scenes(32, 100, 5)
+    r, h, r2, h2 = robot.unsqueeze(1).to(dev), humans.to(dev), robot2.unsqueeze(1).to(dev), humans2.to(dev)
+    rew = torch.rand(100, 1, generator=torch.Generator().manual_seed(5)).to(dev)
+    crit = torch.nn.MSELoss()
+
+    def make():
+        _, ve, sp = build_modules(c, dev)
+        target = copy.deepcopy(ve)
+        v_opt = torch.optim.Adam(ve.parameters(), lr=1e-3, capturable=True)
+        s_opt = torch.optim.Adam(sp.human_motion_predictor.parameters(), lr=1e-3, capturable=True)
+
+        def step():
+            v_opt.zero_grad()
+            out = ve((r, h))
+            with torch.no_grad():
+                tgt = rew + 0.9 * target((r2, h2))
+            crit(out, tgt).backward()
+            v_opt.step()
+            s_opt.zero_grad()
+            _, nh = sp((r, h), None, detach=True)
+            crit(nh, h2).backward()
+            s_opt.step()
+        return ve, sp, step
+    ve_a, sp_a, step_a = make()
+    for _ in range(5):
+        step_a()
+    ve_b, sp_b, step_b = make()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step_b()                                              # one real step (warm-up of the capture recipe)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step_b()                                              # recorded, not executed
+    for _ in range(4):
+        g.replay()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for ma, mb in ((ve_a, ve_b), (sp_a, sp_b)):
+        for (k, pa), (_, pb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+            err = float((pa - pb).abs().max())
+            worst = max(worst, err)
+            assert err <= 1e-6, (k, err)
+    rga.invalidate_packed_weights(ve_b, sp_b)
+    with torch.no_grad():
+        va, vb = ve_a((r, h)), ve_b((r, h))
+    assert float((va - vb).abs().max()) <= 1e-6
+    report("training step replayed from a captured hipGraph: parameters after 1 + 4 steps within %.1e of five eager steps" % worst)
+
+
 def test_path_g_query_env_against_the_reference_fixture(dev):
     """Fixture training_queryenv.npz: the reference MultiHumanRL.predict with query_env=True on the reference CrowdSim (linear
     humans), four states a few steps into seeded test cases: 81 action values and the chosen action."""

@@ -17,6 +17,7 @@ bash tools/timeline.sh $O/${TAG}_timeline.md --roots 256
 bash tools/timeline.sh $O/${TAG}_timeline.md --roots 512 --depth 3
 bash tools/timeline.sh $O/${TAG}_timeline.md --roots 2048
 python tools/train_step_time.py > $O/${TAG}_train_step.jsonl 2>/dev/null
+python tools/train_step_time.py --graph 2>/dev/null | grep "^{" > $O/${TAG}_train_step_graph.jsonl
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_tr && rocprofv3 --kernel-trace --stats -d /tmp/prof_tr -o tr -- python $R/tools/train_step_time.py > /dev/null 2>&1; \
   { echo "# $TAG: kernel trace of tools/train_step_time.py (H = 5 / 19, batch 100 / 4096; source revision $HASH)"; echo; \
     python $R/tools/rocpd_summary.py $(find /tmp/prof_tr -name "*results.db" | head -1) | head -24; } > $O/${TAG}_train_step_trace.md )

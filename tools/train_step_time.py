@@ -28,13 +28,14 @@ def forward_flops(N, L=2, head=28648, motion=False):
 
 def main():
     dev = torch.device("cuda:0")
+    graph_mode = "--graph" in sys.argv     # the whole optimisation step captured once into a hipGraph and replayed
     for H in (5, 19):
         for B in (100, 4096):
             pol = make_mprl_policy("trained", 1, device=dev)
             ve, sp = pol.value_estimator, pol.state_predictor
             target = copy.deepcopy(ve)
-            v_opt = torch.optim.Adam(ve.parameters(), lr=1e-3)
-            s_opt = torch.optim.Adam(sp.human_motion_predictor.parameters(), lr=1e-3)
+            v_opt = torch.optim.Adam(ve.parameters(), lr=1e-3, capturable=graph_mode)
+            s_opt = torch.optim.Adam(sp.human_motion_predictor.parameters(), lr=1e-3, capturable=graph_mode)
             robot, humans = seeded_scenes(3, B, H)
             robot2, humans2 = seeded_scenes(4, B, H)
             r, h, r2, h2 = robot.unsqueeze(1).to(dev), humans.to(dev), robot2.unsqueeze(1).to(dev), humans2.to(dev)
@@ -54,19 +55,31 @@ def main():
                 l2 = crit(nh, h2)
                 l2.backward()
                 s_opt.step()
+            run = step
+            if graph_mode:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        step()
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    step()
+                run = g.replay
             for _ in range(10):
-                step()
+                run()
             torch.cuda.synchronize()
             reps = 50 if B == 100 else 10
             t0 = time.perf_counter()
             for _ in range(reps):
-                step()
+                run()
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / reps * 1e3
             N = H + 1
             # value forward + target forward + value backward (2 forwards) + predictor forward + predictor backward (2)
             flops = B * (4 * forward_flops(N) + 3 * forward_flops(N, motion=True))
-            print(json.dumps({"workload": "MPRLTrainer-style optimisation step, H=%d, batch %d" % (H, B), "ms_per_step": ms,
+            print(json.dumps({"workload": "MPRLTrainer-style optimisation step, H=%d, batch %d%s" % (H, B, ", replayed from a captured hipGraph" if graph_mode else ""), "ms_per_step": ms,
                               "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK / 1e12,
                                            "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / PEAK,
                                            "flops_per_step": flops,
