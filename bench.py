@@ -188,8 +188,10 @@ def make_policy(args, device):
     return pol
 
 
-def cpu_baseline(args, robot, humans, budget_s):
-    """The CPU oracle timed on this host: (i) the reference-order batch-1 walk, (ii) the batched restatement."""
+def cpu_baseline(args, robot, humans, budget_s, device_values=None):
+    """The CPU oracle timed on this host: (i) the reference-order batch-1 walk, (ii) the batched restatement.
+    `device_values`: {mode: best_value tensor of the first roots} -- their deviation from a FLOAT64 evaluation of the same search
+    (the oracle on double tensors, 64 roots) is reported beside the timings (`float64_check`): the checker at work, not timed."""
     from oracle import rgl_oracle as orc          # test infrastructure: only this leg may touch it
     from tests import golden_io as gio
     P = gio.oracle_params("trained", args.layers)
@@ -221,7 +223,18 @@ def cpu_baseline(args, robot, humans, budget_s):
             if time.time() - t0 > budget_s * 0.5:
                 break
     t_bat = time.time() - t0
-    return {"value": n_seq * per_root / t_seq, "unit": "evals/s", "cores": 1, "kind": "port",
+    f64 = None
+    if device_values:
+        n64 = min(64, robot.shape[0])
+        ck = gio.checkpoint("trained", args.layers)
+        P64 = orc.MprlParams.from_checkpoint({k: {kk: vv.double() for kk, vv in v.items()} for k, v in ck.items()})
+        with torch.no_grad():
+            _, v64, _, _ = orc.mprl_predict_batched(robot[:n64].double(), humans[:n64].double(), P64, cfg)
+            _, v32, _, _ = orc.mprl_predict_batched(robot[:n64], humans[:n64], P, cfg)
+        f64 = {"roots": n64, "max_abs_dV_vs_float64": {k: float((v[:n64].double().cpu() - v64).abs().max())
+                                                       for k, v in device_values.items()}}
+        f64["max_abs_dV_vs_float64"]["f32 oracle (torch CPU)"] = float((v32.double() - v64).abs().max())
+    return {"value": n_seq * per_root / t_seq, "unit": "evals/s", "cores": 1, "kind": "port", "float64_check": f64,
             "sample": "%d roots, reference-order batch-1 walk (%d value forwards/root), 1 thread, %.1f s"
                       % (n_seq, per_root, t_seq),
             "batched_value": reps * nb * per_root / t_bat, "batched_cores": threads,
@@ -680,7 +693,12 @@ def main():
         result["multi_gpu"] = multi
         result["ranks_seen"] = multi["ranks_seen"]
     if rank == 0 and world == 1 and args.cpu_seconds > 0 and not STUB:
-        result["cpu_baseline"] = cpu_baseline(args, leg.robot_cpu, leg.humans_cpu, args.cpu_seconds)
+        dv = {"f32 kernels": ts.search(leg.robot[:64], leg.humans[:64], roots_are_joint_states=False,
+                                       want_root_values=False)["best_value"].clone()}
+        if x3 is not None:
+            dv["f16x3 kernels"] = ts3.search(leg.robot[:64], leg.humans[:64], roots_are_joint_states=False,
+                                             want_root_values=False)["best_value"].clone()
+        result["cpu_baseline"] = cpu_baseline(args, leg.robot_cpu, leg.humans_cpu, args.cpu_seconds, dv)
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:

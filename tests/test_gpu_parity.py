@@ -1175,6 +1175,19 @@ def test_f16x3_value_head_at_size_and_at_extreme_magnitudes(dev):
     assert d32 < 1e-5 and same > 0.995, (d32, same)
     report("f16x3 value head, configs[2] in full: max |dV| vs the oracle %.2e, vs the f32 kernels %.2e, %.2f %% identical decisions"
            % (err, d32, 100 * same))
+    # (2b) against a FLOAT64 evaluation of the same search (the oracle on double tensors, 256 roots): the deviation of the split-f16
+    # mode from the exact result next to that of the f32 kernels and of the f32 oracle itself
+    n64 = 256
+    P64 = orc.MprlParams.from_checkpoint({k: {kk: vv.double() for kk, vv in v.items()} for k, v in gio.checkpoint("trained", 2).items()})
+    cfg64 = orc.OracleConfig(planning_depth=2, planning_width=2, do_action_clip=True)
+    with torch.no_grad():
+        _, v64, _, _ = orc.mprl_predict_batched(robot[:n64].double(), humans[:n64].double(), P64, cfg64)
+    e_x3 = float((val[:n64].double().cpu() - v64).abs().max())
+    e_32 = float((v32[:n64].double().cpu() - v64).abs().max())
+    e_or = float((oracle_out[1][:n64].double() - v64).abs().max())
+    report("deviation from a float64 evaluation (256 roots of configs[2]): split-f16 kernels %.2e, f32 kernels %.2e, f32 oracle (torch CPU) %.2e"
+           % (e_x3, e_32, e_or))
+    assert e_x3 < 5e-7 and e_32 < 5e-7
     # (3) magnitudes: children's values with a head whose layers are scaled up / down
     ts = pol.tree_search()
     r, h = robot[:64].to(dev), humans[:64].to(dev)
