@@ -247,6 +247,10 @@ typedef struct MprlPlanner {
      * a captured decision graph) packs once and re-packs after a parameter update; without it every search (or
      * stand-alone mprl_value_children_f32 call) packs the image into its workspace first (~5 us). */
     const float* children_image;
+    /* optional (NULL = absent; ABI 4): device buffer of mprl_predictor_image_bytes() bytes holding the state predictor's scene
+     * kernel weight image in the split-f16 layout (RGL_CONTRACT_F16X3 only), prepared by mprl_pack_predictor_image_f32 from THIS
+     * planner's predictor_graph / motion_head.  NULL: a search in that mode packs it into its workspace itself. */
+    const float* predictor_image;
 } MprlPlanner;
 
 /* Bytes of the weight image above; 0 when the configuration has no image-based children kernel (the searches then ignore
@@ -255,6 +259,9 @@ size_t mprl_children_image_bytes(const MprlPlanner* planner);
 /* Builds the image from the planner's current value_graph / value_head weights on `stream` (planner->children_image is not
  * read).  RGL_ERR_BAD_MODE when mprl_children_image_bytes() is 0, RGL_ERR_WORKSPACE when `image_bytes` is too small. */
 int mprl_pack_children_image_f32(const MprlPlanner* planner, float* image, size_t image_bytes, rgl_stream_t stream);
+/* The same for MprlPlanner::predictor_image (ABI 4).  0 bytes: the planner's mode / predictor has no such image. */
+size_t mprl_predictor_image_bytes(const MprlPlanner* planner);
+int mprl_pack_predictor_image_f32(const MprlPlanner* planner, float* image, size_t image_bytes, rgl_stream_t stream);
 
 /* One tree level for P parent states (the unit `action_clip` evaluates, :242-269):
  *   humans_next[p]      = StatePredictor humans of parent p (or the linear approximation)

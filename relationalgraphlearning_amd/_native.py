@@ -59,7 +59,7 @@ class MprlPlanner(C.Structure):
                 ("do_action_clip", C.c_int), ("sparse_search", C.c_int), ("contraction_dtype", C.c_int),
                 ("time_step", C.c_double), ("gamma_bar", C.c_double), ("actions", C.c_void_p),
                 ("action_groups", C.c_void_p), ("root_robot_f64", C.c_void_p), ("root_humans_f64", C.c_void_p),
-                ("children_image", C.c_void_p)]
+                ("children_image", C.c_void_p), ("predictor_image", C.c_void_p)]
 
 
 class CrowdSimConfig(C.Structure):
@@ -98,6 +98,8 @@ SIGNATURES = {
     "mprl_value_children_workspace_bytes": (C.c_size_t, [C.POINTER(MprlPlanner), C.c_int, C.c_int]),
     "mprl_children_image_bytes": (C.c_size_t, [C.POINTER(MprlPlanner)]),
     "mprl_pack_children_image_f32": (C.c_int, [C.POINTER(MprlPlanner), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mprl_predictor_image_bytes": (C.c_size_t, [C.POINTER(MprlPlanner)]),
+    "mprl_pack_predictor_image_f32": (C.c_int, [C.POINTER(MprlPlanner), C.c_void_p, C.c_size_t, C.c_void_p]),
     "mprl_value_children_f32": (C.c_int, [C.POINTER(MprlPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_size_t, C.c_void_p]),
     "mprl_tree_workspace_bytes": (C.c_size_t, [C.POINTER(MprlPlanner), C.c_int, C.c_int]),

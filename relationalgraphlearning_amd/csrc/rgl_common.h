@@ -98,9 +98,14 @@ size_t value_children_workspace_bytes(const MprlPlanner* pl, int P, int H);     
 // `children` (optional): a ChildrenArgs (rgl_children.h, passed opaquely with its size) describing the level's independent
 // next-state / reward work; when the MFMA scene kernel runs, it executes that work on extra workgroups of the same launch
 // and sets *children_done.
+// `sp_image`: the split-f16 weight image of the scene kernel (scene_image_bytes, pack_scene_image) when the planner's mode is
+// RGL_CONTRACT_F16X3; without one the f32 form of the kernel runs
 int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float* humans, int crowds_per, int P, int H,
                           float* humans_next, void* workspace, size_t workspace_bytes, hipStream_t stream,
-                          const void* children = nullptr, size_t children_bytes = 0, int* children_done = nullptr);  // rgl_scene.hip
+                          const void* children = nullptr, size_t children_bytes = 0, int* children_done = nullptr,
+                          const float* sp_image = nullptr);                                                           // rgl_scene.hip
+size_t scene_image_bytes(const MprlPlanner* pl);                      // 0: no split-f16 scene kernel for this planner
+int pack_scene_image(const MprlPlanner* pl, float* image, hipStream_t stream);
 
 int launch_scene_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
                           float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream);         // rgl_scene.hip

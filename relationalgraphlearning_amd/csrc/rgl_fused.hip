@@ -862,29 +862,6 @@ __device__ __forceinline__ float matrix_element(const float* __restrict__ W, int
     return (r < ROWS && c < COLS) ? W[r * COLS + c] : 0.f;
 }
 
-// float slot `idx` of the f16 (hi, lo) fragment image of W (k-major [IN][OUT]) scaled by sw: two halves.  Unit u = idx / 4 is one
-// lane's 8-half fragment: u = ((ot NC + c) 2 + hl) 64 + lane; half e of it is W[in = tile_feature<IN>(2c + e / 4, q, e % 4)][out of
-// A-operand row lane % 16] -- hi = f16(w sw), lo = f16(w sw - hi).
-template <int IN, int OUT>
-__device__ __forceinline__ float frag_half2(const float* __restrict__ W, int idx, float sw) {
-    constexpr int IT = Tiles<IN>::v, NC = (IT + 1) / 2;
-    const int u = idx >> 2, p = idx & 3;
-    const int l = u & 63, rest = u >> 6;
-    const int hl = rest & 1, c = (rest >> 1) % NC, ot = (rest >> 1) / NC;
-    const int m = l & 15, q = l >> 4;
-    const int out = tile_feature<OUT>(ot, m >> 2, m & 3);
-    f16x2 hv;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int e = 2 * p + k, t = 2 * c + (e >> 2);
-        const int in = t < IT ? tile_feature<IN>(t, q, e & 3) : IN;
-        const float w = (in < IN && out < OUT) ? (W ? W[in * OUT + out] * sw : (in == out ? sw : 0.f)) : 0.f;      // W == null: identity
-        const _Float16 hi = (_Float16)w;
-        hv[k] = hl ? (_Float16)(w - (float)hi) : hi;
-    }
-    return __builtin_bit_cast(float, hv);
-}
-
 // 1 / scale of the four head matrices (HX images): scale = the power of two that brings max |W| into [512, 1024)
 __global__ __launch_bounds__(256) void head_scales_kernel(const FusedArgs a, float* img, int hs_off, int d1, int d2, int d3) {
     __shared__ float red[256];

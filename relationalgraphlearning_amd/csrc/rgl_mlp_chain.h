@@ -287,6 +287,34 @@ __device__ __forceinline__ void layer_mfma_h(const float* frags, const f32x4 (&i
     layer_mfma_hs<IN, OUT, BIAS>(frags, s, out, lane, bias, inv_sw);
 }
 
+// float slot `idx` of the f16 (hi, lo) fragment image layer_mfma_hs reads, for a k-major matrix W[in * ld + out] (columns >= n_out
+// and rows >= IN: 0; W == null: the identity) scaled by sw: two halves.  Unit u = idx / 4 is one lane's 8-half fragment:
+// u = ((ot NC + c) 2 + hl) 64 + lane; half e of it is W[in = tile_feature<IN>(2c + e / 4, q, e % 4)][out of A-operand row lane % 16]
+// -- hi = f16(w sw), lo = f16(w sw - hi).
+template <int IN, int OUT>
+__device__ __forceinline__ float frag_half2_ld(const float* __restrict__ W, int ld, int n_out, int idx, float sw) {
+    constexpr int IT = Tiles<IN>::v, NC = (IT + 1) / 2;
+    const int u = idx >> 2, p = idx & 3;
+    const int l = u & 63, rest = u >> 6;
+    const int hl = rest & 1, c = (rest >> 1) % NC, ot = (rest >> 1) / NC;
+    const int m = l & 15, q = l >> 4;
+    const int out = tile_feature<OUT>(ot, m >> 2, m & 3);
+    f16x2 hv;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = 2 * p + k, t = 2 * c + (e >> 2);
+        const int in = t < IT ? tile_feature<IN>(t, q, e & 3) : IN;
+        const float w = (in < IN && out < n_out) ? (W ? W[in * ld + out] * sw : (in == out ? sw : 0.f)) : 0.f;
+        const _Float16 hi = (_Float16)w;
+        hv[k] = hl ? (_Float16)(w - (float)hi) : hi;
+    }
+    return __builtin_bit_cast(float, hv);
+}
+template <int IN, int OUT>
+__device__ __forceinline__ float frag_half2(const float* __restrict__ W, int idx, float sw) {
+    return frag_half2_ld<IN, OUT>(W, OUT, OUT, idx, sw);
+}
+
 template <int OUT>
 __device__ __forceinline__ void relu_tiles(f32x4 (&x)[Tiles<OUT>::v]) {
 #pragma unroll

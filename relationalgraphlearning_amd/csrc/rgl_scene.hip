@@ -90,6 +90,9 @@ struct SceneArgs {
     const float *er_w1, *er_b1, *er_w2, *er_b2;      // w_r, k-major [9][64], [64], [64][32], [32]
     const float *eh_w1, *eh_b1, *eh_w2, *eh_b2;      // w_h
     int off_er, off_eh;                // LDS: fragment sets of the two MLPs (kRowMlpSetFloats each)
+    int hx;                            // launch the split-f16 (HX) form of the kernel
+    const float* image;                // HX: the weight image [0, off_hs + 8) in this kernel's LDS layout (pack_scene_image)
+    int off_hs;                        // HX kernels: 8 floats, 1 / scale of Wa, Ws[0..3], wm1, wm2 (their blocks hold f16 (hi, lo) fragments)
     const float* xh_rows;              // [n_crowds][H][32]  human embeddings
     const float* x0_rows;              // [P][32]            robot embeddings
     int crowds_per;                    // scene s uses crowd s / crowds_per
@@ -128,9 +131,13 @@ constexpr int M2LD = 20;   // LDS row stride of the [64][5 -> 16] motion output 
 // row_mlp2_tiles) instead of reading rows a separate launch prepared -- with few scenes that launch is ~5 us of latency for ~1 us
 // of work (and a round trip through HBM); sibling scenes repeat their crowd's human embeddings, which only matters when the
 // kernel is throughput-bound (many scenes: the launcher keeps the two-launch form there).
-template <int NT, int SK, int WAVES, bool CH, bool SPLIT, bool EMB = false>
+// HX (RGL_CONTRACT_F16X3, softmax similarity): every product below as three split-f16 MFMA terms (layer_mfma_hs / mfma_h3,
+// rgl_mlp_chain.h); the weight image then holds f16 (hi, lo) fragments of the power-of-two-scaled matrices, converted when the
+// workgroup fills it (the scales from a max reduction over each matrix through LDS atomics).
+template <int NT, int SK, int WAVES, bool CH, bool SPLIT, bool EMB = false, bool HX = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneArgs a, const ChildrenArgs ca, int grid_scene) {
     static_assert(!SPLIT || (SK != 3 && NT > 1 && WAVES % NT == 0), "split scenes: whole scenes per workgroup, no pair-MLP similarity");
+    static_assert(!HX || SK == 0, "split-f16 products: softmax similarity");
     constexpr int kSceneThreads = WAVES * 64;
     constexpr int kSlots = SPLIT ? WAVES / NT : WAVES;      // scenes in flight per workgroup
     constexpr int NCT = SPLIT ? 1 : NT;                     // column tiles of a scene this wave owns
@@ -161,6 +168,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
     const int slot = __builtin_amdgcn_readfirstlane(SPLIT ? wave / NT : wave);
     const int ctb = SPLIT ? __builtin_amdgcn_readfirstlane(wave % NT) : 0;      // my first (SPLIT: only) column tile
     float* Hs = lds + a.off_wave + slot * a.wave_stride;   // [16*NT][XLD] node features of the slot's current scene
+    if constexpr (HX) {
+        // split-f16 image, packed once per parameter state (or per search) in exactly this layout: b128 copies, every load of a
+        // thread in flight at once.  (Converting the matrices here -- two L2 round trips per fragment element -- cost 10 us per launch.)
+        const int n4 = (a.off_hs + 8) >> 2;
+        for (int i = tid; i < n4; i += kSceneThreads)
+            reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(a.image)[i];
+    } else
     {   // weight image in two phases -- every global load of the thread first, then the LDS stores -- so that the whole
         // 30 KB image costs ONE L2 round trip (filling matrix by matrix cost one per matrix: ~9 us of a ~35 us launch)
         float* w = lds;
@@ -208,17 +222,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
             fill_matrix<2 * XD, 2 * XD, HID, W1LD, kSceneThreads>(w + a.off_wc1, a.wc1, tid);
             for (int i = tid; i < HID; i += kSceneThreads) { w[a.off_bc1 + i] = a.bc1[i]; w[a.off_wc2 + i] = a.wc2[i]; }
         }
-        if constexpr (EMB) {
-            constexpr int F1 = 0, F2 = F1 + 4 * 1 * 4 * 64, B1 = F2 + 2 * 4 * 4 * 64, B2 = B1 + HID;
-            fill_frags<9, HID, kSceneThreads>(w + a.off_er + F1, a.er_w1, tid);
-            fill_frags<HID, XD, kSceneThreads>(w + a.off_er + F2, a.er_w2, tid);
-            fill_bias<HID>(w + a.off_er + B1, a.er_b1, tid, kSceneThreads);
-            fill_bias<XD>(w + a.off_er + B2, a.er_b2, tid, kSceneThreads);
-            fill_frags<5, HID, kSceneThreads>(w + a.off_eh + F1, a.eh_w1, tid);
-            fill_frags<HID, XD, kSceneThreads>(w + a.off_eh + F2, a.eh_w2, tid);
-            fill_bias<HID>(w + a.off_eh + B1, a.eh_b1, tid, kSceneThreads);
-            fill_bias<XD>(w + a.off_eh + B2, a.eh_b2, tid, kSceneThreads);
-        }
+    }
+    if constexpr (EMB) {
+        float* w = lds;
+        constexpr int F1 = 0, F2 = F1 + 4 * 1 * 4 * 64, B1 = F2 + 2 * 4 * 4 * 64, B2 = B1 + HID;
+        fill_frags<9, HID, kSceneThreads>(w + a.off_er + F1, a.er_w1, tid);
+        fill_frags<HID, XD, kSceneThreads>(w + a.off_er + F2, a.er_w2, tid);
+        fill_bias<HID>(w + a.off_er + B1, a.er_b1, tid, kSceneThreads);
+        fill_bias<XD>(w + a.off_er + B2, a.er_b2, tid, kSceneThreads);
+        fill_frags<5, HID, kSceneThreads>(w + a.off_eh + F1, a.eh_w1, tid);
+        fill_frags<HID, XD, kSceneThreads>(w + a.off_eh + F2, a.eh_w2, tid);
+        fill_bias<HID>(w + a.off_eh + B1, a.eh_b1, tid, kSceneThreads);
+        fill_bias<XD>(w + a.off_eh + B2, a.eh_b2, tid, kSceneThreads);
     }
     __syncthreads();
     // scene of slot k in pass i: blockIdx + grid_scene * k + i * grid_scene * kSlots (partial round: one scene per workgroup).  SPLIT:
@@ -345,6 +360,41 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
             }
             // G^T = Wa^T X^T   (per column tile: [g = 16gt+4q+r][col n])
             f32x4 gt_[NT][2];
+            if constexpr (HX) {
+                SplitOperand<2> sg[NT];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    load_fence();
+                    f32x4 xin[2];
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft)
+                        xin[ft] = *reinterpret_cast<const f32x4*>(&Hs[(16 * (ct + ctb) + n) * XLD + 16 * ft + 4 * q]);
+                    SplitOperand<2> sx;
+                    make_split<2>(xin, sx);
+                    layer_mfma_hs<XD, XD, false>(wa, sx, gt_[ct], lane, nullptr, lds[a.off_hs + 0]);
+                    make_split<2>(gt_[ct], sg[ct]);
+                }
+                // S^T[j][col] = X[j] . G[col]: the rows of X as A operand (one scale per node tile: its rows are other lanes' columns)
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt) {
+                    load_fence();
+                    const int jrow = (PERM && jt == NT - 1) ? 4 * (n & 3) + (n >> 2) : n;           // D row m <-> node perm(m), see jnode
+                    f32x4 xa[2];
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft)
+                        xa[ft] = *reinterpret_cast<const f32x4*>(&Hs[(16 * jt + jrow) * XLD + 16 * ft + 4 * q]);
+                    SplitOperand<2> sa;
+                    make_split_wave<2>(xa, sa);
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        f32x4 sacc = mfma_h3(sa.hi[0], sa.lo[0], sg[ct].hi[0], sg[ct].lo[0], zero4());
+                        const float post = sa.inv * sg[ct].inv;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sacc[r] *= post;
+                        pr[ct][jt] = sacc;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 gt_[ct][0] = zero4();
@@ -376,6 +426,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                     }
                     pr[ct][jt] = sacc;
                 }
+            }
             if (SK == 2) {
                 // cosine family (graph_model.py:70-79): C_ij = S_ij / (m_i m_j), m_i = |S_i,:|_2 (rows of S itself).  Row norm of
                 // column i: over my registers and the four q-groups; m_j of the other index goes through the padding column
@@ -452,6 +503,35 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                 acc[ct][0] = zero4();
                 acc[ct][1] = zero4();
             }
+            if constexpr (HX) {
+                // H^T as A operand (rows = features, k = nodes in the order of the adjacency registers), one scale for the wave;
+                // the adjacency columns as B operand (probabilities: a fixed scale)
+                load_fence();
+                SplitOperand<NT> sh[2];
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    f32x4 hcol[NT];
+#pragma unroll
+                    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) hcol[jt][r] = Hs[jnode(jt, r) * XLD + 16 * ot + n];
+                    make_split_wave<NT>(hcol, sh[ot]);
+                }
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    if (rows_only && ct + ctb > 0) continue;
+                    SplitOperand<NT> sp;
+                    split_tiles<NT>(pr[ct], 512.f, sp);
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+                        for (int c = 0; c < (NT + 1) / 2; ++c) acc[ct][ot] = mfma_h3(sh[ot].hi[c], sh[ot].lo[c], sp.hi[c], sp.lo[c], acc[ct][ot]);
+                        const float post = sh[ot].inv * (1.f / 512.f);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[ct][ot][r] *= post;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
                 load_fence();
@@ -467,6 +547,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                         acc[ct][1] = mfma4(a1, pr[ct][jt][r], acc[ct][1]);
                     }
                 }
+            }
             }
             if (SPLIT) __syncthreads();      // every wave of the scene has taken its A*H: rows may be overwritten
             if (rows_only) {
@@ -486,6 +567,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
             for (int ct = 0; ct < NCT; ++ct) {
                 load_fence();
                 f32x4 o[2] = {zero4(), zero4()};
+                if constexpr (HX) {
+                    SplitOperand<2> sa;
+                    make_split<2>(acc[ct], sa);
+                    layer_mfma_hs<XD, XD, false>(wl, sa, o, lane, nullptr, lds[a.off_hs + 1 + l]);
+                } else {
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
@@ -493,6 +579,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
 #pragma unroll
                         for (int ot = 0; ot < 2; ++ot)
                             o[ot] = mfma4(wl[(16 * ft + 4 * q + r) * WLD + 16 * ot + n], acc[ct][ft][r], o[ot]);
+                }
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot) {
                     const f32x4 sk = *reinterpret_cast<const f32x4*>(&Hs[(16 * (ct + ctb) + n) * XLD + 16 * ot + 4 * q]);
@@ -507,6 +594,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                 if (last) {
                     // motion head on this tile's columns, straight from registers: 32 -> 64 (ReLU) -> 5
                     f32x4 hm[4] = {zero4(), zero4(), zero4(), zero4()};
+                    f32x4 om = zero4();
+                    if constexpr (HX) {
+                        SplitOperand<2> so;
+                        make_split<2>(o, so);
+                        layer_mfma_hs<XD, HID, true>(wm1, so, hm, lane, bm1, lds[a.off_hs + 5]);
+#pragma unroll
+                        for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) hm[ht][r] = fmaxf(hm[ht][r], 0.f);
+                        SplitOperand<4> sm;
+                        make_split<4>(hm, sm);
+                        f32x4 om1[1];
+                        layer_mfma_hs<HID, 16, false>(wm2, sm, om1, lane, nullptr, lds[a.off_hs + 6]);
+                        om = om1[0];
+                    } else {
 #pragma unroll
                     for (int ot = 0; ot < 2; ++ot) {
                         load_fence();
@@ -516,7 +618,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                             for (int ht = 0; ht < 4; ++ht)
                                 hm[ht] = mfma4(wm1[(16 * ot + 4 * q + r) * W1LD + 16 * ht + n], o[ot][r], hm[ht]);
                     }
-                    f32x4 om = zero4();
 #pragma unroll
                     for (int ht = 0; ht < 4; ++ht) {
                         load_fence();
@@ -526,6 +627,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                             const float hv = fmaxf(hm[ht][r] + bb[r], 0.f);
                             om = mfma4(wm2[(16 * ht + 4 * q + r) * M2LD + n], hv, om);
                         }
+                    }
                     }
                     const int node = 16 * (ct + ctb) + n;
                     if (active && node >= 1 && node < N) {
@@ -542,6 +644,83 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
         }
         if (SPLIT) __syncthreads();      // the slot's rows are free for the next scene
     }
+}
+
+// ---- split-f16 weight image of the scene kernel (HX): global copy of the LDS region [0, off_hs + 8) -------------------------------
+struct SceneImageLayout { int off_wa, off_ws, off_wm1, off_bm1, off_wm2, off_bm2, off_hs, total; };
+inline SceneImageLayout scene_image_layout(int L) {
+    SceneImageLayout o;
+    int off = 0;
+    auto take = [&](int nfl) { int r = off; off += (nfl + 3) & ~3; return r; };
+    o.off_wa = take(XD * WLD);
+    o.off_ws = take(L * XD * WLD);
+    o.off_wm1 = take(XD * W1LD);
+    o.off_bm1 = take(HID);
+    o.off_wm2 = take(HID * M2LD);
+    o.off_bm2 = take(16);
+    o.off_hs = take(8);
+    o.total = off;
+    return o;
+}
+
+struct SceneImageArgs {
+    const float* wa;                      // null: identity (gaussian)
+    const float* Ws[4];
+    const float *wm1, *bm1, *wm2, *bm2;   // null: no motion head (value rows)
+    int L;
+    SceneImageLayout lo;
+};
+
+// 1 / scale of Wa, Ws[0..3], wm1, wm2: scale = the power of two that brings max |W| into [512, 1024)
+__global__ __launch_bounds__(256) void scene_scales_kernel(const SceneImageArgs a, float* img) {
+    __shared__ float red[256];
+    const int k = blockIdx.x;
+    const float* W = k == 0 ? a.wa : (k <= 4 ? (k - 1 < a.L ? a.Ws[k - 1] : nullptr) : (k == 5 ? a.wm1 : a.wm2));
+    const int n = k <= 4 ? XD * XD : (k == 5 ? XD * HID : HID * 5);
+    float m = 0.f;
+    if (W)
+        for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(W[i]));
+    else m = k == 0 ? 1.f : 0.f;
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float sc, inv;
+        pow2_scale(red[0], sc, inv);
+        img[a.lo.off_hs + k] = inv;
+    }
+    if (threadIdx.x == 0 && k == 6) img[a.lo.off_hs + 7] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void scene_pack_kernel(const SceneImageArgs a, float* img) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const SceneImageLayout& lo = a.lo;
+    if (e >= lo.off_hs) return;                       // the scales were written by scene_scales_kernel
+    auto sw = [&](int k) { return 1.f / img[lo.off_hs + k]; };
+    float v = 0.f;
+    if (e < lo.off_ws) {
+        const int i = e - lo.off_wa;
+        if (i < HeadFragFloats<XD, XD, true>::v) v = frag_half2_ld<XD, XD>(a.wa, XD, XD, i, sw(0));
+    } else if (e < lo.off_wm1) {
+        const int i = e - lo.off_ws, l = i / (XD * WLD), j = i - l * XD * WLD;
+        if (l < a.L && j < HeadFragFloats<XD, XD, true>::v) v = frag_half2_ld<XD, XD>(a.Ws[l], XD, XD, j, sw(1 + l));
+    } else if (e < lo.off_bm1) {
+        const int i = e - lo.off_wm1;
+        if (a.wm1 && i < HeadFragFloats<XD, HID, true>::v) v = frag_half2_ld<XD, HID>(a.wm1, HID, HID, i, sw(5));
+    } else if (e < lo.off_wm2) {
+        const int i = e - lo.off_bm1;
+        if (a.bm1 && i < HID) v = a.bm1[i];
+    } else if (e < lo.off_bm2) {
+        const int i = e - lo.off_wm2;
+        if (a.wm2 && i < HeadFragFloats<HID, 16, true>::v) v = frag_half2_ld<HID, 16>(a.wm2, 5, 5, i, sw(6));
+    } else {
+        const int i = e - lo.off_bm2;
+        if (a.bm2 && i < 5) v = a.bm2[i];
+    }
+    img[e] = v;
 }
 
 inline RowMlpArgs row_mlp_args(const RglMlp& m, const float* rows, float* out, int M) {
@@ -584,10 +763,10 @@ inline int scene_split_below(int nt) {
     return nt == 2 ? 3072 : 4096;
 }
 
-template <int NT, int SK, int WAVES, bool SPLIT = false, bool EMB = false>
+template <int NT, int SK, int WAVES, bool SPLIT = false, bool EMB = false, bool HX = false>
 int launch_scene_k(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* children, hipStream_t st) {
     if constexpr (!SPLIT && SK != 3 && (NT == 2 || NT == 4)) {
-        if (sa.P < scene_split_below(NT)) return launch_scene_k<NT, SK, 8, true, EMB>(sa, lds_bytes, children, st);
+        if (sa.P < scene_split_below(NT)) return launch_scene_k<NT, SK, 8, true, EMB, HX>(sa, lds_bytes, children, st);
     }
     constexpr int kSlots = SPLIT ? WAVES / NT : WAVES;
     int grid = (sa.P + kSlots - 1) / kSlots;
@@ -600,7 +779,7 @@ int launch_scene_k(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* ch
         const long long blocks = ((long long)ca.P * ca.A + WAVES * 64 - 1) / (WAVES * 64);
         grid_children = (int)(blocks < 2048 ? blocks : 2048);
     }
-    auto kern = children ? scene_graph_kernel<NT, SK, WAVES, true, SPLIT, EMB> : scene_graph_kernel<NT, SK, WAVES, false, SPLIT, EMB>;
+    auto kern = children ? scene_graph_kernel<NT, SK, WAVES, true, SPLIT, EMB, HX> : scene_graph_kernel<NT, SK, WAVES, false, SPLIT, EMB, HX>;
     if (lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_bytes));
@@ -620,6 +799,11 @@ inline int launch_scene_wide(const SceneArgs& sa, size_t lds_bytes, const Childr
 
 template <int NT, int WAVES>
 int launch_scene(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* children, hipStream_t st) {
+    if constexpr (NT == 2) {
+        if (sa.hx)                                       // split-f16 products (softmax similarity, two node tiles)
+            return sa.robot_rows ? launch_scene_k<2, 0, 8, true, true, true>(sa, lds_bytes, children, st)
+                                 : launch_scene_k<2, 0, WAVES, false, false, true>(sa, lds_bytes, children, st);
+    }
     if constexpr (NT == 1) {
         if (sa.robot_rows) return launch_scene_k<1, 0, 8, false, true>(sa, lds_bytes, children, st);           // embeddings inside
     }
@@ -646,7 +830,8 @@ static bool scene_kernel_covers(const RglGraph& g, int N) {
 // embeddings (one launch) + one-wave-per-scene graph forward; mh != null: motion head -> humans_next; rows_out != null: value rows
 static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* robot, const float* humans, int crowds_per, int P,
                              int H, float* humans_next, float* rows_out, float* x0_rows, float* xh_rows,
-                             const ChildrenArgs* ca, hipStream_t stream, const ChildrenArgs* embed_children = nullptr) {
+                             const ChildrenArgs* ca, hipStream_t stream, const ChildrenArgs* embed_children = nullptr,
+                             const float* sp_image = nullptr) {
     const int N = H + 1, n_crowds = P / crowds_per;
     const int NT0 = N > 64 ? 8 : (N + 15) / 16;
     // few scenes of the shipped shape: the scene kernel embeds its own node tiles (one launch for the level instead of two)
@@ -664,6 +849,9 @@ static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* r
     sa.er_w1 = g.w_r.weight[0]; sa.er_b1 = g.w_r.bias[0]; sa.er_w2 = g.w_r.weight[1]; sa.er_b2 = g.w_r.bias[1];
     sa.eh_w1 = g.w_h.weight[0]; sa.eh_b1 = g.w_h.bias[0]; sa.eh_w2 = g.w_h.weight[1]; sa.eh_b2 = g.w_h.bias[1];
     sa.off_er = sa.off_eh = 0;
+    // (one node tile: measured slower than the f32 form -- 0.0615 vs 0.0496 ms per configs[1] step: too few MFMAs to pay for the splits)
+    sa.hx = (sp_image && mh && scene_similarity_mode(g) == SIM_SOFTMAX && NT0 == 2 && g.num_layer <= 4) ? 1 : 0;
+    sa.image = sp_image;
     sa.xh_rows = xh_rows; sa.x0_rows = x0_rows; sa.crowds_per = crowds_per;
     sa.wa = bilinear_wa(g);
     sa.sim = scene_similarity_mode(g);
@@ -678,12 +866,12 @@ static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* r
     const int NT = N > 64 ? 8 : (N + 15) / 16;
     int off = 0;
     auto take = [&](int nfl) { int o = off; off += (nfl + 3) & ~3; return o; };
-    sa.off_wa = take(XD * WLD);
-    sa.off_ws = take(g.num_layer * XD * WLD);
-    sa.off_wm1 = take(XD * W1LD);
-    sa.off_bm1 = take(HID);
-    sa.off_wm2 = take(HID * M2LD);
-    sa.off_bm2 = take(16);
+    {   // the weight image: one layout for the LDS region and for its packed global copy
+        const SceneImageLayout lo = scene_image_layout(g.num_layer);
+        sa.off_wa = lo.off_wa; sa.off_ws = lo.off_ws; sa.off_wm1 = lo.off_wm1; sa.off_bm1 = lo.off_bm1;
+        sa.off_wm2 = lo.off_wm2; sa.off_bm2 = lo.off_bm2; sa.off_hs = lo.off_hs;
+        off = lo.total;
+    }
     sa.wc1 = sa.bc1 = sa.wc2 = sa.bc2 = nullptr;
     sa.off_wc1 = sa.off_bc1 = sa.off_wc2 = 0;
     if (sa.sim == SIM_CONCAT) {
@@ -710,10 +898,35 @@ static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* r
 
 namespace rgl {
 
+// The split-f16 weight image of the state predictor's scene kernel (RGL_CONTRACT_F16X3): depends on the weights only.
+size_t scene_image_bytes(const MprlPlanner* pl) {
+    if (!pl || pl->contraction_dtype != RGL_CONTRACT_F16X3 || pl->linear_state_predictor) return 0;
+    const RglGraph& g = pl->predictor_graph;
+    if (!scene_kernel_covers(g, 20) || scene_similarity_mode(g) != SIM_SOFTMAX || !mlp_is(pl->motion_head, XD, HID, 5, false)) return 0;
+    return (((size_t)scene_image_layout(g.num_layer).total * sizeof(float)) + 255) & ~(size_t)255;
+}
+
+int pack_scene_image(const MprlPlanner* pl, float* image, hipStream_t stream) {
+    if (!scene_image_bytes(pl)) return 1;
+    const RglGraph& g = pl->predictor_graph;
+    SceneImageArgs ia;
+    ia.wa = bilinear_wa(g);
+    for (int l = 0; l < 4; ++l) ia.Ws[l] = l < g.num_layer ? g.Ws[l] : nullptr;
+    ia.wm1 = pl->motion_head.weight[0]; ia.bm1 = pl->motion_head.bias[0];
+    ia.wm2 = pl->motion_head.weight[1]; ia.bm2 = pl->motion_head.bias[1];
+    ia.L = g.num_layer;
+    ia.lo = scene_image_layout(g.num_layer);
+    hipLaunchKernelGGL(scene_scales_kernel, dim3(7), dim3(256), 0, stream, ia, image);
+    RGL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scene_pack_kernel, dim3((ia.lo.off_hs + 255) / 256), dim3(256), 0, stream, ia, image);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
 // humans_next[s] = motion_head(RGL(robot[s], humans[s / crowds_per]))[1:]  for P scenes (StatePredictor.forward).
 int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float* humans, int crowds_per, int P, int H,
                           float* humans_next, void* workspace, size_t workspace_bytes, hipStream_t stream,
-                          const void* children, size_t children_bytes, int* children_done) {
+                          const void* children, size_t children_bytes, int* children_done, const float* sp_image) {
     const ChildrenArgs* ca = (children && children_bytes == sizeof(ChildrenArgs)) ? (const ChildrenArgs*)children : nullptr;
     if (children_done) *children_done = 0;
     const RglGraph& g = pl->predictor_graph;
@@ -731,7 +944,7 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
     const ChildrenArgs* in_scene = (ca && P < 3072) ? ca : nullptr;
     const ChildrenArgs* in_embed = (ca && !in_scene) ? ca : nullptr;
     const int rc = run_scene_kernels(g, &mh, robot, humans, crowds_per, P, H, humans_next, nullptr, x0_rows, xh_rows, in_scene, stream,
-                                     in_embed);
+                                     in_embed, pl->contraction_dtype == RGL_CONTRACT_F16X3 ? sp_image : nullptr);
     if (rc == RGL_OK && ca && children_done) *children_done = 1;
     return rc;
 }

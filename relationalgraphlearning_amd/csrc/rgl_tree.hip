@@ -264,6 +264,8 @@ inline int plan_levels(const MprlPlanner& pl, int B, int H, LevelLayout* lv, lon
     if (scratch_off) *scratch_off = off;
     if (scratch_bytes) *scratch_bytes = sb;
     off = align_up(off + sb);
+    // split-f16 image of the state predictor's scene kernel, packed once per search unless the caller hands one in
+    off = align_up(off + (long long)rgl::scene_image_bytes(&pl));
     *total = off;
     return RGL_OK;
 }
@@ -294,7 +296,7 @@ inline int validate_planner(const MprlPlanner& pl, int H) {
 int expand_level(const MprlPlanner& pl, const float* robot, const float* humans, int humans_per, int P, int H, int joint,
                  float* humans_next, float* child_robot, float* reward, float* child_value, void* scratch,
                  size_t scratch_bytes, hipStream_t st, int image_ready = 0, const TailArgs* tail = nullptr,
-                 int* tail_done = nullptr) {
+                 int* tail_done = nullptr, const float* sp_image = nullptr) {
     const int A = pl.num_actions;
     ChildrenArgs ca;
     ca.robot = robot; ca.humans = humans; ca.humans_per = humans_per; ca.actions = pl.actions;
@@ -319,7 +321,7 @@ int expand_level(const MprlPlanner& pl, const float* robot, const float* humans,
         RGL_LAUNCH_CHECK();
     } else {
         int rc = rgl::launch_predict_humans(&pl, robot, humans, humans_per, P, H, humans_next, scratch, scratch_bytes, st,
-                                            &ca, sizeof(ca), &children_done);
+                                            &ca, sizeof(ca), &children_done, sp_image);
         if (rc) return rc;
     }
     if (!children_done) {
@@ -343,7 +345,7 @@ extern "C" int mprl_expand_f32(const MprlPlanner* planner, const float* robot, c
     if (P == 0) return RGL_OK;
     hipStream_t st = (hipStream_t)stream;
     rc = expand_level(*planner, robot, humans, 1, P, H, parents_are_joint_states, humans_next, child_robot, reward,
-                      child_value, workspace, workspace_bytes, st);
+                      child_value, workspace, workspace_bytes, st, 0, nullptr, nullptr, planner->predictor_image);
     if (rc) return rc;
     if (value1) {
         const long long n = (long long)P * planner->num_actions;
@@ -369,6 +371,16 @@ extern "C" int mprl_value_children_f32(const MprlPlanner* planner, const float* 
     if (P == 0) return RGL_OK;
     return rgl::launch_value_children(planner, child_robot, humans_next, P, H, child_value, workspace, workspace_bytes,
                                       (hipStream_t)stream);
+}
+
+extern "C" size_t mprl_predictor_image_bytes(const MprlPlanner* planner) { return rgl::scene_image_bytes(planner); }
+
+extern "C" int mprl_pack_predictor_image_f32(const MprlPlanner* planner, float* image, size_t image_bytes, rgl_stream_t stream) {
+    if (!planner || !image) return RGL_ERR_NULL;
+    const size_t need = rgl::scene_image_bytes(planner);
+    if (!need) return RGL_ERR_BAD_MODE;
+    if (image_bytes < need) return RGL_ERR_WORKSPACE;
+    return rgl::pack_scene_image(planner, image, (hipStream_t)stream);
 }
 
 extern "C" size_t mprl_tree_workspace_bytes(const MprlPlanner* planner, int B, int H) {
@@ -432,6 +444,11 @@ extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* rob
                             (pl.children_image != nullptr ||
                              rgl::pack_children_images(&pl.value_graph, &pl.value_head, (int)lv[D - 1].P, A, H, ws + scratch_off,
                                                        (size_t)scratch_bytes, st, pl.contraction_dtype == RGL_CONTRACT_F16X3) == 0);
+    const float* sp_image = pl.predictor_image;
+    if (!sp_image && rgl::scene_image_bytes(&pl)) {
+        float* img = (float*)(ws + align_up(scratch_off + scratch_bytes));
+        if (rgl::pack_scene_image(&pl, img, st) == RGL_OK) sp_image = img;
+    }
     TailArgs tail{};
     tail.enabled = 1;
     tail.D = D; tail.A = A; tail.W = W; tail.clip = pl.do_action_clip; tail.sparse = pl.sparse_search;
@@ -460,7 +477,8 @@ extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* rob
         int tail_done = 0;           // 1: the children kernel selected for its parents; 2: ... and finished the search (deepest level)
         rc = expand_level(pl, pr, ph, humans_per, P, H, l == 0 ? roots_are_joint_states : 0,
                           (float*)(ws + L.humans_next), (float*)(ws + L.child_robot), (float*)(ws + L.reward),
-                          (float*)(ws + L.child_value), ws + scratch_off, (size_t)scratch_bytes, st, image_ready, &tail, &tail_done);
+                          (float*)(ws + L.child_value), ws + scratch_off, (size_t)scratch_bytes, st, image_ready, &tail, &tail_done,
+                          sp_image);
         if (rc) return rc;
         if (!tail_done) {
             // the deepest level's selection also writes the leaf values and (below the root) does its own back-up step

@@ -61,6 +61,7 @@ class TreeSearch:
         self.last = None            # outputs of the most recent search (device tensors)
         self._decisions = {}        # (H, device) -> captured single-scene search (decide())
         self._images = {}           # device -> (parameter-state key, weight image of the value-of-children kernel)
+        self._sp_images = {}        # device -> (parameter-state key, split-f16 weight image of the state predictor's scene kernel)
 
     # -- descriptors -----------------------------------------------------------------------------
     @property
@@ -116,7 +117,31 @@ class TreeSearch:
         pl.action_groups = None if grp is None else grp.data_ptr()
         image = self._children_image(pl, device)
         pl.children_image = None if image is None else image.data_ptr()
+        if not linear and self.contraction_dtype == "f16x3":
+            image = self._predictor_image(pl, device)
+            pl.predictor_image = None if image is None else image.data_ptr()
         return pl
+
+    def _predictor_image(self, pl, device):
+        """MprlPlanner.predictor_image (ABI 4): the state predictor's scene-kernel weight image in the split-f16 layout, packed
+        when the predictor's descriptors were (re)built, into the same device buffer every time.  None when the mode or the
+        predictor has no such kernel."""
+        sp = self.state_predictor
+        key = (sp.graph_model._cache.epoch, sp._cache.epoch)
+        dkey = str(device)
+        ent = self._sp_images.get(dkey)
+        if ent is not None and ent[0] == key:
+            return ent[1]
+        lib = nat.lib()
+        nbytes = lib.mprl_predictor_image_bytes(C.byref(pl))
+        buf = None
+        if nbytes:
+            buf = ent[1] if ent is not None and ent[1] is not None and ent[1].numel() == nbytes else \
+                torch.empty(nbytes, dtype=torch.uint8, device=device)
+            nat.check(lib.mprl_pack_predictor_image_f32(C.byref(pl), buf.data_ptr(), nbytes, _stream()),
+                      "mprl_pack_predictor_image_f32")
+        self._sp_images[dkey] = (key, buf)
+        return buf
 
     def _children_image(self, pl, device):
         """The value-of-children kernel's weight image for the CURRENT parameters (MprlPlanner.children_image): packed when the

@@ -37,7 +37,7 @@ def test_struct_layout_matches_header_sizes():
     graph = 2 * mlp + 6 * 4 + 8 + mlp + 8 * 8
     assert ctypes.sizeof(nat.RglGraph) == graph
     assert ctypes.sizeof(nat.MprlLevelView) == 11 * 8
-    assert ctypes.sizeof(nat.MprlPlanner) == 2 * graph + 2 * mlp + 8 * 4 + 2 * 8 + 2 * 8 + 2 * 8 + 8  # ABI 2: + float64 root pointers; ABI 3: + children_image
+    assert ctypes.sizeof(nat.MprlPlanner) == 2 * graph + 2 * mlp + 8 * 4 + 2 * 8 + 2 * 8 + 2 * 8 + 8 + 8  # ABI 2: + float64 root pointers; ABI 3: + children_image; ABI 4: + predictor_image
     assert ctypes.sizeof(nat.GcnPlanner) == graph + mlp + 2 * 4 + 2 * 8 + 8 + 2 * 8
 
 
