@@ -1230,6 +1230,39 @@ def test_f16x3_value_head_at_size_and_at_extreme_magnitudes(dev):
         check_decisions("f16x3, H=%d D=%d B=%d" % (Hh, D, Bb), a3, v3, (oa, ov, orv, okept), lv)
 
 
+@pytest.mark.parametrize("speeds,rots,H,D,clip,sparse", [(3, 8, 19, 2, True, False), (6, 16, 19, 2, True, True), (5, 16, 5, 1, False, False),
+                                                         (2, 4, 12, 3, True, False), (15, 17, 5, 2, True, False)])
+def test_f16x3_mode_with_other_action_tables_and_search_settings(speeds, rots, H, D, clip, sparse, dev):
+    """The split-f16 mode through the fused kernel's other code paths: partial tiles of every size (A = 25, 97 -> general kernel,
+    81, 9, 256), unclipped depth-1 search (W = A), sparse clipping, depth 3 -- whole searches against the oracle; and the
+    single-decision path (`predict(JointState)`: the search of that mode captured in a hipGraph)."""
+    cfgp = policy_config("model_predictive_rl", action_space__speed_samples=speeds, action_space__rotation_samples=rots,
+                         model_predictive_rl__planning_depth=D, model_predictive_rl__planning_width=2,
+                         model_predictive_rl__do_action_clip=clip, model_predictive_rl__sparse_search=sparse)
+    pol = rga.ModelPredictiveRL()
+    pol.time_step = 0.25
+    pol.configure(cfgp)
+    pol.load_state_dict(gio.checkpoint("trained", 2))
+    pol.set_time_step(0.25)
+    pol.set_phase("test")
+    pol.set_device(dev)
+    pol.contraction_dtype = "f16x3"
+    B = 40
+    robot, humans = seeded_scenes(1234 + speeds + H, B, H)
+    cfg = orc.OracleConfig(speed_samples=speeds, rotation_samples=rots, planning_depth=D, planning_width=2, do_action_clip=clip,
+                           sparse_search=sparse)
+    with torch.no_grad():
+        oa, ov, orv, okept, lv = orc.mprl_predict_batched(robot, humans, gio.oracle_params("trained"), cfg, return_levels=True)
+    act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
+    assert pol.tree_search().last["planner"].contraction_dtype == nat.CONTRACTION_DTYPES["f16x3"]
+    close(val.cpu().numpy(), ov.numpy())
+    check_decisions("f16x3, action table %dx%d+1, H=%d D=%d%s" % (speeds, rots, H, D, " sparse" if sparse else ""), act, val,
+                    (oa, ov, orv, okept), lv)
+    # one decision through predict(): the captured search of this mode
+    a = pol.predict(JS(robot[0].numpy(), humans[0].numpy()))
+    assert a == pol.action_space[int(act[0])] or abs(float(val[0]) - float(ov[0])) < 1e-6
+
+
 _ORACLE_AT_SIZE = {}
 
 
