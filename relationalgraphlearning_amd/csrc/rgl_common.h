@@ -73,8 +73,11 @@ int launch_deep_children(const RglGraph* g, int P, int A, int H, const float* ch
                          float* rows_out, int f16, hipStream_t stream);                                             // rgl_deep.hip
 int launch_tile_children(const RglGraph* g, int P, int A, int H, const float* child_robot, const float* humans_next,
                          float* rows_out, hipStream_t stream);                                                      // rgl_tile.hip
+// `tail` (a TailArgs, opaque) with A = rows per parent: the head kernel's workgroups own whole parents and run the search's select /
+// back-up / root steps for them in its tail (*tail_done = 1 / 2 as for the fused children kernel; the generic-dims head has none)
 int launch_head_rows(const RglGraph* g, const RglMlp* head, const float* rows, int M, float* value,
-                     hipStream_t stream, const float* image = nullptr);                                                                          // rgl_head.hip
+                     hipStream_t stream, const float* image = nullptr, const void* tail = nullptr, size_t tail_bytes = 0,
+                     int* tail_done = nullptr, int A = 0);                                                          // rgl_head.hip
 // the fused tile kernel (rgl_fused.hip).  Its weight image is prepared in global memory by pack_images_kernel: by the caller once per
 // parameter state (caller_image = MprlPlanner::children_image), else once per tree search (image_ready = 1 on the per-level calls)
 // or by the call itself, at the END of the workspace it is given.

@@ -75,7 +75,8 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
         return launch_generic_forward(&pl->value_graph, &pl->value_head, nullptr, child_robot, humans_next, P * A, A, H,
                                       nullptr, nullptr, child_value, nullptr, stream);
     if (rc) return rc;
-    return launch_head_rows(&pl->value_graph, &pl->value_head, (const float*)workspace, P * A, child_value, stream, image);
+    return launch_head_rows(&pl->value_graph, &pl->value_head, (const float*)workspace, P * A, child_value, stream, image,
+                            tail, tail_bytes, tail_done, A);
 }
 
 }  // namespace rgl

@@ -3,6 +3,7 @@
 //   weights as pre-permuted A fragments in LDS.
 // Follows (reference paths): crowd_nav/policy/graph_model.py:124-127 (last layer), value_estimator.py:9,18-19.
 #include "rgl_mlp_chain.h"
+#include "rgl_tail.h"
 
 namespace {
 
@@ -17,6 +18,10 @@ struct HeadArgs {
     float* value;                 // [M]
     int M, n_tiles;
     const float* image;           // null, or the packed weight image (FusedLds<32,100,100> layout): its head vectors and fragments
+    // round 3: with `tail.enabled` workgroup b owns the rows of parents [b k, (b + 1) k) (A rows each) and, behind a workgroup
+    // barrier, runs the search's select / back-up / root steps for them (rgl_tail.h) -- as the fused children kernel does
+    int A, parents_per_wg, P;
+    TailArgs tail;
 };
 
 template <int D1, int D2, int D3>
@@ -64,10 +69,17 @@ __global__ __launch_bounds__(kHeadThreads, 2) void robot_head_kernel(const HeadA
     const float b4 = a.b4[0];
     // tile t -> workgroup t % grid, wave (t / grid) % 8: the tiles of the last, partial round land on DIFFERENT workgroups
     // (one extra tile per CU) instead of filling whole workgroups -- the kernel is MFMA-paced per SIMD, so a SIMD whose
-    // four waves all carry an extra tile would set the kernel's time
-    for (int tile = blockIdx.x + gridDim.x * wave; tile < a.n_tiles; tile += gridDim.x * kHeadWaves) {
-        const int row = 16 * tile + n;
-        const int rc = row < a.M ? row : a.M - 1;
+    // four waves all carry an extra tile would set the kernel's time.  With a tail: the tiles of the workgroup's own rows.
+    const bool owned = a.tail.enabled != 0;
+    const int p_first = owned ? blockIdx.x * a.parents_per_wg : 0;
+    const int k_b = owned ? (a.P - p_first < a.parents_per_wg ? a.P - p_first : a.parents_per_wg) : 0;
+    const int row_lo = owned ? p_first * a.A : 0, row_hi = owned ? (p_first + k_b) * a.A : a.M;
+    const int t_first = owned ? wave : blockIdx.x + gridDim.x * wave;
+    const int t_step = owned ? kHeadWaves : gridDim.x * kHeadWaves;
+    const int t_end = (row_hi - row_lo + 15) / 16;
+    for (int tile = t_first; tile < t_end; tile += t_step) {
+        const int row = row_lo + 16 * tile + n;
+        const int rc = row < row_hi ? row : row_hi - 1;
         const float* src = a.rows + (size_t)rc * 64;
         f32x4 tin[2], hp[2];
         tin[0] = *reinterpret_cast<const f32x4*>(src + 4 * q);
@@ -102,7 +114,32 @@ __global__ __launch_bounds__(kHeadThreads, 2) void robot_head_kernel(const HeadA
         }
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
-        if (q == 0 && row < a.M) a.value[row] = v + b4;
+        if (q == 0 && row < row_hi) a.value[row] = v + b4;
+    }
+    if (owned) {
+        // every value of the owned parents was written by a wave of this workgroup: a barrier, then the select step (one wave per
+        // parent; its tables go where the weight fragments were) and, at the deepest level, the back-up chain and the root decision
+        __syncthreads();
+        static_assert(LO::total >= kHeadWaves * kTailLdsInts, "the select step's tables fit where the fragments were");
+        int* kl = reinterpret_cast<int*>(lds) + wave * kTailLdsInts;
+        for (int lp = wave; lp < k_b; lp += kHeadWaves) tail_select(a.tail, p_first + lp, kl);
+        if (a.tail.chain) {
+            const int W = a.tail.W, lvl = a.tail.level;
+            int per_deep = 1;
+            for (int l = 0; l < lvl; ++l) per_deep *= W;
+            const int r_first = p_first / per_deep, n_roots = k_b / per_deep;
+            int per_l = per_deep;
+            for (int l = lvl - 1; l >= 1; --l) {
+                per_l /= W;
+                __syncthreads();
+                for (int i = tid; i < n_roots * per_l; i += kHeadThreads) tail_backup(a.tail, l, r_first * per_l + i);
+            }
+            __syncthreads();
+            for (int base = 0; base < n_roots * kRootLanes; base += kHeadThreads) {
+                const int i = base + tid, bl = i / kRootLanes;
+                tail_root(a.tail, r_first + bl, i % kRootLanes, bl < n_roots);
+            }
+        }
     }
 }
 
@@ -116,6 +153,7 @@ int launch_head(const HeadArgs& ha, hipStream_t st) {
     int grid = (ha.n_tiles + kHeadWaves - 1) / kHeadWaves;
     const int cap = lds_bytes > 80 * 1024 ? 256 : 512;          // resident workgroups: 1 or 2 per CU
     if (grid > cap) grid = cap;
+    if (ha.tail.enabled) grid = (ha.P + ha.parents_per_wg - 1) / ha.parents_per_wg;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kHeadThreads), lds_bytes, st, ha);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
@@ -218,7 +256,8 @@ namespace rgl {
 
 // rows [M][64] (stage-1 hand-off) -> value;  1 = no kernel for this head (see head_variant)
 int launch_head_rows(const RglGraph* g, const RglMlp* h, const float* rows, int M, float* value, hipStream_t stream,
-                     const float* image) {
+                     const float* image, const void* tail, size_t tail_bytes, int* tail_done, int A) {
+    if (tail_done) *tail_done = 0;
     const int hv = head_variant(*h);
     if (hv < 0) return 1;
     if (hv == 2) {
@@ -251,7 +290,34 @@ int launch_head_rows(const RglGraph* g, const RglMlp* h, const float* rows, int 
     ha.value = value;
     ha.M = M;
     ha.n_tiles = (M + 15) / 16;
-    return hv == 0 ? launch_head<32, 100, 100>(ha, stream) : launch_head<150, 100, 100>(ha, stream);
+    ha.tail = TailArgs{};
+    ha.A = A; ha.P = A > 0 ? M / A : 0; ha.parents_per_wg = 1;
+    const TailArgs* ta = (tail && tail_bytes == sizeof(TailArgs) && ((const TailArgs*)tail)->enabled && A > 0 && M % A == 0)
+                             ? (const TailArgs*)tail : nullptr;
+    static const bool tail_off = [] { const char* e = getenv("RGL_FUSED_NO_TAIL"); return e && e[0] == '1'; }();
+    int chain = 0;
+    if (ta && !tail_off) {
+        // parents per workgroup: one workgroup slot per parent block, whole roots at the deepest level where that keeps >= half
+        // of the slots busy (as in the fused children kernel)
+        const int P = ha.P;
+        const int slots = hv == 0 ? 512 : 256;
+        int unit = 1;
+        if (ta->chain) {
+            long u = 1;
+            for (int l = 0; l < ta->level && u <= P; ++l) u *= ta->W;
+            if (u <= P && P % u == 0 && (P / u >= slots / 2 || P / u >= 128)) { unit = (int)u; chain = 1; }
+            else if (u == 1) chain = 1;
+        }
+        int k = (P + slots - 1) / slots;
+        if (k < 1) k = 1;
+        k = ((k + unit - 1) / unit) * unit;
+        ha.parents_per_wg = k;
+        ha.tail = *ta;
+        ha.tail.chain = chain;
+    }
+    const int rc = hv == 0 ? launch_head<32, 100, 100>(ha, stream) : launch_head<150, 100, 100>(ha, stream);
+    if (rc == RGL_OK && ha.tail.enabled && tail_done) *tail_done = chain ? 2 : 1;
+    return rc;
 }
 
 }  // namespace rgl
