@@ -1032,20 +1032,22 @@ inline ItemPlan plan_items(int P, int n_full, int rem, int unit) {
             const float c_full = kCrowd + G;
             const float c_last = kCrowd + (last_tiles > 0 ? last_tiles : 0) + ((rem && !inl) ? kPartial : 0.f);
             const int rot = (ipp > 1 && c_last > c_full) ? ipp - 1 : 0;
-            float load[4] = {0.f, 0.f, 0.f, 0.f};
-            int busy[kFusedWaves] = {0, 0, 0, 0, 0, 0, 0, 0};
+            float wload[kFusedWaves] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const long n_items = (long)k * ipp;
             for (long i = 0; i < n_items; ++i) {
                 int j = (int)(i / k) + rot;
                 if (j >= ipp) j -= ipp;
                 const long pass = i / kFusedWaves, r = i - pass * kFusedWaves;
                 const int w = (int)((pass & 1) ? kFusedWaves - 1 - r : r);
-                load[w & 3] += j == ipp - 1 ? c_last : c_full;
-                busy[w] = 1;
+                wload[w] += j == ipp - 1 ? c_last : c_full;
             }
+            // a SIMD's two waves (w, w + 4) share the pipe while both run (their loads add) and the longer one finishes alone at
+            // the solo rate: (3.45, 3.45) beats (5.45, 1.45) -- measured at P = 1024: 0.061 vs 0.063 ms (f32), 0.041 vs 0.043 (f16x3)
             float mk = 0.f;
             for (int sidx = 0; sidx < 4; ++sidx) {
-                const float v = load[sidx] * ((busy[sidx] + busy[sidx + 4] == 1) ? kSolo : 1.f);
+                const float hi = wload[sidx] > wload[sidx + 4] ? wload[sidx] : wload[sidx + 4];
+                const float lo = wload[sidx] > wload[sidx + 4] ? wload[sidx + 4] : wload[sidx];
+                const float v = 2.f * lo + (hi - lo) * kSolo;
                 mk = v > mk ? v : mk;
             }
             if (rem && !inl) {                                   // the tile-packed pass behind the barrier
