@@ -1263,6 +1263,60 @@ def test_f16x3_mode_with_other_action_tables_and_search_settings(speeds, rots, H
     assert a == pol.action_space[int(act[0])] or abs(float(val[0]) - float(ov[0])) < 1e-6
 
 
+def test_f16x3_children_over_odd_shapes_and_sharp_attention(dev):
+    """Children's values in the split-f16 mode against the oracle over the shapes the f32 fused kernel is stressed with (partial tiles,
+    every register bucket, skip on / off, raw random-init weights whose hidden features reach 10-100, odd mid-size parent counts)
+    and with SHARP attention: w_a scaled so that the similarities span hundreds.  A product's relative error (~2^-21) becomes an
+    absolute error of the logit and so a relative error of the softmax weights -- the place where the mode could lose to f32."""
+    import copy
+    pol_kw = dict(L=2, device=dev)
+    worst = 0.0
+    for H, skip, P, flavour in ((19, True, 5, "trained"), (19, True, 67, "rand"), (5, True, 7, "trained"), (4, False, 33, "trained"),
+                                (1, True, 3, "trained"), (15, False, 9, "rand"), (16, True, 3, "trained"),
+                                (19, True, 701, "trained"), (5, False, 1501, "trained"), (9, True, 2311, "rand")):
+        pol = make_mprl_policy(flavour, 1, skip=skip, **pol_kw)
+        pol.contraction_dtype = "f16x3"
+        pol.build_action_space(1.0)
+        ts = pol.tree_search()
+        A = ts.num_actions
+        robot, humans = seeded_scenes(900 + H, P, H)
+        acts, _ = orc.mprl_action_space(orc.OracleConfig(), 1.0)
+        cr = orc._children_robot(robot, acts, orc.OracleConfig())
+        got = ts.value_children(cr.to(dev), humans.to(dev)).cpu().numpy()
+        Pm = gio.oracle_params(flavour, 2)
+        with torch.no_grad():
+            want = orc.value_estimator_forward(cr.reshape(P * A, 1, 9), humans[:, None].expand(P, A, H, 5).reshape(P * A, H, 5),
+                                               Pm.ve_graph, Pm.value_network,
+                                               orc.OracleConfig(num_layer=2, skip_connection=skip)).numpy().reshape(P, A)
+        err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
+        worst = max(worst, err)
+        assert err < 1e-4, (H, skip, P, flavour, err)
+    sharp = 0.0
+    for scale, H, P in ((25.0, 19, 40), (-40.0, 9, 33), (300.0, 5, 17)):
+        ck = copy.deepcopy(gio.checkpoint("trained", 2))
+        ck["graph_model1"]["w_a"] = ck["graph_model1"]["w_a"] * scale
+        pol = make_mprl_policy("trained", 1, **pol_kw)
+        pol.load_state_dict(ck)
+        pol.contraction_dtype = "f16x3"
+        pol.build_action_space(1.0)
+        ts = pol.tree_search()
+        A = ts.num_actions
+        robot, humans = seeded_scenes(950 + H, P, H)
+        acts, _ = orc.mprl_action_space(orc.OracleConfig(), 1.0)
+        cr = orc._children_robot(robot, acts, orc.OracleConfig())
+        got = ts.value_children(cr.to(dev), humans.to(dev)).double().cpu().numpy()
+        P64 = orc.MprlParams.from_checkpoint({k: {kk: vv.double() for kk, vv in v.items()} for k, v in ck.items()})
+        with torch.no_grad():
+            want = orc.value_estimator_forward(cr.double().reshape(P * A, 1, 9),
+                                               humans.double()[:, None].expand(P, A, H, 5).reshape(P * A, H, 5),
+                                               P64.ve_graph, P64.value_network, orc.OracleConfig()).numpy().reshape(P, A)
+        err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
+        sharp = max(sharp, err)
+        assert err < 1e-4, (scale, H, P, err)
+    report("f16x3 children over odd shapes / raw random weights: worst relative error %.2e; sharp attention (similarities in the "
+           "hundreds) vs float64: %.2e" % (worst, sharp))
+
+
 _ORACLE_AT_SIZE = {}
 
 
