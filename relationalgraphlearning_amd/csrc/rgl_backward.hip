@@ -722,8 +722,14 @@ extern "C" int rgl_graph_backward_f32(const RglGraph* graph, const RglMlp* value
     if (n_scenes < 1) return RGL_ERR_BAD_SHAPE;
     BackwardArgs a;
     int rc = plan_backward(graph, value_head, motion_head, H, a);
-    if (rc) return rc;
+    const bool too_big = rc == RGL_ERR_LDS;       // a scene's activations do not fit one CU's LDS: only the tile pipeline can run
+    if (rc && !too_big) return rc;
     if (workspace_bytes < (size_t)n_scenes * a.n_params * sizeof(float)) return RGL_ERR_WORKSPACE;
+    // large batches of the shipped structure: the tile pipeline on the matrix cores (rgl_backward_mfma.hip); 1 = not its case
+    rc = rgl::launch_backward_mfma(graph, value_head, motion_head, robot, humans, n_scenes, H, detach_graph, d_value, d_humans_next,
+                                   d_H, grad_out, workspace, workspace_bytes, (hipStream_t)stream, too_big ? 1 : 0);
+    if (rc != 1) return rc;
+    if (too_big) return RGL_ERR_LDS;
     a.detach_graph = detach_graph ? 1 : 0;
     a.robot = robot; a.humans = humans; a.n_scenes = n_scenes; a.H = H;
     a.d_value = d_value; a.d_humans_next = d_humans_next; a.d_H = d_H;

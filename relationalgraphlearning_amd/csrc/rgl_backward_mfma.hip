@@ -1,0 +1,1028 @@
+// rgl_backward_mfma.hip -- the training path's backward pass for LARGE batches, on the matrix cores.
+// (crowd_nav/utils/trainer.py:110-161,199-250 drive forward + backward over replay batches; the reference's own batch is 100,
+// the vector explorer of this build feeds thousands.)  rgl_backward.hip gives every scene a 1024-thread workgroup, a VALU loop per
+// product and a gradient slab of its own; its time per scene does not shrink with the batch.  Here the same gradients are computed
+// as a pipeline of tile kernels, every dense product an fp32 MFMA (v_mfma_f32_16x16x4_f32: exact products, fp32 accumulation,
+// the arithmetic of the VALU kernel up to summation order):
+//
+//   1. mlp_rows_kernel (forward only)   X = [w_r(robot); w_h(humans)]              one wave per 16-row tile
+//   2. graph_kernel<.., false>          H_L = layers(softmax(X Wa X^T), X)          one wave per scene, activations in its LDS slice
+//   3. mlp_rows_kernel (backward)       value head on H_L[:, 0] / motion head on H_L[:, 1:]  ->  dH_L, head gradients
+//   4. graph_kernel<.., true>           recomputes 2., back-propagates  ->  dX, and dWa / dW_l accumulated in REGISTERS over the
+//                                       wave's scenes (one slab per wave, not per scene)
+//   5. mlp_rows_kernel (backward)       w_r / w_h from dX (forward recomputed inside)
+//   6. reduce_ranges_kernel             slabs summed in wave order (fixed tile -> wave assignment: deterministic)
+//
+// The intermediates X, H_L, dH_L, dX travel through HBM ([S][N][32] floats each: 10 MB at 4096 scenes of 20 nodes, ~1.3 us of
+// traffic apiece) so that each kernel keeps one job; everything else lives in LDS / registers.
+//
+// Envelope: embedded_gaussian or gaussian similarity, one adjacency for all layers, x_dim = 32, 1-3 layers, N <= 64; any embedding
+// MLPs and heads within the ABI limits.  Outside it -- and below RGL_BACKWARD_MFMA_MIN scenes -- rgl_backward.hip runs (return 1).
+//
+// Differentiated forward: graph_model.py:99-130, value_estimator.py:11-20, state_predictor.py:28-36, gcn.py:95-128.
+#include "rgl_mfma.h"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+
+__device__ __forceinline__ void wave_sync() {         // LDS written by some lanes of the wave, read by others
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// C[MT*16][NTL*16] += A[.][k] B[k][.] over `ksteps` groups of four k: fa(row, k) / fb(k, col) fetch the operand elements
+// (LDS or L1-resident weights; the callers clamp / zero what lies outside their matrices).  One A fragment per row tile and one B
+// fragment per column tile feed MT*NTL MFMAs.  D row 4 (lane / 16) + r, column lane % 16 is element r of a lane's accumulator.
+template <int MT, int NTL, int U, class FA, class FB>
+__device__ __forceinline__ void mm_steps(f32x4 (&acc)[MT][NTL], int ks0, FA& fa, FB& fb) {
+    const int l16 = threadIdx.x & 15, kk = (threadIdx.x & 63) >> 4;
+    float av[U][MT], bv[U][NTL];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {              // all operand fragments of U k steps in flight, then their MFMAs
+        const int k = (ks0 + u) * 4 + kk;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[u][mt] = fa(mt * 16 + l16, k);
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) bv[u][nt] = fb(k, nt * 16 + l16);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = mfma4(av[u][mt], bv[u][nt], acc[mt][nt]);
+}
+template <int MT, int NTL, int UNROLL = 2, class FA, class FB>
+__device__ __forceinline__ void mm(f32x4 (&acc)[MT][NTL], int ksteps, FA fa, FB fb) {
+    int ks = 0;
+    for (; ks + UNROLL <= ksteps; ks += UNROLL) mm_steps<MT, NTL, UNROLL>(acc, ks, fa, fb);
+    for (; ks < ksteps; ++ks) mm_steps<MT, NTL, 1>(acc, ks, fa, fb);
+}
+template <int MT, int NTL>
+__device__ __forceinline__ void clear(f32x4 (&acc)[MT][NTL]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = zero4();
+}
+// f(row, col, value, mt, nt, r) for every element of the block
+template <int MT, int NTL, class F>
+__device__ __forceinline__ void each(const f32x4 (&acc)[MT][NTL], F f) {
+    const int l16 = threadIdx.x & 15, kk = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f(mt * 16 + 4 * kk + r, nt * 16 + l16, acc[mt][nt][r], mt, nt, r);
+}
+
+// dst(idx, src(idx)) for idx = t0, t0 + step, .. < n, the loads U at a time (a plain loop pays one global-memory latency per
+// iteration: the compiler does not pipeline across iterations)
+template <int U, class Src, class Dst>
+__device__ __forceinline__ void gather(int n, int t0, int step, Src src, Dst dst) {
+    for (int base = t0; base < n; base += U * step) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * step;
+            v[u] = idx < n ? src(idx) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * step;
+            if (idx < n) dst(idx, v[u]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rows of an MLP: forward, and backward with parameter gradients
+// ------------------------------------------------------------------------------------------------
+// row r of a [groups][per][width] tensor embedded in a larger one: p + (r / per) * group_stride + (r % per) * row_stride
+struct RowMap {
+    float* p;
+    int per, row_stride;
+    long long group_stride;
+};
+__device__ __forceinline__ float* row_at(const RowMap& m, int r) {
+    const int g = r / m.per;
+    return m.p + g * m.group_stride + (long long)(r - g * m.per) * m.row_stride;
+}
+
+constexpr int kMaxRowJobs = 2;
+struct RowsJob {
+    RglMlp m;
+    int w_off[RGL_MAX_MLP_LAYERS], b_off[RGL_MAX_MLP_LAYERS];   // inside the job's slab (torch layout [out][in], then the bias)
+    int act_off[RGL_MAX_MLP_LAYERS + 1];                        // column of layer l's input inside a row of the activation tile
+    int w_lds[RGL_MAX_MLP_LAYERS], w_ld[RGL_MAX_MLP_LAYERS];    // layer l's weights in the workgroup's LDS: float offset, row stride
+    int b_lds[RGL_MAX_MLP_LAYERS];
+    int weight_floats;                                          // weights + biases of all layers
+    int act_ld, d_ld, n_params;
+    int n_rows, n_tiles, n_waves;
+    int wg_begin, n_wgs, waves_per_wg;
+    int wave_floats;                                            // LDS of one wave
+    int kind;                                                   // 0: mlp_rows_kernel; 10 T0 + T2: mlp2_rows_kernel<T0, T2>
+    int need_din, din_add;
+    RowMap in, out, d_out, d_in;      // out: forward-only launches; d_out (null = zeros) / d_in: backward launches
+    float* slabs;                     // [n_waves][n_params]
+};
+struct RowsArgs {
+    RowsJob job[kMaxRowJobs];
+    int n_jobs, backward;
+};
+
+// weights and biases of the job's MLP -> the workgroup's LDS (ends with a barrier)
+__device__ __forceinline__ void stage_weights(const RowsJob& J, float* lds) {
+    const RglMlp& m = J.m;
+    for (int l = 0; l < m.n_layers; ++l) {
+        const int in = m.dims[l], out = m.dims[l + 1], ld = J.w_ld[l];
+        float* Wl = lds + J.w_lds[l];
+        const float* __restrict__ W = m.weight[l];
+        // thread (k0 = t / 32, c = t % 32): columns c, c + 32, .. of rows k0, k0 + 8, ..   (no divisions in the loops)
+        for (int c = threadIdx.x & 31; c < out; c += 32)
+            gather<8>(in, threadIdx.x >> 5, blockDim.x >> 5, [&](int k) { return W[k * out + c]; },
+                      [&](int k, float v) { Wl[k * ld + c] = v; });
+        for (int c = threadIdx.x; c < out; c += blockDim.x) lds[J.b_lds[l] + c] = m.bias[l][c];
+    }
+    __syncthreads();
+}
+
+// Workgroups of up to four waves: the MLP's weights are staged once per workgroup in LDS (k-major rows of odd stride: the forward's
+// B-operand reads and the transposed reads of the delta products both stay within two-way bank conflicts), then every wave works
+// through its own 16-row tiles without further barriers: every layer's activations of the tile in LDS ([16][act_ld]) together with
+// two delta buffers ([16][d_ld]).  A wave's first tile writes its gradient slab, later tiles add to it (L2-resident).
+__global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15;
+    const int ji = (a.n_jobs > 1 && (int)blockIdx.x >= a.job[1].wg_begin) ? 1 : 0;
+    const RowsJob& J = a.job[ji];
+    PHASE_START();
+    stage_weights(J, lds);
+    PHASE_MARK(0);
+    const int w = ((int)blockIdx.x - J.wg_begin) * J.waves_per_wg + wave;
+    if (wave >= J.waves_per_wg || w >= J.n_waves) return;
+    const RglMlp& m = J.m;
+    const int L = m.n_layers, ald = J.act_ld, dld = J.d_ld;
+    float* acts = lds + J.weight_floats + wave * (16 * ald + 32 * dld);
+    float* dcur = acts + 16 * ald;
+    float* dnxt = dcur + 16 * dld;
+    float* slab = J.slabs + (size_t)w * J.n_params;
+    bool first = true;
+    // element-wise passes over the tile: lane -> (row rr = lane / 4, columns c4, c4 + 4, ..)
+    const int rr = lane >> 2, c4 = lane & 3;
+    for (int t = w; t < J.n_tiles; t += J.n_waves, first = false) {
+        const int r0 = t * 16;
+        const bool rok = r0 + rr < J.n_rows;
+        const int rrow = rok ? r0 + rr : J.n_rows - 1;
+        {   // input rows (zero beyond the end, zero in the padding columns)
+            const int d0 = m.dims[0], d0p = (d0 + 3) & ~3;
+            const float* src = row_at(J.in, rrow);
+            gather<8>(d0p, c4, 4, [&](int c) { return (rok && c < d0) ? src[c] : 0.f; }, [&](int c, float v) { acts[rr * ald + c] = v; });
+        }
+        wave_sync();
+        PHASE_MARK(1);
+        for (int l = 0; l < L; ++l) {
+            const int in = m.dims[l], out = m.dims[l + 1], inp = (in + 3) & ~3, outp = (out + 3) & ~3;
+            const int ioff = J.act_off[l], ooff = J.act_off[l + 1];
+            const bool relu = (l != L - 1) || m.last_relu;
+            const float* W = lds + J.w_lds[l];
+            const float* b = lds + J.b_lds[l];
+            const int wld = J.w_ld[l];
+            for (int jt = 0; jt * 16 < out; jt += 2) {
+                f32x4 acc[1][2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int col = (jt + nt) * 16 + l16;
+                    const float bv = col < out ? b[col] : 0.f;
+                    acc[0][nt] = f32x4{bv, bv, bv, bv};
+                }
+                mm<1, 2, 4>(acc, inp >> 2,
+                            [&](int row, int k) { return acts[row * ald + ioff + k]; },
+                            // clamped addresses, no guards (a guard becomes a branch and an LDS round trip per k step): the padding
+                            // columns of the activations are zero, and output columns past the end are never stored
+                            [&](int k, int c) { return W[min(k, in - 1) * wld + min(jt * 16 + c, out - 1)]; });
+                each<1, 2>(acc, [&](int row, int c, float v, int, int, int) {
+                    const int col = jt * 16 + c;
+                    if (col < outp) acts[row * ald + ooff + col] = col < out ? (relu ? fmaxf(v, 0.f) : v) : 0.f;
+                });
+            }
+            wave_sync();
+        }
+        PHASE_MARK(2);
+        if (!a.backward) {
+            const int out = m.dims[L], ooff = J.act_off[L];
+            float* dst = row_at(J.out, rrow);
+            if (rok)
+                for (int c = c4; c < out; c += 4) dst[c] = acts[rr * ald + ooff + c];
+            wave_sync();
+            PHASE_MARK(3);
+            continue;
+        }
+        {   // upstream gradient of the tile's rows
+            const int out = m.dims[L], outp = (out + 3) & ~3;
+            const float* src = J.d_out.p ? row_at(J.d_out, rrow) : nullptr;
+            gather<8>(outp, c4, 4, [&](int c) { return (src && rok && c < out) ? src[c] : 0.f; },
+                      [&](int c, float v) { dcur[rr * dld + c] = v; });
+        }
+        wave_sync();
+        PHASE_MARK(3);
+        for (int l = L - 1; l >= 0; --l) {
+            const int in = m.dims[l], out = m.dims[l + 1], inp = (in + 3) & ~3, outp = (out + 3) & ~3;
+            const int ioff = J.act_off[l], ooff = J.act_off[l + 1];
+            const bool relu = (l != L - 1) || m.last_relu;
+            const float* W = lds + J.w_lds[l];
+            const int wld = J.w_ld[l];
+            if (relu) {
+                for (int c = c4; c < out; c += 4)
+                    if (!(acts[rr * ald + ooff + c] > 0.f)) dcur[rr * dld + c] = 0.f;
+                wave_sync();
+            }
+            // dW^T[o][i] = sum_rows delta[row][o] act[row][i]   (M = outputs, N = inputs, K = the tile's 16 rows: the tile's columns
+            // run along the contiguous dimension of torch's [out][in] layout, so a wave's stores are 64-byte runs)
+            float* gW = slab + J.w_off[l];
+            for (int ot = 0; ot * 16 < out; ++ot)
+                for (int it = 0; it * 16 < in; it += 2) {
+                    f32x4 acc[1][2];
+                    clear<1, 2>(acc);
+                    if (!first)                      // later tiles of the wave: the MFMAs accumulate on top of the slab's values
+                        each<1, 2>(acc, [&](int mo, int c, float, int, int nt, int r) {
+                            const int o = ot * 16 + mo, i = it * 16 + c;
+                            if (i < in && o < out) acc[0][nt][r] = gW[(size_t)o * in + i];
+                        });
+                    mm<1, 2, 4>(acc, 4,
+                                [&](int mo, int k) { return dcur[k * dld + min(ot * 16 + mo, outp - 1)]; },
+                                [&](int k, int c) { return acts[k * ald + ioff + min(it * 16 + c, inp - 1)]; });
+                    each<1, 2>(acc, [&](int mo, int c, float v, int, int, int) {
+                        const int o = ot * 16 + mo, i = it * 16 + c;
+                        if (i < in && o < out) gW[(size_t)o * in + i] = v;
+                    });
+                }
+            PHASE_MARK(4);
+            float* gb = slab + J.b_off[l];
+            for (int c = lane; c < out; c += 64) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += dcur[r * dld + c];
+                gb[c] = first ? s : gb[c] + s;
+            }
+            PHASE_MARK(5);
+            if (l > 0 || J.need_din) {
+                // delta_in[row][i] = sum_o delta[row][o] W[i][o]
+                for (int jt = 0; jt * 16 < in; jt += 2) {
+                    f32x4 acc[1][2];
+                    clear<1, 2>(acc);
+                    mm<1, 2, 4>(acc, outp >> 2,
+                                [&](int row, int k) { return dcur[row * dld + k]; },
+                                [&](int k, int c) { return W[min(jt * 16 + c, in - 1) * wld + min(k, out - 1)]; });
+                    each<1, 2>(acc, [&](int row, int c, float v, int, int, int) {
+                        const int i = jt * 16 + c;
+                        if (i < inp) dnxt[row * dld + i] = i < in ? v : 0.f;
+                    });
+                }
+            }
+            wave_sync();
+            PHASE_MARK(6);
+            float* tmp = dcur;
+            dcur = dnxt;
+            dnxt = tmp;
+        }
+        if (J.need_din) {
+            const int d0 = m.dims[0];
+            float* dst = row_at(J.d_in, rrow);
+            gather<8>(d0, c4, 4, [&](int c) { return (J.din_add && rok) ? dst[c] : 0.f; },
+                      [&](int c, float v) { if (rok) dst[c] = v + dcur[rr * dld + c]; });
+        }
+        wave_sync();
+        PHASE_MARK(7);
+    }
+    PHASE_FLUSH();
+}
+
+// The shipped narrow MLPs -- in -> 64 -> out with in, out <= 32: w_r, w_h (9 | 5 | 6 | 7 -> 64 -> 32), the motion head
+// (32 -> 64 -> 5) -- carry nearly all rows of a batch (every node of every scene).  Same organisation as mlp_rows_kernel, but the
+// shapes are template parameters (T0 / T2 = 16-wide tiles of the input / output): every k loop is unrolled with its operand loads
+// batched, and the weight gradients of BOTH layers stay in MFMA accumulators over all tiles of the wave -- (4 T0 + 4 T2) tiles, 48
+// registers -- so a wave touches its slab once, at the end.
+template <int T0, int T2>
+__global__ __launch_bounds__(256) void mlp2_rows_kernel(const RowsArgs a) {
+    constexpr int HT = 4, IN_LD = T0 * 16 + 2, HLD = 66, OLD = T2 * 16 + 2;
+    constexpr int kWaveFloats = 16 * (IN_LD + HLD + OLD + HLD);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15;
+    const int ji = (a.n_jobs > 1 && (int)blockIdx.x >= a.job[1].wg_begin) ? 1 : 0;
+    const RowsJob& J = a.job[ji];
+    stage_weights(J, lds);
+    const int w = ((int)blockIdx.x - J.wg_begin) * J.waves_per_wg + wave;
+    if (wave >= J.waves_per_wg || w >= J.n_waves) return;
+    const RglMlp& m = J.m;
+    const int in = m.dims[0], out = m.dims[2];
+    const float* W0 = lds + J.w_lds[0];
+    const float* W1 = lds + J.w_lds[1];
+    const float* b0 = lds + J.b_lds[0];
+    const float* b1 = lds + J.b_lds[1];
+    const int wld0 = J.w_ld[0], wld1 = J.w_ld[1];
+    float* xin = lds + J.weight_floats + wave * kWaveFloats;      // [16][IN_LD]   input rows, zero beyond `in`; later the input deltas
+    float* hid = xin + 16 * IN_LD;                                // [16][HLD]     hidden activations
+    float* d1 = hid + 16 * HLD;                                   // [16][OLD]     outputs, then their deltas (zero beyond `out`)
+    float* d0 = d1 + 16 * OLD;                                    // [16][HLD]     hidden deltas
+    const bool last_relu = m.last_relu != 0;
+    f32x4 gW0[HT][T0], gW1[T2][HT];
+    clear<HT, T0>(gW0);
+    clear<T2, HT>(gW1);
+    float gb0 = 0.f, gb1 = 0.f;
+    const int rr = lane >> 2, c4 = lane & 3;
+    for (int t = w; t < J.n_tiles; t += J.n_waves) {
+        const int r0 = t * 16;
+        const bool rok = r0 + rr < J.n_rows;
+        const int rrow = rok ? r0 + rr : J.n_rows - 1;
+        {
+            const float* src = row_at(J.in, rrow);
+            float v[T0 * 4];
+#pragma unroll
+            for (int u = 0; u < T0 * 4; ++u) v[u] = (rok && c4 + 4 * u < in) ? src[c4 + 4 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < T0 * 4; ++u) xin[rr * IN_LD + c4 + 4 * u] = v[u];
+        }
+        wave_sync();
+        {   // hidden = relu(x W0 + b0)
+            f32x4 acc[1][HT];
+#pragma unroll
+            for (int nt = 0; nt < HT; ++nt) {
+                const float bv = b0[nt * 16 + l16];
+                acc[0][nt] = f32x4{bv, bv, bv, bv};
+            }
+            mm<1, HT, T0 * 4>(acc, T0 * 4, [&](int row, int k) { return xin[row * IN_LD + k]; },
+                              [&](int k, int c) { return W0[min(k, in - 1) * wld0 + c]; });
+            each<1, HT>(acc, [&](int row, int c, float v, int, int, int) { hid[row * HLD + c] = fmaxf(v, 0.f); });
+        }
+        wave_sync();
+        {   // y = hidden W1 + b1 (ReLU when the MLP ends with one)
+            f32x4 acc[1][T2];
+#pragma unroll
+            for (int nt = 0; nt < T2; ++nt) {
+                const int col = nt * 16 + l16;
+                const float bv = col < out ? b1[col] : 0.f;
+                acc[0][nt] = f32x4{bv, bv, bv, bv};
+            }
+            mm<1, T2, 8>(acc, 16, [&](int row, int k) { return hid[row * HLD + k]; },
+                         [&](int k, int c) { return W1[k * wld1 + min(c, out - 1)]; });
+            each<1, T2>(acc, [&](int row, int c, float v, int, int, int) { d1[row * OLD + c] = last_relu ? fmaxf(v, 0.f) : v; });
+        }
+        wave_sync();
+        if (!a.backward) {
+            float* dst = row_at(J.out, rrow);
+            if (rok)
+                for (int c = c4; c < out; c += 4) dst[c] = d1[rr * OLD + c];
+            wave_sync();
+            continue;
+        }
+        {   // upstream deltas through the last ReLU; zero in the padding columns
+            const float* src = J.d_out.p ? row_at(J.d_out, rrow) : nullptr;
+            float v[T2 * 4];
+#pragma unroll
+            for (int u = 0; u < T2 * 4; ++u) v[u] = (src && rok && c4 + 4 * u < out) ? src[c4 + 4 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < T2 * 4; ++u) {
+                const int c = c4 + 4 * u;
+                d1[rr * OLD + c] = (last_relu && !(d1[rr * OLD + c] > 0.f)) ? 0.f : v[u];
+            }
+        }
+        wave_sync();
+        // dW1^T[o][h] += sum_rows delta1[row][o] hidden[row][h]
+        mm<T2, HT, 4>(gW1, 4, [&](int mo, int k) { return d1[k * OLD + mo]; }, [&](int k, int c) { return hid[k * HLD + c]; });
+        if (lane < T2 * 16) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gb1 += d1[r * OLD + lane];
+        }
+        {   // delta0 = (delta1 W1^T) where the hidden ReLU is open
+            f32x4 acc[1][HT];
+            clear<1, HT>(acc);
+            mm<1, HT, T2 * 4>(acc, T2 * 4, [&](int row, int k) { return d1[row * OLD + k]; },
+                              [&](int k, int c) { return W1[c * wld1 + min(k, out - 1)]; });
+            each<1, HT>(acc, [&](int row, int c, float v, int, int, int) { d0[row * HLD + c] = hid[row * HLD + c] > 0.f ? v : 0.f; });
+        }
+        wave_sync();
+        // dW0^T[h][i] += sum_rows delta0[row][h] x[row][i]
+        mm<HT, T0, 4>(gW0, 4, [&](int mh, int k) { return d0[k * HLD + mh]; }, [&](int k, int c) { return xin[k * IN_LD + c]; });
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gb0 += d0[r * HLD + lane];
+        if (J.need_din) {
+            f32x4 acc[1][T0];
+            clear<1, T0>(acc);
+            mm<1, T0, 8>(acc, 16, [&](int row, int k) { return d0[row * HLD + k]; },
+                         [&](int k, int c) { return W0[min(c, in - 1) * wld0 + k]; });
+            wave_sync();                          // every lane has read x for dW0
+            each<1, T0>(acc, [&](int row, int c, float v, int, int, int) { xin[row * IN_LD + c] = v; });
+            wave_sync();
+            float* dst = row_at(J.d_in, rrow);
+            float v[T0 * 4];
+#pragma unroll
+            for (int u = 0; u < T0 * 4; ++u) v[u] = (J.din_add && rok && c4 + 4 * u < in) ? dst[c4 + 4 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < T0 * 4; ++u) {
+                const int c = c4 + 4 * u;
+                if (rok && c < in) dst[c] = v[u] + xin[rr * IN_LD + c];
+            }
+        }
+        wave_sync();
+    }
+    if (a.backward) {
+        float* slab = J.slabs + (size_t)w * J.n_params;
+        each<HT, T0>(gW0, [&](int h, int i, float v, int, int, int) { if (i < in) slab[J.w_off[0] + h * in + i] = v; });
+        each<T2, HT>(gW1, [&](int o, int h, float v, int, int, int) { if (o < out) slab[J.w_off[1] + o * 64 + h] = v; });
+        slab[J.b_off[0] + lane] = gb0;
+        if (lane < out) slab[J.b_off[1] + lane] = gb1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the graph block: one wave per scene
+// ------------------------------------------------------------------------------------------------
+constexpr int FLD = 34;          // row stride of the 32-wide node-feature arrays (row-indexed A-operand reads hit 32 distinct banks)
+
+struct GraphArgs {
+    const float* X;              // [S][N][32]
+    const float* dHL;            // [S][N][32]   (backward)
+    float* HL;                   // [S][N][32]   (forward)
+    float* dX;                   // [S][N][32]   (backward)
+    const float* w_a;            // [32][32] or null (gaussian: S = X X^T)
+    const float* Ws[3];
+    float* slabs;                // [waves][(has w_a + L) * 1024]
+    int S, N, skip, total_waves;
+};
+
+// LDS: workgroup-shared weights  Wa | W_0 .. W_{L-1}  ([32][FLD] each), then per wave
+//   X, dH, dZ, dT, T_0 .. T_{L-1}, H_1 .. H_{L-1}   ([NP][FLD], NP = N rounded up to 4: the padding rows stay zero, so node-indexed
+//   k loops need no guards)   and   A, dA   ([NP][ALD]).
+template <int NT>
+struct GraphLds {
+    static constexpr int ALD = NT * 16 + 2;
+    static __host__ __device__ int wave_floats(int N, int L) {
+        const int NP = (N + 3) & ~3;
+        return (4 + L + (L - 1)) * NP * FLD + 2 * NP * ALD;
+    }
+    static __host__ __device__ int weight_floats(int L) { return (1 + L) * XD * FLD; }
+};
+
+template <int NT, int L, bool BWD>
+__global__ __launch_bounds__(NT == 4 ? 128 : 512) void graph_kernel(const GraphArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int ALD = GraphLds<NT>::ALD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+    const int N = a.N, NP = (N + 3) & ~3, NK = NP >> 2, last = NP - 1;
+    const bool embedded = a.w_a != nullptr;
+    float* Wa = lds;
+    float* Wl = lds + XD * FLD;
+    for (int idx = threadIdx.x; idx < XD * XD; idx += blockDim.x) {
+        const int k = idx >> 5, c = idx & 31;
+        Wa[k * FLD + c] = embedded ? a.w_a[idx] : 0.f;
+#pragma unroll
+        for (int l = 0; l < L; ++l) Wl[l * XD * FLD + k * FLD + c] = a.Ws[l][idx];
+    }
+    __syncthreads();
+    float* base = lds + GraphLds<NT>::weight_floats(L) + wave * GraphLds<NT>::wave_floats(N, L);
+    const int U = NP * FLD;
+    float* X = base;
+    float* dH = X + U;
+    float* dZ = dH + U;
+    float* dT = dZ + U;
+    float* T = dT + U;                 // [L]
+    float* Hs = T + L * U;             // [L - 1]: H_1 ..
+    float* A = Hs + (L - 1) * U;
+    float* dA = A + NP * ALD;
+    auto Hl = [&](int l) { return l == 0 ? X : Hs + (l - 1) * U; };
+
+    f32x4 gWa[2][2], gW[L][2][2];
+    if constexpr (BWD) {
+        clear<2, 2>(gWa);
+#pragma unroll
+        for (int l = 0; l < L; ++l) clear<2, 2>(gW[l]);
+    }
+    const int gw = blockIdx.x * W + wave;
+    for (int s = gw; s < a.S; s += a.total_waves) {
+        // ---------------- forward ----------------
+        const float* Xg = a.X + (size_t)s * N * XD;
+        gather<8>(NP * XD, lane, 64, [&](int idx) { return idx < N * XD ? Xg[idx] : 0.f; },
+                  [&](int idx, float v) { X[(idx >> 5) * FLD + (idx & 31)] = v; });
+        wave_sync();
+        float* G = dT;                 // X Wa (embedded_gaussian), free until the backward sweep
+        auto make_G = [&]() {
+            f32x4 acc[NT][2];
+            clear<NT, 2>(acc);
+            mm<NT, 2>(acc, XD / 4, [&](int i, int k) { return X[min(i, last) * FLD + k]; },
+                      [&](int k, int j) { return Wa[k * FLD + j]; });
+            each<NT, 2>(acc, [&](int row, int col, float v, int, int, int) {
+                if (row < NP) G[row * FLD + col] = row < N ? v : 0.f;
+            });
+            wave_sync();
+        };
+        if (embedded) make_G();
+        const float* GX = embedded ? G : X;
+        {   // S = G X^T, rows normalised by softmax  (graph_model.py:64-69)
+            f32x4 acc[NT][NT];
+            clear<NT, NT>(acc);
+            mm<NT, NT>(acc, XD / 4, [&](int i, int k) { return GX[min(i, last) * FLD + k]; },
+                       [&](int k, int j) { return X[min(j, last) * FLD + k]; });
+            each<NT, NT>(acc, [&](int row, int col, float v, int, int, int) {
+                if (row < NP) A[row * ALD + col] = (row < N && col < N) ? v : 0.f;
+            });
+            wave_sync();
+            if (lane < N) {
+                float* r = A + lane * ALD;
+                float mx = r[0];
+                for (int j = 1; j < N; ++j) mx = fmaxf(mx, r[j]);
+                float sum = 0.f;
+                for (int j = 0; j < N; ++j) { const float e = expf(r[j] - mx); r[j] = e; sum += e; }
+                for (int j = 0; j < N; ++j) r[j] = r[j] / sum;
+            }
+            wave_sync();
+        }
+        unsigned mask[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const float* Hc = Hl(l);
+            float* Tl = T + l * U;
+            {
+                f32x4 acc[NT][2];
+                clear<NT, 2>(acc);
+                mm<NT, 2>(acc, NK, [&](int i, int k) { return A[min(i, last) * ALD + k]; },
+                          [&](int k, int j) { return Hc[k * FLD + j]; });
+                each<NT, 2>(acc, [&](int row, int col, float v, int, int, int) {
+                    if (row < NP) Tl[row * FLD + col] = row < N ? v : 0.f;
+                });
+            }
+            wave_sync();
+            {
+                f32x4 acc[NT][2];
+                clear<NT, 2>(acc);
+                const float* Wc = Wl + l * XD * FLD;
+                mm<NT, 2>(acc, XD / 4, [&](int i, int k) { return Tl[min(i, last) * FLD + k]; },
+                          [&](int k, int j) { return Wc[k * FLD + j]; });
+                unsigned bits = 0;
+                const bool keep = l + 1 < L;                    // the next layer's input
+                float* Hn = keep ? Hs + l * U : nullptr;
+                float* out = (!BWD && !keep) ? a.HL + (size_t)s * N * XD : nullptr;
+                each<NT, 2>(acc, [&](int row, int col, float v, int mt, int nt, int r) {
+                    if (v > 0.f) bits |= 1u << ((mt * 2 + nt) * 4 + r);
+                    if (row < NP && (keep || out)) {
+                        const float h = row < N ? fmaxf(v, 0.f) + (a.skip ? Hc[row * FLD + col] : 0.f) : 0.f;
+                        if (keep) Hn[row * FLD + col] = h;
+                        else if (row < N) out[row * XD + col] = h;
+                    }
+                });
+                mask[l] = bits;
+            }
+            wave_sync();
+        }
+        if constexpr (BWD) {
+            // ---------------- backward ----------------
+            const float* dg = a.dHL + (size_t)s * N * XD;
+            gather<8>(NP * XD, lane, 64, [&](int idx) { return idx < N * XD ? dg[idx] : 0.f; },
+                      [&](int idx, float v) { dH[(idx >> 5) * FLD + (idx & 31)] = v; });
+            wave_sync();
+            f32x4 dAacc[NT][NT];
+            clear<NT, NT>(dAacc);
+#pragma unroll
+            for (int l = L - 1; l >= 0; --l) {
+                const float* Hc = Hl(l);
+                const float* Tl = T + l * U;
+                const float* Wc = Wl + l * XD * FLD;
+                {   // dZ = dH_{l+1} where the layer's ReLU is open
+                    const unsigned bits = mask[l];
+                    const int l16 = lane & 15, kk = lane >> 4;
+#pragma unroll
+                    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = mt * 16 + 4 * kk + r, col = nt * 16 + l16;
+                                if (row < NP)
+                                    dZ[row * FLD + col] = ((bits >> ((mt * 2 + nt) * 4 + r)) & 1u) && row < N ? dH[row * FLD + col] : 0.f;
+                            }
+                }
+                wave_sync();
+                // dW_l += T_l^T dZ
+                mm<2, 2>(gW[l], NK, [&](int mi, int k) { return Tl[k * FLD + mi]; }, [&](int k, int j) { return dZ[k * FLD + j]; });
+                {   // dT = dZ W_l^T
+                    f32x4 acc[NT][2];
+                    clear<NT, 2>(acc);
+                    mm<NT, 2>(acc, XD / 4, [&](int i, int k) { return dZ[min(i, last) * FLD + k]; },
+                              [&](int k, int j) { return Wc[j * FLD + k]; });
+                    each<NT, 2>(acc, [&](int row, int col, float v, int, int, int) {
+                        if (row < NP) dT[row * FLD + col] = row < N ? v : 0.f;
+                    });
+                }
+                wave_sync();
+                // dA += dT H_l^T
+                mm<NT, NT>(dAacc, XD / 4, [&](int i, int k) { return dT[min(i, last) * FLD + k]; },
+                           [&](int k, int j) { return Hc[min(j, last) * FLD + k]; });
+                {   // dH_l = A^T dT (+ dH_{l+1} through the skip connection)
+                    f32x4 acc[NT][2];
+                    clear<NT, 2>(acc);
+                    mm<NT, 2>(acc, NK, [&](int mi, int k) { return A[k * ALD + mi]; }, [&](int k, int j) { return dT[k * FLD + j]; });
+                    each<NT, 2>(acc, [&](int row, int col, float v, int, int, int) {
+                        if (row < N) dH[row * FLD + col] = v + (a.skip ? dH[row * FLD + col] : 0.f);
+                    });
+                }
+                wave_sync();
+            }
+            // through the row softmax: dS_ij = A_ij (dA_ij - sum_k dA_ik A_ik)
+            each<NT, NT>(dAacc, [&](int row, int col, float v, int, int, int) {
+                if (row < NP) dA[row * ALD + col] = (row < N && col < N) ? v : 0.f;
+            });
+            wave_sync();
+            if (lane < N) {
+                float* d = dA + lane * ALD;
+                const float* p = A + lane * ALD;
+                float dot = 0.f;
+                for (int j = 0; j < N; ++j) dot = fmaf(d[j], p[j], dot);
+                for (int j = 0; j < N; ++j) d[j] = p[j] * (d[j] - dot);
+            }
+            wave_sync();
+            // S = G X^T:  dG = dS X ;  dX += dS^T G        G = X Wa:  dWa += X^T dG ;  dX += dG Wa^T     (gaussian: G = X, dX += dG)
+            if (embedded) make_G();
+            float* dG = dZ;
+            {
+                f32x4 acc[NT][2];
+                clear<NT, 2>(acc);
+                mm<NT, 2>(acc, NK, [&](int i, int k) { return dA[min(i, last) * ALD + k]; }, [&](int k, int j) { return X[k * FLD + j]; });
+                each<NT, 2>(acc, [&](int row, int col, float v, int, int, int) {
+                    if (row < NP) dG[row * FLD + col] = row < N ? v : 0.f;
+                });
+            }
+            {
+                f32x4 acc[NT][2];
+                clear<NT, 2>(acc);
+                mm<NT, 2>(acc, NK, [&](int mi, int k) { return dA[k * ALD + mi]; }, [&](int k, int j) { return GX[k * FLD + j]; });
+                each<NT, 2>(acc, [&](int row, int col, float v, int, int, int) {
+                    if (row < N) dH[row * FLD + col] += v;
+                });
+            }
+            wave_sync();
+            if (embedded) {
+                mm<2, 2>(gWa, NK, [&](int mi, int k) { return X[k * FLD + mi]; }, [&](int k, int j) { return dG[k * FLD + j]; });
+                f32x4 acc[NT][2];
+                clear<NT, 2>(acc);
+                mm<NT, 2>(acc, XD / 4, [&](int i, int k) { return dG[min(i, last) * FLD + k]; },
+                          [&](int k, int j) { return Wa[j * FLD + k]; });
+                each<NT, 2>(acc, [&](int row, int col, float v, int, int, int) {
+                    if (row < N) dH[row * FLD + col] += v;
+                });
+            } else {
+                for (int idx = lane; idx < N * XD; idx += 64) {
+                    const int r = idx >> 5, c = idx & 31;
+                    dH[r * FLD + c] += dG[r * FLD + c];
+                }
+            }
+            wave_sync();
+            float* dxg = a.dX + (size_t)s * N * XD;
+            for (int idx = lane; idx < N * XD; idx += 64) dxg[idx] = dH[(idx >> 5) * FLD + (idx & 31)];
+            wave_sync();
+        }
+    }
+    if constexpr (BWD) {
+        if (gw < a.total_waves) {
+            float* slab = a.slabs + (size_t)gw * ((embedded ? 1 : 0) + L) * XD * XD;
+            if (embedded) {
+                each<2, 2>(gWa, [&](int row, int col, float v, int, int, int) { slab[row * XD + col] = v; });
+                slab += XD * XD;
+            }
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+                each<2, 2>(gW[l], [&](int row, int col, float v, int, int, int) { slab[l * XD * XD + row * XD + col] = v; });
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// slabs -> gradient vector
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxRanges = 8;
+struct Range {
+    const float* slabs;     // [count][n]; count = 0: the range is zero (detached parameters)
+    int count, n, dst;
+};
+struct RangeArgs {
+    Range r[kMaxRanges];
+    int n_ranges, n_params;
+};
+// 256 threads = 32 parameters x 8 slab lanes: lane q sums slabs q, q + 8, .. in order (16 loads in flight), the eight partial sums
+// are added in lane order -- a fixed summation tree, so the result is deterministic.
+__global__ __launch_bounds__(256) void reduce_ranges_kernel(const RangeArgs a, float* __restrict__ out) {
+    __shared__ float part[8][33];
+    const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + c;
+    float acc = 0.f;
+    if (k < a.n_params) {
+        int ri = 0;
+        for (int i = 1; i < a.n_ranges; ++i)
+            if (k >= a.r[i].dst) ri = i;
+        const Range& R = a.r[ri];
+        const float* src = R.slabs + (k - R.dst);
+        int s = q;
+        for (; s + 15 * 8 < R.count; s += 16 * 8) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(s + 8 * u) * R.n];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += v[u];
+        }
+        for (; s < R.count; s += 8) acc += src[(size_t)s * R.n];
+    }
+    part[q][c] = acc;
+    __syncthreads();
+    if (q == 0 && k < a.n_params) {
+        float t = part[0][c];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) t += part[u][c];
+        out[k] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------
+int mlp_params(const RglMlp& m) {
+    int n = 0;
+    for (int l = 0; l < m.n_layers; ++l) n += m.dims[l] * m.dims[l + 1] + m.dims[l + 1];
+    return n;
+}
+
+void plan_rows_job(RowsJob& J, const RglMlp& m, int n_rows, int max_waves) {
+    J = RowsJob{};
+    J.m = m;
+    int off = 0, col = 0, widest = 0, wl = 0;
+    for (int l = 0; l < m.n_layers; ++l) {
+        J.w_off[l] = off; off += m.dims[l] * m.dims[l + 1];
+        J.b_off[l] = off; off += m.dims[l + 1];
+        J.w_ld[l] = m.dims[l + 1] | 1;
+        J.w_lds[l] = wl; wl += (m.dims[l] * J.w_ld[l] + 3) & ~3;
+        J.b_lds[l] = wl; wl += (m.dims[l + 1] + 3) & ~3;
+    }
+    for (int l = 0; l <= m.n_layers; ++l) {
+        J.act_off[l] = col;
+        col += (m.dims[l] + 3) & ~3;
+        widest = m.dims[l] > widest ? m.dims[l] : widest;
+    }
+    J.weight_floats = wl;
+    J.n_params = off;
+    J.act_ld = col + 2;                         // rows two banks apart
+    J.d_ld = ((widest + 3) & ~3) + 2;
+    J.n_rows = n_rows;
+    J.n_tiles = (n_rows + 15) / 16;
+    J.n_waves = J.n_tiles < max_waves ? J.n_tiles : max_waves;
+    if (m.n_layers == 2 && m.dims[1] == 64 && m.dims[0] <= 32 && m.dims[2] <= 32) {
+        const int T0 = (m.dims[0] + 15) / 16, T2 = (m.dims[2] + 15) / 16;
+        J.kind = 10 * T0 + T2;
+        J.waves_per_wg = 4;
+        J.n_wgs = (J.n_waves + 3) / 4;
+        J.wave_floats = 16 * ((T0 * 16 + 2) + 66 + (T2 * 16 + 2) + 66);
+        return;
+    }
+    J.wave_floats = 16 * J.act_ld + 32 * J.d_ld;
+    const size_t per_wave = (size_t)J.wave_floats * sizeof(float);
+    const size_t room = (size_t)rgl::kLdsBytesPerCu - 1024 - (size_t)wl * sizeof(float);
+    // two workgroups per CU when they fit (half the LDS each), else one
+    int wpw = (int)((room / 2 - (size_t)wl * sizeof(float) / 2) / per_wave);
+    if (wpw < 1) wpw = (int)(room / per_wave);
+    J.waves_per_wg = wpw > 4 ? 4 : wpw;
+    J.n_wgs = J.waves_per_wg > 0 ? (J.n_waves + J.waves_per_wg - 1) / J.waves_per_wg : 0;
+}
+size_t rows_job_lds(const RowsJob& J) { return ((size_t)J.weight_floats + (size_t)J.waves_per_wg * J.wave_floats) * sizeof(float); }
+
+template <class K>
+int launch_rows_kernel(K kernel, RowsArgs& ra, hipStream_t st) {
+    size_t lds = 0;
+    int wgs = 0;
+    for (int j = 0; j < ra.n_jobs; ++j) {
+        const size_t b = rows_job_lds(ra.job[j]);
+        lds = b > lds ? b : lds;
+        ra.job[j].wg_begin = wgs;
+        wgs += ra.job[j].n_wgs;
+    }
+    if (lds > 64 * 1024)
+        RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3(wgs), dim3(256), lds, st, ra);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
+// the jobs of one pipeline stage: one launch per kernel kind among them
+int launch_rows(RowsArgs& all, hipStream_t st) {
+    bool done[kMaxRowJobs] = {};
+    for (int j = 0; j < all.n_jobs; ++j) {
+        if (done[j]) continue;
+        RowsArgs ra{};
+        ra.backward = all.backward;
+        const int kind = all.job[j].kind;
+        for (int i = j; i < all.n_jobs; ++i)
+            if (!done[i] && all.job[i].kind == kind) { ra.job[ra.n_jobs++] = all.job[i]; done[i] = true; }
+        int rc;
+        switch (kind) {
+            case 11: rc = launch_rows_kernel(mlp2_rows_kernel<1, 1>, ra, st); break;
+            case 12: rc = launch_rows_kernel(mlp2_rows_kernel<1, 2>, ra, st); break;
+            case 21: rc = launch_rows_kernel(mlp2_rows_kernel<2, 1>, ra, st); break;
+            case 22: rc = launch_rows_kernel(mlp2_rows_kernel<2, 2>, ra, st); break;
+            default: rc = launch_rows_kernel(mlp_rows_kernel, ra, st); break;
+        }
+        if (rc) return rc;
+    }
+    return RGL_OK;
+}
+
+template <int NT, int L>
+int launch_graph_nl(const GraphArgs& ga, bool bwd, int W, size_t lds, int grid, hipStream_t st) {
+    const void* fn = bwd ? reinterpret_cast<const void*>(graph_kernel<NT, L, true>) : reinterpret_cast<const void*>(graph_kernel<NT, L, false>);
+    if (lds > 64 * 1024) RGL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (bwd) hipLaunchKernelGGL((graph_kernel<NT, L, true>), dim3(grid), dim3(W * 64), lds, st, ga);
+    else hipLaunchKernelGGL((graph_kernel<NT, L, false>), dim3(grid), dim3(W * 64), lds, st, ga);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+template <int NT>
+int launch_graph_n(const GraphArgs& ga, int L, bool bwd, int W, size_t lds, int grid, hipStream_t st) {
+    switch (L) {
+        case 1: return launch_graph_nl<NT, 1>(ga, bwd, W, lds, grid, st);
+        case 2: return launch_graph_nl<NT, 2>(ga, bwd, W, lds, grid, st);
+        default: return launch_graph_nl<NT, 3>(ga, bwd, W, lds, grid, st);
+    }
+}
+
+struct GraphPlan { int W, grid, total_waves; size_t lds; };
+template <int NT>
+GraphPlan plan_graph_nt(int S, int N, int L) {
+    const size_t wb = (size_t)GraphLds<NT>::weight_floats(L) * 4, pw = (size_t)GraphLds<NT>::wave_floats(N, L) * 4;
+    int W = (int)(((size_t)rgl::kLdsBytesPerCu - wb) / pw);
+    W = W > (NT == 4 ? 2 : 8) ? (NT == 4 ? 2 : 8) : W;
+    GraphPlan p{};
+    if (W < 1) return p;
+    // at most one workgroup per CU is resident (its LDS slice is most of the CU's): 256 workgroups, scenes dealt round robin
+    int grid = (S + W - 1) / W;
+    grid = grid > 256 ? 256 : grid;
+    p.W = W; p.grid = grid; p.total_waves = grid * W; p.lds = wb + (size_t)W * pw;
+    return p;
+}
+GraphPlan plan_graph(int S, int N, int L) {
+    return N <= 16 ? plan_graph_nt<1>(S, N, L) : (N <= 32 ? plan_graph_nt<2>(S, N, L) : plan_graph_nt<4>(S, N, L));
+}
+int launch_graph(const GraphArgs& ga, int L, bool bwd, const GraphPlan& p, hipStream_t st) {
+    if (ga.N <= 16) return launch_graph_n<1>(ga, L, bwd, p.W, p.lds, p.grid, st);
+    if (ga.N <= 32) return launch_graph_n<2>(ga, L, bwd, p.W, p.lds, p.grid, st);
+    return launch_graph_n<4>(ga, L, bwd, p.W, p.lds, p.grid, st);
+}
+
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && e[0]) ? atoi(e) : dflt;
+}
+
+}  // namespace
+
+#ifdef RGL_PHASE_TIMING
+extern "C" int rgl_debug_read_backward_phase_cycles(unsigned long long* out16, int reset) {
+    RGL_HIP_TRY(hipDeviceSynchronize());
+    RGL_HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        RGL_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)));
+    }
+    return 0;
+}
+#endif
+
+namespace rgl {
+
+// 1 = not this path (outside the envelope, below the batch threshold, or the caller's workspace cannot hold the intermediates):
+// the per-scene VALU kernel of rgl_backward.hip runs.  Slab order of grad_out as documented in rgl_hip.h.
+int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* mh, const float* robot, const float* humans,
+                         int S, int H, int detach_graph, const float* d_value, const float* d_humans_next, const float* d_H,
+                         float* grad_out, void* workspace, size_t workspace_bytes, hipStream_t st, int only_choice) {
+    // RGL_BACKWARD_MFMA = 0: never, 1: whenever the structure allows; default: by batch size, and whenever the per-scene kernel cannot
+    // hold a scene in LDS (only_choice)
+    const int mode = env_int("RGL_BACKWARD_MFMA", -1);
+    if (mode == 0) return 1;
+    if (mode != 1 && !only_choice && S < env_int("RGL_BACKWARD_MFMA_MIN", 512)) return 1;
+    const RglGraph& g = *graph;
+    const int N = H + 1, L = g.num_layer;
+    if (g.x_dim != XD || g.layerwise_graph || L < 1 || L > 3 || N > 64) return 1;
+    if (g.similarity != RGL_SIM_EMBEDDED_GAUSSIAN && g.similarity != RGL_SIM_GAUSSIAN) return 1;
+    const bool has_v = vh && vh->n_layers > 0, has_m = mh && mh->n_layers > 0;
+    const bool embedded = g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN;
+    const GraphPlan gp = plan_graph(S, N, L);
+    if (gp.W < 1) return 1;
+
+    // gradient vector: w_r | w_h | w_a | Ws | value head | motion head
+    const int n_wr = mlp_params(g.w_r), n_wh = mlp_params(g.w_h), n_graph = ((embedded ? 1 : 0) + L) * XD * XD;
+    const int n_v = has_v ? mlp_params(*vh) : 0, n_m = has_m ? mlp_params(*mh) : 0;
+    const int o_wr = 0, o_wh = n_wr, o_graph = o_wh + n_wh, o_v = o_graph + n_graph, o_m = o_v + n_v, n_params = o_m + n_m;
+
+    // workspace: X | H_L | dH_L | dX | slabs of the row jobs and of the graph kernel
+    char* ws = (char*)workspace;
+    size_t used = 0;
+    auto take = [&](size_t bytes) -> void* { void* p = ws + used; used += (bytes + 255) & ~(size_t)255; return p; };
+    const size_t feat = (size_t)S * N * XD * sizeof(float);
+    float* X = (float*)take(feat);
+    float* HL = (float*)take(feat);
+    float* dHL = (float*)take(feat);
+    float* dX = (float*)take(feat);
+    // one slab per wave: fewer waves per row job (more tiles each) when the caller's workspace -- sized for the per-scene kernel's
+    // slabs, n_scenes x n_params floats -- is short (few scenes of many nodes)
+    RowsJob j_wr, j_wh, j_v, j_m;
+    float* g_slabs = nullptr;
+    const size_t used_feat = used;
+    for (int max_waves = 2048; max_waves >= 8; max_waves >>= 1) {
+        used = used_feat;
+        plan_rows_job(j_wr, g.w_r, S, max_waves);
+        plan_rows_job(j_wh, g.w_h, S * H, max_waves);
+        if (has_v) plan_rows_job(j_v, *vh, S, max_waves);
+        if (has_m) plan_rows_job(j_m, *mh, S * H, max_waves);
+        auto slabs_for = [&](RowsJob& J) { J.slabs = (float*)take((size_t)J.n_waves * J.n_params * sizeof(float)); };
+        if (!detach_graph) { slabs_for(j_wr); slabs_for(j_wh); }
+        if (has_v) slabs_for(j_v);
+        if (has_m) slabs_for(j_m);
+        g_slabs = detach_graph ? nullptr : (float*)take((size_t)gp.total_waves * n_graph * sizeof(float));
+        if (used <= workspace_bytes) break;
+    }
+    if (used > workspace_bytes) return 1;
+    for (const RowsJob* J : {&j_wr, &j_wh, has_v ? &j_v : nullptr, has_m ? &j_m : nullptr})
+        if (J && J->waves_per_wg < 1) return 1;
+
+    // 1. embeddings
+    j_wr.in = RowMap{(float*)robot, 1, 0, (long long)g.w_r.dims[0]};
+    j_wr.out = RowMap{X, 1, 0, (long long)N * XD};
+    j_wh.in = RowMap{(float*)humans, H, g.w_h.dims[0], (long long)H * g.w_h.dims[0]};
+    j_wh.out = RowMap{X + XD, H, XD, (long long)N * XD};
+    {
+        RowsArgs ra{};
+        ra.job[0] = j_wr; ra.job[1] = j_wh; ra.n_jobs = 2; ra.backward = 0;
+        const int rc = launch_rows(ra, st);
+        if (rc) return rc;
+    }
+    // 2. graph forward
+    GraphArgs ga{};
+    ga.X = X; ga.dHL = dHL; ga.HL = HL; ga.dX = dX;
+    ga.w_a = embedded ? g.w_a : nullptr;
+    for (int l = 0; l < L; ++l) ga.Ws[l] = g.Ws[l];
+    ga.slabs = g_slabs; ga.S = S; ga.N = N; ga.skip = g.skip_connection ? 1 : 0; ga.total_waves = gp.total_waves;
+    if (has_v || has_m) {
+        const int rc = launch_graph(ga, L, false, gp, st);
+        if (rc) return rc;
+    }
+    // 3. heads: dH_L starts as the caller's d_H (or zero) and receives the heads' input gradients
+    if (d_H) RGL_HIP_TRY(hipMemcpyAsync(dHL, d_H, feat, hipMemcpyDeviceToDevice, st));
+    else RGL_HIP_TRY(hipMemsetAsync(dHL, 0, feat, st));
+    if (has_v || has_m) {
+        RowsArgs ra{};
+        ra.backward = 1;
+        if (has_v) {
+            j_v.in = RowMap{HL, 1, 0, (long long)N * XD};
+            j_v.d_out = RowMap{(float*)d_value, 1, 0, 1};
+            j_v.d_in = RowMap{dHL, 1, 0, (long long)N * XD};
+            j_v.need_din = detach_graph ? 0 : 1; j_v.din_add = 1;
+            ra.job[ra.n_jobs++] = j_v;
+        }
+        if (has_m) {
+            const int od = mh->dims[mh->n_layers];
+            j_m.in = RowMap{HL + XD, H, XD, (long long)N * XD};
+            j_m.d_out = RowMap{(float*)d_humans_next, H, od, (long long)H * od};
+            j_m.d_in = RowMap{dHL + XD, H, XD, (long long)N * XD};
+            j_m.need_din = detach_graph ? 0 : 1; j_m.din_add = 1;
+            ra.job[ra.n_jobs++] = j_m;
+        }
+        const int rc = launch_rows(ra, st);
+        if (rc) return rc;
+    }
+    if (!detach_graph) {
+        // 4. graph backward
+        int rc = launch_graph(ga, L, true, gp, st);
+        if (rc) return rc;
+        // 5. embeddings backward
+        j_wr.d_out = RowMap{dX, 1, 0, (long long)N * XD};
+        j_wh.d_out = RowMap{dX + XD, H, XD, (long long)N * XD};
+        RowsArgs ra{};
+        ra.job[0] = j_wr; ra.job[1] = j_wh; ra.n_jobs = 2; ra.backward = 1;
+        rc = launch_rows(ra, st);
+        if (rc) return rc;
+    }
+    // 6. slabs -> grad_out
+    RangeArgs rr{};
+    auto range = [&](const float* slabs, int count, int n, int dst) {
+        if (n > 0) rr.r[rr.n_ranges++] = Range{slabs, count, n, dst};
+    };
+    range(detach_graph ? nullptr : j_wr.slabs, detach_graph ? 0 : j_wr.n_waves, n_wr, o_wr);
+    range(detach_graph ? nullptr : j_wh.slabs, detach_graph ? 0 : j_wh.n_waves, n_wh, o_wh);
+    range(g_slabs, detach_graph ? 0 : gp.total_waves, n_graph, o_graph);
+    if (has_v) range(j_v.slabs, j_v.n_waves, n_v, o_v);
+    if (has_m) range(j_m.slabs, j_m.n_waves, n_m, o_m);
+    rr.n_params = n_params;
+    hipLaunchKernelGGL(reduce_ranges_kernel, dim3((n_params + 31) / 32), dim3(256), 0, st, rr, grad_out);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
+}  // namespace rgl

@@ -114,6 +114,12 @@ int launch_scene_children(const MprlPlanner* pl, const float* child_robot, const
                           float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream);         // rgl_scene.hip
 size_t scene_children_workspace_bytes(int P, int A, int H);                                                        // rgl_scene.hip
 
+// the backward pass of large batches as MFMA tile kernels; 1 = outside its envelope / below its batch threshold
+int launch_backward_mfma(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head, const float* robot,
+                         const float* humans, int n_scenes, int H, int detach_graph, const float* d_value,
+                         const float* d_humans_next, const float* d_H, float* grad_out, void* workspace, size_t workspace_bytes,
+                         hipStream_t stream, int only_choice);                                                                     // rgl_backward_mfma.hip
+
 inline int mlp_max_hidden(const RglMlp& m) {
     int w = 0;
     for (int l = 1; l < m.n_layers; ++l) w = m.dims[l] > w ? m.dims[l] : w;

@@ -1525,6 +1525,73 @@ def test_gradients_value_estimator_and_state_predictor(H, L, sim, skip, flavour,
                 _grad_close(v.grad, gsd[k].grad, "sp_graph." + k)
 
 
+@pytest.mark.parametrize("H,L,sim,skip,flavour,B", [
+    (5, 2, "embedded_gaussian", True, "trained", 7),
+    (19, 2, "embedded_gaussian", True, "trained", 4),
+    (5, 3, "embedded_gaussian", False, "trained", 5),
+    (3, 1, "gaussian", True, "trained", 6),
+    (5, 2, "embedded_gaussian", True, "rand", 3),
+    (16, 2, "embedded_gaussian", True, "trained", 35),
+    (40, 2, "gaussian", False, "trained", 3),])
+def test_gradients_on_the_mfma_backward(H, L, sim, skip, flavour, B, dev, monkeypatch):
+    """The tile pipeline of rgl_backward_mfma.hip (the large-batch backward: MFMA row kernels for the MLPs, one wave per scene for the
+    graph block) forced on for the small oracle-autograd cases of the test above (it is chosen by batch size otherwise), and for the
+    RGL-output / path-G gradients."""
+    monkeypatch.setenv("RGL_BACKWARD_MFMA", "1")
+    test_gradients_value_estimator_and_state_predictor(H, L, sim, skip, flavour, B, False, dev)
+    test_gradients_rgl_output_and_path_g(dev)
+
+
+@pytest.mark.parametrize("H,L,B", [(19, 2, 1024), (5, 2, 1500), (49, 3, 96), (31, 1, 200)])
+def test_mfma_backward_at_size(H, L, B, dev, monkeypatch):
+    """Batches the vector explorer feeds: every parameter gradient of the value estimator and of the state
+    predictor from the tile pipeline against torch autograd over the oracle AND against the per-scene VALU kernel of
+    rgl_backward.hip; two runs are bit-identical (fixed tile -> wave -> slab order)."""
+    c = dict(L=L, sim="embedded_gaussian", layerwise=False, skip=True, flavour="trained")
+    g1, ve, sp = build_modules(c, dev)
+    robot, humans = seeded_scenes(4000 + H, B, H)
+    r, h = robot.unsqueeze(1).to(dev), humans.to(dev)
+    cfg = orc.OracleConfig(num_layer=L, similarity="embedded_gaussian", skip_connection=True, layerwise_graph=False)
+    gen = torch.Generator().manual_seed(11)
+    wv = torch.randn(B, 1, generator=gen)
+    wm = torch.randn(B, H, 5, generator=gen)
+
+    def grads(mode):
+        monkeypatch.setenv("RGL_BACKWARD_MFMA", mode)
+        for p_ in list(ve.parameters()) + list(sp.parameters()):
+            p_.grad = None
+        (ve((r, h)) * wv.to(dev)).sum().backward()
+        _, nh = sp((r, h), None, detach=False)
+        (nh * wm.to(dev)).sum().backward()
+        return {("ve." if m is ve else "sp.") + k: v.grad.detach().clone() for m in (ve, sp) for k, v in m.named_parameters()}
+    tiles, again = grads("1"), grads("1")
+    try:
+        valu = grads("0")
+    except nat.NativeLibraryError:            # N = 50 with three layers: a scene does not fit the per-scene kernel's LDS
+        assert H >= 49
+        valu = None
+    for k in tiles:
+        assert torch.equal(tiles[k], again[k]), k
+        if valu is not None:
+            _grad_close(tiles[k], valu[k].cpu(), "tiles vs per-scene kernel " + k, tol=5e-5)
+    gsd, vsd = _oracle_leafs(ve.graph_model.state_dict()), _oracle_leafs(ve.value_network.state_dict())
+    (orc.value_estimator_forward(robot.unsqueeze(1), humans, gsd, vsd, cfg) * wv).sum().backward()
+    worst = 0.0
+    for prefix, sd in (("ve.graph_model.", gsd), ("ve.value_network.", vsd)):
+        for k, v in sd.items():
+            _grad_close(tiles[prefix + k], v.grad, prefix + k)
+            worst = max(worst, float((tiles[prefix + k].cpu() - v.grad).abs().max() / max(1e-3, float(v.grad.abs().max()))))
+    gsd, msd = _oracle_leafs(sp.graph_model.state_dict()), _oracle_leafs(sp.human_motion_predictor.state_dict())
+    emb, _ = orc.rgl_forward(robot.unsqueeze(1), humans, gsd, cfg)
+    (orc.mlp_forward(emb, orc.mlp_layers(msd, ""), last_relu=False)[:, 1:, :] * wm).sum().backward()
+    for k, v in gsd.items():
+        _grad_close(tiles["sp.graph_model." + k], v.grad, "sp.graph_model." + k)
+    for k, v in msd.items():
+        _grad_close(tiles["sp.human_motion_predictor." + k], v.grad, "sp.human_motion_predictor." + k)
+    report("tile-pipeline backward, H=%d L=%d batch %d: every gradient within 2e-4 of autograd over the oracle (worst %.1e of the "
+           "largest entry), 5e-5 of the per-scene kernel, bit-identical between runs" % (H, L, B, worst))
+
+
 def test_gradients_rgl_output_and_path_g(dev):
     c = dict(L=2, sim="embedded_gaussian", layerwise=False, skip=True, flavour="trained")
     g1, _, _ = build_modules(c, dev)
