@@ -6,10 +6,10 @@
 // the arithmetic of the VALU kernel up to summation order):
 //
 //   1. mlp_rows_kernel (forward only)   X = [w_r(robot); w_h(humans)]              one wave per 16-row tile
-//   2. graph_kernel<.., false>          H_L = layers(softmax(X Wa X^T), X)          one wave per scene, activations in its LDS slice
+//   2. graph_kernel<.., false>          H_L = layers(softmax(X Wa X^T), X)          one workgroup per scene, activations in its LDS
 //   3. mlp_rows_kernel (backward)       value head on H_L[:, 0] / motion head on H_L[:, 1:]  ->  dH_L, head gradients
 //   4. graph_kernel<.., true>           recomputes 2., back-propagates  ->  dX, and dWa / dW_l accumulated in REGISTERS over the
-//                                       wave's scenes (one slab per wave, not per scene)
+//                                       workgroup's scenes (one slab per workgroup, not per scene)
 //   5. mlp_rows_kernel (backward)       w_r / w_h from dX (forward recomputed inside)
 //   6. reduce_ranges_kernel             slabs summed in wave order (fixed tile -> wave assignment: deterministic)
 //
@@ -55,11 +55,15 @@ __device__ __forceinline__ void mm_steps(f32x4 (&acc)[MT][NTL], int ks0, FA& fa,
 #pragma unroll
             for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = mfma4(av[u][mt], bv[u][nt], acc[mt][nt]);
 }
+template <int MT, int NTL, int U, class FA, class FB>
+__device__ __forceinline__ void mm_from(f32x4 (&acc)[MT][NTL], int& ks, int ksteps, FA& fa, FB& fb) {
+    for (; ks + U <= ksteps; ks += U) mm_steps<MT, NTL, U>(acc, ks, fa, fb);
+    if constexpr (U > 1) mm_from<MT, NTL, U / 2>(acc, ks, ksteps, fa, fb);        // the remainder in halving batches
+}
 template <int MT, int NTL, int UNROLL = 2, class FA, class FB>
 __device__ __forceinline__ void mm(f32x4 (&acc)[MT][NTL], int ksteps, FA fa, FB fb) {
     int ks = 0;
-    for (; ks + UNROLL <= ksteps; ks += UNROLL) mm_steps<MT, NTL, UNROLL>(acc, ks, fa, fb);
-    for (; ks < ksteps; ++ks) mm_steps<MT, NTL, 1>(acc, ks, fa, fb);
+    mm_from<MT, NTL, UNROLL>(acc, ks, ksteps, fa, fb);
 }
 template <int MT, int NTL>
 __device__ __forceinline__ void clear(f32x4 (&acc)[MT][NTL]) {
@@ -124,6 +128,7 @@ struct RowsJob {
     int act_ld, d_ld, n_params;
     int n_rows, n_tiles, n_waves;
     int wg_begin, n_wgs, waves_per_wg;
+    int coop;                                                   // mlp_rows_kernel: one tile per WORKGROUP (n_waves counts workgroups)
     int wave_floats;                                            // LDS of one wave
     int kind;                                                   // 0: mlp_rows_kernel; 10 T0 + T2: mlp2_rows_kernel<T0, T2>
     int need_din, din_add;
@@ -160,14 +165,17 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15;
     const int ji = (a.n_jobs > 1 && (int)blockIdx.x >= a.job[1].wg_begin) ? 1 : 0;
     const RowsJob& J = a.job[ji];
-    PHASE_START();
     stage_weights(J, lds);
-    PHASE_MARK(0);
-    const int w = ((int)blockIdx.x - J.wg_begin) * J.waves_per_wg + wave;
-    if (wave >= J.waves_per_wg || w >= J.n_waves) return;
+    // coop (few tiles, wide layers: the value head): the four waves of the workgroup share ONE tile -- the column tiles of every
+    // product are dealt to them, with a workgroup barrier between phases -- instead of a tile each
+    const bool coop = J.coop != 0;
+    const int WV = coop ? 4 : 1, wv = coop ? wave : 0;
+    const int w = coop ? (int)blockIdx.x - J.wg_begin : ((int)blockIdx.x - J.wg_begin) * J.waves_per_wg + wave;
+    if ((!coop && wave >= J.waves_per_wg) || w >= J.n_waves) return;
+    auto sync = [&]() { if (coop) __syncthreads(); else wave_sync(); };
     const RglMlp& m = J.m;
     const int L = m.n_layers, ald = J.act_ld, dld = J.d_ld;
-    float* acts = lds + J.weight_floats + wave * (16 * ald + 32 * dld);
+    float* acts = lds + J.weight_floats + (coop ? 0 : wave) * (16 * ald + 32 * dld);
     float* dcur = acts + 16 * ald;
     float* dnxt = dcur + 16 * dld;
     float* slab = J.slabs + (size_t)w * J.n_params;
@@ -183,8 +191,7 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs a) {
             const float* src = row_at(J.in, rrow);
             gather<8>(d0p, c4, 4, [&](int c) { return (rok && c < d0) ? src[c] : 0.f; }, [&](int c, float v) { acts[rr * ald + c] = v; });
         }
-        wave_sync();
-        PHASE_MARK(1);
+        sync();
         for (int l = 0; l < L; ++l) {
             const int in = m.dims[l], out = m.dims[l + 1], inp = (in + 3) & ~3, outp = (out + 3) & ~3;
             const int ioff = J.act_off[l], ooff = J.act_off[l + 1];
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs a) {
             const float* W = lds + J.w_lds[l];
             const float* b = lds + J.b_lds[l];
             const int wld = J.w_ld[l];
-            for (int jt = 0; jt * 16 < out; jt += 2) {
+            for (int jt = 2 * wv; jt * 16 < out; jt += 2 * WV) {
                 f32x4 acc[1][2];
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
@@ -210,16 +217,14 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs a) {
                     if (col < outp) acts[row * ald + ooff + col] = col < out ? (relu ? fmaxf(v, 0.f) : v) : 0.f;
                 });
             }
-            wave_sync();
+            sync();
         }
-        PHASE_MARK(2);
         if (!a.backward) {
             const int out = m.dims[L], ooff = J.act_off[L];
             float* dst = row_at(J.out, rrow);
-            if (rok)
+            if (rok && wv == 0)
                 for (int c = c4; c < out; c += 4) dst[c] = acts[rr * ald + ooff + c];
-            wave_sync();
-            PHASE_MARK(3);
+            sync();
             continue;
         }
         {   // upstream gradient of the tile's rows
@@ -228,8 +233,7 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs a) {
             gather<8>(outp, c4, 4, [&](int c) { return (src && rok && c < out) ? src[c] : 0.f; },
                       [&](int c, float v) { dcur[rr * dld + c] = v; });
         }
-        wave_sync();
-        PHASE_MARK(3);
+        sync();
         for (int l = L - 1; l >= 0; --l) {
             const int in = m.dims[l], out = m.dims[l + 1], inp = (in + 3) & ~3, outp = (out + 3) & ~3;
             const int ioff = J.act_off[l], ooff = J.act_off[l + 1];
@@ -239,13 +243,15 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs a) {
             if (relu) {
                 for (int c = c4; c < out; c += 4)
                     if (!(acts[rr * ald + ooff + c] > 0.f)) dcur[rr * dld + c] = 0.f;
-                wave_sync();
+                sync();
             }
             // dW^T[o][i] = sum_rows delta[row][o] act[row][i]   (M = outputs, N = inputs, K = the tile's 16 rows: the tile's columns
             // run along the contiguous dimension of torch's [out][in] layout, so a wave's stores are 64-byte runs)
             float* gW = slab + J.w_off[l];
+            int block = 0;
             for (int ot = 0; ot * 16 < out; ++ot)
                 for (int it = 0; it * 16 < in; it += 2) {
+                    if ((block++ & (WV - 1)) != wv) continue;
                     f32x4 acc[1][2];
                     clear<1, 2>(acc);
                     if (!first)                      // later tiles of the wave: the MFMAs accumulate on top of the slab's values
@@ -261,18 +267,16 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs a) {
                         if (i < in && o < out) gW[(size_t)o * in + i] = v;
                     });
                 }
-            PHASE_MARK(4);
             float* gb = slab + J.b_off[l];
-            for (int c = lane; c < out; c += 64) {
+            for (int c = lane + 64 * wv; c < out; c += 64 * WV) {
                 float s = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s += dcur[r * dld + c];
                 gb[c] = first ? s : gb[c] + s;
             }
-            PHASE_MARK(5);
             if (l > 0 || J.need_din) {
                 // delta_in[row][i] = sum_o delta[row][o] W[i][o]
-                for (int jt = 0; jt * 16 < in; jt += 2) {
+                for (int jt = 2 * wv; jt * 16 < in; jt += 2 * WV) {
                     f32x4 acc[1][2];
                     clear<1, 2>(acc);
                     mm<1, 2, 4>(acc, outp >> 2,
@@ -284,22 +288,19 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs a) {
                     });
                 }
             }
-            wave_sync();
-            PHASE_MARK(6);
+            sync();
             float* tmp = dcur;
             dcur = dnxt;
             dnxt = tmp;
         }
-        if (J.need_din) {
+        if (J.need_din && wv == 0) {
             const int d0 = m.dims[0];
             float* dst = row_at(J.d_in, rrow);
             gather<8>(d0, c4, 4, [&](int c) { return (J.din_add && rok) ? dst[c] : 0.f; },
                       [&](int c, float v) { if (rok) dst[c] = v + dcur[rr * dld + c]; });
         }
-        wave_sync();
-        PHASE_MARK(7);
+        sync();
     }
-    PHASE_FLUSH();
 }
 
 // The shipped narrow MLPs -- in -> 64 -> out with in, out <= 32: w_r, w_h (9 | 5 | 6 | 7 -> 64 -> 32), the motion head
@@ -307,17 +308,18 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs a) {
 // shapes are template parameters (T0 / T2 = 16-wide tiles of the input / output): every k loop is unrolled with its operand loads
 // batched, and the weight gradients of BOTH layers stay in MFMA accumulators over all tiles of the wave -- (4 T0 + 4 T2) tiles, 48
 // registers -- so a wave touches its slab once, at the end.
+constexpr int kNarrowWaves = 4;       // waves per workgroup of mlp2_rows_kernel: two workgroups fit a CU (LDS, and ~200 VGPRs per lane)
 template <int T0, int T2>
-__global__ __launch_bounds__(256) void mlp2_rows_kernel(const RowsArgs a) {
+__global__ __launch_bounds__(kNarrowWaves * 64) void mlp2_rows_kernel(const RowsArgs a) {
     constexpr int HT = 4, IN_LD = T0 * 16 + 2, HLD = 66, OLD = T2 * 16 + 2;
     constexpr int kWaveFloats = 16 * (IN_LD + HLD + OLD + HLD);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15;
     const int ji = (a.n_jobs > 1 && (int)blockIdx.x >= a.job[1].wg_begin) ? 1 : 0;
     const RowsJob& J = a.job[ji];
-    stage_weights(J, lds);
+    PHASE_START();
     const int w = ((int)blockIdx.x - J.wg_begin) * J.waves_per_wg + wave;
-    if (wave >= J.waves_per_wg || w >= J.n_waves) return;
+    const bool on = wave < J.waves_per_wg && w < J.n_waves;
     const RglMlp& m = J.m;
     const int in = m.dims[0], out = m.dims[2];
     const float* W0 = lds + J.w_lds[0];
@@ -335,19 +337,53 @@ __global__ __launch_bounds__(256) void mlp2_rows_kernel(const RowsArgs a) {
     clear<T2, HT>(gW1);
     float gb0 = 0.f, gb1 = 0.f;
     const int rr = lane >> 2, c4 = lane & 3;
+    // the rows of a tile (inputs, and upstream deltas in a backward launch) are fetched one tile ahead: lane -> (row lane / 4,
+    // columns lane % 4 + 4 u); the first tile's before the weights, so that the two latencies overlap
+    float vin[T0 * 4], vd[T2 * 4];
+    auto fetch = [&](int t) {
+        const bool ok = t < J.n_tiles && t * 16 + rr < J.n_rows;
+        const int row = ok ? t * 16 + rr : 0;
+        const float* src = row_at(J.in, row);
+#pragma unroll
+        for (int u = 0; u < T0 * 4; ++u) vin[u] = (ok && c4 + 4 * u < in) ? src[c4 + 4 * u] : 0.f;
+        if (a.backward) {
+            const float* dsrc = J.d_out.p ? row_at(J.d_out, row) : nullptr;
+#pragma unroll
+            for (int u = 0; u < T2 * 4; ++u) vd[u] = (dsrc && ok && c4 + 4 * u < out) ? dsrc[c4 + 4 * u] : 0.f;
+        }
+    };
+    fetch(on ? w : J.n_tiles);
+    {   // both layers' weights and biases -> LDS: ONE batch of loads per thread (2.4 k floats over 256 threads), then the stores
+        constexpr int o0 = 64;
+        const int n0 = in * o0, n1 = o0 * out, nb = n0 + n1, total = nb + o0 + out;
+        const float* __restrict__ g0 = m.weight[0];
+        const float* __restrict__ g1 = m.weight[1];
+        const float* __restrict__ gb0p = m.bias[0];
+        const float* __restrict__ gb1p = m.bias[1];
+        gather<10>(total, threadIdx.x, kNarrowWaves * 64,
+                   [&](int idx) { return idx < n0 ? g0[idx] : (idx < nb ? g1[idx - n0] : (idx < nb + o0 ? gb0p[idx - nb] : gb1p[idx - nb - o0])); },
+                   [&](int idx, float v) {
+                       if (idx < n0) { const int k = idx / o0; lds[J.w_lds[0] + k * wld0 + idx - k * o0] = v; }
+                       else if (idx < nb) { const int j = idx - n0, k = j / out; lds[J.w_lds[1] + k * wld1 + j - k * out] = v; }
+                       else if (idx < nb + o0) lds[J.b_lds[0] + idx - nb] = v;
+                       else lds[J.b_lds[1] + idx - nb - o0] = v;
+                   });
+    }
+    __syncthreads();
+    PHASE_MARK(0);
+    if (!on) return;
     for (int t = w; t < J.n_tiles; t += J.n_waves) {
         const int r0 = t * 16;
         const bool rok = r0 + rr < J.n_rows;
         const int rrow = rok ? r0 + rr : J.n_rows - 1;
-        {
-            const float* src = row_at(J.in, rrow);
-            float v[T0 * 4];
+        float vdc[T2 * 4];
 #pragma unroll
-            for (int u = 0; u < T0 * 4; ++u) v[u] = (rok && c4 + 4 * u < in) ? src[c4 + 4 * u] : 0.f;
+        for (int u = 0; u < T0 * 4; ++u) xin[rr * IN_LD + c4 + 4 * u] = vin[u];
 #pragma unroll
-            for (int u = 0; u < T0 * 4; ++u) xin[rr * IN_LD + c4 + 4 * u] = v[u];
-        }
+        for (int u = 0; u < T2 * 4; ++u) vdc[u] = vd[u];
+        fetch(t + J.n_waves);
         wave_sync();
+        PHASE_MARK(1);
         {   // hidden = relu(x W0 + b0)
             f32x4 acc[1][HT];
 #pragma unroll
@@ -360,6 +396,7 @@ __global__ __launch_bounds__(256) void mlp2_rows_kernel(const RowsArgs a) {
             each<1, HT>(acc, [&](int row, int c, float v, int, int, int) { hid[row * HLD + c] = fmaxf(v, 0.f); });
         }
         wave_sync();
+        PHASE_MARK(2);
         {   // y = hidden W1 + b1 (ReLU when the MLP ends with one)
             f32x4 acc[1][T2];
 #pragma unroll
@@ -373,6 +410,7 @@ __global__ __launch_bounds__(256) void mlp2_rows_kernel(const RowsArgs a) {
             each<1, T2>(acc, [&](int row, int c, float v, int, int, int) { d1[row * OLD + c] = last_relu ? fmaxf(v, 0.f) : v; });
         }
         wave_sync();
+        PHASE_MARK(3);
         if (!a.backward) {
             float* dst = row_at(J.out, rrow);
             if (rok)
@@ -381,17 +419,14 @@ __global__ __launch_bounds__(256) void mlp2_rows_kernel(const RowsArgs a) {
             continue;
         }
         {   // upstream deltas through the last ReLU; zero in the padding columns
-            const float* src = J.d_out.p ? row_at(J.d_out, rrow) : nullptr;
-            float v[T2 * 4];
-#pragma unroll
-            for (int u = 0; u < T2 * 4; ++u) v[u] = (src && rok && c4 + 4 * u < out) ? src[c4 + 4 * u] : 0.f;
 #pragma unroll
             for (int u = 0; u < T2 * 4; ++u) {
                 const int c = c4 + 4 * u;
-                d1[rr * OLD + c] = (last_relu && !(d1[rr * OLD + c] > 0.f)) ? 0.f : v[u];
+                d1[rr * OLD + c] = (last_relu && !(d1[rr * OLD + c] > 0.f)) ? 0.f : vdc[u];
             }
         }
         wave_sync();
+        PHASE_MARK(4);
         // dW1^T[o][h] += sum_rows delta1[row][o] hidden[row][h]
         mm<T2, HT, 4>(gW1, 4, [&](int mo, int k) { return d1[k * OLD + mo]; }, [&](int k, int c) { return hid[k * HLD + c]; });
         if (lane < T2 * 16) {
@@ -406,10 +441,12 @@ __global__ __launch_bounds__(256) void mlp2_rows_kernel(const RowsArgs a) {
             each<1, HT>(acc, [&](int row, int c, float v, int, int, int) { d0[row * HLD + c] = hid[row * HLD + c] > 0.f ? v : 0.f; });
         }
         wave_sync();
+        PHASE_MARK(5);
         // dW0^T[h][i] += sum_rows delta0[row][h] x[row][i]
         mm<HT, T0, 4>(gW0, 4, [&](int mh, int k) { return d0[k * HLD + mh]; }, [&](int k, int c) { return xin[k * IN_LD + c]; });
 #pragma unroll
         for (int r = 0; r < 16; ++r) gb0 += d0[r * HLD + lane];
+        PHASE_MARK(6);
         if (J.need_din) {
             f32x4 acc[1][T0];
             clear<1, T0>(acc);
@@ -429,7 +466,9 @@ __global__ __launch_bounds__(256) void mlp2_rows_kernel(const RowsArgs a) {
             }
         }
         wave_sync();
+        PHASE_MARK(7);
     }
+    PHASE_FLUSH();
     if (a.backward) {
         float* slab = J.slabs + (size_t)w * J.n_params;
         each<HT, T0>(gW0, [&](int h, int i, float v, int, int, int) { if (i < in) slab[J.w_off[0] + h * in + i] = v; });
@@ -440,7 +479,7 @@ __global__ __launch_bounds__(256) void mlp2_rows_kernel(const RowsArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// the graph block: one wave per scene
+// the graph block: one workgroup per scene
 // ------------------------------------------------------------------------------------------------
 constexpr int FLD = 34;          // row stride of the 32-wide node-feature arrays (row-indexed A-operand reads hit 32 distinct banks)
 
@@ -451,40 +490,67 @@ struct GraphArgs {
     float* dX;                   // [S][N][32]   (backward)
     const float* w_a;            // [32][32] or null (gaussian: S = X X^T)
     const float* Ws[3];
-    float* slabs;                // [waves][(has w_a + L) * 1024]
-    int S, N, skip, total_waves;
+    float* slabs;                // [workgroups][(has w_a + L) * 1024]
+    int S, N, skip;
 };
 
-// LDS: workgroup-shared weights  Wa | W_0 .. W_{L-1}  ([32][FLD] each), then per wave
+// sum / max over the 16 lanes of a DPP row, every lane gets it
+__device__ __forceinline__ float dpp_f(float x, int ctrl) {
+    switch (ctrl) {
+        case 0: return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
+        case 1: return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+        case 2: return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x141, 0xf, 0xf, true));    // row_half_mirror
+        default: return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x140, 0xf, 0xf, true));   // row_mirror
+    }
+}
+__device__ __forceinline__ float row16_sum(float x) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) x += dpp_f(x, c);
+    return x;
+}
+__device__ __forceinline__ float row16_maxf(float x) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) x = fmaxf(x, dpp_f(x, c));
+    return x;
+}
+
+// LDS of a workgroup: weights  Wa | W_0 .. W_{L-1}  ([32][FLD] each), then the scene's
 //   X, dH, dZ, dT, T_0 .. T_{L-1}, H_1 .. H_{L-1}   ([NP][FLD], NP = N rounded up to 4: the padding rows stay zero, so node-indexed
 //   k loops need no guards)   and   A, dA   ([NP][ALD]).
 template <int NT>
 struct GraphLds {
     static constexpr int ALD = NT * 16 + 2;
-    static __host__ __device__ int wave_floats(int N, int L) {
+    static __host__ __device__ int scene_floats(int N, int L) {
         const int NP = (N + 3) & ~3;
         return (4 + L + (L - 1)) * NP * FLD + 2 * NP * ALD;
     }
     static __host__ __device__ int weight_floats(int L) { return (1 + L) * XD * FLD; }
 };
 
+// A scene is a chain of ~20 small products (8 MFMAs per 16 x 16 tile each), every one needing the whole result of the one before:
+// a wave per scene spends its time in LDS round trips.  So the 2 NT waves of a workgroup share ONE scene: each product's output tiles
+// are dealt to the waves -- an [N][32] result has NT x 2 tiles, one per wave; [N][N] results NT x NT; the [32][32] weight gradients
+// four -- with a workgroup barrier between phases, and several workgroups per CU overlap each other's barriers.  The weight
+// gradients stay in the accumulators of the waves that own their tiles over all scenes of the workgroup (one slab per workgroup).
 template <int NT, int L, bool BWD>
-__global__ __launch_bounds__(NT == 4 ? 128 : 512) void graph_kernel(const GraphArgs a) {
+__global__ __launch_bounds__(NT * 128) void graph_kernel(const GraphArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int ALD = GraphLds<NT>::ALD;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+    constexpr int W = 2 * NT;                        // waves
+    constexpr int NTW = NT >= 2 ? NT / 2 : 1;        // column tiles of an [N][N] result per wave
+    constexpr int GT = W >= 4 ? 1 : 2;               // column tiles of a [32][32] result per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, kq = lane >> 4;
     const int N = a.N, NP = (N + 3) & ~3, NK = NP >> 2, last = NP - 1;
     const bool embedded = a.w_a != nullptr;
     float* Wa = lds;
     float* Wl = lds + XD * FLD;
-    for (int idx = threadIdx.x; idx < XD * XD; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < XD * XD; idx += W * 64) {
         const int k = idx >> 5, c = idx & 31;
         Wa[k * FLD + c] = embedded ? a.w_a[idx] : 0.f;
 #pragma unroll
         for (int l = 0; l < L; ++l) Wl[l * XD * FLD + k * FLD + c] = a.Ws[l][idx];
     }
-    __syncthreads();
-    float* base = lds + GraphLds<NT>::weight_floats(L) + wave * GraphLds<NT>::wave_floats(N, L);
+    float* base = lds + GraphLds<NT>::weight_floats(L);
     const int U = NP * FLD;
     float* X = base;
     float* dH = X + U;
@@ -495,206 +561,233 @@ __global__ __launch_bounds__(NT == 4 ? 128 : 512) void graph_kernel(const GraphA
     float* A = Hs + (L - 1) * U;
     float* dA = A + NP * ALD;
     auto Hl = [&](int l) { return l == 0 ? X : Hs + (l - 1) * U; };
+    // this wave's tile of an [N][32] result, its block of an [N][N] result, its block of a [32][32] result
+    const int fm = (wave >> 1) * 16, fn = (wave & 1) * 16;
+    const int am = fm, an = (wave & 1) * NTW * 16;
+    const bool a_on = (wave & 1) * NTW < NT;
+    const int gm = (W >= 4 ? (wave >> 1) : wave) * 16, gn = W >= 4 ? (wave & 1) * 16 : 0;
+    const bool g_on = W >= 4 ? wave < 4 : true;
+    // element r of this lane in its [N][32] tile: row fm + 4 kq + r, column fn + l16
+    const int frow = fm + 4 * kq, fcol = fn + l16;
 
-    f32x4 gWa[2][2], gW[L][2][2];
-    if constexpr (BWD) {
-        clear<2, 2>(gWa);
+    f32x4 gWa[1][GT], gW[L][1][GT];
+    clear<1, GT>(gWa);
 #pragma unroll
-        for (int l = 0; l < L; ++l) clear<2, 2>(gW[l]);
-    }
-    const int gw = blockIdx.x * W + wave;
-    for (int s = gw; s < a.S; s += a.total_waves) {
-        // ---------------- forward ----------------
-        const float* Xg = a.X + (size_t)s * N * XD;
-        gather<8>(NP * XD, lane, 64, [&](int idx) { return idx < N * XD ? Xg[idx] : 0.f; },
-                  [&](int idx, float v) { X[(idx >> 5) * FLD + (idx & 31)] = v; });
-        wave_sync();
-        float* G = dT;                 // X Wa (embedded_gaussian), free until the backward sweep
+    for (int l = 0; l < L; ++l) clear<1, GT>(gW[l]);
+    __syncthreads();
+
+    for (int s = blockIdx.x; s < a.S; s += gridDim.x) {
+        {   // X (and the upstream gradient) of the scene; rows N .. NP-1 zero
+            const float* Xg = a.X + (size_t)s * N * XD;
+            gather<4>(NP * XD, threadIdx.x, W * 64, [&](int idx) { return idx < N * XD ? Xg[idx] : 0.f; },
+                      [&](int idx, float v) { X[(idx >> 5) * FLD + (idx & 31)] = v; });
+            if constexpr (BWD) {
+                const float* dg = a.dHL + (size_t)s * N * XD;
+                gather<4>(NP * XD, threadIdx.x, W * 64, [&](int idx) { return idx < N * XD ? dg[idx] : 0.f; },
+                          [&](int idx, float v) { dH[(idx >> 5) * FLD + (idx & 31)] = v; });
+            }
+        }
+        __syncthreads();
+        float* G = dT;                 // X Wa (embedded_gaussian): lives in dT's buffer until the backward sweep needs that
         auto make_G = [&]() {
-            f32x4 acc[NT][2];
-            clear<NT, 2>(acc);
-            mm<NT, 2>(acc, XD / 4, [&](int i, int k) { return X[min(i, last) * FLD + k]; },
-                      [&](int k, int j) { return Wa[k * FLD + j]; });
-            each<NT, 2>(acc, [&](int row, int col, float v, int, int, int) {
-                if (row < NP) G[row * FLD + col] = row < N ? v : 0.f;
-            });
-            wave_sync();
+            f32x4 acc[1][1];
+            clear<1, 1>(acc);
+            mm<1, 1, 8>(acc, XD / 4, [&](int i, int k) { return X[min(fm + i, last) * FLD + k]; },
+                        [&](int k, int j) { return Wa[k * FLD + fn + j]; });
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (frow + r < NP) G[(frow + r) * FLD + fcol] = frow + r < N ? acc[0][0][r] : 0.f;
         };
-        if (embedded) make_G();
+        if (embedded) {
+            make_G();
+            __syncthreads();
+        }
         const float* GX = embedded ? G : X;
-        {   // S = G X^T, rows normalised by softmax  (graph_model.py:64-69)
-            f32x4 acc[NT][NT];
-            clear<NT, NT>(acc);
-            mm<NT, NT>(acc, XD / 4, [&](int i, int k) { return GX[min(i, last) * FLD + k]; },
-                       [&](int k, int j) { return X[min(j, last) * FLD + k]; });
-            each<NT, NT>(acc, [&](int row, int col, float v, int, int, int) {
+        if (a_on) {   // S = G X^T   (graph_model.py:64-69)
+            f32x4 acc[1][NTW];
+            clear<1, NTW>(acc);
+            mm<1, NTW, 8>(acc, XD / 4, [&](int i, int k) { return GX[min(am + i, last) * FLD + k]; },
+                          [&](int k, int j) { return X[min(an + j, last) * FLD + k]; });
+            each<1, NTW>(acc, [&](int i, int j, float v, int, int, int) {
+                const int row = am + i, col = an + j;
                 if (row < NP) A[row * ALD + col] = (row < N && col < N) ? v : 0.f;
             });
-            wave_sync();
-            if (lane < N) {
-                float* r = A + lane * ALD;
-                float mx = r[0];
-                for (int j = 1; j < N; ++j) mx = fmaxf(mx, r[j]);
-                float sum = 0.f;
-                for (int j = 0; j < N; ++j) { const float e = expf(r[j] - mx); r[j] = e; sum += e; }
-                for (int j = 0; j < N; ++j) r[j] = r[j] / sum;
-            }
-            wave_sync();
         }
+        __syncthreads();
+        // row softmax: 16 lanes per row, four rows per wave and pass
+        for (int row = wave * 4 + kq; row < N; row += W * 4) {
+            float* r = A + row * ALD;
+            float v[NT], mx = -3.4e38f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                v[j] = l16 + 16 * j < N ? r[l16 + 16 * j] : -3.4e38f;
+                mx = fmaxf(mx, v[j]);
+            }
+            mx = row16_maxf(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                v[j] = l16 + 16 * j < N ? expf(v[j] - mx) : 0.f;
+                sum += v[j];
+            }
+            sum = row16_sum(sum);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                if (l16 + 16 * j < N) r[l16 + 16 * j] = v[j] / sum;
+        }
+        __syncthreads();
         unsigned mask[L];
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             const float* Hc = Hl(l);
             float* Tl = T + l * U;
-            {
-                f32x4 acc[NT][2];
-                clear<NT, 2>(acc);
-                mm<NT, 2>(acc, NK, [&](int i, int k) { return A[min(i, last) * ALD + k]; },
-                          [&](int k, int j) { return Hc[k * FLD + j]; });
-                each<NT, 2>(acc, [&](int row, int col, float v, int, int, int) {
-                    if (row < NP) Tl[row * FLD + col] = row < N ? v : 0.f;
-                });
+            {   // T_l = A H_l
+                f32x4 acc[1][1];
+                clear<1, 1>(acc);
+                mm<1, 1, 8>(acc, NK, [&](int i, int k) { return A[min(fm + i, last) * ALD + k]; },
+                            [&](int k, int j) { return Hc[k * FLD + fn + j]; });
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (frow + r < NP) Tl[(frow + r) * FLD + fcol] = frow + r < N ? acc[0][0][r] : 0.f;
             }
-            wave_sync();
-            {
-                f32x4 acc[NT][2];
-                clear<NT, 2>(acc);
+            __syncthreads();
+            {   // H_{l+1} = relu(T_l W_l) (+ H_l)
+                f32x4 acc[1][1];
+                clear<1, 1>(acc);
                 const float* Wc = Wl + l * XD * FLD;
-                mm<NT, 2>(acc, XD / 4, [&](int i, int k) { return Tl[min(i, last) * FLD + k]; },
-                          [&](int k, int j) { return Wc[k * FLD + j]; });
+                mm<1, 1, 8>(acc, XD / 4, [&](int i, int k) { return Tl[min(fm + i, last) * FLD + k]; },
+                            [&](int k, int j) { return Wc[k * FLD + fn + j]; });
                 unsigned bits = 0;
                 const bool keep = l + 1 < L;                    // the next layer's input
                 float* Hn = keep ? Hs + l * U : nullptr;
                 float* out = (!BWD && !keep) ? a.HL + (size_t)s * N * XD : nullptr;
-                each<NT, 2>(acc, [&](int row, int col, float v, int mt, int nt, int r) {
-                    if (v > 0.f) bits |= 1u << ((mt * 2 + nt) * 4 + r);
-                    if (row < NP && (keep || out)) {
-                        const float h = row < N ? fmaxf(v, 0.f) + (a.skip ? Hc[row * FLD + col] : 0.f) : 0.f;
-                        if (keep) Hn[row * FLD + col] = h;
-                        else if (row < N) out[row * XD + col] = h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = frow + r;
+                    const float v = acc[0][0][r];
+                    if (v > 0.f) bits |= 1u << r;
+                    if (row < NP) {
+                        const float h = row < N ? fmaxf(v, 0.f) + (a.skip ? Hc[row * FLD + fcol] : 0.f) : 0.f;
+                        if (keep) Hn[row * FLD + fcol] = h;
+                        else if (out && row < N) out[row * XD + fcol] = h;
+                        // the top layer's dZ = dH_L where its ReLU is open, straight from here
+                        if (BWD && !keep) dZ[row * FLD + fcol] = (v > 0.f && row < N) ? dH[row * FLD + fcol] : 0.f;
                     }
-                });
+                }
                 mask[l] = bits;
             }
-            wave_sync();
+            __syncthreads();
         }
         if constexpr (BWD) {
-            // ---------------- backward ----------------
-            const float* dg = a.dHL + (size_t)s * N * XD;
-            gather<8>(NP * XD, lane, 64, [&](int idx) { return idx < N * XD ? dg[idx] : 0.f; },
-                      [&](int idx, float v) { dH[(idx >> 5) * FLD + (idx & 31)] = v; });
-            wave_sync();
-            f32x4 dAacc[NT][NT];
-            clear<NT, NT>(dAacc);
+            f32x4 dAacc[1][NTW];
+            clear<1, NTW>(dAacc);
 #pragma unroll
             for (int l = L - 1; l >= 0; --l) {
                 const float* Hc = Hl(l);
                 const float* Tl = T + l * U;
                 const float* Wc = Wl + l * XD * FLD;
-                {   // dZ = dH_{l+1} where the layer's ReLU is open
-                    const unsigned bits = mask[l];
-                    const int l16 = lane & 15, kk = lane >> 4;
-#pragma unroll
-                    for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = mt * 16 + 4 * kk + r, col = nt * 16 + l16;
-                                if (row < NP)
-                                    dZ[row * FLD + col] = ((bits >> ((mt * 2 + nt) * 4 + r)) & 1u) && row < N ? dH[row * FLD + col] : 0.f;
-                            }
-                }
-                wave_sync();
                 // dW_l += T_l^T dZ
-                mm<2, 2>(gW[l], NK, [&](int mi, int k) { return Tl[k * FLD + mi]; }, [&](int k, int j) { return dZ[k * FLD + j]; });
+                if (g_on)
+                    mm<1, GT, 8>(gW[l], NK, [&](int mi, int k) { return Tl[k * FLD + gm + mi]; },
+                                 [&](int k, int j) { return dZ[k * FLD + gn + j]; });
                 {   // dT = dZ W_l^T
-                    f32x4 acc[NT][2];
-                    clear<NT, 2>(acc);
-                    mm<NT, 2>(acc, XD / 4, [&](int i, int k) { return dZ[min(i, last) * FLD + k]; },
-                              [&](int k, int j) { return Wc[j * FLD + k]; });
-                    each<NT, 2>(acc, [&](int row, int col, float v, int, int, int) {
-                        if (row < NP) dT[row * FLD + col] = row < N ? v : 0.f;
-                    });
+                    f32x4 acc[1][1];
+                    clear<1, 1>(acc);
+                    mm<1, 1, 8>(acc, XD / 4, [&](int i, int k) { return dZ[min(fm + i, last) * FLD + k]; },
+                                [&](int k, int j) { return Wc[(fn + j) * FLD + k]; });
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (frow + r < NP) dT[(frow + r) * FLD + fcol] = frow + r < N ? acc[0][0][r] : 0.f;
                 }
-                wave_sync();
+                __syncthreads();
                 // dA += dT H_l^T
-                mm<NT, NT>(dAacc, XD / 4, [&](int i, int k) { return dT[min(i, last) * FLD + k]; },
-                           [&](int k, int j) { return Hc[min(j, last) * FLD + k]; });
-                {   // dH_l = A^T dT (+ dH_{l+1} through the skip connection)
-                    f32x4 acc[NT][2];
-                    clear<NT, 2>(acc);
-                    mm<NT, 2>(acc, NK, [&](int mi, int k) { return A[k * ALD + mi]; }, [&](int k, int j) { return dT[k * FLD + j]; });
-                    each<NT, 2>(acc, [&](int row, int col, float v, int, int, int) {
-                        if (row < N) dH[row * FLD + col] = v + (a.skip ? dH[row * FLD + col] : 0.f);
-                    });
+                if (a_on)
+                    mm<1, NTW, 8>(dAacc, XD / 4, [&](int i, int k) { return dT[min(am + i, last) * FLD + k]; },
+                                  [&](int k, int j) { return Hc[min(an + j, last) * FLD + k]; });
+                {   // dH_l = A^T dT (+ dH_{l+1} through the skip connection); the next layer's dZ right away
+                    f32x4 acc[1][1];
+                    clear<1, 1>(acc);
+                    mm<1, 1, 8>(acc, NK, [&](int mi, int k) { return A[k * ALD + fm + mi]; },
+                                [&](int k, int j) { return dT[k * FLD + fn + j]; });
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = frow + r;
+                        if (row < N) {
+                            const float d = acc[0][0][r] + (a.skip ? dH[row * FLD + fcol] : 0.f);
+                            dH[row * FLD + fcol] = d;
+                            if (l > 0) dZ[row * FLD + fcol] = ((mask[l > 0 ? l - 1 : 0] >> r) & 1u) ? d : 0.f;
+                        }
+                    }
                 }
-                wave_sync();
+                __syncthreads();
             }
             // through the row softmax: dS_ij = A_ij (dA_ij - sum_k dA_ik A_ik)
-            each<NT, NT>(dAacc, [&](int row, int col, float v, int, int, int) {
-                if (row < NP) dA[row * ALD + col] = (row < N && col < N) ? v : 0.f;
-            });
-            wave_sync();
-            if (lane < N) {
-                float* d = dA + lane * ALD;
-                const float* p = A + lane * ALD;
-                float dot = 0.f;
-                for (int j = 0; j < N; ++j) dot = fmaf(d[j], p[j], dot);
-                for (int j = 0; j < N; ++j) d[j] = p[j] * (d[j] - dot);
+            if (a_on)
+                each<1, NTW>(dAacc, [&](int i, int j, float v, int, int, int) {
+                    const int row = am + i, col = an + j;
+                    if (row < NP) dA[row * ALD + col] = (row < N && col < N) ? v : 0.f;
+                });
+            if (embedded) make_G();            // dT's buffer is free again
+            __syncthreads();
+            for (int row = wave * 4 + kq; row < N; row += W * 4) {
+                float* d = dA + row * ALD;
+                const float* p = A + row * ALD;
+                float dv[NT], pv[NT], dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const bool ok = l16 + 16 * j < N;
+                    dv[j] = ok ? d[l16 + 16 * j] : 0.f;
+                    pv[j] = ok ? p[l16 + 16 * j] : 0.f;
+                    dot = fmaf(dv[j], pv[j], dot);
+                }
+                dot = row16_sum(dot);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    if (l16 + 16 * j < N) d[l16 + 16 * j] = pv[j] * (dv[j] - dot);
             }
-            wave_sync();
+            __syncthreads();
             // S = G X^T:  dG = dS X ;  dX += dS^T G        G = X Wa:  dWa += X^T dG ;  dX += dG Wa^T     (gaussian: G = X, dX += dG)
-            if (embedded) make_G();
             float* dG = dZ;
+            f32x4 dx[1][1];
             {
-                f32x4 acc[NT][2];
-                clear<NT, 2>(acc);
-                mm<NT, 2>(acc, NK, [&](int i, int k) { return dA[min(i, last) * ALD + k]; }, [&](int k, int j) { return X[k * FLD + j]; });
-                each<NT, 2>(acc, [&](int row, int col, float v, int, int, int) {
-                    if (row < NP) dG[row * FLD + col] = row < N ? v : 0.f;
-                });
-            }
-            {
-                f32x4 acc[NT][2];
-                clear<NT, 2>(acc);
-                mm<NT, 2>(acc, NK, [&](int mi, int k) { return dA[k * ALD + mi]; }, [&](int k, int j) { return GX[k * FLD + j]; });
-                each<NT, 2>(acc, [&](int row, int col, float v, int, int, int) {
-                    if (row < N) dH[row * FLD + col] += v;
-                });
-            }
-            wave_sync();
-            if (embedded) {
-                mm<2, 2>(gWa, NK, [&](int mi, int k) { return X[k * FLD + mi]; }, [&](int k, int j) { return dG[k * FLD + j]; });
-                f32x4 acc[NT][2];
-                clear<NT, 2>(acc);
-                mm<NT, 2>(acc, XD / 4, [&](int i, int k) { return dG[min(i, last) * FLD + k]; },
-                          [&](int k, int j) { return Wa[j * FLD + k]; });
-                each<NT, 2>(acc, [&](int row, int col, float v, int, int, int) {
-                    if (row < N) dH[row * FLD + col] += v;
-                });
-            } else {
-                for (int idx = lane; idx < N * XD; idx += 64) {
-                    const int r = idx >> 5, c = idx & 31;
-                    dH[r * FLD + c] += dG[r * FLD + c];
+                f32x4 acc[1][1];
+                clear<1, 1>(acc);
+                mm<1, 1, 8>(acc, NK, [&](int i, int k) { return dA[min(fm + i, last) * ALD + k]; },
+                            [&](int k, int j) { return X[k * FLD + fn + j]; });
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (frow + r < NP) dG[(frow + r) * FLD + fcol] = frow + r < N ? acc[0][0][r] : 0.f;
+                clear<1, 1>(dx);
+                mm<1, 1, 8>(dx, NK, [&](int mi, int k) { return dA[k * ALD + fm + mi]; }, [&](int k, int j) { return GX[k * FLD + fn + j]; });
+                if (!embedded) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dx[0][0][r] += acc[0][0][r];
                 }
             }
-            wave_sync();
+            __syncthreads();
+            if (embedded) {
+                if (g_on)
+                    mm<1, GT, 8>(gWa, NK, [&](int mi, int k) { return X[k * FLD + gm + mi]; }, [&](int k, int j) { return dG[k * FLD + gn + j]; });
+                mm<1, 1, 8>(dx, XD / 4, [&](int i, int k) { return dG[min(fm + i, last) * FLD + k]; },
+                            [&](int k, int j) { return Wa[(fn + j) * FLD + k]; });
+            }
             float* dxg = a.dX + (size_t)s * N * XD;
-            for (int idx = lane; idx < N * XD; idx += 64) dxg[idx] = dH[(idx >> 5) * FLD + (idx & 31)];
-            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (frow + r < N) dxg[(frow + r) * XD + fcol] = dx[0][0][r] + dH[(frow + r) * FLD + fcol];
+            __syncthreads();
         }
     }
     if constexpr (BWD) {
-        if (gw < a.total_waves) {
-            float* slab = a.slabs + (size_t)gw * ((embedded ? 1 : 0) + L) * XD * XD;
+        if (g_on) {
+            float* slab = a.slabs + (size_t)blockIdx.x * ((embedded ? 1 : 0) + L) * XD * XD;
             if (embedded) {
-                each<2, 2>(gWa, [&](int row, int col, float v, int, int, int) { slab[row * XD + col] = v; });
+                each<1, GT>(gWa, [&](int i, int j, float v, int, int, int) { slab[(gm + i) * XD + gn + j] = v; });
                 slab += XD * XD;
             }
 #pragma unroll
             for (int l = 0; l < L; ++l)
-                each<2, 2>(gW[l], [&](int row, int col, float v, int, int, int) { slab[l * XD * XD + row * XD + col] = v; });
+                each<1, GT>(gW[l], [&](int i, int j, float v, int, int, int) { slab[l * XD * XD + (gm + i) * XD + gn + j] = v; });
         }
     }
 }
@@ -779,12 +872,18 @@ void plan_rows_job(RowsJob& J, const RglMlp& m, int n_rows, int max_waves) {
     if (m.n_layers == 2 && m.dims[1] == 64 && m.dims[0] <= 32 && m.dims[2] <= 32) {
         const int T0 = (m.dims[0] + 15) / 16, T2 = (m.dims[2] + 15) / 16;
         J.kind = 10 * T0 + T2;
-        J.waves_per_wg = 4;
-        J.n_wgs = (J.n_waves + 3) / 4;
+        J.waves_per_wg = kNarrowWaves;
+        J.n_wgs = (J.n_waves + kNarrowWaves - 1) / kNarrowWaves;
         J.wave_floats = 16 * ((T0 * 16 + 2) + 66 + (T2 * 16 + 2) + 66);
         return;
     }
     J.wave_floats = 16 * J.act_ld + 32 * J.d_ld;
+    if (J.n_tiles <= 1024 && ((size_t)wl + J.wave_floats) * sizeof(float) <= (size_t)rgl::kLdsBytesPerCu - 1024) {
+        J.coop = 1;                             // few tiles: a workgroup per tile (the value head: one row per scene)
+        J.waves_per_wg = 1;                     // LDS slices per workgroup
+        J.n_wgs = J.n_waves;
+        return;
+    }
     const size_t per_wave = (size_t)J.wave_floats * sizeof(float);
     const size_t room = (size_t)rgl::kLdsBytesPerCu - 1024 - (size_t)wl * sizeof(float);
     // two workgroups per CU when they fit (half the LDS each), else one
@@ -807,9 +906,35 @@ int launch_rows_kernel(K kernel, RowsArgs& ra, hipStream_t st) {
     }
     if (lds > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3(wgs), dim3(256), lds, st, ra);
+    hipLaunchKernelGGL(kernel, dim3(wgs), dim3(ra.job[0].kind ? kNarrowWaves * 64 : 256), lds, st, ra);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
+}
+
+// The narrow jobs that share a launch (same kernel kind) get the same number of tiles per wave, chosen so that all their waves are
+// resident at once (2 workgroups of kNarrowWaves waves per CU): a launch in one round with 3 tiles per wave beats 2 tiles per wave
+// plus a second round for the overflow.
+void balance_narrow(RowsJob* const* jobs, int n, int max_waves) {
+    for (int j = 0; j < n; ++j) {
+        if (!jobs[j] || !jobs[j]->kind) continue;
+        bool first_of_kind = true;
+        long tiles = 0;
+        for (int i = 0; i < n; ++i)
+            if (jobs[i] && jobs[i]->kind == jobs[j]->kind) {
+                if (i < j) first_of_kind = false;
+                tiles += jobs[i]->n_tiles;
+            }
+        if (!first_of_kind) continue;
+        long capacity = 256L * 2 * kNarrowWaves;
+        capacity = capacity < max_waves ? capacity : max_waves;
+        const int per_wave = (int)((tiles + capacity - 1) / capacity);
+        for (int i = 0; i < n; ++i)
+            if (jobs[i] && jobs[i]->kind == jobs[j]->kind) {
+                RowsJob& J = *jobs[i];
+                J.n_waves = (J.n_tiles + per_wave - 1) / per_wave;
+                J.n_wgs = (J.n_waves + kNarrowWaves - 1) / kNarrowWaves;
+            }
+    }
 }
 
 // the jobs of one pipeline stage: one launch per kernel kind among them
@@ -836,44 +961,44 @@ int launch_rows(RowsArgs& all, hipStream_t st) {
 }
 
 template <int NT, int L>
-int launch_graph_nl(const GraphArgs& ga, bool bwd, int W, size_t lds, int grid, hipStream_t st) {
+int launch_graph_nl(const GraphArgs& ga, bool bwd, size_t lds, int grid, hipStream_t st) {
     const void* fn = bwd ? reinterpret_cast<const void*>(graph_kernel<NT, L, true>) : reinterpret_cast<const void*>(graph_kernel<NT, L, false>);
     if (lds > 64 * 1024) RGL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (bwd) hipLaunchKernelGGL((graph_kernel<NT, L, true>), dim3(grid), dim3(W * 64), lds, st, ga);
-    else hipLaunchKernelGGL((graph_kernel<NT, L, false>), dim3(grid), dim3(W * 64), lds, st, ga);
+    if (bwd) hipLaunchKernelGGL((graph_kernel<NT, L, true>), dim3(grid), dim3(NT * 128), lds, st, ga);
+    else hipLaunchKernelGGL((graph_kernel<NT, L, false>), dim3(grid), dim3(NT * 128), lds, st, ga);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }
 template <int NT>
-int launch_graph_n(const GraphArgs& ga, int L, bool bwd, int W, size_t lds, int grid, hipStream_t st) {
+int launch_graph_n(const GraphArgs& ga, int L, bool bwd, size_t lds, int grid, hipStream_t st) {
     switch (L) {
-        case 1: return launch_graph_nl<NT, 1>(ga, bwd, W, lds, grid, st);
-        case 2: return launch_graph_nl<NT, 2>(ga, bwd, W, lds, grid, st);
-        default: return launch_graph_nl<NT, 3>(ga, bwd, W, lds, grid, st);
+        case 1: return launch_graph_nl<NT, 1>(ga, bwd, lds, grid, st);
+        case 2: return launch_graph_nl<NT, 2>(ga, bwd, lds, grid, st);
+        default: return launch_graph_nl<NT, 3>(ga, bwd, lds, grid, st);
     }
 }
 
-struct GraphPlan { int W, grid, total_waves; size_t lds; };
+struct GraphPlan { int grid; size_t lds; };
 template <int NT>
 GraphPlan plan_graph_nt(int S, int N, int L) {
-    const size_t wb = (size_t)GraphLds<NT>::weight_floats(L) * 4, pw = (size_t)GraphLds<NT>::wave_floats(N, L) * 4;
-    int W = (int)(((size_t)rgl::kLdsBytesPerCu - wb) / pw);
-    W = W > (NT == 4 ? 2 : 8) ? (NT == 4 ? 2 : 8) : W;
     GraphPlan p{};
-    if (W < 1) return p;
-    // at most one workgroup per CU is resident (its LDS slice is most of the CU's): 256 workgroups, scenes dealt round robin
-    int grid = (S + W - 1) / W;
-    grid = grid > 256 ? 256 : grid;
-    p.W = W; p.grid = grid; p.total_waves = grid * W; p.lds = wb + (size_t)W * pw;
+    p.lds = (size_t)(GraphLds<NT>::weight_floats(L) + GraphLds<NT>::scene_floats(N, L)) * sizeof(float);
+    if (p.lds > (size_t)rgl::kLdsBytesPerCu) return p;
+    // persistent workgroups: as many as are resident at once (LDS, and 32 waves per CU), scenes dealt round robin
+    int per_cu = (int)((size_t)rgl::kLdsBytesPerCu / p.lds);
+    const int by_waves = 32 / (2 * NT);
+    per_cu = per_cu > by_waves ? by_waves : per_cu;
+    const int resident = 256 * per_cu;
+    p.grid = S < resident ? S : resident;
     return p;
 }
 GraphPlan plan_graph(int S, int N, int L) {
     return N <= 16 ? plan_graph_nt<1>(S, N, L) : (N <= 32 ? plan_graph_nt<2>(S, N, L) : plan_graph_nt<4>(S, N, L));
 }
 int launch_graph(const GraphArgs& ga, int L, bool bwd, const GraphPlan& p, hipStream_t st) {
-    if (ga.N <= 16) return launch_graph_n<1>(ga, L, bwd, p.W, p.lds, p.grid, st);
-    if (ga.N <= 32) return launch_graph_n<2>(ga, L, bwd, p.W, p.lds, p.grid, st);
-    return launch_graph_n<4>(ga, L, bwd, p.W, p.lds, p.grid, st);
+    if (ga.N <= 16) return launch_graph_n<1>(ga, L, bwd, p.lds, p.grid, st);
+    if (ga.N <= 32) return launch_graph_n<2>(ga, L, bwd, p.lds, p.grid, st);
+    return launch_graph_n<4>(ga, L, bwd, p.lds, p.grid, st);
 }
 
 int env_int(const char* name, int dflt) {
@@ -906,7 +1031,7 @@ int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
     // hold a scene in LDS (only_choice)
     const int mode = env_int("RGL_BACKWARD_MFMA", -1);
     if (mode == 0) return 1;
-    if (mode != 1 && !only_choice && S < env_int("RGL_BACKWARD_MFMA_MIN", 512)) return 1;
+    if (mode != 1 && !only_choice && S < env_int("RGL_BACKWARD_MFMA_MIN", 256)) return 1;
     const RglGraph& g = *graph;
     const int N = H + 1, L = g.num_layer;
     if (g.x_dim != XD || g.layerwise_graph || L < 1 || L > 3 || N > 64) return 1;
@@ -914,7 +1039,7 @@ int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
     const bool has_v = vh && vh->n_layers > 0, has_m = mh && mh->n_layers > 0;
     const bool embedded = g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN;
     const GraphPlan gp = plan_graph(S, N, L);
-    if (gp.W < 1) return 1;
+    if (gp.grid < 1) return 1;
 
     // gradient vector: w_r | w_h | w_a | Ws | value head | motion head
     const int n_wr = mlp_params(g.w_r), n_wh = mlp_params(g.w_h), n_graph = ((embedded ? 1 : 0) + L) * XD * XD;
@@ -941,11 +1066,17 @@ int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
         plan_rows_job(j_wh, g.w_h, S * H, max_waves);
         if (has_v) plan_rows_job(j_v, *vh, S, max_waves);
         if (has_m) plan_rows_job(j_m, *mh, S * H, max_waves);
+        {   // the launches: (w_r, w_h) forward and backward, (value head, motion head)
+            RowsJob* emb[2] = {&j_wr, &j_wh};
+            RowsJob* heads[2] = {has_v ? &j_v : nullptr, has_m ? &j_m : nullptr};
+            balance_narrow(emb, 2, max_waves);
+            balance_narrow(heads, 2, max_waves);
+        }
         auto slabs_for = [&](RowsJob& J) { J.slabs = (float*)take((size_t)J.n_waves * J.n_params * sizeof(float)); };
         if (!detach_graph) { slabs_for(j_wr); slabs_for(j_wh); }
         if (has_v) slabs_for(j_v);
         if (has_m) slabs_for(j_m);
-        g_slabs = detach_graph ? nullptr : (float*)take((size_t)gp.total_waves * n_graph * sizeof(float));
+        g_slabs = detach_graph ? nullptr : (float*)take((size_t)gp.grid * n_graph * sizeof(float));
         if (used <= workspace_bytes) break;
     }
     if (used > workspace_bytes) return 1;
@@ -968,7 +1099,7 @@ int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
     ga.X = X; ga.dHL = dHL; ga.HL = HL; ga.dX = dX;
     ga.w_a = embedded ? g.w_a : nullptr;
     for (int l = 0; l < L; ++l) ga.Ws[l] = g.Ws[l];
-    ga.slabs = g_slabs; ga.S = S; ga.N = N; ga.skip = g.skip_connection ? 1 : 0; ga.total_waves = gp.total_waves;
+    ga.slabs = g_slabs; ga.S = S; ga.N = N; ga.skip = g.skip_connection ? 1 : 0;
     if (has_v || has_m) {
         const int rc = launch_graph(ga, L, false, gp, st);
         if (rc) return rc;
@@ -1016,7 +1147,7 @@ int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
     };
     range(detach_graph ? nullptr : j_wr.slabs, detach_graph ? 0 : j_wr.n_waves, n_wr, o_wr);
     range(detach_graph ? nullptr : j_wh.slabs, detach_graph ? 0 : j_wh.n_waves, n_wh, o_wh);
-    range(g_slabs, detach_graph ? 0 : gp.total_waves, n_graph, o_graph);
+    range(g_slabs, detach_graph ? 0 : gp.grid, n_graph, o_graph);
     if (has_v) range(j_v.slabs, j_v.n_waves, n_v, o_v);
     if (has_m) range(j_m.slabs, j_m.n_waves, n_m, o_m);
     rr.n_params = n_params;

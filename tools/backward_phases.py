@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-phase cycles of mlp_rows_kernel (debug build: make -C relationalgraphlearning_amd/csrc timing)."""
+"""Per-phase cycles of mlp2_rows_kernel (debug build: make -C relationalgraphlearning_amd/csrc timing)."""
 import ctypes as C
 import os
 import sys
@@ -14,8 +14,8 @@ from relationalgraphlearning_amd import _native as nat  # noqa: E402
 from tests.helpers import make_mprl_policy  # noqa: E402
 from tests.test_gpu_parity import seeded_scenes  # noqa: E402
 
-NAMES = ["weights -> LDS + barrier", "input rows", "forward layers", "output rows / upstream deltas", "relu mask + dW", "db",
-         "delta_in", "d_in rows"]
+NAMES = ["weights -> LDS + barrier", "rows -> LDS, next tile's fetch issued", "layer 0", "layer 1", "output rows / delta1 pass",
+         "dW1, db1, delta0", "dW0, db0", "d_in"]
 
 
 def main():
