@@ -21,6 +21,11 @@ python tools/train_step_time.py --graph 2>/dev/null | grep "^{" > $O/${TAG}_trai
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_tr && rocprofv3 --kernel-trace --stats -d /tmp/prof_tr -o tr -- python $R/tools/train_step_time.py > /dev/null 2>&1; \
   { echo "# $TAG: kernel trace of tools/train_step_time.py (H = 5 / 19, batch 100 / 4096; source revision $HASH)"; echo; \
     python $R/tools/rocpd_summary.py $(find /tmp/prof_tr -name "*results.db" | head -1) | head -24; } > $O/${TAG}_train_step_trace.md )
+# backward pass alone: device time per call by batch size, per-scene kernel (mode 0) against the tile pipeline (mode 1)
+( cd /tmp && export TMPDIR=/tmp; echo "# $TAG: device time of ONE backward call (kernel trace, value estimator and state predictor averaged; source revision $HASH)"; \
+  for H in 5 19; do for B in 100 256 1024 4096; do for M in 0 1; do rm -rf /tmp/prof_bw; \
+    BT_H=$H BT_B=$B BT_MODES=$M rocprofv3 --kernel-trace -d /tmp/prof_bw -o bw -- python $R/tools/backward_time.py > /dev/null 2>&1; \
+    echo -n "H=$H batch=$B RGL_BACKWARD_MFMA=$M: "; python $R/tools/backward_sum.py $(find /tmp/prof_bw -name "*results.db" | head -1); done; done; done ) > $O/${TAG}_backward_by_batch.txt 2>&1
 { python tools/gcn_trace.py; python tools/episodes.py; } > $O/${TAG}_path_g_and_episodes.txt 2>&1
 python tools/pcie_inclusive.py > $O/${TAG}_pcie_inclusive.txt 2>&1
 tail -5 $O/${TAG}_other_configs.log; cat $O/${TAG}_share_regime.txt | tail -14; cat $O/${TAG}_train_step.jsonl | cut -c1-200; cat $O/${TAG}_path_g_and_episodes.txt | tail -8; head -c 600 $O/${TAG}_bench_default.json

@@ -83,8 +83,9 @@ def main():
                               "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK / 1e12,
                                            "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / PEAK,
                                            "flops_per_step": flops,
-                                           "note": "forwards on the one-wave-per-scene MFMA kernel, backward on the VALU kernel "
-                                                   "(rgl_scene_backward_kernel); at batch 100 the step is launch / host bound"}}))
+                                           "note": "forwards on the one-wave-per-scene MFMA kernel; backward: the per-scene VALU kernel "
+                                                   "below 256 scenes of an eager step (launch / host bound there), the MFMA tile "
+                                                   "pipeline of rgl_backward_mfma.hip from 256 scenes and in every captured step"}}))
 
 
 if __name__ == "__main__":
