@@ -54,6 +54,7 @@ __device__ __forceinline__ void mm_steps(f32x4 (&acc)[MT][NTL], int ks0, FA& fa,
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = mfma4(av[u][mt], bv[u][nt], acc[mt][nt]);
+    load_fence();            // the next batch's loads stay behind this batch (hoisting them all costs hundreds of VGPRs)
 }
 template <int MT, int NTL, int U, class FA, class FB>
 __device__ __forceinline__ void mm_from(f32x4 (&acc)[MT][NTL], int& ks, int ksteps, FA& fa, FB& fb) {
@@ -308,11 +309,11 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs a) {
 // shapes are template parameters (T0 / T2 = 16-wide tiles of the input / output): every k loop is unrolled with its operand loads
 // batched, and the weight gradients of BOTH layers stay in MFMA accumulators over all tiles of the wave -- (4 T0 + 4 T2) tiles, 48
 // registers -- so a wave touches its slab once, at the end.
-constexpr int kNarrowWaves = 4;       // waves per workgroup of mlp2_rows_kernel: two workgroups fit a CU (LDS, and ~200 VGPRs per lane)
+constexpr int kNarrowWaves = 4;       // waves per workgroup of mlp2_rows_kernel: three workgroups fit a CU (40 KB of LDS each, <= 170 VGPRs)
 template <int T0, int T2>
-__global__ __launch_bounds__(kNarrowWaves * 64) void mlp2_rows_kernel(const RowsArgs a) {
+__global__ __launch_bounds__(kNarrowWaves * 64, 3) void mlp2_rows_kernel(const RowsArgs a) {
     constexpr int HT = 4, IN_LD = T0 * 16 + 2, HLD = 66, OLD = T2 * 16 + 2;
-    constexpr int kWaveFloats = 16 * (IN_LD + HLD + OLD + HLD);
+    constexpr int kWaveFloats = 16 * (IN_LD + HLD + OLD);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15;
     const int ji = (a.n_jobs > 1 && (int)blockIdx.x >= a.job[1].wg_begin) ? 1 : 0;
@@ -326,11 +327,12 @@ __global__ __launch_bounds__(kNarrowWaves * 64) void mlp2_rows_kernel(const Rows
     const float* W1 = lds + J.w_lds[1];
     const float* b0 = lds + J.b_lds[0];
     const float* b1 = lds + J.b_lds[1];
-    const int wld0 = J.w_ld[0], wld1 = J.w_ld[1];
+    constexpr int wld0 = 65, wld1 = T2 * 16 + 1;      // compile-time row strides of the two weight matrices in LDS (plan_rows_job)
     float* xin = lds + J.weight_floats + wave * kWaveFloats;      // [16][IN_LD]   input rows, zero beyond `in`; later the input deltas
     float* hid = xin + 16 * IN_LD;                                // [16][HLD]     hidden activations
     float* d1 = hid + 16 * HLD;                                   // [16][OLD]     outputs, then their deltas (zero beyond `out`)
-    float* d0 = d1 + 16 * OLD;                                    // [16][HLD]     hidden deltas
+    float* d0 = hid;                                              // the hidden deltas replace the hidden activations in place (each
+                                                                  // element is read -- its ReLU mask -- and written by the same lane)
     const bool last_relu = m.last_relu != 0;
     f32x4 gW0[HT][T0], gW1[T2][HT];
     clear<HT, T0>(gW0);
@@ -353,21 +355,26 @@ __global__ __launch_bounds__(kNarrowWaves * 64) void mlp2_rows_kernel(const Rows
         }
     };
     fetch(on ? w : J.n_tiles);
-    {   // both layers' weights and biases -> LDS: ONE batch of loads per thread (2.4 k floats over 256 threads), then the stores
-        constexpr int o0 = 64;
-        const int n0 = in * o0, n1 = o0 * out, nb = n0 + n1, total = nb + o0 + out;
+    {   // both layers' weights and biases -> LDS, padded with zeros to whole tiles (rows of W0 beyond `in`, columns of W1 / b1 beyond
+        // `out`): the k loops then need neither guards nor clamps, and every LDS address is a base register plus a constant
+        constexpr int n0 = T0 * 16 * 64, n1 = 64 * T2 * 16, nb = n0 + n1, total = nb + 64 + T2 * 16;
         const float* __restrict__ g0 = m.weight[0];
         const float* __restrict__ g1 = m.weight[1];
         const float* __restrict__ gb0p = m.bias[0];
         const float* __restrict__ gb1p = m.bias[1];
-        gather<10>(total, threadIdx.x, kNarrowWaves * 64,
-                   [&](int idx) { return idx < n0 ? g0[idx] : (idx < nb ? g1[idx - n0] : (idx < nb + o0 ? gb0p[idx - nb] : gb1p[idx - nb - o0])); },
-                   [&](int idx, float v) {
-                       if (idx < n0) { const int k = idx / o0; lds[J.w_lds[0] + k * wld0 + idx - k * o0] = v; }
-                       else if (idx < nb) { const int j = idx - n0, k = j / out; lds[J.w_lds[1] + k * wld1 + j - k * out] = v; }
-                       else if (idx < nb + o0) lds[J.b_lds[0] + idx - nb] = v;
-                       else lds[J.b_lds[1] + idx - nb - o0] = v;
-                   });
+        gather<7>(total, threadIdx.x, kNarrowWaves * 64,
+                  [&](int idx) {
+                      if (idx < n0) return (idx >> 6) < in ? g0[idx] : 0.f;
+                      if (idx < nb) { const int j = idx - n0, k = j / (T2 * 16), c = j % (T2 * 16); return c < out ? g1[k * out + c] : 0.f; }
+                      if (idx < nb + 64) return gb0p[idx - nb];
+                      return idx - nb - 64 < out ? gb1p[idx - nb - 64] : 0.f;
+                  },
+                  [&](int idx, float v) {
+                      if (idx < n0) lds[J.w_lds[0] + (idx >> 6) * wld0 + (idx & 63)] = v;
+                      else if (idx < nb) { const int j = idx - n0; lds[J.w_lds[1] + (j / (T2 * 16)) * wld1 + j % (T2 * 16)] = v; }
+                      else if (idx < nb + 64) lds[J.b_lds[0] + idx - nb] = v;
+                      else lds[J.b_lds[1] + idx - nb - 64] = v;
+                  });
     }
     __syncthreads();
     PHASE_MARK(0);
@@ -391,8 +398,8 @@ __global__ __launch_bounds__(kNarrowWaves * 64) void mlp2_rows_kernel(const Rows
                 const float bv = b0[nt * 16 + l16];
                 acc[0][nt] = f32x4{bv, bv, bv, bv};
             }
-            mm<1, HT, T0 * 4>(acc, T0 * 4, [&](int row, int k) { return xin[row * IN_LD + k]; },
-                              [&](int k, int c) { return W0[min(k, in - 1) * wld0 + c]; });
+            mm<1, HT, 4>(acc, T0 * 4, [&](int row, int k) { return xin[row * IN_LD + k]; },
+                              [&](int k, int c) { return W0[k * wld0 + c]; });
             each<1, HT>(acc, [&](int row, int c, float v, int, int, int) { hid[row * HLD + c] = fmaxf(v, 0.f); });
         }
         wave_sync();
@@ -402,11 +409,11 @@ __global__ __launch_bounds__(kNarrowWaves * 64) void mlp2_rows_kernel(const Rows
 #pragma unroll
             for (int nt = 0; nt < T2; ++nt) {
                 const int col = nt * 16 + l16;
-                const float bv = col < out ? b1[col] : 0.f;
+                const float bv = b1[col];
                 acc[0][nt] = f32x4{bv, bv, bv, bv};
             }
-            mm<1, T2, 8>(acc, 16, [&](int row, int k) { return hid[row * HLD + k]; },
-                         [&](int k, int c) { return W1[k * wld1 + min(c, out - 1)]; });
+            mm<1, T2, 4>(acc, 16, [&](int row, int k) { return hid[row * HLD + k]; },
+                         [&](int k, int c) { return W1[k * wld1 + c]; });
             each<1, T2>(acc, [&](int row, int c, float v, int, int, int) { d1[row * OLD + c] = last_relu ? fmaxf(v, 0.f) : v; });
         }
         wave_sync();
@@ -436,8 +443,8 @@ __global__ __launch_bounds__(kNarrowWaves * 64) void mlp2_rows_kernel(const Rows
         {   // delta0 = (delta1 W1^T) where the hidden ReLU is open
             f32x4 acc[1][HT];
             clear<1, HT>(acc);
-            mm<1, HT, T2 * 4>(acc, T2 * 4, [&](int row, int k) { return d1[row * OLD + k]; },
-                              [&](int k, int c) { return W1[c * wld1 + min(k, out - 1)]; });
+            mm<1, HT, 4>(acc, T2 * 4, [&](int row, int k) { return d1[row * OLD + k]; },
+                              [&](int k, int c) { return W1[c * wld1 + k]; });
             each<1, HT>(acc, [&](int row, int c, float v, int, int, int) { d0[row * HLD + c] = hid[row * HLD + c] > 0.f ? v : 0.f; });
         }
         wave_sync();
@@ -450,8 +457,8 @@ __global__ __launch_bounds__(kNarrowWaves * 64) void mlp2_rows_kernel(const Rows
         if (J.need_din) {
             f32x4 acc[1][T0];
             clear<1, T0>(acc);
-            mm<1, T0, 8>(acc, 16, [&](int row, int k) { return d0[row * HLD + k]; },
-                         [&](int k, int c) { return W0[min(c, in - 1) * wld0 + k]; });
+            mm<1, T0, 4>(acc, 16, [&](int row, int k) { return d0[row * HLD + k]; },
+                         [&](int k, int c) { return W0[c * wld0 + k]; });
             wave_sync();                          // every lane has read x for dW0
             each<1, T0>(acc, [&](int row, int c, float v, int, int, int) { xin[row * IN_LD + c] = v; });
             wave_sync();
@@ -574,19 +581,32 @@ __global__ __launch_bounds__(NT * 128) void graph_kernel(const GraphArgs a) {
     clear<1, GT>(gWa);
 #pragma unroll
     for (int l = 0; l < L; ++l) clear<1, GT>(gW[l]);
+    // X (and the upstream gradient) of a scene are fetched into registers one scene ahead: <= 4 elements per thread
+    float xp[4], dp[4];
+    auto prefetch = [&](int s) {
+        const bool ok = s < a.S;
+        const float* Xg = a.X + (size_t)(ok ? s : 0) * N * XD;
+        const float* dg = BWD ? a.dHL + (size_t)(ok ? s : 0) * N * XD : nullptr;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = threadIdx.x + u * W * 64;
+            xp[u] = (ok && idx < N * XD) ? Xg[idx] : 0.f;
+            if constexpr (BWD) dp[u] = (ok && idx < N * XD) ? dg[idx] : 0.f;
+        }
+    };
+    prefetch(blockIdx.x);
     __syncthreads();
 
     for (int s = blockIdx.x; s < a.S; s += gridDim.x) {
-        {   // X (and the upstream gradient) of the scene; rows N .. NP-1 zero
-            const float* Xg = a.X + (size_t)s * N * XD;
-            gather<4>(NP * XD, threadIdx.x, W * 64, [&](int idx) { return idx < N * XD ? Xg[idx] : 0.f; },
-                      [&](int idx, float v) { X[(idx >> 5) * FLD + (idx & 31)] = v; });
-            if constexpr (BWD) {
-                const float* dg = a.dHL + (size_t)s * N * XD;
-                gather<4>(NP * XD, threadIdx.x, W * 64, [&](int idx) { return idx < N * XD ? dg[idx] : 0.f; },
-                          [&](int idx, float v) { dH[(idx >> 5) * FLD + (idx & 31)] = v; });
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {      // rows N .. NP-1 zero
+            const int idx = threadIdx.x + u * W * 64;
+            if (idx < NP * XD) {
+                X[(idx >> 5) * FLD + (idx & 31)] = xp[u];
+                if constexpr (BWD) dH[(idx >> 5) * FLD + (idx & 31)] = dp[u];
             }
         }
+        prefetch(s + gridDim.x);
         __syncthreads();
         float* G = dT;                 // X Wa (embedded_gaussian): lives in dT's buffer until the backward sweep needs that
         auto make_G = [&]() {
@@ -872,9 +892,13 @@ void plan_rows_job(RowsJob& J, const RglMlp& m, int n_rows, int max_waves) {
     if (m.n_layers == 2 && m.dims[1] == 64 && m.dims[0] <= 32 && m.dims[2] <= 32) {
         const int T0 = (m.dims[0] + 15) / 16, T2 = (m.dims[2] + 15) / 16;
         J.kind = 10 * T0 + T2;
+        J.w_ld[0] = 65; J.w_ld[1] = T2 * 16 + 1;           // the strides mlp2_rows_kernel<T0, T2> is compiled for
+        J.w_lds[0] = 0; J.b_lds[0] = (T0 * 16 * 65 + 3) & ~3;        // W0 padded to T0 * 16 rows, W1 / b1 to T2 * 16 columns
+        J.w_lds[1] = J.b_lds[0] + 64; J.b_lds[1] = J.w_lds[1] + ((64 * J.w_ld[1] + 3) & ~3);
+        J.weight_floats = J.b_lds[1] + 32;
         J.waves_per_wg = kNarrowWaves;
         J.n_wgs = (J.n_waves + kNarrowWaves - 1) / kNarrowWaves;
-        J.wave_floats = 16 * ((T0 * 16 + 2) + 66 + (T2 * 16 + 2) + 66);
+        J.wave_floats = 16 * ((T0 * 16 + 2) + 66 + (T2 * 16 + 2));
         return;
     }
     J.wave_floats = 16 * J.act_ld + 32 * J.d_ld;
@@ -912,7 +936,7 @@ int launch_rows_kernel(K kernel, RowsArgs& ra, hipStream_t st) {
 }
 
 // The narrow jobs that share a launch (same kernel kind) get the same number of tiles per wave, chosen so that all their waves are
-// resident at once (2 workgroups of kNarrowWaves waves per CU): a launch in one round with 3 tiles per wave beats 2 tiles per wave
+// resident at once (3 workgroups of kNarrowWaves waves per CU): a launch in one round with 3 tiles per wave beats 2 tiles per wave
 // plus a second round for the overflow.
 void balance_narrow(RowsJob* const* jobs, int n, int max_waves) {
     for (int j = 0; j < n; ++j) {
@@ -925,7 +949,7 @@ void balance_narrow(RowsJob* const* jobs, int n, int max_waves) {
                 tiles += jobs[i]->n_tiles;
             }
         if (!first_of_kind) continue;
-        long capacity = 256L * 2 * kNarrowWaves;
+        long capacity = 256L * 3 * kNarrowWaves;
         capacity = capacity < max_waves ? capacity : max_waves;
         const int per_wave = (int)((tiles + capacity - 1) / capacity);
         for (int i = 0; i < n; ++i)
