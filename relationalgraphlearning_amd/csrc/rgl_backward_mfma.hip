@@ -540,7 +540,7 @@ struct GraphLds {
 // four -- with a workgroup barrier between phases, and several workgroups per CU overlap each other's barriers.  The weight
 // gradients stay in the accumulators of the waves that own their tiles over all scenes of the workgroup (one slab per workgroup).
 template <int NT, int L, bool BWD>
-__global__ __launch_bounds__(NT * 128) void graph_kernel(const GraphArgs a) {
+__global__ __launch_bounds__(NT * 128, NT == 2 ? 4 : (NT == 1 ? 3 : 2)) void graph_kernel(const GraphArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int ALD = GraphLds<NT>::ALD;
     constexpr int W = 2 * NT;                        // waves
