@@ -488,17 +488,17 @@ __global__ __launch_bounds__(kNarrowWaves * 64, 3) void mlp2_rows_kernel(const R
 // ------------------------------------------------------------------------------------------------
 // the graph block: one workgroup per scene
 // ------------------------------------------------------------------------------------------------
-constexpr int FLD = 34;          // row stride of the 32-wide node-feature arrays (row-indexed A-operand reads hit 32 distinct banks)
-
 struct GraphArgs {
-    const float* X;              // [S][N][32]
-    const float* dHL;            // [S][N][32]   (backward)
-    float* HL;                   // [S][N][32]   (forward)
-    float* dX;                   // [S][N][32]   (backward)
-    const float* w_a;            // [32][32] or null (gaussian: S = X X^T)
+    const float* Xr;             // [S][X]            embedded robot rows
+    const float* Xh;             // [S / spc][H][X]   embedded human rows; the spc sibling scenes of a rollout share their crowd
+    const float* dHL;            // [S][N][X]   (backward)
+    float* HL;                   // [S][N][X], or [S][X] (row 0 only: hl_row0)   (forward)
+    float* dXr;                  // [S][X]      (backward)
+    float* dXh;                  // [S][H][X]   (backward)
+    const float* w_a;            // [X][X] or null (gaussian: S = X X^T)
     const float* Ws[3];
-    float* slabs;                // [workgroups][(has w_a + L) * 1024]
-    int S, N, skip;
+    float* slabs;                // [workgroups][(has w_a + L) * X * X]
+    int S, N, skip, spc, hl_row0;
 };
 
 // sum / max over the 16 lanes of a DPP row, every lane gets it
@@ -521,77 +521,82 @@ __device__ __forceinline__ float row16_maxf(float x) {
     return x;
 }
 
-// LDS of a workgroup: weights  Wa | W_0 .. W_{L-1}  ([32][FLD] each), then the scene's
-//   X, dH, dZ, dT, T_0 .. T_{L-1}, H_1 .. H_{L-1}   ([NP][FLD], NP = N rounded up to 4: the padding rows stay zero, so node-indexed
-//   k loops need no guards)   and   A, dA   ([NP][ALD]).
-template <int NT>
+// LDS of a workgroup: weights  Wa | W_0 .. W_{L-1}  ([X][FLD] each, FLD = X + 2: row-indexed A-operand reads hit 32 distinct banks),
+// then the scene's   X, dH, dZ, dT, T_0 .. T_{L-1}, H_1 .. H_{L-1}   ([NP][FLD], NP = N rounded up to 4: the padding rows stay zero,
+// so node-indexed k loops need no guards)   and   A, dA   ([NP][ALD]).  A forward-only launch has no dH, dZ, dA.
+template <int NT, int XT>
 struct GraphLds {
-    static constexpr int ALD = NT * 16 + 2;
-    static __host__ __device__ int scene_floats(int N, int L) {
+    static constexpr int XW = XT * 16, FLD = XW + 2, ALD = NT * 16 + 2;
+    static __host__ __device__ int scene_floats(int N, int L, bool bwd) {
         const int NP = (N + 3) & ~3;
-        return (4 + L + (L - 1)) * NP * FLD + 2 * NP * ALD;
+        return ((bwd ? 4 : 2) + L + (L - 1)) * NP * FLD + (bwd ? 2 : 1) * NP * ALD;
     }
-    static __host__ __device__ int weight_floats(int L) { return (1 + L) * XD * FLD; }
+    static __host__ __device__ int weight_floats(int L) { return (1 + L) * XW * FLD; }
 };
 
 // A scene is a chain of ~20 small products (8 MFMAs per 16 x 16 tile each), every one needing the whole result of the one before:
 // a wave per scene spends its time in LDS round trips.  So the 2 NT waves of a workgroup share ONE scene: each product's output tiles
-// are dealt to the waves -- an [N][32] result has NT x 2 tiles, one per wave; [N][N] results NT x NT; the [32][32] weight gradients
-// four -- with a workgroup barrier between phases, and several workgroups per CU overlap each other's barriers.  The weight
-// gradients stay in the accumulators of the waves that own their tiles over all scenes of the workgroup (one slab per workgroup).
-template <int NT, int L, bool BWD>
-__global__ __launch_bounds__(NT * 128, NT == 2 ? 4 : (NT == 1 ? 3 : 2)) void graph_kernel(const GraphArgs a) {
+// are dealt to the waves -- an [N][X] result has NT x XT tiles (X = 16 XT features: 32 shipped, 64 supported), a 1 x XT/2 block per
+// wave; [N][N] results NT x NT; the [X][X] weight gradients XT x XT over four waves -- with a workgroup barrier between phases, and
+// several workgroups per CU overlap each other's barriers.  The weight gradients stay in the accumulators of the waves that own
+// their tiles over all scenes of the workgroup (one slab per workgroup).
+template <int NT, int XT, int L, bool BWD>
+__global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 : 2)) void graph_kernel(const GraphArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int ALD = GraphLds<NT>::ALD;
+    using Lds = GraphLds<NT, XT>;
+    constexpr int XW = Lds::XW, FLD = Lds::FLD, ALD = Lds::ALD;
     constexpr int W = 2 * NT;                        // waves
+    constexpr int XTW = XT / 2;                      // column tiles of an [N][X] result per wave
     constexpr int NTW = NT >= 2 ? NT / 2 : 1;        // column tiles of an [N][N] result per wave
-    constexpr int GT = W >= 4 ? 1 : 2;               // column tiles of a [32][32] result per wave
+    constexpr int GM = XT / 2, GN = W >= 4 ? XT / 2 : XT;        // this wave's block of an [X][X] result, in tiles
+    constexpr int PF = XW / 8;                       // elements per thread of a scene's [NP][X] rows (NP X / 64 W <= X / 8)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, kq = lane >> 4;
     const int N = a.N, NP = (N + 3) & ~3, NK = NP >> 2, last = NP - 1;
     const bool embedded = a.w_a != nullptr;
     float* Wa = lds;
-    float* Wl = lds + XD * FLD;
-    for (int idx = threadIdx.x; idx < XD * XD; idx += W * 64) {
-        const int k = idx >> 5, c = idx & 31;
+    float* Wl = lds + XW * FLD;
+    for (int idx = threadIdx.x; idx < XW * XW; idx += W * 64) {
+        const int k = idx / XW, c = idx % XW;
         Wa[k * FLD + c] = embedded ? a.w_a[idx] : 0.f;
 #pragma unroll
-        for (int l = 0; l < L; ++l) Wl[l * XD * FLD + k * FLD + c] = a.Ws[l][idx];
+        for (int l = 0; l < L; ++l) Wl[l * XW * FLD + k * FLD + c] = a.Ws[l][idx];
     }
-    float* base = lds + GraphLds<NT>::weight_floats(L);
+    float* base = lds + Lds::weight_floats(L);
     const int U = NP * FLD;
     float* X = base;
-    float* dH = X + U;
-    float* dZ = dH + U;
-    float* dT = dZ + U;
+    float* dT = X + U;                 // G = X Wa lives here in the forward sweep
     float* T = dT + U;                 // [L]
     float* Hs = T + L * U;             // [L - 1]: H_1 ..
     float* A = Hs + (L - 1) * U;
-    float* dA = A + NP * ALD;
+    float* dA = A + NP * ALD;          // backward only from here
+    float* dH = dA + NP * ALD;
+    float* dZ = dH + U;
     auto Hl = [&](int l) { return l == 0 ? X : Hs + (l - 1) * U; };
-    // this wave's tile of an [N][32] result, its block of an [N][N] result, its block of a [32][32] result
-    const int fm = (wave >> 1) * 16, fn = (wave & 1) * 16;
+    // this wave's block of an [N][X] result, of an [N][N] result, of an [X][X] result
+    const int fm = (wave >> 1) * 16, fn = (wave & 1) * XTW * 16;
     const int am = fm, an = (wave & 1) * NTW * 16;
     const bool a_on = (wave & 1) * NTW < NT;
-    const int gm = (W >= 4 ? (wave >> 1) : wave) * 16, gn = W >= 4 ? (wave & 1) * 16 : 0;
+    const int gm = (W >= 4 ? (wave >> 1) : wave) * GM * 16, gn = W >= 4 ? (wave & 1) * GN * 16 : 0;
     const bool g_on = W >= 4 ? wave < 4 : true;
-    // element r of this lane in its [N][32] tile: row fm + 4 kq + r, column fn + l16
-    const int frow = fm + 4 * kq, fcol = fn + l16;
+    const int frow = fm + 4 * kq;      // element r of this lane in a tile of its [N][X] block: row frow + r, column fn + 16 nt + l16
 
-    f32x4 gWa[1][GT], gW[L][1][GT];
-    clear<1, GT>(gWa);
+    f32x4 gWa[GM][GN], gW[L][GM][GN];
+    clear<GM, GN>(gWa);
 #pragma unroll
-    for (int l = 0; l < L; ++l) clear<1, GT>(gW[l]);
-    // X (and the upstream gradient) of a scene are fetched into registers one scene ahead: <= 4 elements per thread
-    float xp[4], dp[4];
+    for (int l = 0; l < L; ++l) clear<GM, GN>(gW[l]);
+    // X (and the upstream gradient) of a scene are fetched into registers one scene ahead
+    float xp[PF], dp[PF];
     auto prefetch = [&](int s) {
         const bool ok = s < a.S;
-        const float* Xg = a.X + (size_t)(ok ? s : 0) * N * XD;
-        const float* dg = BWD ? a.dHL + (size_t)(ok ? s : 0) * N * XD : nullptr;
+        const int sc = ok ? s : 0;
+        const float* xr = a.Xr + (size_t)sc * XW;
+        const float* xh = a.Xh + (size_t)(sc / a.spc) * (N - 1) * XW - XW;      // row i >= 1 at xh + i * XW
+        const float* dg = BWD ? a.dHL + (size_t)sc * N * XW : nullptr;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < PF; ++u) {
             const int idx = threadIdx.x + u * W * 64;
-            xp[u] = (ok && idx < N * XD) ? Xg[idx] : 0.f;
-            if constexpr (BWD) dp[u] = (ok && idx < N * XD) ? dg[idx] : 0.f;
+            xp[u] = (ok && idx < N * XW) ? (idx < XW ? xr[idx] : xh[idx]) : 0.f;
+            if constexpr (BWD) dp[u] = (ok && idx < N * XW) ? dg[idx] : 0.f;
         }
     };
     prefetch(blockIdx.x);
@@ -599,24 +604,30 @@ __global__ __launch_bounds__(NT * 128, NT == 2 ? 4 : (NT == 1 ? 3 : 2)) void gra
 
     for (int s = blockIdx.x; s < a.S; s += gridDim.x) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {      // rows N .. NP-1 zero
+        for (int u = 0; u < PF; ++u) {      // rows N .. NP-1 zero
             const int idx = threadIdx.x + u * W * 64;
-            if (idx < NP * XD) {
-                X[(idx >> 5) * FLD + (idx & 31)] = xp[u];
-                if constexpr (BWD) dH[(idx >> 5) * FLD + (idx & 31)] = dp[u];
+            if (idx < NP * XW) {
+                X[(idx / XW) * FLD + idx % XW] = xp[u];
+                if constexpr (BWD) dH[(idx / XW) * FLD + idx % XW] = dp[u];
             }
         }
         prefetch(s + gridDim.x);
         __syncthreads();
-        float* G = dT;                 // X Wa (embedded_gaussian): lives in dT's buffer until the backward sweep needs that
-        auto make_G = [&]() {
-            f32x4 acc[1][1];
-            clear<1, 1>(acc);
-            mm<1, 1, 8>(acc, XD / 4, [&](int i, int k) { return X[min(fm + i, last) * FLD + k]; },
-                        [&](int k, int j) { return Wa[k * FLD + fn + j]; });
+        float* G = dT;
+        // out[row][fn ..] of this wave's [N][X] block = v, zero in the padding rows
+        auto put = [&](float* out, const f32x4 (&acc)[1][XTW]) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (frow + r < NP) G[(frow + r) * FLD + fcol] = frow + r < N ? acc[0][0][r] : 0.f;
+            for (int nt = 0; nt < XTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (frow + r < NP) out[(frow + r) * FLD + fn + nt * 16 + l16] = frow + r < N ? acc[0][nt][r] : 0.f;
+        };
+        auto make_G = [&]() {
+            f32x4 acc[1][XTW];
+            clear<1, XTW>(acc);
+            mm<1, XTW, 8>(acc, XW / 4, [&](int i, int k) { return X[min(fm + i, last) * FLD + k]; },
+                          [&](int k, int j) { return Wa[k * FLD + fn + j]; });
+            put(G, acc);
         };
         if (embedded) {
             make_G();
@@ -626,7 +637,7 @@ __global__ __launch_bounds__(NT * 128, NT == 2 ? 4 : (NT == 1 ? 3 : 2)) void gra
         if (a_on) {   // S = G X^T   (graph_model.py:64-69)
             f32x4 acc[1][NTW];
             clear<1, NTW>(acc);
-            mm<1, NTW, 8>(acc, XD / 4, [&](int i, int k) { return GX[min(am + i, last) * FLD + k]; },
+            mm<1, NTW, 8>(acc, XW / 4, [&](int i, int k) { return GX[min(am + i, last) * FLD + k]; },
                           [&](int k, int j) { return X[min(an + j, last) * FLD + k]; });
             each<1, NTW>(acc, [&](int i, int j, float v, int, int, int) {
                 const int row = am + i, col = an + j;
@@ -662,38 +673,39 @@ __global__ __launch_bounds__(NT * 128, NT == 2 ? 4 : (NT == 1 ? 3 : 2)) void gra
             const float* Hc = Hl(l);
             float* Tl = T + l * U;
             {   // T_l = A H_l
-                f32x4 acc[1][1];
-                clear<1, 1>(acc);
-                mm<1, 1, 8>(acc, NK, [&](int i, int k) { return A[min(fm + i, last) * ALD + k]; },
-                            [&](int k, int j) { return Hc[k * FLD + fn + j]; });
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (frow + r < NP) Tl[(frow + r) * FLD + fcol] = frow + r < N ? acc[0][0][r] : 0.f;
+                f32x4 acc[1][XTW];
+                clear<1, XTW>(acc);
+                mm<1, XTW, 8>(acc, NK, [&](int i, int k) { return A[min(fm + i, last) * ALD + k]; },
+                              [&](int k, int j) { return Hc[k * FLD + fn + j]; });
+                put(Tl, acc);
             }
             __syncthreads();
             {   // H_{l+1} = relu(T_l W_l) (+ H_l)
-                f32x4 acc[1][1];
-                clear<1, 1>(acc);
-                const float* Wc = Wl + l * XD * FLD;
-                mm<1, 1, 8>(acc, XD / 4, [&](int i, int k) { return Tl[min(fm + i, last) * FLD + k]; },
-                            [&](int k, int j) { return Wc[k * FLD + fn + j]; });
+                f32x4 acc[1][XTW];
+                clear<1, XTW>(acc);
+                const float* Wc = Wl + l * XW * FLD;
+                mm<1, XTW, 8>(acc, XW / 4, [&](int i, int k) { return Tl[min(fm + i, last) * FLD + k]; },
+                              [&](int k, int j) { return Wc[k * FLD + fn + j]; });
                 unsigned bits = 0;
                 const bool keep = l + 1 < L;                    // the next layer's input
                 float* Hn = keep ? Hs + l * U : nullptr;
-                float* out = (!BWD && !keep) ? a.HL + (size_t)s * N * XD : nullptr;
+                float* out = (!BWD && !keep) ? (a.hl_row0 ? a.HL + (size_t)s * XW : a.HL + (size_t)s * N * XW) : nullptr;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = frow + r;
-                    const float v = acc[0][0][r];
-                    if (v > 0.f) bits |= 1u << r;
-                    if (row < NP) {
-                        const float h = row < N ? fmaxf(v, 0.f) + (a.skip ? Hc[row * FLD + fcol] : 0.f) : 0.f;
-                        if (keep) Hn[row * FLD + fcol] = h;
-                        else if (out && row < N) out[row * XD + fcol] = h;
-                        // the top layer's dZ = dH_L where its ReLU is open, straight from here
-                        if (BWD && !keep) dZ[row * FLD + fcol] = (v > 0.f && row < N) ? dH[row * FLD + fcol] : 0.f;
+                for (int nt = 0; nt < XTW; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = frow + r, col = fn + nt * 16 + l16;
+                        const float v = acc[0][nt][r];
+                        if (v > 0.f) bits |= 1u << (nt * 4 + r);
+                        if (row < NP) {
+                            const float h = row < N ? fmaxf(v, 0.f) + (a.skip ? Hc[row * FLD + col] : 0.f) : 0.f;
+                            if (keep) Hn[row * FLD + col] = h;
+                            else if (out && row < (a.hl_row0 ? 1 : N)) out[row * XW + col] = h;
+                            // the top layer's dZ = dH_L where its ReLU is open, straight from here
+                            if constexpr (BWD)
+                                if (!keep) dZ[row * FLD + col] = (v > 0.f && row < N) ? dH[row * FLD + col] : 0.f;
+                        }
                     }
-                }
                 mask[l] = bits;
             }
             __syncthreads();
@@ -705,39 +717,39 @@ __global__ __launch_bounds__(NT * 128, NT == 2 ? 4 : (NT == 1 ? 3 : 2)) void gra
             for (int l = L - 1; l >= 0; --l) {
                 const float* Hc = Hl(l);
                 const float* Tl = T + l * U;
-                const float* Wc = Wl + l * XD * FLD;
+                const float* Wc = Wl + l * XW * FLD;
                 // dW_l += T_l^T dZ
                 if (g_on)
-                    mm<1, GT, 8>(gW[l], NK, [&](int mi, int k) { return Tl[k * FLD + gm + mi]; },
-                                 [&](int k, int j) { return dZ[k * FLD + gn + j]; });
+                    mm<GM, GN, 8>(gW[l], NK, [&](int mi, int k) { return Tl[k * FLD + gm + mi]; },
+                                  [&](int k, int j) { return dZ[k * FLD + gn + j]; });
                 {   // dT = dZ W_l^T
-                    f32x4 acc[1][1];
-                    clear<1, 1>(acc);
-                    mm<1, 1, 8>(acc, XD / 4, [&](int i, int k) { return dZ[min(fm + i, last) * FLD + k]; },
-                                [&](int k, int j) { return Wc[(fn + j) * FLD + k]; });
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (frow + r < NP) dT[(frow + r) * FLD + fcol] = frow + r < N ? acc[0][0][r] : 0.f;
+                    f32x4 acc[1][XTW];
+                    clear<1, XTW>(acc);
+                    mm<1, XTW, 8>(acc, XW / 4, [&](int i, int k) { return dZ[min(fm + i, last) * FLD + k]; },
+                                  [&](int k, int j) { return Wc[(fn + j) * FLD + k]; });
+                    put(dT, acc);
                 }
                 __syncthreads();
                 // dA += dT H_l^T
                 if (a_on)
-                    mm<1, NTW, 8>(dAacc, XD / 4, [&](int i, int k) { return dT[min(am + i, last) * FLD + k]; },
+                    mm<1, NTW, 8>(dAacc, XW / 4, [&](int i, int k) { return dT[min(am + i, last) * FLD + k]; },
                                   [&](int k, int j) { return Hc[min(an + j, last) * FLD + k]; });
                 {   // dH_l = A^T dT (+ dH_{l+1} through the skip connection); the next layer's dZ right away
-                    f32x4 acc[1][1];
-                    clear<1, 1>(acc);
-                    mm<1, 1, 8>(acc, NK, [&](int mi, int k) { return A[k * ALD + fm + mi]; },
-                                [&](int k, int j) { return dT[k * FLD + fn + j]; });
+                    f32x4 acc[1][XTW];
+                    clear<1, XTW>(acc);
+                    mm<1, XTW, 8>(acc, NK, [&](int mi, int k) { return A[k * ALD + fm + mi]; },
+                                  [&](int k, int j) { return dT[k * FLD + fn + j]; });
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = frow + r;
-                        if (row < N) {
-                            const float d = acc[0][0][r] + (a.skip ? dH[row * FLD + fcol] : 0.f);
-                            dH[row * FLD + fcol] = d;
-                            if (l > 0) dZ[row * FLD + fcol] = ((mask[l > 0 ? l - 1 : 0] >> r) & 1u) ? d : 0.f;
+                    for (int nt = 0; nt < XTW; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = frow + r, col = fn + nt * 16 + l16;
+                            if (row < N) {
+                                const float d = acc[0][nt][r] + (a.skip ? dH[row * FLD + col] : 0.f);
+                                dH[row * FLD + col] = d;
+                                if (l > 0) dZ[row * FLD + col] = ((mask[l > 0 ? l - 1 : 0] >> (nt * 4 + r)) & 1u) ? d : 0.f;
+                            }
                         }
-                    }
                 }
                 __syncthreads();
             }
@@ -768,46 +780,53 @@ __global__ __launch_bounds__(NT * 128, NT == 2 ? 4 : (NT == 1 ? 3 : 2)) void gra
             __syncthreads();
             // S = G X^T:  dG = dS X ;  dX += dS^T G        G = X Wa:  dWa += X^T dG ;  dX += dG Wa^T     (gaussian: G = X, dX += dG)
             float* dG = dZ;
-            f32x4 dx[1][1];
+            f32x4 dx[1][XTW];
             {
-                f32x4 acc[1][1];
-                clear<1, 1>(acc);
-                mm<1, 1, 8>(acc, NK, [&](int i, int k) { return dA[min(fm + i, last) * ALD + k]; },
-                            [&](int k, int j) { return X[k * FLD + fn + j]; });
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (frow + r < NP) dG[(frow + r) * FLD + fcol] = frow + r < N ? acc[0][0][r] : 0.f;
-                clear<1, 1>(dx);
-                mm<1, 1, 8>(dx, NK, [&](int mi, int k) { return dA[k * ALD + fm + mi]; }, [&](int k, int j) { return GX[k * FLD + fn + j]; });
+                f32x4 acc[1][XTW];
+                clear<1, XTW>(acc);
+                mm<1, XTW, 8>(acc, NK, [&](int i, int k) { return dA[min(fm + i, last) * ALD + k]; },
+                              [&](int k, int j) { return X[k * FLD + fn + j]; });
+                put(dG, acc);
+                clear<1, XTW>(dx);
+                mm<1, XTW, 8>(dx, NK, [&](int mi, int k) { return dA[k * ALD + fm + mi]; },
+                              [&](int k, int j) { return GX[k * FLD + fn + j]; });
                 if (!embedded) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dx[0][0][r] += acc[0][0][r];
+                    for (int nt = 0; nt < XTW; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dx[0][nt][r] += acc[0][nt][r];
                 }
             }
             __syncthreads();
             if (embedded) {
                 if (g_on)
-                    mm<1, GT, 8>(gWa, NK, [&](int mi, int k) { return X[k * FLD + gm + mi]; }, [&](int k, int j) { return dG[k * FLD + gn + j]; });
-                mm<1, 1, 8>(dx, XD / 4, [&](int i, int k) { return dG[min(fm + i, last) * FLD + k]; },
-                            [&](int k, int j) { return Wa[(fn + j) * FLD + k]; });
+                    mm<GM, GN, 8>(gWa, NK, [&](int mi, int k) { return X[k * FLD + gm + mi]; },
+                                  [&](int k, int j) { return dG[k * FLD + gn + j]; });
+                mm<1, XTW, 8>(dx, XW / 4, [&](int i, int k) { return dG[min(fm + i, last) * FLD + k]; },
+                              [&](int k, int j) { return Wa[(fn + j) * FLD + k]; });
             }
-            float* dxg = a.dX + (size_t)s * N * XD;
+            float* dxr = a.dXr + (size_t)s * XW;
+            float* dxh = a.dXh + (size_t)s * (N - 1) * XW - XW;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (frow + r < N) dxg[(frow + r) * XD + fcol] = dx[0][0][r] + dH[(frow + r) * FLD + fcol];
+            for (int nt = 0; nt < XTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = frow + r, col = fn + nt * 16 + l16;
+                    if (row < N) (row == 0 ? dxr : dxh + (size_t)row * XW)[col] = dx[0][nt][r] + dH[row * FLD + col];
+                }
             __syncthreads();
         }
     }
     if constexpr (BWD) {
         if (g_on) {
-            float* slab = a.slabs + (size_t)blockIdx.x * ((embedded ? 1 : 0) + L) * XD * XD;
+            float* slab = a.slabs + (size_t)blockIdx.x * ((embedded ? 1 : 0) + L) * XW * XW;
             if (embedded) {
-                each<1, GT>(gWa, [&](int i, int j, float v, int, int, int) { slab[(gm + i) * XD + gn + j] = v; });
-                slab += XD * XD;
+                each<GM, GN>(gWa, [&](int i, int j, float v, int, int, int) { slab[(gm + i) * XW + gn + j] = v; });
+                slab += XW * XW;
             }
 #pragma unroll
             for (int l = 0; l < L; ++l)
-                each<1, GT>(gW[l], [&](int i, int j, float v, int, int, int) { slab[l * XD * XD + (gm + i) * XD + gn + j] = v; });
+                each<GM, GN>(gW[l], [&](int i, int j, float v, int, int, int) { slab[l * XW * XW + (gm + i) * XW + gn + j] = v; });
         }
     }
 }
@@ -984,45 +1003,55 @@ int launch_rows(RowsArgs& all, hipStream_t st) {
     return RGL_OK;
 }
 
-template <int NT, int L>
-int launch_graph_nl(const GraphArgs& ga, bool bwd, size_t lds, int grid, hipStream_t st) {
-    const void* fn = bwd ? reinterpret_cast<const void*>(graph_kernel<NT, L, true>) : reinterpret_cast<const void*>(graph_kernel<NT, L, false>);
+template <int NT, int XT, int L>
+int launch_graph_nxl(const GraphArgs& ga, bool bwd, size_t lds, int grid, hipStream_t st) {
+    const void* fn = bwd ? reinterpret_cast<const void*>(graph_kernel<NT, XT, L, true>)
+                         : reinterpret_cast<const void*>(graph_kernel<NT, XT, L, false>);
     if (lds > 64 * 1024) RGL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (bwd) hipLaunchKernelGGL((graph_kernel<NT, L, true>), dim3(grid), dim3(NT * 128), lds, st, ga);
-    else hipLaunchKernelGGL((graph_kernel<NT, L, false>), dim3(grid), dim3(NT * 128), lds, st, ga);
+    if (bwd) hipLaunchKernelGGL((graph_kernel<NT, XT, L, true>), dim3(grid), dim3(NT * 128), lds, st, ga);
+    else hipLaunchKernelGGL((graph_kernel<NT, XT, L, false>), dim3(grid), dim3(NT * 128), lds, st, ga);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }
-template <int NT>
-int launch_graph_n(const GraphArgs& ga, int L, bool bwd, size_t lds, int grid, hipStream_t st) {
+template <int NT, int XT>
+int launch_graph_nx(const GraphArgs& ga, int L, bool bwd, size_t lds, int grid, hipStream_t st) {
     switch (L) {
-        case 1: return launch_graph_nl<NT, 1>(ga, bwd, lds, grid, st);
-        case 2: return launch_graph_nl<NT, 2>(ga, bwd, lds, grid, st);
-        default: return launch_graph_nl<NT, 3>(ga, bwd, lds, grid, st);
+        case 1: return launch_graph_nxl<NT, XT, 1>(ga, bwd, lds, grid, st);
+        case 2: return launch_graph_nxl<NT, XT, 2>(ga, bwd, lds, grid, st);
+        default: return launch_graph_nxl<NT, XT, 3>(ga, bwd, lds, grid, st);
     }
 }
 
 struct GraphPlan { int grid; size_t lds; };
-template <int NT>
-GraphPlan plan_graph_nt(int S, int N, int L) {
+template <int NT, int XT>
+GraphPlan plan_graph_nx(int S, int N, int L, bool bwd) {
     GraphPlan p{};
-    p.lds = (size_t)(GraphLds<NT>::weight_floats(L) + GraphLds<NT>::scene_floats(N, L)) * sizeof(float);
+    p.lds = (size_t)(GraphLds<NT, XT>::weight_floats(L) + GraphLds<NT, XT>::scene_floats(N, L, bwd)) * sizeof(float);
     if (p.lds > (size_t)rgl::kLdsBytesPerCu) return p;
-    // persistent workgroups: as many as are resident at once (LDS, and 32 waves per CU), scenes dealt round robin
+    // persistent workgroups: as many as are resident at once (LDS, and the waves the kernel's register budget allows), scenes dealt
+    // round robin
     int per_cu = (int)((size_t)rgl::kLdsBytesPerCu / p.lds);
-    const int by_waves = 32 / (2 * NT);
+    const int by_waves = ((NT == 2 && XT == 2) ? 16 : (NT == 1 ? 12 : 8)) / (2 * NT);
     per_cu = per_cu > by_waves ? by_waves : per_cu;
+    per_cu = per_cu < 1 ? 1 : per_cu;
     const int resident = 256 * per_cu;
     p.grid = S < resident ? S : resident;
     return p;
 }
-GraphPlan plan_graph(int S, int N, int L) {
-    return N <= 16 ? plan_graph_nt<1>(S, N, L) : (N <= 32 ? plan_graph_nt<2>(S, N, L) : plan_graph_nt<4>(S, N, L));
+// x_dim 32 or 64
+GraphPlan plan_graph(int S, int N, int X, int L, bool bwd) {
+    if (X == 32) return N <= 16 ? plan_graph_nx<1, 2>(S, N, L, bwd) : (N <= 32 ? plan_graph_nx<2, 2>(S, N, L, bwd) : plan_graph_nx<4, 2>(S, N, L, bwd));
+    return N <= 16 ? plan_graph_nx<1, 4>(S, N, L, bwd) : (N <= 32 ? plan_graph_nx<2, 4>(S, N, L, bwd) : plan_graph_nx<4, 4>(S, N, L, bwd));
 }
-int launch_graph(const GraphArgs& ga, int L, bool bwd, const GraphPlan& p, hipStream_t st) {
-    if (ga.N <= 16) return launch_graph_n<1>(ga, L, bwd, p.lds, p.grid, st);
-    if (ga.N <= 32) return launch_graph_n<2>(ga, L, bwd, p.lds, p.grid, st);
-    return launch_graph_n<4>(ga, L, bwd, p.lds, p.grid, st);
+int launch_graph(const GraphArgs& ga, int X, int L, bool bwd, const GraphPlan& p, hipStream_t st) {
+    if (X == 32) {
+        if (ga.N <= 16) return launch_graph_nx<1, 2>(ga, L, bwd, p.lds, p.grid, st);
+        if (ga.N <= 32) return launch_graph_nx<2, 2>(ga, L, bwd, p.lds, p.grid, st);
+        return launch_graph_nx<4, 2>(ga, L, bwd, p.lds, p.grid, st);
+    }
+    if (ga.N <= 16) return launch_graph_nx<1, 4>(ga, L, bwd, p.lds, p.grid, st);
+    if (ga.N <= 32) return launch_graph_nx<2, 4>(ga, L, bwd, p.lds, p.grid, st);
+    return launch_graph_nx<4, 4>(ga, L, bwd, p.lds, p.grid, st);
 }
 
 int env_int(const char* name, int dflt) {
@@ -1044,8 +1073,122 @@ extern "C" int rgl_debug_read_backward_phase_cycles(unsigned long long* out16, i
 }
 #endif
 
+namespace {
+
+// what the tile kernels cover: embedded_gaussian / gaussian similarity, one adjacency for all layers, x_dim 32 or 64, 1-3 layers,
+// N <= 64; any embedding MLPs and heads within the ABI limits
+bool tiles_cover(const RglGraph& g, int H) {
+    const int N = H + 1, L = g.num_layer;
+    if ((g.x_dim != 32 && g.x_dim != 64) || g.layerwise_graph || L < 1 || L > 3 || N > 64 || H < 1) return false;
+    return g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN || g.similarity == RGL_SIM_GAUSSIAN;
+}
+
+void graph_args(GraphArgs& ga, const RglGraph& g, int S, int N, int spc) {
+    ga = GraphArgs{};
+    ga.w_a = g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN ? g.w_a : nullptr;
+    for (int l = 0; l < g.num_layer; ++l) ga.Ws[l] = g.Ws[l];
+    ga.S = S; ga.N = N; ga.skip = g.skip_connection ? 1 : 0; ga.spc = spc;
+}
+
+struct Taker {                 // carves 256-byte aligned pieces out of a workspace
+    char* base;
+    size_t used = 0;
+    template <class T>
+    T* take(size_t count) {
+        T* p = (T*)(base + used);
+        used += (count * sizeof(T) + 255) & ~(size_t)255;
+        return p;
+    }
+};
+
+}  // namespace
+
 namespace rgl {
 
+// ------------------------------------------------------------------------------------------------
+// forward on the same tile kernels: models the shipped-shape MFMA kernels (rgl_scene.hip, rgl_fused.hip, ..) do not cover -- other
+// embedding MLPs (wr_dims / wh_dims), x_dim = 64 -- instead of the general VALU kernel.  0 bytes / 1 = not covered.
+//   1. mlp rows (forward): robot rows [S][X], human rows [S / spc][H][X] (sibling scenes share their crowd's rows)
+//   2. graph_kernel<.., false>: H_L -- all rows (motion head, H_out) or the robot row only (value head)
+//   3. mlp rows (forward): value head on row 0 -> value_out, motion head on rows 1.. -> humans_next
+// ------------------------------------------------------------------------------------------------
+size_t tiles_forward_workspace_bytes(const RglGraph* g, const RglMlp* vh, const RglMlp* mh, int S, int spc, int H, int want_H) {
+    if (!g || !tiles_cover(*g, H) || S < 1 || spc < 1 || S % spc) return 0;
+    const bool has_m = mh && mh->n_layers > 0;
+    const size_t X = g->x_dim, N = H + 1;
+    const size_t hl = (has_m && !want_H) ? (size_t)S * N * X : ((!has_m && !want_H) ? (size_t)S * X : 0);     // H_out doubles as H_L
+    return ((size_t)S * X + (size_t)(S / spc) * H * X + hl) * sizeof(float) + 3 * 256;
+}
+
+int launch_tiles_forward(const RglGraph* graph, const RglMlp* vh, const RglMlp* mh, const float* robot, const float* humans, int S,
+                         int spc, int H, float* H_out, float* value_out, float* humans_next, void* workspace, size_t workspace_bytes,
+                         hipStream_t st) {
+    const bool has_v = vh && vh->n_layers > 0 && value_out, has_m = mh && mh->n_layers > 0 && humans_next;
+    if (!graph || !workspace || !tiles_cover(*graph, H) || S < 1 || spc < 1 || S % spc) return 1;
+    if (env_int("RGL_TILES_FORWARD", 1) == 0) return 1;          // measurements: the general kernel instead
+    if (workspace_bytes < tiles_forward_workspace_bytes(graph, has_v ? vh : nullptr, has_m ? mh : nullptr, S, spc, H, H_out != nullptr))
+        return 1;
+    const RglGraph& g = *graph;
+    const int N = H + 1, L = g.num_layer, X = g.x_dim, crowds = S / spc;
+    const GraphPlan gp = plan_graph(S, N, X, L, false);
+    if (gp.grid < 1) return 1;
+    Taker ws{(char*)workspace};
+    float* Xr = ws.take<float>((size_t)S * X);
+    float* Xh = ws.take<float>((size_t)crowds * H * X);
+    const bool row0 = !has_m && !H_out;
+    float* HL = H_out ? H_out : ws.take<float>(row0 ? (size_t)S * X : (size_t)S * N * X);
+    RowsJob j_wr, j_wh, j_v, j_m;
+    plan_rows_job(j_wr, g.w_r, S, 2048);
+    plan_rows_job(j_wh, g.w_h, crowds * H, 2048);
+    if (has_v) plan_rows_job(j_v, *vh, S, 2048);
+    if (has_m) plan_rows_job(j_m, *mh, S * H, 2048);
+    {
+        RowsJob* emb[2] = {&j_wr, &j_wh};
+        RowsJob* heads[2] = {has_v ? &j_v : nullptr, has_m ? &j_m : nullptr};
+        balance_narrow(emb, 2, 2048);
+        balance_narrow(heads, 2, 2048);
+    }
+    for (const RowsJob* J : {&j_wr, &j_wh, has_v ? &j_v : nullptr, has_m ? &j_m : nullptr})
+        if (J && J->waves_per_wg < 1) return 1;
+    j_wr.in = RowMap{(float*)robot, 1, 0, (long long)g.w_r.dims[0]};
+    j_wr.out = RowMap{Xr, 1, 0, (long long)X};
+    j_wh.in = RowMap{(float*)humans, H, g.w_h.dims[0], (long long)H * g.w_h.dims[0]};
+    j_wh.out = RowMap{Xh, H, X, (long long)H * X};
+    {
+        RowsArgs ra{};
+        ra.job[0] = j_wr; ra.job[1] = j_wh; ra.n_jobs = 2; ra.backward = 0;
+        const int rc = launch_rows(ra, st);
+        if (rc) return rc;
+    }
+    GraphArgs ga;
+    graph_args(ga, g, S, N, spc);
+    ga.Xr = Xr; ga.Xh = Xh; ga.HL = HL; ga.hl_row0 = row0 ? 1 : 0;
+    int rc = launch_graph(ga, X, L, false, gp, st);
+    if (rc) return rc;
+    if (has_v || has_m) {
+        const long long hs = row0 ? X : (long long)N * X;
+        RowsArgs ra{};
+        ra.backward = 0;
+        if (has_v) {
+            j_v.in = RowMap{HL, 1, 0, hs};
+            j_v.out = RowMap{value_out, 1, 0, 1};
+            ra.job[ra.n_jobs++] = j_v;
+        }
+        if (has_m) {
+            const int od = mh->dims[mh->n_layers];
+            j_m.in = RowMap{HL + X, H, X, (long long)N * X};
+            j_m.out = RowMap{humans_next, H, od, (long long)H * od};
+            ra.job[ra.n_jobs++] = j_m;
+        }
+        rc = launch_rows(ra, st);
+        if (rc) return rc;
+    }
+    return RGL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
 // 1 = not this path (outside the envelope, below the batch threshold, or the caller's workspace cannot hold the intermediates):
 // the per-scene VALU kernel of rgl_backward.hip runs.  Slab order of grad_out as documented in rgl_hip.h.
 int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* mh, const float* robot, const float* humans,
@@ -1063,35 +1206,34 @@ int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
         if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusActive) return 1;
     }
     const RglGraph& g = *graph;
-    const int N = H + 1, L = g.num_layer;
-    if (g.x_dim != XD || g.layerwise_graph || L < 1 || L > 3 || N > 64) return 1;
-    if (g.similarity != RGL_SIM_EMBEDDED_GAUSSIAN && g.similarity != RGL_SIM_GAUSSIAN) return 1;
+    if (!tiles_cover(g, H)) return 1;
+    const int N = H + 1, L = g.num_layer, X = g.x_dim;
     const bool has_v = vh && vh->n_layers > 0, has_m = mh && mh->n_layers > 0;
     const bool embedded = g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN;
-    const GraphPlan gp = plan_graph(S, N, L);
-    if (gp.grid < 1) return 1;
+    const GraphPlan gpf = plan_graph(S, N, X, L, false), gp = plan_graph(S, N, X, L, true);
+    if (gp.grid < 1 || gpf.grid < 1) return 1;
 
     // gradient vector: w_r | w_h | w_a | Ws | value head | motion head
-    const int n_wr = mlp_params(g.w_r), n_wh = mlp_params(g.w_h), n_graph = ((embedded ? 1 : 0) + L) * XD * XD;
+    const int n_wr = mlp_params(g.w_r), n_wh = mlp_params(g.w_h), n_graph = ((embedded ? 1 : 0) + L) * X * X;
     const int n_v = has_v ? mlp_params(*vh) : 0, n_m = has_m ? mlp_params(*mh) : 0;
     const int o_wr = 0, o_wh = n_wr, o_graph = o_wh + n_wh, o_v = o_graph + n_graph, o_m = o_v + n_v, n_params = o_m + n_m;
 
-    // workspace: X | H_L | dH_L | dX | slabs of the row jobs and of the graph kernel
-    char* ws = (char*)workspace;
-    size_t used = 0;
-    auto take = [&](size_t bytes) -> void* { void* p = ws + used; used += (bytes + 255) & ~(size_t)255; return p; };
-    const size_t feat = (size_t)S * N * XD * sizeof(float);
-    float* X = (float*)take(feat);
-    float* HL = (float*)take(feat);
-    float* dHL = (float*)take(feat);
-    float* dX = (float*)take(feat);
+    // workspace: X (robot rows | human rows) | H_L | dH_L | dX (robot rows | human rows) | slabs of the row jobs and of the graph kernel
+    Taker ws{(char*)workspace};
+    const size_t feat = (size_t)S * N * X;
+    float* Xr = ws.take<float>((size_t)S * X);
+    float* Xh = ws.take<float>((size_t)S * H * X);
+    float* HL = ws.take<float>(feat);
+    float* dHL = ws.take<float>(feat);
+    float* dXr = ws.take<float>((size_t)S * X);
+    float* dXh = ws.take<float>((size_t)S * H * X);
     // one slab per wave: fewer waves per row job (more tiles each) when the caller's workspace -- sized for the per-scene kernel's
     // slabs, n_scenes x n_params floats -- is short (few scenes of many nodes)
     RowsJob j_wr, j_wh, j_v, j_m;
     float* g_slabs = nullptr;
-    const size_t used_feat = used;
-    for (int max_waves = 2048; max_waves >= 8; max_waves >>= 1) {
-        used = used_feat;
+    const size_t used_feat = ws.used;
+    for (int max_waves = 2048; max_waves >= 1; max_waves >>= 1) {
+        ws.used = used_feat;
         plan_rows_job(j_wr, g.w_r, S, max_waves);
         plan_rows_job(j_wh, g.w_h, S * H, max_waves);
         if (has_v) plan_rows_job(j_v, *vh, S, max_waves);
@@ -1102,22 +1244,22 @@ int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
             balance_narrow(emb, 2, max_waves);
             balance_narrow(heads, 2, max_waves);
         }
-        auto slabs_for = [&](RowsJob& J) { J.slabs = (float*)take((size_t)J.n_waves * J.n_params * sizeof(float)); };
+        auto slabs_for = [&](RowsJob& J) { J.slabs = ws.take<float>((size_t)J.n_waves * J.n_params); };
         if (!detach_graph) { slabs_for(j_wr); slabs_for(j_wh); }
         if (has_v) slabs_for(j_v);
         if (has_m) slabs_for(j_m);
-        g_slabs = detach_graph ? nullptr : (float*)take((size_t)gp.grid * n_graph * sizeof(float));
-        if (used <= workspace_bytes) break;
+        g_slabs = detach_graph ? nullptr : ws.take<float>((size_t)gp.grid * n_graph);
+        if (ws.used <= workspace_bytes) break;
     }
-    if (used > workspace_bytes) return 1;
+    if (ws.used > workspace_bytes) return 1;
     for (const RowsJob* J : {&j_wr, &j_wh, has_v ? &j_v : nullptr, has_m ? &j_m : nullptr})
         if (J && J->waves_per_wg < 1) return 1;
 
     // 1. embeddings
     j_wr.in = RowMap{(float*)robot, 1, 0, (long long)g.w_r.dims[0]};
-    j_wr.out = RowMap{X, 1, 0, (long long)N * XD};
+    j_wr.out = RowMap{Xr, 1, 0, (long long)X};
     j_wh.in = RowMap{(float*)humans, H, g.w_h.dims[0], (long long)H * g.w_h.dims[0]};
-    j_wh.out = RowMap{X + XD, H, XD, (long long)N * XD};
+    j_wh.out = RowMap{Xh, H, X, (long long)H * X};
     {
         RowsArgs ra{};
         ra.job[0] = j_wr; ra.job[1] = j_wh; ra.n_jobs = 2; ra.backward = 0;
@@ -1125,33 +1267,31 @@ int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
         if (rc) return rc;
     }
     // 2. graph forward
-    GraphArgs ga{};
-    ga.X = X; ga.dHL = dHL; ga.HL = HL; ga.dX = dX;
-    ga.w_a = embedded ? g.w_a : nullptr;
-    for (int l = 0; l < L; ++l) ga.Ws[l] = g.Ws[l];
-    ga.slabs = g_slabs; ga.S = S; ga.N = N; ga.skip = g.skip_connection ? 1 : 0;
+    GraphArgs ga;
+    graph_args(ga, g, S, N, 1);
+    ga.Xr = Xr; ga.Xh = Xh; ga.dHL = dHL; ga.HL = HL; ga.dXr = dXr; ga.dXh = dXh; ga.slabs = g_slabs;
     if (has_v || has_m) {
-        const int rc = launch_graph(ga, L, false, gp, st);
+        const int rc = launch_graph(ga, X, L, false, gpf, st);
         if (rc) return rc;
     }
     // 3. heads: dH_L starts as the caller's d_H (or zero) and receives the heads' input gradients
-    if (d_H) RGL_HIP_TRY(hipMemcpyAsync(dHL, d_H, feat, hipMemcpyDeviceToDevice, st));
-    else RGL_HIP_TRY(hipMemsetAsync(dHL, 0, feat, st));
+    if (d_H) RGL_HIP_TRY(hipMemcpyAsync(dHL, d_H, feat * sizeof(float), hipMemcpyDeviceToDevice, st));
+    else RGL_HIP_TRY(hipMemsetAsync(dHL, 0, feat * sizeof(float), st));
     if (has_v || has_m) {
         RowsArgs ra{};
         ra.backward = 1;
         if (has_v) {
-            j_v.in = RowMap{HL, 1, 0, (long long)N * XD};
+            j_v.in = RowMap{HL, 1, 0, (long long)N * X};
             j_v.d_out = RowMap{(float*)d_value, 1, 0, 1};
-            j_v.d_in = RowMap{dHL, 1, 0, (long long)N * XD};
+            j_v.d_in = RowMap{dHL, 1, 0, (long long)N * X};
             j_v.need_din = detach_graph ? 0 : 1; j_v.din_add = 1;
             ra.job[ra.n_jobs++] = j_v;
         }
         if (has_m) {
             const int od = mh->dims[mh->n_layers];
-            j_m.in = RowMap{HL + XD, H, XD, (long long)N * XD};
+            j_m.in = RowMap{HL + X, H, X, (long long)N * X};
             j_m.d_out = RowMap{(float*)d_humans_next, H, od, (long long)H * od};
-            j_m.d_in = RowMap{dHL + XD, H, XD, (long long)N * XD};
+            j_m.d_in = RowMap{dHL + X, H, X, (long long)N * X};
             j_m.need_din = detach_graph ? 0 : 1; j_m.din_add = 1;
             ra.job[ra.n_jobs++] = j_m;
         }
@@ -1160,11 +1300,11 @@ int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
     }
     if (!detach_graph) {
         // 4. graph backward
-        int rc = launch_graph(ga, L, true, gp, st);
+        int rc = launch_graph(ga, X, L, true, gp, st);
         if (rc) return rc;
         // 5. embeddings backward
-        j_wr.d_out = RowMap{dX, 1, 0, (long long)N * XD};
-        j_wh.d_out = RowMap{dX + XD, H, XD, (long long)N * XD};
+        j_wr.d_out = RowMap{dXr, 1, 0, (long long)X};
+        j_wh.d_out = RowMap{dXh, H, X, (long long)H * X};
         RowsArgs ra{};
         ra.job[0] = j_wr; ra.job[1] = j_wh; ra.n_jobs = 2; ra.backward = 1;
         rc = launch_rows(ra, st);

@@ -120,6 +120,14 @@ int launch_backward_mfma(const RglGraph* graph, const RglMlp* value_head, const 
                          const float* d_humans_next, const float* d_H, float* grad_out, void* workspace, size_t workspace_bytes,
                          hipStream_t stream, int only_choice);                                                                     // rgl_backward_mfma.hip
 
+// forward of models outside the shipped shapes (other embedding MLPs, x_dim = 64) on the tile kernels of rgl_backward_mfma.hip instead
+// of the general VALU kernel: embedded_gaussian / gaussian, one adjacency, 1-3 layers, N <= 64.  0 bytes / 1 = not covered.
+size_t tiles_forward_workspace_bytes(const RglGraph* g, const RglMlp* value_head, const RglMlp* motion_head, int S, int crowds_per,
+                                     int H, int want_H);
+int launch_tiles_forward(const RglGraph* g, const RglMlp* value_head, const RglMlp* motion_head, const float* robot,
+                         const float* humans, int S, int crowds_per, int H, float* H_out, float* value_out, float* humans_next,
+                         void* workspace, size_t workspace_bytes, hipStream_t stream);                               // rgl_backward_mfma.hip
+
 inline int mlp_max_hidden(const RglMlp& m) {
     int w = 0;
     for (int l = 1; l < m.n_layers; ++l) w = m.dims[l] > w ? m.dims[l] : w;

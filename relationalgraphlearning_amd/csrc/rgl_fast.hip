@@ -17,8 +17,13 @@ size_t value_children_workspace_bytes(const MprlPlanner* pl, int P, int H) {
     const size_t predictor = (size_t)P * (H + 1) * XD * sizeof(float);         // embeddings of launch_predict_humans
     const size_t fused = H + 1 <= 32 ? fused_children_workspace_bytes(P, pl->num_actions, H) : 0;
     const size_t scene = scene_children_workspace_bytes(P, pl->num_actions, H);
+    // the tile kernels, for planners outside the shipped shapes: children of the value graph, scenes of the state predictor
+    const size_t tiles_v = tiles_forward_workspace_bytes(&pl->value_graph, &pl->value_head, nullptr, P * pl->num_actions, pl->num_actions, H, 0);
+    const size_t tiles_p = pl->linear_state_predictor ? 0 : tiles_forward_workspace_bytes(&pl->predictor_graph, nullptr, &pl->motion_head, P, 1, H, 0);
+    const size_t tiles = tiles_v > tiles_p ? tiles_v : tiles_p;
     const size_t m0 = children > predictor ? children : predictor;
-    const size_t m = m0 > scene ? m0 : scene;
+    const size_t m1 = m0 > scene ? m0 : scene;
+    const size_t m = m1 > tiles ? m1 : tiles;
     // the fused kernel keeps its weight images at the END of the workspace: room for them behind every other use
     return H + 1 <= 32 ? ((m + 255) & ~(size_t)255) + fused_children_workspace_bytes(0, pl->num_actions, H) + (fused > m ? fused - m : 0) : m;
 }
@@ -66,6 +71,12 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
         }
     }
     if (want_f16 && rc == 1) return RGL_ERR_BAD_MODE;
+    if (rc == 1) {
+        // outside the shipped shapes (other embedding MLPs, x_dim = 64): the tile kernels, the children of a parent sharing its crowd's rows
+        rc = launch_tiles_forward(&pl->value_graph, &pl->value_head, nullptr, child_robot, humans_next, P * A, A, H, nullptr, child_value,
+                                  nullptr, workspace, workspace_bytes, stream);
+        if (rc != 1) return rc;
+    }
     if (rc == 1) {
         // RGL_REQUIRE_MFMA_CHILDREN=1 (tests): refuse instead of running the general VALU kernel
         static const bool require = [] { const char* e = getenv("RGL_REQUIRE_MFMA_CHILDREN"); return e && e[0] == '1'; }();

@@ -8,6 +8,8 @@
 // state_predictor.py:28-36, gcn.py:95-128, helpers.py:5-13.
 #include "rgl_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -398,7 +400,11 @@ int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, cons
 extern "C" size_t rgl_graph_forward_workspace_bytes(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
                                                     int n_scenes, int scenes_per_crowd, int H) {
     if (!graph || n_scenes < 1 || scenes_per_crowd < 1 || H < 1) return 0;
-    return rgl::scene_forward_workspace_bytes(graph, value_head, motion_head, n_scenes, scenes_per_crowd, H);
+    const size_t scene = rgl::scene_forward_workspace_bytes(graph, value_head, motion_head, n_scenes, scenes_per_crowd, H);
+    if (scene) return scene;
+    // outside the shipped shapes: the tile kernels (other embedding MLPs, x_dim = 64)
+    if (rgl::validate_graph(*graph, H)) return 0;
+    return rgl::tiles_forward_workspace_bytes(graph, value_head, motion_head, n_scenes, scenes_per_crowd, H, 0);
 }
 
 extern "C" int rgl_graph_forward_f32(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
@@ -414,6 +420,12 @@ extern "C" int rgl_graph_forward_f32(const RglGraph* graph, const RglMlp* value_
         rc = rgl::launch_scene_forward(graph, value_head, motion_head, robot, humans, n_scenes, scenes_per_crowd, H, value_out,
                                        humans_next, workspace, workspace_bytes, (hipStream_t)stream);
         if (rc != 1) return rc;
+        rc = rgl::launch_tiles_forward(graph, value_head, motion_head, robot, humans, n_scenes, scenes_per_crowd, H, nullptr, value_out,
+                                       humans_next, workspace, workspace_bytes, (hipStream_t)stream);
+        if (rc != 1) return rc;
+        // RGL_REQUIRE_MFMA_FORWARD=1 (tests): refuse instead of running the general VALU kernel
+        const char* e = getenv("RGL_REQUIRE_MFMA_FORWARD");
+        if (e && e[0] == '1') return RGL_ERR_BAD_MODE;
     }
     return rgl::launch_generic_forward(graph, value_head, motion_head, robot, humans, n_scenes, scenes_per_crowd, H,
                                        H_out, A_out, value_out, humans_next, (hipStream_t)stream);

@@ -934,9 +934,18 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
     const int N = H + 1;
     const bool ok = scene_kernel_covers(g, N) && mlp_is(mh, XD, HID, 5, false) && workspace &&
                     workspace_bytes >= (size_t)P * N * XD * sizeof(float) && P % crowds_per == 0;
-    if (!ok)
+    if (!ok) {
+        // outside the shipped shapes: the tile kernels (rgl_backward_mfma.hip) where they cover the model, else the general kernel
+        if (P % crowds_per == 0) {
+            const int rc = launch_tiles_forward(&g, nullptr, &mh, robot, humans, P, crowds_per, H, nullptr, nullptr, humans_next, workspace,
+                                                workspace_bytes, stream);
+            if (rc != 1) return rc;
+        }
+        const char* e = getenv("RGL_REQUIRE_MFMA_FORWARD");          // tests: refuse instead of running the general VALU kernel
+        if (e && e[0] == '1') return RGL_ERR_BAD_MODE;
         return launch_generic_forward(&g, nullptr, &mh, robot, humans, P, crowds_per, H, nullptr, nullptr, nullptr,
                                       humans_next, stream);
+    }
     float* x0_rows = (float*)workspace;                      // [P][32]
     float* xh_rows = x0_rows + (size_t)P * XD;               // [n_crowds][H][32]
     // the level's reward / next-state work rides in the scene kernel's launch while the scene workgroups leave LDS free (few scenes),
