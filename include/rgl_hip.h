@@ -115,8 +115,9 @@ typedef struct RglGraph {
  *   workspace  NULL or device scratch of rgl_graph_forward_workspace_bytes(...) bytes (ABI 3).  With it, and with H_out = A_out =
  *              NULL, models the one-wave-per-scene MFMA kernel covers (the shipped path-M shapes: w_r 9-64-32, w_h 5-64-32,
  *              x_dim 32, <= 4 layers, N <= 128 (concatenation: N <= 64), every similarity function, layerwise graphs) run on
- *              it; everything else, and
- *              every call without workspace, runs on the general kernel -- same numbers up to summation order.
+ *              it; other embedding MLPs and x_dim = 64 (embedded_gaussian / gaussian, one adjacency, 1-3 layers, N <= 64) run on
+ *              the MFMA tile kernels (rgl_backward_mfma.hip); everything else, and every call without workspace, runs on the
+ *              general kernel -- same numbers up to summation order.
  * Limits: N = H+1 <= RGL_MAX_NODES, x_dim <= RGL_MAX_XDIM, widths <= RGL_MAX_WIDTH.
  * ------------------------------------------------------------------------------------------- */
 size_t rgl_graph_forward_workspace_bytes(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
@@ -132,8 +133,12 @@ int rgl_graph_forward_f32(const RglGraph* graph, const RglMlp* value_head, const
  * parameter, summed over the n_scenes scenes (deterministic: per-scene slabs reduced in scene order).
  * Replaces: torch autograd through RGL.forward / ValueEstimator.forward / StatePredictor.forward /
  * gcn.ValueNetwork.forward as driven by MPRLTrainer / VNRLTrainer (crowd_nav/utils/trainer.py:110-161,
- * 199-250).  Supported: all eight similarity functions, layerwise_graph 0 | 1 (RGL_ERR_LDS when a scene's
- * activations exceed the 160 KB LDS of a CU: N = 64 with deep MLPs; the training batches have N = 6).
+ * 199-250).  Supported: all eight similarity functions, layerwise_graph 0 | 1.  Two implementations behind this entry point:
+ * a per-scene kernel (one workgroup and one gradient slab per scene; RGL_ERR_LDS when a scene's activations exceed the 160 KB
+ * LDS of a CU: N = 64 with deep MLPs) and, for embedded_gaussian / gaussian with one adjacency, x_dim 32 | 64, 1-3 layers,
+ * N <= 64, a pipeline of MFMA tile kernels (rgl_backward_mfma.hip) -- taken from 256 scenes, whenever `stream` is being
+ * captured into a hipGraph, and where the per-scene kernel does not fit.  Environment: RGL_BACKWARD_MFMA = 0 | 1 forces a
+ * path, RGL_BACKWARD_MFMA_MIN moves the threshold.  Both are deterministic (fixed summation order per shape).
  *   d_value [n_scenes], d_humans_next [n_scenes][H][out], d_H [n_scenes][N][x_dim]: upstream gradients of the
  *   corresponding forward outputs (device; NULL = zero).  detach_graph = 1 reproduces
  *   StatePredictor(..., detach=True): only the heads receive gradients.

@@ -26,6 +26,7 @@ python tools/train_step_time.py --graph 2>/dev/null | grep "^{" > $O/${TAG}_trai
   for H in 5 19; do for B in 100 256 1024 4096; do for M in 0 1; do rm -rf /tmp/prof_bw; \
     BT_H=$H BT_B=$B BT_MODES=$M rocprofv3 --kernel-trace -d /tmp/prof_bw -o bw -- python $R/tools/backward_time.py > /dev/null 2>&1; \
     echo -n "H=$H batch=$B RGL_BACKWARD_MFMA=$M: "; python $R/tools/backward_sum.py $(find /tmp/prof_bw -name "*results.db" | head -1); done; done; done ) > $O/${TAG}_backward_by_batch.txt 2>&1
+python tools/envelope_timing.py > $O/${TAG}_envelope.txt 2>&1
 { python tools/gcn_trace.py; python tools/episodes.py; } > $O/${TAG}_path_g_and_episodes.txt 2>&1
 python tools/pcie_inclusive.py > $O/${TAG}_pcie_inclusive.txt 2>&1
 tail -5 $O/${TAG}_other_configs.log; cat $O/${TAG}_share_regime.txt | tail -14; cat $O/${TAG}_train_step.jsonl | cut -c1-200; cat $O/${TAG}_path_g_and_episodes.txt | tail -8; head -c 600 $O/${TAG}_bench_default.json
