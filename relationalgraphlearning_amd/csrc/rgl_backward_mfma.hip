@@ -1,29 +1,37 @@
-// rgl_backward_mfma.hip -- the training path's backward pass for LARGE batches, on the matrix cores.
-// (crowd_nav/utils/trainer.py:110-161,199-250 drive forward + backward over replay batches; the reference's own batch is 100,
-// the vector explorer of this build feeds thousands.)  rgl_backward.hip gives every scene a 1024-thread workgroup, a VALU loop per
-// product and a gradient slab of its own; its time per scene does not shrink with the batch.  Here the same gradients are computed
-// as a pipeline of tile kernels, every dense product an fp32 MFMA (v_mfma_f32_16x16x4_f32: exact products, fp32 accumulation,
-// the arithmetic of the VALU kernel up to summation order):
+// rgl_backward_mfma.hip -- MFMA tile kernels for (1) the training path's backward pass on LARGE batches and (2) the forward of models
+// outside the shipped shapes.
 //
-//   1. mlp_rows_kernel (forward only)   X = [w_r(robot); w_h(humans)]              one wave per 16-row tile
+// (1) crowd_nav/utils/trainer.py:110-161,199-250 drive forward + backward over replay batches; the reference's own batch is 100, the
+// vector explorer of this build feeds thousands.  rgl_backward.hip gives every scene a 1024-thread workgroup, a VALU loop per product
+// and a gradient slab of its own; its time per scene does not shrink with the batch.  Here the same gradients are computed as a
+// pipeline of tile kernels, every dense product an fp32 MFMA (v_mfma_f32_16x16x4_f32: exact products, fp32 accumulation -- the
+// arithmetic of the VALU kernel up to summation order):
+//
+//   1. mlp rows (forward only)          X = [w_r(robot); w_h(humans)]              one wave per 16-row tile
 //   2. graph_kernel<.., false>          H_L = layers(softmax(X Wa X^T), X)          one workgroup per scene, activations in its LDS
-//   3. mlp_rows_kernel (backward)       value head on H_L[:, 0] / motion head on H_L[:, 1:]  ->  dH_L, head gradients
+//   3. mlp rows (backward)              value head on H_L[:, 0] / motion head on H_L[:, 1:]  ->  dH_L, head gradients
 //   4. graph_kernel<.., true>           recomputes 2., back-propagates  ->  dX, and dWa / dW_l accumulated in REGISTERS over the
 //                                       workgroup's scenes (one slab per workgroup, not per scene)
-//   5. mlp_rows_kernel (backward)       w_r / w_h from dX (forward recomputed inside)
-//   6. reduce_ranges_kernel             slabs summed in wave order (fixed tile -> wave assignment: deterministic)
+//   5. mlp rows (backward)              w_r / w_h from dX (forward recomputed inside)
+//   6. reduce_ranges_kernel             slabs summed in a fixed order (fixed tile -> wave -> slab assignment: deterministic)
 //
-// The intermediates X, H_L, dH_L, dX travel through HBM ([S][N][32] floats each: 10 MB at 4096 scenes of 20 nodes, ~1.3 us of
-// traffic apiece) so that each kernel keeps one job; everything else lives in LDS / registers.
+// "mlp rows" is mlp2_rows_kernel<T0, T2> for the shipped narrow MLPs (in -> 64 -> out, in / out <= 32: weight gradients in
+// registers) and mlp_rows_kernel for everything else (any MLP of the ABI; the value head: one workgroup per tile).  The intermediates
+// X, H_L, dH_L, dX travel through HBM ([S][N][x_dim] floats each: 10 MB at 4096 scenes of 20 nodes, ~1.3 us of traffic apiece) so that
+// each kernel keeps one job; everything else lives in LDS / registers.  Below RGL_BACKWARD_MFMA_MIN scenes of an eager step
+// rgl_backward.hip runs.
 //
-// Envelope: embedded_gaussian or gaussian similarity, one adjacency for all layers, x_dim = 32, 1-3 layers, N <= 64; any embedding
-// MLPs and heads within the ABI limits.  Outside it -- and below RGL_BACKWARD_MFMA_MIN scenes -- rgl_backward.hip runs (return 1).
+// (2) launch_tiles_forward chains 1., 2. and head rows forward-only for models the shipped-shape kernels (rgl_scene.hip, rgl_fused.hip,
+// ...) do not cover -- other embedding MLPs, x_dim = 64 -- instead of the general VALU kernel; sibling scenes of a rollout share
+// their crowd's embedded rows.
+//
+// Envelope of both: embedded_gaussian or gaussian similarity, one adjacency for all layers, x_dim 32 | 64, 1-3 layers, N <= 64; any
+// embedding MLPs and heads within the ABI limits.  Outside it: return 1 (the caller falls back to rgl_backward.hip / the general kernel).
 //
 // Differentiated forward: graph_model.py:99-130, value_estimator.py:11-20, state_predictor.py:28-36, gcn.py:95-128.
 #include "rgl_mfma.h"
 
 #include <cstdlib>
-#include <cstring>
 
 namespace {
 
@@ -255,11 +263,16 @@ __global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs a) {
                     if ((block++ & (WV - 1)) != wv) continue;
                     f32x4 acc[1][2];
                     clear<1, 2>(acc);
-                    if (!first)                      // later tiles of the wave: the MFMAs accumulate on top of the slab's values
-                        each<1, 2>(acc, [&](int mo, int c, float, int, int nt, int r) {
-                            const int o = ot * 16 + mo, i = it * 16 + c;
-                            if (i < in && o < out) acc[0][nt][r] = gW[(size_t)o * in + i];
-                        });
+                    if (!first) {                    // later tiles of the wave: the MFMAs accumulate on top of the slab's values
+                        const int kq = lane >> 4;
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int o = ot * 16 + 4 * kq + r, i = (it + nt) * 16 + l16;
+                                if (i < in && o < out) acc[0][nt][r] = gW[(size_t)o * in + i];
+                            }
+                    }
                     mm<1, 2, 4>(acc, 4,
                                 [&](int mo, int k) { return dcur[k * dld + min(ot * 16 + mo, outp - 1)]; },
                                 [&](int k, int c) { return acts[k * ald + ioff + min(it * 16 + c, inp - 1)]; });
