@@ -169,16 +169,17 @@ __device__ __forceinline__ void stage_weights(const RowsJob& J, float* lds) {
 // B-operand reads and the transposed reads of the delta products both stay within two-way bank conflicts), then every wave works
 // through its own 16-row tiles without further barriers: every layer's activations of the tile in LDS ([16][act_ld]) together with
 // two delta buffers ([16][d_ld]).  A wave's first tile writes its gradient slab, later tiles add to it (L2-resident).
-__global__ __launch_bounds__(256) void mlp_rows_kernel(const RowsArgs a) {
+constexpr int kCoopWaves = 8;          // waves of a workgroup that shares one tile (mlp_rows_kernel, coop)
+__global__ __launch_bounds__(kCoopWaves * 64) void mlp_rows_kernel(const RowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15;
     const int ji = (a.n_jobs > 1 && (int)blockIdx.x >= a.job[1].wg_begin) ? 1 : 0;
     const RowsJob& J = a.job[ji];
     stage_weights(J, lds);
-    // coop (few tiles, wide layers: the value head): the four waves of the workgroup share ONE tile -- the column tiles of every
+    // coop (few tiles, wide layers: the value head): the eight waves of the workgroup share ONE tile -- the column tiles of every
     // product are dealt to them, with a workgroup barrier between phases -- instead of a tile each
     const bool coop = J.coop != 0;
-    const int WV = coop ? 4 : 1, wv = coop ? wave : 0;
+    const int WV = coop ? kCoopWaves : 1, wv = coop ? wave : 0;
     const int w = coop ? (int)blockIdx.x - J.wg_begin : ((int)blockIdx.x - J.wg_begin) * J.waves_per_wg + wave;
     if ((!coop && wave >= J.waves_per_wg) || w >= J.n_waves) return;
     auto sync = [&]() { if (coop) __syncthreads(); else wave_sync(); };
@@ -962,7 +963,9 @@ int launch_rows_kernel(K kernel, RowsArgs& ra, hipStream_t st) {
     }
     if (lds > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3(wgs), dim3(ra.job[0].kind ? kNarrowWaves * 64 : 256), lds, st, ra);
+    bool any_coop = false;
+    for (int j = 0; j < ra.n_jobs; ++j) any_coop |= ra.job[j].coop != 0;
+    hipLaunchKernelGGL(kernel, dim3(wgs), dim3(ra.job[0].kind ? kNarrowWaves * 64 : (any_coop ? kCoopWaves * 64 : 256)), lds, st, ra);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }
