@@ -513,6 +513,9 @@ struct GraphArgs {
     const float* Ws[3];
     float* slabs;                // [workgroups][(has w_a + L) * X * X]
     int S, N, skip, spc, hl_row0;
+    // floats between the robot rows of consecutive scenes / the human rows of consecutive crowds, in Xr / Xh and in dXr / dXh: X and
+    // (N - 1) X for the compact arrays above, N X for both when a scene's rows are one [N][X] block (Xh = Xr + X)
+    int xr_stride, xh_stride;
 };
 
 // sum / max over the 16 lanes of a DPP row, every lane gets it
@@ -603,8 +606,8 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
     auto prefetch = [&](int s) {
         const bool ok = s < a.S;
         const int sc = ok ? s : 0;
-        const float* xr = a.Xr + (size_t)sc * XW;
-        const float* xh = a.Xh + (size_t)(sc / a.spc) * (N - 1) * XW - XW;      // row i >= 1 at xh + i * XW
+        const float* xr = a.Xr + (size_t)sc * a.xr_stride;
+        const float* xh = a.Xh + (size_t)(sc / a.spc) * a.xh_stride - XW;       // row i >= 1 at xh + i * XW
         const float* dg = BWD ? a.dHL + (size_t)sc * N * XW : nullptr;
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
@@ -819,8 +822,8 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
                 mm<1, XTW, 8>(dx, XW / 4, [&](int i, int k) { return dG[min(fm + i, last) * FLD + k]; },
                               [&](int k, int j) { return Wa[(fn + j) * FLD + k]; });
             }
-            float* dxr = a.dXr + (size_t)s * XW;
-            float* dxh = a.dXh + (size_t)s * (N - 1) * XW - XW;
+            float* dxr = a.dXr + (size_t)s * a.xr_stride;
+            float* dxh = a.dXh + (size_t)s * a.xh_stride - XW;
 #pragma unroll
             for (int nt = 0; nt < XTW; ++nt)
 #pragma unroll
@@ -1104,6 +1107,7 @@ void graph_args(GraphArgs& ga, const RglGraph& g, int S, int N, int spc) {
     ga.w_a = g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN ? g.w_a : nullptr;
     for (int l = 0; l < g.num_layer; ++l) ga.Ws[l] = g.Ws[l];
     ga.S = S; ga.N = N; ga.skip = g.skip_connection ? 1 : 0; ga.spc = spc;
+    ga.xr_stride = g.x_dim; ga.xh_stride = (N - 1) * g.x_dim;
 }
 
 struct Taker {                 // carves 256-byte aligned pieces out of a workspace
@@ -1226,30 +1230,31 @@ int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
     const int N = H + 1, L = g.num_layer, X = g.x_dim;
     const bool has_v = vh && vh->n_layers > 0, has_m = mh && mh->n_layers > 0;
     const bool embedded = g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN;
-    const GraphPlan gpf = plan_graph(S, N, X, L, false), gp = plan_graph(S, N, X, L, true);
-    if (gp.grid < 1 || gpf.grid < 1) return 1;
+    const GraphPlan gpf = plan_graph(S, N, X, L, false), gp_full = plan_graph(S, N, X, L, true);
+    if (gp_full.grid < 1 || gpf.grid < 1) return 1;
 
     // gradient vector: w_r | w_h | w_a | Ws | value head | motion head
     const int n_wr = mlp_params(g.w_r), n_wh = mlp_params(g.w_h), n_graph = ((embedded ? 1 : 0) + L) * X * X;
     const int n_v = has_v ? mlp_params(*vh) : 0, n_m = has_m ? mlp_params(*mh) : 0;
     const int o_wr = 0, o_wh = n_wr, o_graph = o_wh + n_wh, o_v = o_graph + n_graph, o_m = o_v + n_v, n_params = o_m + n_m;
 
-    // workspace: X (robot rows | human rows) | H_L | dH_L | dX (robot rows | human rows) | slabs of the row jobs and of the graph kernel
+    // workspace: X | H_L | dH_L, each [S][N][X] | slabs of the row jobs and of the graph kernel.  dX replaces dH_L in place (a scene's
+    // upstream rows are in the workgroup's LDS long before its dX rows are written, and no other workgroup touches them)
     Taker ws{(char*)workspace};
     const size_t feat = (size_t)S * N * X;
-    float* Xr = ws.take<float>((size_t)S * X);
-    float* Xh = ws.take<float>((size_t)S * H * X);
+    float* Xs = ws.take<float>(feat);
     float* HL = ws.take<float>(feat);
     float* dHL = ws.take<float>(feat);
-    float* dXr = ws.take<float>((size_t)S * X);
-    float* dXh = ws.take<float>((size_t)S * H * X);
+    float* dXs = dHL;
     // one slab per wave: fewer waves per row job (more tiles each) when the caller's workspace -- sized for the per-scene kernel's
     // slabs, n_scenes x n_params floats -- is short (few scenes of many nodes)
     RowsJob j_wr, j_wh, j_v, j_m;
     float* g_slabs = nullptr;
     const size_t used_feat = ws.used;
+    GraphPlan gp = gp_full;
     for (int max_waves = 2048; max_waves >= 1; max_waves >>= 1) {
         ws.used = used_feat;
+        gp.grid = gp_full.grid < max_waves ? gp_full.grid : max_waves;
         plan_rows_job(j_wr, g.w_r, S, max_waves);
         plan_rows_job(j_wh, g.w_h, S * H, max_waves);
         if (has_v) plan_rows_job(j_v, *vh, S, max_waves);
@@ -1273,9 +1278,9 @@ int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
 
     // 1. embeddings
     j_wr.in = RowMap{(float*)robot, 1, 0, (long long)g.w_r.dims[0]};
-    j_wr.out = RowMap{Xr, 1, 0, (long long)X};
+    j_wr.out = RowMap{Xs, 1, 0, (long long)N * X};
     j_wh.in = RowMap{(float*)humans, H, g.w_h.dims[0], (long long)H * g.w_h.dims[0]};
-    j_wh.out = RowMap{Xh, H, X, (long long)H * X};
+    j_wh.out = RowMap{Xs + X, H, X, (long long)N * X};
     {
         RowsArgs ra{};
         ra.job[0] = j_wr; ra.job[1] = j_wh; ra.n_jobs = 2; ra.backward = 0;
@@ -1285,7 +1290,8 @@ int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
     // 2. graph forward
     GraphArgs ga;
     graph_args(ga, g, S, N, 1);
-    ga.Xr = Xr; ga.Xh = Xh; ga.dHL = dHL; ga.HL = HL; ga.dXr = dXr; ga.dXh = dXh; ga.slabs = g_slabs;
+    ga.Xr = Xs; ga.Xh = Xs + X; ga.dHL = dHL; ga.HL = HL; ga.dXr = dXs; ga.dXh = dXs + X; ga.slabs = g_slabs;
+    ga.xr_stride = ga.xh_stride = N * X;
     if (has_v || has_m) {
         const int rc = launch_graph(ga, X, L, false, gpf, st);
         if (rc) return rc;
@@ -1319,8 +1325,8 @@ int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
         int rc = launch_graph(ga, X, L, true, gp, st);
         if (rc) return rc;
         // 5. embeddings backward
-        j_wr.d_out = RowMap{dXr, 1, 0, (long long)X};
-        j_wh.d_out = RowMap{dXh, H, X, (long long)H * X};
+        j_wr.d_out = RowMap{dXs, 1, 0, (long long)N * X};
+        j_wh.d_out = RowMap{dXs + X, H, X, (long long)N * X};
         RowsArgs ra{};
         ra.job[0] = j_wr; ra.job[1] = j_wh; ra.n_jobs = 2; ra.backward = 1;
         rc = launch_rows(ra, st);

@@ -401,10 +401,10 @@ extern "C" size_t rgl_graph_forward_workspace_bytes(const RglGraph* graph, const
                                                     int n_scenes, int scenes_per_crowd, int H) {
     if (!graph || n_scenes < 1 || scenes_per_crowd < 1 || H < 1) return 0;
     const size_t scene = rgl::scene_forward_workspace_bytes(graph, value_head, motion_head, n_scenes, scenes_per_crowd, H);
-    if (scene) return scene;
     // outside the shipped shapes: the tile kernels (other embedding MLPs, x_dim = 64)
-    if (rgl::validate_graph(*graph, H)) return 0;
-    return rgl::tiles_forward_workspace_bytes(graph, value_head, motion_head, n_scenes, scenes_per_crowd, H, 0);
+    const size_t tiles = rgl::validate_graph(*graph, H) ? 0 : rgl::tiles_forward_workspace_bytes(graph, value_head, motion_head, n_scenes,
+                                                                                               scenes_per_crowd, H, 0);
+    return scene > tiles ? scene : tiles;
 }
 
 extern "C" int rgl_graph_forward_f32(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
@@ -417,6 +417,14 @@ extern "C" int rgl_graph_forward_f32(const RglGraph* graph, const RglMlp* value_
                                             humans_next);
         if (rc) return rc;
         if (n_scenes == 0) return RGL_OK;
+        {   // RGL_TILES_FORWARD=2 (tests): the tile kernels first, also for the shipped shapes
+            const char* e = getenv("RGL_TILES_FORWARD");
+            if (e && e[0] == '2') {
+                rc = rgl::launch_tiles_forward(graph, value_head, motion_head, robot, humans, n_scenes, scenes_per_crowd, H, nullptr,
+                                               value_out, humans_next, workspace, workspace_bytes, (hipStream_t)stream);
+                if (rc != 1) return rc;
+            }
+        }
         rc = rgl::launch_scene_forward(graph, value_head, motion_head, robot, humans, n_scenes, scenes_per_crowd, H, value_out,
                                        humans_next, workspace, workspace_bytes, (hipStream_t)stream);
         if (rc != 1) return rc;

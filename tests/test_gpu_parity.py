@@ -945,6 +945,48 @@ print("OK worst relative error %.2e (values, next humans, searches), %.2e (gradi
     report("X_dim 64 / other wr_dims, wh_dims on the tile kernels (general kernel refused): " + out.stdout.strip().splitlines()[-1])
 
 
+@pytest.mark.parametrize("H", [1, 2, 3, 14, 15, 16, 17, 30, 31, 32, 47, 48, 62, 63])
+def test_tile_kernels_across_node_counts(H, dev, monkeypatch):
+    """The tile kernels at every boundary of their tiling -- N = 2 .. 64 nodes: one, two or four node tiles, a last tile with a single
+    valid row (N = 17, 33), N a multiple of 4 or not, batches that are not a multiple of 16 rows -- forced on for the shipped shapes
+    (RGL_TILES_FORWARD=2, RGL_BACKWARD_MFMA=1): values and next humans against the oracle, every gradient against autograd over it."""
+    monkeypatch.setenv("RGL_TILES_FORWARD", "2")
+    monkeypatch.setenv("RGL_BACKWARD_MFMA", "1")
+    L = 3 if H in (2, 16, 31, 47) else 2
+    skip = H % 3 != 0
+    c = dict(L=L, sim="embedded_gaussian" if H % 2 else "gaussian", layerwise=False, skip=skip, flavour="trained")
+    g1, ve, sp = build_modules(c, dev)
+    B = 7 if H < 40 else 3
+    robot, humans = seeded_scenes(1300 + H, B, H)
+    r, h = robot.unsqueeze(1).to(dev), humans.to(dev)
+    cfg = orc.OracleConfig(num_layer=L, similarity=c["sim"], skip_connection=skip, layerwise_graph=False)
+    wv = torch.linspace(-1.0, 1.5, B).reshape(B, 1)
+    wm = torch.randn(B, H, 5, generator=torch.Generator().manual_seed(3))
+    for p_ in list(ve.parameters()) + list(sp.parameters()):
+        p_.grad = None
+    out = ve((r, h))
+    (out * wv.to(dev)).sum().backward()
+    _, nh = sp((r, h), None, detach=False)
+    (nh * wm.to(dev)).sum().backward()
+    gsd, vsd = _oracle_leafs(ve.graph_model.state_dict()), _oracle_leafs(ve.value_network.state_dict())
+    want = orc.value_estimator_forward(robot.unsqueeze(1), humans, gsd, vsd, cfg)
+    close(out.detach().cpu().numpy(), want.detach().numpy())
+    (want * wv).sum().backward()
+    for k, v in ve.graph_model.named_parameters():
+        _grad_close(v.grad, gsd[k].grad, "graph." + k)
+    for k, v in ve.value_network.named_parameters():
+        _grad_close(v.grad, vsd[k].grad, "value." + k)
+    gsd, msd = _oracle_leafs(sp.graph_model.state_dict()), _oracle_leafs(sp.human_motion_predictor.state_dict())
+    emb, _ = orc.rgl_forward(robot.unsqueeze(1), humans, gsd, cfg)
+    wantm = orc.mlp_forward(emb, orc.mlp_layers(msd, ""), last_relu=False)[:, 1:, :]
+    close(nh.detach().cpu().numpy(), wantm.detach().numpy())
+    (wantm * wm).sum().backward()
+    for k, v in sp.graph_model.named_parameters():
+        _grad_close(v.grad, gsd[k].grad, "sp_graph." + k)
+    for k, v in sp.human_motion_predictor.named_parameters():
+        _grad_close(v.grad, msd[k].grad, "motion." + k)
+
+
 def test_non_default_value_heads_keep_the_mfma_path(dev):
     """VERDICT r2 missing 3: a `value_network_dims` other than the shipped [32, 100, 100, 1] (path G: `planning_dims` other than
     [150, 100, 100, 1]) used to drop the whole search to the general VALU kernel.  robot_head_any_kernel (any depth <= 6, widths
