@@ -33,6 +33,17 @@
 
 #include <cstdlib>
 
+// The launchers of this file answer 1 for "not this path" -- and hipErrorInvalidValue is 1 as well (a launch that asks for more LDS
+// than a CU has): a runtime failure must never read as "not covered" and fall through to another kernel with the error still pending.
+#undef RGL_HIP_TRY
+#undef RGL_LAUNCH_CHECK
+#define RGL_HIP_TRY(expr)                                                          \
+    do {                                                                           \
+        hipError_t e__ = (expr);                                                   \
+        if (e__ != hipSuccess) return e__ == hipErrorInvalidValue ? (int)hipErrorLaunchFailure : (int)e__; \
+    } while (0)
+#define RGL_LAUNCH_CHECK() RGL_HIP_TRY(hipGetLastError())
+
 namespace {
 
 __device__ __forceinline__ void wave_sync() {         // LDS written by some lanes of the wave, read by others
@@ -944,12 +955,13 @@ void plan_rows_job(RowsJob& J, const RglMlp& m, int n_rows, int max_waves) {
         J.n_wgs = J.n_waves;
         return;
     }
-    const size_t per_wave = (size_t)J.wave_floats * sizeof(float);
-    const size_t room = (size_t)rgl::kLdsBytesPerCu - 1024 - (size_t)wl * sizeof(float);
-    // two workgroups per CU when they fit (half the LDS each), else one
-    int wpw = (int)((room / 2 - (size_t)wl * sizeof(float) / 2) / per_wave);
-    if (wpw < 1) wpw = (int)(room / per_wave);
-    J.waves_per_wg = wpw > 4 ? 4 : wpw;
+    // waves per workgroup: two workgroups per CU when a half of the LDS holds the weights and at least one wave's tile, else one
+    // workgroup; 0 = the MLP does not fit this kernel (the caller takes another path)
+    const long per_wave = (long)J.wave_floats * (long)sizeof(float), weights = (long)wl * (long)sizeof(float);
+    const long lds = (long)rgl::kLdsBytesPerCu - 1024;
+    long wpw = (lds / 2 - weights) / per_wave;
+    if (wpw < 1) wpw = (lds - weights) / per_wave;
+    J.waves_per_wg = wpw < 0 ? 0 : (wpw > 4 ? 4 : (int)wpw);
     J.n_wgs = J.waves_per_wg > 0 ? (J.n_waves + J.waves_per_wg - 1) / J.waves_per_wg : 0;
 }
 size_t rows_job_lds(const RowsJob& J) { return ((size_t)J.weight_floats + (size_t)J.waves_per_wg * J.wave_floats) * sizeof(float); }

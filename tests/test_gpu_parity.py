@@ -532,6 +532,23 @@ def test_scene_kernel_split_and_unsplit_forced(dev):
     report("scene kernel: split / unsplit forced over the predictor, similarity and forward-KAT tests: green")
 
 
+def test_tile_pipeline_forced_over_the_module_and_training_tests(dev):
+    """The tile kernels of rgl_backward_mfma.hip are chosen by shape (forward: models outside the shipped shapes) and by batch size
+    (backward: from 256 scenes).  Forced on for everything they cover -- RGL_TILES_FORWARD=2, RGL_BACKWARD_MFMA=1 -- the forward KATs,
+    the state-predictor tests, the non-default heads, every gradient test and the reference-trainer fixtures must stay green (this
+    run found the 6-layer head whose weights alone exceed one half of a CU's LDS)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RGL_TILES_FORWARD="2", RGL_BACKWARD_MFMA="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                          "-k", "forward_kats or state_predictor or non_default_value_heads or gradients or training_against or "
+                                "training_step_matches or target_model"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    report("tile kernels forced over the forward KATs, predictor, head, gradient and trainer-fixture tests: " + out.stdout.strip().splitlines()[-1])
+
+
 def test_tile_kernel_variant_forced(dev):
     """With RGL_CHILDREN_TILE_KERNEL=1 the MFMA tile kernel also handles what the shared-crowd kernels (rank-1: L=2,
     N<=32; deep: L in {2,3}, N<=56) take by default.  The switch is read once per process, so this runs in a child process."""
