@@ -44,6 +44,18 @@ def _require_device_tensor(t, what):
     return t.contiguous()
 
 
+def _flat_params(module):
+    """The parameters of `module` and its sub-modules, like list(module.parameters()) but without walking the module tree on every
+    call (nn.Module.parameters() re-discovers the sub-modules each time: ~115 such walks were a fifth of an eager training step's
+    host time).  The list of sub-modules is kept on the module (its structure is fixed after construction); the Parameter objects
+    are read from the sub-modules' own dicts each time, so replaced parameters and moved storages are seen."""
+    mods = module.__dict__.get("_rgl_submodules")
+    if mods is None:
+        mods = list(module.modules())
+        module.__dict__["_rgl_submodules"] = mods
+    return [p for m in mods for p in m._parameters.values() if p is not None]
+
+
 def _needs_grad(params):
     return torch.is_grad_enabled() and any(p.requires_grad for p in params)
 
@@ -229,7 +241,7 @@ class _PackCache:
                                   # compare it to notice a refresh -- or another module put in this one's place
 
     def get(self, modules, build):
-        key = tuple((p.data_ptr(), p._version, p.device.index) for m in modules for p in m.parameters())
+        key = tuple((p.data_ptr(), p._version, p.device.index) for m in modules for p in _flat_params(m))
         if key != self.key:
             keep = []
             self.value = build(keep, self.buffers)
@@ -352,7 +364,7 @@ class RGL(_GraphCore):
         robot, humans = state
         if robot.dim() != 3 or humans.dim() != 3:
             raise AssertionError("states must be (batch, agents, features)")
-        if _needs_grad(list(self.parameters())):
+        if _needs_grad(_flat_params(self)):
             out = _graph_apply(_Spec(self, want_H=True, want_A=True), robot.reshape(robot.shape[0], -1), humans)
         else:
             out = graph_forward(self.descriptor(), None, None, robot.reshape(robot.shape[0], -1), humans,
@@ -374,7 +386,7 @@ class ValueEstimator(nn.Module):
     def forward(self, state):
         robot, humans = state
         assert len(robot.shape) == 3 and len(humans.shape) == 3
-        if _needs_grad(list(self.parameters())):
+        if _needs_grad(_flat_params(self)):
             spec = _Spec(self.graph_model, value_seq=self.value_network, value_desc=self.head_descriptor)
             return _graph_apply(spec, robot.reshape(robot.shape[0], -1), humans)["value"]
         out = graph_forward(self.graph_model.descriptor(), self.head_descriptor(), None,
@@ -399,7 +411,7 @@ class StatePredictor(nn.Module):
     def forward(self, state, action, detach=False):
         robot, humans = state
         assert len(robot.shape) == 3 and len(humans.shape) == 3
-        if _needs_grad(list(self.parameters())):
+        if _needs_grad(_flat_params(self)):
             spec = _Spec(self.graph_model, motion_seq=self.human_motion_predictor, motion_desc=self.head_descriptor,
                          detach_graph=bool(detach))
             out = _graph_apply(spec, robot.reshape(robot.shape[0], -1), humans)
@@ -506,7 +518,7 @@ class ValueNetwork(_GraphCore):
         state = state_input[0] if isinstance(state_input, tuple) else state_input
         state = _require_device_tensor(state, "rotated joint states")
         d = self.self_state_dim
-        if _needs_grad(list(self.parameters())):
+        if _needs_grad(_flat_params(self)):
             spec = _Spec(self, value_seq=self.value_net, value_desc=self.head_descriptor, want_A=True)
             out = _graph_apply(spec, state[:, 0, :d].contiguous(), state[:, :, d:].contiguous())
         else:
