@@ -196,3 +196,28 @@ def test_empty_crowd_takes_the_reference_greedy_action():
     for row, want in zip(fx["greedy.robot"], fx["greedy.action"]):
         a = pol.predict(JS(row, []))
         assert a == pol.action_space[int(want)]
+
+
+def test_flat_params_follow_the_module_like_parameters_does():
+    """nets._flat_params (the descriptor caches' view of a module's parameters: a cached sub-module list, parameters read from the
+    sub-modules' dicts on every call) against nn.Module.parameters(): same objects in the same order for every module of both
+    policies, after a deep copy (the copy must list ITS parameters), after a parameter object was replaced, and after pickling."""
+    import copy
+    import io
+    from relationalgraphlearning_amd import nets
+    pol = make_mprl_policy("trained", 1)
+    gcn = make_gcn_policy()
+    for mod in (pol.value_estimator, pol.state_predictor, pol.value_estimator.graph_model, gcn.model):
+        assert [id(p) for p in nets._flat_params(mod)] == [id(p) for p in mod.parameters()]
+        assert [id(p) for p in nets._flat_params(mod)] == [id(p) for p in mod.parameters()]          # from the cached list
+        twin = copy.deepcopy(mod)
+        assert [id(p) for p in nets._flat_params(twin)] == [id(p) for p in twin.parameters()]
+        assert not set(id(p) for p in nets._flat_params(twin)) & set(id(p) for p in mod.parameters())
+        buf = io.BytesIO()
+        torch.save(mod, buf)
+        buf.seek(0)
+        back = torch.load(buf, weights_only=False)
+        assert [id(p) for p in nets._flat_params(back)] == [id(p) for p in back.parameters()]
+    ve = pol.value_estimator
+    ve.value_network[0].weight = torch.nn.Parameter(torch.zeros_like(ve.value_network[0].weight))      # a replaced Parameter object
+    assert [id(p) for p in nets._flat_params(ve)] == [id(p) for p in ve.parameters()]
