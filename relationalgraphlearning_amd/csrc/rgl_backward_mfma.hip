@@ -160,19 +160,22 @@ struct RowsArgs {
     int n_jobs, backward;
 };
 
-// weights and biases of the job's MLP -> the workgroup's LDS (ends with a barrier)
-__device__ __forceinline__ void stage_weights(const RowsJob& J, float* lds) {
+// weights and bias of layer l of the job's MLP -> the workgroup's LDS
+__device__ __forceinline__ void stage_layer(const RowsJob& J, float* lds, int l) {
     const RglMlp& m = J.m;
-    for (int l = 0; l < m.n_layers; ++l) {
-        const int in = m.dims[l], out = m.dims[l + 1], ld = J.w_ld[l];
-        float* Wl = lds + J.w_lds[l];
-        const float* __restrict__ W = m.weight[l];
-        // thread (k0 = t / 32, c = t % 32): columns c, c + 32, .. of rows k0, k0 + 8, ..   (no divisions in the loops)
-        for (int c = threadIdx.x & 31; c < out; c += 32)
-            gather<8>(in, threadIdx.x >> 5, blockDim.x >> 5, [&](int k) { return W[k * out + c]; },
-                      [&](int k, float v) { Wl[k * ld + c] = v; });
-        for (int c = threadIdx.x; c < out; c += blockDim.x) lds[J.b_lds[l] + c] = m.bias[l][c];
-    }
+    const int in = m.dims[l], out = m.dims[l + 1], ld = J.w_ld[l];
+    float* Wl = lds + J.w_lds[l];
+    const float* __restrict__ W = m.weight[l];
+    // thread (k0 = t / 32, c = t % 32): columns c, c + 32, .. of rows k0, k0 + 8, ..   (no divisions in the loops)
+    for (int c = threadIdx.x & 31; c < out; c += 32)
+        gather<8>(in, threadIdx.x >> 5, blockDim.x >> 5, [&](int k) { return W[k * out + c]; },
+                  [&](int k, float v) { Wl[k * ld + c] = v; });
+    for (int c = threadIdx.x; c < out; c += blockDim.x) lds[J.b_lds[l] + c] = m.bias[l][c];
+}
+// all layers (ends with a barrier); a job whose layers are staged one at a time (coop == 2) stages nothing here
+__device__ __forceinline__ void stage_weights(const RowsJob& J, float* lds) {
+    if (J.coop != 2)
+        for (int l = 0; l < J.m.n_layers; ++l) stage_layer(J, lds, l);
     __syncthreads();
 }
 
@@ -189,7 +192,9 @@ __global__ __launch_bounds__(kCoopWaves * 64) void mlp_rows_kernel(const RowsArg
     stage_weights(J, lds);
     // coop (few tiles, wide layers: the value head): the eight waves of the workgroup share ONE tile -- the column tiles of every
     // product are dealt to them, with a workgroup barrier between phases -- instead of a tile each
-    const bool coop = J.coop != 0;
+    // (coop == 2: the MLP's weights do not fit LDS next to the tile -- path G's 150-100-100-1 head is 121 KB -- and every layer is
+    // staged when it is needed, forward and again backward: a tile uses each weight once per direction anyway)
+    const bool coop = J.coop != 0, per_layer = J.coop == 2;
     const int WV = coop ? kCoopWaves : 1, wv = coop ? wave : 0;
     const int w = coop ? (int)blockIdx.x - J.wg_begin : ((int)blockIdx.x - J.wg_begin) * J.waves_per_wg + wave;
     if ((!coop && wave >= J.waves_per_wg) || w >= J.n_waves) return;
@@ -220,6 +225,10 @@ __global__ __launch_bounds__(kCoopWaves * 64) void mlp_rows_kernel(const RowsArg
             const float* W = lds + J.w_lds[l];
             const float* b = lds + J.b_lds[l];
             const int wld = J.w_ld[l];
+            if (per_layer) {              // the previous layer's reads of the region ended at its barrier
+                stage_layer(J, lds, l);
+                __syncthreads();
+            }
             for (int jt = 2 * wv; jt * 16 < out; jt += 2 * WV) {
                 f32x4 acc[1][2];
 #pragma unroll
@@ -261,6 +270,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void mlp_rows_kernel(const RowsArg
             const bool relu = (l != L - 1) || m.last_relu;
             const float* W = lds + J.w_lds[l];
             const int wld = J.w_ld[l];
+            if (per_layer && (l > 0 || J.need_din)) stage_layer(J, lds, l);      // read after the barriers below
             if (relu) {
                 for (int c = c4; c < out; c += 4)
                     if (!(acts[rr * ald + ooff + c] > 0.f)) dcur[rr * dld + c] = 0.f;
@@ -302,6 +312,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void mlp_rows_kernel(const RowsArg
             }
             if (l > 0 || J.need_din) {
                 // delta_in[row][i] = sum_o delta[row][o] W[i][o]
+                if (per_layer) __syncthreads();
                 for (int jt = 2 * wv; jt * 16 < in; jt += 2 * WV) {
                     f32x4 acc[1][2];
                     clear<1, 2>(acc);
@@ -955,6 +966,23 @@ void plan_rows_job(RowsJob& J, const RglMlp& m, int n_rows, int max_waves) {
         J.n_wgs = J.n_waves;
         return;
     }
+    {   // all layers do not fit next to a tile (path G's head): a workgroup per tile, one layer's weights in LDS at a time
+        int wmax = 0, bmax = 0;
+        for (int l = 0; l < m.n_layers; ++l) {
+            const int wf = (m.dims[l] * J.w_ld[l] + 3) & ~3, bf = (m.dims[l + 1] + 3) & ~3;
+            wmax = wf > wmax ? wf : wmax;
+            bmax = bf > bmax ? bf : bmax;
+        }
+        if (((size_t)wl + J.wave_floats) * sizeof(float) > (size_t)rgl::kLdsBytesPerCu - 1024 &&
+            ((size_t)wmax + bmax + J.wave_floats) * sizeof(float) <= (size_t)rgl::kLdsBytesPerCu - 1024) {
+            J.coop = 2;
+            for (int l = 0; l < m.n_layers; ++l) { J.w_lds[l] = 0; J.b_lds[l] = wmax; }
+            J.weight_floats = wmax + bmax;
+            J.waves_per_wg = 1;
+            J.n_wgs = J.n_waves;
+            return;
+        }
+    }
     // waves per workgroup: two workgroups per CU when a half of the LDS holds the weights and at least one wave's tile, else one
     // workgroup; 0 = the MLP does not fit this kernel (the caller takes another path)
     const long per_wave = (long)J.wave_floats * (long)sizeof(float), weights = (long)wl * (long)sizeof(float);
@@ -1223,14 +1251,14 @@ int launch_tiles_forward(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
 // ------------------------------------------------------------------------------------------------
 // 1 = not this path (outside the envelope, below the batch threshold, or the caller's workspace cannot hold the intermediates):
 // the per-scene VALU kernel of rgl_backward.hip runs.  Slab order of grad_out as documented in rgl_hip.h.
-int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* mh, const float* robot, const float* humans,
+static int backward_tiles(const RglGraph* graph, const RglMlp* vh, const RglMlp* mh, const float* robot, const float* humans,
                          int S, int H, int detach_graph, const float* d_value, const float* d_humans_next, const float* d_H,
                          float* grad_out, void* workspace, size_t workspace_bytes, hipStream_t st, int only_choice) {
     // RGL_BACKWARD_MFMA = 0: never, 1: whenever the structure allows; default: by batch size, and whenever the per-scene kernel cannot
     // hold a scene in LDS (only_choice)
     const int mode = env_int("RGL_BACKWARD_MFMA", -1);
     if (mode == 0) return 1;
-    if (mode != 1 && !only_choice && S < env_int("RGL_BACKWARD_MFMA_MIN", 256)) {
+    if (mode < 1 && !only_choice && S < env_int("RGL_BACKWARD_MFMA_MIN", 256)) {
         // Below the threshold the pipeline's device time is still the shorter one (84 vs 94 us at 100 scenes of 6 nodes, 95 vs 125 us
         // at 20 nodes), but it is seven launches instead of two and an eager training step is bound by the host.  While the stream
         // is being captured into a hipGraph only the device time counts.
@@ -1358,6 +1386,17 @@ int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
     hipLaunchKernelGGL(reduce_ranges_kernel, dim3((n_params + 31) / 32), dim3(256), 0, st, rr, grad_out);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
+}
+
+
+// 1 = not this path (outside the envelope, below the batch threshold, or the caller's workspace cannot hold the intermediates): the
+// per-scene VALU kernel of rgl_backward.hip runs -- unless RGL_BACKWARD_MFMA=2 (tests), which turns "not this path" into an error.
+int launch_backward_mfma(const RglGraph* graph, const RglMlp* vh, const RglMlp* mh, const float* robot, const float* humans,
+                         int S, int H, int detach_graph, const float* d_value, const float* d_humans_next, const float* d_H,
+                         float* grad_out, void* workspace, size_t workspace_bytes, hipStream_t st, int only_choice) {
+    const int rc = backward_tiles(graph, vh, mh, robot, humans, S, H, detach_graph, d_value, d_humans_next, d_H, grad_out, workspace,
+                                  workspace_bytes, st, only_choice);
+    return (rc == 1 && env_int("RGL_BACKWARD_MFMA", -1) == 2) ? RGL_ERR_BAD_MODE : rc;
 }
 
 }  // namespace rgl

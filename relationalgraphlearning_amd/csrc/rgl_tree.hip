@@ -9,6 +9,8 @@
 #include "rgl_children.h"
 #include "rgl_tail.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -555,9 +557,15 @@ extern "C" int gcn_predict_f32(const GcnPlanner* planner, const float* robot, co
     // inputs, 64-32 embeddings, head 150-100-100-1), else the general kernel
     rc = rgl::launch_scene_forward(&pl.graph, &pl.value_head, nullptr, self6, hum7, (int)S, 1, H, value, nullptr, fwd_ws, fwd_bytes,
                                    st);
-    if (rc == 1)
+    if (rc == 1)      // other embedding MLPs (x_dim 32: what this workspace is sized for): the tile kernels of rgl_backward_mfma.hip
+        rc = rgl::launch_tiles_forward(&pl.graph, &pl.value_head, nullptr, self6, hum7, (int)S, 1, H, nullptr, value, nullptr, fwd_ws,
+                                       fwd_bytes, st);
+    if (rc == 1) {
+        const char* e = getenv("RGL_REQUIRE_MFMA_FORWARD");          // tests: refuse instead of running the general VALU kernel
+        if (e && e[0] == '1') return RGL_ERR_BAD_MODE;
         rc = rgl::launch_generic_forward(&pl.graph, &pl.value_head, nullptr, self6, hum7, (int)S, 1, H, nullptr, nullptr, value,
                                          nullptr, st);
+    }
     if (rc) return rc;
     hipLaunchKernelGGL(gcn_argmax_kernel, grid_for((long long)B * kRootLanes, 256), dim3(256), 0, st, robot, reward, value, B, A, pl.gamma,
                        pl.time_step, action_values, best_action);

@@ -953,9 +953,30 @@ for X, wr, wh, H, L, D, B, sim in ((64, [64, 64], [64, 64], 5, 2, 2, 6, "embedde
             err = float((v.grad.cpu() - sd[k].grad).abs().max()) / scale
             assert err < 2e-4, (X, wr, wh, k, err)
             worst_g = max(worst_g, err)
-print("OK worst relative error %.2e (values, next humans, searches), %.2e (gradients)" % (worst, worst_g))
+# path G with other embedding MLPs (x_dim 32): its B x 81 rotated scenes on the tile kernels
+for wr, wh, H, B in (([128, 32], [48, 32], 5, 6), ([32], [64, 64, 32], 19, 3)):
+    cfgp = policy_config("gcn", gcn__wr_dims=wr, gcn__wh_dims=wh)
+    torch.manual_seed(H)
+    gp = rga.GCN()
+    gp.configure(cfgp)
+    with torch.no_grad():
+        for n_, p_ in gp.model.named_parameters():
+            if n_ in ("w_a", "w1", "w2"):
+                p_.mul_(1.0 / 32 ** 0.5)
+    gp.time_step = 0.25
+    gp.set_phase("test"); gp.set_device(dev)
+    gp.build_action_space(1.0)
+    robot, humans = seeded_scenes(1700 + H, B, H)
+    vals, best = gp.gcn_search().search(robot.to(dev), humans.to(dev))
+    ob, ovv = orc.gcn_predict_batched(robot.numpy(), humans.numpy(), {k: v.detach().cpu() for k, v in gp.model.state_dict().items()}, orc.OracleConfig())
+    eg = float(np.abs(vals.cpu().numpy().astype(np.float64) - ovv).max()) / max(1.0, float(np.abs(ovv).max()))
+    assert eg < 1e-4, ("path G", wr, wh, eg)
+    assert (best.cpu().numpy().astype(np.int64) == ob).all() or eg < 1e-6
+    worst = max(worst, eg)
+    print("path G ok:", wr, wh, H, eg, flush=True)
+print("OK worst relative error %.2e (values, next humans, searches, path G), %.2e (gradients)" % (worst, worst_g))
 '''
-    env = dict(os.environ, RGL_REQUIRE_MFMA_CHILDREN="1", RGL_REQUIRE_MFMA_FORWARD="1", RGL_BACKWARD_MFMA="1")
+    env = dict(os.environ, RGL_REQUIRE_MFMA_CHILDREN="1", RGL_REQUIRE_MFMA_FORWARD="1", RGL_BACKWARD_MFMA="2")
     out = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
@@ -1671,7 +1692,7 @@ def test_gradients_on_the_mfma_backward(H, L, sim, skip, flavour, B, dev, monkey
     """The tile pipeline of rgl_backward_mfma.hip (the large-batch backward: MFMA row kernels for the MLPs, one wave per scene for the
     graph block) forced on for the small oracle-autograd cases of the test above (it is chosen by batch size otherwise), and for the
     RGL-output / path-G gradients."""
-    monkeypatch.setenv("RGL_BACKWARD_MFMA", "1")
+    monkeypatch.setenv("RGL_BACKWARD_MFMA", "2")        # 2: an error instead of the per-scene kernel where the pipeline says "not mine"
     test_gradients_value_estimator_and_state_predictor(H, L, sim, skip, flavour, B, False, dev)
     test_gradients_rgl_output_and_path_g(dev)
 
