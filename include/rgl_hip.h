@@ -138,7 +138,8 @@ int rgl_graph_forward_f32(const RglGraph* graph, const RglMlp* value_head, const
  * LDS of a CU: N = 64 with deep MLPs) and, for embedded_gaussian / gaussian with one adjacency, x_dim 32 | 64, 1-3 layers,
  * N <= 64, a pipeline of MFMA tile kernels (rgl_backward_mfma.hip) -- taken from 256 scenes, whenever `stream` is being
  * captured into a hipGraph, and where the per-scene kernel does not fit.  Environment: RGL_BACKWARD_MFMA = 0 | 1 forces a
- * path, RGL_BACKWARD_MFMA_MIN moves the threshold.  Both are deterministic (fixed summation order per shape).
+ * path (2: RGL_ERR_BAD_MODE instead of the per-scene kernel where the pipeline does not apply), RGL_BACKWARD_MFMA_MIN moves the
+ * threshold.  Both are deterministic (fixed summation order per shape).
  *   d_value [n_scenes], d_humans_next [n_scenes][H][out], d_H [n_scenes][N][x_dim]: upstream gradients of the
  *   corresponding forward outputs (device; NULL = zero).  detach_graph = 1 reproduces
  *   StatePredictor(..., detach=True): only the heads receive gradients.
