@@ -1262,8 +1262,9 @@ static int backward_tiles(const RglGraph* graph, const RglMlp* vh, const RglMlp*
         // Below the threshold the pipeline's device time is still the shorter one (84 vs 94 us at 100 scenes of 6 nodes, 95 vs 125 us
         // at 20 nodes), but it is seven launches instead of two and an eager training step is bound by the host.  While the stream
         // is being captured into a hipGraph only the device time counts.
+        // (never asked of the legacy NULL stream: querying it while another stream captures would invalidate that capture)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusActive) return 1;
+        if (!st || hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusActive) return 1;
     }
     const RglGraph& g = *graph;
     if (!tiles_cover(g, H)) return 1;
