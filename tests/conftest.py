@@ -16,6 +16,11 @@ PARITY_REPORT = []
 
 
 def pytest_terminal_summary(terminalreporter):
+    mod = sys.modules.get("tests.test_gpu_parity") or sys.modules.get("test_gpu_parity")
+    worst = getattr(mod, "GRAD_WORST", None)
+    if worst and worst["rel"] > 0.0:
+        PARITY_REPORT.append("gradients: worst deviation from autograd over the oracle %.2e of the gradient's largest entry (%s); "
+                             "asserted 2e-4 and, regression level, 2e-5" % (worst["rel"], worst["name"]))
     if PARITY_REPORT:
         terminalreporter.write_sep("-", "parity report")
         for line in PARITY_REPORT:

@@ -19,6 +19,12 @@ from tests.helpers import make_mprl_policy, make_gcn_policy, JS
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+# Regression-level bounds beside the north-star one (VERDICT r3 "weak" 1): the kernels measure 1.5e-8 (f32 values), 1.2e-6 (f16
+# contractions) and 2e-6 of the largest entry (gradients) -- a regression that costs two digits must not pass at 1e-4.  Every bound
+# below is >= 8x what is measured today; the north-star assertion stays next to it.
+REG_F32 = 1e-6
+REG_F16 = 1e-5
+REG_GRAD = 2e-5
 
 
 @pytest.fixture(scope="module")
@@ -27,13 +33,16 @@ def dev():
     return torch.device("cuda:0")
 
 
-def close(a, b, tol=TOL):
+def close(a, b, tol=TOL, reg=None):
+    """North-star bound `tol` (relative to max(1, max|ref|)); `reg`: the regression-level bound on the same quantity."""
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
     scale = max(1.0, float(np.abs(b).max()))
     err = float(np.abs(a - b).max())
     assert err <= tol * scale, (err, scale)
+    if reg is not None:
+        assert err <= reg * scale, ("regression-level bound", err, reg, scale)
     return err
 
 
@@ -1492,30 +1501,118 @@ def _oracle_at_size(H, L, D, B, robot, humans):
     return _ORACLE_AT_SIZE[key]
 
 
-@pytest.mark.parametrize("tag,H,L,D,B,contraction,tol", [
+AT_SIZE_CASES = [
     ("configs[1] in full (N=5)", 4, 2, 1, 512, "f32", TOL),
     ("configs[1] in full (N=6)", 5, 2, 1, 512, "f32", TOL),
     ("configs[2] in full", 19, 2, 2, 2048, "f32", TOL),
     ("configs[3] per-GPU share", 19, 2, 3, 512, "f32", TOL),
+    ("configs[3] in full (4096 roots, depth 3)", 19, 2, 3, 4096, "f32", TOL),
     ("configs[4] per-GPU share in full (256 roots)", 49, 3, 2, 256, "f32", TOL),
-    ("configs[4] per-GPU share in full, f16 contractions", 49, 3, 2, 256, "f16", 1e-3)])
-def test_baseline_workloads_against_the_oracle_at_size(tag, H, L, D, B, contraction, tol, dev):
-    """The BASELINE workloads with bench.py's own scenes and weights against the batched CPU oracle: every value within
-    tolerance, decisions identical except on numerical ties.  configs[2] is checked in full (2048 roots, 510 k value
-    forwards, ~20 s of CPU time on the GPU box); configs[4] at the full 256-root share each GPU is benchmarked at (round 3; the
-    oracle walks it in chunks of 64 roots -- 1.3 MFLOP per forward there -- and its outputs are shared by the f32 / f16 cases)."""
+    ("configs[4] per-GPU share in full, f16 contractions", 49, 3, 2, 256, "f16", 1e-3)]
+
+
+def _bench_policy(L, D, H, contraction, dev):
     import bench
 
     class Args:
         pass
     Args.layers, Args.depth, Args.width, Args.humans, Args.contraction = L, D, 2, H, contraction
-    pol = bench.make_policy(Args, dev)
+    return bench.make_policy(Args, dev)
+
+
+@pytest.mark.parametrize("tag,H,L,D,B,contraction,tol", AT_SIZE_CASES)
+def test_baseline_workloads_against_the_oracle_at_size(tag, H, L, D, B, contraction, tol, dev):
+    """The BASELINE workloads with bench.py's own scenes and weights against the batched CPU oracle: every value within
+    tolerance, decisions identical except on numerical ties.  configs[2] is checked in full (2048 roots, 510 k value
+    forwards, ~20 s of CPU time on the GPU box); configs[4] at the full 256-root share each GPU is benchmarked at (round 3; the
+    oracle walks it in chunks of 64 roots -- 1.3 MFLOP per forward there -- and its outputs are shared by the f32 / f16 cases);
+    configs[3] also IN FULL (round 4: 4096 roots at depth 3 -- 16 parents per CU at the deepest level, another dealing plan than
+    its 512-root share; 2.4 M value forwards for the oracle, ~70 s of CPU time).
+    Two bounds: the north star's (1e-4; 1e-3 with f16 contractions) and the regression-level one (REG_F32 / REG_F16)."""
+    import bench
+    pol = _bench_policy(L, D, H, contraction, dev)
     robot, humans = bench.synth_scenes(1000, B, H)
     act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
     oracle_out, v1 = _oracle_at_size(H, L, D, B, robot, humans)
-    err = close(val.cpu().numpy(), oracle_out[1].numpy(), tol=tol)
+    err = close(val.cpu().numpy(), oracle_out[1].numpy(), tol=tol, reg=REG_F32 if contraction == "f32" else REG_F16)
     check_decisions("at size, %s" % tag, act, val, oracle_out, [{"value1": v1}], tol)
     report("at size, %s: max |dV| = %.2e absolute (max |V| = %.3f)" % (tag, err, float(oracle_out[1].abs().max())))
+
+
+def test_configs3_in_full_properties(dev):
+    """configs[3] in full on one GPU (4096 roots, depth 3): run-to-run determinism, root-permutation equivariance (bit-exact), the
+    chosen value = the maximum of the reported root values, and the first 512 roots of the full batch searched on their own -- the
+    per-GPU share's launch shapes, another dealing plan at every level -- agree to rounding."""
+    import bench
+    B, H = 4096, 19
+    pol = _bench_policy(2, 3, H, "f32", dev)
+    robot, humans = bench.synth_scenes(1000, B, H)
+    r, h = robot.to(dev), humans.to(dev)
+    a1, v1 = pol.predict_batch(r, h)
+    a1, v1 = a1.clone(), v1.clone()
+    out = pol.tree_search().last
+    assert torch.equal(out["root_values"].max(dim=1).values, out["best_value"])
+    a2, v2 = pol.predict_batch(r, h)
+    assert torch.equal(a1, a2) and torch.equal(v1, v2)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).to(dev)
+    a3, v3 = pol.predict_batch(r[perm].contiguous(), h[perm].contiguous())
+    assert torch.equal(a3, a1[perm]) and torch.equal(v3, v1[perm])
+    a4, v4 = pol.predict_batch(r[:512].contiguous(), h[:512].contiguous())
+    dv = float((v4 - v1[:512]).abs().max())
+    assert dv <= REG_F32, dv
+    differ = a4 != a1[:512]
+    assert int(differ.sum()) <= 2, int(differ.sum())
+    report("configs[3] in full: deterministic, root-permutation equivariant (bit-exact), 512-root share vs the same roots inside "
+           "the 4096-root batch: max |dV| = %.1e, %d decisions differ" % (dv, int(differ.sum())))
+
+
+# kernel family forced for a whole process -> (environment, roots of configs[2] it is run on)
+FORCED_FAMILIES = {
+    "two-stage pair (children_rank1_kernel + robot_head_kernel)": ({"RGL_CHILDREN_TWO_STAGE": "1"}, 2048),
+    "fused kernel without its tail (stand-alone select / back-up / root kernels)": ({"RGL_FUSED_NO_TAIL": "1"}, 2048),
+    "MFMA tile kernel (children_graph_kernel)": ({"RGL_CHILDREN_TILE_KERNEL": "1"}, 2048),
+    "fused kernel forced at every launch size": ({"RGL_CHILDREN_FUSED": "1"}, 2048),
+    "general VALU kernel": ({"RGL_FORCE_GENERIC": "1"}, 256),
+}
+
+
+@pytest.mark.parametrize("family", list(FORCED_FAMILIES), ids=lambda f: f.split(" (")[0].replace(" ", "_"))
+def test_forced_kernel_families_at_size(family, dev, tmp_path):
+    """DESIGN.md section 5 says every kernel family serves the whole path; the driver's `pytest -m gpu` only sees the default
+    dispatch.  Here the at-size configs[2] oracle check (bench.py's scenes and weights, all 2048 roots; the first 256 for the
+    general VALU kernel) is re-run in a child process under each forcing switch -- the switches are read once per process.  The
+    oracle's outputs are computed once in this process (memoised with the default-dispatch test) and handed over as a file."""
+    import subprocess
+    import sys
+    import bench
+    env_add, B = FORCED_FAMILIES[family]
+    H, L, D = 19, 2, 2
+    robot, humans = bench.synth_scenes(1000, 2048, H)
+    oracle_out, v1 = _oracle_at_size(H, L, D, 2048, robot, humans)
+    ref = str(tmp_path / "oracle_c2.npz")
+    np.savez(ref, oa=oracle_out[0].numpy()[:B], ov=oracle_out[1].numpy()[:B], orv=oracle_out[2].numpy()[:B],
+             okept=oracle_out[3].numpy()[:B], v1=v1.numpy()[:B])
+    code = r'''
+import sys, numpy as np, torch
+import bench
+from tests import test_gpu_parity as T
+ref = np.load(sys.argv[1])
+B = int(sys.argv[2])
+dev = torch.device("cuda:0")
+pol = T._bench_policy(2, 2, 19, "f32", dev)
+robot, humans = bench.synth_scenes(1000, 2048, 19)
+act, val = pol.predict_batch(robot[:B].to(dev), humans[:B].to(dev), roots_are_joint_states=True)
+err = T.close(val.cpu().numpy(), ref["ov"], tol=T.TOL, reg=T.REG_F32)
+oracle_out = [torch.tensor(ref[k]) for k in ("oa", "ov", "orv", "okept")]
+n = T.check_decisions("forced", act, val, oracle_out, [{"value1": torch.tensor(ref["v1"])}], T.TOL)
+print("OK max |dV| = %.2e, %d of %d decisions differ (ties in the oracle)" % (err, n, B))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code, ref, str(B)], cwd=root, env=dict(os.environ, **env_add), capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    report("configs[2] at size (%d roots) with %s forced (%s): %s" % (B, family, " ".join("%s=%s" % kv for kv in env_add.items()),
+                                                                      out.stdout.strip().splitlines()[-1]))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -1608,11 +1705,19 @@ def _oracle_leafs(module_sd):
     return {k: v.detach().cpu().clone().requires_grad_(True) for k, v in module_sd.items()}
 
 
-def _grad_close(got, want, name, tol=2e-4):
+GRAD_WORST = {"rel": 0.0, "name": ""}
+
+
+def _grad_close(got, want, name, tol=2e-4, reg=REG_GRAD):
+    """`tol`: the bound of rounds 1-3 (relative to the gradient's largest entry); `reg`: the regression-level bound (round 4)."""
     got, want = got.detach().cpu().numpy().astype(np.float64), want.detach().numpy().astype(np.float64)
     scale = max(1e-3, float(np.abs(want).max()))
     err = float(np.abs(got - want).max())
+    if err / scale > GRAD_WORST["rel"]:
+        GRAD_WORST["rel"], GRAD_WORST["name"] = err / scale, name
     assert err <= tol * scale, (name, err, scale)
+    if reg is not None:
+        assert err <= reg * scale, ("regression-level bound", name, err, reg, scale)
 
 
 @pytest.mark.parametrize("H,L,sim,skip,flavour,B,layerwise", [
@@ -1728,7 +1833,7 @@ def test_mfma_backward_at_size(H, L, B, dev, monkeypatch):
     for k in tiles:
         assert torch.equal(tiles[k], again[k]), k
         if valu is not None:
-            _grad_close(tiles[k], valu[k].cpu(), "tiles vs per-scene kernel " + k, tol=5e-5)
+            _grad_close(tiles[k], valu[k].cpu(), "tiles vs per-scene kernel " + k, tol=5e-5, reg=None)
     gsd, vsd = _oracle_leafs(ve.graph_model.state_dict()), _oracle_leafs(ve.value_network.state_dict())
     (orc.value_estimator_forward(robot.unsqueeze(1), humans, gsd, vsd, cfg) * wv).sum().backward()
     worst = 0.0
