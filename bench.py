@@ -412,6 +412,21 @@ class Leg:
             elapsed = float(t.item())
         return elapsed, step_ms
 
+    def decisions_digest(self):
+        """One more (untimed) step, gathered on every rank: sha256 over the int32 action indices of ALL roots in root order, and
+        over the fp32 values.  In the fixed-total reading every world size searches the same seeded roots, so the action digest of
+        an N-rank run can be held against the single-process run (tests/test_bench_launcher.py does, over gloo; on hardware a
+        differing digest can only come from numerical ties, since the launch shapes -- and with them the summation order -- change
+        with the shard size)."""
+        import hashlib
+        self.fence()
+        act, val = self.sharded.launch_local(self.robot, self.humans, self.total_roots).result()
+        self.fence()
+        a = act.detach().cpu().numpy().astype(np.int32)
+        v = val.detach().cpu().numpy().astype(np.float32)
+        return {"roots": int(a.shape[0]), "actions_sha256": hashlib.sha256(a.tobytes()).hexdigest(),
+                "values_sha256": hashlib.sha256(v.tobytes()).hexdigest()}
+
     def diagnose(self, n_diag=10):
         """Search and exchange timed SEPARATELY (no pipelining) after the timed region, every rank's medians gathered."""
         dist, dev = self.dist, self.device
@@ -613,6 +628,7 @@ def main():
     total_roots, B = leg.total_roots, leg.B
     value = per_root * total_roots * args.steps / elapsed
     multi = leg.diagnose() if dist is not None else None
+    digest = leg.decisions_digest()
 
     weak = None
     if extra_leg is not None:
@@ -682,6 +698,7 @@ def main():
                    "graph_replay": bool(leg.graphs),
                    "exchange": "all_gather_into_tensor of (roots_per_gpu,2) fp32 per rank" if world > 1 else "none"},
         "roofline": roofline,
+        "decisions": digest,
     }
     if x3 is not None:
         result["f16x3"] = x3

@@ -38,12 +38,35 @@ def test_bench_launches_its_own_ranks_and_reports_both_readings():
     assert r["cpu_baseline"] is None and r["roofline"] is None
 
 
+def test_eight_ranks_uneven_shards_and_the_single_process_decisions():
+    """The shape the driver's 8-GPU node will see, on gloo: 8 ranks through bench.py's own launcher, the
+    fixed-total reading over 2048 roots (configs[2]: 256 per rank), 4096 roots at depth 3 (configs[3]: 512 per rank) and a root
+    count 8 does not divide (2051: three ranks carry one root more).  Every rank is seen, the shards add up, the `multi_gpu`
+    block is there, and the gathered decisions of the 8-rank run are the single-process run's, digest for digest."""
+    for argv, total, per_rank in (
+            (["--roots", "2048"], 2048, [256] * 8),
+            (["--scaling", "strong", "--total-roots", "4096", "--depth", "3"], 4096, [512] * 8),
+            (["--scaling", "strong", "--total-roots", "2051"], 2051, [257] * 3 + [256] * 5)):
+        r8 = _run(["--gpus", "8", "--steps", "2", "--warmup", "1"] + argv)
+        assert r8["n_gpus"] == 8 and r8["ranks_seen"] == 8 and r8["scaling"] == "strong"
+        assert r8["config"]["total_roots"] == total and r8["multi_gpu"]["roots_per_rank"] == per_rank
+        assert sum(r8["multi_gpu"]["roots_per_rank"]) == total
+        assert len(r8["multi_gpu"]["search_ms_per_step_by_rank"]) == 8 and len(r8["multi_gpu"]["exchange_ms_per_step_by_rank"]) == 8
+        assert r8["decisions"]["roots"] == total
+        one = ["--scaling", "strong", "--total-roots", str(total)] + (["--depth", "3"] if "--depth" in argv else [])
+        r1 = _run(["--gpus", "1", "--steps", "2", "--warmup", "1"] + one)
+        assert r1["n_gpus"] == 1 and r1["config"]["total_roots"] == total and "multi_gpu" not in r1
+        assert r1["decisions"] == r8["decisions"], (argv, r1["decisions"], r8["decisions"])
+        if argv[0] == "--roots":                      # `both`: the per-GPU-fixed reading rides along (2048 roots on each of 8 ranks)
+            assert r8["weak_total_roots"] == 8 * 2048 and r8["weak_multi_gpu"]["roots_per_rank"] == [2048] * 8
+
+
 def test_single_rank_line_keeps_its_shape():
     r = _run(["--steps", "3", "--warmup", "1", "--roots", "7"])
     assert r["n_gpus"] == 1 and r["scaling"] == "weak" and r["config"]["total_roots"] == 7 and "weak_value" not in r
     assert "multi_gpu" not in r and "ranks_seen" not in r
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "step_ms_device", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "step_ms_device", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "decisions"):
         assert key in r, key
 
 

@@ -35,10 +35,12 @@ def _worker(rank, world, port, total, out_dir):
     calls = []
 
     def search(r, h):
+        # root by root: a root's result must not depend on which other roots share its batch (MKL's summation order does), or the
+        # comparisons across different shard sizes below would only hold by luck
         calls.append(r.shape[0])
         with torch.no_grad():
-            a, v, _, _ = orc.mprl_predict_batched(r, h, P, cfg)
-        return a, v
+            outs = [orc.mprl_predict_batched(r[i:i + 1], h[i:i + 1], P, cfg)[:2] for i in range(r.shape[0])]
+        return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
     sr = ShardedRollout(search)
     act, val = sr.run(robot, humans)
     assert act.dtype == torch.int64 and val.dtype == torch.float32        # run(): torch's index type
@@ -90,12 +92,18 @@ def _worker(rank, world, port, total, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_rollout_matches_single_process(tmp_path):
-    total, world = 7, 2                                   # uneven split: 4 + 3
+import pytest
+
+
+@pytest.mark.parametrize("total,world,shards", [(7, 2, [4, 3]),                     # uneven split: 4 + 3
+                                                (9, 8, [2, 1, 1, 1, 1, 1, 1, 1]),      # the node the driver scales to: 8 ranks, uneven
+                                                (8, 8, [1] * 8)])                      # ... and the equal-shard (no-copy) unpacking
+def test_sharded_rollout_matches_single_process(total, world, shards, tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
     res = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(world)]
-    assert res[0]["calls"] == [4] and res[1]["calls"] == [3]
-    assert torch.equal(res[0]["act"], res[1]["act"]) and torch.equal(res[0]["val"], res[1]["val"])
+    assert [r["calls"] for r in res] == [[n] for n in shards]
+    for r in res[1:]:
+        assert torch.equal(res[0]["act"], r["act"]) and torch.equal(res[0]["val"], r["val"])
     from oracle import rgl_oracle as orc
     pl = gio.load("planning")
     robot = torch.tensor(np.tile(pl["plan.scene.s5.robot"], (3, 1))[:total].astype(np.float32))
@@ -103,5 +111,6 @@ def test_two_rank_sharded_rollout_matches_single_process(tmp_path):
     robot[:, 0] += torch.arange(total) * 0.01
     cfg = orc.OracleConfig(planning_depth=2, planning_width=2, do_action_clip=True)
     with torch.no_grad():
-        a, v, _, _ = orc.mprl_predict_batched(robot, humans, gio.oracle_params("trained"), cfg)
+        outs = [orc.mprl_predict_batched(robot[i:i + 1], humans[i:i + 1], gio.oracle_params("trained"), cfg)[:2] for i in range(total)]
+    a, v = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
     assert torch.equal(res[0]["act"], a) and torch.equal(res[0]["val"], v)
