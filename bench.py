@@ -96,6 +96,16 @@ def children_flops_per_scene(N, L, A):
             "tiles (children_graph_kernel + robot_head_kernel)")
 
 
+def predictor_flops_per_scene(N, L):
+    """Algorithmic FLOPs of one state-predictor graph forward (state_predictor.py:20-39: embeddings, similarity, L GCN layers on
+    every node, motion head on the human rows; 2 per MAC, softmax ~5 per element) -- one per tree node."""
+    H = N - 1
+    return (5248 + H * 4736                                        # w_r on the robot row, w_h on the human rows
+            + 2 * N * 32 * 32 + 2 * N * N * 32 + 5 * N * N         # X Wa, (X Wa) X^T, softmax
+            + L * (2 * N * N * 32 + 2 * N * 32 * 32)               # A H, (A H) W
+            + H * (2 * 32 * 64 + 2 * 64 * 5))                      # motion head 32 -> 64 -> 5
+
+
 def workload_name(N, args, reading=None):
     key = (N, args.layers, args.depth, args.width)
     if key == (20, 2, 2, 2):
@@ -465,10 +475,13 @@ class Leg:
                 "roots_per_rank": self.roots_per_rank}
 
 
-def children_roofline(args, ts, device, N, H, last):
-    """Roofline of the dominant kernels (value of the sibling children), HIP events on the launch stream.  Launched straight
-    through the C ABI (prebuilt descriptor, no Python work between launches) on the inputs the last search left in its
-    workspace, one launch per tree level, in the same mix as inside a step."""
+def children_roofline(args, ts, device, N, H, last, robot=None, humans=None):
+    """Roofline of the dominant kernels (value of the sibling children), HIP events on the launch stream.
+    `achieved` / `frac` price the kernel AS IT RUNS IN THE SEARCH (round 4): mprl_tree_search_traced_f32 records events around
+    every level's value-of-children launch -- with the selection, and at the deepest level the back-up chain and the root
+    decision, in its tail -- and the mean launch duration over the levels of a step divides the executed FLOPs of a launch.
+    `standalone_*`: the same kernels launched straight through mprl_value_children_f32 (no tail work) on the inputs the last
+    search left in its workspace, one launch per tree level, in the same mix -- the figure rounds 1-3 reported."""
     import ctypes as C
     from relationalgraphlearning_amd import _native as nat
     if last is not None:
@@ -504,6 +517,17 @@ def children_roofline(args, ts, device, N, H, last):
     kern_ms = e0.elapsed_time(e1) / kern_launches
     scenes_per_launch = sum(lv["n_parents"] for lv in levels) * A / len(levels)
     flop_per_scene, kernel_path = children_flops_per_scene(N, args.layers, A)
+    standalone_ms = kern_ms
+    in_search = None
+    if robot is not None:
+        n_tr = 10
+        acc = np.zeros(args.depth)
+        for i in range(n_tr + 2):
+            ts.search(robot, humans, roots_are_joint_states=False, want_root_values=False, trace=True)
+            if i >= 2:
+                acc += np.asarray(ts.last["trace"]["children_ms"])
+        in_search = (acc / n_tr).tolist()
+        kern_ms = float(sum(in_search) / len(in_search))
     achieved = scenes_per_launch * flop_per_scene / (kern_ms * 1e-3) / 1e12
     peak, peak_note = FP32_PEAK_TFLOPS, "fp32 vector == f32-MFMA peak (the two do not co-execute on gfx950)"
     if args.contraction == "f16x3":
@@ -546,7 +570,13 @@ def children_roofline(args, ts, device, N, H, last):
             "traffic_source": traffic_src, "traffic_measured_at_revision": traffic_rev,
             "traffic_stale": stale,
             "algorithmic_bytes": scenes_per_launch * (9 * 4 + 4) + scenes_per_launch / A * H * 20,
-            "launch_ms": kern_ms, "scenes_per_launch": scenes_per_launch,
+            "launch_ms": kern_ms, "launch_ms_source": ("HIP events around the level's children launch inside mprl_tree_search_traced_f32 "
+                                                      "(tail work included), mean over the levels of a step" if in_search else
+                                                      "stand-alone mprl_value_children_f32 launches"),
+            "in_search_children_ms_by_level": in_search,
+            "standalone_launch_ms": standalone_ms,
+            "standalone_frac": scenes_per_launch * flop_per_scene / (standalone_ms * 1e-3) / 1e12 / peak,
+            "scenes_per_launch": scenes_per_launch,
             "flop_per_scene": flop_per_scene,
             "reference_flop_per_eval": {(20, 2): 328120, (50, 3): 1337660, (6, 2): 102300}.get((N, args.layers))}
 
@@ -641,11 +671,21 @@ def main():
         del leg2
 
     A, W = ts.num_actions, ts.kept_per_node
-    roofline = None
+    roofline = roofline_step = None
     if not STUB and B > 0:
         if not leg.graphs:                                   # leave the main leg's levels in the shared workspace
             ts.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
-        roofline = children_roofline(args, ts, device, N, H, leg.graph_last)
+        roofline = children_roofline(args, ts, device, N, H, leg.graph_last, leg.robot, leg.humans)
+        # the whole step against the same peak: executed (algorithmic) FLOPs of everything a step computes -- the children's
+        # value forwards and the state predictor's graph forwards, one per tree node -- over the measured step time
+        n_nodes = sum(W_ ** l for W_ in [ts.kept_per_node] for l in range(args.depth)) * B
+        step_flops = n_nodes * (ts.num_actions * roofline["flop_per_scene"] + predictor_flops_per_scene(N, args.layers))
+        step_tflops = step_flops / (elapsed / args.steps) / 1e12
+        roofline_step = {"flops_per_step": step_flops, "achieved": step_tflops, "peak": roofline["peak"], "unit": "TFLOP/s",
+                         "frac": step_tflops / roofline["peak"],
+                         "note": "children value forwards (%d per tree node) + state-predictor graph forwards (one per tree node, "
+                                 "%.0f FLOP), %d tree nodes on this GPU, over ms_per_step" % (ts.num_actions,
+                                                                                         predictor_flops_per_scene(N, args.layers), n_nodes)}
 
     # ---- auxiliary reading (never `value`): the same workload with the children kernel's dense products as three split-f16 MFMA
     # terms (contraction_dtype "f16x3": f32-equivalent to ~2^-21 per product, on the f16 matrix pipe), timed the same way, with
@@ -662,12 +702,12 @@ def main():
         e3, s3 = leg3.timed(args.steps, args.warmup, INIT_STEPS)
         o32 = ts.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
         o3 = ts3.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
-        r3 = children_roofline(a3, ts3, device, N, H, None)
+        r3 = children_roofline(a3, ts3, device, N, H, None, leg.robot, leg.humans)
         x3 = {"value": per_root * total_roots * args.steps / e3, "ms_per_step": e3 / args.steps * 1e3,
               "step_ms_device_median": s3[len(s3) // 2],
               "max_abs_dV_vs_f32_kernels": float((o3["best_value"] - o32["best_value"]).abs().max()),
               "identical_decisions": float((o3["best_action"] == o32["best_action"]).float().mean()),
-              "roofline": {k: r3[k] for k in ("achieved", "peak", "frac", "peak_note", "launch_ms", "unit")},
+              "roofline": {k: r3[k] for k in ("achieved", "peak", "frac", "peak_note", "launch_ms", "standalone_launch_ms", "unit")},
               "note": "contraction_dtype f16x3 (MprlPlanner.contraction_dtype = RGL_CONTRACT_F16X3): same search, the dense "
                       "products of the value-of-children kernel (value head, embedding chains, robot row / column of S, p Xh, crowd "
                       "quantities) as W^T a = W_hi a_hi + W_hi a_lo + W_lo a_hi on v_mfma_f32_16x16x32_f16 with f32 accumulation over "
@@ -698,6 +738,7 @@ def main():
                    "graph_replay": bool(leg.graphs),
                    "exchange": "all_gather_into_tensor of (roots_per_gpu,2) fp32 per rank" if world > 1 else "none"},
         "roofline": roofline,
+        "roofline_step": roofline_step,
         "decisions": digest,
     }
     if x3 is not None:

@@ -15,7 +15,8 @@
  *     during the call only; the device pointers inside them must stay valid until the work
  *     queued on `stream` has finished;
  *   - launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
- *     stream); no call synchronises the device, so all of them may be captured into a hipGraph;
+ *     stream); no call synchronises the device, so all of them may be captured into a hipGraph
+ *     (the one exception, by purpose: mprl_tree_search_traced_f32, a measurement call);
  *   - return value: 0 on success, a positive hipError_t if the runtime reported one, or one of
  *     the negative RGL_ERR_* codes below.  No exceptions cross this boundary;
  *   - thread safety: calls on distinct streams may run concurrently; there is no hidden
@@ -39,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RGL_ABI_VERSION 4
+#define RGL_ABI_VERSION 5
 
 #define RGL_MAX_MLP_LAYERS 6
 #define RGL_MAX_GCN_LAYERS 8
@@ -204,6 +205,12 @@ typedef struct GcnPlanner {
     const double* root_humans_f64;
 } GcnPlanner;
 
+/* The first step of gcn_predict_f32 on its own (ABI 5): for every (root b, action a) CADRL.propagate (cadrl.py:113-138) of the
+ * robot, constant-velocity humans, CADRL.rotate (:241-276) into the pairwise relation features and compute_reward
+ * (multi_human_rl.py:73-96; float64, reading planner->root_*_f64 when set).  Reads planner->actions, num_actions, kinematics,
+ * time_step only.  self6 device [B*A][6], hum7 device [B*A][H][7], reward device [B*A]. */
+int gcn_prepare_f32(const GcnPlanner* planner, const float* robot, const float* humans, int B, int H,
+                    float* self6, float* hum7, float* reward, rgl_stream_t stream);
 size_t gcn_predict_workspace_bytes(int B, int H, int A);
 int gcn_predict_f32(const GcnPlanner* planner, const float* robot, const float* humans, int B, int H,
                     void* workspace, size_t workspace_bytes,
@@ -308,6 +315,35 @@ int mprl_tree_search_f32(const MprlPlanner* planner, const float* robot, const f
                          int roots_are_joint_states, void* workspace, size_t workspace_bytes,
                          int* best_action, float* best_value, float* root_values, int* root_kept,
                          rgl_stream_t stream);
+
+/* The same search with timing marks (ABI 5) -- a MEASUREMENT call, the one entry point that synchronises: the library records
+ * HIP events on `stream` around the launches of every level l and, after waiting for the last one, reports (host arrays of
+ * planning_depth floats, milliseconds)
+ *   predictor_ms[l]  the level's state-predictor / next-state / reward launches,
+ *   children_ms[l]   its value-of-children launch(es) AS THEY RUN IN THE SEARCH: with the selection -- and at the deepest level
+ *                    the back-up chain and the root decision -- in the kernel's tail where the fused kernel takes the level
+ *                    (the stand-alone select kernel included where it does not): what bench.py's `roofline` prices,
+ *   *total_ms        (NULL allowed) first record to last record.
+ * Not capturable into a hipGraph (event records, a host wait). */
+int mprl_tree_search_traced_f32(const MprlPlanner* planner, const float* robot, const float* humans, int B, int H,
+                                int roots_are_joint_states, void* workspace, size_t workspace_bytes,
+                                int* best_action, float* best_value, float* root_values, int* root_kept,
+                                rgl_stream_t stream, float* predictor_ms, float* children_ms, float* total_ms);
+
+/* estimate_reward (model_predictive_rl.py:304-357) and compute_next_state (state_predictor.py:41-60) for every (parent,
+ * action) pair on their own (ABI 5) -- the float64 reward kernel every tree level runs:
+ *   child_robot device [P][A][9], reward device [P][A]; robot [P][9], humans [P][H][5] (each parent its own crowd);
+ *   parents_are_joint_states as for mprl_expand_f32 (with planner->root_*_f64 set the float64 states are read).
+ * Reads planner->actions, num_actions, kinematics, time_step only. */
+int mprl_estimate_reward_f32(const MprlPlanner* planner, const float* robot, const float* humans, int P, int H,
+                             int parents_are_joint_states, float* child_robot, float* reward, rgl_stream_t stream);
+
+/* action_clip's selection on its own (model_predictive_rl.py:242-269; ABI 5): value1[p][a] = reward + gamma_bar * child_value
+ * (each op rounded to fp32), keep[p][0..W-1] = the planning_width best actions of parent p in descending one-step value
+ * (ties: lower index first; sparse_search: one action per action_groups id) -- W = num_actions and keep = 0..A-1 without
+ * do_action_clip.  value1 device [P][A], keep device [P][W] int32. */
+int mprl_action_clip_f32(const MprlPlanner* planner, const float* reward, const float* child_value, int P,
+                         float* value1, int* keep, rgl_stream_t stream);
 
 /* Where level `level` keeps its arrays inside the workspace (byte offsets), so a host can read
  * back the best trajectory (ModelPredictiveRL.traj) or any intermediate without a second pass. */

@@ -321,69 +321,84 @@ def _normalized_gamma(cfg):
     return pow(cfg.gamma, cfg.time_step * cfg.v_pref)
 
 
-def mprl_predict_sequential(robot9, humans, P: MprlParams, cfg: OracleConfig, trace: SeqTrace = None):
-    """robot9: 9 python floats; humans: list of 5-float rows (a root JointState's contents).
-    Returns (action index, max value float32).  Walks the tree exactly as the reference does."""
-    actions, groups = mprl_action_space(cfg, robot9[7])
-    gamma = _normalized_gamma(cfg)
-    trace = trace if trace is not None else SeqTrace()
+class SeqPlanner:
+    """The reference's recursive planner, method by method (model_predictive_rl.py:242-302), over tensor states
+    (robot (1,1,9), humans (1,H,5)): `clip` = action_clip, `plan` = V_planning (value only), `reward_of` = estimate_reward on a
+    tensor-born state (or on the float64 root rows given to the constructor).  mprl_predict_sequential walks it from a root;
+    the GPU tests hold ModelPredictiveRL.action_clip / V_planning / estimate_reward against it."""
 
-    def V(state):
-        trace.n_value_forwards += 1
-        return value_estimator_forward(state[0], state[1], P.ve_graph, P.value_network, cfg).reshape(())
+    def __init__(self, P: MprlParams, cfg: OracleConfig, v_pref=1.0, root_rows=None, trace: SeqTrace = None):
+        self.P, self.cfg = P, cfg
+        self.actions, self.groups = mprl_action_space(cfg, v_pref)
+        self.gamma = _normalized_gamma(cfg)
+        self.root_rows = root_rows                  # (robot9 floats, human rows): the JointState the root tensors came from
+        self.trace = trace if trace is not None else SeqTrace()
 
-    def SP(state, a):
-        trace.n_predictor_forwards += 1
-        nr = next_robot_state(state[0].reshape(-1), a, cfg).reshape(1, 1, 9)
-        if cfg.linear_state_predictor:
+    def V(self, state):
+        self.trace.n_value_forwards += 1
+        return value_estimator_forward(state[0], state[1], self.P.ve_graph, self.P.value_network, self.cfg).reshape(())
+
+    def SP(self, state, a):
+        self.trace.n_predictor_forwards += 1
+        nr = next_robot_state(state[0].reshape(-1), a, self.cfg).reshape(1, 1, 9)
+        if self.cfg.linear_state_predictor:
             nh = linear_humans(state[1])
         else:
-            nh = state_predictor_humans(state[0], state[1], P.sp_graph, P.motion_predictor, cfg)
+            nh = state_predictor_humans(state[0], state[1], self.P.sp_graph, self.P.motion_predictor, self.cfg)
         return (nr, nh)
 
-    def reward_of(state, a, root):
+    def reward_of(self, state, a, root):
         if root:
-            return estimate_reward(robot9, humans, a, cfg)
+            return estimate_reward(self.root_rows[0], self.root_rows[1], a, self.cfg)
         r, h = _tensor_state_scalars(state[0], state[1])
-        return estimate_reward(r, h, a, cfg)
+        return estimate_reward(r, h, a, self.cfg)
 
-    def clip(state, width, root):
+    def clip(self, state, width, root):
+        """action_clip (:242-269) -> (kept action indices in the reference's order, one-step values of every action)."""
         vals = []
-        for a in actions:
-            nxt = SP(state, a)
-            ret = V(nxt)
-            vals.append(reward_of(state, a, root) + gamma * ret)
+        for a in self.actions:
+            nxt = self.SP(state, a)
+            ret = self.V(nxt)
+            vals.append(self.reward_of(state, a, root) + self.gamma * ret)
         vals_np = np.array([float(v) for v in vals], dtype=np.float32)
-        if cfg.sparse_search:
+        if self.cfg.sparse_search:
             seen, keep = set(), []
             for idx in np.argsort(vals_np)[::-1]:
-                if groups[idx] not in seen:
+                if self.groups[idx] not in seen:
                     keep.append(int(idx))
-                    seen.add(groups[idx])
+                    seen.add(self.groups[idx])
                     if len(keep) == width:
                         break
         else:
             keep = [int(i) for i in np.argpartition(vals_np, -width)[-width:]]
         return keep, vals_np
 
-    def plan(state, depth, width):
-        v = V(state)
+    def plan(self, state, depth, width):
+        """V_planning (:271-302), the value only."""
+        v = self.V(state)
         if depth == 1:
             return v
-        keep = clip(state, width, False)[0] if cfg.do_action_clip else list(range(len(actions)))
+        keep = self.clip(state, width, False)[0] if self.cfg.do_action_clip else list(range(len(self.actions)))
         rets = []
         for ai in keep:
-            a = actions[ai]
-            nxt = SP(state, a)
-            r = reward_of(state, a, False)
-            nv = plan(nxt, depth - 1, width)
-            rets.append(v / depth + (depth - 1) / depth * (gamma * nv + r))
+            a = self.actions[ai]
+            nxt = self.SP(state, a)
+            r = self.reward_of(state, a, False)
+            nv = self.plan(nxt, depth - 1, width)
+            rets.append(v / depth + (depth - 1) / depth * (self.gamma * nv + r))
         return rets[int(np.argmax([float(x) for x in rets]))]
 
+
+def mprl_predict_sequential(robot9, humans, P: MprlParams, cfg: OracleConfig, trace: SeqTrace = None):
+    """robot9: 9 python floats; humans: list of 5-float rows (a root JointState's contents).
+    Returns (action index, max value float32).  Walks the tree exactly as the reference does."""
+    trace = trace if trace is not None else SeqTrace()
+    sp = SeqPlanner(P, cfg, robot9[7], (robot9, humans), trace)
+    actions, gamma = sp.actions, sp.gamma
     root = (torch.tensor([[robot9]], dtype=torch.float32),
             torch.tensor([humans], dtype=torch.float32).reshape(1, len(humans), 5))
     if cfg.do_action_clip:
-        keep, vals_np = clip(root, cfg.planning_width, True)
+        keep, vals_np = sp.clip(root, cfg.planning_width, True)
         trace.root_clip_values = vals_np
     else:
         keep = list(range(len(actions)))
@@ -391,8 +406,8 @@ def mprl_predict_sequential(robot9, humans, P: MprlParams, cfg: OracleConfig, tr
     best, best_v, root_vals = None, float("-inf"), []
     for ai in keep:
         a = actions[ai]
-        nxt = SP(root, a)
-        ret = plan(nxt, cfg.planning_depth, cfg.planning_width)
+        nxt = sp.SP(root, a)
+        ret = sp.plan(nxt, cfg.planning_depth, cfg.planning_width)
         val = estimate_reward(robot9, humans, a, cfg) + gamma * ret
         root_vals.append(float(val))
         if val > best_v:

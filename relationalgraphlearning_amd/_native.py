@@ -15,7 +15,7 @@ MAX_NODES = 128
 MAX_XDIM = 64
 MAX_WIDTH = 256
 MAX_ACTIONS = 256
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 SIMILARITY = {"embedded_gaussian": 0, "gaussian": 1, "cosine": 2, "cosine_softmax": 3, "concatenation": 4,
               "squared": 5, "equal_attention": 6, "diagonal": 7}
@@ -89,6 +89,8 @@ SIGNATURES = {
     "rgl_transpose_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rgl_transpose_many_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "gcn_rotate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "gcn_prepare_f32": (C.c_int, [C.POINTER(GcnPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
     "gcn_predict_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "gcn_predict_f32": (C.c_int, [C.POINTER(GcnPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                   C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -105,6 +107,13 @@ SIGNATURES = {
     "mprl_tree_workspace_bytes": (C.c_size_t, [C.POINTER(MprlPlanner), C.c_int, C.c_int]),
     "mprl_tree_search_f32": (C.c_int, [C.POINTER(MprlPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
+    "mprl_tree_search_traced_f32": (C.c_int, [C.POINTER(MprlPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, c_float_p, c_float_p, c_float_p]),
+    "mprl_estimate_reward_f32": (C.c_int, [C.POINTER(MprlPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mprl_action_clip_f32": (C.c_int, [C.POINTER(MprlPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     "mprl_tree_level_view": (C.c_int, [C.POINTER(MprlPlanner), C.c_int, C.c_int, C.c_int, C.POINTER(MprlLevelView)]),
     "crowd_step_f64": (C.c_int, [C.POINTER(CrowdSimConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -298,7 +298,7 @@ inline int validate_planner(const MprlPlanner& pl, int H) {
 int expand_level(const MprlPlanner& pl, const float* robot, const float* humans, int humans_per, int P, int H, int joint,
                  float* humans_next, float* child_robot, float* reward, float* child_value, void* scratch,
                  size_t scratch_bytes, hipStream_t st, int image_ready = 0, const TailArgs* tail = nullptr,
-                 int* tail_done = nullptr, const float* sp_image = nullptr) {
+                 int* tail_done = nullptr, const float* sp_image = nullptr, hipEvent_t before_children = nullptr) {
     const int A = pl.num_actions;
     ChildrenArgs ca;
     ca.robot = robot; ca.humans = humans; ca.humans_per = humans_per; ca.actions = pl.actions;
@@ -330,6 +330,7 @@ int expand_level(const MprlPlanner& pl, const float* robot, const float* humans,
         hipLaunchKernelGGL(mprl_children_kernel, grid_for((long long)P * A), dim3(kBlock), 0, st, ca);
         RGL_LAUNCH_CHECK();
     }
+    if (before_children) RGL_HIP_TRY(hipEventRecord(before_children, st));     // traced searches: state predictor | children
     return rgl::launch_value_children(&pl, child_robot, humans_next, P, H, child_value, scratch, scratch_bytes, st, image_ready,
                                       tail, tail ? sizeof(TailArgs) : 0, tail_done);
 }
@@ -416,10 +417,12 @@ extern "C" int mprl_tree_level_view(const MprlPlanner* planner, int B, int H, in
     return RGL_OK;
 }
 
-extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* robot, const float* humans, int B, int H,
-                                    int roots_are_joint_states, void* workspace, size_t workspace_bytes,
-                                    int* best_action, float* best_value, float* root_values, int* root_kept,
-                                    rgl_stream_t stream) {
+namespace {
+// `events`: null, or 3 * planning_depth + 1 hipEvent_t of the caller's (mprl_tree_search_traced_f32)
+int tree_search(const MprlPlanner* planner, const float* robot, const float* humans, int B, int H,
+                int roots_are_joint_states, void* workspace, size_t workspace_bytes,
+                int* best_action, float* best_value, float* root_values, int* root_kept,
+                rgl_stream_t stream, void* const* events) {
     if (!planner || !robot || !humans || !workspace || !best_action || !best_value) return RGL_ERR_NULL;
     if (B < 1) return RGL_ERR_BAD_SHAPE;
     int rc = validate_planner(*planner, H);
@@ -477,16 +480,18 @@ extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* rob
         tail.next_robot = deepest ? nullptr : (float*)(ws + lv[l + 1].robot);
         tail.chain = deepest;
         int tail_done = 0;           // 1: the children kernel selected for its parents; 2: ... and finished the search (deepest level)
+        if (events) RGL_HIP_TRY(hipEventRecord((hipEvent_t)events[3 * l], st));
         rc = expand_level(pl, pr, ph, humans_per, P, H, l == 0 ? roots_are_joint_states : 0,
                           (float*)(ws + L.humans_next), (float*)(ws + L.child_robot), (float*)(ws + L.reward),
                           (float*)(ws + L.child_value), ws + scratch_off, (size_t)scratch_bytes, st, image_ready, &tail, &tail_done,
-                          sp_image);
+                          sp_image, events ? (hipEvent_t)events[3 * l + 1] : nullptr);
         if (rc) return rc;
         if (!tail_done) {
             // the deepest level's selection also writes the leaf values and (below the root) does its own back-up step
             hipLaunchKernelGGL(mprl_select_kernel, grid_for(P, 4), dim3(256), 0, st, tail);
             RGL_LAUNCH_CHECK();
         }
+        if (events) RGL_HIP_TRY(hipEventRecord((hipEvent_t)events[3 * l + 2], st));
         if (deepest && tail_done == 2) chain_done = 1;
     }
     if (!chain_done) {
@@ -497,6 +502,93 @@ extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* rob
         hipLaunchKernelGGL(mprl_root_kernel, grid_for((long long)B * kRootLanes, 256), dim3(256), 0, st, tail);
         RGL_LAUNCH_CHECK();
     }
+    if (events) RGL_HIP_TRY(hipEventRecord((hipEvent_t)events[3 * D], st));
+    return RGL_OK;
+}
+}  // namespace
+
+extern "C" int mprl_tree_search_f32(const MprlPlanner* planner, const float* robot, const float* humans, int B, int H,
+                                    int roots_are_joint_states, void* workspace, size_t workspace_bytes,
+                                    int* best_action, float* best_value, float* root_values, int* root_kept,
+                                    rgl_stream_t stream) {
+    return tree_search(planner, robot, humans, B, H, roots_are_joint_states, workspace, workspace_bytes, best_action, best_value,
+                       root_values, root_kept, stream, nullptr);
+}
+
+extern "C" int mprl_tree_search_traced_f32(const MprlPlanner* planner, const float* robot, const float* humans, int B, int H,
+                                           int roots_are_joint_states, void* workspace, size_t workspace_bytes,
+                                           int* best_action, float* best_value, float* root_values, int* root_kept,
+                                           rgl_stream_t stream, float* predictor_ms, float* children_ms, float* total_ms) {
+    if (!planner || !predictor_ms || !children_ms) return RGL_ERR_NULL;
+    const int D = planner->planning_depth;
+    if (D < 1 || D > 8) return RGL_ERR_BAD_SHAPE;
+    hipEvent_t ev[3 * 8 + 1];
+    const int n = 3 * D + 1;
+    for (int i = 0; i < n; ++i) RGL_HIP_TRY(hipEventCreate(&ev[i]));
+    int rc = tree_search(planner, robot, humans, B, H, roots_are_joint_states, workspace, workspace_bytes, best_action, best_value,
+                         root_values, root_kept, stream, reinterpret_cast<void* const*>(ev));
+    if (rc == RGL_OK) rc = (int)hipEventSynchronize(ev[3 * D]);
+    for (int l = 0; l < D && rc == RGL_OK; ++l) {
+        rc = (int)hipEventElapsedTime(&predictor_ms[l], ev[3 * l], ev[3 * l + 1]);
+        if (rc == RGL_OK) rc = (int)hipEventElapsedTime(&children_ms[l], ev[3 * l + 1], ev[3 * l + 2]);
+    }
+    if (rc == RGL_OK && total_ms) rc = (int)hipEventElapsedTime(total_ms, ev[0], ev[3 * D]);
+    for (int i = 0; i < n; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
+}
+
+// estimate_reward + compute_next_state for every (parent, action) pair on their own (model_predictive_rl.py:304-357,
+// state_predictor.py:41-60): the kernel every tree level runs, exported for ModelPredictiveRL.estimate_reward
+extern "C" int mprl_estimate_reward_f32(const MprlPlanner* planner, const float* robot, const float* humans, int P, int H,
+                                        int parents_are_joint_states, float* child_robot, float* reward, rgl_stream_t stream) {
+    if (!planner || !robot || !humans || !child_robot || !reward) return RGL_ERR_NULL;
+    if (P < 0 || H < 1 || H + 1 > RGL_MAX_NODES) return RGL_ERR_BAD_SHAPE;
+    const MprlPlanner& pl = *planner;
+    if (pl.num_actions < 1 || pl.num_actions > RGL_MAX_ACTIONS) return RGL_ERR_BAD_SHAPE;
+    if (pl.kinematics != RGL_HOLONOMIC && pl.kinematics != RGL_UNICYCLE) return RGL_ERR_BAD_MODE;
+    if (!pl.actions) return RGL_ERR_NULL;
+    if (P == 0) return RGL_OK;
+    ChildrenArgs ca;
+    ca.robot = robot; ca.humans = humans; ca.humans_per = 1; ca.actions = pl.actions;
+    ca.P = P; ca.H = H; ca.A = pl.num_actions; ca.kinematics = pl.kinematics; ca.dt = pl.time_step; ca.joint = parents_are_joint_states;
+    ca.child_robot = child_robot; ca.reward = reward;
+    const bool roots64 = parents_are_joint_states && pl.root_robot_f64 && pl.root_humans_f64;
+    ca.robot64 = roots64 ? pl.root_robot_f64 : nullptr;
+    ca.humans64 = roots64 ? pl.root_humans_f64 : nullptr;
+    hipLaunchKernelGGL(mprl_children_kernel, grid_for((long long)P * pl.num_actions), dim3(kBlock), 0, (hipStream_t)stream, ca);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
+// action_clip's selection on its own (model_predictive_rl.py:242-269): value1 = reward + gamma_bar * child_value, then the
+// planning_width best actions per parent (argpartition semantics; sparse: one action per group) -- tail_select, the step every
+// search level runs, without the gather of the next level's states
+extern "C" int mprl_action_clip_f32(const MprlPlanner* planner, const float* reward, const float* child_value, int P,
+                                    float* value1, int* keep, rgl_stream_t stream) {
+    if (!planner || !reward || !child_value || !value1 || !keep) return RGL_ERR_NULL;
+    if (P < 0) return RGL_ERR_BAD_SHAPE;
+    const MprlPlanner& pl = *planner;
+    const int A = pl.num_actions;
+    if (A < 1 || A > RGL_MAX_ACTIONS) return RGL_ERR_BAD_SHAPE;
+    if (pl.do_action_clip && (pl.planning_width < 1 || pl.planning_width > A)) return RGL_ERR_BAD_SHAPE;
+    const int W = pl.do_action_clip ? pl.planning_width : A;
+    if (pl.do_action_clip && pl.sparse_search) {
+        if (!pl.action_groups) return RGL_ERR_NULL;
+        if (W > kMaxSparseWidth) return RGL_ERR_BAD_MODE;
+    }
+    if (P == 0) return RGL_OK;
+    TailArgs t{};
+    t.enabled = 1;
+    t.level = 0; t.D = 2;                       // "not the deepest level": no leaf values, no back-up step
+    t.A = A; t.W = W; t.clip = pl.do_action_clip; t.sparse = pl.sparse_search;
+    t.gamma_f = (float)pl.gamma_bar;
+    t.groups = pl.action_groups;
+    t.child_robot = nullptr; t.next_robot = nullptr;
+    t.value1 = value1;
+    t.lv[0] = TailLevel{reward, child_value, keep, nullptr, nullptr, P};
+    t.B = P;
+    hipLaunchKernelGGL(mprl_select_kernel, grid_for(P, 4), dim3(256), 0, (hipStream_t)stream, t);
+    RGL_LAUNCH_CHECK();
     return RGL_OK;
 }
 
@@ -511,6 +603,25 @@ extern "C" int gcn_rotate_f32(const float* joint14, float* rotated13, int n_rows
     if (n_rows == 0) return RGL_OK;
     hipLaunchKernelGGL(gcn_rotate_kernel, grid_for(n_rows), dim3(kBlock), 0, (hipStream_t)stream, joint14, rotated13,
                        n_rows, kinematics == RGL_UNICYCLE);
+    RGL_LAUNCH_CHECK();
+    return RGL_OK;
+}
+
+// propagate + rotate + compute_reward for the B x A candidate scenes of a one-step search on their own (ABI 5): the first launch of
+// gcn_predict_f32 (cadrl.py:113-138,241-276, multi_human_rl.py:46-51,73-96), exported for GCN.compute_reward / tests
+extern "C" int gcn_prepare_f32(const GcnPlanner* planner, const float* robot, const float* humans, int B, int H,
+                               float* self6, float* hum7, float* reward, rgl_stream_t stream) {
+    if (!planner || !robot || !humans || !self6 || !hum7 || !reward) return RGL_ERR_NULL;
+    if (B < 1 || H < 1 || H + 1 > RGL_MAX_NODES) return RGL_ERR_BAD_SHAPE;
+    const GcnPlanner& pl = *planner;
+    if (pl.num_actions < 1 || pl.num_actions > RGL_MAX_ACTIONS || !pl.actions) return RGL_ERR_BAD_SHAPE;
+    if (pl.kinematics != RGL_HOLONOMIC && pl.kinematics != RGL_UNICYCLE) return RGL_ERR_BAD_MODE;
+    const long long S = (long long)B * pl.num_actions;
+    const int prep_threads = (H >= kBlock ? 1 : kBlock / H) * H;        // whole (root, action) groups per workgroup
+    const bool r64 = pl.root_robot_f64 && pl.root_humans_f64;
+    hipLaunchKernelGGL(gcn_prepare_kernel, grid_for(S * H, prep_threads), dim3(prep_threads), prep_threads * sizeof(double),
+                       (hipStream_t)stream, robot, humans, r64 ? pl.root_robot_f64 : nullptr, r64 ? pl.root_humans_f64 : nullptr,
+                       pl.actions, B, H, pl.num_actions, pl.kinematics, pl.time_step, self6, hum7, reward);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }

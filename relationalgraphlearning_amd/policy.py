@@ -14,7 +14,7 @@ import torch
 
 from . import actions as act
 from .nets import RGL, ValueEstimator, StatePredictor, LinearStatePredictor, ValueNetwork
-from .rollout import TreeSearch, GcnSearch, rotate
+from .rollout import TreeSearch, GcnSearch, rotate, prepare_scenes
 
 
 class Policy(object):
@@ -286,6 +286,102 @@ class ModelPredictiveRL(Policy):
             out = self.tree_search().search(robot, humans, roots_are_joint_states=roots_are_joint_states)
         return out["best_action"], out["best_value"]
 
+    # -- the planner's steps as methods (model_predictive_rl.py:242-357), each backed by the device function the search runs --------
+    def _planner_state(self, state):
+        """A JointState, or the (robot (1,1,9) | (1,9), humans (1,H,5)) tensor pair the reference's planner passes around
+        -> (robot (1,9) fp32, humans (1,H,5) fp32 device tensors, is_joint_state, float64 roots or None)."""
+        if isinstance(state, (tuple, list)):
+            robot = torch.as_tensor(state[0], dtype=torch.float32).reshape(1, 9).to(self.device).contiguous()
+            humans = torch.as_tensor(state[1], dtype=torch.float32).to(self.device)
+            return robot, humans.reshape(1, -1, 5).contiguous(), False, None
+        rrow, hrows = _state_rows(state)
+        r64 = torch.tensor([rrow], dtype=torch.float64, device=self.device)
+        h64 = torch.tensor([hrows], dtype=torch.float64, device=self.device).reshape(1, len(hrows), 5)
+        return r64.float(), h64.float(), True, (r64, h64)
+
+    def _search_for(self, action_space):
+        """The device search object for an action list: the policy's own table -> tree_search(); another list -> a TreeSearch over
+        that table (groups only when they still index it)."""
+        if self.action_space is None:
+            self.build_action_space(self.v_pref)
+        if action_space is None or action_space is self.action_space or list(action_space) == list(self.action_space):
+            return self.tree_search()
+        groups = self.action_group_index if len(self.action_group_index) == len(action_space) else None
+        return TreeSearch(self.value_estimator, self.state_predictor, act.as_array(action_space), groups, self.kinematics,
+                          self.time_step, self.get_normalized_gamma(), self.planning_depth, self.planning_width,
+                          self.do_action_clip, self.sparse_search and groups is not None, self.contraction_dtype)
+
+    def estimate_reward(self, state, action):
+        """model_predictive_rl.py:304-357 for one (state, action): the level kernel's float64 reward arithmetic
+        (mprl_estimate_reward_f32) on a one-row action table.  A JointState is read in float64, a tensor state through the
+        float32 differences tensor_to_joint_state + numpy scalars produce.  The device hands the reward back as float32 -- the
+        precision it enters `reward_est + gamma * value` with upstream (a float32 tensor expression)."""
+        robot, humans, joint, roots64 = self._planner_state(state)
+        a = [action.vx, action.vy] if self.kinematics == 'holonomic' else [action.v, action.r]
+        with torch.no_grad():
+            _, rew = self.tree_search().estimate_reward(robot, humans, joint, roots64, actions=[a])
+        return float(rew[0, 0])
+
+    def action_clip(self, state, action_space, width, depth=1):
+        """model_predictive_rl.py:242-269: the `width` actions with the best `reward + gamma_bar * V_planning(next state, depth,
+        width)` (one per action group in a sparse search).  depth = 1 (every call upstream makes) is one device level --
+        mprl_expand_f32 -- and the selection kernel of the search (mprl_action_clip_f32); deeper values come from V_planning.
+        The kept SET is the reference's; the order is descending one-step value (np.argpartition's order is arbitrary)."""
+        robot, humans, joint, roots64 = self._planner_state(state)
+        ts = self._search_for(action_space)
+        with torch.no_grad():
+            if roots64 is not None:
+                child, reward = ts.estimate_reward(robot, humans, True, roots64)
+            o = ts.expand(robot, humans, parents_are_joint_states=joint)
+            if roots64 is not None:
+                o["reward"] = reward
+            if depth == 1:
+                child_value = o["child_value"]
+            else:
+                vals = [float(self.V_planning((o["child_robot"][0, a].reshape(1, 1, 9), o["humans_next"]), depth, width)[0])
+                        for a in range(ts.num_actions)]
+                child_value = torch.tensor([vals], dtype=torch.float32, device=self.device)
+            if not ts.do_action_clip:                      # the method clips whatever the policy's own flag says
+                ts = TreeSearch(ts.value_estimator, ts.state_predictor, ts.actions_np, ts.groups_np, ts.kinematics, ts.time_step,
+                                ts.gamma_bar, ts.planning_depth, width, True, ts.sparse_search, ts.contraction_dtype)
+            value1, keep = ts.action_clip(o["reward"], child_value, width)
+        return [action_space[i] for i in keep[0].tolist()]
+
+    def V_planning(self, state, depth, width):
+        """model_predictive_rl.py:271-302: (value (1,1) tensor, trajectory [(state, action, reward), ...]) of planning `depth`
+        steps ahead from a tensor state (or a JointState).  Every level is the search's own device work -- ValueEstimator forward,
+        mprl_expand_f32 (state predictor, next states, rewards, V of the 81 children), mprl_action_clip_f32 -- and the back-up
+        `v/d + (d-1)/d (gamma_bar * next + r)` is taken on the host in float32, op for op as the device back-up (rgl_tail.h) and
+        the reference's tensor expression do."""
+        robot, humans, joint, roots64 = self._planner_state(state)
+        state_t = (robot.reshape(1, 1, 9), humans)
+        with torch.no_grad():
+            v = self.value_estimator((state_t[0], humans))
+            if depth == 1:
+                return v, [(state_t, None, None)]
+            ts = self.tree_search()
+            o = ts.expand(robot, humans, parents_are_joint_states=joint)
+            if roots64 is not None:
+                o["reward"] = ts.estimate_reward(robot, humans, True, roots64)[1]
+            if self.do_action_clip:
+                kept = ts.action_clip(o["reward"], o["child_value"], width)[1][0].tolist()
+            else:
+                kept = list(range(ts.num_actions))
+            f32 = np.float32
+            g, d = f32(self.get_normalized_gamma()), f32(depth)
+            c = f32((depth - 1) / depth)
+            v_over_d = f32(f32(v.reshape(-1)[0].item()) / d)
+            rewards = o["reward"][0].cpu().numpy()
+            best, best_ret, best_traj = None, None, None
+            for a in kept:
+                nxt = (o["child_robot"][0, a].reshape(1, 1, 9).clone(), o["humans_next"].clone())
+                nv, ntraj = self.V_planning(nxt, depth - 1, self.planning_width)
+                inner = f32(f32(g * f32(nv.reshape(-1)[0].item())) + rewards[a])
+                ret = f32(v_over_d + f32(c * inner))
+                if best is None or ret > best_ret:          # np.argmax: the first maximum
+                    best, best_ret, best_traj = a, ret, [(state_t, self.action_space[a], float(rewards[a]))] + ntraj
+        return torch.tensor([[best_ret]], dtype=torch.float32, device=self.device), best_traj
+
     def _root_tensors(self, state):
         robot, humans = _state_rows(state)
         robot_t = torch.tensor([robot], dtype=torch.float32, device=self.device)
@@ -439,6 +535,16 @@ class GCN(Policy):
         disc = pow(self.gamma, dt * float(robot[7]))
         vals = (reward.double() + disc * v[:, 0].double()).float().reshape(1, A)
         return vals, _first_strict_maximum(vals)
+
+    def compute_reward(self, nav, humans):
+        """multi_human_rl.py:73-96 for one (next robot state, next human states) pair: the END-point clearance reward the one-step
+        search scores every action with, evaluated by the search's own device step (gcn_prepare_f32, float64) -- the pair is
+        handed over as a scene that a zero action and resting humans leave where it is."""
+        row = [nav.px, nav.py, 0.0, 0.0, nav.radius, nav.gx, nav.gy, getattr(nav, "v_pref", 1.0), getattr(nav, "theta", 0.0)]
+        hrows = [[h.px, h.py, 0.0, 0.0, h.radius] for h in humans]
+        r64 = torch.tensor([row], dtype=torch.float64, device=self.device)
+        h64 = torch.tensor([hrows], dtype=torch.float64, device=self.device).reshape(1, len(hrows), 5)
+        return float(prepare_scenes(r64.float(), h64.float(), [[0.0, 0.0]], self.kinematics, self.time_step, (r64, h64))[2][0])
 
     def select_greedy_action(self, self_state):
         """Empty crowd (multi_human_rl.py:27-31 -> cadrl.py:193-228): no graph to evaluate -- the table action closest to the

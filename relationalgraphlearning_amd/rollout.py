@@ -167,9 +167,12 @@ class TreeSearch:
         return buf
 
     # -- device calls ----------------------------------------------------------------------------
-    def search(self, robot, humans, roots_are_joint_states=True, want_root_values=True, out=None, roots64=None):
+    def search(self, robot, humans, roots_are_joint_states=True, want_root_values=True, out=None, roots64=None, trace=False):
         """robot (B,9), humans (B,H,5) fp32 device tensors -> dict of device tensors:
         best_action (B,) int32, best_value (B,) fp32, root_values/root_kept (B,W0).
+        `trace`: run mprl_tree_search_traced_f32 instead (a measurement call: it waits for the search) and leave
+        {"predictor_ms": [...], "children_ms": [...], "total_ms": x} (per tree level, HIP events on the launch stream) in
+        `self.last["trace"]`.
         `out` = (int32 (B,), fp32 (B,)) contiguous device tensors to receive best_action / best_value in place.
         `roots64` = (robot (B,9), humans (B,H,5)) float64 device tensors: the JointStates the fp32 roots were rounded from; the
         root level's estimate_reward reads them, as the reference does (model_predictive_rl.py:226)."""
@@ -202,11 +205,21 @@ class TreeSearch:
                 out["root_values"] = torch.empty(B, W0, dtype=torch.float32, device=dev)
                 out["root_kept"] = torch.empty(B, W0, dtype=torch.int32, device=dev)
                 rv, rk = out["root_values"].data_ptr(), out["root_kept"].data_ptr()
-            rc = lib.mprl_tree_search_f32(C.byref(pl), robot.data_ptr(), humans.data_ptr(), B, H,
-                                          int(roots_are_joint_states), ws.data_ptr(), ws.numel(),
-                                          out["best_action"].data_ptr(), out["best_value"].data_ptr(), rv, rk, _stream())
-        nat.check(rc, "mprl_tree_search_f32")
-        self.last = dict(out, B=B, H=H, robot=robot, humans=humans, planner=pl, workspace=ws, roots64=roots64)
+            tr = None
+            if trace:
+                D = self.planning_depth
+                sp_ms, ch_ms, tot = (C.c_float * D)(), (C.c_float * D)(), C.c_float()
+                rc = lib.mprl_tree_search_traced_f32(C.byref(pl), robot.data_ptr(), humans.data_ptr(), B, H,
+                                                     int(roots_are_joint_states), ws.data_ptr(), ws.numel(),
+                                                     out["best_action"].data_ptr(), out["best_value"].data_ptr(), rv, rk, _stream(),
+                                                     sp_ms, ch_ms, C.byref(tot))
+                tr = {"predictor_ms": list(sp_ms), "children_ms": list(ch_ms), "total_ms": float(tot.value)}
+            else:
+                rc = lib.mprl_tree_search_f32(C.byref(pl), robot.data_ptr(), humans.data_ptr(), B, H,
+                                              int(roots_are_joint_states), ws.data_ptr(), ws.numel(),
+                                              out["best_action"].data_ptr(), out["best_value"].data_ptr(), rv, rk, _stream())
+        nat.check(rc, "mprl_tree_search_traced_f32" if trace else "mprl_tree_search_f32")
+        self.last = dict(out, B=B, H=H, robot=robot, humans=humans, planner=pl, workspace=ws, roots64=roots64, trace=tr)
         return out
 
     def decide(self, robot_row, human_rows):
@@ -300,6 +313,53 @@ class TreeSearch:
                                            ws.numel(), _stream())
         nat.check(rc, "mprl_expand_f32")
         return o
+
+    def estimate_reward(self, robot, humans, parents_are_joint_states=True, roots64=None, actions=None):
+        """estimate_reward + compute_next_state for every (parent, action) pair (mprl_estimate_reward_f32: the float64 reward
+        kernel of a tree level on its own; model_predictive_rl.py:304-357, state_predictor.py:41-60).  robot (P,9), humans
+        (P,H,5) -> (child_robot (P,A,9), reward (P,A)).  `actions`: a float64 (A',2) table to use instead of the policy's."""
+        robot = _require_device_tensor(robot, "robot states")
+        humans = _require_device_tensor(humans, "human states")
+        P, H = robot.shape[0], humans.shape[1]
+        dev = robot.device
+        with torch.cuda.device(dev):
+            pl = self.planner(dev)
+            table = None
+            if actions is not None:
+                table = torch.as_tensor(np.asarray(actions, dtype=np.float64).reshape(-1, 2), dtype=torch.float64).to(dev).contiguous()
+                pl.actions, pl.num_actions = table.data_ptr(), table.shape[0]
+            A = pl.num_actions
+            if roots64 is not None:
+                r64, h64 = _check_roots64(roots64, P, H)
+                pl.root_robot_f64, pl.root_humans_f64 = r64.data_ptr(), h64.data_ptr()
+            child = torch.empty(P, A, 9, dtype=torch.float32, device=dev)
+            reward = torch.empty(P, A, dtype=torch.float32, device=dev)
+            rc = nat.lib().mprl_estimate_reward_f32(C.byref(pl), robot.data_ptr(), humans.data_ptr(), P, H,
+                                                    int(parents_are_joint_states), child.data_ptr(), reward.data_ptr(), _stream())
+            nat.check(rc, "mprl_estimate_reward_f32")
+            if table is not None:
+                torch.cuda.current_stream(dev).synchronize()          # the temporary table must outlive the launch
+        return child, reward
+
+    def action_clip(self, reward, child_value, width=None):
+        """action_clip's selection (mprl_action_clip_f32; model_predictive_rl.py:242-269): reward, child_value (P,A) ->
+        (value1 (P,A) = reward + gamma_bar * child_value, keep (P,W) int32: the `width` (default: planning_width) best actions
+        per parent in descending one-step value, one per group in a sparse search; every action when clipping is off)."""
+        reward = _require_device_tensor(reward, "rewards")
+        child_value = _require_device_tensor(child_value, "child values")
+        P, A = reward.shape
+        dev = reward.device
+        with torch.cuda.device(dev):
+            pl = self.planner(dev)
+            if width is not None:
+                pl.planning_width = int(width)
+            W = pl.planning_width if pl.do_action_clip else A
+            value1 = torch.empty(P, A, dtype=torch.float32, device=dev)
+            keep = torch.empty(P, W, dtype=torch.int32, device=dev)
+            rc = nat.lib().mprl_action_clip_f32(C.byref(pl), reward.data_ptr(), child_value.data_ptr(), P, value1.data_ptr(),
+                                                keep.data_ptr(), _stream())
+        nat.check(rc, "mprl_action_clip_f32")
+        return value1, keep
 
     def value_children(self, child_robot, humans_next, out=None):
         """child_robot (P,A,9), humans_next (P,H,5) -> child_value (P,A): the dominant kernel alone."""
@@ -417,6 +477,32 @@ def rotate(joint14, kinematics="holonomic"):
                                       nat.KINEMATICS[kinematics], _stream())
     nat.check(rc, "gcn_rotate_f32")
     return out
+
+
+def prepare_scenes(robot, humans, actions, kinematics="holonomic", time_step=0.25, roots64=None):
+    """gcn_prepare_f32: robot (B,9), humans (B,H,5), actions (A,2) float64 -> (self6 (B*A,6), hum7 (B*A,H,7), reward (B*A,)) --
+    CADRL.propagate + constant-velocity humans + CADRL.rotate + compute_reward for every (root, action) pair
+    (cadrl.py:113-138,241-276, multi_human_rl.py:46-51,73-96)."""
+    robot = _require_device_tensor(robot, "robot states")
+    humans = _require_device_tensor(humans, "human states")
+    B, H = robot.shape[0], humans.shape[1]
+    dev = robot.device
+    table = torch.as_tensor(np.asarray(actions, dtype=np.float64).reshape(-1, 2), dtype=torch.float64).to(dev).contiguous()
+    A = table.shape[0]
+    pl = nat.GcnPlanner()
+    pl.kinematics, pl.num_actions, pl.time_step, pl.actions = nat.KINEMATICS[kinematics], A, float(time_step), table.data_ptr()
+    if roots64 is not None:
+        r64, h64 = _check_roots64(roots64, B, H)
+        pl.root_robot_f64, pl.root_humans_f64 = r64.data_ptr(), h64.data_ptr()
+    self6 = torch.empty(B * A, 6, dtype=torch.float32, device=dev)
+    hum7 = torch.empty(B * A, H, 7, dtype=torch.float32, device=dev)
+    reward = torch.empty(B * A, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = nat.lib().gcn_prepare_f32(C.byref(pl), robot.data_ptr(), humans.data_ptr(), B, H, self6.data_ptr(), hum7.data_ptr(),
+                                       reward.data_ptr(), _stream())
+        nat.check(rc, "gcn_prepare_f32")
+        torch.cuda.current_stream(dev).synchronize()              # the action table is a temporary
+    return self6, hum7, reward
 
 
 # --------------------------------------------------------------------------------------------------

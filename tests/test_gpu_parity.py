@@ -189,6 +189,85 @@ def test_planning_kats(c, dev):
     assert ts.logical_value_evals_per_root() == int(pl[k + "counts"][0][0])
 
 
+def test_planner_step_methods_match_the_reference_planner(dev):
+    """ModelPredictiveRL.estimate_reward / action_clip / V_planning and GCN.compute_reward (model_predictive_rl.py:242-357,
+    multi_human_rl.py:73-96) as Python-callable methods backed by the device functions of the search (VERDICT r3 missing 5):
+    rewards against the reference's own KATs (fixture actions_rewards.npz), action_clip against the kept sets / clip values the
+    reference returned (planning.npz), V_planning against the oracle's restatement of the recursive planner (SeqPlanner, pinned
+    through mprl_predict_sequential on the same fixtures)."""
+    from relationalgraphlearning_amd import actions as A_
+    ar, pl = gio.load("actions_rewards"), gio.load("planning")
+    pol = make_mprl_policy("trained", D=2, w=2, clip=True, device=dev)
+    pol.build_action_space(1.0)
+    # estimate_reward: tensor states (fp32-difference convention) and JointStates (float64)
+    for i, name in enumerate(ar["rew.names"]):
+        n = int(ar["rew.n_humans"][i])
+        a = A_.ActionXY(*[float(x) for x in ar["rew.actions"][i]])
+        st = (torch.tensor(ar["rew.robot"][i:i + 1].astype(np.float32)).reshape(1, 1, 9),
+              torch.tensor(ar["rew.humans"][i:i + 1, :n].astype(np.float32)))
+        assert abs(pol.estimate_reward(st, a) - float(ar["rew.tensor"][i])) < 1e-7, name
+        js = JS(ar["rew.robot"][i], ar["rew.humans"][i, :n])
+        assert abs(pol.estimate_reward(js, a) - float(ar["rew.joint"][i])) < 1e-7, name
+    # action_clip on the fixture's root scenes: the kept SET and the one-step values the reference computed
+    k = "plan.d2w2."
+    R, Hh = pl["plan.scene.s5.robot"], pl["plan.scene.s5.humans"]
+    P = gio.oracle_params("trained")
+    cfg = orc.OracleConfig(planning_depth=2, planning_width=2, do_action_clip=True)
+    worst = 0.0
+    for b in range(R.shape[0]):
+        js = JS(R[b], Hh[b])
+        kept = pol.action_clip(js, pol.action_space, 2)
+        idx = sorted(pol.action_space.index(a) for a in kept)
+        assert idx == sorted(int(x) for x in pl[k + "kept"][b]), (b, idx, pl[k + "kept"][b])
+        # V_planning of the kept children against the oracle's recursive planner, depth 1 and 2
+        sp = orc.SeqPlanner(P, cfg, 1.0, ([float(x) for x in R[b]], [[float(x) for x in row] for row in Hh[b]]))
+        root = (torch.tensor(R[b:b + 1].astype(np.float32)).reshape(1, 1, 9), torch.tensor(Hh[b:b + 1].astype(np.float32)))
+        with torch.no_grad():
+            for a in kept:
+                nxt = sp.SP(root, sp.actions[pol.action_space.index(a)])
+                for depth in (1, 2):
+                    want = float(sp.plan(nxt, depth, 2))
+                    got, traj = pol.V_planning((nxt[0].to(dev), nxt[1].to(dev)), depth, 2)
+                    assert tuple(got.shape) == (1, 1) and len(traj) == depth
+                    assert traj[-1][1] is None and (depth == 1 or traj[0][1] in pol.action_space)
+                    worst = max(worst, abs(float(got) - want))
+    assert worst < 1e-6, worst
+    # the reference's root value of a kept action = estimate_reward + gamma_bar * V_planning(next, D, w): rebuild one from the methods
+    js = JS(R[0], Hh[0])
+    out = pol.tree_search().search(torch.tensor(R[:1].astype(np.float32)).to(dev), torch.tensor(Hh[:1].astype(np.float32)).to(dev), True)
+    a0 = int(out["root_kept"][0, 0])
+    o = pol.tree_search().expand(torch.tensor(R[:1].astype(np.float32)).to(dev), torch.tensor(Hh[:1].astype(np.float32)).to(dev))
+    nxt = (o["child_robot"][0, a0].reshape(1, 1, 9), o["humans_next"])
+    v, _ = pol.V_planning(nxt, 2, 2)
+    rebuilt = pol.estimate_reward(js, pol.action_space[a0]) + pol.get_normalized_gamma() * float(v)
+    assert abs(rebuilt - float(out["root_values"][0, 0])) < 1e-6
+    # GCN.compute_reward: every branch of multi_human_rl.py:73-96 against a float64 evaluation of the same lines
+    gp = make_gcn_policy(device=dev)
+    gp.time_step = 0.25
+
+    class S(object):
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+    rng = np.random.RandomState(3)
+    for case in range(40):
+        nav = S(px=rng.uniform(-2, 2), py=rng.uniform(-2, 2), radius=0.3, gx=rng.uniform(-2, 2), gy=rng.uniform(-2, 2), v_pref=1.0, theta=0.0)
+        if case % 5 == 0:
+            nav.gx, nav.gy = nav.px + 0.1, nav.py
+        hs = [S(px=nav.px + rng.uniform(-1.5, 1.5), py=nav.py + rng.uniform(-1.5, 1.5), radius=0.3) for _ in range(1 + case % 6)]
+        dmin, coll = float("inf"), False
+        for h in hs:
+            d = np.linalg.norm((nav.px - h.px, nav.py - h.py)) - nav.radius - h.radius
+            if d < 0:
+                coll = True
+                break
+            dmin = min(dmin, d)
+        reach = np.linalg.norm((nav.px - nav.gx, nav.py - nav.gy)) < nav.radius
+        want = -0.25 if coll else (1 if reach else ((dmin - 0.2) * 0.5 * 0.25 if dmin < 0.2 else 0))
+        assert abs(gp.compute_reward(nav, hs) - want) < 1e-7, (case, want)
+    report("planner-step methods (estimate_reward / action_clip / V_planning / compute_reward): reference KATs and kept sets exact, "
+           "V_planning within %.1e of the recursive oracle" % worst)
+
+
 def test_sparse_search_takes_any_group_ids(dev):
     """the select kernel used to mask group ids with `& 63`, so a direct C-ABI caller with other ids got silent
     aliasing.  It now compares ids like the reference's python set (model_predictive_rl.py:252-263): a relabelling of the groups by
