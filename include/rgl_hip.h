@@ -140,7 +140,10 @@ int rgl_graph_forward_f32(const RglGraph* graph, const RglMlp* value_head, const
  * N <= 64, a pipeline of MFMA tile kernels (rgl_backward_mfma.hip) -- taken from 256 scenes, whenever `stream` is being
  * captured into a hipGraph, and where the per-scene kernel does not fit.  Environment: RGL_BACKWARD_MFMA = 0 | 1 forces a
  * path (2: RGL_ERR_BAD_MODE instead of the per-scene kernel where the pipeline does not apply), RGL_BACKWARD_MFMA_MIN moves the
- * threshold.  Both are deterministic (fixed summation order per shape).
+ * threshold.  Both are deterministic (fixed summation order per shape) -- but they are TWO summation orders: the same call below the
+ * threshold runs the per-scene kernel eagerly and the tile pipeline while `stream` is being captured, so an eager step and its
+ * captured replay agree to rounding (~4e-8 relative on the shipped shapes), not bit for bit.  Force one path with
+ * RGL_BACKWARD_MFMA where bitwise equality between the two forms is wanted (the switches are read on every call).
  *   d_value [n_scenes], d_humans_next [n_scenes][H][out], d_H [n_scenes][N][x_dim]: upstream gradients of the
  *   corresponding forward outputs (device; NULL = zero).  detach_graph = 1 reproduces
  *   StatePredictor(..., detach=True): only the heads receive gradients.

@@ -90,7 +90,11 @@ __device__ __forceinline__ void tail_select(const TailArgs& t, int p, int* kl) {
     if (!t.clip) {
         for (int a = lane; a < A; a += 64) { kp[a] = a; kl[a] = a; }
     } else {
-        // sparse search: one action per group.  The groups taken so far are kept BY ID (any int32, as in the reference's python
+        // sparse search: one action per group, visited in descending one-step value; EXACTLY tied values are visited lower index
+        // first.  (Upstream walks np.argsort(values)[::-1], model_predictive_rl.py:254: numpy's default sort is not stable and is
+        // vectorised per CPU, so the order of exact ties is platform-defined there -- a stable sort would visit the HIGHER index
+        // first.  Ties between different actions need bit-equal reward + gamma * V: documented deviation)
+        // The groups taken so far are kept BY ID (any int32, as in the reference's python
         // set, model_predictive_rl.py:252-263) -- the width of a sparse search is at most kMaxSparseWidth (checked by the entry
         // point), so the set is a handful of wave-uniform registers and no id range has to be imposed on the caller.
         int seen[kMaxSparseWidth];

@@ -47,12 +47,18 @@ def _require_device_tensor(t, what):
 def _flat_params(module):
     """The parameters of `module` and its sub-modules, like list(module.parameters()) but without walking the module tree on every
     call (nn.Module.parameters() re-discovers the sub-modules each time: ~115 such walks were a fifth of an eager training step's
-    host time).  The list of sub-modules is kept on the module (its structure is fixed after construction); the Parameter objects
-    are read from the sub-modules' own dicts each time, so replaced parameters and moved storages are seen."""
-    mods = module.__dict__.get("_rgl_submodules")
-    if mods is None:
+    host time).  The list of sub-modules is kept on the module; the Parameter objects are read from the sub-modules' own dicts each
+    time, so replaced parameters and moved storages are seen.  A REPLACED SUB-MODULE (`seq[2] = nn.Linear(...)`, `add_module`) is
+    seen too: the kept list carries a fingerprint -- the identity of every child in every sub-module's `_modules` dict -- that is
+    checked on each call (a walk over a few small dicts, no generator recursion) and the list is rebuilt when it differs."""
+    ent = module.__dict__.get("_rgl_submodules")
+    if ent is not None:
+        mods, print_ = ent
+        if tuple(id(c) for m in mods for c in m._modules.values()) != print_:
+            ent = None
+    if ent is None:
         mods = list(module.modules())
-        module.__dict__["_rgl_submodules"] = mods
+        module.__dict__["_rgl_submodules"] = (mods, tuple(id(c) for m in mods for c in m._modules.values()))
     return [p for m in mods for p in m._parameters.values() if p is not None]
 
 
@@ -123,7 +129,10 @@ def _seq_last_relu(seq):
     return len(mods) > 0 and isinstance(mods[-1], nn.ReLU)
 
 
-_PENDING_TRANSPOSES = []      # (torch weight (out,in), k-major destination, rows, cols) collected by pack_mlp
+# (torch weight (out,in), k-major destination, rows, cols) collected by pack_mlp.  Process-global and unsynchronised, like torch's
+# own current-stream state: descriptors are packed from one thread at a time (the thread that runs the forwards); a failing pack
+# takes its own entries back out (_PackCache.get, batched_transposes.__exit__).
+_PENDING_TRANSPOSES = []
 _BATCH_DEPTH = [0]
 
 
@@ -136,10 +145,13 @@ class batched_transposes(object):
         _BATCH_DEPTH[0] += 1
         return self
 
-    def __exit__(self, *exc):
+    def __exit__(self, exc_type, *exc):
         _BATCH_DEPTH[0] -= 1
         if _BATCH_DEPTH[0] == 0:
-            flush_transposes()
+            if exc_type is None:
+                flush_transposes()
+            else:
+                del _PENDING_TRANSPOSES[:]          # the block failed: nothing it queued may be launched later by somebody else
         return False
 
 
@@ -244,7 +256,14 @@ class _PackCache:
         key = tuple((p.data_ptr(), p._version, p.device.index) for m in modules for p in _flat_params(m))
         if key != self.key:
             keep = []
-            self.value = build(keep, self.buffers)
+            n_pending = len(_PENDING_TRANSPOSES)
+            try:
+                self.value = build(keep, self.buffers)
+            except BaseException:
+                # a descriptor that failed half-way (a CPU tensor in a later layer ...) must not leave its first layers queued: the
+                # next unrelated flush would launch them, on whatever stream is current then, and the queue pins their tensors
+                del _PENDING_TRANSPOSES[n_pending:]
+                raise
             if _BATCH_DEPTH[0] == 0:
                 flush_transposes()
             self.keep = keep
@@ -273,6 +292,7 @@ def invalidate_packed_weights(*modules):
     replays mutate the parameters in place but do not bump `tensor._version`, which is what the caches key on."""
     for top in modules:
         for m in top.modules():
+            m.__dict__.pop("_rgl_submodules", None)          # and the kept sub-module lists (_flat_params)
             for name in ("_cache", "_head_cache"):
                 c = getattr(m, name, None)
                 if isinstance(c, _PackCache):

@@ -127,7 +127,7 @@ class TreeSearch:
         when the predictor's descriptors were (re)built, into the same device buffer every time.  None when the mode or the
         predictor has no such kernel."""
         sp = self.state_predictor
-        key = (sp.graph_model._cache.epoch, sp._cache.epoch)
+        key = (sp.graph_model._cache.epoch, sp._cache.epoch, self.contraction_dtype)     # the layout depends on the mode
         dkey = str(device)
         ent = self._sp_images.get(dkey)
         if ent is not None and ent[0] == key:
@@ -150,7 +150,9 @@ class TreeSearch:
         image-based kernel."""
         ve = self.value_estimator
         gcache, hcache = ve.graph_model._cache, ve._cache
-        key = (gcache.epoch, hcache.epoch)        # process-wide pack serials (nets._PACK_SERIAL): identify the parameter state
+        # process-wide pack serials (nets._PACK_SERIAL) identify the parameter state; the image's LAYOUT depends on the
+        # contraction mode (f32 matrices vs split-f16 fragments, same byte size): a mode changed on a live object repacks
+        key = (gcache.epoch, hcache.epoch, self.contraction_dtype)
         dkey = str(device)
         ent = self._images.get(dkey)
         if ent is not None and ent[0] == key:

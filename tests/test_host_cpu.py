@@ -221,3 +221,35 @@ def test_flat_params_follow_the_module_like_parameters_does():
     ve = pol.value_estimator
     ve.value_network[0].weight = torch.nn.Parameter(torch.zeros_like(ve.value_network[0].weight))      # a replaced Parameter object
     assert [id(p) for p in nets._flat_params(ve)] == [id(p) for p in ve.parameters()]
+    # a replaced SUB-MODULE (the kept sub-module list used to hide it for ever) and an added one
+    old = [id(p) for p in nets._flat_params(ve)]
+    ve.value_network[2] = torch.nn.Linear(ve.value_network[2].in_features, ve.value_network[2].out_features)
+    assert [id(p) for p in nets._flat_params(ve)] == [id(p) for p in ve.parameters()] != old
+    ve.value_network.add_module("extra", torch.nn.Linear(1, 1))
+    assert [id(p) for p in nets._flat_params(ve)] == [id(p) for p in ve.parameters()]
+    nets.invalidate_packed_weights(ve)
+    assert "_rgl_submodules" not in ve.__dict__
+
+
+def test_a_failed_pack_leaves_no_transposes_queued():
+    """pack_mlp queues one transpose job per Linear weight; a descriptor that fails part-way (here: the module's
+    parameters are CPU tensors) must take its jobs back out instead of leaving them for the next unrelated flush."""
+    from relationalgraphlearning_amd import nets
+    pol = make_mprl_policy("trained", 1)
+    assert not nets._PENDING_TRANSPOSES
+    with pytest.raises(nat.NativeLibraryError):
+        pol.value_estimator.graph_model.descriptor()
+    assert not nets._PENDING_TRANSPOSES
+    with pytest.raises(nat.NativeLibraryError):
+        with nets.batched_transposes():
+            pol.value_estimator.graph_model.descriptor()
+    assert not nets._PENDING_TRANSPOSES and nets._BATCH_DEPTH[0] == 0
+
+
+def test_tree_search_image_caches_are_keyed_on_the_contraction_mode():
+    """the children / predictor weight images are laid out per contraction mode; the cache key must carry it."""
+    import inspect
+    from relationalgraphlearning_amd import rollout
+    for fn in (rollout.TreeSearch._children_image, rollout.TreeSearch._predictor_image):
+        src = inspect.getsource(fn)
+        assert "self.contraction_dtype" in src.split("ent = ")[0], fn.__name__
