@@ -9,8 +9,9 @@ from .policy import Policy, ModelPredictiveRL, GCN, register
 from .state import FullState, ObservableState, JointState, tensor_to_joint_state
 from .rollout import TreeSearch, GcnSearch, ShardedRollout, rotate, shard_bounds
 from .vector_explorer import VectorExplorer, ReplayMemory
+from .trainer import MPRLTrainer, VNRLTrainer, register_trainers
 
 __all__ = ["ActionXY", "ActionRot", "mlp", "RGL", "ValueEstimator", "StatePredictor", "LinearStatePredictor",
            "ValueNetwork", "invalidate_packed_weights", "Policy", "ModelPredictiveRL", "GCN", "register", "TreeSearch", "GcnSearch",
            "ShardedRollout", "rotate", "shard_bounds", "FullState", "ObservableState", "JointState",
-           "tensor_to_joint_state", "VectorExplorer", "ReplayMemory"]
+           "tensor_to_joint_state", "VectorExplorer", "ReplayMemory", "MPRLTrainer", "VNRLTrainer", "register_trainers"]

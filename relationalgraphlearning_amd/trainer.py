@@ -1,0 +1,474 @@
+"""Trainers with the reference's contract whose optimisation step is ONE replayed hipGraph.
+
+Mirrors crowd_nav/utils/trainer.py: `MPRLTrainer` (:10-161, path M: value update against a frozen target copy + state-predictor
+update, two optimizers) and `VNRLTrainer` (:164-250, path G) -- same constructor arguments, `update_target_model`,
+`set_learning_rate`, `optimize_epoch(num_epochs)`, `optimize_batch(num_batches, episode)`, same log lines / writer scalars, same
+batch bookkeeping (including upstream's `batch_count > num_batches` off-by-one and its division by `num_batches`).
+`register_trainers(module)` puts them into the namespace crowd_nav/train.py imports its trainers from.
+
+What is different is how a step runs.  Upstream's step is ~60 launches of launch-sized work driven from Python (1.0-1.6 ms at batch
+100 on this box, host-bound); here the whole step -- both forwards, both backwards (rgl_graph_backward_f32), the Adam updates, the
+repacking of the k-major weight copies, the loss accumulation -- is captured once per batch shape into a hipGraph and replayed
+(0.36-0.37 ms): the library allocates only through torch, never synchronises and repacks on the capture stream, which is what makes
+the capture legal.  Per batch the host copies the batch into the graph's static input buffers and launches
+the graph; losses accumulate on the device (float64, the sum upstream forms from `loss.data.item()`), read once per call.
+
+Batches: upstream draws them with `DataLoader(memory, batch_size, shuffle=True)`.  A `memory` that offers `as_tensors()` (this
+package's ReplayMemory: the experience as stacked device tensors) is sampled by index instead -- the SAME indices in the same
+order, drawn from torch's global generator exactly as the DataLoader's RandomSampler would (`_ShuffledIndexBatches`, checked
+against the real DataLoader on CPU) -- and gathered with one index_select per field; any other dataset, and a `data_loader` set
+by the caller, goes through the DataLoader itself.  SGD and shapes that change from batch to batch run the same step eagerly.
+"""
+import copy
+import logging
+
+import torch
+import torch.nn as nn
+import torch.optim as optim
+from torch.utils.data import DataLoader
+
+from .nets import invalidate_packed_weights
+
+
+class _ShuffledIndexBatches(object):
+    """The index batches `DataLoader(dataset of n items, batch_size, shuffle=True)` would yield, consuming torch's global generator
+    the way the loader does: one int64 draw when the iterator is made (_BaseDataLoaderIter's base seed), one when the sampler
+    starts (RandomSampler's private generator), then `randperm(n)` from that generator cut into batches (the last one short)."""
+
+    def __init__(self, n, batch_size):
+        self.n, self.batch_size = int(n), int(batch_size)
+
+    def __iter__(self):
+        torch.empty((), dtype=torch.int64).random_()                                    # the loader iterator's base seed
+        if self.n == 0:
+            return
+        g = torch.Generator()
+        g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))         # RandomSampler.__iter__
+        perm = torch.randperm(self.n, generator=g)
+        for lo in range(0, self.n, self.batch_size):
+            yield perm[lo:lo + self.batch_size]
+
+
+class _CapturedStep(object):
+    """`fn(*static inputs)` captured into a hipGraph after two warm-up runs on a side stream; `run(batch)` copies the batch into
+    the static inputs and replays.  `signature` = what the capture baked in (shapes, optimizer / module identities)."""
+
+    def __init__(self, fn, example, signature, warmup_is_a_step):
+        self.signature = signature
+        self.static = [torch.empty_like(t).copy_(t) for t in example]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn(*self.static)                     # a REAL step: code objects, workspaces, optimizer state; counted by the caller
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            fn(*self.static)                     # recorded, not executed
+        self.consumed_first = warmup_is_a_step
+
+    def run(self, batch):
+        for dst, src in zip(self.static, batch):
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+
+
+def _stack_field(x, device):
+    return x.to(device) if torch.is_tensor(x) else x
+
+
+class _TrainerBase(object):
+    """Graph bookkeeping shared by the two trainers."""
+
+    capture = True                # class-level switch: False = every step eager (measurements, debugging)
+
+    def _init_graphs(self):
+        self._steps = {}          # (kind, shapes...) -> _CapturedStep
+        self._loss = None         # device float64 [2]: accumulated value / predictor loss of the current call
+        self._stale = []          # modules whose packed weights a replay leaves behind the parameters
+        self._replayed = False    # a replay ran since the caches were last invalidated
+
+    def _can_capture(self, *optimizers):
+        if not (self.capture and torch.cuda.is_available() and str(self.device).startswith("cuda")):
+            return False
+        return all(o is None or isinstance(o, optim.Adam) for o in optimizers)
+
+    def _drop_graphs(self):
+        self._steps = {}
+
+    def _run(self, kind, fn, batch, modules, signature):
+        """One optimisation step on `batch` (a list of device tensors): replay of the step captured for this kind / these shapes,
+        or -- SGD, capture switched off -- the eager step."""
+        batch = [b.contiguous() for b in batch]
+        key = (kind,) + tuple(tuple(b.shape) for b in batch)
+        st = self._steps.get(key) if self._capturable else None
+        if st is not None and st.signature != signature:
+            st = None
+        if st is None:
+            # an EAGER run follows (the plain step, or the warm-up step of a new capture): replays moved the parameters without
+            # bumping their version counters, so the descriptor caches would hand it the packed weights of one step ago
+            if self._replayed:
+                invalidate_packed_weights(*self._stale)
+                self._replayed = False
+            if not self._capturable:
+                fn(*batch)
+                return
+            self._steps[key] = _CapturedStep(fn, batch, signature, True)      # its warm-up run WAS this batch's step
+            for m in modules:
+                if all(m is not x for x in self._stale):
+                    self._stale.append(m)
+            return
+        st.run(batch)
+        self._replayed = True
+
+    def _finish(self):
+        """After the last replay of a call: replays do not bump autograd's version counters, so the descriptor caches of the
+        trained modules (k-major weight copies, the search's weight images) must be told the parameters moved."""
+        if self._stale and self._replayed:
+            invalidate_packed_weights(*self._stale)
+            self._replayed = False
+
+    def _loss_begin(self):
+        if self._loss is None:
+            self._loss = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self._loss.zero_()
+
+    def _loss_read(self):
+        v, s = self._loss.tolist()               # the one host read of the call
+        return v, s
+
+
+class MPRLTrainer(_TrainerBase):
+    def __init__(self, value_estimator, state_predictor, memory, device, policy, writer, batch_size, optimizer_str, human_num,
+                 reduce_sp_update_frequency, freeze_state_predictor, detach_state_predictor, share_graph_model):
+        """Train the trainable models of a ModelPredictiveRL policy (crowd_nav/utils/trainer.py:10-36, same arguments)."""
+        self.value_estimator = value_estimator
+        self.state_predictor = state_predictor
+        self.device = device
+        self.writer = writer
+        self.target_policy = policy
+        self.target_model = None
+        self.criterion = nn.MSELoss().to(device)
+        self.memory = memory
+        self.data_loader = None
+        self.batch_size = batch_size
+        self.optimizer_str = optimizer_str
+        self.reduce_sp_update_frequency = reduce_sp_update_frequency
+        self.state_predictor_update_interval = human_num
+        self.freeze_state_predictor = freeze_state_predictor
+        self.detach_state_predictor = detach_state_predictor
+        self.share_graph_model = share_graph_model
+        self.v_optimizer = None
+        self.s_optimizer = None
+        # for value update
+        self.gamma = 0.9
+        self.time_step = 0.25
+        self.v_pref = 1
+        self._capturable = False
+        self._init_graphs()
+
+    # -- the reference's set-up calls ------------------------------------------------------------------------------------------
+    def update_target_model(self, target_model):
+        """A frozen copy of `target_model` (trainer.py:41).  The first call deep-copies; later calls copy the parameters INTO that
+        copy, so captured steps -- which read the target's weights through fixed device pointers -- stay valid."""
+        if self.target_model is not None and self._same_structure(self.target_model, target_model):
+            with torch.no_grad():
+                for dst, src in zip(self.target_model.parameters(), target_model.parameters()):
+                    dst.copy_(src)
+            if next(self.target_model.parameters()).is_cuda:
+                invalidate_packed_weights(self.target_model)
+                self._refresh_packed(self.target_model)
+        else:
+            self.target_model = copy.deepcopy(target_model)
+            self._drop_graphs()
+
+    @staticmethod
+    def _same_structure(a, b):
+        pa, pb = list(a.parameters()), list(b.parameters())
+        return len(pa) == len(pb) and all(x.shape == y.shape and x.device == y.device for x, y in zip(pa, pb))
+
+    @staticmethod
+    def _refresh_packed(model):
+        """Repack the descriptors of `model` now (in place: same device buffers), so that a captured step whose recording did not
+        contain the repack reads the current weights."""
+        with torch.no_grad():
+            for m in model.modules():
+                for name in ("descriptor", "head_descriptor"):
+                    fn = getattr(m, name, None)
+                    if callable(fn):
+                        fn()
+
+    def set_learning_rate(self, learning_rate):
+        capturable = self.capture and str(self.device).startswith("cuda")
+        if self.optimizer_str == 'Adam':
+            self.v_optimizer = optim.Adam(self.value_estimator.parameters(), lr=learning_rate, capturable=capturable)
+            if self.state_predictor.trainable:
+                self.s_optimizer = optim.Adam(self.state_predictor.parameters(), lr=learning_rate, capturable=capturable)
+        elif self.optimizer_str == 'SGD':
+            self.v_optimizer = optim.SGD(self.value_estimator.parameters(), lr=learning_rate, momentum=0.9)
+            if self.state_predictor.trainable:
+                self.s_optimizer = optim.SGD(self.state_predictor.parameters(), lr=learning_rate)
+        else:
+            raise NotImplementedError
+        self._capturable = self._can_capture(self.v_optimizer, self.s_optimizer)
+        self._drop_graphs()                       # the optimizers (and their state tensors) are new
+        if self.state_predictor.trainable:
+            logging.info('Lr: {} for parameters {} with {} optimizer'.format(learning_rate, ' '.join(
+                [name for name, param in list(self.value_estimator.named_parameters()) +
+                 list(self.state_predictor.named_parameters())]), self.optimizer_str))
+        else:
+            logging.info('Lr: {} for parameters {} with {} optimizer'.format(learning_rate, ' '.join(
+                [name for name, param in list(self.value_estimator.named_parameters())]), self.optimizer_str))
+
+    # -- batches ---------------------------------------------------------------------------------------------------------------
+    def _batches(self):
+        """Batches of (robot_states, human_states, values, rewards, next_robot_states, next_human_states), upstream's order."""
+        fast = getattr(self.memory, "as_tensors", None)
+        if self.data_loader is None and callable(fast):
+            fields = fast()
+            if fields is not None:
+                for idx in _ShuffledIndexBatches(len(self.memory), self.batch_size):
+                    idx = idx.to(fields[0].device)
+                    yield [f.index_select(0, idx) for f in fields]
+                return
+        if self.data_loader is None:
+            self.data_loader = DataLoader(self.memory, self.batch_size, shuffle=True)
+        for data in self.data_loader:
+            yield [_stack_field(x, self.device) for x in data]
+
+    # -- the two kinds of step ---------------------------------------------------------------------------------------------------
+    def _signature(self):
+        return (id(self.v_optimizer), id(self.s_optimizer), id(self.target_model), id(self.value_estimator), id(self.state_predictor),
+                bool(self.detach_state_predictor))
+
+    def _value_step(self, robot_states, human_states, target_values_fn):
+        self.v_optimizer.zero_grad()
+        outputs = self.value_estimator((robot_states, human_states))
+        loss = self.criterion(outputs, target_values_fn())
+        loss.backward()
+        self.v_optimizer.step()
+        self._loss[0] += loss.detach().double()
+
+    def _predictor_step(self, robot_states, human_states, next_human_states, detach):
+        self.s_optimizer.zero_grad()
+        if detach is None:
+            _, next_human_states_est = self.state_predictor((robot_states, human_states), None)
+        else:
+            _, next_human_states_est = self.state_predictor((robot_states, human_states), None, detach=detach)
+        loss = self.criterion(next_human_states_est, next_human_states)
+        loss.backward()
+        self.s_optimizer.step()
+        self._loss[1] += loss.detach().double()
+
+    def optimize_epoch(self, num_epochs):
+        if self.v_optimizer is None:
+            raise ValueError('Learning rate is not set!')
+        modules = [self.value_estimator, self.state_predictor]
+
+        def il_step(update_sp):
+            def fn(robot_states, human_states, values, next_human_states):
+                self._value_step(robot_states, human_states, lambda: values)
+                if update_sp:
+                    self._predictor_step(robot_states, human_states, next_human_states, None)
+            return fn
+        steps = {False: il_step(False), True: il_step(True)}
+        for epoch in range(num_epochs):
+            self._loss_begin()
+            logging.debug('{}-th epoch starts'.format(epoch))
+            update_counter = 0
+            for data in self._batches():
+                robot_states, human_states, values, _, _, next_human_states = data
+                update_sp = False
+                if self.state_predictor.trainable:
+                    update_sp = update_counter % self.state_predictor_update_interval == 0
+                    update_counter += 1
+                self._run(("il", update_sp), steps[update_sp], [robot_states, human_states, values.to(self.device), next_human_states],
+                          modules, self._signature())
+            epoch_v_loss, epoch_s_loss = self._loss_read()
+            logging.debug('{}-th epoch ends'.format(epoch))
+            self.writer.add_scalar('IL/epoch_v_loss', epoch_v_loss / len(self.memory), epoch)
+            self.writer.add_scalar('IL/epoch_s_loss', epoch_s_loss / len(self.memory), epoch)
+            logging.info('Average loss in epoch %d: %.2E, %.2E', epoch, epoch_v_loss / len(self.memory),
+                         epoch_s_loss / len(self.memory))
+        self._finish()
+        return
+
+    def optimize_batch(self, num_batches, episode):
+        if self.v_optimizer is None:
+            raise ValueError('Learning rate is not set!')
+        gamma_bar = pow(self.gamma, self.time_step * self.v_pref)
+        modules = [self.value_estimator, self.state_predictor]
+
+        def rl_step(update_sp):
+            def fn(robot_states, human_states, rewards, next_robot_states, next_human_states):
+                def target():
+                    with torch.no_grad():          # the frozen copy: upstream lets autograd walk it and never uses the result
+                        return rewards + gamma_bar * self.target_model((next_robot_states, next_human_states))
+                self._value_step(robot_states, human_states, target)
+                if update_sp:
+                    self._predictor_step(robot_states, human_states, next_human_states, self.detach_state_predictor)
+            return fn
+        steps = {False: rl_step(False), True: rl_step(True)}
+        self._loss_begin()
+        batch_count = 0
+        for data in self._batches():
+            robot_states, human_states, _, rewards, next_robot_states, next_human_states = data
+            update_sp = False
+            if self.state_predictor.trainable:
+                update_sp = True
+                if self.freeze_state_predictor:
+                    update_sp = False
+                elif self.reduce_sp_update_frequency and batch_count % self.state_predictor_update_interval == 0:
+                    update_sp = False
+            self._run(("rl", update_sp), steps[update_sp],
+                      [robot_states, human_states, rewards, next_robot_states, next_human_states], modules, self._signature())
+            batch_count += 1
+            if batch_count > num_batches:
+                break
+        v_losses, s_losses = self._loss_read()
+        self._finish()
+        average_v_loss = v_losses / num_batches
+        average_s_loss = s_losses / num_batches
+        logging.info('Average loss : %.2E, %.2E', average_v_loss, average_s_loss)
+        self.writer.add_scalar('RL/average_v_loss', average_v_loss, episode)
+        self.writer.add_scalar('RL/average_s_loss', average_s_loss, episode)
+        return average_v_loss, average_s_loss
+
+
+def pad_batch(batch):
+    """trainer.py:253-272: sort the sequences by decreasing length, pad, keep the lengths -> (states, lengths) pairs."""
+    def sort_states(position):
+        sequences = sorted([x[position] for x in batch], reverse=True, key=lambda t: t.size()[0])
+        packed_sequences = torch.nn.utils.rnn.pack_sequence(sequences)
+        return torch.nn.utils.rnn.pad_packed_sequence(packed_sequences, batch_first=True)
+    states = sort_states(0)
+    values = torch.cat([x[1] for x in batch]).unsqueeze(1)
+    rewards = torch.cat([x[2] for x in batch]).unsqueeze(1)
+    next_states = sort_states(3)
+    return states, values, rewards, next_states
+
+
+class VNRLTrainer(_TrainerBase):
+    def __init__(self, model, memory, device, policy, batch_size, optimizer_str, writer):
+        """Train the value network of a path-G policy (crowd_nav/utils/trainer.py:164-186, same arguments)."""
+        self.model = model
+        self.device = device
+        self.policy = policy
+        self.target_model = None
+        self.criterion = nn.MSELoss().to(device)
+        self.memory = memory
+        self.data_loader = None
+        self.batch_size = batch_size
+        self.optimizer_str = optimizer_str
+        self.optimizer = None
+        self.writer = writer
+        # for value update
+        self.gamma = 0.9
+        self.time_step = 0.25
+        self.v_pref = 1
+        self._capturable = False
+        self._init_graphs()
+
+    update_target_model = MPRLTrainer.update_target_model
+    _same_structure = staticmethod(MPRLTrainer._same_structure)
+    _refresh_packed = staticmethod(MPRLTrainer._refresh_packed)
+
+    def set_learning_rate(self, learning_rate):
+        capturable = self.capture and str(self.device).startswith("cuda")
+        if self.optimizer_str == 'Adam':
+            self.optimizer = optim.Adam(self.model.parameters(), lr=learning_rate, capturable=capturable)
+        elif self.optimizer_str == 'SGD':
+            self.optimizer = optim.SGD(self.model.parameters(), lr=learning_rate, momentum=0.9)
+        else:
+            raise NotImplementedError
+        self._capturable = self._can_capture(self.optimizer)
+        self._drop_graphs()
+        logging.info('Lr: {} for parameters {} with {} optimizer'.format(learning_rate, ' '.join(
+            [name for name, param in self.model.named_parameters()]), self.optimizer_str))
+
+    def _batches(self):
+        """Batches of ((states, lengths), values, rewards, (next_states, lengths)) -- pad_batch's output."""
+        if self.data_loader is None:
+            self.data_loader = DataLoader(self.memory, self.batch_size, shuffle=True, collate_fn=pad_batch)
+        for data in self.data_loader:
+            yield data
+
+    def _signature(self):
+        return (id(self.optimizer), id(self.target_model), id(self.model))
+
+    def _step(self, inputs, lengths, target_values_fn):
+        self.optimizer.zero_grad()
+        outputs = self.model((inputs, lengths))
+        loss = self.criterion(outputs, target_values_fn())
+        loss.backward()
+        self.optimizer.step()
+        self._loss[0] += loss.detach().double()
+
+    def _full_lengths(self, lengths, width):
+        """The graph network takes whole batches of equally long sequences (gcn.ValueNetwork.forward's `lengths` only names the
+        crowd size); mixed lengths have no static shape to capture and run eagerly."""
+        return bool((torch.as_tensor(lengths) == width).all())
+
+    def optimize_epoch(self, num_epochs):
+        if self.optimizer is None:
+            raise ValueError('Learning rate is not set!')
+        average_epoch_loss = 0
+        for epoch in range(num_epochs):
+            self._loss_begin()
+            logging.debug('{}-th epoch starts'.format(epoch))
+            for data in self._batches():
+                (inputs, lengths), values, _, _ = data
+                inputs, values = inputs.to(self.device), values.to(self.device)
+                lengths = torch.as_tensor(lengths)
+
+                def fn(x, v, lengths=lengths):
+                    self._step(x, lengths, lambda: v)
+                if self._full_lengths(lengths, inputs.shape[1]):
+                    self._run(("il",), fn, [inputs, values], [self.model], self._signature())
+                else:
+                    fn(inputs, values)
+            epoch_loss = self._loss_read()[0]
+            logging.debug('{}-th epoch ends'.format(epoch))
+            average_epoch_loss = epoch_loss / len(self.memory)
+            self.writer.add_scalar('IL/average_epoch_loss', average_epoch_loss, epoch)
+            logging.info('Average loss in epoch %d: %.2E', epoch, average_epoch_loss)
+        self._finish()
+        return average_epoch_loss
+
+    def optimize_batch(self, num_batches, episode=None):
+        if self.optimizer is None:
+            raise ValueError('Learning rate is not set!')
+        gamma_bar = pow(self.gamma, self.time_step * self.v_pref)
+        self._loss_begin()
+        batch_count = 0
+        for data in self._batches():
+            (inputs, lengths), _, rewards, (next_states, next_lengths) = data
+            inputs, rewards, next_states = inputs.to(self.device), rewards.to(self.device), next_states.to(self.device)
+            lengths, next_lengths = torch.as_tensor(lengths), torch.as_tensor(next_lengths)
+
+            def fn(x, r, x2, lengths=lengths, next_lengths=next_lengths):
+                def target():
+                    with torch.no_grad():
+                        return r + gamma_bar * self.target_model((x2, next_lengths))
+                self._step(x, lengths, target)
+            if self._full_lengths(lengths, inputs.shape[1]) and self._full_lengths(next_lengths, next_states.shape[1]):
+                self._run(("rl",), fn, [inputs, rewards, next_states], [self.model], self._signature())
+            else:
+                fn(inputs, rewards, next_states)
+            batch_count += 1
+            if batch_count > num_batches:
+                break
+        losses = self._loss_read()[0]
+        self._finish()
+        average_loss = losses / num_batches
+        logging.info('Average loss : %.2E', average_loss)
+        return average_loss
+
+
+def register_trainers(namespace):
+    """Install the graph-replaying trainers under the names crowd_nav/train.py imports (`from crowd_nav.utils.trainer import
+    VNRLTrainer, MPRLTrainer`): pass the module (before train.py is imported) or a dict."""
+    target = namespace if isinstance(namespace, dict) else namespace.__dict__
+    target['MPRLTrainer'] = MPRLTrainer
+    target['VNRLTrainer'] = VNRLTrainer
+    target['pad_batch'] = pad_batch
+    return namespace

@@ -25,18 +25,24 @@ CASE_SIZE = {"train": np.iinfo(np.uint32).max - 2000, "val": 100, "test": 500}  
 
 
 class ReplayMemory(Dataset):
-    """Fixed-capacity ring of experience tuples; the oldest entry is overwritten once full."""
+    """Fixed-capacity ring of experience tuples; the oldest entry is overwritten once full (crowd_nav/utils/memory.py).
+    Additive: `as_tensors()` -- the experience as one stacked tensor per tuple field, kept up to date incrementally -- which lets
+    the trainers gather a batch with one index_select per field instead of collating 100 python tuples (trainer.py)."""
 
     def __init__(self, capacity):
         self.capacity = int(capacity)
         self.memory = []
         self.position = 0
+        self._mirror = None           # per field: (capacity, *item shape) tensor on the items' device
+        self._dirty = []              # positions written since the mirror was last brought up to date
 
     def push(self, item):
         if self.position < len(self.memory):
             self.memory[self.position] = item
+            self._dirty.append(self.position)
         else:
-            self.memory.append(item)
+            self.memory.append(item)                 # (after clear() the write position is ahead of the list: upstream's ring)
+            self._dirty.append(len(self.memory) - 1)
         self.position = (self.position + 1) % self.capacity
 
     def is_full(self):
@@ -44,12 +50,39 @@ class ReplayMemory(Dataset):
 
     def clear(self):
         self.memory = []          # the write position is kept, as upstream does
+        self._mirror, self._dirty = None, []
 
     def __getitem__(self, index):
         return self.memory[index]
 
     def __len__(self):
         return len(self.memory)
+
+    def as_tensors(self):
+        """[field 0 of every item stacked (n, ...), field 1 ..., ...] in item order -- what DataLoader's default collate would make
+        of the whole memory -- or None when the items are not tuples of equally shaped tensors (path G's variable crowds).  Only the
+        entries pushed since the last call are copied."""
+        n = len(self.memory)
+        if n == 0:
+            return None
+        first = self.memory[0]
+        if not (isinstance(first, tuple) and all(torch.is_tensor(x) for x in first)):
+            return None
+        if self._mirror is None or len(self._mirror) != len(first) or any(
+                m.shape[1:] != x.shape or m.device != x.device or m.dtype != x.dtype for m, x in zip(self._mirror, first)):
+            self._mirror = [torch.empty((self.capacity,) + tuple(x.shape), dtype=x.dtype, device=x.device) for x in first]
+            self._dirty = list(range(n))
+        dirty = sorted(set(i for i in self._dirty if i < n))
+        if dirty:
+            idx = torch.tensor(dirty, dtype=torch.int64, device=self._mirror[0].device)
+            for f, m in enumerate(self._mirror):
+                rows = [self.memory[i][f] for i in dirty]
+                if any(r.shape != m.shape[1:] for r in rows):
+                    self._mirror, self._dirty = None, []
+                    return None
+                m.index_copy_(0, idx, torch.stack(rows))
+        self._dirty = []
+        return [m[:n] for m in self._mirror]
 
 
 def discounted_statistics(rewards, lengths, step_discount):

@@ -2165,6 +2165,143 @@ def test_training_against_the_reference_vnrl_trainer_fixture(case, dev):
            % (tag, worst, losses / 2))
 
 
+class _Writer(object):
+    def __init__(self):
+        self.scalars = []
+
+    def add_scalar(self, tag, value, step):
+        self.scalars.append((tag, float(value), step))
+
+
+class _ListDataset(torch.utils.data.Dataset):
+    """A dataset WITHOUT as_tensors(): the trainers then draw their batches through torch's DataLoader, as upstream does."""
+
+    def __init__(self, items):
+        self.items = items
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+    def __len__(self):
+        return len(self.items)
+
+
+@pytest.mark.parametrize("tag", ["plain", "detach"])
+def test_product_trainer_reproduces_the_reference_trainer_fixture(tag, dev):
+    """the fast optimisation step through the PUBLIC trainer (relationalgraphlearning_amd.MPRLTrainer: the
+    reference's constructor / set_learning_rate / update_target_model / optimize_batch contract, every step after the first a
+    replay of one captured hipGraph).  Same fixture as test_training_against_the_reference_trainer_fixture: the REFERENCE
+    MPRLTrainer.optimize_batch over three un-shuffled batches of 16 transitions -- same final parameters, same reported losses."""
+    fx = gio.load("training_queryenv")
+    c = dict(L=2, sim="embedded_gaussian", layerwise=False, skip=False, flavour="trained")
+    _, ve, sp = build_modules(c, dev)
+    items = [(torch.tensor(fx["tr.robot"][i]).unsqueeze(0).to(dev), torch.tensor(fx["tr.humans"][i]).to(dev),
+              torch.zeros(1, device=dev), torch.tensor(fx["tr.rewards"][i]).reshape(1).to(dev),
+              torch.tensor(fx["tr.next_robot"][i]).unsqueeze(0).to(dev), torch.tensor(fx["tr.next_humans"][i]).to(dev)) for i in range(48)]
+    writer = _Writer()
+    t = rga.MPRLTrainer(ve, sp, _ListDataset(items), dev, None, writer, 16, "Adam", 5, reduce_sp_update_frequency=False,
+                        freeze_state_predictor=False, detach_state_predictor=(tag == "detach"), share_graph_model=False)
+    t.set_learning_rate(1e-3)
+    t.update_target_model(ve)
+    t.data_loader = torch.utils.data.DataLoader(t.memory, 16, shuffle=False)          # the fixture's order
+    av, as_ = t.optimize_batch(2, 7)                                                # upstream's off-by-one: three batches
+    assert t._capturable and len(t._steps) == 1                                    # one capture, two replays
+    want_v, want_s = fx["tr.%s.losses" % tag]
+    assert abs(av - want_v) <= 1e-5 * max(1.0, abs(want_v)) and abs(as_ - want_s) <= 1e-5 * max(1.0, abs(want_s)), (av, as_)
+    assert [s[0] for s in writer.scalars] == ["RL/average_v_loss", "RL/average_s_loss"] and writer.scalars[0][2] == 7
+    worst = 0.0
+    for name, mod in (("graph_model1", ve.graph_model), ("value_network", ve.value_network), ("graph_model2", sp.graph_model),
+                      ("motion_predictor", sp.human_motion_predictor)):
+        for k, v in mod.state_dict().items():
+            err = float(np.abs(v.cpu().numpy() - fx["tr.%s.%s.%s" % (tag, name, k)]).max())
+            worst = max(worst, err)
+            assert err <= 2e-5, (name, k, err)
+    # after the call the modules' packed weights follow the trained parameters (replays do not bump version counters)
+    r, h = items[0][0].unsqueeze(0), items[0][1].unsqueeze(0)
+    with torch.no_grad():
+        v_now = ve((r, h))
+        rga.invalidate_packed_weights(ve)
+        assert torch.equal(v_now, ve((r, h)))
+    report("product MPRLTrainer.optimize_batch (%s; one captured step + two replays): final parameters within %.1e of the "
+           "reference trainer's, losses %.6f / %.6f" % (tag, worst, av, as_))
+
+
+def test_product_trainer_fast_batches_equal_the_dataloaders(dev):
+    """The trainer's index sampling over ReplayMemory.as_tensors() against the DataLoader path on a plain dataset: same torch seed
+    -> the same shuffled batches -> bit-identical parameters after an IL epoch and two RL calls (both replay captured steps); and
+    the eager form (capture switched off) agrees to rounding."""
+    import copy
+    c = dict(L=2, sim="embedded_gaussian", layerwise=False, skip=True, flavour="trained")
+    robot, humans = seeded_scenes(61, 230, 5)
+    robot2, humans2 = seeded_scenes(62, 230, 5)
+    rew = torch.rand(230, generator=torch.Generator().manual_seed(9))
+    items = [(robot[i:i + 1].to(dev), humans[i].to(dev), rew[i:i + 1].to(dev) * 0.5, rew[i:i + 1].to(dev),
+              robot2[i:i + 1].to(dev), humans2[i].to(dev)) for i in range(230)]
+
+    def run(kind):
+        _, ve, sp = build_modules(c, dev)
+        if kind == "fast":
+            mem = rga.ReplayMemory(1000)
+            for it in items:
+                mem.push(it)
+        else:
+            mem = _ListDataset(items)
+        cls = rga.MPRLTrainer
+        if kind == "eager":
+            cls = type("EagerTrainer", (rga.MPRLTrainer,), {"capture": False})
+        t = cls(ve, sp, mem, dev, None, _Writer(), 100, "Adam", 5, reduce_sp_update_frequency=True,
+                freeze_state_predictor=False, detach_state_predictor=True, share_graph_model=False)
+        torch.manual_seed(77)
+        t.set_learning_rate(1e-3)
+        t.optimize_epoch(1)                                  # 100 + 100 + 30: two shapes, predictor every 5th batch
+        t.update_target_model(ve)
+        t.set_learning_rate(5e-4)
+        losses = [t.optimize_batch(1, e) for e in range(2)]  # two batches per call, predictor skipped on batch 0
+        t.update_target_model(ve)                            # in place: the captured steps stay
+        losses.append(t.optimize_batch(1, 2))
+        return ve, sp, losses, t
+    ve_f, sp_f, l_f, t_f = run("fast")
+    ve_d, sp_d, l_d, t_d = run("loader")
+    ve_e, sp_e, l_e, _ = run("eager")
+    assert t_f._capturable and t_d._capturable and len(t_f._steps) >= 2
+    assert l_f == l_d
+    worst = 0.0
+    for a, b, e in ((ve_f, ve_d, ve_e), (sp_f, sp_d, sp_e)):
+        for (k, pa), (_, pb), (_, pe) in zip(a.state_dict().items(), b.state_dict().items(), e.state_dict().items()):
+            assert torch.equal(pa, pb), k
+            worst = max(worst, float((pa - pe).abs().max()))
+    assert worst <= 2e-6, worst
+    for (a, b), (c_, d) in zip(l_f, l_e):
+        assert abs(a - c_) <= 1e-6 * max(1.0, abs(c_)) and abs(b - d) <= 1e-6 * max(1.0, abs(d))
+    report("product MPRLTrainer: index-sampled batches == DataLoader batches (bit-identical parameters); captured vs eager steps: "
+           "parameters within %.1e" % worst)
+
+
+@pytest.mark.parametrize("case", ["shipped|2|0|1", "layerwise_noskip|2|1|0"])
+def test_product_vnrl_trainer_reproduces_the_reference_fixture(case, dev):
+    """relationalgraphlearning_amd.VNRLTrainer (path G's trainer, crowd_nav/utils/trainer.py:164-250) over the fixture of
+    test_training_against_the_reference_vnrl_trainer_fixture, with upstream's pad_batch collate: same parameters, same loss."""
+    fx = gio.load("vnrl_trainer")
+    tag, L, lw, sk = case.split("|")
+    pol = make_gcn_policy(int(L), bool(int(lw)), bool(int(sk)), device=dev)
+    items = [(torch.tensor(fx["vn.states"][i]).to(dev), torch.zeros(1, device=dev), torch.tensor(fx["vn.rewards"][i]).reshape(1).to(dev),
+              torch.tensor(fx["vn.next_states"][i]).to(dev)) for i in range(48)]
+    from relationalgraphlearning_amd.trainer import pad_batch
+    t = rga.VNRLTrainer(pol.model, _ListDataset(items), dev, pol, 16, "Adam", _Writer())
+    t.set_learning_rate(1e-3)
+    t.update_target_model(pol.model)
+    t.data_loader = torch.utils.data.DataLoader(t.memory, 16, shuffle=False, collate_fn=pad_batch)
+    loss = t.optimize_batch(2)
+    want = float(fx["vn.%s.loss" % tag][0])
+    assert abs(loss - want) <= 1e-5 * max(1.0, abs(want)), (loss, want)
+    worst = 0.0
+    for k, v in pol.model.state_dict().items():
+        err = float(np.abs(v.cpu().numpy() - fx["vn.%s.model.%s" % (tag, k)]).max())
+        worst = max(worst, err)
+        assert err <= 2e-5, (k, err)
+    report("product VNRLTrainer.optimize_batch (%s): final parameters within %.1e of the reference's, loss %.6f" % (tag, worst, loss))
+
+
 def test_training_step_replayed_from_a_captured_graph(dev):
     """A whole MPRLTrainer-style optimisation step (value forward, frozen-target forward, backward, Adam; state-predictor forward,
     backward, Adam: crowd_nav/utils/trainer.py:110-161) captured once into a hipGraph and replayed: the library allocates nothing
