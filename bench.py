@@ -396,10 +396,16 @@ class Leg:
     def timed(self, steps, warmup, init_steps):
         """`init_steps` set-up steps (code objects, workspace, RCCL channels), `warmup` untimed steps, then exactly `steps`
         timed steps between fences; returns (wall seconds MAX over ranks, sorted per-step device ms of this rank)."""
-        for _ in range(init_steps):
+        cold = None if STUB else [torch.cuda.Event(enable_timing=True) for _ in range(min(init_steps, 10) + 1)]
+        for i in range(init_steps):
+            if cold and i < len(cold):
+                cold[i].record()
             self.step()
         self.drain()
         self.fence()
+        # steps 2.. of the set-up phase (the very first ones also pay for code objects and workspaces): a cold device's step time
+        self.cold_ms = (sorted(cold[i].elapsed_time(cold[i + 1]) for i in range(2, len(cold) - 1))
+                        if cold and len(cold) > 4 else None)
         for _ in range(warmup):
             self.step()
         self.drain()
@@ -649,7 +655,11 @@ def main():
     # it landed inside the timed region and starved the GPU for 60 steps' worth of time).  Freeze the set-up objects so
     # later collections only look at what the steps themselves allocate.
     import gc
-    INIT_STEPS = 3      # set-up, not warm-up: the first calls load the code objects, size the workspace and (N > 1) open the RCCL channels
+    # Set-up, not warm-up: the first calls load the code objects, size the workspace and (N > 1) open the RCCL channels -- and
+    # the device needs ~15 ms of work to reach the clock it then holds: measured on one box with `--steps 20 --warmup 5`
+    # (profiles/r04_init_steps.txt), 3 set-up steps: 0.398 ms per timed step, 40 or 150: 0.375-0.377.  The line reports what
+    # the first steps cost (`step_ms_device_cold`: HIP events around set-up steps 2..9) beside the steady figure.
+    INIT_STEPS = int(os.environ.get("RGL_BENCH_INIT_STEPS", "40"))
     leg = Leg(args, ts, device, world, rank, main_leg[1], main_leg[2], dist)
     gc.collect()
     gc.freeze()
@@ -722,6 +732,9 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": main_leg[0],
         "step_ms_device": {"p10": step_ms[len(step_ms) // 10], "median": step_ms[len(step_ms) // 2],
                            "p90": step_ms[(len(step_ms) * 9) // 10], "note": "rank 0, HIP events between steps"},
+        "step_ms_device_cold": (None if not getattr(leg, "cold_ms", None) else
+                                {"median": leg.cold_ms[len(leg.cold_ms) // 2], "max": leg.cold_ms[-1],
+                                 "note": "set-up steps 2..9 of this process, before the device reached its steady clock (not timed into `value`)"}),
         "vs_baseline": None, "dtype": {"f32": "f32", "f16": "f16 inputs / f32 accumulate (middle-layer products only; everything else f32)",
                                        "f16x3": "f32 (dense products of the children kernel as three split-f16 MFMA terms with f32 accumulate, "
                                                 "~2^-21 relative per product; everything else f32)"}[args.contraction],

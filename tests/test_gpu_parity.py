@@ -1407,7 +1407,7 @@ def test_f16x3_value_head_at_size_and_at_extreme_magnitudes(dev):
     robot, humans = bench.synth_scenes(1000, B, H)
     act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
     assert pol.tree_search().last["planner"].contraction_dtype == nat.CONTRACTION_DTYPES["f16x3"]
-    oracle_out, v1 = _oracle_at_size(H, 2, 2, B, robot, humans)
+    oracle_out, v1, _ = _oracle_at_size(H, 2, 2, B, robot, humans)
     err = close(val.cpu().numpy(), oracle_out[1].numpy())
     check_decisions("at size, configs[2] in full, f16x3 value head", act, val, oracle_out, [{"value1": v1}], TOL)
     Args.contraction = "f32"
@@ -1564,20 +1564,76 @@ _ORACLE_AT_SIZE = {}
 
 
 def _oracle_at_size(H, L, D, B, robot, humans):
-    """The batched oracle over bench.py's scenes, walked in chunks (256 roots; 64 for the dense crowds) and memoised per workload."""
+    """The batched oracle over bench.py's scenes, walked in chunks (256 roots; 64 for the dense crowds) and memoised per workload.
+    Returns ((best action, best value, root values, root kept), level-0 one-step values, [per level {"value1", "keep"}])."""
     key = (H, L, D, B)
     if key not in _ORACLE_AT_SIZE:
         cfg = orc.OracleConfig(num_layer=L, planning_depth=D, planning_width=2, do_action_clip=(D > 1))
         step = 64 if H >= 40 else 256
-        outs, v1 = [], []
+        outs, lv = [], [[] for _ in range(D)]
         with torch.no_grad():
             for lo in range(0, B, step):
                 o = orc.mprl_predict_batched(robot[lo:lo + step], humans[lo:lo + step], gio.oracle_params("trained", L), cfg,
                                              return_levels=True)
                 outs.append(o[:4])
-                v1.append(o[4][0]["value1"])
-        _ORACLE_AT_SIZE[key] = ([torch.cat([o[i] for o in outs]) for i in range(4)], torch.cat(v1))
+                for l in range(D):                       # parents of a level are root-major: chunks concatenate
+                    lv[l].append((o[4][l]["value1"], o[4][l]["keep"]))
+        levels = [{"value1": torch.cat([x[0] for x in lv[l]]), "keep": torch.cat([x[1] for x in lv[l]])} for l in range(D)]
+        _ORACLE_AT_SIZE[key] = ([torch.cat([o[i] for o in outs]) for i in range(4)], levels[0]["value1"], levels)
     return _ORACLE_AT_SIZE[key]
+
+
+def compare_trees(tag, ts, val, oracle_out, oracle_levels, tol, reg):
+    """Level by level against the oracle's tree.  A search is a chain of top-w selections, and a selection between two actions whose
+    one-step values differ in the 8th digit may legitimately fall the other way on the GPU (another summation order): from there on
+    the two trees hold different nodes, and the root's value may move by the difference between two ALMOST equally good branches --
+    1e-4 was seen at 4096 roots, where 28 672 selections are made.  So: the trees are aligned node by node (kept sets are matched as
+    sets: the GPU orders them by value, np.argpartition does not); at every aligned node the one-step values of all actions must
+    agree to `reg` (regression level) and a kept set may differ only where the oracle itself has a tie -- the action the GPU kept is
+    within `tie` of the weakest one the oracle kept; the sub-trees below such a node are not comparable and their roots are held to
+    the north-star bound `tol` only.  Every other root's value must agree to `reg`.  Returns (worst aligned |dV|, roots with a
+    tie-diverged tree, worst |dV| among those)."""
+    tie = 10 * reg
+    D = len(oracle_levels)
+    B = oracle_out[1].shape[0]
+    w = oracle_levels[0]["keep"].shape[1]
+    gp = np.arange(B)                                   # oracle parent -> the GPU parent holding the same node, -1: diverged above
+    diverged_root = np.zeros(B, bool)
+    worst_v1 = 0.0
+    for l in range(D):
+        arr = ts.level_arrays(l)
+        g_v1, g_keep = arr["value1"].cpu().numpy(), arr["keep"].cpu().numpy().astype(np.int64)
+        o_v1, o_keep = oracle_levels[l]["value1"].numpy(), oracle_levels[l]["keep"].numpy().astype(np.int64)
+        P = o_v1.shape[0]
+        per_root = P // B
+        ok = gp >= 0
+        d1 = np.abs(g_v1[gp[ok]] - o_v1[ok])
+        worst_v1 = max(worst_v1, float(d1.max()) if d1.size else 0.0)
+        assert worst_v1 <= reg, (tag, "one-step values of aligned nodes, level %d" % l, worst_v1)
+        nxt = np.full(P * w, -1, np.int64)
+        for p in np.nonzero(ok)[0]:
+            gk = g_keep[gp[p]]
+            same = sorted(gk.tolist()) == sorted(o_keep[p].tolist())
+            if not same:
+                weakest = o_v1[p, o_keep[p]].min()
+                for a in gk:
+                    assert o_v1[p, a] >= weakest - tie, (tag, "level %d parent %d: kept set differs and it is no tie in the oracle" % (l, p),
+                                                         float(o_v1[p, a]), float(weakest))
+                diverged_root[p // per_root] = True
+                continue
+            for k in range(w):
+                nxt[p * w + k] = gp[p] * w + int(np.nonzero(gk == o_keep[p, k])[0][0])
+        gp = nxt
+    dv = np.abs(val.cpu().numpy().astype(np.float64) - oracle_out[1].numpy().astype(np.float64))
+    aligned = ~diverged_root
+    worst_aligned = float(dv[aligned].max()) if aligned.any() else 0.0
+    worst_div = float(dv[diverged_root].max()) if diverged_root.any() else 0.0
+    assert worst_aligned <= reg, (tag, "values of roots with aligned trees", worst_aligned)
+    assert worst_div <= tol, (tag, "values of roots whose tree diverged at a tie", worst_div)
+    report("%s: trees aligned node by node -- one-step values within %.1e at every level, %d of %d roots with a selection tied in "
+           "the oracle (|dV| <= %.1e there), every other root within %.1e"
+           % (tag, worst_v1, int(diverged_root.sum()), B, worst_div, worst_aligned))
+    return worst_aligned, int(diverged_root.sum()), worst_div
 
 
 AT_SIZE_CASES = [
@@ -1612,8 +1668,10 @@ def test_baseline_workloads_against_the_oracle_at_size(tag, H, L, D, B, contract
     pol = _bench_policy(L, D, H, contraction, dev)
     robot, humans = bench.synth_scenes(1000, B, H)
     act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
-    oracle_out, v1 = _oracle_at_size(H, L, D, B, robot, humans)
-    err = close(val.cpu().numpy(), oracle_out[1].numpy(), tol=tol, reg=REG_F32 if contraction == "f32" else REG_F16)
+    oracle_out, v1, levels = _oracle_at_size(H, L, D, B, robot, humans)
+    reg = REG_F32 if contraction == "f32" else REG_F16
+    worst, n_div, _ = compare_trees("at size, %s" % tag, pol.tree_search(), val, oracle_out, levels, tol, reg)
+    err = close(val.cpu().numpy(), oracle_out[1].numpy(), tol=tol, reg=None if n_div else reg)
     check_decisions("at size, %s" % tag, act, val, oracle_out, [{"value1": v1}], tol)
     report("at size, %s: max |dV| = %.2e absolute (max |V| = %.3f)" % (tag, err, float(oracle_out[1].abs().max())))
 
@@ -1667,7 +1725,7 @@ def test_forced_kernel_families_at_size(family, dev, tmp_path):
     env_add, B = FORCED_FAMILIES[family]
     H, L, D = 19, 2, 2
     robot, humans = bench.synth_scenes(1000, 2048, H)
-    oracle_out, v1 = _oracle_at_size(H, L, D, 2048, robot, humans)
+    oracle_out, v1, _ = _oracle_at_size(H, L, D, 2048, robot, humans)
     ref = str(tmp_path / "oracle_c2.npz")
     np.savez(ref, oa=oracle_out[0].numpy()[:B], ov=oracle_out[1].numpy()[:B], orv=oracle_out[2].numpy()[:B],
              okept=oracle_out[3].numpy()[:B], v1=v1.numpy()[:B])
@@ -1792,7 +1850,7 @@ def _grad_close(got, want, name, tol=2e-4, reg=REG_GRAD):
     got, want = got.detach().cpu().numpy().astype(np.float64), want.detach().numpy().astype(np.float64)
     scale = max(1e-3, float(np.abs(want).max()))
     err = float(np.abs(got - want).max())
-    if err / scale > GRAD_WORST["rel"]:
+    if reg is not None and err / scale > GRAD_WORST["rel"]:          # the comparisons against autograd over the oracle
         GRAD_WORST["rel"], GRAD_WORST["name"] = err / scale, name
     assert err <= tol * scale, (name, err, scale)
     if reg is not None:
@@ -2270,7 +2328,7 @@ def test_product_trainer_fast_batches_equal_the_dataloaders(dev):
         for (k, pa), (_, pb), (_, pe) in zip(a.state_dict().items(), b.state_dict().items(), e.state_dict().items()):
             assert torch.equal(pa, pb), k
             worst = max(worst, float((pa - pe).abs().max()))
-    assert worst <= 2e-6, worst
+    assert worst <= 1e-5, worst          # capturable Adam + the tile-pipeline backward vs plain Adam + the per-scene kernel, ~8 steps
     for (a, b), (c_, d) in zip(l_f, l_e):
         assert abs(a - c_) <= 1e-6 * max(1.0, abs(c_)) and abs(b - d) <= 1e-6 * max(1.0, abs(d))
     report("product MPRLTrainer: index-sampled batches == DataLoader batches (bit-identical parameters); captured vs eager steps: "
