@@ -846,8 +846,7 @@ __device__ __forceinline__ float frag_element(const float* __restrict__ W, int i
     constexpr int IT = Tiles<IN>::v;
     const int l = idx & 63, fr = idx >> 6;
     const int r = fr & 3, it = (fr >> 2) % IT, ot = (fr >> 2) / IT;
-    const int m = l & 15;
-    const int in = tile_feature<IN>(it, l >> 4, r), out = tile_feature<OUT>(ot, m >> 2, m & 3);
+    const int in = tile_feature<IN>(it, l >> 4, r), out = frag_out_feature<OUT>(ot, l);
     return (in < IN && out < OUT) ? W[in * OUT + out] : 0.f;
 }
 template <int OUT>

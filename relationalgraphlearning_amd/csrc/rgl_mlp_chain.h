@@ -21,6 +21,34 @@ __device__ __forceinline__ int tile_feature(int t, int q, int r) {
 template <int D>
 struct LastTileSteps { static constexpr int v = (D % 16) == 0 ? 4 : ((D % 16) + 3) / 4; };
 
+// A partial LAST OUTPUT tile of at most four features (the 100-wide layers of the value heads: 6 tiles + 4 features) is not worth a
+// 16 x 16 x 4 MFMA per k step -- 12 of its 16 rows are padding.  Those features are produced by v_mfma_f32_4x4x1_16B_f32 instead
+// (round 4; tools/micro/mfma_4x4.hip: 12 clocks against 32, layout checked on the hardware): 16 independent 4 x 4 x 1 blocks, block
+// = lane / 4.  With the activations in the D layout (lane (n, q): child n, k slot q) the B operand is the very register the
+// 16 x 16 product reads: block (q, n / 4) multiplies the four features (A row = lane % 4) with the children 4 (n / 4) .. + 3 for
+// ITS k slot; the four k-group partial sums of feature i sit in register i of the lanes (n, q = 0..3) and meet in a
+// reduce-scatter of three permlane swaps that leaves feature 16 t + q in register 0 of lane (n, q) -- exactly where
+// tile_feature() puts a partial tile's features.
+template <int OUT>
+struct Partial4 { static constexpr bool v = (OUT % 16) != 0 && (OUT % 16) <= 4; };
+// output feature multiplied by A-operand lane l of the fragments of output tile ot
+template <int OUT>
+__device__ __forceinline__ int frag_out_feature(int ot, int l) {
+    if (Partial4<OUT>::v && ot == Tiles<OUT>::v - 1) return 16 * ot + (l & 3);
+    const int m = l & 15;                                            // A-operand row = D row of the output tile
+    return tile_feature<OUT>(ot, m >> 2, m & 3);
+}
+__device__ __forceinline__ f32x4 mfma4x4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+// lane (n, q) <- sum over the four k-groups of register q (see above)
+__device__ __forceinline__ float kgroups_reduce_scatter(const f32x4& p) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p[0]), __float_as_uint(p[1]), false, false);
+    const float s01 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p[2]), __float_as_uint(p[3]), false, false);
+    const float s23 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // NTHR > 0: the workgroup size as a compile-time constant -- the loops are fully unrolled and every global load of a thread is
 // in flight at once (one L2 round trip for the whole image instead of one per batch of 8: the 74 KB image of the value head
 // took ~10 us per workgroup to build, which is most of a small launch).
@@ -31,8 +59,7 @@ __device__ __forceinline__ void fill_frags(float* dst, const float* __restrict__
     auto element = [&](int idx, float& w, bool& ok) {
         const int l = idx & 63, fr = idx >> 6;
         const int r = fr & 3, it = (fr >> 2) % IT, ot = (fr >> 2) / IT;
-        const int m = l & 15;                                        // A-operand row = D row of the output tile
-        const int in = tile_feature<IN>(it, l >> 4, r), out = tile_feature<OUT>(ot, m >> 2, m & 3);
+        const int in = tile_feature<IN>(it, l >> 4, r), out = frag_out_feature<OUT>(ot, l);
         w = W[(in < IN ? in : IN - 1) * OUT + (out < OUT ? out : OUT - 1)];   // unconditional load (batched), then mask
         ok = in < IN && out < OUT;
     };
@@ -151,15 +178,18 @@ __device__ __forceinline__ void copy_image(float* dst, const float* __restrict__
     }
 }
 
-// out = W^T in (+ bias): the accumulators START at the bias (no zero-init moves, no add afterwards).
+// out = W^T in (+ bias): the accumulators START at the bias (no zero-init moves, no add afterwards).  A partial last output tile
+// of <= 4 features runs on the 4 x 4 x 1 16-block MFMA (Partial4 above; its fragments take the place of that tile's).
 template <int IN, int OUT, bool BIAS>
 __device__ __forceinline__ void layer_mfma(const float* frags, const f32x4 (&in)[Tiles<IN>::v], f32x4 (&out)[Tiles<OUT>::v],
                                            int lane, const float* bias = nullptr) {
     constexpr int IT = Tiles<IN>::v, OT = Tiles<OUT>::v;
+    constexpr bool P4 = Partial4<OUT>::v;
+    constexpr int OTF = P4 ? OT - 1 : OT;                 // output tiles on the 16 x 16 x 4 MFMA
     const int q = lane >> 4;
     // BIAS is a template flag, not a pointer test: with a run-time test hipcc zero-initialises every accumulator first
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) {
+    for (int ot = 0; ot < OTF; ++ot) {
         if constexpr (BIAS) out[ot] = *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * q]);
         else out[ot] = zero4();
     }
@@ -170,10 +200,28 @@ __device__ __forceinline__ void layer_mfma(const float* frags, const f32x4 (&in)
         for (int r = 0; r < 4; ++r) {
             if (it == IT - 1 && r >= LastTileSteps<IN>::v) continue;          // k steps over padding only
 #pragma unroll
-            for (int ot = 0; ot < OT; ++ot) out[ot] = mfma4(frags[((ot * IT + it) * 4 + r) * 64 + lane], in[it][r], out[ot]);
+            for (int ot = 0; ot < OTF; ++ot) out[ot] = mfma4(frags[((ot * IT + it) * 4 + r) * 64 + lane], in[it][r], out[ot]);
         }
     }
     load_fence();
+    if constexpr (P4) {
+        // the <= 4 features of the partial tile: a pass of its own (in the k loop above its operand loads raised the kernel's
+        // register pressure past 256), two accumulators so that consecutive 4 x 4 x 1 MFMAs do not wait for each other
+        f32x4 p4[2] = {zero4(), zero4()};
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            load_fence();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (it == IT - 1 && r >= LastTileSteps<IN>::v) continue;
+                p4[r & 1] = mfma4x4(frags[((OTF * IT + it) * 4 + r) * 64 + lane], in[it][r], p4[r & 1]);
+            }
+        }
+        load_fence();
+        float v = kgroups_reduce_scatter(p4[0] + p4[1]);
+        if constexpr (BIAS) v += bias[16 * OTF + 4 * q];
+        out[OTF] = f32x4{v, 0.f, 0.f, 0.f};
+    }
 }
 
 // The same product on the f16 matrix pipe at (nearly) f32 accuracy: a = a_hi + a_lo, W = W_hi + W_lo with f16 halves, and
