@@ -51,6 +51,15 @@ __host__ __device__ constexpr int fused_scratch_floats(int HR, int NT, bool SOFT
     return ((fl > kTailLdsInts ? fl : kTailLdsInts) + 3) & ~3;      // ... and, after the last item, the tables of the select step
 }
 
+// lane n of every 16-lane row <- lane n & 3 of that row (three DPP row shifts, each writing one bank of four lanes)
+__device__ __forceinline__ float quad0_bcast(float x) {
+    int v = __float_as_int(x);
+    v = __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0x2, false);      // row_shr:4  -> lanes 4..7
+    v = __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0x4, false);      // row_shr:8  -> lanes 8..11
+    v = __builtin_amdgcn_update_dpp(v, v, 0x11C, 0xf, 0x8, false);      // row_shr:12 -> lanes 12..15
+    return __int_as_float(v);
+}
+
 struct FusedArgs {
     const float *wr1, *br1, *wr2, *br2, *wa, *w1;                       // child-side weights (k-major)
     const float *wh1, *bh1, *wh2, *bh2;                                 // w_h (crowd side)
@@ -127,6 +136,11 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
     const int lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
     constexpr bool PK = fused_packed_rows(HR, SOFT);    // row pass in the D layout with packed fp32 math
+    // 16 < N <= 20 (the shipped crowd): the second node tile holds four valid nodes.  Its rows of the robot row / column of S come
+    // from v_mfma_f32_4x4x1_16B_f32 (rgl_mlp_chain.h: 12 clocks instead of 32 per k step) and land, after a reduce-scatter over
+    // the k-groups, as node 16 + q in register 0 of lane (n, q): the tile's node order is 16 + 4 r + q, registers 1..3 are
+    // padding -- their exps, table entries and k steps of p Xh are not computed at all.
+    constexpr bool T1P = PK && NT == 2 && HR <= 20 && !HX;
     constexpr int HRL = HR < NP ? HR : NP;              // rows of UW the row pass visits (rows >= N are zero)
     constexpr int SLDK = HRL + 2;
     const int N = a.N, A = a.A, SLD = PK ? SLDK : a.SLD;
@@ -164,6 +178,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
     const int n_tiles_inl = a.n_full + (a.inline_partial ? 1 : 0);      // tiles that run their own head
     float rin[3], hin[NT][2];
     f32x4 gq[NT][2], xq[NT][2], ms[NT], zs[NT], xt[NT][2], uw4[HRL / 4];
+    float xt1p[2] = {0.f, 0.f}, ms1 = 0.f, zs1 = 1.f;      // T1P: Xh^T[f][node 16 + q], msh / Zsh of node 16 + q
     // HX: the crowd operands as split-f16 halves.  gqs / xqs [node tile]: rows = nodes, k = features (the D layout of the crowd chain,
     // packed pairwise); xts [feature tile]: rows = features, k = nodes.  One power-of-two scale per family (they serve as A operands).
     SplitOperand<2> gqs[NT], xqs[NT];
@@ -292,7 +307,12 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xt[nt][ot][r] = Xs[(16 * nt + 4 * q + r) * XLD + 16 * ot + n];      // Xh^T for p Xh and U
+                for (int r = 0; r < 4; ++r)      // Xh^T for p Xh and U; T1P: only k step 0 of tile 1 is read by the tiles (node 16 + q)
+                    xt[nt][ot][r] = Xs[(16 * nt + 4 * q + r) * XLD + 16 * ot + n];
+        if constexpr (T1P) {
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) xt1p[ot] = Xs[(16 + q) * XLD + 16 * ot + n];
+        }
         load_fence();
         __builtin_amdgcn_wave_barrier();
         if constexpr (HX) {
@@ -420,9 +440,21 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         __builtin_amdgcn_wave_barrier();
         load_fence();
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int nt = 0; nt < (T1P ? 1 : NT); ++nt) {
             ms[nt] = *reinterpret_cast<const f32x4*>(&msz[16 * nt + 4 * q]);
             zs[nt] = *reinterpret_cast<const f32x4*>(&msz[NP + 16 * nt + 4 * q]);
+        }
+        if constexpr (T1P) {
+            ms1 = msz[16 + q];
+            zs1 = msz[NP + 16 + q];
+            // rows 16..19 of G and Xh as A operands of the 4 x 4 x 1 blocks: A row = lane % 4 (rows 20..31 were zero padding)
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gq[1][ot][r] = quad0_bcast(gq[1][ot][r]);
+                    xq[1][ot][r] = quad0_bcast(xq[1][ot][r]);
+                }
         }
         if constexpr (!PK) {
 #pragma unroll
@@ -533,8 +565,23 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
             float mx0 = NEG_INF;
             SplitOperand<2> sgs;
             if constexpr (HX) make_split<2>(gacc, sgs);
+            float sc1 = NEG_INF, p1 = NEG_INF;           // T1P: S_c[16 + q][0], then S_c[0][16 + q] -> p of node 16 + q
+            if constexpr (T1P) {
+                f32x4 psc[2] = {zero4(), zero4()}, ps0[2] = {zero4(), zero4()};
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+                for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        psc[r & 1] = mfma4x4(gq[1][ot][r], xacc[ot][r], psc[r & 1]);
+                        ps0[r & 1] = mfma4x4(xq[1][ot][r], gacc[ot][r], ps0[r & 1]);
+                    }
+                sc1 = kgroups_reduce_scatter(psc[0] + psc[1]);
+                p1 = kgroups_reduce_scatter(ps0[0] + ps0[1]);
+                if (16 + q >= N) { sc1 = NEG_INF; p1 = NEG_INF; }
+                mx0 = p1;
+            }
+#pragma unroll
+            for (int nt = 0; nt < (T1P ? 1 : NT); ++nt) {
                 f32x4 sc = zero4(), s0 = zero4();
                 if constexpr (HX) {
                     sc = mfma_h3(gqs[nt].hi[0], gqs[nt].lo[0], sxs.hi[0], sxs.lo[0], sc);
@@ -564,16 +611,21 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
             }
             mx0 = kgroups_max(mx0);
             float z0 = 0.f;
+            if constexpr (T1P) {
+                p1 = __expf(p1 - mx0);
+                z0 = p1;
+            }
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < (T1P ? 1 : NT); ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (sim == SIM_SOFTMAX) s0t[nt][r] = __expf(s0t[nt][r] - mx0);
                     z0 += s0t[nt][r];
                 }
             const float iz0 = __builtin_amdgcn_rcpf(kgroups_sum(z0));
+            if constexpr (T1P) p1 *= iz0;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < (T1P ? 1 : NT); ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s0t[nt][r] *= iz0;                       // p = A_c[0][:] (0 beyond row N-1)
             p00 = kgroups_sum(q == 0 ? s0t[0][0] : 0.f);
@@ -591,19 +643,23 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                 }
             } else {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < (T1P ? 1 : NT); ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     t0h[0] = mfma4(xt[nt][0][r], s0t[nt][r], t0h[0]);
                     t0h[1] = mfma4(xt[nt][1][r], s0t[nt][r], t0h[1]);
                 }
+            if constexpr (T1P) {                                 // nodes 16..19: ONE k step (k slot q = node 16 + q)
+                t0h[0] = mfma4(xt1p[0], p1, t0h[0]);
+                t0h[1] = mfma4(xt1p[1], p1, t0h[1]);
+            }
             }
             if constexpr (PK) {
                 // human row i of child c: relu((alpha UW_i + beta y_c) / Z) weighted by p_i = b_i relu(r_i UW_i + y_c) with
                 // r_i = alpha / beta = exp(msh_i - S_i0), b_i = p_i beta / Z = p_i / (r_i Zsh_i + 1); r is capped at e^60 (beyond,
                 // beta y is below fp32 resolution of the row and b r = p / Zsh is exact)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < (T1P ? 1 : NT); ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int nd = 16 * nt + 4 * q + r;
@@ -612,6 +668,13 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                         const bool rh = nd >= 1 && nd < N;
                         if (nd < HRL) *reinterpret_cast<f32x2*>(&AB[(n * SLDK + nd) * 2]) = f32x2{rh ? rr : 0.f, rh ? bb : 0.f};
                     }
+                if constexpr (T1P) {                             // node 16 + q (HRL == 20: rows 16..19 of the table)
+                    const int nd = 16 + q;
+                    const float rr = __expf(fminf(ms1 - sc1, 60.f));
+                    const float bb = p1 * __builtin_amdgcn_rcpf(fmaf(rr, zs1, 1.f));
+                    const bool rh = nd < N;
+                    if (nd < HRL) *reinterpret_cast<f32x2*>(&AB[(n * SLDK + nd) * 2]) = f32x2{rh ? rr : 0.f, rh ? bb : 0.f};
+                }
             } else {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
