@@ -49,13 +49,55 @@ class _ShuffledIndexBatches(object):
             yield perm[lo:lo + self.batch_size]
 
 
+class _Batch(object):
+    """The fields of one batch, as tensors (DataLoader path) or as (stacked memory fields, device indices) to be gathered."""
+
+    def __init__(self, tensors=None, fields=None, idx=None):
+        self._tensors, self._fields, self._idx = tensors, fields, idx
+
+    def pick(self, which):
+        if self._tensors is not None:
+            return _Batch(tensors=[self._tensors[i] for i in which])
+        return _Batch(fields=[self._fields[i] for i in which], idx=self._idx)
+
+    def shapes(self):
+        if self._tensors is not None:
+            return tuple(tuple(t.shape) for t in self._tensors)
+        return tuple((int(self._idx.shape[0]),) + tuple(f.shape[1:]) for f in self._fields)
+
+    def tensors(self):
+        if self._tensors is not None:
+            return [t.contiguous() for t in self._tensors]
+        return [f.index_select(0, self._idx) for f in self._fields]
+
+    def identity(self):
+        """What a captured step bakes in besides the shapes: the addresses of the memory's stacked fields it gathers from."""
+        return () if self._tensors is not None else tuple(f.data_ptr() for f in self._fields)
+
+    def capture_inputs(self, fn):
+        """(static input buffers, the function to record).  Tensor batches: the step's own inputs.  Indexed batches: ONE static
+        buffer -- the batch's indices -- and the gathers become part of the recorded step, so a replayed batch costs the host one
+        small copy and one graph launch."""
+        if self._tensors is not None:
+            return self.tensors(), fn
+        fields = self._fields
+        return [self._idx.clone()], (lambda idx: fn(*[f.index_select(0, idx) for f in fields]))
+
+    def fill(self, static):
+        if self._tensors is not None:
+            for dst, src in zip(static, self._tensors):
+                dst.copy_(src, non_blocking=True)
+        else:
+            static[0].copy_(self._idx, non_blocking=True)
+
+
 class _CapturedStep(object):
     """`fn(*static inputs)` captured into a hipGraph after two warm-up runs on a side stream; `run(batch)` copies the batch into
     the static inputs and replays.  `signature` = what the capture baked in (shapes, optimizer / module identities)."""
 
-    def __init__(self, fn, example, signature, warmup_is_a_step):
+    def __init__(self, fn, batch, signature, warmup_is_a_step):
         self.signature = signature
-        self.static = [torch.empty_like(t).copy_(t) for t in example]
+        self.static, fn = batch.capture_inputs(fn)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -67,8 +109,7 @@ class _CapturedStep(object):
         self.consumed_first = warmup_is_a_step
 
     def run(self, batch):
-        for dst, src in zip(self.static, batch):
-            dst.copy_(src, non_blocking=True)
+        batch.fill(self.static)
         self.graph.replay()
 
 
@@ -96,10 +137,10 @@ class _TrainerBase(object):
         self._steps = {}
 
     def _run(self, kind, fn, batch, modules, signature):
-        """One optimisation step on `batch` (a list of device tensors): replay of the step captured for this kind / these shapes,
-        or -- SGD, capture switched off -- the eager step."""
-        batch = [b.contiguous() for b in batch]
-        key = (kind,) + tuple(tuple(b.shape) for b in batch)
+        """One optimisation step on `batch` (a _Batch): replay of the step captured for this kind / these shapes, or -- SGD,
+        capture switched off -- the eager step."""
+        key = (kind,) + batch.shapes()
+        signature = signature + batch.identity()
         st = self._steps.get(key) if self._capturable else None
         if st is not None and st.signature != signature:
             st = None
@@ -110,7 +151,7 @@ class _TrainerBase(object):
                 invalidate_packed_weights(*self._stale)
                 self._replayed = False
             if not self._capturable:
-                fn(*batch)
+                fn(*batch.tensors())
                 return
             self._steps[key] = _CapturedStep(fn, batch, signature, True)      # its warm-up run WAS this batch's step
             for m in modules:
@@ -119,6 +160,13 @@ class _TrainerBase(object):
             return
         st.run(batch)
         self._replayed = True
+
+    def _run_eager(self, fn, tensors):
+        """A step that is not captured (batches of mixed crowd sizes), after replays: the packed weights first."""
+        if self._replayed:
+            invalidate_packed_weights(*self._stale)
+            self._replayed = False
+        fn(*tensors)
 
     def _finish(self):
         """After the last replay of a call: replays do not bump autograd's version counters, so the descriptor caches of the
@@ -226,14 +274,21 @@ class MPRLTrainer(_TrainerBase):
         if self.data_loader is None and callable(fast):
             fields = fast()
             if fields is not None:
-                for idx in _ShuffledIndexBatches(len(self.memory), self.batch_size):
-                    idx = idx.to(fields[0].device)
-                    yield [f.index_select(0, idx) for f in fields]
+                # the whole epoch's permutation goes to the device in ONE copy (a pageable host-to-device copy per batch would
+                # stall the host behind the previous step every time); the batches are slices of it
+                order = list(_ShuffledIndexBatches(len(self.memory), self.batch_size))
+                if not order:
+                    return
+                perm = torch.cat(order).to(fields[0].device)
+                lo = 0
+                for idx in order:
+                    yield _Batch(fields=fields, idx=perm[lo:lo + idx.shape[0]])
+                    lo += idx.shape[0]
                 return
         if self.data_loader is None:
             self.data_loader = DataLoader(self.memory, self.batch_size, shuffle=True)
         for data in self.data_loader:
-            yield [_stack_field(x, self.device) for x in data]
+            yield _Batch(tensors=[_stack_field(x, self.device) for x in data])
 
     # -- the two kinds of step ---------------------------------------------------------------------------------------------------
     def _signature(self):
@@ -276,13 +331,12 @@ class MPRLTrainer(_TrainerBase):
             logging.debug('{}-th epoch starts'.format(epoch))
             update_counter = 0
             for data in self._batches():
-                robot_states, human_states, values, _, _, next_human_states = data
                 update_sp = False
                 if self.state_predictor.trainable:
                     update_sp = update_counter % self.state_predictor_update_interval == 0
                     update_counter += 1
-                self._run(("il", update_sp), steps[update_sp], [robot_states, human_states, values.to(self.device), next_human_states],
-                          modules, self._signature())
+                # robot_states, human_states, values, next_human_states of (robot, humans, value, reward, next robot, next humans)
+                self._run(("il", update_sp), steps[update_sp], data.pick([0, 1, 2, 5]), modules, self._signature())
             epoch_v_loss, epoch_s_loss = self._loss_read()
             logging.debug('{}-th epoch ends'.format(epoch))
             self.writer.add_scalar('IL/epoch_v_loss', epoch_v_loss / len(self.memory), epoch)
@@ -311,7 +365,6 @@ class MPRLTrainer(_TrainerBase):
         self._loss_begin()
         batch_count = 0
         for data in self._batches():
-            robot_states, human_states, _, rewards, next_robot_states, next_human_states = data
             update_sp = False
             if self.state_predictor.trainable:
                 update_sp = True
@@ -319,8 +372,8 @@ class MPRLTrainer(_TrainerBase):
                     update_sp = False
                 elif self.reduce_sp_update_frequency and batch_count % self.state_predictor_update_interval == 0:
                     update_sp = False
-            self._run(("rl", update_sp), steps[update_sp],
-                      [robot_states, human_states, rewards, next_robot_states, next_human_states], modules, self._signature())
+            # robot_states, human_states, rewards, next_robot_states, next_human_states
+            self._run(("rl", update_sp), steps[update_sp], data.pick([0, 1, 3, 4, 5]), modules, self._signature())
             batch_count += 1
             if batch_count > num_batches:
                 break
@@ -423,9 +476,9 @@ class VNRLTrainer(_TrainerBase):
                 def fn(x, v, lengths=lengths):
                     self._step(x, lengths, lambda: v)
                 if self._full_lengths(lengths, inputs.shape[1]):
-                    self._run(("il",), fn, [inputs, values], [self.model], self._signature())
+                    self._run(("il",), fn, _Batch(tensors=[inputs, values]), [self.model], self._signature())
                 else:
-                    fn(inputs, values)
+                    self._run_eager(fn, [inputs, values])
             epoch_loss = self._loss_read()[0]
             logging.debug('{}-th epoch ends'.format(epoch))
             average_epoch_loss = epoch_loss / len(self.memory)
@@ -451,9 +504,9 @@ class VNRLTrainer(_TrainerBase):
                         return r + gamma_bar * self.target_model((x2, next_lengths))
                 self._step(x, lengths, target)
             if self._full_lengths(lengths, inputs.shape[1]) and self._full_lengths(next_lengths, next_states.shape[1]):
-                self._run(("rl",), fn, [inputs, rewards, next_states], [self.model], self._signature())
+                self._run(("rl",), fn, _Batch(tensors=[inputs, rewards, next_states]), [self.model], self._signature())
             else:
-                fn(inputs, rewards, next_states)
+                self._run_eager(fn, [inputs, rewards, next_states])
             batch_count += 1
             if batch_count > num_batches:
                 break
