@@ -77,6 +77,7 @@ struct FusedArgs {
     int items_per_parent;         // = ceil(n_full / tiles_per_item); the last group also carries the partial tile
     int rot;                      // item order: group (o + rot) % items_per_parent at order position o (heaviest group first)
     int parents_per_wg;           // workgroup b owns parents [b k, (b + 1) k): every item of a parent runs on that workgroup's waves
+    int image_sync;               // measurements: stage the whole weight image through registers before anything else (round 3)
     int inline_partial;           // few parents per workgroup: the partial tile is an ordinary (padded) tile with its own head
                                   // instead of a row hand-off to the tile-packed pass at the end (a barrier + a serial head)
     TailArgs tail;                // tail.enabled: select (+ back-up chain + root step) for the owned parents at the end
@@ -145,8 +146,6 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
     constexpr int SLDK = HRL + 2;
     const int N = a.N, A = a.A, SLD = PK ? SLDK : a.SLD;
     const float NEG_INF = -INFINITY;
-    copy_image<LO::scratch, nthreads>(lds, a.image, tid);      // weight image, once per workgroup
-    __syncthreads();
     const float* wr1 = lds + LO::wr1;   // [12][W1LD], rows 9..11 zero
     const float* br1 = lds + LO::br1;
     const float* wr2 = lds + LO::wr2;   // [HID][WLD]
@@ -465,8 +464,47 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         load_fence();
         __builtin_amdgcn_wave_barrier();      // the tiles' AB / Y0 writes stay behind these reads
     };
-    PHASE_START();
+    // Weight image -> LDS with LDS-direct loads (global_load_lds_dwordx4: a wave moves 1 KB per instruction, no registers in
+    // between), in TWO parts (round 4): everything the crowd quantities and a tile need before its head -- the embedding and graph
+    // matrices, the per-feature vectors: [0, f_last), a third of the image -- is waited for here; the value head's fragments (the
+    // other two thirds) keep streaming in under the first item's crowd computation and its first tile's embedding / row pass, and
+    // every wave waits for them once, in front of its first head (await_image: its own loads via vmcnt, the other waves' via an
+    // LDS counter).  Until round 4 the whole image was staged through registers before anything else ran: ~4 us of every launch.
+    static_assert(LO::scratch % 4 == 0 && LO::f_last % 4 == 0, "b128 granules");
+    constexpr int kChunk = 256;                                            // floats per wave and instruction
+    constexpr int kChunksA = (LO::f_last + kChunk - 1) / kChunk, kChunksAll = (LO::scratch + kChunk - 1) / kChunk;
+    int* image_arrivals = reinterpret_cast<int*>(lds + LO::scratch + kFusedWaves * fused_scratch_floats(HR, NT, SOFT));
+    auto image_chunk = [&](int c) {
+        const int fl = c * kChunk + lane * 4;
+        if (fl < LO::scratch)                                              // the last chunk is partial
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.image + fl),
+                                             (__attribute__((address_space(3))) void*)(lds + c * kChunk), 16, 0, 0);
+    };
+    // (the first item's state rows are requested BEFORE the image: the wait in front of the barrier covers them, and no later
+    // wait for them can hold the wave until the head fragments have landed as well -- vmcnt counts in order)
     if (wave < n_items) item_loads(item_at(0));
+    if (tid == 0) *image_arrivals = 0;
+    bool image_complete = false;                                           // wave-uniform
+    if (a.image_sync) {                                                    // RGL_FUSED_IMAGE_SYNC=1 (measurements): the round-3 copy
+        copy_image<LO::scratch, nthreads>(lds, a.image, tid);
+        __syncthreads();
+        image_complete = true;
+    } else {
+    for (int c = wave; c < kChunksA; c += kFusedWaves) image_chunk(c);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0)
+    __syncthreads();
+    for (int c = kChunksA + wave; c < kChunksAll; c += kFusedWaves) image_chunk(c);
+    }
+    auto await_image = [&]() {
+        if (image_complete) return;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                // my share of the head fragments has landed
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(image_arrivals, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(image_arrivals, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kFusedWaves) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        image_complete = true;
+    };
+    PHASE_START();
     for (int pass = 0; pass < n_pass; ++pass) {
         const int wi = item_at(pass);
         if (wi >= n_items) break;                          // only the last pass is short
@@ -839,11 +877,13 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         }
 
         // ---------------- last GCN layer on the robot row + value head: one register-resident MFMA chain -------------------
+        await_image();
         const float v = head_chain<LO, D1, D2, D3, SKIP, HX>(lds, tin, hp, lane);
         if (q == 0 && c < A) a.value[(size_t)p * A + c] = v + hb4;
         PHASE_MARK(6);
       }
     }
+    await_image();                       // waves without a head of their own (no items, partial tiles only)
     if (a.rem && !a.inline_partial) {
         // Rows of this workgroup's partial tiles (its own parents, all written by waves of THIS workgroup): scored here,
         // tile-packed over parents -- 16 parents' `stop` children fill one head tile exactly, so the head never multiplies
@@ -1158,7 +1198,7 @@ inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A,
         pl.grid = ip.grid;
     }
     pl.lds_bytes = (size_t)((pl.hx ? FusedLds<32, 100, 100, true>::scratch : FusedLds<32, 100, 100, false>::scratch) +
-                            kFusedWaves * fused_scratch_floats(pl.hr, pl.nt, a.sim == SIM_SOFTMAX)) * sizeof(float);
+                            kFusedWaves * fused_scratch_floats(pl.hr, pl.nt, a.sim == SIM_SOFTMAX) + 4) * sizeof(float);   // + the arrival counter of the image
     if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
     a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];
     a.wa = bilinear_wa(g); a.w1 = g.Ws[0];
@@ -1278,6 +1318,8 @@ int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, i
     fp.a.value = child_value;
     fp.a.image = image;
     fp.a.rows_left = rows_left;
+    static const int image_sync = env_int("RGL_FUSED_IMAGE_SYNC", 0);
+    fp.a.image_sync = image_sync;
     if (ta) {
         fp.a.tail = *ta;
         fp.a.tail.chain = chain;
