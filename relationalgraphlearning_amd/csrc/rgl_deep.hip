@@ -61,7 +61,7 @@ __device__ __forceinline__ f16x8 pack8(f32x4 lo, f32x4 hi) {
     return v;
 }
 
-template <int NT, bool F16, bool SKIP, bool SOFT>
+template <int NT, bool F16, bool SKIP, bool SOFT, bool T4 = false>
 __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const DeepArgs a) {
     const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -144,6 +144,15 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
     const int jrow = PERM ? 4 * (n & 3) + (n >> 2) : n;
     auto knode = [&](int jt, int r) { return PERM ? 16 * jt + 4 * r + q : 16 * jt + 4 * q + r; };
     const int KS = (N + 3) >> 2;
+    // T4 (round 4): the LAST node tile holds at most four valid nodes (configs[4]: N = 50 -> nodes 48, 49 in a tile of 16).  Its
+    // rows of O = H1 W2 and of E O then come from v_mfma_f32_4x4x1_16B_f32 (rgl_mfma.h: 12 clocks per k step instead of 32): the
+    // A operands -- the layer-0 rows of nodes 16 LT + (lane & 3), E's last row tile replicated over the quads once per parent --
+    // pair with the B operands the 16 x 16 products read anyway, and a reduce(-scatter) over the k-groups leaves the results where
+    // the next step wants them (O: node 16 LT + q in k-slot order; E O: row 16 LT + q in k-group q).
+    // A template flag (launch_deep_t picks it from N and L): with both forms in one kernel the fourth tile's registers stay live.
+    constexpr int LT = NT - 1;
+    constexpr bool t4 = T4;
+    static_assert(!T4 || (!F16 && NT >= 2), "T4: the f32 form, at least two node tiles");
     const bool crowd_wave = wave < NT;
     const int n_child_waves = kDeepWaves - NT;
 
@@ -417,6 +426,13 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
 #pragma unroll
                     for (int jt = 0; jt < NT; ++jt)
                         Ef[F16 ? 0 : it][F16 ? 0 : jt] = *reinterpret_cast<const f32x4*>(&EX[((it * NT + jt) * 64 + lane) * 4]);
+                if (t4) {                  // rows 16 LT .. 16 LT + 3 of E as the A operand of the 4 x 4 x 1 blocks (A row = lane % 4)
+#pragma unroll
+                    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            Ef[F16 ? 0 : LT][F16 ? 0 : jt][r] = quad0_bcast(Ef[F16 ? 0 : LT][F16 ? 0 : jt][r]);
+                }
             }
         }
         __syncthreads();
@@ -511,11 +527,13 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
             f32x4 tsk[2] = {zero4(), zero4()};
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
-                const int j = 16 * jt + jrow;
+                // T4: the last tile's rows in the 4 x 4 x 1 A layout -- node 16 LT + (n & 3), four copies of each (p counts one)
+                const bool last4 = t4 && jt == LT;
+                const int j = last4 ? 16 * LT + (n & 3) : 16 * jt + jrow;
                 const bool jv = j < TLD;
                 const float aj = jv ? TA[c * TLD + j] : 0.f;
                 const float bj = jv ? TB[c * TLD + j] : 0.f;
-                const float pj = jv ? TP[c * TLD + j] : 0.f;
+                const float pj = (jv && !(last4 && n >= 4)) ? TP[c * TLD + j] : 0.f;
 #pragma unroll
                 for (int fh = 0; fh < 2; ++fh) {
                     const int fo = fh ? fo1 : fo0;
@@ -569,6 +587,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                         O[jt][gt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, w2h[gt], O[jt][gt], 0, 0, 0);
                 }
             } else {
+                f32x4 o4[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};      // T4: [gt][accumulator]
 #pragma unroll
                 for (int fh = 0; fh < 2; ++fh) {
                     load_fence();
@@ -579,12 +598,25 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                         wb[r][1] = w2[(16 * fh + 4 * q + r) * WLD + 16 + n];
                     }
 #pragma unroll
-                    for (int jt = 0; jt < NT; ++jt)
+                    for (int jt = 0; jt < NT; ++jt) {
+                        if (t4 && jt == LT) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                o4[0][r & 1] = mfma4x4(h1[jt][fh][r], wb[r][0], o4[0][r & 1]);
+                                o4[1][r & 1] = mfma4x4(h1[jt][fh][r], wb[r][1], o4[1][r & 1]);
+                            }
+                            continue;
+                        }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             O[jt][0] = mfma4(h1[jt][fh][r], wb[r][0], O[jt][0]);
                             O[jt][1] = mfma4(h1[jt][fh][r], wb[r][1], O[jt][1]);
                         }
+                    }
+                }
+                if (t4) {          // node 16 LT + q of the last tile in register 0 of lane (n, q): its only populated k step
+                    O[LT][0] = f32x4{kgroups_reduce_scatter(o4[0][0] + o4[0][1]), 0.f, 0.f, 0.f};
+                    O[LT][1] = f32x4{kgroups_reduce_scatter(o4[1][0] + o4[1][1]), 0.f, 0.f, 0.f};
                 }
             }
             // row scalars in the D layout: i = 16 it + 4 q + r;  pn = p in k-slot order (row 0 of E's first tile)
@@ -647,6 +679,30 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
 #pragma unroll
                 for (int it = 0; it < NT; ++it) {
                     load_fence();
+                    if (t4 && it == LT) {
+                        // rows 16 LT + i of E O on the 4 x 4 x 1 blocks; the reduce-scatter over the k-groups leaves row 16 LT + q in
+                        // lane (n, q), column g = n: every row is finished (and weighted into t_c) by one k-group
+                        f32x4 d4[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};
+#pragma unroll
+                        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                if (jt == NT - 1 && 4 * jt + r >= KS) continue;
+                                const float ea = Ef[F16 ? 0 : LT][F16 ? 0 : jt][r];
+                                d4[0][r & 1] = mfma4x4(ea, O[jt][0][r], d4[0][r & 1]);
+                                d4[1][r & 1] = mfma4x4(ea, O[jt][1][r], d4[1][r & 1]);
+                            }
+                        const int i4 = 16 * LT + q;               // the reduce-scatter leaves row 16 LT + q in lane (n, q), column g = n
+                        const bool rv4 = i4 < TLD;
+                        const float p1 = rv4 ? TP[c * TLD + i4] : 0.f, a1 = rv4 ? TA[c * TLD + i4] : 0.f, b1 = rv4 ? TB[c * TLD + i4] : 0.f;
+#pragma unroll
+                        for (int gt = 0; gt < 2; ++gt) {
+                            const float x = kgroups_reduce_scatter(d4[gt][0] + d4[gt][1]);
+                            const float v = relu1(fmaf(a1, x, b1 * o0[gt]));
+                            tacc[gt] = fmaf(p1, v, tacc[gt]);
+                        }
+                        continue;
+                    }
                     const bool rv = 16 * it + 4 * q < TLD;
                     const f32x4 pq = rv ? *reinterpret_cast<const f32x4*>(&TP[c * TLD + 16 * it + 4 * q]) : zero4();
                     const f32x4 aq = rv ? *reinterpret_cast<const f32x4*>(&TA[c * TLD + 16 * it + 4 * q]) : zero4();
@@ -737,9 +793,14 @@ inline DeepPlan plan_deep(const RglGraph& g, int P, int A, int H) {
     return pl;
 }
 
-template <int NT, bool F16, bool SKIP, bool SOFT>
+template <int NT, bool F16, bool SKIP, bool SOFT, bool T4 = false>
 int launch_deep_t(const DeepPlan& pl, hipStream_t st) {
-    auto kern = children_deep_kernel<NT, F16, SKIP, SOFT>;
+    if constexpr (!T4 && !F16 && SOFT && NT >= 2) {
+        // last node tile with at most four valid nodes, three layers: the 4 x 4 x 1 form of that tile (RGL_DEEP_T4=0: measurements)
+        static const bool t4_off = [] { const char* e = getenv("RGL_DEEP_T4"); return e && e[0] == '0'; }();
+        if (!t4_off && pl.a.L == 3 && pl.a.N - 16 * (NT - 1) <= 4) return launch_deep_t<NT, F16, SKIP, SOFT, true>(pl, st);
+    }
+    auto kern = children_deep_kernel<NT, F16, SKIP, SOFT, T4>;
     if (pl.lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)pl.lds_bytes));

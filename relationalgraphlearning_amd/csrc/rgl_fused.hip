@@ -51,15 +51,6 @@ __host__ __device__ constexpr int fused_scratch_floats(int HR, int NT, bool SOFT
     return ((fl > kTailLdsInts ? fl : kTailLdsInts) + 3) & ~3;      // ... and, after the last item, the tables of the select step
 }
 
-// lane n of every 16-lane row <- lane n & 3 of that row (three DPP row shifts, each writing one bank of four lanes)
-__device__ __forceinline__ float quad0_bcast(float x) {
-    int v = __float_as_int(x);
-    v = __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0x2, false);      // row_shr:4  -> lanes 4..7
-    v = __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0x4, false);      // row_shr:8  -> lanes 8..11
-    v = __builtin_amdgcn_update_dpp(v, v, 0x11C, 0xf, 0x8, false);      // row_shr:12 -> lanes 12..15
-    return __int_as_float(v);
-}
-
 struct FusedArgs {
     const float *wr1, *br1, *wr2, *br2, *wa, *w1;                       // child-side weights (k-major)
     const float *wh1, *bh1, *wh2, *bh2;                                 // w_h (crowd side)

@@ -40,6 +40,29 @@ __device__ __forceinline__ float kgroups_sum(float x) {
     r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// v_mfma_f32_4x4x1_16B_f32: sixteen independent 4 x 4 x 1 blocks, block = lane / 4, A row = B column = lane % 4, D register = row
+// (tools/micro/mfma_4x4.hip: layout checked on the hardware, 12 clocks per instruction against 32 for the 16 x 16 x 4 form).
+// Used where a 16-row MFMA tile would carry at most four valid rows (rgl_mlp_chain.h Partial4, rgl_fused.hip T1P, rgl_deep.hip T4).
+__device__ __forceinline__ f32x4 mfma4x4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+// lane (n, q) <- sum over the four k-groups of register q (see above)
+__device__ __forceinline__ float kgroups_reduce_scatter(const f32x4& p) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p[0]), __float_as_uint(p[1]), false, false);
+    const float s01 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p[2]), __float_as_uint(p[3]), false, false);
+    const float s23 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// lane n of every 16-lane row <- lane n & 3 of that row (three DPP row shifts, each writing one bank of four lanes)
+__device__ __forceinline__ float quad0_bcast(float x) {
+    int v = __float_as_int(x);
+    v = __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0x2, false);      // row_shr:4  -> lanes 4..7
+    v = __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0x4, false);      // row_shr:8  -> lanes 8..11
+    v = __builtin_amdgcn_update_dpp(v, v, 0x11C, 0xf, 0x8, false);      // row_shr:12 -> lanes 12..15
+    return __int_as_float(v);
+}
+
 // max over the 16 lanes of a DPP row (every lane gets it); the DPP operand rides in the v_max itself
 // (s_nop 1: a DPP read of a VGPR needs two wait states after the VALU write of it, and the compiler's hazard recognizer does
 // not look inside inline assembly)

@@ -38,17 +38,6 @@ __device__ __forceinline__ int frag_out_feature(int ot, int l) {
     const int m = l & 15;                                            // A-operand row = D row of the output tile
     return tile_feature<OUT>(ot, m >> 2, m & 3);
 }
-__device__ __forceinline__ f32x4 mfma4x4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
-// lane (n, q) <- sum over the four k-groups of register q (see above)
-__device__ __forceinline__ float kgroups_reduce_scatter(const f32x4& p) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p[0]), __float_as_uint(p[1]), false, false);
-    const float s01 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p[2]), __float_as_uint(p[3]), false, false);
-    const float s23 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
 // NTHR > 0: the workgroup size as a compile-time constant -- the loops are fully unrolled and every global load of a thread is
 // in flight at once (one L2 round trip for the whole image instead of one per batch of 8: the 74 KB image of the value head
 // took ~10 us per workgroup to build, which is most of a small launch).
