@@ -1235,6 +1235,48 @@ def test_value_children_f16_contraction(H, skip, flavour, dev):
     assert not np.array_equal(got["f16"], got["f32"])
 
 
+def test_deep_kernel_last_node_tile_forms_agree(dev):
+    """children_deep_kernel computes a last node tile of <= 4 valid nodes (N = 50, 36, 20 with three layers) on the 4 x 4 x 1 MFMA
+    (T4, round 4); RGL_DEEP_T4=0 keeps the 16-row form.  Both against the oracle in child processes (the switch is read once),
+    over crowd sizes on both sides of the condition (N = 49..53: 1..4 valid nodes and 5), skip on / off."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+from oracle import rgl_oracle as orc
+from tests import golden_io as gio
+from tests.helpers import make_mprl_policy
+from tests.test_gpu_parity import seeded_scenes
+dev = torch.device("cuda:0")
+worst = 0.0
+for H, skip in ((48, True), (49, True), (49, False), (50, True), (51, True), (52, True), (35, True), (19, True), (16, False), (33, True)):
+    pol = make_mprl_policy("trained", 1, L=3, skip=skip, device=dev)
+    pol.build_action_space(1.0)
+    ts = pol.tree_search()
+    A = ts.num_actions
+    robot, humans = seeded_scenes(1500 + H, 3, H)
+    acts, _ = orc.mprl_action_space(orc.OracleConfig(), 1.0)
+    cr = orc._children_robot(robot, acts, orc.OracleConfig())
+    got = ts.value_children(cr.to(dev), humans.to(dev)).cpu().numpy()
+    Pm = gio.oracle_params("trained", 3)
+    with torch.no_grad():
+        want = orc.value_estimator_forward(cr.reshape(3 * A, 1, 9), humans[:, None].expand(3, A, H, 5).reshape(3 * A, H, 5),
+                                           Pm.ve_graph, Pm.value_network, orc.OracleConfig(num_layer=3, skip_connection=skip)).numpy().reshape(3, A)
+    err = float(np.abs(got - want).max())
+    worst = max(worst, err)
+    assert err < 1e-6, (H, skip, err)
+print("OK worst %.2e" % worst)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = []
+    for sw in ("1", "0"):
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RGL_DEEP_T4=sw, RGL_REQUIRE_MFMA_CHILDREN="1"),
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+        lines.append("RGL_DEEP_T4=%s %s" % (sw, out.stdout.strip().splitlines()[-1]))
+    report("deep kernel, last node tile on the 4x4x1 MFMA vs the 16-row form, N = 17..54, L = 3: " + "; ".join(lines))
+
+
 def test_f16_tree_search_and_refusals(dev):
     """configs[4] shape (N = 50, L = 3, D = 2, w = 2) with the f16 products: root values within F16_TOL, same decisions as
     the fp32 oracle except on numerical ties; configurations without an f16 kernel are refused, not silently run in fp32."""
@@ -1710,6 +1752,7 @@ FORCED_FAMILIES = {
     "MFMA tile kernel (children_graph_kernel)": ({"RGL_CHILDREN_TILE_KERNEL": "1"}, 2048),
     "fused kernel forced at every launch size": ({"RGL_CHILDREN_FUSED": "1"}, 2048),
     "general VALU kernel": ({"RGL_FORCE_GENERIC": "1"}, 256),
+    "fused kernel with the round-3 register-staged weight image": ({"RGL_FUSED_IMAGE_SYNC": "1"}, 2048),
 }
 
 
