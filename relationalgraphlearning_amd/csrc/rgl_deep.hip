@@ -70,6 +70,9 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
     const int lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
     const int N = a.N, H = a.H, A = a.A, TLD = a.TLD;
+    // T4 kernels touch table rows 0 .. 16 LT + 3 only, all below TLD (plan_deep): the `row < TLD` guards of the per-child loop --
+    // ~200 exec-mask / branch instructions per child in the general form -- are compile-time truths there
+    auto in_table = [&](int row) { return T4 ? true : row < TLD; };
     const float* wh1 = lds + a.off_wh1;   // [8][W1LD], rows 5..7 zero
     const float* bh1 = lds + a.off_bh1;
     const float* wh2 = lds + a.off_wh2;   // [HID][WLD]
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                 // T4: the last tile's rows in the 4 x 4 x 1 A layout -- node 16 LT + (n & 3), four copies of each (p counts one)
                 const bool last4 = t4 && jt == LT;
                 const int j = last4 ? 16 * LT + (n & 3) : 16 * jt + jrow;
-                const bool jv = j < TLD;
+                const bool jv = in_table(j);
                 const float aj = jv ? TA[c * TLD + j] : 0.f;
                 const float bj = jv ? TB[c * TLD + j] : 0.f;
                 const float pj = (jv && !(last4 && n >= 4)) ? TP[c * TLD + j] : 0.f;
@@ -625,7 +628,10 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
             for (int jt = 0; jt < NT; ++jt) {
                 if (PERM) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pn[jt][r] = knode(jt, r) < TLD ? TP[c * TLD + knode(jt, r)] : 0.f;
+                    for (int r = 0; r < 4; ++r) {
+                        if (T4 && jt == LT && r >= 1) pn[jt][r] = 0.f;          // nodes 16 LT + 4 r + q >= 16 LT + 4: beyond the crowd
+                        else pn[jt][r] = in_table(knode(jt, r)) ? TP[c * TLD + knode(jt, r)] : 0.f;
+                    }
                 } else {
                     pn[jt] = 16 * jt + 4 * q < TLD ? *reinterpret_cast<const f32x4*>(&TP[c * TLD + 16 * jt + 4 * q]) : zero4();
                 }
@@ -687,14 +693,13 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                         for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                if (jt == NT - 1 && 4 * jt + r >= KS) continue;
+                                if (jt == LT && r >= 1) continue;             // T4: the last tile's one populated k step
                                 const float ea = Ef[F16 ? 0 : LT][F16 ? 0 : jt][r];
                                 d4[0][r & 1] = mfma4x4(ea, O[jt][0][r], d4[0][r & 1]);
                                 d4[1][r & 1] = mfma4x4(ea, O[jt][1][r], d4[1][r & 1]);
                             }
                         const int i4 = 16 * LT + q;               // the reduce-scatter leaves row 16 LT + q in lane (n, q), column g = n
-                        const bool rv4 = i4 < TLD;
-                        const float p1 = rv4 ? TP[c * TLD + i4] : 0.f, a1 = rv4 ? TA[c * TLD + i4] : 0.f, b1 = rv4 ? TB[c * TLD + i4] : 0.f;
+                        const float p1 = TP[c * TLD + i4], a1 = TA[c * TLD + i4], b1 = TB[c * TLD + i4];      // i4 <= 16 LT + 3 < TLD
 #pragma unroll
                         for (int gt = 0; gt < 2; ++gt) {
                             const float x = kgroups_reduce_scatter(d4[gt][0] + d4[gt][1]);
@@ -703,7 +708,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                         }
                         continue;
                     }
-                    const bool rv = 16 * it + 4 * q < TLD;
+                    const bool rv = in_table(16 * it + 4 * q);
                     const f32x4 pq = rv ? *reinterpret_cast<const f32x4*>(&TP[c * TLD + 16 * it + 4 * q]) : zero4();
                     const f32x4 aq = rv ? *reinterpret_cast<const f32x4*>(&TA[c * TLD + 16 * it + 4 * q]) : zero4();
                     const f32x4 bq = rv ? *reinterpret_cast<const f32x4*>(&TB[c * TLD + 16 * it + 4 * q]) : zero4();
@@ -712,7 +717,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                     for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            if (jt == NT - 1 && 4 * jt + r >= KS) continue;       // k steps beyond the last node (uniform)
+                            if (T4 ? (jt == LT && r >= 1) : (jt == NT - 1 && 4 * jt + r >= KS)) continue;   // k steps beyond the last node (uniform)
                             float ea = Ef[F16 ? 0 : it][F16 ? 0 : jt][r];
                             if (it == 0 && n == 0) ea = pn[jt][r];
                             d[0] = mfma4(ea, O[jt][0][r], d[0]);
@@ -754,6 +759,7 @@ struct DeepPlan {
     size_t lds_bytes;
     int NT;
     bool ok;
+    bool t4;            // the T4 form (last node tile on the 4 x 4 x 1 MFMA, TLD = 16 NT)
 };
 
 inline DeepPlan plan_deep(const RglGraph& g, int P, int A, int H) {
@@ -771,6 +777,11 @@ inline DeepPlan plan_deep(const RglGraph& g, int P, int A, int H) {
     pl.NT = (N + 15) / 16;
     a.CT = (A + 15) / 16;
     a.TLD = (N + 3) & ~3;
+    // last node tile with at most four valid nodes, three layers, softmax similarity: the T4 form of the kernel (4 x 4 x 1 MFMA for
+    // that tile).  Its table rows end at node 16 LT + 3 (TLD = (N + 3) & ~3 >= 16 LT + 4): every row the T4 kernel touches is inside.
+    static const bool t4_off = [] { const char* e = getenv("RGL_DEEP_T4"); return e && e[0] == '0'; }();
+    const bool t4_wanted = !t4_off && a.L == 3 && pl.NT >= 2 && N - 16 * (pl.NT - 1) <= 4 && a.sim == SIM_SOFTMAX;
+    pl.t4 = t4_wanted;
     int off = 0;
     auto take = [&](int nfl) { int o = off; off += (nfl + 3) & ~3; return o; };
     a.off_wh1 = take(8 * W1LD); a.off_bh1 = take(HID); a.off_wh2 = take(HID * WLD); a.off_bh2 = take(XD);
@@ -796,9 +807,7 @@ inline DeepPlan plan_deep(const RglGraph& g, int P, int A, int H) {
 template <int NT, bool F16, bool SKIP, bool SOFT, bool T4 = false>
 int launch_deep_t(const DeepPlan& pl, hipStream_t st) {
     if constexpr (!T4 && !F16 && SOFT && NT >= 2) {
-        // last node tile with at most four valid nodes, three layers: the 4 x 4 x 1 form of that tile (RGL_DEEP_T4=0: measurements)
-        static const bool t4_off = [] { const char* e = getenv("RGL_DEEP_T4"); return e && e[0] == '0'; }();
-        if (!t4_off && pl.a.L == 3 && pl.a.N - 16 * (NT - 1) <= 4) return launch_deep_t<NT, F16, SKIP, SOFT, true>(pl, st);
+        if (pl.t4) return launch_deep_t<NT, F16, SKIP, SOFT, true>(pl, st);      // plan_deep: eligible and its tables fit (RGL_DEEP_T4=0: never)
     }
     auto kern = children_deep_kernel<NT, F16, SKIP, SOFT, T4>;
     if (pl.lds_bytes > 64 * 1024)
