@@ -42,17 +42,31 @@ struct DeepArgs {
 constexpr int kDeepThreads = 512;
 constexpr int kDeepWaves = 8;
 
-// all-reduce over the 16 lanes of a DPP row.  The DPP operand rides in the add itself: through the update_dpp builtin every step was
-// v_mov 0 + v_mov_dpp + v_add (96 of the ~520 VALU instructions of the f16 per-child loop went into the eight sums of t_c)
-__device__ __forceinline__ float row16_sum(float x) {
-    // (s_nop 1: a DPP read of a VGPR needs two wait states after the VALU write of it, and the compiler's hazard recognizer does
-    // not look inside inline assembly)
-    float y;
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(y));
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x));
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(y));
-    return x;
+// all-reduce over the 16 lanes of a DPP row, four values at once.  The DPP operand rides in the add itself (through the update_dpp
+// builtin every step was v_mov 0 + v_mov_dpp + v_add), and the stages of the four sums interleave: three independent instructions
+// between a write and its DPP read, so no wait states to pad beyond the first (a DPP read of a VGPR needs two after the VALU write
+// of it, and the compiler's hazard recognizer does not look inside inline assembly; the one-value form spent an s_nop 1 per step)
+__device__ __forceinline__ f32x4 row16_sum4(f32x4 v) {
+    float a = v[0], b = v[1], c = v[2], d = v[3];
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    return f32x4{a, b, c, d};
 }
 __device__ __forceinline__ f16x8 pack8(f32x4 lo, f32x4 hi) {
     f16x8 v;
@@ -72,7 +86,9 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
     const int N = a.N, H = a.H, A = a.A, TLD = a.TLD;
     // T4 kernels touch table rows 0 .. 16 LT + 3 only, all below TLD (plan_deep): the `row < TLD` guards of the per-child loop --
     // ~200 exec-mask / branch instructions per child in the general form -- are compile-time truths there
-    auto in_table = [&](int row) { return T4 ? true : row < TLD; };
+    // -- and in every form the rows of the node tiles before the last lie inside (N > 16 LT, TLD >= N): only the last tile is checked
+    auto in_table = [&](int row, int tile) { return tile < NT - 1 ? true : row < TLD; };
+    auto child_row = [&](int row, int tile) { return T4 ? true : in_table(row, tile); };     // the reads of the per-child loop
     const float* wh1 = lds + a.off_wh1;   // [8][W1LD], rows 5..7 zero
     const float* bh1 = lds + a.off_bh1;
     const float* wh2 = lds + a.off_wh2;   // [HID][WLD]
@@ -383,7 +399,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                         mx0 = fmaxf(mx0, s0[r]);
                     }
                     s0t[nt] = s0;
-                    if (c < A && 16 * nt + 4 * q < TLD) *reinterpret_cast<f32x4*>(&TA[c * TLD + 16 * nt + 4 * q]) = sc;
+                    if (c < A && in_table(16 * nt + 4 * q, nt)) *reinterpret_cast<f32x4*>(&TA[c * TLD + 16 * nt + 4 * q]) = sc;
                 }
                 // p = softmax of the robot row, in the D layout: my lane holds nodes 16 nt + 4 q + r of child c
                 mx0 = kgroups_max(mx0);
@@ -400,7 +416,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                 for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s0t[nt][r] *= iz0;
-                    if (c < A && 16 * nt + 4 * q < TLD) *reinterpret_cast<f32x4*>(&TP[c * TLD + 16 * nt + 4 * q]) = s0t[nt];
+                    if (c < A && in_table(16 * nt + 4 * q, nt)) *reinterpret_cast<f32x4*>(&TP[c * TLD + 16 * nt + 4 * q]) = s0t[nt];
                 }
             }
         }
@@ -449,7 +465,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
             // row scalars a, b of my 16 children (D layout: nodes 16 nt + 4 q + r), over the raw S_c[node][0] left in TA
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                if (16 * nt + 4 * q >= TLD) continue;
+                if (!in_table(16 * nt + 4 * q, nt)) continue;
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(&TA[cc * TLD + 16 * nt + 4 * q]);
                 const f32x4 ms = *reinterpret_cast<const f32x4*>(&MSH[16 * nt + 4 * q]);
                 const f32x4 zs = *reinterpret_cast<const f32x4*>(&ZSH[16 * nt + 4 * q]);
@@ -480,7 +496,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
                 load_fence();
-                const f32x4 pb = 16 * jt + 4 * q < TLD ? *reinterpret_cast<const f32x4*>(&TP[cc * TLD + 16 * jt + 4 * q]) : zero4();
+                const f32x4 pb = in_table(16 * jt + 4 * q, jt) ? *reinterpret_cast<const f32x4*>(&TP[cc * TLD + 16 * jt + 4 * q]) : zero4();
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     t0[0] = mfma4(Xh[(16 * jt + 4 * q + r) * XLD + n], pb[r], t0[0]);
@@ -533,7 +549,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                 // T4: the last tile's rows in the 4 x 4 x 1 A layout -- node 16 LT + (n & 3), four copies of each (p counts one)
                 const bool last4 = t4 && jt == LT;
                 const int j = last4 ? 16 * LT + (n & 3) : 16 * jt + jrow;
-                const bool jv = in_table(j);
+                const bool jv = child_row(j, jt);
                 const float aj = jv ? TA[c * TLD + j] : 0.f;
                 const float bj = jv ? TB[c * TLD + j] : 0.f;
                 const float pj = (jv && !(last4 && n >= 4)) ? TP[c * TLD + j] : 0.f;
@@ -562,8 +578,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
             if (SKIP || a.L == 2) {
 #pragma unroll
                 for (int fh = 0; fh < 2; ++fh) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tsk[fh][r] = row16_sum(tsk[fh][r]);
+                    tsk[fh] = row16_sum4(tsk[fh]);
                     if (n == 0) *reinterpret_cast<f32x4*>(&scr[fh ? fo1 : fo0]) = tsk[fh];
                 }
             }
@@ -630,10 +645,10 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (T4 && jt == LT && r >= 1) pn[jt][r] = 0.f;          // nodes 16 LT + 4 r + q >= 16 LT + 4: beyond the crowd
-                        else pn[jt][r] = in_table(knode(jt, r)) ? TP[c * TLD + knode(jt, r)] : 0.f;
+                        else pn[jt][r] = child_row(knode(jt, r), jt) ? TP[c * TLD + knode(jt, r)] : 0.f;
                     }
                 } else {
-                    pn[jt] = 16 * jt + 4 * q < TLD ? *reinterpret_cast<const f32x4*>(&TP[c * TLD + 16 * jt + 4 * q]) : zero4();
+                    pn[jt] = in_table(16 * jt + 4 * q, jt) ? *reinterpret_cast<const f32x4*>(&TP[c * TLD + 16 * jt + 4 * q]) : zero4();
                 }
             }
             // O_0[g]: held by the q == 0 lanes (r = 0 of tile jt = 0: node 0)
@@ -654,8 +669,8 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
 #pragma unroll
                 for (int it = 0; it < NT; ++it) {
                     load_fence();
-                    const bool rv = 16 * it + 4 * q < TLD;
-                    const f32x4 pq = rv ? *reinterpret_cast<const f32x4*>(&TP[c * TLD + 16 * it + 4 * q]) : zero4();
+                    const bool rv = in_table(16 * it + 4 * q, it);
+                    const f32x4 pq = pn[it];               // plain node order: the k-slot order of p is its row order
                     const f32x4 aq = rv ? *reinterpret_cast<const f32x4*>(&TA[c * TLD + 16 * it + 4 * q]) : zero4();
                     const f32x4 bq = rv ? *reinterpret_cast<const f32x4*>(&TB[c * TLD + 16 * it + 4 * q]) : zero4();
                     f32x4 d[2] = {zero4(), zero4()};
@@ -708,7 +723,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                         }
                         continue;
                     }
-                    const bool rv = in_table(16 * it + 4 * q);
+                    const bool rv = child_row(16 * it + 4 * q, it);
                     const f32x4 pq = rv ? *reinterpret_cast<const f32x4*>(&TP[c * TLD + 16 * it + 4 * q]) : zero4();
                     const f32x4 aq = rv ? *reinterpret_cast<const f32x4*>(&TA[c * TLD + 16 * it + 4 * q]) : zero4();
                     const f32x4 bq = rv ? *reinterpret_cast<const f32x4*>(&TB[c * TLD + 16 * it + 4 * q]) : zero4();

@@ -632,7 +632,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                     const int nd = 16 * nt + 4 * q + r;
                     if (nd == 0) { sc[r] = s00; s0[r] = s00; }
                     if (sim != SIM_SOFTMAX) s0[r] = plain_weight(sim, s0[r], 0, nd);
-                    if (nd >= N) { sc[r] = NEG_INF; s0[r] = sim == SIM_SOFTMAX ? NEG_INF : 0.f; }
+                    if (!T1P && nd >= N) { sc[r] = NEG_INF; s0[r] = sim == SIM_SOFTMAX ? NEG_INF : 0.f; }   // T1P: nd <= 15 < N here
                     mx0 = fmaxf(mx0, s0[r]);
                 }
                 s0t[nt] = s0;
@@ -694,15 +694,16 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                         const int nd = 16 * nt + 4 * q + r;
                         const float rr = __expf(fminf(ms[nt][r] - sct[nt][r], 60.f));
                         const float bb = s0t[nt][r] * __builtin_amdgcn_rcpf(fmaf(rr, zs[nt][r], 1.f));
-                        const bool rh = nd >= 1 && nd < N;
-                        if (nd < HRL) *reinterpret_cast<f32x2*>(&AB[(n * SLDK + nd) * 2]) = f32x2{rh ? rr : 0.f, rh ? bb : 0.f};
+                        // T1P: rows 1..15 are humans whatever N is (N > 16) and lie inside the table: no guards, no exec masks
+                        const bool rh = T1P ? nd >= 1 : (nd >= 1 && nd < N);
+                        if (T1P || nd < HRL) *reinterpret_cast<f32x2*>(&AB[(n * SLDK + nd) * 2]) = f32x2{rh ? rr : 0.f, rh ? bb : 0.f};
                     }
                 if constexpr (T1P) {                             // node 16 + q (HRL == 20: rows 16..19 of the table)
                     const int nd = 16 + q;
                     const float rr = __expf(fminf(ms1 - sc1, 60.f));
                     const float bb = p1 * __builtin_amdgcn_rcpf(fmaf(rr, zs1, 1.f));
                     const bool rh = nd < N;
-                    if (nd < HRL) *reinterpret_cast<f32x2*>(&AB[(n * SLDK + nd) * 2]) = f32x2{rh ? rr : 0.f, rh ? bb : 0.f};
+                    *reinterpret_cast<f32x2*>(&AB[(n * SLDK + nd) * 2]) = f32x2{rh ? rr : 0.f, rh ? bb : 0.f};      // nd <= 19 < HRL = 20
                 }
             } else {
 #pragma unroll

@@ -10,5 +10,7 @@ for sw in "X=1" "RGL_DEEP_T4=0"; do
   env $sw RGL_BENCH_NO_F16X3=1 python bench.py --cpu-seconds 0 --humans 49 --layers 3 --roots 256 --steps 100 2>/dev/null | line "c4 f32 256 roots [$sw]" >> $O
   env $sw RGL_BENCH_NO_F16X3=1 python bench.py --cpu-seconds 0 --humans 49 --layers 3 --roots 2048 --steps 30 2>/dev/null | line "c4 f32 2048 roots [$sw]" >> $O
 done
+env RGL_BENCH_NO_F16X3=1 python bench.py --cpu-seconds 0 --humans 49 --layers 3 --roots 256 --steps 100 --contraction f16 2>/dev/null | line "c4 f16 256 roots" >> $O
+env RGL_BENCH_NO_F16X3=1 python bench.py --cpu-seconds 0 --humans 39 --layers 3 --roots 256 --steps 100 2>/dev/null | line "N=40 L=3 f32 256 roots (non-T4 form)" >> $O
 done
 cat $O
