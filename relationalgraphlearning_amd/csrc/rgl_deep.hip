@@ -228,69 +228,69 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
             load_fence();
             *reinterpret_cast<f32x4*>(&Gm[node * XLD + 4 * q]) = pg[0];
             *reinterpret_cast<f32x4*>(&Gm[node * XLD + 16 + 4 * q]) = pg[1];
-        } else {
-            for (int ct = wave - NT; ct < a.CT; ct += n_child_waves) {
-                const int c = 16 * ct + n;
-                const int cc = c < A ? c : A - 1;
-                const float* rr = a.child_robot + ((size_t)p * A + cc) * 9;
-                f32x4 hacc[4] = {zero4(), zero4(), zero4(), zero4()};
+        }
+        // the 16-child tiles: the child waves first, the crowd waves join with the tiles beyond them once their crowd work is done
+        for (int ct = crowd_wave ? n_child_waves + wave : wave - NT; ct < a.CT; ct += kDeepWaves) {
+            const int c = 16 * ct + n;
+            const int cc = c < A ? c : A - 1;
+            const float* rr = a.child_robot + ((size_t)p * A + cc) * 9;
+            f32x4 hacc[4] = {zero4(), zero4(), zero4(), zero4()};
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const int k = 4 * s + q;
-                    const float b = k < 9 ? rr[k] : 0.f;
+            for (int s = 0; s < 3; ++s) {
+                const int k = 4 * s + q;
+                const float b = k < 9 ? rr[k] : 0.f;
 #pragma unroll
-                    for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wr1[k * W1LD + 16 * ht + n], b, hacc[ht]);
-                }
-#pragma unroll
-                for (int ht = 0; ht < 4; ++ht) {
-                    const f32x4 bb = *reinterpret_cast<const f32x4*>(&br1[16 * ht + 4 * q]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) hacc[ht][r] = relu1(hacc[ht][r] + bb[r]);
-                }
-                f32x4 xacc[2] = {zero4(), zero4()};
-#pragma unroll
-                for (int ht = 0; ht < 4; ++ht) {
-                    load_fence();
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int ot = 0; ot < 2; ++ot)
-                            xacc[ot] = mfma4(wr2[(16 * ht + 4 * q + r) * WLD + 16 * ot + n], hacc[ht][r], xacc[ot]);
-                }
-                load_fence();
-#pragma unroll
-                for (int ot = 0; ot < 2; ++ot) {
-                    const f32x4 bb = *reinterpret_cast<const f32x4*>(&br2[16 * ot + 4 * q]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xacc[ot][r] = relu1(xacc[ot][r] + bb[r]);
-                    if (c < A) *reinterpret_cast<f32x4*>(&X0[c * XLD + 16 * ot + 4 * q]) = xacc[ot];
-                }
-                f32x4 yacc[2] = {zero4(), zero4()}, gacc[2] = {zero4(), zero4()};
-#pragma unroll
-                for (int ot = 0; ot < 2; ++ot) {
-                    load_fence();
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int gt = 0; gt < 2; ++gt) {
-                            gacc[gt] = mfma4(wa[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], gacc[gt]);
-                            yacc[gt] = mfma4(w1[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], yacc[gt]);
-                        }
-                }
-                load_fence();
-                float s00 = 0.f;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    if (c < A) {
-                        *reinterpret_cast<f32x4*>(&Y0[c * XLD + 16 * t + 4 * q]) = yacc[t];
-                        *reinterpret_cast<f32x4*>(&G0[c * XLD + 16 * t + 4 * q]) = gacc[t];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s00 = fmaf(gacc[t][r], xacc[t][r], s00);
-                }
-                s00 = kgroups_sum(s00);
-                if (q == 0 && c < A) S00[c] = s00;
+                for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wr1[k * W1LD + 16 * ht + n], b, hacc[ht]);
             }
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&br1[16 * ht + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hacc[ht][r] = relu1(hacc[ht][r] + bb[r]);
+            }
+            f32x4 xacc[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot)
+                        xacc[ot] = mfma4(wr2[(16 * ht + 4 * q + r) * WLD + 16 * ot + n], hacc[ht][r], xacc[ot]);
+            }
+            load_fence();
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&br2[16 * ot + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xacc[ot][r] = relu1(xacc[ot][r] + bb[r]);
+                if (c < A) *reinterpret_cast<f32x4*>(&X0[c * XLD + 16 * ot + 4 * q]) = xacc[ot];
+            }
+            f32x4 yacc[2] = {zero4(), zero4()}, gacc[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                load_fence();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int gt = 0; gt < 2; ++gt) {
+                        gacc[gt] = mfma4(wa[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], gacc[gt]);
+                        yacc[gt] = mfma4(w1[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xacc[ot][r], yacc[gt]);
+                    }
+            }
+            load_fence();
+            float s00 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (c < A) {
+                    *reinterpret_cast<f32x4*>(&Y0[c * XLD + 16 * t + 4 * q]) = yacc[t];
+                    *reinterpret_cast<f32x4*>(&G0[c * XLD + 16 * t + 4 * q]) = gacc[t];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s00 = fmaf(gacc[t][r], xacc[t][r], s00);
+            }
+            s00 = kgroups_sum(s00);
+            if (q == 0 && c < A) S00[c] = s00;
         }
         PHASE_MARK(1);
         __syncthreads();
@@ -363,61 +363,61 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
             load_fence();
             *reinterpret_cast<f32x4*>(&UW[node * XLD + 4 * q]) = uw[0];
             *reinterpret_cast<f32x4*>(&UW[node * XLD + 16 + 4 * q]) = uw[1];
-        } else {
-            for (int ct = wave - NT; ct < a.CT; ct += n_child_waves) {
-                const int c = 16 * ct + n;
-                const int cc = c < A ? c : A - 1;
-                f32x4 xq[2], gq[2];
+        }
+        // the 16-child tiles: the child waves first, the crowd waves join with the tiles beyond them once their crowd work is done
+        for (int ct = crowd_wave ? n_child_waves + wave : wave - NT; ct < a.CT; ct += kDeepWaves) {
+            const int c = 16 * ct + n;
+            const int cc = c < A ? c : A - 1;
+            f32x4 xq[2], gq[2];
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                xq[ot] = *reinterpret_cast<const f32x4*>(&X0[cc * XLD + 16 * ot + 4 * q]);
+                gq[ot] = *reinterpret_cast<const f32x4*>(&G0[cc * XLD + 16 * ot + 4 * q]);
+            }
+            const float s00 = S00[cc];
+            f32x4 s0t[NT];
+            float mx0 = NEG_INF;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                load_fence();
+                f32x4 sc = zero4(), s0 = zero4();
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot) {
-                    xq[ot] = *reinterpret_cast<const f32x4*>(&X0[cc * XLD + 16 * ot + 4 * q]);
-                    gq[ot] = *reinterpret_cast<const f32x4*>(&G0[cc * XLD + 16 * ot + 4 * q]);
-                }
-                const float s00 = S00[cc];
-                f32x4 s0t[NT];
-                float mx0 = NEG_INF;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    load_fence();
-                    f32x4 sc = zero4(), s0 = zero4();
-#pragma unroll
-                    for (int ot = 0; ot < 2; ++ot) {
-                        const f32x4 gm = *reinterpret_cast<const f32x4*>(&Gm[(16 * nt + n) * XLD + 16 * ot + 4 * q]);
-                        const f32x4 xh = *reinterpret_cast<const f32x4*>(&Xh[(16 * nt + n) * XLD + 16 * ot + 4 * q]);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            sc = mfma4(gm[r], xq[ot][r], sc);       // S_c[node][0]
-                            s0 = mfma4(xh[r], gq[ot][r], s0);       // S_c[0][node]
-                        }
-                    }
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(&Gm[(16 * nt + n) * XLD + 16 * ot + 4 * q]);
+                    const f32x4 xh = *reinterpret_cast<const f32x4*>(&Xh[(16 * nt + n) * XLD + 16 * ot + 4 * q]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int nd = 16 * nt + 4 * q + r;
-                        if (nd == 0) { sc[r] = s00; s0[r] = s00; }
-                        if (sim != SIM_SOFTMAX) s0[r] = plain_weight(sim, s0[r], 0, nd);
-                        if (nd >= N) { sc[r] = NEG_INF; s0[r] = sim == SIM_SOFTMAX ? NEG_INF : 0.f; }
-                        mx0 = fmaxf(mx0, s0[r]);
+                        sc = mfma4(gm[r], xq[ot][r], sc);       // S_c[node][0]
+                        s0 = mfma4(xh[r], gq[ot][r], s0);       // S_c[0][node]
                     }
-                    s0t[nt] = s0;
-                    if (c < A && in_table(16 * nt + 4 * q, nt)) *reinterpret_cast<f32x4*>(&TA[c * TLD + 16 * nt + 4 * q]) = sc;
                 }
-                // p = softmax of the robot row, in the D layout: my lane holds nodes 16 nt + 4 q + r of child c
-                mx0 = kgroups_max(mx0);
-                float z0 = 0.f;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (sim == SIM_SOFTMAX) s0t[nt][r] = __expf(s0t[nt][r] - mx0);
-                        z0 += s0t[nt][r];
-                    }
-                const float iz0 = __builtin_amdgcn_rcpf(kgroups_sum(z0));
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s0t[nt][r] *= iz0;
-                    if (c < A && in_table(16 * nt + 4 * q, nt)) *reinterpret_cast<f32x4*>(&TP[c * TLD + 16 * nt + 4 * q]) = s0t[nt];
+                for (int r = 0; r < 4; ++r) {
+                    const int nd = 16 * nt + 4 * q + r;
+                    if (nd == 0) { sc[r] = s00; s0[r] = s00; }
+                    if (sim != SIM_SOFTMAX) s0[r] = plain_weight(sim, s0[r], 0, nd);
+                    if (nd >= N) { sc[r] = NEG_INF; s0[r] = sim == SIM_SOFTMAX ? NEG_INF : 0.f; }
+                    mx0 = fmaxf(mx0, s0[r]);
                 }
+                s0t[nt] = s0;
+                if (c < A && in_table(16 * nt + 4 * q, nt)) *reinterpret_cast<f32x4*>(&TA[c * TLD + 16 * nt + 4 * q]) = sc;
+            }
+            // p = softmax of the robot row, in the D layout: my lane holds nodes 16 nt + 4 q + r of child c
+            mx0 = kgroups_max(mx0);
+            float z0 = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (sim == SIM_SOFTMAX) s0t[nt][r] = __expf(s0t[nt][r] - mx0);
+                    z0 += s0t[nt][r];
+                }
+            const float iz0 = __builtin_amdgcn_rcpf(kgroups_sum(z0));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s0t[nt][r] *= iz0;
+                if (c < A && in_table(16 * nt + 4 * q, nt)) *reinterpret_cast<f32x4*>(&TP[c * TLD + 16 * nt + 4 * q]) = s0t[nt];
             }
         }
         PHASE_MARK(3);
