@@ -117,6 +117,19 @@ __device__ __forceinline__ float head_chain(const float* lds, const f32x4 (&tin)
 
 // HR >= N: human rows of UW held in registers (padded rows contribute exactly 0); SOFT: softmax row normalisation
 // HX: the value head's dense products as f16-split MFMAs (layer_mfma_h; MprlPlanner::contraction_dtype = RGL_CONTRACT_F16X3)
+// scale of the PK row pass (children_fused_kernel): its ReLU sits in the clamp bit of v_pk_fma_f32, which clamps to [0, 1]
+constexpr float kRowScale = 0x1p-110f, kRowUnscale = 0x1p110f;
+// clamp01(s.lo * u + y) on both halves, and s.hi * t + acc on both halves: the pair s = (r_i, b_i) is read in place by op_sel
+__device__ __forceinline__ f32x2 pk_fma_lo_clamp(f32x2 s, f32x2 u, f32x2 y) {
+    f32x2 t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp" : "=v"(t) : "v"(s), "v"(u), "v"(y));
+    return t;
+}
+__device__ __forceinline__ f32x2 pk_fma_hi(f32x2 s, f32x2 t, f32x2 acc) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(s), "v"(t));
+    return acc;
+}
+
 template <int HR, int NT, bool SKIP, bool SOFT, int D1, int D2, int D3, bool HX = false>
 __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const FusedArgs a) {
     const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
@@ -696,14 +709,14 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                         const float bb = s0t[nt][r] * __builtin_amdgcn_rcpf(fmaf(rr, zs[nt][r], 1.f));
                         // T1P: rows 1..15 are humans whatever N is (N > 16) and lie inside the table: no guards, no exec masks
                         const bool rh = T1P ? nd >= 1 : (nd >= 1 && nd < N);
-                        if (T1P || nd < HRL) *reinterpret_cast<f32x2*>(&AB[(n * SLDK + nd) * 2]) = f32x2{rh ? rr : 0.f, rh ? bb : 0.f};
+                        if (T1P || nd < HRL) *reinterpret_cast<f32x2*>(&AB[(n * SLDK + nd) * 2]) = f32x2{rh ? rr * kRowScale : 0.f, rh ? bb : 0.f};
                     }
                 if constexpr (T1P) {                             // node 16 + q (HRL == 20: rows 16..19 of the table)
                     const int nd = 16 + q;
                     const float rr = __expf(fminf(ms1 - sc1, 60.f));
                     const float bb = p1 * __builtin_amdgcn_rcpf(fmaf(rr, zs1, 1.f));
                     const bool rh = nd < N;
-                    *reinterpret_cast<f32x2*>(&AB[(n * SLDK + nd) * 2]) = f32x2{rh ? rr : 0.f, rh ? bb : 0.f};      // nd <= 19 < HRL = 20
+                    *reinterpret_cast<f32x2*>(&AB[(n * SLDK + nd) * 2]) = f32x2{rh ? rr * kRowScale : 0.f, rh ? bb : 0.f};      // nd <= 19 < HRL = 20
                 }
             } else {
 #pragma unroll
@@ -736,11 +749,15 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         if constexpr (PK) {
             // D layout throughout: lane (n, q) = child n, features 4q..4q+3 and 16+4q..: y and the result stay in registers, the
             // child's (r_i, b_i) come as broadcast b128 reads (two nodes each), UW_i as two broadcast b128 reads; per node and feature
-            // pair: v_pk_fma (r UW + y), two integer-max relus, v_pk_fma (acc += b relu) -- 4 instructions per 2 elements where
-            // the lane = feature form spends 8 (DPP broadcasts cannot feed packed operands).
+            // pair: v_pk_fma (r UW + y) with the ReLU in its clamp bit, v_pk_fma (acc += b relu) -- 2 instructions per 2 elements
+            // (round 3: 4, with two integer-max relus; the lane = feature form spends 8: DPP broadcasts cannot feed packed operands).
+            // The clamp is to [0, 1], so the pass runs on 2^-110 of its values: r (in the table) and y carry the factor, every
+            // product and sum is the exact 2^-110 multiple of the unscaled one -- power-of-two scalings commute with rounding -- as
+            // long as r UW + y stays below 2^110 = 1.3e33 (r <= e^60 = 1.1e26: UW up to 1e7) and terms below 2^-39 are not missed;
+            // the sum is scaled back once per tile.
             f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
-            const f32x2 y2[4] = {f32x2{yacc[0][0], yacc[0][1]}, f32x2{yacc[0][2], yacc[0][3]},
-                                 f32x2{yacc[1][0], yacc[1][1]}, f32x2{yacc[1][2], yacc[1][3]}};
+            const f32x2 y2[4] = {f32x2{yacc[0][0], yacc[0][1]} * kRowScale, f32x2{yacc[0][2], yacc[0][3]} * kRowScale,
+                                 f32x2{yacc[1][0], yacc[1][1]} * kRowScale, f32x2{yacc[1][2], yacc[1][3]} * kRowScale};
             const float* abrow = AB + n * SLDK * 2;
             // software pipeline by node pair: the loads of pair j + 1 are issued before the arithmetic of pair j; the register
             // fence after it keeps hipcc from stacking all 48 b128 loads (192 VGPRs) in front of the arithmetic
@@ -761,22 +778,19 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                 static_for<0, 2>([&](auto ec) {
                     constexpr int e = decltype(ec)::value, i = 2 * j2 + e;
                     if constexpr (i >= 1) {                                             // node 0 is the robot slot
-                        const f32x2 r2 = f32x2{ab[buf][2 * e], ab[buf][2 * e]}, b2 = f32x2{ab[buf][2 * e + 1], ab[buf][2 * e + 1]};
+                        const f32x2 rb = f32x2{ab[buf][2 * e], ab[buf][2 * e + 1]};       // (2^-110 r_i, b_i): one register pair
                         const f32x2 u2[4] = {f32x2{ua[buf][e][0], ua[buf][e][1]}, f32x2{ua[buf][e][2], ua[buf][e][3]},
                                              f32x2{ub[buf][e][0], ub[buf][e][1]}, f32x2{ub[buf][e][2], ub[buf][e][3]}};
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            f32x2 t = r2 * u2[k] + y2[k];
-                            t[0] = relu1(t[0]);
-                            t[1] = relu1(t[1]);
-                            acc[k] = b2 * t + acc[k];
+                            acc[k] = pk_fma_hi(rb, pk_fma_lo_clamp(rb, u2[k], y2[k]), acc[k]);
                         }
                     }
                 });
                 asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) :: "memory");
             });
-            tp4[0] = f32x4{acc[0][0], acc[0][1], acc[1][0], acc[1][1]};
-            tp4[1] = f32x4{acc[2][0], acc[2][1], acc[3][0], acc[3][1]};
+            tp4[0] = f32x4{acc[0][0], acc[0][1], acc[1][0], acc[1][1]} * kRowUnscale;
+            tp4[1] = f32x4{acc[2][0], acc[2][1], acc[3][0], acc[3][1]} * kRowUnscale;
         } else {
             const int hh = lane >> 5, f = lane & 31;
             constexpr int HRV = HR < 16 * NT ? HR : 16 * NT;      // the table holds 16*NT rows per child
