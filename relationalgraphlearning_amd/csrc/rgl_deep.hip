@@ -39,6 +39,10 @@ struct DeepArgs {
     int off_tp, off_ta, off_tb;                         // tables [A][TLD]: p, S_c[.][0] -> a, (E exchange) -> b
 };
 
+// The ReLUs of the per-child loop sit in the clamp bit of their FMAs (rgl_mfma.h): the row scalars a, b are held as 2^-64 a, 2^-64 b
+// in the tables (|a UW + b y| < 2^64 = 1.8e19 stays exact), layer 0 scales back in the FMA that adds the skip term, layer 1 once per
+// child after the p-weighted sum.
+constexpr float kAbScale = 0x1p-64f, kAbUnscale = 0x1p64f;
 constexpr int kDeepThreads = 512;
 constexpr int kDeepWaves = 8;
 
@@ -484,8 +488,8 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                     }
                     const float iz = __builtin_amdgcn_rcpf(fmaf(al, zs[r], be));
                     const bool row_h = nd >= 1 && nd < N;
-                    av[r] = row_h ? al * iz : (nd == 0 ? 1.f : 0.f);
-                    bv[r] = row_h ? be * iz : 0.f;
+                    av[r] = row_h ? al * iz * kAbScale : (nd == 0 ? kAbScale : 0.f);
+                    bv[r] = row_h ? be * iz * kAbScale : 0.f;
                 }
                 if (c < A) {
                     *reinterpret_cast<f32x4*>(&TA[c * TLD + 16 * nt + 4 * q]) = av;
@@ -562,10 +566,9 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
 #pragma unroll
                     for (int hp = 0; hp < 2; ++hp) {
                         const f32x2 y2{yv[fh][2 * hp], yv[fh][2 * hp + 1]}, u2{uw[2 * hp], uw[2 * hp + 1]};
-                        f32x2 v = __builtin_elementwise_fma(f32x2{aj, aj}, u2, f32x2{bj, bj} * y2);      // fma(a, uw, round(b y))
-                        v[0] = relu1(v[0]);
-                        v[1] = relu1(v[1]);
-                        if (SKIP) v += f32x2{xh[2 * hp], xh[2 * hp + 1]};
+                        f32x2 v = pk_fma_lo_clamp(f32x2{aj, bj}, u2, f32x2{bj, bj} * y2);      // 2^-64 relu(fma(a, uw, round(b y)))
+                        if (SKIP) v = __builtin_elementwise_fma(f32x2{kAbUnscale, kAbUnscale}, v, f32x2{xh[2 * hp], xh[2 * hp + 1]});
+                        else v *= kAbUnscale;
                         if (jt == 0 && n == 0) v = f32x2{h10v[fh][2 * hp], h10v[fh][2 * hp + 1]};
                         h1[jt][fh][2 * hp] = v[0];
                         h1[jt][fh][2 * hp + 1] = v[1];
@@ -687,9 +690,9 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
 #pragma unroll
                         for (int hp = 0; hp < 2; ++hp) {
                             const f32x2 a2{aq[2 * hp], aq[2 * hp + 1]}, b2{bq[2 * hp], bq[2 * hp + 1]}, p2{pq[2 * hp], pq[2 * hp + 1]};
-                            f32x2 v = __builtin_elementwise_fma(a2, f32x2{d[gt][2 * hp], d[gt][2 * hp + 1]}, b2 * f32x2{o0[gt], o0[gt]});
-                            v[0] = relu1(v[0]);
-                            v[1] = relu1(v[1]);
+                            // (a D2 rounded first, then the FMA with b O_0: the inline-assembly FMA must not read the MFMA's result
+                            // itself -- see pk_fma_clamp)
+                            const f32x2 v = pk_fma_clamp(b2, f32x2{o0[gt], o0[gt]}, a2 * f32x2{d[gt][2 * hp], d[gt][2 * hp + 1]});
                             tacc2[gt] = __builtin_elementwise_fma(p2, v, tacc2[gt]);
                             if (it == 0 && hp == 0) hrow0[gt] = v[0];
                         }
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
 #pragma unroll
                         for (int gt = 0; gt < 2; ++gt) {
                             const float x = kgroups_reduce_scatter(d4[gt][0] + d4[gt][1]);
-                            const float v = relu1(fmaf(a1, x, b1 * o0[gt]));
+                            const float v = fma_clamp(a1, x, b1 * o0[gt]);
                             tacc[gt] = fmaf(p1, v, tacc[gt]);
                         }
                         continue;
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
                     for (int gt = 0; gt < 2; ++gt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float v = relu1(fmaf(aq[r], d[gt][r], bq[r] * o0[gt]));
+                            const float v = fma_clamp(aq[r], d[gt][r], bq[r] * o0[gt]);
                             tacc[gt] = fmaf(pq[r], v, tacc[gt]);
                             if (it == 0 && r == 0) hrow0[gt] = v;
                         }
@@ -751,8 +754,8 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
 #pragma unroll
             for (int gt = 0; gt < 2; ++gt) {
                 const int g = 16 * gt + n;
-                float t = kgroups_sum(tacc[gt]);
-                float hp = hrow0[gt];                       // valid in the q == 0 lanes (row i = 0)
+                float t = kgroups_sum(tacc[gt]) * kAbUnscale;       // the layer-1 ReLUs ran on 2^-64 of their values
+                float hp = hrow0[gt] * kAbUnscale;          // valid in the q == 0 lanes (row i = 0)
                 if (SKIP) {
                     t += scr[g];
                     hp += H10[c * XLD + g];

@@ -115,21 +115,11 @@ __device__ __forceinline__ float head_chain(const float* lds, const f32x4 (&tin)
     return kgroups_sum(v);
 }
 
+// scale of the PK row pass (children_fused_kernel): its ReLU sits in the clamp bit of v_pk_fma_f32 (rgl_mfma.h), which clamps to [0, 1]
+constexpr float kRowScale = 0x1p-110f, kRowUnscale = 0x1p110f;
+
 // HR >= N: human rows of UW held in registers (padded rows contribute exactly 0); SOFT: softmax row normalisation
 // HX: the value head's dense products as f16-split MFMAs (layer_mfma_h; MprlPlanner::contraction_dtype = RGL_CONTRACT_F16X3)
-// scale of the PK row pass (children_fused_kernel): its ReLU sits in the clamp bit of v_pk_fma_f32, which clamps to [0, 1]
-constexpr float kRowScale = 0x1p-110f, kRowUnscale = 0x1p110f;
-// clamp01(s.lo * u + y) on both halves, and s.hi * t + acc on both halves: the pair s = (r_i, b_i) is read in place by op_sel
-__device__ __forceinline__ f32x2 pk_fma_lo_clamp(f32x2 s, f32x2 u, f32x2 y) {
-    f32x2 t;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp" : "=v"(t) : "v"(s), "v"(u), "v"(y));
-    return t;
-}
-__device__ __forceinline__ f32x2 pk_fma_hi(f32x2 s, f32x2 t, f32x2 acc) {
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(s), "v"(t));
-    return acc;
-}
-
 template <int HR, int NT, bool SKIP, bool SOFT, int D1, int D2, int D3, bool HX = false>
 __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const FusedArgs a) {
     const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;

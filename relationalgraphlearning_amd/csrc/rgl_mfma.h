@@ -205,4 +205,32 @@ inline bool rank1_enabled() {
     return !off;
 }
 
+// ReLU in the clamp bit of a packed FMA.  VOP3P has no packed f32 max, but every packed op can clamp its result to [0, 1] (DX10
+// clamp mode: NaN -> 0): on operands scaled by a power of two 2^-k the clamp IS the ReLU -- clamp01(2^-k x) = 2^-k relu(x) for
+// x < 2^k, and power-of-two scalings commute with the rounding of every product and sum (no overflow, and what underflows is
+// below 2^(k-149) in unscaled terms) -- so the scaled pass computes exactly 2^-k times the unscaled values and is scaled back
+// where the next exact operation happens anyway.
+// RULE for the inline-assembly forms: no operand may be the result register of an MFMA.  hipcc's hazard recognizer pads the wait
+// states between an MFMA's write and a VALU read of it only for instructions it can see; an operand of an asm statement it
+// cannot (measured: children_deep_kernel<NT = 1, f16> read its E O accumulators three instructions after the MFMA and was 2e-2
+// off).  Results of compiler-visible VALU instructions, LDS loads (their s_waitcnt is inserted for asm operands too) and other asm
+// outputs are fine.
+// clamp01(s.lo * u + y) on both halves, and s.hi * t + acc on both halves: a pair s = (r, b) is read in place by op_sel
+__device__ __forceinline__ f32x2 pk_fma_lo_clamp(f32x2 s, f32x2 u, f32x2 y) {
+    f32x2 t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp" : "=v"(t) : "v"(s), "v"(u), "v"(y));
+    return t;
+}
+__device__ __forceinline__ f32x2 pk_fma_hi(f32x2 s, f32x2 t, f32x2 acc) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(s), "v"(t));
+    return acc;
+}
+// clamp01(a * b + c), element-wise
+__device__ __forceinline__ f32x2 pk_fma_clamp(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(t) : "v"(a), "v"(b), "v"(c));
+    return t;
+}
+__device__ __forceinline__ float fma_clamp(float a, float b, float c) { return __builtin_amdgcn_fmed3f(fmaf(a, b, c), 0.f, 1.f); }
+
 }  // namespace
