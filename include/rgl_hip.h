@@ -270,7 +270,10 @@ typedef struct MprlPlanner {
 } MprlPlanner;
 
 /* Bytes of the weight image above; 0 when the configuration has no image-based children kernel (the searches then ignore
- * `children_image`).  Depends on the architecture only (not on the weights, P, A or H <= 31). */
+ * `children_image`).  Depends on the architecture only (not on the weights, P, A or H).  Round 4: also offered for three-layer
+ * graphs and crowds beyond 32 agents with the shipped embedding / head shapes (f32 layout, not in RGL_CONTRACT_F16X3): there the
+ * image feeds the stage-2 head, which with an image at hand runs inside the stage-1 launch (children_deep_kernel) instead of in
+ * a launch of its own. */
 size_t mprl_children_image_bytes(const MprlPlanner* planner);
 /* Builds the image from the planner's current value_graph / value_head weights on `stream` (planner->children_image is not
  * read).  RGL_ERR_BAD_MODE when mprl_children_image_bytes() is 0, RGL_ERR_WORKSPACE when `image_bytes` is too small. */

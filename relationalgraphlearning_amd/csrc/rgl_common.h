@@ -70,7 +70,9 @@ int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, cons
 int launch_rank1_children(const RglGraph* g, int P, int A, int H, const float* child_robot, const float* humans_next,
                           float* rows_out, hipStream_t stream, const float* image = nullptr);                       // rgl_rank1.hip
 int launch_deep_children(const RglGraph* g, int P, int A, int H, const float* child_robot, const float* humans_next,
-                         float* rows_out, int f16, hipStream_t stream);                                             // rgl_deep.hip
+                         float* rows_out, int f16, hipStream_t stream, const RglMlp* head = nullptr, float* value = nullptr,
+                         const float* image = nullptr, const void* tail = nullptr, size_t tail_bytes = 0, int* tail_done = nullptr,
+                         int* head_done = nullptr);                                                                 // rgl_deep.hip
 int launch_tile_children(const RglGraph* g, int P, int A, int H, const float* child_robot, const float* humans_next,
                          float* rows_out, hipStream_t stream);                                                      // rgl_tile.hip
 // `tail` (a TailArgs, opaque) with A = rows per parent: the head kernel's workgroups own whole parents and run the search's select /

@@ -20,7 +20,7 @@
 //
 // Follows (reference paths): crowd_nav/policy/graph_model.py:99-130, value_estimator.py:11-20,
 // model_predictive_rl.py:245-250.
-#include "rgl_mfma.h"
+#include "rgl_head_body.h"
 
 namespace {
 
@@ -37,6 +37,9 @@ struct DeepArgs {
     int off_xh, off_uw, off_gm, off_msh, off_zsh;       // crowd block
     int off_x0, off_y0, off_g0, off_s00;                // per-child rows; g0 is re-used for H1_0
     int off_tp, off_ta, off_tb;                         // tables [A][TLD]: p, S_c[.][0] -> a, (E exchange) -> b
+    // round 4: stage 2 in the same launch.  Workgroup b owns the parents [b k, (b + 1) k) and, once their rows are written, runs the
+    // value head over them (and the search's tail steps) where robot_head_kernel would in a launch of its own: head_rows_and_tail
+    int fuse_head, parents_per_wg;
 };
 
 // The ReLUs of the per-child loop sit in the clamp bit of their FMAs (rgl_mfma.h): the row scalars a, b are held as 2^-64 a, 2^-64 b
@@ -80,7 +83,7 @@ __device__ __forceinline__ f16x8 pack8(f32x4 lo, f32x4 hi) {
 }
 
 template <int NT, bool F16, bool SKIP, bool SOFT, bool T4 = false>
-__global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const DeepArgs a) {
+__global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const DeepArgs a, const HeadArgs ha) {
     const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int KT = (NT + 1) / 2;          // f16: k tiles of 32 nodes
@@ -180,7 +183,10 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
     const int n_child_waves = kDeepWaves - NT;
 
     PHASE_START();
-    for (int p = blockIdx.x; p < a.P; p += gridDim.x) {
+    const int p_first = a.fuse_head ? blockIdx.x * a.parents_per_wg : blockIdx.x;
+    const int p_end = a.fuse_head ? (p_first + a.parents_per_wg < a.P ? p_first + a.parents_per_wg : a.P) : a.P;
+    const int p_step = a.fuse_head ? 1 : gridDim.x;
+    for (int p = p_first; p < p_end; p += p_step) {
         PHASE_MARK(0);
         // =========================== phase A: crowd embedding  ||  child embedding ===========================
         f32x4 pg[2] = {zero4(), zero4()};          // crowd waves: G^T of my column tile, carried into phase B
@@ -770,7 +776,17 @@ __global__ __launch_bounds__(kDeepThreads, 2) void children_deep_kernel(const De
         __syncthreads();
     }
     PHASE_FLUSH();
+    if (a.fuse_head) {
+        // stage 2 over the rows this workgroup has just written (behind the loop's closing barrier: every table above is dead, the
+        // head's 73 KB of fragments take their place).  One launch and one weight image per level less than the two-stage form;
+        // workgroups that finish their parents early run their heads under the others' children.
+        head_load_image<32, 100, 100>(lds, ha, tid);
+        __syncthreads();
+        head_rows_and_tail<32, 100, 100>(lds, ha, blockIdx.x, gridDim.x);
+    }
 }
+
+inline int deep_workgroups_per_cu(size_t lds_bytes) { return lds_bytes * 2 <= (size_t)rgl::kLdsBytesPerCu ? 2 : 1; }
 
 struct DeepPlan {
     DeepArgs a;
@@ -823,30 +839,31 @@ inline DeepPlan plan_deep(const RglGraph& g, int P, int A, int H) {
 }
 
 template <int NT, bool F16, bool SKIP, bool SOFT, bool T4 = false>
-int launch_deep_t(const DeepPlan& pl, hipStream_t st) {
+int launch_deep_t(const DeepPlan& pl, const HeadArgs& ha, hipStream_t st) {
     if constexpr (!T4 && !F16 && SOFT && NT >= 2) {
-        if (pl.t4) return launch_deep_t<NT, F16, SKIP, SOFT, true>(pl, st);      // plan_deep: eligible and its tables fit (RGL_DEEP_T4=0: never)
+        if (pl.t4) return launch_deep_t<NT, F16, SKIP, SOFT, true>(pl, ha, st);      // plan_deep: eligible and its tables fit (RGL_DEEP_T4=0: never)
     }
     auto kern = children_deep_kernel<NT, F16, SKIP, SOFT, T4>;
     if (pl.lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)pl.lds_bytes));
-    const int per_cu = pl.lds_bytes * 2 <= (size_t)rgl::kLdsBytesPerCu ? 2 : 1;
-    const int grid = pl.a.P < 256 * per_cu ? pl.a.P : 256 * per_cu;       // persistent workgroups
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kDeepThreads), pl.lds_bytes, st, pl.a);
+    const int per_cu = deep_workgroups_per_cu(pl.lds_bytes);
+    int grid = pl.a.P < 256 * per_cu ? pl.a.P : 256 * per_cu;             // persistent workgroups
+    if (pl.a.fuse_head) grid = (pl.a.P + pl.a.parents_per_wg - 1) / pl.a.parents_per_wg;      // contiguous parents per workgroup
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kDeepThreads), pl.lds_bytes, st, pl.a, ha);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }
 
 template <int NT>
-int launch_deep_nt(const DeepPlan& pl, bool f16, bool skip, hipStream_t st) {
+int launch_deep_nt(const DeepPlan& pl, const HeadArgs& ha, bool f16, bool skip, hipStream_t st) {
     const bool soft = pl.a.sim == SIM_SOFTMAX;
     if (f16) {
         if (!soft) return 1;                      // f16 contractions are built for the softmax similarities only
-        return skip ? launch_deep_t<NT, true, true, true>(pl, st) : launch_deep_t<NT, true, false, true>(pl, st);
+        return skip ? launch_deep_t<NT, true, true, true>(pl, ha, st) : launch_deep_t<NT, true, false, true>(pl, ha, st);
     }
-    if (soft) return skip ? launch_deep_t<NT, false, true, true>(pl, st) : launch_deep_t<NT, false, false, true>(pl, st);
-    return skip ? launch_deep_t<NT, false, true, false>(pl, st) : launch_deep_t<NT, false, false, false>(pl, st);
+    if (soft) return skip ? launch_deep_t<NT, false, true, true>(pl, ha, st) : launch_deep_t<NT, false, false, true>(pl, ha, st);
+    return skip ? launch_deep_t<NT, false, true, false>(pl, ha, st) : launch_deep_t<NT, false, false, false>(pl, ha, st);
 }
 
 }  // namespace
@@ -867,19 +884,44 @@ namespace rgl {
 
 // Returns RGL_OK after launching, a negative / hip error code on failure, or 1 when the request is outside this
 // kernel's envelope (the caller then picks another kernel).
+// `head` .. `head_done` (optional): with the shipped value head and its packed image at hand the kernel also runs stage 2 -- and the
+// search's tail steps, `tail` / `tail_done` as in launch_head_rows -- over the rows of the parents each workgroup owns; *head_done = 1
+// then, and `value` holds the children's values (RGL_DEEP_FUSE_HEAD=0: never, the caller launches robot_head_kernel as before).
 int launch_deep_children(const RglGraph* g, int P, int A, int H, const float* child_robot, const float* humans_next,
-                         float* rows_out, int f16, hipStream_t stream) {
+                         float* rows_out, int f16, hipStream_t stream, const RglMlp* head, float* value, const float* image,
+                         const void* tail, size_t tail_bytes, int* tail_done, int* head_done) {
+    if (head_done) *head_done = 0;
     DeepPlan pl = plan_deep(*g, P, A, H);
     if (!pl.ok) return 1;
     pl.a.child_robot = child_robot;
     pl.a.humans = humans_next;
     pl.a.rows_out = rows_out;
+    pl.a.fuse_head = 0;
+    pl.a.parents_per_wg = 1;
+    HeadArgs ha{};
+    static const bool fuse_off = [] { const char* e = getenv("RGL_DEEP_FUSE_HEAD"); return e && e[0] == '0'; }();
+    const size_t head_lds = (size_t)HeadLds<32, 100, 100>::total * sizeof(float);
+    if (head && head_done && value && image && !fuse_off && head_variant(*head) == 0) {
+        const size_t lds = pl.lds_bytes > head_lds ? pl.lds_bytes : head_lds;
+        int chain = 0;
+        head_args_for(g, head, 0, rows_out, P * A, value, image, tail, tail_bytes, A, 256 * deep_workgroups_per_cu(lds), &ha, &chain);
+        if (!ha.tail.enabled) {                   // stand-alone call: no tail, the same ownership of rows
+            const int slots = 256 * deep_workgroups_per_cu(lds);
+            ha.parents_per_wg = (P + slots - 1) / slots;
+            ha.own_rows = 1;
+        }
+        pl.lds_bytes = lds;
+        pl.a.fuse_head = 1;
+        pl.a.parents_per_wg = ha.parents_per_wg;
+        if (tail_done) *tail_done = ha.tail.enabled ? (chain ? 2 : 1) : 0;
+        *head_done = 1;
+    }
     const bool skip = g->skip_connection != 0;
     switch (pl.NT) {
-        case 1: return launch_deep_nt<1>(pl, f16 != 0, skip, stream);
-        case 2: return launch_deep_nt<2>(pl, f16 != 0, skip, stream);
-        case 3: return launch_deep_nt<3>(pl, f16 != 0, skip, stream);
-        default: return launch_deep_nt<4>(pl, f16 != 0, skip, stream);
+        case 1: return launch_deep_nt<1>(pl, ha, f16 != 0, skip, stream);
+        case 2: return launch_deep_nt<2>(pl, ha, f16 != 0, skip, stream);
+        case 3: return launch_deep_nt<3>(pl, ha, f16 != 0, skip, stream);
+        default: return launch_deep_nt<4>(pl, ha, f16 != 0, skip, stream);
     }
 }
 

@@ -60,8 +60,12 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
         float* rows = (float*)workspace;
         if (!want_f16) rc = launch_rank1_children(g, P, A, H, child_robot, humans_next, rows, stream, image);
         if (rc == 1) {
-            rc = launch_deep_children(g, P, A, H, child_robot, humans_next, rows, want_f16 && g->num_layer == 3, stream);
+            int head_done = 0;
+            rc = launch_deep_children(g, P, A, H, child_robot, humans_next, rows, want_f16 && g->num_layer == 3, stream,
+                                      &pl->value_head, child_value, image, tail, tail_bytes, tail_done, &head_done);
             if (want_f16 && (rc == 1 || g->num_layer != 3)) return RGL_ERR_BAD_MODE;
+            if (rc != 1 && head_done) return rc;           // stage 2 (and the tail) ran inside the launch
+            if (rc == 1 && tail_done) *tail_done = 0;
         }
         if (rc == 1) rc = launch_tile_children(g, P, A, H, child_robot, humans_next, rows, stream);
         if (rc == 1 && !want_f16) {

@@ -1329,17 +1329,38 @@ int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, i
 
 // The image depends on the weights (and on the contraction mode: f16-split head fragments for RGL_CONTRACT_F16X3) only: a caller
 // with fixed weights packs it once (MprlPlanner::children_image).
+// Outside the fused kernel's envelope (three layers, crowds beyond 32 agents) the image still serves the stage-2 head -- launched
+// on its own or run by children_deep_kernel behind its parents -- as long as the shipped head and embedding shapes are there: the
+// same f32 layout, `w_last` = the graph's last layer.
+static bool head_image_args(const RglGraph& g, const RglMlp& head, FusedArgs& a) {
+    if (!fast_path_enabled() || g.x_dim != XD || g.num_layer < 2 || g.num_layer > RGL_MAX_GCN_LAYERS) return false;
+    if (!mlp_is(g.w_r, 9, HID, XD, true) || !mlp_is(g.w_h, 5, HID, XD, true) || head_variant(head) != 0) return false;
+    a = FusedArgs{};
+    a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];
+    a.wa = bilinear_wa(g); a.w1 = g.Ws[0];
+    a.w_last = g.Ws[g.num_layer - 1];
+    a.hw1 = head.weight[0]; a.hb1 = head.bias[0]; a.hw2 = head.weight[1]; a.hb2 = head.bias[1];
+    a.hw3 = head.weight[2]; a.hb3 = head.bias[2]; a.hw4 = head.weight[3]; a.hb4 = head.bias[3];
+    a.wh1 = g.w_h.weight[0]; a.bh1 = g.w_h.bias[0]; a.wh2 = g.w_h.weight[1]; a.bh2 = g.w_h.bias[1];
+    return true;
+}
+
 extern "C" size_t mprl_children_image_bytes(const MprlPlanner* planner) {
     if (!planner) return 0;
     const bool hx = planner->contraction_dtype == RGL_CONTRACT_F16X3;
-    return plan_fused(planner->value_graph, planner->value_head, 4096, 16, 1, 1, hx).ok ? kImageBytes : 0;      // architecture test only
+    if (plan_fused(planner->value_graph, planner->value_head, 4096, 16, 1, 1, hx).ok) return kImageBytes;      // architecture test only
+    FusedArgs a;
+    return (!hx && head_image_args(planner->value_graph, planner->value_head, a)) ? kImageBytes : 0;
 }
 
 extern "C" int mprl_pack_children_image_f32(const MprlPlanner* planner, float* image, size_t image_bytes, rgl_stream_t stream) {
     if (!planner || !image) return RGL_ERR_NULL;
     const bool hx = planner->contraction_dtype == RGL_CONTRACT_F16X3;
     FusedPlan fp = plan_fused(planner->value_graph, planner->value_head, 4096, 16, 1, 1, hx);
-    if (!fp.ok) return RGL_ERR_BAD_MODE;
+    if (!fp.ok) {
+        if (hx || !head_image_args(planner->value_graph, planner->value_head, fp.a)) return RGL_ERR_BAD_MODE;
+        fp.hx = false;
+    }
     if (image_bytes < kImageBytes) return RGL_ERR_WORKSPACE;
     return launch_pack_image(fp.a, image, fp.hx, (hipStream_t)stream);
 }

@@ -1269,12 +1269,56 @@ print("OK worst %.2e" % worst)
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lines = []
-    for sw in ("1", "0"):
-        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RGL_DEEP_T4=sw, RGL_REQUIRE_MFMA_CHILDREN="1"),
+    for sw, fuse in (("1", "1"), ("0", "1"), ("1", "0")):
+        out = subprocess.run([sys.executable, "-c", code], cwd=root,
+                             env=dict(os.environ, RGL_DEEP_T4=sw, RGL_DEEP_FUSE_HEAD=fuse, RGL_REQUIRE_MFMA_CHILDREN="1"),
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
-        lines.append("RGL_DEEP_T4=%s %s" % (sw, out.stdout.strip().splitlines()[-1]))
-    report("deep kernel, last node tile on the 4x4x1 MFMA vs the 16-row form, N = 17..54, L = 3: " + "; ".join(lines))
+        lines.append("RGL_DEEP_T4=%s RGL_DEEP_FUSE_HEAD=%s %s" % (sw, fuse, out.stdout.strip().splitlines()[-1]))
+    report("deep kernel, last node tile on the 4x4x1 MFMA vs the 16-row form, stage 2 inside the launch vs robot_head_kernel, "
+           "N = 17..54, L = 3: " + "; ".join(lines))
+
+
+def test_deep_kernel_searches_with_stage_two_inside_and_outside_the_launch(dev):
+    """Round 4: with the packed weight image at hand children_deep_kernel runs the value head -- and the search's select / back-up /
+    root steps -- over the rows of the parents each workgroup owns, behind its last parent (RGL_DEEP_FUSE_HEAD=0: robot_head_kernel
+    in a launch of its own, as before).  Whole searches over the configurations the deep kernel serves (three layers; two layers
+    beyond 32 agents; depth 1..3; f32 and f16 contraction) against the batched oracle, both ways, in child processes."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+from oracle import rgl_oracle as orc
+from tests import golden_io as gio
+from tests.helpers import make_mprl_policy
+from tests.test_gpu_parity import seeded_scenes
+dev = torch.device("cuda:0")
+worst = {"f32": 0.0, "f16": 0.0}
+for H, L, D, B, dt in ((49, 3, 2, 12, "f32"), (49, 3, 2, 12, "f16"), (19, 3, 3, 9, "f32"), (40, 2, 2, 7, "f32"), (5, 3, 1, 33, "f32"),
+                       (33, 3, 2, 300, "f32"), (49, 3, 1, 700, "f16")):
+    pol = make_mprl_policy("trained", D, 2, D > 1, L=L, device=dev)
+    pol.contraction_dtype = dt
+    robot, humans = seeded_scenes(1700 + H + D, B, H)
+    cfg = orc.OracleConfig(num_layer=L, planning_depth=D, planning_width=2, do_action_clip=D > 1)
+    Pm = gio.oracle_params("trained", L)
+    with torch.no_grad():
+        oa, ov, orv, okept = orc.mprl_predict_batched(robot, humans, Pm, cfg)
+    act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
+    err = float((val.cpu() - ov).abs().max())
+    same = float((act.cpu().long() == oa).float().mean())
+    tol = 1e-3 if dt == "f16" else 1e-4
+    assert err < tol and (same == 1.0 or err < 1e-5), (H, L, D, B, dt, err, same)
+    worst[dt] = max(worst[dt], err)
+print("OK max |dV| f32 %.2e, f16 %.2e" % (worst["f32"], worst["f16"]))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = []
+    for fuse in ("1", "0"):
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RGL_DEEP_FUSE_HEAD=fuse, RGL_REQUIRE_MFMA_CHILDREN="1"),
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+        lines.append("RGL_DEEP_FUSE_HEAD=%s %s" % (fuse, out.stdout.strip().splitlines()[-1]))
+    report("searches on the deep kernel, stage 2 + tail inside the launch vs robot_head_kernel: " + "; ".join(lines))
 
 
 def test_f16_tree_search_and_refusals(dev):
@@ -1600,6 +1644,44 @@ def test_f16x3_children_over_odd_shapes_and_sharp_attention(dev):
         assert err < 1e-4, (scale, H, P, err)
     report("f16x3 children over odd shapes / raw random weights: worst relative error %.2e; sharp attention (similarities in the "
            "hundreds) vs float64: %.2e" % (worst, sharp))
+
+
+def test_clamp_bit_relu_over_sharp_attention_and_large_activations(dev):
+    """Round 4: the ReLUs of the row passes sit in the clamp bit of packed FMAs on power-of-two-scaled operands (fused kernel: 2^-110,
+    the softmax ratio r = e^(msh - S_c) reaches e^60 there; deep kernel: 2^-64).  Exact while r UW + y < 2^110 (a UW + b y < 2^64): so
+    the cases that stretch the range -- similarities in the hundreds (w_a scaled), graph weights scaled until the hidden features
+    reach 10^3..10^4, both together -- against the float64 oracle, f32 fused kernel (L = 2), deep kernel (L = 3, f32 and f16
+    contraction)."""
+    import copy
+    worst = {}
+    for L, H, P, wa_scale, w_scale, dt in ((2, 19, 40, 25.0, 1.0, "f32"), (2, 9, 33, -40.0, 1.0, "f32"), (2, 5, 17, 300.0, 1.0, "f32"),
+                                           (2, 19, 21, 300.0, 1e3, "f32"), (2, 19, 21, 1.0, 1e4, "f32"), (2, 16, 9, -300.0, 30.0, "f32"),
+                                           (3, 49, 3, 25.0, 1.0, "f32"), (3, 49, 3, 300.0, 100.0, "f32"), (3, 49, 3, 25.0, 1.0, "f16"),
+                                           (3, 19, 5, 300.0, 100.0, "f32"), (3, 5, 5, 40.0, 10.0, "f16")):
+        ck = copy.deepcopy(gio.checkpoint("trained", L))
+        ck["graph_model1"]["w_a"] = ck["graph_model1"]["w_a"] * wa_scale
+        ck["graph_model1"]["Ws.0"] = ck["graph_model1"]["Ws.0"] * w_scale
+        pol = make_mprl_policy("trained", 1, L=L, device=dev)
+        pol.load_state_dict(ck)
+        pol.contraction_dtype = dt
+        pol.build_action_space(1.0)
+        ts = pol.tree_search()
+        A = ts.num_actions
+        robot, humans = seeded_scenes(960 + H, P, H)
+        acts, _ = orc.mprl_action_space(orc.OracleConfig(), 1.0)
+        cr = orc._children_robot(robot, acts, orc.OracleConfig())
+        got = ts.value_children(cr.to(dev), humans.to(dev)).double().cpu().numpy()
+        P64 = orc.MprlParams.from_checkpoint({k: {kk: vv.double() for kk, vv in v.items()} for k, v in ck.items()})
+        with torch.no_grad():
+            want = orc.value_estimator_forward(cr.double().reshape(P * A, 1, 9),
+                                               humans.double()[:, None].expand(P, A, H, 5).reshape(P * A, H, 5),
+                                               P64.ve_graph, P64.value_network, orc.OracleConfig(num_layer=L)).numpy().reshape(P, A)
+        assert np.isfinite(got).all(), (L, H, wa_scale, w_scale, dt)
+        err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
+        worst[dt] = max(worst.get(dt, 0.0), err)
+        assert err < (F16_TOL if dt == "f16" else 1e-4), (L, H, P, wa_scale, w_scale, dt, err)
+    report("clamp-bit ReLU at the edges of its range (sharp attention, hidden features to 1e4) vs float64: worst relative error "
+           + ", ".join("%s %.2e" % kv for kv in sorted(worst.items())))
 
 
 _ORACLE_AT_SIZE = {}
