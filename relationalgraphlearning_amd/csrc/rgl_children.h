@@ -36,7 +36,7 @@ __device__ __forceinline__ double seg_point_dist_origin(double px, double py, do
 
 // One (parent, action) pair: next robot state + estimate_reward.  `near_mask`: bit h clear = human h provably cannot influence
 // any child of this parent (children_wave), skipped outright.
-__device__ __forceinline__ void children_pa(const ChildrenArgs& ca, int p, int a, unsigned int near_mask = ~0u) {
+__device__ __forceinline__ void children_pa(const ChildrenArgs& ca, int p, int a, unsigned long long near_mask = ~0ull) {
     const long long idx = (long long)p * ca.A + a;
     const float* __restrict__ robot = ca.robot;
     const float* __restrict__ humans = ca.humans;
@@ -90,7 +90,7 @@ __device__ __forceinline__ void children_pa(const ChildrenArgs& ca, int p, int a
     double dmin = INFINITY;
     const float favx = (float)avx, favy = (float)avy, fdt = (float)dt;
     for (int h = 0; h < H; ++h) {
-        if (h < 32 && !((near_mask >> h) & 1u)) continue;
+        if (h < 64 && !((near_mask >> h) & 1ull)) continue;
         const float* hu = hs + h * 5;
         {
             // fp32 pre-test of the exact shortcut below: with T = radii + 0.25, |p|^2 >= 2 (|e - p|^2 + T^2) proves that this
@@ -152,27 +152,34 @@ __device__ __forceinline__ void children_thread(const ChildrenArgs& ca, long lon
 // children of the parent -- the per-child pre-test of children_pa would pass for each of them.  Lanes 0..31 evaluate that test
 // for the humans of pA, lanes 32..63 for pA + 1 (fp32, 1 % margin; the per-child test it implies keeps 0.1 %), one ballot makes the
 // two masks, and every pair skips its parent's far humans outright instead of pre-testing them one by one: same results,
-// H pre-tests per parent instead of per child.  (H <= 32; float64 roots and larger crowds take children_thread.)
+// H pre-tests per parent instead of per child.  Crowds of 33..64 humans (round 4: BASELINE configs[4], 49 humans, spent 6 us per
+// level on per-child pre-tests) take one ballot per parent, every lane a human.  (Float64 roots and larger crowds: children_thread.)
 __device__ __forceinline__ void children_wave(const ChildrenArgs& ca, long long idx0, long long total, float v_max) {
     const int lane = threadIdx.x & 63;
     const int A = ca.A, H = ca.H;
     const int pA = (int)(idx0 / A);
-    const int half = lane >> 5, h = lane & 31;
-    const int pm = pA + half;                                        // the parent whose human h this lane examines
-    bool near = false;
-    if (h < H && pm < ca.P) {
+    auto near_of = [&](int pm, int h) {
+        if (h >= H || pm >= ca.P) return false;
         const float* r = ca.robot + (size_t)pm * 9;
         const float* hu = ca.humans + ((size_t)(pm / ca.humans_per) * H + h) * 5;
         const float qx = hu[0] - r[0], qy = hu[1] - r[1];
         const float sm = (sqrtf(hu[2] * hu[2] + hu[3] * hu[3]) + v_max) * (float)ca.dt;
         const float Tf = hu[4] + r[4] + 0.25f;
-        near = !(qx * qx + qy * qy >= 2.02f * (sm * sm + Tf * Tf));
+        return !(qx * qx + qy * qy >= 2.02f * (sm * sm + Tf * Tf));
+    };
+    unsigned long long mask_a, mask_b;
+    if (H <= 32) {
+        const unsigned long long bal = __ballot(near_of(pA + (lane >> 5), lane & 31));      // lanes 0..31: pA, lanes 32..63: pA + 1
+        mask_a = bal & 0xffffffffull;
+        mask_b = bal >> 32;
+    } else {
+        mask_a = __ballot(near_of(pA, lane));
+        mask_b = __ballot(near_of(pA + 1, lane));
     }
-    const unsigned long long bal = __ballot(near);
     const long long idx = idx0 + lane;
     if (idx < total) {
         const int p = (int)(idx / A);
-        children_pa(ca, p, (int)(idx - (long long)p * A), p == pA ? (unsigned int)bal : (unsigned int)(bal >> 32));
+        children_pa(ca, p, (int)(idx - (long long)p * A), p == pA ? mask_a : mask_b);
     }
 }
 

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kThreads, 2) void row_mlp2_pair_kernel(const RowMlp
     if ((int)blockIdx.x >= grid_mlp) {
         const long long total = (long long)ca.P * ca.A, stride = (long long)(gridDim.x - grid_mlp) * kThreads;
         const long long first_pair = (long long)(blockIdx.x - grid_mlp) * kThreads + threadIdx.x;
-        if (ca.A >= 64 && ca.H <= 32 && !ca.robot64) {
+        if (ca.A >= 64 && ca.H <= 64 && !ca.robot64) {
             const float v_max = table_speed_bound(ca);
             for (long long base = first_pair & ~63LL; base < total; base += stride) children_wave(ca, base, total, v_max);
         } else {
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
         if ((int)blockIdx.x >= grid_scene) {
             const long long total = (long long)ca.P * ca.A, stride = (long long)(gridDim.x - grid_scene) * kSceneThreads;
             const long long first = (long long)(blockIdx.x - grid_scene) * kSceneThreads + threadIdx.x;
-            if (ca.A >= 64 && ca.H <= 32 && !ca.robot64) {       // whole waves: far-human masks per parent (children_wave)
+            if (ca.A >= 64 && ca.H <= 64 && !ca.robot64) {       // whole waves: far-human masks per parent (children_wave)
                 const float v_max = table_speed_bound(ca);
                 for (long long base = first & ~63LL; base < total; base += stride) children_wave(ca, base, total, v_max);
             } else {

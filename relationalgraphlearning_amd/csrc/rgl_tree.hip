@@ -20,7 +20,7 @@ constexpr int kBlock = 256;
 __global__ void mprl_children_kernel(const ChildrenArgs ca) {
     const long long total = (long long)ca.P * ca.A;
     const long long idx0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) & ~63LL;      // my wave's first pair
-    if (ca.A >= 64 && ca.H <= 32 && !ca.robot64) {
+    if (ca.A >= 64 && ca.H <= 64 && !ca.robot64) {
         if (idx0 < total) children_wave(ca, idx0, total, table_speed_bound(ca));
     } else {
         const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
