@@ -883,7 +883,12 @@ static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* r
         sa.off_eh = take(kRowMlpSetFloats);
     }
     sa.wave_stride = 16 * NT * XLD;
-    sa.off_wave = take((NT <= 2 ? 8 : (NT <= 4 ? 4 : 1)) * sa.wave_stride);
+    // scene slots of a workgroup: one per wave, or -- the split form, which launch_scene always takes with the embeddings inside --
+    // one per NT waves of its 8 (with the unsplit count a 50-agent scene workgroup held 95 KB instead of 76: one per CU, and the
+    // launch's reward workgroups, which reserve the same LDS, waited for a scene workgroup to retire)
+    static const bool wide_slots = [] { const char* e = getenv("RGL_SCENE_WIDE_SLOTS"); return e && e[0] == '1'; }();      // measurements
+    const int slots = (embed_inside && (NT == 2 || NT == 4) && !wide_slots) ? 8 / NT : (NT <= 2 ? 8 : (NT <= 4 ? 4 : 1));
+    sa.off_wave = take(slots * sa.wave_stride);
     const size_t lds_bytes = (size_t)off * sizeof(float);
     switch (NT) {
         case 1: return launch_scene<1, 8>(sa, lds_bytes, ca, stream);

@@ -12,6 +12,7 @@ for sw in "X=default" "$1"; do
   env $sw RGL_BENCH_NO_F16X3=1 python bench.py --cpu-seconds 0 --humans 49 --layers 3 --roots 256 --steps 100 --contraction f16 2>/dev/null | line "c4 f16 256 roots  [$sw]" >> $O
   env $sw RGL_BENCH_NO_F16X3=1 python bench.py --cpu-seconds 0 --humans 49 --layers 3 --roots 2048 --steps 30 2>/dev/null | line "c4 f32 2048 roots [$sw]" >> $O
   env $sw RGL_BENCH_NO_F16X3=1 python bench.py --cpu-seconds 0 --humans 19 --layers 3 --roots 256 --steps 100 2>/dev/null | line "N=20 L=3 f32 256  [$sw]" >> $O
+  env $sw RGL_BENCH_NO_F16X3=1 python bench.py --cpu-seconds 0 --roots 256 --steps 200 2>/dev/null | line "c2 256 roots      [$sw]" >> $O
 done
 done
 cat $O
