@@ -88,7 +88,7 @@ def children_flops_per_scene(N, L, A):
             per_child += 2 * N * 32 + 2 * N * 32 * 32 + 2 * N * N * 32 + 6 * N * 32 + 2 * 32    # p*H1, H1*W2, E*O, H2 + t_c
         else:
             per_child += 2 * N * 32                                                     # t_c = p*H1
-        return per_parent / A + per_child + last_layer + head, "shared-crowd deep (children_deep_kernel + robot_head_kernel)"
+        return per_parent / A + per_child + last_layer + head, "shared-crowd deep (children_deep_kernel, stage 2 -- the value head -- as its trailing phase; robot_head_kernel with RGL_DEEP_FUSE_HEAD=0)"
     per_parent = H * 4736 + 2 * H * 32 * 32 + 2 * H * H * 32
     sim = 2 * 32 * 32 + 4 * N * 32 + 5 * N * N
     full_layer = 2 * N * N * 32 + 2 * N * 32 * 32 + 2 * N * 32
