@@ -77,6 +77,52 @@ __device__ __forceinline__ void fill_frags(float* dst, const float* __restrict__
     }
 }
 
+// fill_frags in two halves, so that a caller can put the loads of SEVERAL images in flight before the first store (one L2 round trip
+// for all of them: the scene kernel's embedding sets behind its weight image)
+template <int IN, int OUT, int NTHR>
+struct FragRegs {
+    static constexpr int TOTAL = Tiles<OUT>::v * Tiles<IN>::v * 4 * 64;
+    static constexpr int ITERS = (TOTAL + NTHR - 1) / NTHR;
+    float w[ITERS];
+    bool ok[ITERS];
+};
+template <int IN, int OUT, int NTHR>
+__device__ __forceinline__ void frag_load(FragRegs<IN, OUT, NTHR>& r, const float* __restrict__ W, int tid) {
+    constexpr int IT = Tiles<IN>::v;
+    using R = FragRegs<IN, OUT, NTHR>;
+#pragma unroll
+    for (int k = 0; k < R::ITERS; ++k) {
+        int idx = tid + k * NTHR;
+        if (idx >= R::TOTAL) idx = R::TOTAL - 1;
+        const int l = idx & 63, fr = idx >> 6;
+        const int rr = fr & 3, it = (fr >> 2) % IT, ot = (fr >> 2) / IT;
+        const int in = tile_feature<IN>(it, l >> 4, rr), out = frag_out_feature<OUT>(ot, l);
+        r.w[k] = W[(in < IN ? in : IN - 1) * OUT + (out < OUT ? out : OUT - 1)];
+        r.ok[k] = in < IN && out < OUT;
+    }
+}
+template <int IN, int OUT, int NTHR>
+__device__ __forceinline__ void frag_store(const FragRegs<IN, OUT, NTHR>& r, float* dst, int tid) {
+    using R = FragRegs<IN, OUT, NTHR>;
+#pragma unroll
+    for (int k = 0; k < R::ITERS; ++k) {
+        const int idx = tid + k * NTHR;
+        if (idx < R::TOTAL) dst[idx] = r.ok[k] ? r.w[k] : 0.f;
+    }
+}
+// one element of a fill_bias vector per thread (threads >= Tiles<OUT> * 16 hold nothing): load, then store
+template <int OUT>
+__device__ __forceinline__ float bias_load(const float* __restrict__ b, int tid) {
+    const int idx = tid < Tiles<OUT>::v * 16 ? tid : 0;
+    const int feat = tile_feature<OUT>(idx >> 4, (idx >> 2) & 3, idx & 3);
+    const float v = b[feat < OUT ? feat : OUT - 1];
+    return feat < OUT ? v : 0.f;
+}
+template <int OUT>
+__device__ __forceinline__ void bias_store(float v, float* dst, int tid) {
+    if (tid < Tiles<OUT>::v * 16) dst[tid] = v;
+}
+
 // per-feature vectors (bias, last-layer weights) in D-row order: dst[16 t + 4 q + r] belongs to tile_feature(t, q, r)
 template <int OUT>
 __device__ __forceinline__ void fill_bias(float* dst, const float* __restrict__ b, int tid, int nthr = kThreads) {

@@ -168,6 +168,25 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
     const int slot = __builtin_amdgcn_readfirstlane(SPLIT ? wave / NT : wave);
     const int ctb = SPLIT ? __builtin_amdgcn_readfirstlane(wave % NT) : 0;      // my first (SPLIT: only) column tile
     float* Hs = lds + a.off_wave + slot * a.wave_stride;   // [16*NT][XLD] node features of the slot's current scene
+    // EMB: the fragment sets of the two embedding MLPs.  Their loads go out together with the weight image's (non-HX: before its
+    // stores), so that the whole prologue is ONE L2 round trip instead of one per fill (round 4)
+    constexpr int kEmbThreads = EMB ? kSceneThreads : 64;
+    FragRegs<9, HID, kEmbThreads> er1;
+    FragRegs<HID, XD, kEmbThreads> er2, eh2;
+    FragRegs<5, HID, kEmbThreads> eh1;
+    float ebias[4] = {0.f, 0.f, 0.f, 0.f};
+    auto emb_loads = [&]() {
+        if constexpr (EMB) {
+            frag_load(er1, a.er_w1, tid);
+            frag_load(er2, a.er_w2, tid);
+            frag_load(eh1, a.eh_w1, tid);
+            frag_load(eh2, a.eh_w2, tid);
+            ebias[0] = bias_load<HID>(a.er_b1, tid);
+            ebias[1] = bias_load<XD>(a.er_b2, tid);
+            ebias[2] = bias_load<HID>(a.eh_b1, tid);
+            ebias[3] = bias_load<XD>(a.eh_b2, tid);
+        }
+    };
     if constexpr (HX) {
         // split-f16 image, packed once per parameter state (or per search) in exactly this layout: b128 copies, every load of a
         // thread in flight at once.  (Converting the matrices here -- two L2 round trips per fragment element -- cost 10 us per launch.)
@@ -198,6 +217,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
             vm2[k] = a.wm2 ? a.wm2[r * 5 + (c < 5 ? c : 0)] : 0.f;
         }
         vb = !a.bm1 ? 0.f : (tid < HID ? a.bm1[tid] : (tid < HID + 5 ? a.bm2[tid - HID] : 0.f));
+        emb_loads();
 #pragma unroll
         for (int k = 0; k < KQ; ++k) {
             const int i = tid + k * NT_, r = i / XD, c = i - r * XD;
@@ -226,14 +246,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
     if constexpr (EMB) {
         float* w = lds;
         constexpr int F1 = 0, F2 = F1 + 4 * 1 * 4 * 64, B1 = F2 + 2 * 4 * 4 * 64, B2 = B1 + HID;
-        fill_frags<9, HID, kSceneThreads>(w + a.off_er + F1, a.er_w1, tid);
-        fill_frags<HID, XD, kSceneThreads>(w + a.off_er + F2, a.er_w2, tid);
-        fill_bias<HID>(w + a.off_er + B1, a.er_b1, tid, kSceneThreads);
-        fill_bias<XD>(w + a.off_er + B2, a.er_b2, tid, kSceneThreads);
-        fill_frags<5, HID, kSceneThreads>(w + a.off_eh + F1, a.eh_w1, tid);
-        fill_frags<HID, XD, kSceneThreads>(w + a.off_eh + F2, a.eh_w2, tid);
-        fill_bias<HID>(w + a.off_eh + B1, a.eh_b1, tid, kSceneThreads);
-        fill_bias<XD>(w + a.off_eh + B2, a.eh_b2, tid, kSceneThreads);
+        if constexpr (HX) emb_loads();
+        frag_store(er1, w + a.off_er + F1, tid);
+        frag_store(er2, w + a.off_er + F2, tid);
+        bias_store<HID>(ebias[0], w + a.off_er + B1, tid);
+        bias_store<XD>(ebias[1], w + a.off_er + B2, tid);
+        frag_store(eh1, w + a.off_eh + F1, tid);
+        frag_store(eh2, w + a.off_eh + F2, tid);
+        bias_store<HID>(ebias[2], w + a.off_eh + B1, tid);
+        bias_store<XD>(ebias[3], w + a.off_eh + B2, tid);
     }
     __syncthreads();
     // scene of slot k in pass i: blockIdx + grid_scene * k + i * grid_scene * kSlots (partial round: one scene per workgroup).  SPLIT:
