@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RGL_ABI_VERSION 5
+#define RGL_ABI_VERSION 6
 
 #define RGL_MAX_MLP_LAYERS 6
 #define RGL_MAX_GCN_LAYERS 8
@@ -315,7 +315,14 @@ int mprl_value_children_f32(const MprlPlanner* planner, const float* child_robot
  *   best_action device [B] int32, best_value device [B] float32
  *   root_values NULL or device [B][W0] float32, root_kept NULL or device [B][W0] int32, with
  *   W0 = planning_width if do_action_clip else num_actions; kept actions are ordered by
- *   descending one-step value (ties: lower action index first). */
+ *   descending one-step value (ties: lower action index first).
+ * roots_are_joint_states = 1 (ABI 6 semantics): the roots are JointStates (predict(), :192-240).  Upstream then prices every
+ * root action TWICE: action_clip is handed the float32 TENSOR of the state (:216-218 -> :246-248 -> tensor_to_joint_state,
+ * crowd_sim/envs/utils/state.py:82-92: float32-born scalars, position differences rounded to float32), while the values of the
+ * kept actions read the float64 JointState (:226).  The search does the same: level 0's selection uses the tensor-born rewards
+ * (kept in the workspace at MprlLevelView::reward_clip_off), root_values / best_value the float64 ones (reward_off; read from
+ * planner->root_*_f64 when set).  Without do_action_clip only the second exists.  roots_are_joint_states = 0: the roots are
+ * tensor states themselves (V_planning's view of a state), one reward array. */
 size_t mprl_tree_workspace_bytes(const MprlPlanner* planner, int B, int H);
 int mprl_tree_search_f32(const MprlPlanner* planner, const float* robot, const float* humans, int B, int H,
                          int roots_are_joint_states, void* workspace, size_t workspace_bytes,
@@ -360,6 +367,9 @@ typedef struct MprlLevelView {
     long long keep_off;                       /* int32 [P][W]                                  */
     long long backup_off;                     /* float32 [P][W] returns of the kept children   */
     long long best_slot_off;                  /* int32 [P] first-max slot among the kept       */
+    long long reward_clip_off;                /* ABI 6: float32 [B][A], level 0 of a clipped search, else -1: the root rewards as
+                                               * upstream's root action_clip reads them (see mprl_tree_search_f32); written by
+                                               * searches with roots_are_joint_states = 1                                 */
 } MprlLevelView;
 int mprl_tree_level_view(const MprlPlanner* planner, int B, int H, int level, MprlLevelView* view);
 

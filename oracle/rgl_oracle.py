@@ -243,9 +243,22 @@ def point_to_segment_dist(x1, y1, x2, y2, x3, y3):
     return np.linalg.norm((x1 + u * px - x3, y1 + u * py - y3))
 
 
+def action_object(actions, i):
+    """Row i of an action table as the scalars upstream's action object holds: numpy float64 products for every entry
+    (model_predictive_rl.py:183-186) except the stop action, which is `ActionXY(0, 0)` / `ActionRot(0, 0)` -- PYTHON INTS (:166).
+    The difference is arithmetic, not cosmetic: under numpy >= 2 promotion (NEP 50) python scalars are weak, so estimate_reward
+    of a tensor-born state (numpy float32 scalars) with the stop action runs in float32 from end to end, while a float64 action
+    component widens it.  (The reference as it runs in this image, numpy 2.2.6; fixture root_clip.npz, action 0.)"""
+    a0, a1 = actions[i][0], actions[i][1]
+    if a0 == 0 and a1 == 0:
+        return (0, 0)
+    return (np.float64(a0), np.float64(a1))
+
+
 def estimate_reward(robot, humans, action, cfg):
     """robot: 9 scalars, humans: iterable of 5-scalar rows (python floats for a root JointState,
-    np.float32 for states that came back from tensors), action: 2 np.float64 scalars."""
+    np.float32 for states that came back from tensors), action: 2 scalars as `action_object` gives them (np.float64, or
+    python ints for the stop action).  Scalar code: numpy's promotion rules do the rest, as in the reference."""
     dt = cfg.time_step
     rpx, rpy, _, _, rrad, gx, gy, _, rtheta = robot
     holo = cfg.kinematics == "holonomic"
@@ -313,6 +326,8 @@ class SeqTrace:
     n_value_forwards: int = 0
     n_predictor_forwards: int = 0
     root_clip_values: Optional[np.ndarray] = None       # (A,) one-step values of every root action
+    root_clip_rewards: Optional[np.ndarray] = None      # (A,) the rewards inside the root's action_clip (tensor-born reading)
+    root_rewards: Optional[np.ndarray] = None           # reward of each kept root action (float64 JointState reading)
     root_clipped: Optional[List[int]] = None            # action indices kept at the root
     root_values: Optional[np.ndarray] = None            # value of each kept root action
 
@@ -330,6 +345,7 @@ class SeqPlanner:
     def __init__(self, P: MprlParams, cfg: OracleConfig, v_pref=1.0, root_rows=None, trace: SeqTrace = None):
         self.P, self.cfg = P, cfg
         self.actions, self.groups = mprl_action_space(cfg, v_pref)
+        self.action_objs = [action_object(self.actions, i) for i in range(len(self.actions))]
         self.gamma = _normalized_gamma(cfg)
         self.root_rows = root_rows                  # (robot9 floats, human rows): the JointState the root tensors came from
         self.trace = trace if trace is not None else SeqTrace()
@@ -348,18 +364,26 @@ class SeqPlanner:
         return (nr, nh)
 
     def reward_of(self, state, a, root):
+        """estimate_reward (:304-357) of a planner state.  `root` = the state is the root JointState itself (python floats: the
+        final loop of predict, :226); everything action_clip / V_planning see -- the root's own action_clip included, which is
+        handed `state.to_tensor(...)` (:216-218) -- is a tensor and goes through tensor_to_joint_state (state.py:82-92):
+        float32-born numpy scalars."""
         if root:
             return estimate_reward(self.root_rows[0], self.root_rows[1], a, self.cfg)
         r, h = _tensor_state_scalars(state[0], state[1])
         return estimate_reward(r, h, a, self.cfg)
 
-    def clip(self, state, width, root):
-        """action_clip (:242-269) -> (kept action indices in the reference's order, one-step values of every action)."""
+    def clip(self, state, width, rewards_out=None):
+        """action_clip (:242-269) -> (kept action indices in the reference's order, one-step values of every action).
+        The state is always a tensor state here (upstream never calls action_clip with anything else)."""
         vals = []
-        for a in self.actions:
+        for a, ao in zip(self.actions, self.action_objs):
             nxt = self.SP(state, a)
             ret = self.V(nxt)
-            vals.append(self.reward_of(state, a, root) + self.gamma * ret)
+            rew = self.reward_of(state, ao, False)
+            if rewards_out is not None:
+                rewards_out.append(float(rew))
+            vals.append(rew + self.gamma * ret)
         vals_np = np.array([float(v) for v in vals], dtype=np.float32)
         if self.cfg.sparse_search:
             seen, keep = set(), []
@@ -378,12 +402,12 @@ class SeqPlanner:
         v = self.V(state)
         if depth == 1:
             return v
-        keep = self.clip(state, width, False)[0] if self.cfg.do_action_clip else list(range(len(self.actions)))
+        keep = self.clip(state, width)[0] if self.cfg.do_action_clip else list(range(len(self.actions)))
         rets = []
         for ai in keep:
             a = self.actions[ai]
             nxt = self.SP(state, a)
-            r = self.reward_of(state, a, False)
+            r = self.reward_of(state, self.action_objs[ai], False)
             nv = self.plan(nxt, depth - 1, width)
             rets.append(v / depth + (depth - 1) / depth * (self.gamma * nv + r))
         return rets[int(np.argmax([float(x) for x in rets]))]
@@ -398,21 +422,28 @@ def mprl_predict_sequential(robot9, humans, P: MprlParams, cfg: OracleConfig, tr
     root = (torch.tensor([[robot9]], dtype=torch.float32),
             torch.tensor([humans], dtype=torch.float32).reshape(1, len(humans), 5))
     if cfg.do_action_clip:
-        keep, vals_np = sp.clip(root, cfg.planning_width, True)
+        # the root's clipping runs on the float32 TENSOR of the state (:216-218), the values of the kept actions below on the
+        # float64 JointState (:226): the same action is priced with two roundings
+        rewards = []
+        keep, vals_np = sp.clip(root, cfg.planning_width, rewards)
         trace.root_clip_values = vals_np
+        trace.root_clip_rewards = np.array(rewards, dtype=np.float64)
     else:
         keep = list(range(len(actions)))
     trace.root_clipped = keep
-    best, best_v, root_vals = None, float("-inf"), []
+    best, best_v, root_vals, root_rews = None, float("-inf"), [], []
     for ai in keep:
         a = actions[ai]
         nxt = sp.SP(root, a)
         ret = sp.plan(nxt, cfg.planning_depth, cfg.planning_width)
-        val = estimate_reward(robot9, humans, a, cfg) + gamma * ret
+        rew = sp.reward_of(root, sp.action_objs[ai], True)
+        val = rew + gamma * ret
         root_vals.append(float(val))
+        root_rews.append(float(rew))
         if val > best_v:
             best_v, best = val, ai
     trace.root_values = np.array(root_vals, dtype=np.float32)
+    trace.root_rewards = np.array(root_rews, dtype=np.float64)
     return best, np.float32(best_v)
 
 
@@ -420,12 +451,13 @@ def mprl_predict_sequential(robot9, humans, P: MprlParams, cfg: OracleConfig, tr
 # path M planner -- batched, level synchronous (same arithmetic, B roots at once)
 # --------------------------------------------------------------------------------------------------
 def estimate_reward_batched(robot, humans, actions, cfg, root):
-    """robot (P,9) fp32, humans (P,H,5) fp32, actions (A,2) float64 -> rewards (P,A) float64.
+    """robot (P,9), humans (P,H,5) (fp32 tensors, or float64 arrays = genuine float64 JointStates with `root`), actions (A,2)
+    float64 -> rewards (P,A) float64.
     Vectorised transcription of `estimate_reward`; `root` selects float64 differences (JointState
     inputs) versus the float32 differences the reference gets from tensor-born states."""
     dt = cfg.time_step
-    r = robot.numpy()
-    h = humans.numpy()
+    r = robot.numpy() if torch.is_tensor(robot) else np.asarray(robot)
+    h = humans.numpy() if torch.is_tensor(humans) else np.asarray(humans)
     if root:
         r = r.astype(np.float64)
         h = h.astype(np.float64)
@@ -465,7 +497,35 @@ def estimate_reward_batched(robot, humans, actions, cfg, root):
     rew = np.where(dmin < 0.2, (dmin - 0.2) * 0.5 * dt, 0.0)
     rew = np.where(reaching, 1.0, rew)
     rew = np.where(collision, -0.25, rew)
+    if not root and r.dtype == np.float32:
+        for ai in range(actions.shape[0]):
+            if action_object(actions, ai) == (0, 0):
+                rew[:, ai] = _stop_reward_f32(r, h, dt)
     return rew
+
+
+def _stop_reward_f32(r, h, dt):
+    """estimate_reward of tensor-born states (P,9) / (P,H,5) float32 under the python-int stop action: float32 from end to end
+    (see `action_object`); array form of the scalar code, one float32 operation per numpy scalar operation."""
+    f = np.float32
+    assert r.dtype == np.float32 and h.dtype == np.float32
+    px, py = h[:, :, 0] - r[:, None, 0], h[:, :, 1] - r[:, None, 1]
+    ex, ey = px + h[:, :, 2] * f(dt), py + h[:, :, 3] * f(dt)
+    sx, sy = ex - px, ey - py
+    degenerate = (sx == 0) & (sy == 0)
+    u = ((f(0) - px) * sx + (f(0) - py) * sy) / np.where(degenerate, f(1), sx * sx + sy * sy)
+    u = np.clip(np.where(degenerate, f(0), u), f(0), f(1))
+    cx, cy = px + u * sx, py + u * sy
+    closest = np.sqrt(cx * cx + cy * cy) - h[:, :, 4] - r[:, None, 4]
+    assert closest.dtype == np.float32
+    collision = (closest < 0).any(axis=1)
+    dmin = closest.min(axis=1)
+    gx, gy = r[:, 0] - r[:, 5], r[:, 1] - r[:, 6]
+    reaching = np.sqrt(gx * gx + gy * gy) < r[:, 4]
+    rew = np.where(dmin < f(0.2), (dmin - f(0.2)) * f(0.5) * f(dt), f(0))
+    assert rew.dtype == np.float32
+    rew = np.where(reaching, f(1), rew)
+    return np.where(collision, f(-0.25), rew).astype(np.float64)
 
 
 def _children_robot(robot, actions, cfg):
@@ -507,10 +567,14 @@ def select_top(values, width, groups, sparse):
     return keep
 
 
-def mprl_expand_batched(robot, humans, P: MprlParams, cfg, actions, root):
+def mprl_expand_batched(robot, humans, P: MprlParams, cfg, actions, root, roots64=None, root_clip=False):
     """One tree level for a batch of parents.
     robot (Pn,9), humans (Pn,H,5) -> dict(next_humans (Pn,H,5), child_robot (Pn,A,9),
-    child_value (Pn,A) fp32 = V(child), reward (Pn,A) fp32, value1 (Pn,A) fp32 = r + g*V)."""
+    child_value (Pn,A) fp32 = V(child), reward (Pn,A) fp32, value1 (Pn,A) fp32 = r + g*V).
+    `root`: the parents are JointStates (float64 reading; `roots64` = the (robot, humans) float64 arrays the fp32 rows were
+    rounded from, when they are not float32-representable).  `root_clip`: the level is the root of a clipped search -- the
+    one-step values the selection runs on use the TENSOR-BORN reading of the same rows (`reward_clip`), as upstream's root
+    action_clip does (model_predictive_rl.py:216-218,246-248); `reward` keeps the float64 reading for the root values (:226)."""
     Pn, A = robot.shape[0], actions.shape[0]
     if cfg.linear_state_predictor:
         nh = linear_humans(humans)
@@ -521,15 +585,26 @@ def mprl_expand_batched(robot, humans, P: MprlParams, cfg, actions, root):
     cv = value_estimator_forward(cr.reshape(Pn * A, 1, 9),
                                  nh[:, None].expand(Pn, A, H, 5).reshape(Pn * A, H, 5),
                                  P.ve_graph, P.value_network, cfg).reshape(Pn, A)
-    rew = torch.tensor(estimate_reward_batched(robot, humans, actions, cfg, root)).to(torch.float32)
+    if root and roots64 is not None:
+        rew = torch.tensor(estimate_reward_batched(roots64[0], roots64[1], actions, cfg, True)).to(torch.float32)
+    else:
+        rew = torch.tensor(estimate_reward_batched(robot, humans, actions, cfg, root)).to(torch.float32)
     gamma = _normalized_gamma(cfg)
-    value1 = rew + gamma * cv
-    return dict(next_humans=nh, child_robot=cr, child_value=cv, reward=rew, value1=value1)
+    out = dict(next_humans=nh, child_robot=cr, child_value=cv, reward=rew)
+    sel = rew
+    if root and root_clip:
+        sel = torch.tensor(estimate_reward_batched(robot, humans, actions, cfg, False)).to(torch.float32)
+        out["reward_clip"] = sel
+    out["value1"] = sel + gamma * cv
+    return out
 
 
-def mprl_predict_batched(robot, humans, P: MprlParams, cfg: OracleConfig, return_levels=False):
+def mprl_predict_batched(robot, humans, P: MprlParams, cfg: OracleConfig, return_levels=False, roots64=None,
+                         roots_are_joint_states=True):
     """robot (B,9), humans (B,H,5) fp32 tensors -> (best action (B,) int64, best value (B,) fp32,
-    root_values (B,W0) fp32, root_kept (B,W0) int64).  W0 = width if clipping else |A|."""
+    root_values (B,W0) fp32, root_kept (B,W0) int64).  W0 = width if clipping else |A|.
+    The roots are JointStates (what predict() is given) unless `roots_are_joint_states` is False; `roots64` = (robot (B,9),
+    humans (B,H,5)) float64 arrays when the JointStates are not float32-representable (the fp32 tensors are their roundings)."""
     actions, groups = mprl_action_space(cfg, cfg.v_pref)
     A = actions.shape[0]
     gamma = _normalized_gamma(cfg)
@@ -539,7 +614,8 @@ def mprl_predict_batched(robot, humans, P: MprlParams, cfg: OracleConfig, return
     levels = []
     pr, ph = robot, humans
     for lvl in range(D):
-        ex = mprl_expand_batched(pr, ph, P, cfg, actions, root=(lvl == 0))
+        ex = mprl_expand_batched(pr, ph, P, cfg, actions, root=(lvl == 0 and roots_are_joint_states), roots64=roots64,
+                                 root_clip=bool(cfg.do_action_clip))
         if cfg.do_action_clip:
             keep = select_top(ex["value1"].numpy(), w, groups, cfg.sparse_search)
         else:

@@ -15,7 +15,7 @@ MAX_NODES = 128
 MAX_XDIM = 64
 MAX_WIDTH = 256
 MAX_ACTIONS = 256
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 SIMILARITY = {"embedded_gaussian": 0, "gaussian": 1, "cosine": 2, "cosine_softmax": 3, "concatenation": 4,
               "squared": 5, "equal_attention": 6, "diagonal": 7}
@@ -71,7 +71,7 @@ class CrowdSimConfig(C.Structure):
 class MprlLevelView(C.Structure):
     _fields_ = [(n, C.c_longlong) for n in
                 ("n_parents", "robot_off", "humans_off", "humans_next_off", "child_robot_off", "reward_off",
-                 "child_value_off", "value1_off", "keep_off", "backup_off", "best_slot_off")]
+                 "child_value_off", "value1_off", "keep_off", "backup_off", "best_slot_off", "reward_clip_off")]
 
 
 # name -> (restype, argtypes); every symbol include/rgl_hip.h declares

@@ -18,6 +18,8 @@ struct ChildrenArgs {
     float* reward;             // [P][A]
     const double* robot64;     // null, or the float64 states robot / humans were rounded from (joint roots): the reward reads these
     const double* humans64;
+    float* reward_clip;        // null, or [P][A]: the same rewards read as a TENSOR-BORN state (joint = 0 on the fp32 rows) -- what
+                               // upstream's root action_clip sees of a joint-state root (model_predictive_rl.py:216-218,246-248)
 };
 
 __device__ __forceinline__ double seg_point_dist_origin(double px, double py, double ex, double ey, bool f32_degenerate,
@@ -34,46 +36,29 @@ __device__ __forceinline__ double seg_point_dist_origin(double px, double py, do
     return sqrt(cx * cx + cy * cy);
 }
 
-// One (parent, action) pair: next robot state + estimate_reward.  `near_mask`: bit h clear = human h provably cannot influence
-// any child of this parent (children_wave), skipped outright.
-__device__ __forceinline__ void children_pa(const ChildrenArgs& ca, int p, int a, unsigned long long near_mask = ~0ull) {
-    const long long idx = (long long)p * ca.A + a;
-    const float* __restrict__ robot = ca.robot;
-    const float* __restrict__ humans = ca.humans;
-    const double* __restrict__ actions = ca.actions;
-    float* __restrict__ child_robot = ca.child_robot;
-    float* __restrict__ reward = ca.reward;
-    const int humans_per = ca.humans_per, H = ca.H, kinematics = ca.kinematics, joint = ca.joint;
-    const double dt = ca.dt;
-
-    const float* r = robot + (size_t)p * 9;
-    const float* hs = humans + (size_t)(p / humans_per) * H * 5;
-    const double* r64 = ca.robot64 ? ca.robot64 + (size_t)p * 9 : nullptr;          // float64 roots (humans_per == 1 there)
-    const double* hs64 = ca.humans64 ? ca.humans64 + (size_t)p * H * 5 : nullptr;
+// estimate_reward of one (parent, action) pair under one reading of the parent state (model_predictive_rl.py:304-357):
+//   joint = 1: a JointState of python floats -- position differences in float64, of the float64 rows when `use64` (and the
+//              planner carries them), of the fp32 rows widened otherwise;
+//   joint = 0: a tensor-born state (tensor_to_joint_state, state.py:82-92) -- numpy float32 scalars, position differences
+//              rounded to fp32 first, everything else widened by the float64 action / time step.
+// `near_mask`: bit h clear = human h provably cannot influence any child of this parent (children_wave), skipped outright.
+__device__ __forceinline__ double pair_reward(const ChildrenArgs& ca, int p, int a, unsigned long long near_mask, int joint,
+                                              bool use64) {
+    const float* __restrict__ r = ca.robot + (size_t)p * 9;
+    const float* __restrict__ hs = ca.humans + (size_t)(p / ca.humans_per) * ca.H * 5;
+    const double* r64 = use64 && ca.robot64 ? ca.robot64 + (size_t)p * 9 : nullptr;          // float64 roots (humans_per == 1 there)
+    const double* hs64 = use64 && ca.humans64 ? ca.humans64 + (size_t)p * ca.H * 5 : nullptr;
     auto R = [&](int i) { return r64 ? r64[i] : (double)r[i]; };
-    const double a0 = actions[2 * a], a1 = actions[2 * a + 1];
-    float c[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) c[i] = r[i];
+    const double a0 = ca.actions[2 * a], a1 = ca.actions[2 * a + 1];
+    const double dt = ca.dt;
+    const int H = ca.H;
     double avx, avy, nx, ny;
-    if (kinematics == RGL_HOLONOMIC) {
-        c[0] = __fadd_rn(r[0], (float)(a0 * dt));
-        c[1] = __fadd_rn(r[1], (float)(a1 * dt));
-        c[2] = (float)a0;
-        c[3] = (float)a1;
+    if (ca.kinematics == RGL_HOLONOMIC) {
         avx = a0;
         avy = a1;
         nx = R(0) + a0 * dt;
         ny = R(1) + a1 * dt;
     } else {
-        // the reference rotates slot 7 (v_pref), not slot 8 (theta): kept (state_predictor.py:53-58)
-        const float th7 = __fadd_rn(r[7], (float)a1);
-        const float cs = cosf(th7), sn = sinf(th7);
-        c[7] = th7;
-        c[0] = __fadd_rn(r[0], (float)((double)cs * a0 * dt));
-        c[1] = __fadd_rn(r[1], (float)((double)sn * a0 * dt));
-        c[2] = (float)((double)cs * a0);
-        c[3] = (float)((double)sn * a0);
         // estimate_reward uses theta (slot 8) for the relative velocity and the goal test
         const double th = a1 + R(8);
         avx = a0 * cos(th);
@@ -82,10 +67,6 @@ __device__ __forceinline__ void children_pa(const ChildrenArgs& ca, int p, int a
         nx = R(0) + cos(th2) * a0 * dt;
         ny = R(1) + sin(th2) * a0 * dt;
     }
-    float* co = child_robot + (size_t)idx * 9;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) co[i] = c[i];
-
     bool collision = false;
     double dmin = INFINITY;
     const float favx = (float)avx, favy = (float)avy, fdt = (float)dt;
@@ -132,12 +113,98 @@ __device__ __forceinline__ void children_pa(const ChildrenArgs& ca, int p, int a
     }
     const double gx = nx - R(5), gy = ny - R(6);
     const bool reaching = sqrt(gx * gx + gy * gy) < R(4);
-    double rew;
-    if (collision) rew = -0.25;
-    else if (reaching) rew = 1.0;
-    else if (dmin < 0.2) rew = (dmin - 0.2) * 0.5 * dt;
-    else rew = 0.0;
-    reward[idx] = (float)rew;
+    if (collision) return -0.25;
+    if (reaching) return 1.0;
+    if (dmin < 0.2) return (dmin - 0.2) * 0.5 * dt;
+    return 0.0;
+}
+
+// estimate_reward of a TENSOR-BORN state under the table's stop action.  Upstream builds that one entry from python ints --
+// `ActionXY(0, 0)` / `ActionRot(0, 0)` (model_predictive_rl.py:166) -- and every other entry from numpy float64 products
+// (:183-186).  The state's fields are numpy float32 scalars (state.py:82-92); under numpy >= 2 promotion (NEP 50: python scalars
+// are weak) nothing in estimate_reward widens them when the action is made of python ints -- the whole function, the time step
+// and the 0.2 / 0.5 constants included, runs in float32 -- whereas a float64 action component widens everything but the
+// position differences (pair_reward, joint = 0).  Observed in the reference as it runs in this image (numpy 2.2.6): fixture
+// root_clip.npz, action 0.  Each operation below is one float32 numpy scalar operation of utils.py:4-26 / :316-355, in order;
+// with v = 0 both kinematics reduce to the same arithmetic (v * cos(..) = +-0).
+__device__ __forceinline__ double stop_reward_f32(const ChildrenArgs& ca, int p, unsigned long long near_mask) {
+    const float* __restrict__ r = ca.robot + (size_t)p * 9;
+    const float* __restrict__ hs = ca.humans + (size_t)(p / ca.humans_per) * ca.H * 5;
+    const float fdt = (float)ca.dt;
+    bool collision = false;
+    float dmin = INFINITY;
+    for (int h = 0; h < ca.H; ++h) {
+        if (h < 64 && !((near_mask >> h) & 1ull)) continue;
+        const float* hu = hs + h * 5;
+        const float px = __fsub_rn(hu[0], r[0]), py = __fsub_rn(hu[1], r[1]);
+        const float ex = __fadd_rn(px, __fmul_rn(hu[2], fdt)), ey = __fadd_rn(py, __fmul_rn(hu[3], fdt));
+        const float sx = __fsub_rn(ex, px), sy = __fsub_rn(ey, py);
+        {
+            // the same exact shortcut as pair_reward: provably >= 0.25 of clearance, the human cannot influence the reward
+            const float Tf = hu[4] + r[4] + 0.25f;
+            if (px * px + py * py >= 2.002f * (sx * sx + sy * sy + Tf * Tf)) continue;
+        }
+        float dist;
+        if (sx == 0.f && sy == 0.f) {
+            dist = sqrtf(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)));
+        } else {
+            float u = __fdiv_rn(__fadd_rn(__fmul_rn(-px, sx), __fmul_rn(-py, sy)), __fadd_rn(__fmul_rn(sx, sx), __fmul_rn(sy, sy)));
+            u = u > 1.f ? 1.f : (u < 0.f ? 0.f : u);
+            const float cx = __fadd_rn(px, __fmul_rn(u, sx)), cy = __fadd_rn(py, __fmul_rn(u, sy));
+            dist = sqrtf(__fadd_rn(__fmul_rn(cx, cx), __fmul_rn(cy, cy)));
+        }
+        const float d = __fsub_rn(__fsub_rn(dist, hu[4]), r[4]);
+        if (d < 0.f) collision = true;
+        if (d < dmin) dmin = d;
+    }
+    const float gx = __fsub_rn(r[0], r[5]), gy = __fsub_rn(r[1], r[6]);
+    const bool reaching = sqrtf(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy))) < r[4];
+    if (collision) return -0.25;
+    if (reaching) return 1.0;
+    if (dmin < 0.2f) return (double)__fmul_rn(__fmul_rn(__fsub_rn(dmin, 0.2f), 0.5f), fdt);
+    return 0.0;
+}
+
+// A table row that is exactly (0, 0) is upstream's python-int stop action (no other entry of build_action_space can be: speeds
+// are > 0); see stop_reward_f32.
+__device__ __forceinline__ bool is_python_int_stop(const ChildrenArgs& ca, int a) {
+    return ca.actions[2 * a] == 0.0 && ca.actions[2 * a + 1] == 0.0;
+}
+
+// One (parent, action) pair: next robot state (state_predictor.py:41-60) + estimate_reward -- under the reading the level asked
+// for and, when `reward_clip` is set (joint-state roots of a clipped search), ALSO as the tensor-born state upstream's root
+// action_clip is handed (model_predictive_rl.py:216-218 -> :246-248): the root's selection and the root's values price the same
+// action with two different roundings there.
+__device__ __forceinline__ void children_pa(const ChildrenArgs& ca, int p, int a, unsigned long long near_mask = ~0ull) {
+    const long long idx = (long long)p * ca.A + a;
+    const float* r = ca.robot + (size_t)p * 9;
+    const double a0 = ca.actions[2 * a], a1 = ca.actions[2 * a + 1];
+    const double dt = ca.dt;
+    float c[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c[i] = r[i];
+    if (ca.kinematics == RGL_HOLONOMIC) {
+        c[0] = __fadd_rn(r[0], (float)(a0 * dt));
+        c[1] = __fadd_rn(r[1], (float)(a1 * dt));
+        c[2] = (float)a0;
+        c[3] = (float)a1;
+    } else {
+        // the reference rotates slot 7 (v_pref), not slot 8 (theta): kept (state_predictor.py:53-58)
+        const float th7 = __fadd_rn(r[7], (float)a1);
+        const float cs = cosf(th7), sn = sinf(th7);
+        c[7] = th7;
+        c[0] = __fadd_rn(r[0], (float)((double)cs * a0 * dt));
+        c[1] = __fadd_rn(r[1], (float)((double)sn * a0 * dt));
+        c[2] = (float)((double)cs * a0);
+        c[3] = (float)((double)sn * a0);
+    }
+    float* co = ca.child_robot + (size_t)idx * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) co[i] = c[i];
+    const bool stop = is_python_int_stop(ca, a);
+    ca.reward[idx] = (float)(!ca.joint && stop ? stop_reward_f32(ca, p, near_mask) : pair_reward(ca, p, a, near_mask, ca.joint, true));
+    if (ca.reward_clip)
+        ca.reward_clip[idx] = (float)(stop ? stop_reward_f32(ca, p, near_mask) : pair_reward(ca, p, a, near_mask, 0, false));
 }
 
 __device__ __forceinline__ void children_thread(const ChildrenArgs& ca, long long idx) {

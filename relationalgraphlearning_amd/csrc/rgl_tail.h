@@ -28,6 +28,8 @@ struct TailArgs {
     const int* groups;        // [A] or null
     const float* child_robot; // this level [P][A][9]
     float* value1;            // this level [P][A]
+    const float* reward_sel;  // null, or [P][A]: the rewards THIS level's selection uses instead of lv[level].reward (joint-state
+                              // roots: upstream's root action_clip reads the tensor state, the root values the JointState)
     float* next_robot;        // next level's robot rows [P*W][9]; null at the deepest level
     TailLevel lv[8];
     int chain;                // deepest level only: the launch also runs the back-up steps of the levels above and the root step
@@ -54,7 +56,7 @@ __device__ __forceinline__ void tail_select(const TailArgs& t, int p, int* kl) {
     const int lane = threadIdx.x & 63;
     const int A = t.A, W = t.W;
     const TailLevel& L = t.lv[t.level];
-    const float* rw = L.reward + (size_t)p * A;
+    const float* rw = (t.reward_sel ? t.reward_sel : L.reward) + (size_t)p * A;
     const float* cv = L.child_value + (size_t)p * A;
     float* v1 = t.value1 + (size_t)p * A;
     float* cvl = reinterpret_cast<float*>(kl) + RGL_MAX_ACTIONS;

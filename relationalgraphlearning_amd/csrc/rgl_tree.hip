@@ -235,6 +235,7 @@ inline dim3 grid_for(long long n, int block = kBlock) { return dim3((unsigned)((
 struct LevelLayout {
     long long P;
     long long robot, humans, humans_next, child_robot, reward, child_value, value1, keep, backup, best_slot;
+    long long reward_clip;      // level 0 only (-1 elsewhere): the root rewards as upstream's action_clip reads them
 };
 
 inline long long align_up(long long x) { return (x + 255) & ~255ll; }
@@ -252,6 +253,8 @@ inline int plan_levels(const MprlPlanner& pl, int B, int H, LevelLayout* lv, lon
         L.humans_next = off;  off = align_up(off + P * H * 5 * 4);
         L.child_robot = off;  off = align_up(off + P * A * 9 * 4);
         L.reward = off;       off = align_up(off + P * A * 4);
+        L.reward_clip = -1;
+        if (l == 0) { L.reward_clip = off; off = align_up(off + P * A * 4); }
         L.child_value = off;  off = align_up(off + P * A * 4);
         L.value1 = off;       off = align_up(off + P * A * 4);
         L.keep = off;         off = align_up(off + P * W * 4);
@@ -298,9 +301,11 @@ inline int validate_planner(const MprlPlanner& pl, int H) {
 int expand_level(const MprlPlanner& pl, const float* robot, const float* humans, int humans_per, int P, int H, int joint,
                  float* humans_next, float* child_robot, float* reward, float* child_value, void* scratch,
                  size_t scratch_bytes, hipStream_t st, int image_ready = 0, const TailArgs* tail = nullptr,
-                 int* tail_done = nullptr, const float* sp_image = nullptr, hipEvent_t before_children = nullptr) {
+                 int* tail_done = nullptr, const float* sp_image = nullptr, hipEvent_t before_children = nullptr,
+                 float* reward_clip = nullptr) {
     const int A = pl.num_actions;
     ChildrenArgs ca;
+    ca.reward_clip = reward_clip;
     ca.robot = robot; ca.humans = humans; ca.humans_per = humans_per; ca.actions = pl.actions;
     ca.P = P; ca.H = H; ca.A = A; ca.kinematics = pl.kinematics; ca.dt = pl.time_step; ca.joint = joint;
     ca.child_robot = child_robot; ca.reward = reward;
@@ -409,6 +414,7 @@ extern "C" int mprl_tree_level_view(const MprlPlanner* planner, int B, int H, in
     view->humans_next_off = L.humans_next;
     view->child_robot_off = L.child_robot;
     view->reward_off = L.reward;
+    view->reward_clip_off = level == 0 && planner->do_action_clip ? L.reward_clip : -1;
     view->child_value_off = L.child_value;
     view->value1_off = L.value1;
     view->keep_off = L.keep;
@@ -479,12 +485,17 @@ int tree_search(const MprlPlanner* planner, const float* robot, const float* hum
         tail.value1 = (float*)(ws + L.value1);
         tail.next_robot = deepest ? nullptr : (float*)(ws + lv[l + 1].robot);
         tail.chain = deepest;
+        // Joint-state roots of a clipped search: upstream clips the root on the TENSOR state (model_predictive_rl.py:216-218 ->
+        // :246-248, float32-born scalars) and prices the kept actions on the float64 JointState (:226) -- two reward arrays at
+        // level 0, the first for the selection, the second for the root values.
+        float* reward_clip = l == 0 && roots_are_joint_states && pl.do_action_clip ? (float*)(ws + L.reward_clip) : nullptr;
+        tail.reward_sel = reward_clip;
         int tail_done = 0;           // 1: the children kernel selected for its parents; 2: ... and finished the search (deepest level)
         if (events) RGL_HIP_TRY(hipEventRecord((hipEvent_t)events[3 * l], st));
         rc = expand_level(pl, pr, ph, humans_per, P, H, l == 0 ? roots_are_joint_states : 0,
                           (float*)(ws + L.humans_next), (float*)(ws + L.child_robot), (float*)(ws + L.reward),
                           (float*)(ws + L.child_value), ws + scratch_off, (size_t)scratch_bytes, st, image_ready, &tail, &tail_done,
-                          sp_image, events ? (hipEvent_t)events[3 * l + 1] : nullptr);
+                          sp_image, events ? (hipEvent_t)events[3 * l + 1] : nullptr, reward_clip);
         if (rc) return rc;
         if (!tail_done) {
             // the deepest level's selection also writes the leaf values and (below the root) does its own back-up step
@@ -549,6 +560,7 @@ extern "C" int mprl_estimate_reward_f32(const MprlPlanner* planner, const float*
     if (!pl.actions) return RGL_ERR_NULL;
     if (P == 0) return RGL_OK;
     ChildrenArgs ca;
+    ca.reward_clip = nullptr;
     ca.robot = robot; ca.humans = humans; ca.humans_per = 1; ca.actions = pl.actions;
     ca.P = P; ca.H = H; ca.A = pl.num_actions; ca.kinematics = pl.kinematics; ca.dt = pl.time_step; ca.joint = parents_are_joint_states;
     ca.child_robot = child_robot; ca.reward = reward;

@@ -221,7 +221,8 @@ class TreeSearch:
                                               int(roots_are_joint_states), ws.data_ptr(), ws.numel(),
                                               out["best_action"].data_ptr(), out["best_value"].data_ptr(), rv, rk, _stream())
         nat.check(rc, "mprl_tree_search_traced_f32" if trace else "mprl_tree_search_f32")
-        self.last = dict(out, B=B, H=H, robot=robot, humans=humans, planner=pl, workspace=ws, roots64=roots64, trace=tr)
+        self.last = dict(out, B=B, H=H, robot=robot, humans=humans, planner=pl, workspace=ws, roots64=roots64, trace=tr,
+                         roots_are_joint_states=bool(roots_are_joint_states))
         return out
 
     def decide(self, robot_row, human_rows):
@@ -401,6 +402,10 @@ class TreeSearch:
                "backup": f32(view.backup_off, P, W), "best_slot": i32(view.best_slot_off, P)}
         if level == 0:
             arr["robot"], arr["humans"], arr["humans_per"] = L["robot"], L["humans"], 1
+            if view.reward_clip_off >= 0 and L.get("roots_are_joint_states"):
+                # joint-state roots of a clipped search: the rewards the root's action_clip selected on (tensor-born reading,
+                # model_predictive_rl.py:216-218,246-248); "reward" holds the float64 reading the root values use (:226)
+                arr["reward_clip"] = f32(view.reward_clip_off, P, A)
         else:
             arr["robot"] = f32(view.robot_off, P, 9)
             arr["humans"] = f32(view.humans_off, P // W, H, 5)

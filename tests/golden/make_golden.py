@@ -457,7 +457,7 @@ def gen_planning_kats(masters, scenes, out):
     meta = []
     for tag, sk, D, w, clip, sparse, variant, flavour in plans:
         pol = make_ref_mprl(masters[flavour], D, w, clip, sparse, variant)
-        rec = PlanRecorder(pol)
+        rec = RootClipRecorder(pol)
         r, h = sets[sk]
         gamma = pol.get_normalized_gamma()
         acts, maxv, clipvals, kept, rootvals, counts = [], [], [], [], [], []
@@ -470,9 +470,10 @@ def gen_planning_kats(masters, scenes, out):
                 one_step = rec.top_returns[:nA]
                 main = rec.top_returns[nA:]
                 keep = rec.clipped
-                cv = [float(np.float32(pol.estimate_reward(js, pol.action_space[i])) +
-                            np.float32(gamma) * np.float32(one_step[i])) for i in range(nA)]
-                clipvals.append(cv)
+                # the values upstream's root action_clip selected on, as IT computed them (round 5: captured, not recomputed --
+                # it prices the float32 tensor of the state there, model_predictive_rl.py:216-218,246-248)
+                assert rec.clip_values.shape == (nA,) and len(one_step) == nA
+                clipvals.append(rec.clip_values)
             else:
                 main = rec.top_returns
                 keep = list(range(nA))
@@ -492,6 +493,134 @@ def gen_planning_kats(masters, scenes, out):
             out[k + "clip_values"] = np.array(clipvals, np.float32)
         meta.append("%s|%s|%d|%d|%d|%d|%s|%s" % (tag, sk, D, w, int(clip), int(sparse), variant, flavour))
     out["plan_cases"] = np.array(meta)
+
+
+
+# --------------------------------------------------------------------------------------------------
+class _NumpyTap:
+    """Stands in for the name `np` inside the reference planner's module while a RootClipRecorder runs: every attribute is
+    numpy's own, except that the array handed to np.argpartition / np.argsort is noted first -- the `values` list upstream's
+    action_clip selects on (model_predictive_rl.py:254,265), which no other hook can see."""
+
+    def __init__(self, sink):
+        self._sink = sink
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    def argpartition(self, a, *args, **kw):
+        self._sink(a)
+        return np.argpartition(a, *args, **kw)
+
+    def argsort(self, a, *args, **kw):
+        self._sink(a)
+        return np.argsort(a, *args, **kw)
+
+
+class RootClipRecorder(PlanRecorder):
+    """PlanRecorder that also keeps what happens INSIDE the root's action_clip of one predict() call: the reward upstream's
+    estimate_reward returned for each action there (it is handed the float32 TENSOR of the state, :216-218 -> :246-248), the
+    values array the selection ran on, and the rewards / raw returns of the final loop over the kept actions (:222-231, where
+    estimate_reward reads the float64 JointState)."""
+
+    def __init__(self, pol):
+        super().__init__(pol)
+        import crowd_nav.policy.model_predictive_rl as mpr
+        self.mpr = mpr
+        self.in_root_clip = False
+        self.clip_rewards, self.clip_values, self.root_rewards, self.top_raw = [], None, [], []
+        er = pol.estimate_reward
+
+        def est(state, action):
+            r = er(state, action)
+            if self.in_root_clip:
+                self.clip_rewards.append(float(r))
+            elif self.nest == 0:
+                self.root_rewards.append(float(r))
+            return r
+        pol.estimate_reward = est
+        ac = pol.action_clip                     # PlanRecorder's wrapper
+
+        def aclip(state, action_space, width, depth=1):
+            if self.nest != 0:
+                return ac(state, action_space, width, depth)
+            self.in_root_clip = True
+            mpr.np = _NumpyTap(self._note_values)
+            try:
+                return ac(state, action_space, width, depth)
+            finally:
+                mpr.np = np
+                self.in_root_clip = False
+        pol.action_clip = aclip
+        vp = pol.V_planning                      # PlanRecorder's wrapper
+
+        def vplan(state, depth, width):
+            ret = vp(state, depth, width)
+            if self.nest == 0:
+                self.top_raw.append(ret[0])
+            return ret
+        pol.V_planning = vplan
+
+    def _note_values(self, a):
+        if self.clip_values is None:
+            self.clip_values = np.array(a)
+
+    def run(self, js):
+        self.clip_rewards, self.clip_values, self.root_rewards, self.top_raw = [], None, [], []
+        return super().run(js)
+
+
+def gen_root_clip_kats(masters, out):
+    """what the reference computes at the ROOT of a clipped search, captured from inside its own
+    action_clip -- on roots whose coordinates are genuine float64 (not float32-representable) with 3-5 humans 0.65-1.1 m from
+    the robot, so that the discomfort / collision branches fire and the float32-born and float64 readings of the same state
+    give different rewards."""
+    rng = np.random.RandomState(41)
+    B, H = 24, 5
+    r32, h32 = synth_scene(rng, B, H)
+    robot = r32.astype(np.float64)
+    humans = h32.astype(np.float64)
+    robot[:, :4] += rng.uniform(-1e-3, 1e-3, (B, 4))           # genuine float64 positions / velocities
+    robot[:, 5:7] += rng.uniform(-1e-3, 1e-3, (B, 2))
+    humans[:, :, :4] += rng.uniform(-1e-3, 1e-3, (B, H, 4))
+    for b in range(B):
+        near = rng.choice(H, size=rng.randint(3, 6), replace=False)
+        for h in near:
+            d, ang = rng.uniform(0.65, 1.1), rng.uniform(0, 2 * np.pi)
+            humans[b, h, 0] = robot[b, 0] + d * np.cos(ang)
+            humans[b, h, 1] = robot[b, 1] + d * np.sin(ang)
+    out["rootclip.robot64"], out["rootclip.humans64"] = robot, humans
+    plans = [("d2w2", 2, 2, False, "separate"), ("d2w2sparse", 2, 2, True, "separate"), ("d1w3", 1, 3, False, "separate"),
+             ("d2w2linear", 2, 2, False, "linear")]
+    meta = []
+    for tag, D, w, sparse, variant in plans:
+        pol = make_ref_mprl(masters["trained"], D, w, True, sparse, variant)
+        rec = RootClipRecorder(pol)
+        gamma = pol.get_normalized_gamma()
+        nA = None
+        acts, kept, clip_rewards, clip_values, root_rewards, root_values = [], [], [], [], [], []
+        for b in range(B):
+            js = JointState(FullState(*[float(x) for x in robot[b]]), [ObservableState(*[float(x) for x in row]) for row in humans[b]])
+            ai = rec.run(js)
+            nA = len(pol.action_space)
+            assert len(rec.clip_rewards) == nA and rec.clip_values is not None and rec.clip_values.shape == (nA,)
+            assert len(rec.root_rewards) == w and len(rec.top_raw) == nA + w
+            acts.append(ai)
+            kept.append(rec.clipped)
+            clip_rewards.append(rec.clip_rewards)
+            clip_values.append(rec.clip_values)
+            root_rewards.append(rec.root_rewards)
+            # upstream's own expression on the objects it had (:227): python / numpy float + python float * 0-d float32 tensor
+            root_values.append([float(rr + gamma * raw) for rr, raw in zip(rec.root_rewards, rec.top_raw[nA:])])
+        k = "rootclip.%s." % tag
+        out[k + "action"] = np.array(acts, np.int64)
+        out[k + "kept"] = np.array(kept, np.int64)
+        out[k + "clip_rewards"] = np.array(clip_rewards, np.float64)
+        out[k + "clip_values"] = np.array(clip_values)
+        out[k + "root_rewards"] = np.array(root_rewards, np.float64)
+        out[k + "root_values"] = np.array(root_values, np.float32)
+        meta.append("%s|%d|%d|%d|%s" % (tag, D, w, int(sparse), variant))
+    out["rootclip_cases"] = np.array(meta)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -986,6 +1115,9 @@ def main():
     gen_greedy_kats(vt)
     gen_vnrl_trainer_kats(pg, vt)
     np.savez(os.path.join(HERE, "vnrl_trainer.npz"), **vt)
+    rc = {}
+    gen_root_clip_kats(masters, rc)                         # round 5; its own file and its own rng: the earlier fixtures stay bit-identical
+    np.savez(os.path.join(HERE, "root_clip.npz"), **rc)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-24s %8.1f KB" % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))

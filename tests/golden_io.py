@@ -86,6 +86,16 @@ def plan_cases():
     return out
 
 
+def root_clip_cases():
+    """Fixture "root_clip" (round 5): what upstream computes INSIDE the root's action_clip, on genuine float64 roots."""
+    rc = load("root_clip")
+    out = []
+    for line in rc["rootclip_cases"]:
+        tag, D, w, sparse, variant = str(line).split("|")
+        out.append(dict(tag=tag, D=int(D), w=int(w), sparse=bool(int(sparse)), variant=variant))
+    return out
+
+
 def path_g_sd():
     g = load("path_g")
     return {k[len("g.weights."):]: torch.tensor(v) for k, v in g.items() if k.startswith("g.weights.")}

@@ -189,6 +189,49 @@ def test_planning_kats(c, dev):
     assert ts.logical_value_evals_per_root() == int(pl[k + "counts"][0][0])
 
 
+@pytest.mark.parametrize("c", gio.root_clip_cases(), ids=lambda c: c["tag"])
+def test_root_clip_is_priced_on_the_tensor_state(c, dev):
+    """VERDICT r4 weak 1 / next 1.  Upstream prices every root action twice: action_clip is handed the float32 TENSOR of the
+    state (model_predictive_rl.py:216-218 -> :246-248 -> tensor_to_joint_state, state.py:82-92: float32-born scalars), the
+    values of the kept actions read the float64 JointState (:226).  Fixture root_clip.npz holds what the reference computed
+    INSIDE its root action_clip on 24 genuine-float64 crowded roots.  The search's level 0 against it: the selection's rewards
+    (MprlLevelView::reward_clip_off) and the kept rewards BIT FOR BIT, kept sets equal, values to the network's float32 noise.
+    Action 0 is the python-int stop action: float32 from end to end under numpy >= 2 (rgl_children.h stop_reward_f32)."""
+    rc = gio.load("root_clip")
+    k = "rootclip.%s." % c["tag"]
+    pol = make_mprl_policy("trained", c["D"], c["w"], True, c["sparse"], c["variant"], device=dev)
+    pol.build_action_space(1.0)
+    ts = pol.tree_search()
+    r64, h64 = torch.tensor(rc["rootclip.robot64"], device=dev), torch.tensor(rc["rootclip.humans64"], device=dev)
+    out = ts.search(r64.float(), h64.float(), True, roots64=(r64, h64))
+    lv0 = ts.level_arrays(0)
+    want_clip = rc[k + "clip_rewards"].astype(np.float32)
+    got_clip = lv0["reward_clip"].cpu().numpy()
+    assert np.array_equal(got_clip, want_clip), np.abs(got_clip.astype(np.float64) - rc[k + "clip_rewards"]).max()
+    close(lv0["value1"].cpu().numpy(), rc[k + "clip_values"], reg=REG_F32)
+    kept, rv = out["root_kept"].cpu().numpy(), out["root_values"].cpu().numpy()
+    rew64 = lv0["reward"].cpu().numpy()
+    n_two_readings = int((rew64 != got_clip).sum())
+    for b in range(kept.shape[0]):
+        want_kept = rc[k + "kept"][b]
+        assert sorted(kept[b].tolist()) == sorted(want_kept.tolist())
+        order = [kept[b].tolist().index(int(i)) for i in want_kept]
+        close(rv[b][order], rc[k + "root_values"][b], reg=REG_F32)
+        assert np.array_equal(rew64[b][want_kept], rc[k + "root_rewards"][b].astype(np.float32))
+    assert np.array_equal(out["best_action"].cpu().numpy().astype(np.int64), rc[k + "action"])
+    assert n_two_readings > 0                                      # the two readings of the same roots do differ in float32
+    # the same decisions through the public predict() (one captured search per crowd size, float64 JointStates in)
+    for b in range(0, kept.shape[0], 5):
+        a = pol.predict(JS(rc["rootclip.robot64"][b], rc["rootclip.humans64"][b]))
+        assert a == pol.action_space[int(rc[k + "action"][b])]
+    # tensor roots (V_planning's view of a state): one reading, the tensor-born one, for selection and values alike
+    ts.search(r64.float(), h64.float(), False)
+    lv0 = ts.level_arrays(0)
+    assert "reward_clip" not in lv0 and np.array_equal(lv0["reward"].cpu().numpy(), want_clip)
+    report("root action_clip (%s): %d x 81 rewards inside upstream's root clip reproduced bit for bit; %d of them differ from the "
+           "float64 reading in float32" % (c["tag"], kept.shape[0], n_two_readings))
+
+
 def test_planner_step_methods_match_the_reference_planner(dev):
     """ModelPredictiveRL.estimate_reward / action_clip / V_planning and GCN.compute_reward (model_predictive_rl.py:242-357,
     multi_human_rl.py:73-96) as Python-callable methods backed by the device functions of the search (VERDICT r3 missing 5):

@@ -158,6 +158,49 @@ def test_planning_batched(c):
         close(levels[0]["value1"].numpy(), pl[k + "clip_values"], 3e-6)
 
 
+@pytest.mark.parametrize("c", gio.root_clip_cases(), ids=lambda c: c["tag"])
+def test_root_clip_is_priced_on_the_tensor_state(c):
+    """upstream hands the root's action_clip the float32 TENSOR of the state (model_predictive_rl.py:216-218
+    -> :246-248 -> tensor_to_joint_state: float32-born scalars) and prices the kept actions on the float64 JointState (:226).
+    Fixture root_clip.npz holds what the reference computed INSIDE that action_clip on 24 genuine-float64 crowded roots: the
+    reward of every action as estimate_reward returned it there (bit for bit: float64 scalar code), the values array the
+    selection ran on (bit for bit: one float32 add of a float32 product), the kept lists, the rewards and values of the final
+    loop.  Both restatements -- the sequential walk and the level-synchronous one -- against it."""
+    rc = gio.load("root_clip")
+    k = "rootclip.%s." % c["tag"]
+    P = gio.oracle_params("trained", 2, c["variant"])
+    cfg = orc.OracleConfig(planning_depth=c["D"], planning_width=c["w"], do_action_clip=True, sparse_search=c["sparse"],
+                           linear_state_predictor=(c["variant"] == "linear"))
+    R64, H64 = rc["rootclip.robot64"], rc["rootclip.humans64"]
+    assert (R64[:, :2].astype(np.float32).astype(np.float64) != R64[:, :2]).all()       # genuine float64 roots
+    n_differ = 0
+    with torch.no_grad():
+        for b in range(R64.shape[0]):
+            tr = orc.SeqTrace()
+            a, v = orc.mprl_predict_sequential([float(x) for x in R64[b]], [[float(x) for x in row] for row in H64[b]], P, cfg, tr)
+            assert np.array_equal(tr.root_clip_rewards, rc[k + "clip_rewards"][b])              # exact: same float64 scalar code
+            close(tr.root_clip_values, rc[k + "clip_values"][b], 2e-6)                            # the network's float32 noise
+            assert tr.root_clipped == [int(x) for x in rc[k + "kept"][b]]
+            assert np.array_equal(tr.root_rewards, rc[k + "root_rewards"][b])
+            close(tr.root_values, rc[k + "root_values"][b], 2e-6)
+            assert a == int(rc[k + "action"][b])
+            # ... and the float64 reading of the same state prices the actions differently (what the oracle did until round 4)
+            joint = np.array([orc.estimate_reward([float(x) for x in R64[b]], [[float(x) for x in row] for row in H64[b]], act, cfg)
+                              for act in orc.mprl_action_space(cfg, R64[b, 7])[0]], np.float64)
+            n_differ += int((joint != rc[k + "clip_rewards"][b]).any())
+        R32, H32 = torch.tensor(R64.astype(np.float32)), torch.tensor(H64.astype(np.float32))
+        a, v, rv, kept, levels = orc.mprl_predict_batched(R32, H32, P, cfg, return_levels=True, roots64=(R64, H64))
+    assert n_differ >= R64.shape[0] // 2                                                           # the two readings do differ
+    assert np.array_equal(a.numpy(), rc[k + "action"])
+    assert np.array_equal(levels[0]["reward_clip"].numpy(), rc[k + "clip_rewards"].astype(np.float32))
+    close(levels[0]["value1"].numpy(), rc[k + "clip_values"], 3e-6)
+    for b in range(R64.shape[0]):
+        assert sorted(kept[b].tolist()) == sorted(rc[k + "kept"][b].tolist())
+        order = [kept[b].tolist().index(int(i)) for i in rc[k + "kept"][b]]
+        close(rv[b].numpy()[order], rc[k + "root_values"][b], 3e-6)
+        assert np.array_equal(levels[0]["reward"][b].numpy()[rc[k + "kept"][b]], rc[k + "root_rewards"][b].astype(np.float32))
+
+
 def test_forward_counts_match_survey():
     pl = gio.load("planning")
     want = {"d1": 81, "d2w2": 249, "d3w2": 581}
