@@ -34,7 +34,10 @@ def scene_flops(N):
 
 
 dev = torch.device("cuda:0")
+ONLY_H = os.environ.get("RGL_GCN_TRACE_ONLY_H")          # counter passes: one crowd size, so per-kernel averages mean one shape
 for H, B in ((5, 2048), (19, 2048)):
+    if ONLY_H and int(ONLY_H) != H:
+        continue
     pol = make_gcn_policy(device=dev)
     robot, humans = seeded_scenes(11, B, H)
     r, h = robot.to(dev), humans.to(dev)

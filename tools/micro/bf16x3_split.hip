@@ -1,0 +1,413 @@
+// Micro-benchmark: can an f32-EQUIVALENT contraction run on the gfx950 matrix pipe faster than the f32 MFMA?
+//
+// The workload is the value head of the children kernel as it sits in rgl_fused.hip: a wave owns a 16-child tile, the activations
+// are the B operand (column = my lane's child, the D registers of the previous layer ARE the next B operand), the weights are A
+// fragments read from an LDS image every wave shares; chain 32 -> 32 -> 100 -> 100 with bias + ReLU (the 100 -> 1 row is noise).
+//
+//   mode 0  f32      v_mfma_f32_16x16x4_f32, exact fp32 operands (what carries `value` today)
+//   mode 1  f16x3    two f16 halves (RNE, power-of-two column scale), 3 terms          -- the 22/23-bit mode of round 3
+//   mode 2  bf16x6   three bf16 pieces (exact 8+8+8-bit truncation split, no scaling), 6 terms: hh hm mh hl mm lh
+//   mode 3  bf16x9   three bf16 pieces, all 9 terms
+//
+// and NB = 1 | 2 child tiles per wave per weight-fragment read (register blocking over N: halves the LDS traffic per tile).
+// Reported per mode: ns per 16-child tile per wave (4 waves / CU and 8 waves / CU, all 256 CUs), the same as a fraction of
+// mode 0, LDS bytes of the weight image, and the error of the chain's output against a float64 host reference (max and rms,
+// relative to the largest output) on torch-Linear-like random weights.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 bf16x3_split.hip -o bf16x3_split
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kLayers = 3;
+__host__ __device__ constexpr int in_of(int l) { return l == 0 ? 32 : (l == 1 ? 32 : 100); }
+__host__ __device__ constexpr int out_of(int l) { return l == 0 ? 32 : 100; }
+__host__ __device__ constexpr int tiles(int n) { return (n + 15) / 16; }
+__host__ __device__ constexpr int pieces_of(int mode) { return mode == 0 ? 1 : (mode == 1 ? 2 : 3); }
+// 16-byte units (one lane's fragment) per layer image: mode 0 -> floats [ot][kstep = (t, r)][lane] (4 B units, counted in floats)
+__host__ __device__ constexpr int layer_floats(int mode, int l) {
+    const int IT = tiles(in_of(l)), OT = tiles(out_of(l));
+    return mode == 0 ? OT * IT * 4 * 64 : OT * ((IT + 1) / 2) * pieces_of(mode) * 64 * 4;
+}
+__host__ __device__ constexpr int image_floats(int mode) {
+    int s = 0;
+    for (int l = 0; l < kLayers; ++l) s += layer_floats(mode, l) + 16 * tiles(out_of(l));      // + bias per out feature
+    return s;
+}
+
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// ---- mode 0 -------------------------------------------------------------------------------------------------------------------
+template <int IN, int OUT, int NB>
+__device__ __forceinline__ void layer_f32(const float* img, const f32x4 (&in)[NB][tiles(IN)], f32x4 (&out)[NB][tiles(OUT)], int lane) {
+    constexpr int IT = tiles(IN), OT = tiles(OUT);
+    const float* bias = img + OT * IT * 4 * 64;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+        f32x4 acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = zero4();
+#pragma unroll
+        for (int t = 0; t < IT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float w = img[((ot * IT + t) * 4 + r) * 64 + lane];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, in[b][t][r], acc[b], 0, 0, 0);
+            }
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * (lane >> 4)]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[b][ot][r] = fmaxf(acc[b][r] + bb[r], 0.f);
+    }
+}
+
+// ---- mode 1: two f16 halves, per-column power-of-two scale (as rgl_mlp_chain.h) -------------------------------------------------
+__device__ __forceinline__ float kgroups_max(float m) {       // max over the four lanes (n, q = 0..3) that hold one column
+    m = fmaxf(m, __shfl_xor(m, 16));
+    return fmaxf(m, __shfl_xor(m, 32));
+}
+__device__ __forceinline__ void pow2_scale(float m, float& sc, float& inv) {
+    const unsigned E = __float_as_uint(m) >> 23;
+    const bool tiny = E < 32u || E > 254u;
+    sc = tiny ? 1.f : __uint_as_float((263u - E) << 23);
+    inv = tiny ? 1.f : __uint_as_float((E - 9u) << 23);
+}
+template <int IN, int OUT, int NB>
+__device__ __forceinline__ void layer_f16x3(const float* img, const f32x4 (&in)[NB][tiles(IN)], f32x4 (&out)[NB][tiles(OUT)], int lane,
+                                            float inv_sw) {
+    constexpr int IT = tiles(IN), OT = tiles(OUT), NC = (IT + 1) / 2;
+    const float* bias = img + OT * NC * 2 * 64 * 4;
+    f16x8 hi[NB][NC], lo[NB][NC];
+    float post[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float m = 0.f;
+#pragma unroll
+        for (int t = 0; t < IT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(in[b][t][r]));
+        float sc, inv;
+        pow2_scale(kgroups_max(m), sc, inv);
+        post[b] = inv * inv_sw;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int t = 2 * c + (p >> 1), r0 = 2 * (p & 1);
+                f32x2 x = f32x2{0.f, 0.f};
+                if (t < IT) x = f32x2{in[b][t < IT ? t : 0][r0], in[b][t < IT ? t : 0][r0 + 1]} * sc;
+                const f16x2 hh = __builtin_convertvector(x, f16x2);
+                const f16x2 ll = __builtin_convertvector(x - __builtin_convertvector(hh, f32x2), f16x2);
+                hi[b][c][2 * p] = hh[0]; hi[b][c][2 * p + 1] = hh[1];
+                lo[b][c][2 * p] = ll[0]; lo[b][c][2 * p + 1] = ll[1];
+            }
+    }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+        f32x4 acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = zero4();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(&img[(((ot * NC + c) * 2 + 0) * 64 + lane) * 4]);
+            const f16x8 wl = *reinterpret_cast<const f16x8*>(&img[(((ot * NC + c) * 2 + 1) * 64 + lane) * 4]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, hi[b][c], acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, lo[b][c], acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hi[b][c], acc[b], 0, 0, 0);
+            }
+        }
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * (lane >> 4)]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[b][ot][r] = fmaxf(fmaf(acc[b][r], post[b], bb[r]), 0.f);
+    }
+}
+
+// ---- modes 2, 3: three bf16 pieces by truncation; x = hi + mid + lo EXACTLY (8 + 8 + 8 significand bits, f32's exponent range) ---
+__device__ __forceinline__ unsigned pack_hi16(float a, float b) {       // {upper 16 bits of a, upper 16 bits of b} -> one dword
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+struct Split3 { bf16x8 h, m, l; };
+template <int IT, int C>
+__device__ __forceinline__ Split3 split3(const f32x4 (&in)[IT]) {
+    u32x4 H, M, L;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int t = 2 * C + (p >> 1), r0 = 2 * (p & 1);
+        float x0 = 0.f, x1 = 0.f;
+        if (t < IT) { x0 = in[t < IT ? t : 0][r0]; x1 = in[t < IT ? t : 0][r0 + 1]; }
+        const float h0 = __uint_as_float(__float_as_uint(x0) & 0xffff0000u), h1 = __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+        const float r0_ = x0 - h0, r1_ = x1 - h1;                                      // exact
+        const float m0 = __uint_as_float(__float_as_uint(r0_) & 0xffff0000u), m1 = __uint_as_float(__float_as_uint(r1_) & 0xffff0000u);
+        const float l0 = r0_ - m0, l1 = r1_ - m1;                                      // exact, <= 8 significant bits left
+        H[p] = pack_hi16(x0, x1);
+        M[p] = pack_hi16(r0_, r1_);
+        L[p] = pack_hi16(l0, l1);
+    }
+    Split3 s;
+    s.h = __builtin_bit_cast(bf16x8, H);
+    s.m = __builtin_bit_cast(bf16x8, M);
+    s.l = __builtin_bit_cast(bf16x8, L);
+    return s;
+}
+template <int IN, int OUT, int NB, bool NINE>
+__device__ __forceinline__ void layer_bf16(const float* img, const f32x4 (&in)[NB][tiles(IN)], f32x4 (&out)[NB][tiles(OUT)], int lane) {
+    constexpr int IT = tiles(IN), OT = tiles(OUT), NC = (IT + 1) / 2;
+    const float* bias = img + OT * NC * 3 * 64 * 4;
+    Split3 s[NB][NC];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        s[b][0] = split3<IT, 0>(in[b]);
+        if constexpr (NC > 1) s[b][1] = split3<IT, 1>(in[b]);
+        if constexpr (NC > 2) s[b][2] = split3<IT, 2>(in[b]);
+        if constexpr (NC > 3) s[b][3] = split3<IT, 3>(in[b]);
+    }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+        f32x4 acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = zero4();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&img[(((ot * NC + c) * 3 + 0) * 64 + lane) * 4]);
+            const bf16x8 wm = *reinterpret_cast<const bf16x8*>(&img[(((ot * NC + c) * 3 + 1) * 64 + lane) * 4]);
+            const bf16x8 wl = *reinterpret_cast<const bf16x8*>(&img[(((ot * NC + c) * 3 + 2) * 64 + lane) * 4]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {                     // small terms first
+                const Split3& a = s[b][c];
+                if constexpr (NINE) {
+                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, a.l, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, a.m, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, a.l, acc[b], 0, 0, 0);
+                }
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, a.h, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, a.m, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, a.l, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, a.h, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, a.m, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, a.h, acc[b], 0, 0, 0);
+            }
+        }
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * (lane >> 4)]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[b][ot][r] = fmaxf(acc[b][r] + bb[r], 0.f);
+    }
+}
+
+template <int MODE, int L, int NB>
+__device__ __forceinline__ void layer(const float* img, const f32x4 (&in)[NB][tiles(in_of(L))], f32x4 (&out)[NB][tiles(out_of(L))],
+                                      int lane, const float* inv_sw) {
+    if constexpr (MODE == 0) layer_f32<in_of(L), out_of(L), NB>(img, in, out, lane);
+    else if constexpr (MODE == 1) layer_f16x3<in_of(L), out_of(L), NB>(img, in, out, lane, inv_sw[L]);
+    else layer_bf16<in_of(L), out_of(L), NB, MODE == 3>(img, in, out, lane);
+}
+
+struct Scales { float inv_sw[kLayers]; };
+
+// x_in: [n_tiles][16 children][32] fp32 or null (synthetic inputs); y_out: [n_tiles][16][100] or null (a checksum per thread instead)
+template <int MODE, int NB>
+__global__ __launch_bounds__(512) void head_chain(const float* __restrict__ image, const float* __restrict__ x_in, float* __restrict__ y_out,
+                                                  float* __restrict__ sink, int tiles_per_wave, Scales sc) {
+    extern __shared__ float lds[];
+    for (int i = threadIdx.x; i < image_floats(MODE); i += blockDim.x) lds[i] = image[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    float check = 0.f;
+    for (int it = 0; it < tiles_per_wave; it += NB) {
+        f32x4 x[NB][2];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * t + 4 * q + r;
+                    const long long tile = (long long)wave * tiles_per_wave + it + b;
+                    x[b][t][r] = x_in ? x_in[(tile * 16 + n) * 32 + f] : fmaxf(0.f, __sinf((float)(f + 3 * n + it + b)) * 0.7f + 0.2f);
+                }
+        f32x4 h1[NB][2], h2[NB][7], h3[NB][7];
+        const float* img = lds;
+        layer<MODE, 0, NB>(img, x, h1, lane, sc.inv_sw);
+        img += layer_floats(MODE, 0) + 16 * tiles(out_of(0));
+        layer<MODE, 1, NB>(img, h1, h2, lane, sc.inv_sw);
+        img += layer_floats(MODE, 1) + 16 * tiles(out_of(1));
+        layer<MODE, 2, NB>(img, h2, h3, lane, sc.inv_sw);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int t = 0; t < 7; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * t + 4 * q + r;
+                    if (y_out) {
+                        const long long tile = (long long)wave * tiles_per_wave + it + b;
+                        if (f < 100) y_out[(tile * 16 + n) * 100 + f] = h3[b][t][r];
+                    } else {
+                        check += h3[b][t][r];
+                    }
+                }
+    }
+    if (!y_out) sink[blockIdx.x * blockDim.x + threadIdx.x] = check;
+}
+
+// ---- host: weights, images, float64 reference -------------------------------------------------------------------------------
+static float frand() { return (float)rand() / (float)RAND_MAX * 2.f - 1.f; }
+static float bf_trunc(float x) { unsigned u; memcpy(&u, &x, 4); u &= 0xffff0000u; memcpy(&x, &u, 4); return x; }
+static unsigned short bf_bits(float x) { unsigned u; memcpy(&u, &x, 4); return (unsigned short)(u >> 16); }
+static unsigned short f16_bits(float x) { _Float16 h = (_Float16)x; unsigned short b; memcpy(&b, &h, 2); return b; }
+static float f16_val(float x) { return (float)(_Float16)x; }
+
+struct Net { std::vector<float> W[kLayers], b[kLayers]; };      // W[l][in * OUT + out]
+
+static std::vector<float> build_image(const Net& net, int mode, Scales* sc) {
+    std::vector<float> img(image_floats(mode), 0.f);
+    size_t off = 0;
+    for (int l = 0; l < kLayers; ++l) {
+        const int IN = in_of(l), OUT = out_of(l), IT = tiles(IN), OT = tiles(OUT), NC = (IT + 1) / 2;
+        auto w_at = [&](int in, int out) { return (in < IN && out < OUT) ? net.W[l][in * OUT + out] : 0.f; };
+        float sw = 1.f;
+        if (mode == 1) {                        // power-of-two scale bringing max |W| into [512, 1024)
+            float m = 0.f;
+            for (float w : net.W[l]) m = fmaxf(m, fabsf(w));
+            int e; frexpf(m, &e);
+            sw = ldexpf(1.f, 10 - e);
+            sc->inv_sw[l] = 1.f / sw;
+        }
+        float* base = img.data() + off;
+        if (mode == 0) {
+            for (int ot = 0; ot < OT; ++ot)
+                for (int t = 0; t < IT; ++t)
+                    for (int r = 0; r < 4; ++r)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int m = lane & 15, q = lane >> 4;
+                            base[((ot * IT + t) * 4 + r) * 64 + lane] = w_at(16 * t + 4 * q + r, 16 * ot + m);
+                        }
+        } else {
+            const int NP = pieces_of(mode);
+            unsigned short* hb = reinterpret_cast<unsigned short*>(base);
+            for (int ot = 0; ot < OT; ++ot)
+                for (int c = 0; c < NC; ++c)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int m = lane & 15, q = lane >> 4, t = 2 * c + e / 4;
+                            const float w = (t < IT ? w_at(16 * t + 4 * q + e % 4, 16 * ot + m) : 0.f) * sw;
+                            unsigned short pc[3];
+                            if (mode == 1) {
+                                const float hi = f16_val(w);
+                                pc[0] = f16_bits(w); pc[1] = f16_bits(w - hi);
+                            } else {
+                                const float hi = bf_trunc(w), r1 = w - hi, mid = bf_trunc(r1), lo = r1 - mid;
+                                pc[0] = bf_bits(hi); pc[1] = bf_bits(mid); pc[2] = bf_bits(lo);
+                            }
+                            for (int p = 0; p < NP; ++p) hb[((((size_t)(ot * NC + c) * NP + p) * 64 + lane) * 8) + e] = pc[p];
+                        }
+        }
+        off += layer_floats(mode, l);
+        for (int o = 0; o < 16 * OT; ++o) img[off + o] = o < OUT ? net.b[l][o] : 0.f;
+        off += 16 * OT;
+    }
+    return img;
+}
+
+template <int MODE, int NB>
+static void run_mode(const char* name, const Net& net, const std::vector<float>& x, const std::vector<double>& ref, int n_tiles) {
+    Scales sc{};
+    const std::vector<float> img = build_image(net, MODE, &sc);
+    float *d_img, *d_x, *d_y, *d_sink;
+    (void)hipMalloc(&d_img, img.size() * 4);
+    (void)hipMemcpy(d_img, img.data(), img.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMalloc(&d_x, x.size() * 4);
+    (void)hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMalloc(&d_y, (size_t)n_tiles * 16 * 100 * 4);
+    (void)hipMalloc(&d_sink, 256 * 512 * 4);
+    const size_t lds = img.size() * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_chain<MODE, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // accuracy: n_tiles tiles over n_tiles / 8 waves
+    hipLaunchKernelGGL((head_chain<MODE, NB>), dim3(n_tiles / 8 / 4), dim3(256), lds, 0, d_img, d_x, d_y, d_sink, 8, sc);
+    std::vector<float> y((size_t)n_tiles * 16 * 100);
+    (void)hipMemcpy(y.data(), d_y, y.size() * 4, hipMemcpyDeviceToHost);
+    double mx = 0, ss = 0, scale = 0;
+    for (size_t i = 0; i < y.size(); ++i) scale = fmax(scale, fabs(ref[i]));
+    for (size_t i = 0; i < y.size(); ++i) { const double d = fabs((double)y[i] - ref[i]); mx = fmax(mx, d); ss += d * d; }
+    // timing
+    double ns[2];
+    for (int wi = 0; wi < 2; ++wi) {
+        const int threads = wi == 0 ? 256 : 512, tpw = 512;
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        float best = 1e9f;
+        for (int rep = 0; rep < 4; ++rep) {
+            (void)hipEventRecord(e0);
+            hipLaunchKernelGGL((head_chain<MODE, NB>), dim3(256), dim3(threads), lds, 0, d_img, nullptr, nullptr, d_sink, tpw, sc);
+            (void)hipEventRecord(e1);
+            (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            if (rep > 0 && ms < best) best = ms;
+        }
+        ns[wi] = best * 1e6 / tpw;           // ns per tile per wave stream
+    }
+    const hipError_t err = hipGetLastError();
+    printf("%-8s NB=%d  image %6.1f KB   ns/tile/wave: %7.1f (4 waves/CU)  %7.1f (8 waves/CU)   chip tiles/us: %6.1f %6.1f   "
+           "err vs f64: max %.2e rms %.2e (rel. to max |y| = %.3f)%s\n",
+           name, NB, lds / 1024.0, ns[0], ns[1], 1024.0 / ns[0] * 1e3, 2048.0 / ns[1] * 1e3, mx / scale,
+           sqrt(ss / y.size()) / scale, scale, err == hipSuccess ? "" : "   [HIP ERROR]");
+    (void)hipFree(d_img); (void)hipFree(d_x); (void)hipFree(d_y); (void)hipFree(d_sink);
+}
+
+int main() {
+    srand(7);
+    Net net;
+    for (int l = 0; l < kLayers; ++l) {
+        const int IN = in_of(l), OUT = out_of(l);
+        const float k = 1.f / sqrtf((float)IN);
+        net.W[l].resize(IN * OUT);
+        net.b[l].resize(OUT);
+        for (auto& w : net.W[l]) w = frand() * k;
+        for (auto& b : net.b[l]) b = frand() * k;
+    }
+    const int n_tiles = 512;                          // 8192 children for the accuracy check
+    std::vector<float> x((size_t)n_tiles * 16 * 32);
+    for (auto& v : x) v = fmaxf(0.f, frand() * 1.5f + 0.3f);
+    std::vector<double> ref((size_t)n_tiles * 16 * 100);
+    for (int i = 0; i < n_tiles * 16; ++i) {
+        double a[100], b2[100];
+        for (int f = 0; f < 32; ++f) a[f] = x[(size_t)i * 32 + f];
+        for (int l = 0; l < kLayers; ++l) {
+            const int IN = in_of(l), OUT = out_of(l);
+            for (int o = 0; o < OUT; ++o) {
+                double s = net.b[l][o];
+                for (int k = 0; k < IN; ++k) s += a[k] * (double)net.W[l][k * OUT + o];
+                b2[o] = s > 0 ? s : 0;
+            }
+            for (int o = 0; o < OUT; ++o) a[o] = b2[o];
+        }
+        for (int o = 0; o < 100; ++o) ref[(size_t)i * 100 + o] = a[o];
+    }
+    printf("value-head chain 32 -> 32 -> 100 -> 100 (bias + ReLU), one 16-child tile per wave pass; f32 MFMA cycles per tile = 7904\n");
+    run_mode<0, 1>("f32", net, x, ref, n_tiles);
+    run_mode<0, 2>("f32", net, x, ref, n_tiles);
+    run_mode<1, 1>("f16x3", net, x, ref, n_tiles);
+    run_mode<1, 2>("f16x3", net, x, ref, n_tiles);
+    run_mode<2, 1>("bf16x6", net, x, ref, n_tiles);
+    run_mode<2, 2>("bf16x6", net, x, ref, n_tiles);
+    run_mode<3, 1>("bf16x9", net, x, ref, n_tiles);
+    run_mode<3, 2>("bf16x9", net, x, ref, n_tiles);
+    return 0;
+}
