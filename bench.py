@@ -396,16 +396,21 @@ class Leg:
     def timed(self, steps, warmup, init_steps):
         """`init_steps` set-up steps (code objects, workspace, RCCL channels), `warmup` untimed steps, then exactly `steps`
         timed steps between fences; returns (wall seconds MAX over ranks, sorted per-step device ms of this rank)."""
-        cold = None if STUB else [torch.cuda.Event(enable_timing=True) for _ in range(min(init_steps, 10) + 1)]
+        # one event in front of each of the first (up to) 10 set-up steps and one behind the last of them: every event in the list
+        # is recorded whatever `init_steps` is (ADVICE r4: with 4..10 set-up steps the last one never was, and elapsed_time raised)
+        n_cold = min(init_steps, 10)
+        cold = None if STUB or n_cold == 0 else [torch.cuda.Event(enable_timing=True) for _ in range(n_cold + 1)]
         for i in range(init_steps):
-            if cold and i < len(cold):
+            if cold and i <= n_cold:
                 cold[i].record()
             self.step()
+        if cold and init_steps == n_cold:
+            cold[n_cold].record()
         self.drain()
         self.fence()
         # steps 2.. of the set-up phase (the very first ones also pay for code objects and workspaces): a cold device's step time
-        self.cold_ms = (sorted(cold[i].elapsed_time(cold[i + 1]) for i in range(2, len(cold) - 1))
-                        if cold and len(cold) > 4 else None)
+        self.cold_ms = (sorted(cold[i].elapsed_time(cold[i + 1]) for i in range(2, n_cold))
+                        if cold and n_cold > 3 else None)
         for _ in range(warmup):
             self.step()
         self.drain()
@@ -750,6 +755,10 @@ def main():
                                                             ("%d root scenes per GPU" % B) if main_leg[0] == "weak" else
                                                             ("%d root scenes in total over %d GPU(s)" % (total_roots, world))),
                    "roots_per_gpu": B, "total_roots": total_roots, "logical_value_evals_per_root": per_root, "init_steps": INIT_STEPS,
+                   # what changed in HOW the line is measured, so that round-over-round deltas can be read: 1 = rounds
+                   # 1-3 (3 set-up steps, event marks inside the timed loop); 2 = round 4 on (40 untimed set-up steps in front of
+                   # --warmup so the device holds its steady clock; per-step event marks in a second pass after the timed region)
+                   "methodology_revision": 2,
                    "executed_graph_forwards_per_root": sum(W ** l for l in range(args.depth)) * (A + 1),
                    "decisions_per_s": total_roots * args.steps / elapsed,
                    "weights": "fixture F1 trained-like (tests/golden/weights_trained.npz)",

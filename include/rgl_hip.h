@@ -354,7 +354,9 @@ int mprl_estimate_reward_f32(const MprlPlanner* planner, const float* robot, con
 /* action_clip's selection on its own (model_predictive_rl.py:242-269; ABI 5): value1[p][a] = reward + gamma_bar * child_value
  * (each op rounded to fp32), keep[p][0..W-1] = the planning_width best actions of parent p in descending one-step value
  * (ties: lower index first; sparse_search: one action per action_groups id) -- W = num_actions and keep = 0..A-1 without
- * do_action_clip.  value1 device [P][A], keep device [P][W] int32. */
+ * do_action_clip.  value1 device [P][A], keep device [P][W] int32.  A sparse search whose table has FEWER distinct group ids than
+ * planning_width fills the tail of a row by repeating the last action kept (rows have a fixed width; upstream returns the shorter
+ * list there: the first <number of distinct groups> entries of the row are that list). */
 int mprl_action_clip_f32(const MprlPlanner* planner, const float* reward, const float* child_value, int P,
                          float* value1, int* keep, rgl_stream_t stream);
 

@@ -535,7 +535,13 @@ extern "C" int mprl_tree_search_traced_f32(const MprlPlanner* planner, const flo
     if (D < 1 || D > 8) return RGL_ERR_BAD_SHAPE;
     hipEvent_t ev[3 * 8 + 1];
     const int n = 3 * D + 1;
-    for (int i = 0; i < n; ++i) RGL_HIP_TRY(hipEventCreate(&ev[i]));
+    for (int i = 0; i < n; ++i) {
+        const hipError_t e = hipEventCreate(&ev[i]);
+        if (e != hipSuccess) {                                   // give back what was created
+            for (int k = 0; k < i; ++k) (void)hipEventDestroy(ev[k]);
+            return (int)e;
+        }
+    }
     int rc = tree_search(planner, robot, humans, B, H, roots_are_joint_states, workspace, workspace_bytes, best_action, best_value,
                          root_values, root_kept, stream, reinterpret_cast<void* const*>(ev));
     if (rc == RGL_OK) rc = (int)hipEventSynchronize(ev[3 * D]);

@@ -345,7 +345,13 @@ class ModelPredictiveRL(Policy):
                 ts = TreeSearch(ts.value_estimator, ts.state_predictor, ts.actions_np, ts.groups_np, ts.kinematics, ts.time_step,
                                 ts.gamma_bar, ts.planning_depth, width, True, ts.sparse_search, ts.contraction_dtype)
             value1, keep = ts.action_clip(o["reward"], child_value, width)
-        return [action_space[i] for i in keep[0].tolist()]
+        kept = keep[0].tolist()
+        if ts.sparse_search and ts.groups_np is not None:
+            # fewer distinct groups than `width`: upstream's walk ends with the shorter list (:252-263); the device step pads its
+            # fixed-width row by repeating the last kept action -- cut the padding off again
+            n_groups = len(set(int(g) for g in ts.groups_np))
+            kept = kept[:min(len(kept), n_groups)]
+        return [action_space[i] for i in kept]
 
     def V_planning(self, state, depth, width):
         """model_predictive_rl.py:271-302: (value (1,1) tensor, trajectory [(state, action, reward), ...]) of planning `depth`
@@ -540,6 +546,11 @@ class GCN(Policy):
         """multi_human_rl.py:73-96 for one (next robot state, next human states) pair: the END-point clearance reward the one-step
         search scores every action with, evaluated by the search's own device step (gcn_prepare_f32, float64) -- the pair is
         handed over as a scene that a zero action and resting humans leave where it is."""
+        if len(humans) == 0:
+            # no crowd: upstream's loop body never runs -- the goal test decides alone (multi_human_rl.py:88-95; dmin stays inf).
+            # The device step needs at least one human row, and there is nothing to evaluate on a device here.
+            reaching = np.linalg.norm((nav.px - nav.gx, nav.py - nav.gy)) < nav.radius
+            return 1 if reaching else 0
         row = [nav.px, nav.py, 0.0, 0.0, nav.radius, nav.gx, nav.gy, getattr(nav, "v_pref", 1.0), getattr(nav, "theta", 0.0)]
         hrows = [[h.px, h.py, 0.0, 0.0, h.radius] for h in humans]
         r64 = torch.tensor([row], dtype=torch.float64, device=self.device)

@@ -61,9 +61,11 @@ class _Batch(object):
         return _Batch(fields=[self._fields[i] for i in which], idx=self._idx)
 
     def shapes(self):
+        """Batch shapes, plus -- indexed batches -- the extent of the fields the gathers read from (a recorded index_select is
+        only valid for the source extent it was recorded with)."""
         if self._tensors is not None:
             return tuple(tuple(t.shape) for t in self._tensors)
-        return tuple((int(self._idx.shape[0]),) + tuple(f.shape[1:]) for f in self._fields)
+        return tuple((int(self._idx.shape[0]),) + tuple(f.shape[1:]) for f in self._fields) + (int(self._fields[0].shape[0]),)
 
     def tensors(self):
         if self._tensors is not None:
@@ -92,10 +94,11 @@ class _Batch(object):
 
 
 class _CapturedStep(object):
-    """`fn(*static inputs)` captured into a hipGraph after two warm-up runs on a side stream; `run(batch)` copies the batch into
-    the static inputs and replays.  `signature` = what the capture baked in (shapes, optimizer / module identities)."""
+    """`fn(*static inputs)` captured into a hipGraph after ONE warm-up run on a side stream (a real step: the caller counts it as
+    this batch's); `run(batch)` copies the batch into the static inputs and replays.  `signature` = what the capture baked in
+    (shapes, optimizer / module identities, the addresses of the stacked memory fields)."""
 
-    def __init__(self, fn, batch, signature, warmup_is_a_step):
+    def __init__(self, fn, batch, signature):
         self.signature = signature
         self.static, fn = batch.capture_inputs(fn)
         side = torch.cuda.Stream()
@@ -106,7 +109,6 @@ class _CapturedStep(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             fn(*self.static)                     # recorded, not executed
-        self.consumed_first = warmup_is_a_step
 
     def run(self, batch):
         batch.fill(self.static)
@@ -115,6 +117,31 @@ class _CapturedStep(object):
 
 def _stack_field(x, device):
     return x.to(device) if torch.is_tensor(x) else x
+
+
+# optimizer_str -> (class, keyword arguments of the value-side optimizer, of the predictor-side optimizer).  Upstream's choices
+# (crowd_nav/utils/trainer.py:43-61,189-197): Adam with defaults for both; SGD with momentum 0.9 for the value side and plain SGD
+# for the state predictor.  Adam is built `capturable` on a CUDA device so that its step can be recorded into the graph.
+_OPTIMIZERS = {
+    'Adam': (optim.Adam, {}, {}),
+    'SGD': (optim.SGD, {'momentum': 0.9}, {}),
+}
+
+
+def _new_optimizer(kind, module, learning_rate, capturable, predictor_side=False):
+    if kind not in _OPTIMIZERS:
+        raise NotImplementedError
+    cls, value_kw, predictor_kw = _OPTIMIZERS[kind]
+    kw = dict(predictor_kw if predictor_side else value_kw)
+    if cls is optim.Adam:
+        kw['capturable'] = capturable
+    return cls(module.parameters(), lr=learning_rate, **kw)
+
+
+def _log_learning_rate(learning_rate, modules, kind):
+    """The line upstream logs from set_learning_rate (its format is part of the contract: logs are diffed against upstream runs)."""
+    names = [name for m in modules for name, _ in m.named_parameters()]
+    logging.info('Lr: {} for parameters {} with {} optimizer'.format(learning_rate, ' '.join(names), kind))
 
 
 class _TrainerBase(object):
@@ -153,7 +180,7 @@ class _TrainerBase(object):
             if not self._capturable:
                 fn(*batch.tensors())
                 return
-            self._steps[key] = _CapturedStep(fn, batch, signature, True)      # its warm-up run WAS this batch's step
+            self._steps[key] = _CapturedStep(fn, batch, signature)            # its warm-up run WAS this batch's step
             for m in modules:
                 if all(m is not x for x in self._stale):
                     self._stale.append(m)
@@ -246,26 +273,15 @@ class MPRLTrainer(_TrainerBase):
                         fn()
 
     def set_learning_rate(self, learning_rate):
+        """Fresh optimizers at this rate (trainer.py:43-61); the state predictor gets one only while it is trainable."""
         capturable = self.capture and str(self.device).startswith("cuda")
-        if self.optimizer_str == 'Adam':
-            self.v_optimizer = optim.Adam(self.value_estimator.parameters(), lr=learning_rate, capturable=capturable)
-            if self.state_predictor.trainable:
-                self.s_optimizer = optim.Adam(self.state_predictor.parameters(), lr=learning_rate, capturable=capturable)
-        elif self.optimizer_str == 'SGD':
-            self.v_optimizer = optim.SGD(self.value_estimator.parameters(), lr=learning_rate, momentum=0.9)
-            if self.state_predictor.trainable:
-                self.s_optimizer = optim.SGD(self.state_predictor.parameters(), lr=learning_rate)
-        else:
-            raise NotImplementedError
+        trained = [self.value_estimator] + ([self.state_predictor] if self.state_predictor.trainable else [])
+        self.v_optimizer = _new_optimizer(self.optimizer_str, self.value_estimator, learning_rate, capturable)
+        if self.state_predictor.trainable:
+            self.s_optimizer = _new_optimizer(self.optimizer_str, self.state_predictor, learning_rate, capturable, predictor_side=True)
         self._capturable = self._can_capture(self.v_optimizer, self.s_optimizer)
         self._drop_graphs()                       # the optimizers (and their state tensors) are new
-        if self.state_predictor.trainable:
-            logging.info('Lr: {} for parameters {} with {} optimizer'.format(learning_rate, ' '.join(
-                [name for name, param in list(self.value_estimator.named_parameters()) +
-                 list(self.state_predictor.named_parameters())]), self.optimizer_str))
-        else:
-            logging.info('Lr: {} for parameters {} with {} optimizer'.format(learning_rate, ' '.join(
-                [name for name, param in list(self.value_estimator.named_parameters())]), self.optimizer_str))
+        _log_learning_rate(learning_rate, trained, self.optimizer_str)
 
     # -- batches ---------------------------------------------------------------------------------------------------------------
     def _batches(self):
@@ -274,6 +290,13 @@ class MPRLTrainer(_TrainerBase):
         if self.data_loader is None and callable(fast):
             fields = fast()
             if fields is not None:
+                # Gather from the FULL-CAPACITY stacked fields when the memory offers them: a captured step records its
+                # index_select kernels with the source extent of the day of the capture, and the memory grows every episode --
+                # replaying against `fields` (views of the first len(memory) rows at capture time) would index past the recorded
+                # extent.  Indices are always < len(memory), so the rows beyond it are never read.
+                whole = getattr(self.memory, "stacked_capacity_fields", None)
+                if callable(whole):
+                    fields = whole() or fields
                 # the whole epoch's permutation goes to the device in ONE copy (a pageable host-to-device copy per batch would
                 # stall the host behind the previous step every time); the batches are slices of it
                 order = list(_ShuffledIndexBatches(len(self.memory), self.batch_size))
@@ -387,17 +410,24 @@ class MPRLTrainer(_TrainerBase):
         return average_v_loss, average_s_loss
 
 
+def _pad_longest_first(sequences):
+    """Variable-length (L_i, D) sequences -> ((n, L_max, D) zero-padded tensor, int64 lengths), LONGEST FIRST; equally long ones
+    keep their order (a stable sort on the negated length)."""
+    order = sorted(range(len(sequences)), key=lambda i: -sequences[i].shape[0])
+    picked = [sequences[i] for i in order]
+    lengths = torch.tensor([t.shape[0] for t in picked], dtype=torch.int64)
+    return torch.nn.utils.rnn.pad_sequence(picked, batch_first=True), lengths
+
+
 def pad_batch(batch):
-    """trainer.py:253-272: sort the sequences by decreasing length, pad, keep the lengths -> (states, lengths) pairs."""
-    def sort_states(position):
-        sequences = sorted([x[position] for x in batch], reverse=True, key=lambda t: t.size()[0])
-        packed_sequences = torch.nn.utils.rnn.pack_sequence(sequences)
-        return torch.nn.utils.rnn.pad_packed_sequence(packed_sequences, batch_first=True)
-    states = sort_states(0)
-    values = torch.cat([x[1] for x in batch]).unsqueeze(1)
-    rewards = torch.cat([x[2] for x in batch]).unsqueeze(1)
-    next_states = sort_states(3)
-    return states, values, rewards, next_states
+    """Collate function of the path-G trainer (the role of crowd_nav/utils/trainer.py:253-272): items (state (L, D), value (1,),
+    reward (1,), next state (L', D)) -> ((states, lengths), values (n, 1), rewards (n, 1), (next states, lengths)).
+    As upstream: each of the two state lists is ordered longest first ON ITS OWN while values and rewards keep the batch order --
+    only consistent when every crowd of a batch has one size, which is the only case the graph network accepts anyway."""
+    columns = list(zip(*batch))
+    values = torch.cat(columns[1]).unsqueeze(1)
+    rewards = torch.cat(columns[2]).unsqueeze(1)
+    return _pad_longest_first(columns[0]), values, rewards, _pad_longest_first(columns[3])
 
 
 class VNRLTrainer(_TrainerBase):
@@ -426,17 +456,12 @@ class VNRLTrainer(_TrainerBase):
     _refresh_packed = staticmethod(MPRLTrainer._refresh_packed)
 
     def set_learning_rate(self, learning_rate):
-        capturable = self.capture and str(self.device).startswith("cuda")
-        if self.optimizer_str == 'Adam':
-            self.optimizer = optim.Adam(self.model.parameters(), lr=learning_rate, capturable=capturable)
-        elif self.optimizer_str == 'SGD':
-            self.optimizer = optim.SGD(self.model.parameters(), lr=learning_rate, momentum=0.9)
-        else:
-            raise NotImplementedError
+        """A fresh optimizer at this rate (trainer.py:189-197)."""
+        self.optimizer = _new_optimizer(self.optimizer_str, self.model, learning_rate,
+                                        self.capture and str(self.device).startswith("cuda"))
         self._capturable = self._can_capture(self.optimizer)
         self._drop_graphs()
-        logging.info('Lr: {} for parameters {} with {} optimizer'.format(learning_rate, ' '.join(
-            [name for name, param in self.model.named_parameters()]), self.optimizer_str))
+        _log_learning_rate(learning_rate, [self.model], self.optimizer_str)
 
     def _batches(self):
         """Batches of ((states, lengths), values, rewards, (next_states, lengths)) -- pad_batch's output."""

@@ -35,6 +35,9 @@ class ReplayMemory(Dataset):
         self.position = 0
         self._mirror = None           # per field: (capacity, *item shape) tensor on the items' device
         self._dirty = []              # positions written since the mirror was last brought up to date
+        self._unstackable_at = -1     # len(memory) when the items were last found to differ in shape (no stacked view): the
+                                      # check is not repeated -- O(n) host work and capacity-sized allocations -- until the ring
+                                      # has been cleared or has wrapped far enough to have dropped the odd items
 
     def push(self, item):
         if self.position < len(self.memory):
@@ -50,7 +53,7 @@ class ReplayMemory(Dataset):
 
     def clear(self):
         self.memory = []          # the write position is kept, as upstream does
-        self._mirror, self._dirty = None, []
+        self._mirror, self._dirty, self._unstackable_at = None, [], -1
 
     def __getitem__(self, index):
         return self.memory[index]
@@ -68,21 +71,36 @@ class ReplayMemory(Dataset):
         first = self.memory[0]
         if not (isinstance(first, tuple) and all(torch.is_tensor(x) for x in first)):
             return None
+        if self._unstackable_at >= 0:
+            # mixed shapes were found with this many items: until the ring is full and has been overwritten once more (the odd
+            # items may be gone then) the answer cannot change -- no re-allocation, no walk over the items per call
+            if not (self.is_full() and len(self._dirty) >= self.capacity):
+                if len(self._dirty) > self.capacity:
+                    self._dirty = self._dirty[-self.capacity:]
+                return None
+            self._unstackable_at = -1
         if self._mirror is None or len(self._mirror) != len(first) or any(
                 m.shape[1:] != x.shape or m.device != x.device or m.dtype != x.dtype for m, x in zip(self._mirror, first)):
             self._mirror = [torch.empty((self.capacity,) + tuple(x.shape), dtype=x.dtype, device=x.device) for x in first]
             self._dirty = list(range(n))
         dirty = sorted(set(i for i in self._dirty if i < n))
         if dirty:
-            idx = torch.tensor(dirty, dtype=torch.int64, device=self._mirror[0].device)
             for f, m in enumerate(self._mirror):
                 rows = [self.memory[i][f] for i in dirty]
-                if any(r.shape != m.shape[1:] for r in rows):
-                    self._mirror, self._dirty = None, []
+                if any(r.shape != m.shape[1:] or r.device != m.device or r.dtype != m.dtype for r in rows):
+                    self._mirror, self._dirty, self._unstackable_at = None, [], n
                     return None
-                m.index_copy_(0, idx, torch.stack(rows))
+                m.index_copy_(0, torch.tensor(dirty, dtype=torch.int64, device=m.device), torch.stack(rows))   # index on the field's device
         self._dirty = []
         return [m[:n] for m in self._mirror]
+
+    def stacked_capacity_fields(self):
+        """The tensors `as_tensors()` returns views of, at their full (capacity, ...) extent -- rows >= len(self) are unwritten.
+        What a trainer's CAPTURED step gathers from: the extent never changes while the memory grows, so the recorded
+        index_select kernels stay valid (indices are always < len(self)).  None when there is no stacked view."""
+        if self.as_tensors() is None:
+            return None
+        return list(self._mirror)
 
 
 def discounted_statistics(rewards, lengths, step_discount):

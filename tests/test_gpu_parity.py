@@ -2503,6 +2503,53 @@ def test_product_trainer_fast_batches_equal_the_dataloaders(dev):
            "parameters within %.1e" % worst)
 
 
+def test_product_trainer_replays_stay_valid_while_the_memory_grows(dev):
+    """a captured RL step gathers its batch with index_select from the memory's stacked fields.  The memory
+    grows every episode, so the step must gather from the FULL-CAPACITY fields (ReplayMemory.stacked_capacity_fields): recorded
+    against the len(memory)-row views of the day of the capture, a replay would read rows beyond the recorded source extent.
+    Push items between optimize_batch calls (same batch shape -> the same captured step is replayed) and hold the captured
+    trainer against the eager one on the same seeds."""
+    c = dict(L=2, sim="embedded_gaussian", layerwise=False, skip=True, flavour="trained")
+    robot, humans = seeded_scenes(71, 420, 5)
+    robot2, humans2 = seeded_scenes(72, 420, 5)
+    rew = torch.rand(420, generator=torch.Generator().manual_seed(19))
+    items = [(robot[i:i + 1].to(dev), humans[i].to(dev), rew[i:i + 1].to(dev) * 0.5, rew[i:i + 1].to(dev),
+              robot2[i:i + 1].to(dev), humans2[i].to(dev)) for i in range(420)]
+
+    def run(capture):
+        _, ve, sp = build_modules(c, dev)
+        mem = rga.ReplayMemory(400)                          # the last pushes wrap around the ring
+        for it in items[:150]:
+            mem.push(it)
+        cls = rga.MPRLTrainer if capture else type("EagerTrainer", (rga.MPRLTrainer,), {"capture": False})
+        t = cls(ve, sp, mem, dev, None, _Writer(), 100, "Adam", 5, reduce_sp_update_frequency=False,
+                freeze_state_predictor=False, detach_state_predictor=True, share_graph_model=False)
+        torch.manual_seed(5)
+        t.set_learning_rate(1e-3)
+        t.update_target_model(ve)
+        losses, lo = [], 150
+        for episode in range(4):
+            losses.append(t.optimize_batch(1, episode))      # two batches of 100 (upstream's off-by-one), the second shorter at first
+            for it in items[lo:lo + 90]:                     # the memory grows: 150 -> 240 -> 330 -> 400 (full, wrapped)
+                mem.push(it)
+            lo += 90
+        return ve, sp, losses, t
+    ve_c, sp_c, l_c, t_c = run(True)
+    ve_e, sp_e, l_e, _ = run(False)
+    assert t_c._capturable and any(st.graph is not None for st in t_c._steps.values())
+    key_sizes = sorted(k[-1] for k in t_c._steps)            # the source extent each captured step was recorded with
+    assert key_sizes and all(n == 400 for n in key_sizes), key_sizes
+    worst = 0.0
+    for a, e in ((ve_c, ve_e), (sp_c, sp_e)):
+        for (k, pa), (_, pe) in zip(a.state_dict().items(), e.state_dict().items()):
+            worst = max(worst, float((pa - pe).abs().max()))
+    assert worst <= 1e-5, worst
+    for (a, b), (c_, d) in zip(l_c, l_e):
+        assert abs(a - c_) <= 1e-6 * max(1.0, abs(c_)) and abs(b - d) <= 1e-6 * max(1.0, abs(d))
+    report("product MPRLTrainer: captured steps replayed across a growing (and wrapping) replay memory stay within %.1e of the eager "
+           "trainer's parameters" % worst)
+
+
 @pytest.mark.parametrize("case", ["shipped|2|0|1", "layerwise_noskip|2|1|0"])
 def test_product_vnrl_trainer_reproduces_the_reference_fixture(case, dev):
     """relationalgraphlearning_amd.VNRLTrainer (path G's trainer, crowd_nav/utils/trainer.py:164-250) over the fixture of

@@ -52,6 +52,52 @@ def test_replay_memory_mirror_follows_the_ring():
     assert mem.as_tensors() is None                          # mixed crowd sizes: no stacked view (the DataLoader path serves them)
 
 
+def test_pad_batch_orders_each_state_list_longest_first():
+    """The path-G collate function (the role of crowd_nav/utils/trainer.py:253-272): both state lists longest first (equally long
+    ones in batch order), zero padded, with their lengths; values / rewards in BATCH order, as upstream leaves them."""
+    g = torch.Generator().manual_seed(3)
+    lens, next_lens = [2, 4, 3, 4, 1], [3, 3, 5, 1, 2]
+    batch = [(torch.randn(a, 13, generator=g), torch.tensor([float(i)]), torch.tensor([10.0 + i]), torch.randn(b, 13, generator=g))
+             for i, (a, b) in enumerate(zip(lens, next_lens))]
+    (states, ls), values, rewards, (nxt, nls) = tr.pad_batch(batch)
+    assert ls.tolist() == [4, 4, 3, 2, 1] and nls.tolist() == [5, 3, 3, 2, 1] and ls.dtype == torch.int64
+    assert states.shape == (5, 4, 13) and nxt.shape == (5, 5, 13)
+    for row, src in zip(range(5), [1, 3, 2, 0, 4]):                       # stable: item 1 before item 3
+        L = lens[src]
+        assert torch.equal(states[row, :L], batch[src][0]) and not states[row, L:].any()
+    for row, src in zip(range(5), [2, 0, 1, 4, 3]):
+        L = next_lens[src]
+        assert torch.equal(nxt[row, :L], batch[src][3]) and not nxt[row, L:].any()
+    assert values.reshape(-1).tolist() == [0.0, 1.0, 2.0, 3.0, 4.0] and values.shape == (5, 1)
+    assert rewards.reshape(-1).tolist() == [10.0, 11.0, 12.0, 13.0, 14.0]
+    # against torch's own pack / unpack of the same longest-first lists (what upstream's function goes through)
+    seqs = sorted([b[0] for b in batch], key=lambda t: -t.shape[0])
+    ref, ref_l = torch.nn.utils.rnn.pad_packed_sequence(torch.nn.utils.rnn.pack_sequence(seqs), batch_first=True)
+    assert torch.equal(ref, states) and torch.equal(ref_l, ls)
+
+
+def test_replay_memory_capacity_fields_and_unstackable_memo():
+    """stacked_capacity_fields(): the full-extent tensors as_tensors() views (what a captured step gathers from -- ADVICE r4);
+    a memory of mixed crowd sizes remembers that it has no stacked view instead of re-walking itself on every call."""
+    mem = rga.ReplayMemory(6)
+    assert mem.stacked_capacity_fields() is None
+    _fill(mem, 4)
+    whole = mem.stacked_capacity_fields()
+    assert [w.shape[0] for w in whole] == [6] * 6
+    assert all(torch.equal(w[:4], f) for w, f in zip(whole, mem.as_tensors()))
+    _fill(mem, 1, seed=4)
+    again = mem.stacked_capacity_fields()
+    assert all(a.data_ptr() == w.data_ptr() for a, w in zip(again, whole))       # same buffers while the memory grows
+    assert torch.equal(again[2][:5].reshape(-1), torch.tensor([0.0, 1.0, 2.0, 3.0, 0.0]))
+    mem.push((torch.zeros(1, 9), torch.zeros(2, 5), torch.zeros(1), torch.zeros(1), torch.zeros(1, 9), torch.zeros(2, 5)))
+    assert mem.as_tensors() is None and mem._unstackable_at == 6 and mem._mirror is None
+    assert mem.as_tensors() is None and mem._mirror is None                       # memoised: nothing re-allocated
+    _fill(mem, 6, seed=9)                                                         # the ring wraps: the odd item is overwritten
+    assert mem.as_tensors() is not None and mem.stacked_capacity_fields()[1].shape == (6, 3, 5)
+    mem.clear()
+    assert mem._unstackable_at == -1
+
+
 def test_trainer_contract_on_cpu():
     """Constructor arguments, attributes and errors of crowd_nav/utils/trainer.py; on a CPU device nothing is capturable and the
     trainers refuse nothing they accept upstream (the forward itself needs the GPU: not run here)."""

@@ -45,6 +45,8 @@ __host__ __device__ constexpr int image_floats(int mode) {
 }
 
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+// compiler-only fence (as rgl_mfma.h): keeps hipcc from hoisting every fragment load of the unrolled chain to the top
+__device__ __forceinline__ void load_fence() { asm volatile("" ::: "memory"); }
 
 // ---- mode 0 -------------------------------------------------------------------------------------------------------------------
 template <int IN, int OUT, int NB>
@@ -53,6 +55,7 @@ __device__ __forceinline__ void layer_f32(const float* img, const f32x4 (&in)[NB
     const float* bias = img + OT * IT * 4 * 64;
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
+        load_fence();
         f32x4 acc[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[b] = zero4();
@@ -120,6 +123,7 @@ __device__ __forceinline__ void layer_f16x3(const float* img, const f32x4 (&in)[
         for (int b = 0; b < NB; ++b) acc[b] = zero4();
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
+            load_fence();
             const f16x8 wh = *reinterpret_cast<const f16x8*>(&img[(((ot * NC + c) * 2 + 0) * 64 + lane) * 4]);
             const f16x8 wl = *reinterpret_cast<const f16x8*>(&img[(((ot * NC + c) * 2 + 1) * 64 + lane) * 4]);
 #pragma unroll
@@ -183,6 +187,7 @@ __device__ __forceinline__ void layer_bf16(const float* img, const f32x4 (&in)[N
         for (int b = 0; b < NB; ++b) acc[b] = zero4();
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
+            load_fence();
             const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&img[(((ot * NC + c) * 3 + 0) * 64 + lane) * 4]);
             const bf16x8 wm = *reinterpret_cast<const bf16x8*>(&img[(((ot * NC + c) * 3 + 1) * 64 + lane) * 4]);
             const bf16x8 wl = *reinterpret_cast<const bf16x8*>(&img[(((ot * NC + c) * 3 + 2) * 64 + lane) * 4]);
@@ -221,8 +226,8 @@ __device__ __forceinline__ void layer(const float* img, const f32x4 (&in)[NB][ti
 struct Scales { float inv_sw[kLayers]; };
 
 // x_in: [n_tiles][16 children][32] fp32 or null (synthetic inputs); y_out: [n_tiles][16][100] or null (a checksum per thread instead)
-template <int MODE, int NB>
-__global__ __launch_bounds__(512) void head_chain(const float* __restrict__ image, const float* __restrict__ x_in, float* __restrict__ y_out,
+template <int MODE, int NB, int THREADS>
+__global__ __launch_bounds__(THREADS) void head_chain(const float* __restrict__ image, const float* __restrict__ x_in, float* __restrict__ y_out,
                                                   float* __restrict__ sink, int tiles_per_wave, Scales sc) {
     extern __shared__ float lds[];
     for (int i = threadIdx.x; i < image_floats(MODE); i += blockDim.x) lds[i] = image[i];
@@ -338,9 +343,10 @@ static void run_mode(const char* name, const Net& net, const std::vector<float>&
     (void)hipMalloc(&d_y, (size_t)n_tiles * 16 * 100 * 4);
     (void)hipMalloc(&d_sink, 256 * 512 * 4);
     const size_t lds = img.size() * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_chain<MODE, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_chain<MODE, NB, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_chain<MODE, NB, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // accuracy: n_tiles tiles over n_tiles / 8 waves
-    hipLaunchKernelGGL((head_chain<MODE, NB>), dim3(n_tiles / 8 / 4), dim3(256), lds, 0, d_img, d_x, d_y, d_sink, 8, sc);
+    hipLaunchKernelGGL((head_chain<MODE, NB, 256>), dim3(n_tiles / 8 / 4), dim3(256), lds, 0, d_img, d_x, d_y, d_sink, 8, sc);
     std::vector<float> y((size_t)n_tiles * 16 * 100);
     (void)hipMemcpy(y.data(), d_y, y.size() * 4, hipMemcpyDeviceToHost);
     double mx = 0, ss = 0, scale = 0;
@@ -349,13 +355,14 @@ static void run_mode(const char* name, const Net& net, const std::vector<float>&
     // timing
     double ns[2];
     for (int wi = 0; wi < 2; ++wi) {
-        const int threads = wi == 0 ? 256 : 512, tpw = 512;
+        const int tpw = 512;
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         float best = 1e9f;
         for (int rep = 0; rep < 4; ++rep) {
             (void)hipEventRecord(e0);
-            hipLaunchKernelGGL((head_chain<MODE, NB>), dim3(256), dim3(threads), lds, 0, d_img, nullptr, nullptr, d_sink, tpw, sc);
+            if (wi == 0) hipLaunchKernelGGL((head_chain<MODE, NB, 256>), dim3(256), dim3(256), lds, 0, d_img, nullptr, nullptr, d_sink, tpw, sc);
+            else hipLaunchKernelGGL((head_chain<MODE, NB, 512>), dim3(256), dim3(512), lds, 0, d_img, nullptr, nullptr, d_sink, tpw, sc);
             (void)hipEventRecord(e1);
             (void)hipEventSynchronize(e1);
             float ms; (void)hipEventElapsedTime(&ms, e0, e1);
