@@ -8,6 +8,11 @@
 //   mode 1  f16x3    two f16 halves (RNE, power-of-two column scale), 3 terms          -- the 22/23-bit mode of round 3
 //   mode 2  bf16x6   three bf16 pieces (exact 8+8+8-bit truncation split, no scaling), 6 terms: hh hm mh hl mm lh
 //   mode 3  bf16x9   three bf16 pieces, all 9 terms
+//   mode 4  bf16x6r  three bf16 pieces by ROUND-TO-NEAREST (v_cvt_pk_bf16_f32; x = hi + mid + lo still exact), 6 terms: the dropped
+//                    terms are then bounded by 2^-26 + 2^-26 + 2^-34 < 2^-24 of |a||w| and are not biased (truncated pieces all carry
+//                    the operand's sign, so what mode 2 drops always has the sign of the product)
+//   mode 5  hybrid   what fits the children kernel's LDS: layers 0, 1 as mode 0; the 100 x 100 layer with k = 0..63 as mode 4 (two
+//                    K = 32 chunks) and k = 64..99 on the f32 MFMA
 //
 // and NB = 1 | 2 child tiles per wave per weight-fragment read (register blocking over N: halves the LDS traffic per tile).
 // Reported per mode: ns per 16-child tile per wave (4 waves / CU and 8 waves / CU, all 256 CUs), the same as a fraction of
@@ -33,10 +38,12 @@ __host__ __device__ constexpr int in_of(int l) { return l == 0 ? 32 : (l == 1 ? 
 __host__ __device__ constexpr int out_of(int l) { return l == 0 ? 32 : 100; }
 __host__ __device__ constexpr int tiles(int n) { return (n + 15) / 16; }
 __host__ __device__ constexpr int pieces_of(int mode) { return mode == 0 ? 1 : (mode == 1 ? 2 : 3); }
+__host__ __device__ constexpr int layer_mode(int mode, int l) { return mode == 5 ? (l == 2 ? 5 : 0) : mode; }
 // 16-byte units (one lane's fragment) per layer image: mode 0 -> floats [ot][kstep = (t, r)][lane] (4 B units, counted in floats)
 __host__ __device__ constexpr int layer_floats(int mode, int l) {
-    const int IT = tiles(in_of(l)), OT = tiles(out_of(l));
-    return mode == 0 ? OT * IT * 4 * 64 : OT * ((IT + 1) / 2) * pieces_of(mode) * 64 * 4;
+    const int IT = tiles(in_of(l)), OT = tiles(out_of(l)), lm = layer_mode(mode, l);
+    if (lm == 5) return OT * 2 * 3 * 64 * 4 + OT * (IT - 4) * 4 * 64;      // two bf16 chunks (input tiles 0..3) | f32 k steps of tiles 4..
+    return lm == 0 ? OT * IT * 4 * 64 : OT * ((IT + 1) / 2) * pieces_of(lm) * 64 * 4;
 }
 __host__ __device__ constexpr int image_floats(int mode) {
     int s = 0;
@@ -168,6 +175,84 @@ __device__ __forceinline__ Split3 split3(const f32x4 (&in)[IT]) {
     s.l = __builtin_bit_cast(bf16x8, L);
     return s;
 }
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// round-to-nearest pieces: hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid (<= 7 significant bits left: exact in bf16)
+template <int IT, int C>
+__device__ __forceinline__ Split3 split3_rn(const f32x4 (&in)[IT]) {
+    u32x4 H, M, L;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int t = 2 * C + (p >> 1), r0 = 2 * (p & 1);
+        f32x2 x = f32x2{0.f, 0.f};
+        if (t < IT) x = f32x2{in[t < IT ? t : 0][r0], in[t < IT ? t : 0][r0 + 1]};
+        const bf16x2 h = __builtin_convertvector(x, bf16x2);
+        const f32x2 r1 = x - __builtin_convertvector(h, f32x2);
+        const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+        const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+        const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+        H[p] = __builtin_bit_cast(unsigned, h);
+        M[p] = __builtin_bit_cast(unsigned, m);
+        L[p] = __builtin_bit_cast(unsigned, l);
+    }
+    Split3 s;
+    s.h = __builtin_bit_cast(bf16x8, H);
+    s.m = __builtin_bit_cast(bf16x8, M);
+    s.l = __builtin_bit_cast(bf16x8, L);
+    return s;
+}
+__device__ __forceinline__ f32x4 mfma_b6(const bf16x8& wh, const bf16x8& wm, const bf16x8& wl, const Split3& a, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, a.h, acc, 0, 0, 0);          // small terms first
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, a.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, a.l, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, a.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, a.m, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, a.h, acc, 0, 0, 0);
+}
+// NCB chunks of K = 32 as six bf16 terms (RN pieces), the input tiles past them on the f32 MFMA
+template <int IN, int OUT, int NB, int NCB>
+__device__ __forceinline__ void layer_bf16_rn(const float* img, const f32x4 (&in)[NB][tiles(IN)], f32x4 (&out)[NB][tiles(OUT)], int lane) {
+    constexpr int IT = tiles(IN), OT = tiles(OUT), ITF = IT - 2 * NCB > 0 ? IT - 2 * NCB : 0;      // f32 input tiles
+    const float* f32frags = img + OT * NCB * 3 * 64 * 4;
+    const float* bias = f32frags + OT * ITF * 4 * 64;
+    Split3 s[NB][NCB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        s[b][0] = split3_rn<IT, 0>(in[b]);
+        if constexpr (NCB > 1) s[b][1] = split3_rn<IT, 1>(in[b]);
+        if constexpr (NCB > 2) s[b][2] = split3_rn<IT, 2>(in[b]);
+        if constexpr (NCB > 3) s[b][3] = split3_rn<IT, 3>(in[b]);
+    }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+        f32x4 acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = zero4();
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            load_fence();
+            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&img[(((ot * NCB + c) * 3 + 0) * 64 + lane) * 4]);
+            const bf16x8 wm = *reinterpret_cast<const bf16x8*>(&img[(((ot * NCB + c) * 3 + 1) * 64 + lane) * 4]);
+            const bf16x8 wl = *reinterpret_cast<const bf16x8*>(&img[(((ot * NCB + c) * 3 + 2) * 64 + lane) * 4]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] = mfma_b6(wh, wm, wl, s[b][c], acc[b]);
+        }
+        load_fence();
+#pragma unroll
+        for (int t = 0; t < ITF; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float w = f32frags[((ot * ITF + t) * 4 + r) * 64 + lane];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, in[b][2 * NCB + t][r], acc[b], 0, 0, 0);
+            }
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * (lane >> 4)]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[b][ot][r] = fmaxf(acc[b][r] + bb[r], 0.f);
+    }
+}
+
 template <int IN, int OUT, int NB, bool NINE>
 __device__ __forceinline__ void layer_bf16(const float* img, const f32x4 (&in)[NB][tiles(IN)], f32x4 (&out)[NB][tiles(OUT)], int lane) {
     constexpr int IT = tiles(IN), OT = tiles(OUT), NC = (IT + 1) / 2;
@@ -218,7 +303,9 @@ __device__ __forceinline__ void layer_bf16(const float* img, const f32x4 (&in)[N
 template <int MODE, int L, int NB>
 __device__ __forceinline__ void layer(const float* img, const f32x4 (&in)[NB][tiles(in_of(L))], f32x4 (&out)[NB][tiles(out_of(L))],
                                       int lane, const float* inv_sw) {
-    if constexpr (MODE == 0) layer_f32<in_of(L), out_of(L), NB>(img, in, out, lane);
+    if constexpr (layer_mode(MODE, L) == 0) layer_f32<in_of(L), out_of(L), NB>(img, in, out, lane);
+    else if constexpr (MODE == 4) layer_bf16_rn<in_of(L), out_of(L), NB, (tiles(in_of(L)) + 1) / 2>(img, in, out, lane);
+    else if constexpr (MODE == 5) layer_bf16_rn<in_of(L), out_of(L), NB, 2>(img, in, out, lane);
     else if constexpr (MODE == 1) layer_f16x3<in_of(L), out_of(L), NB>(img, in, out, lane, inv_sw[L]);
     else layer_bf16<in_of(L), out_of(L), NB, MODE == 3>(img, in, out, lane);
 }
@@ -275,6 +362,11 @@ __global__ __launch_bounds__(THREADS) void head_chain(const float* __restrict__ 
 // ---- host: weights, images, float64 reference -------------------------------------------------------------------------------
 static float frand() { return (float)rand() / (float)RAND_MAX * 2.f - 1.f; }
 static float bf_trunc(float x) { unsigned u; memcpy(&u, &x, 4); u &= 0xffff0000u; memcpy(&x, &u, 4); return x; }
+static float bf_rn(float x) {                                   // round to nearest even at bit 16 (finite inputs)
+    unsigned u; memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u; memcpy(&x, &u, 4); return x;
+}
 static unsigned short bf_bits(float x) { unsigned u; memcpy(&u, &x, 4); return (unsigned short)(u >> 16); }
 static unsigned short f16_bits(float x) { _Float16 h = (_Float16)x; unsigned short b; memcpy(&b, &h, 2); return b; }
 static float f16_val(float x) { return (float)(_Float16)x; }
@@ -296,7 +388,20 @@ static std::vector<float> build_image(const Net& net, int mode, Scales* sc) {
             sc->inv_sw[l] = 1.f / sw;
         }
         float* base = img.data() + off;
-        if (mode == 0) {
+        const int lm = layer_mode(mode, l);
+        const int NCB = lm == 5 ? 2 : NC;                 // bf16 chunks of this layer
+        if (lm == 5) {                                    // f32 k steps of input tiles 4..
+            float* f32b = base + OT * NCB * 3 * 64 * 4;
+            const int ITF = IT - 2 * NCB;
+            for (int ot = 0; ot < OT; ++ot)
+                for (int t = 0; t < ITF; ++t)
+                    for (int r = 0; r < 4; ++r)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int m = lane & 15, q = lane >> 4;
+                            f32b[((ot * ITF + t) * 4 + r) * 64 + lane] = w_at(16 * (2 * NCB + t) + 4 * q + r, 16 * ot + m);
+                        }
+        }
+        if (lm == 0) {
             for (int ot = 0; ot < OT; ++ot)
                 for (int t = 0; t < IT; ++t)
                     for (int r = 0; r < 4; ++r)
@@ -305,10 +410,10 @@ static std::vector<float> build_image(const Net& net, int mode, Scales* sc) {
                             base[((ot * IT + t) * 4 + r) * 64 + lane] = w_at(16 * t + 4 * q + r, 16 * ot + m);
                         }
         } else {
-            const int NP = pieces_of(mode);
+            const int NP = pieces_of(lm);
             unsigned short* hb = reinterpret_cast<unsigned short*>(base);
             for (int ot = 0; ot < OT; ++ot)
-                for (int c = 0; c < NC; ++c)
+                for (int c = 0; c < NCB; ++c)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int e = 0; e < 8; ++e) {
                             const int m = lane & 15, q = lane >> 4, t = 2 * c + e / 4;
@@ -317,11 +422,14 @@ static std::vector<float> build_image(const Net& net, int mode, Scales* sc) {
                             if (mode == 1) {
                                 const float hi = f16_val(w);
                                 pc[0] = f16_bits(w); pc[1] = f16_bits(w - hi);
+                            } else if (mode >= 4) {
+                                const float hi = bf_rn(w), r1 = w - hi, mid = bf_rn(r1), lo = r1 - mid;
+                                pc[0] = bf_bits(hi); pc[1] = bf_bits(mid); pc[2] = bf_bits(lo);
                             } else {
                                 const float hi = bf_trunc(w), r1 = w - hi, mid = bf_trunc(r1), lo = r1 - mid;
                                 pc[0] = bf_bits(hi); pc[1] = bf_bits(mid); pc[2] = bf_bits(lo);
                             }
-                            for (int p = 0; p < NP; ++p) hb[((((size_t)(ot * NC + c) * NP + p) * 64 + lane) * 8) + e] = pc[p];
+                            for (int p = 0; p < NP; ++p) hb[((((size_t)(ot * NCB + c) * NP + p) * 64 + lane) * 8) + e] = pc[p];
                         }
         }
         off += layer_floats(mode, l);
@@ -416,5 +524,9 @@ int main() {
     run_mode<2, 2>("bf16x6", net, x, ref, n_tiles);
     run_mode<3, 1>("bf16x9", net, x, ref, n_tiles);
     run_mode<3, 2>("bf16x9", net, x, ref, n_tiles);
+    run_mode<4, 1>("bf16x6r", net, x, ref, n_tiles);
+    run_mode<4, 2>("bf16x6r", net, x, ref, n_tiles);
+    run_mode<5, 1>("hybrid", net, x, ref, n_tiles);
+    run_mode<5, 2>("hybrid", net, x, ref, n_tiles);
     return 0;
 }
