@@ -268,7 +268,7 @@ def parse_args(argv=None):
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--depth", type=int, default=2)
     ap.add_argument("--width", type=int, default=2)
-    ap.add_argument("--contraction", choices=("f32", "f16", "f16x3"), default="f32",
+    ap.add_argument("--contraction", choices=("f32", "f16", "f16x3", "bf16x6"), default="f32",
                     help="f16: f16-input MFMA for the dense middle-layer products (BASELINE configs[4]; needs --layers 3); "
                          "f16x3: the children kernel's dense products as three split-f16 MFMA terms (f32-equivalent to ~2^-21, L = 2, N <= 20)")
     ap.add_argument("--scenes", choices=("clearance", "uniform"), default="clearance",
@@ -560,6 +560,14 @@ def children_roofline(args, ts, device, N, H, last, robot=None, humans=None):
         peak = flop_per_scene / (dense / x3_peak + (flop_per_scene - dense) / FP32_PEAK_TFLOPS)
         peak_note = "blend: %.0f%% of the FLOPs as 3 split-f16 MFMA terms (a third of the dense f16 MFMA peak = %.0f), the rest at the fp32 peak (%.1f)" % (
             100.0 * dense / flop_per_scene, x3_peak, FP32_PEAK_TFLOPS)
+    if args.contraction == "bf16x6":
+        # the first 64 input features of the 100 x 100 head matrix onto its 96 full-tile outputs run on the bf16 matrix pipe as SIX
+        # terms, i.e. at a sixth of the dense bf16 MFMA peak; everything else at the fp32 rate: time-weighted peak
+        dense = 2 * 64 * 96
+        b6_peak = F16_MFMA_PEAK_TFLOPS / 6.0
+        peak = flop_per_scene / (dense / b6_peak + (flop_per_scene - dense) / FP32_PEAK_TFLOPS)
+        peak_note = "blend: %.0f%% of the FLOPs as 6 bf16 MFMA terms over three-piece (24-bit) operands (a sixth of the dense bf16 MFMA peak = %.0f), the rest at the fp32 peak (%.1f)" % (
+            100.0 * dense / flop_per_scene, b6_peak, FP32_PEAK_TFLOPS)
     if args.contraction == "f16":
         # the two dense middle-layer products run on the f16 matrix pipe, the rest at the fp32 rate: time-weighted peak
         dense = 2 * N * 32 * 32 + 2 * N * N * 32
@@ -748,7 +756,10 @@ def main():
                                  "note": "set-up steps 2..9 of this process, before the device reached its steady clock (not timed into `value`)"}),
         "vs_baseline": None, "dtype": {"f32": "f32", "f16": "f16 inputs / f32 accumulate (middle-layer products only; everything else f32)",
                                        "f16x3": "f32 (dense products of the children kernel as three split-f16 MFMA terms with f32 accumulate, "
-                                                "~2^-21 relative per product; everything else f32)"}[args.contraction],
+                                                "~2^-21 relative per product; everything else f32)",
+                                       "bf16x6": "f32 (24-bit operands throughout; the first 64 input features of the children kernel's 100 x 100 "
+                                                 "head matrix as six bf16 MFMA terms over three round-to-nearest bf16 pieces per operand, f32 "
+                                                 "accumulate, dropped terms < 2^-24 |w||a|; everything else on the f32 MFMA / VALU)"}[args.contraction],
         "data": "synthetic",
         "config": {"workload": "%s: N=%d agents (H=%d humans), %d-layer GCN, depth-%d width-%d "
                                "action-tree rollout, %s" % (workload_name(N, args, main_leg[0]), N, H, args.layers, args.depth, args.width,

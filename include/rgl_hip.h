@@ -57,6 +57,7 @@ extern "C" {
 #define RGL_CONTRACT_F32 0
 #define RGL_CONTRACT_F16 1
 #define RGL_CONTRACT_F16X3 2        /* ABI 4: f32-equivalent dense products as three split-f16 MFMA terms */
+#define RGL_CONTRACT_BF16X6 3       /* ABI 6: f32-WIDTH products on the matrix pipe: three bf16 pieces per operand, six terms */
 
 #define RGL_ERR_LDS (-5)            /* configuration does not fit the 160 KiB LDS of one CU    */
 
@@ -244,7 +245,15 @@ typedef struct MprlPlanner {
                                  * W_hi a_hi + W_hi a_lo + W_lo a_hi with f16 halves of power-of-two-scaled      *
                                  * operands and f32 accumulation: ~2^-21 relative per product (f32 rounding is   *
                                  * 2^-24), 5x the MFMA rate of the f32 form, any finite input.  Where no kernel   *
-                                 * offers it, plain f32 runs (never less accurate), nothing is refused.           */
+                                 * offers it, plain f32 runs (never less accurate), nothing is refused.           *
+                                 * | RGL_CONTRACT_BF16X6 (ABI 6): products whose operands keep all 24 significand   *
+                                 * bits -- x = hi + mid + lo exactly, three bf16 pieces by round-to-nearest, f32's  *
+                                 * exponent range, no scaling -- as the six terms W_lo a_hi + W_mid a_mid + W_hi    *
+                                 * a_lo + W_mid a_hi + W_hi a_mid + W_hi a_hi of v_mfma_f32_16x16x32_bf16 with f32  *
+                                 * accumulation; the dropped terms are < 2^-24 |W||a| (below one f32 rounding).    *
+                                 * Offered by the value-of-children kernel of the shipped shape for the first 64    *
+                                 * input features of the 100 x 100 head matrix (what its LDS holds: DESIGN.md 4);  *
+                                 * everything else, and every other kernel, computes plain f32.                    */
     double time_step;
     double gamma_bar;           /* gamma^(time_step * v_pref), get_normalized_gamma (:104-105)  */
     const double* actions;      /* device [A][2] float64, table of build_action_space (:155-190)*/

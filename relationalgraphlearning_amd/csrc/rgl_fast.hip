@@ -38,7 +38,11 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
     const bool want_f16 = pl->contraction_dtype == RGL_CONTRACT_F16;
     // RGL_CONTRACT_F16X3: f32-equivalent products on the f16 matrix pipe (three split-f16 terms) where a kernel offers them -- the
     // fused kernel's value head; every other kernel computes plain f32, which is at least as accurate, so nothing is refused
-    const bool want_x3 = pl->contraction_dtype == RGL_CONTRACT_F16X3;
+    // RGL_CONTRACT_BF16X6 (round 5): f32-WIDTH products (three bf16 pieces per operand, six terms) on the matrix pipe where a kernel
+    // offers them -- the first 64 input features of the fused kernel's last head matrix; plain f32 everywhere else
+    const bool want_b6 = pl->contraction_dtype == RGL_CONTRACT_BF16X6;
+    const bool want_x3 = pl->contraction_dtype == RGL_CONTRACT_F16X3 || want_b6;      // "the image is in the fused kernel's layout only"
+    const int fused_mode = want_b6 ? 2 : (want_x3 ? 1 : 0);
     if (pl->contraction_dtype != RGL_CONTRACT_F32 && !want_f16 && !want_x3) return RGL_ERR_BAD_MODE;
     const bool staged = hv >= 0 && workspace && workspace_bytes >= value_children_workspace_bytes(pl, P, H);
     // stage 1, in order of preference: rank-1 (L = 2, N <= 32), shared-crowd deep (L in {2,3}, N <= 60), tiles (softmax
@@ -47,7 +51,7 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
     if (staged && !want_f16) {
         // one fused kernel over 16-child tiles (L = 2, N <= 32, default head): values come out directly, no stage 2
         rc = launch_fused_children(&pl->value_graph, &pl->value_head, P, A, H, child_robot, humans_next, child_value, workspace,
-                                   workspace_bytes, image_ready, stream, pl->children_image, tail, tail_bytes, tail_done, want_x3);
+                                   workspace_bytes, image_ready, stream, pl->children_image, tail, tail_bytes, tail_done, fused_mode);
         if (rc != 1) return rc;
     }
     // packed weight image of the value estimator (the caller's, or this search's at the end of the workspace): the two-stage pair

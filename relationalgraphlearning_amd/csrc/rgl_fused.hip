@@ -79,7 +79,7 @@ constexpr int kFusedWaves = 8;
 
 // h = relu(t W_last)(+hprev), value head 32 -> D1 -> D2 -> D3 -> 1 for the 16 children of a tile (lane (n, q): child n, D-layout
 // registers); returns the value of child n in every lane of its column (without the last bias)
-template <class LO, int D1, int D2, int D3, bool SKIP, bool HX = false>
+template <class LO, int D1, int D2, int D3, bool SKIP, bool HX = false, bool BX = false>
 __device__ __forceinline__ float head_chain(const float* lds, const f32x4 (&tin)[2], const f32x4 (&hp)[2], int lane) {
     const int q = lane >> 4;
     f32x4 h[2];
@@ -103,6 +103,7 @@ __device__ __forceinline__ float head_chain(const float* lds, const f32x4 (&tin)
     relu_tiles<D2>(a2);
     f32x4 a3[Tiles<D3>::v];
     if constexpr (HX) layer_mfma_h<D2, D3, true>(lds + LO::f3, a2, a3, lane, lds + LO::b3, lds[LO::hs + 3]);
+    else if constexpr (BX) layer_mfma_bx<D2, D3, true>(lds + LO::f3, a2, a3, lane, lds + LO::b3);
     else layer_mfma<D2, D3, true>(lds + LO::f3, a2, a3, lane, lds + LO::b3);
     relu_tiles<D3>(a3);
     float v = 0.f;
@@ -120,11 +121,12 @@ constexpr float kRowScale = 0x1p-110f, kRowUnscale = 0x1p110f;
 
 // HR >= N: human rows of UW held in registers (padded rows contribute exactly 0); SOFT: softmax row normalisation
 // HX: the value head's dense products as f16-split MFMAs (layer_mfma_h; MprlPlanner::contraction_dtype = RGL_CONTRACT_F16X3)
-template <int HR, int NT, bool SKIP, bool SOFT, int D1, int D2, int D3, bool HX = false>
+// BX: the D2 x D3 head matrix's first 64 input features as six bf16 terms on the matrix pipe (layer_mfma_bx; RGL_CONTRACT_BF16X6)
+template <int HR, int NT, bool SKIP, bool SOFT, int D1, int D2, int D3, bool HX = false, bool BX = false>
 __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const FusedArgs a) {
     const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    using LO = FusedLds<D1, D2, D3, HX>;
+    using LO = FusedLds<D1, D2, D3, HX, BX>;
     constexpr int NP = 16 * NT;
     constexpr int nthreads = kFusedWaves * 64;
     const int tid = threadIdx.x;
@@ -874,7 +876,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
 
         // ---------------- last GCN layer on the robot row + value head: one register-resident MFMA chain -------------------
         await_image();
-        const float v = head_chain<LO, D1, D2, D3, SKIP, HX>(lds, tin, hp, lane);
+        const float v = head_chain<LO, D1, D2, D3, SKIP, HX, BX>(lds, tin, hp, lane);
         if (q == 0 && c < A) a.value[(size_t)p * A + c] = v + hb4;
         PHASE_MARK(6);
       }
@@ -898,7 +900,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                 tin[ot] = valid ? *reinterpret_cast<const f32x4*>(row + 16 * ot + 4 * q) : zero4();
                 hp[ot] = valid ? *reinterpret_cast<const f32x4*>(row + 32 + 16 * ot + 4 * q) : zero4();
             }
-            const float v = head_chain<LO, D1, D2, D3, SKIP, HX>(lds, tin, hp, lane);
+            const float v = head_chain<LO, D1, D2, D3, SKIP, HX, BX>(lds, tin, hp, lane);
             if (valid && q == 0) a.value[(size_t)p * A + 16 * a.n_full + k] = v + hb4;
         }
     }
@@ -984,9 +986,38 @@ __global__ __launch_bounds__(256) void head_scales_kernel(const FusedArgs a, flo
     }
 }
 
-template <int D1, int D2, int D3, bool HX>
+// one float of the BX f3 region (BxLayout): a pair of bf16 pieces of the matrix-pipe fragments, or an f32 fragment element
+template <int IN, int OUT>
+__device__ __forceinline__ float bx_element(const float* __restrict__ W, int idx) {
+    using BL = BxLayout<IN, OUT>;
+    if (idx >= BL::p4) {
+        const int j = idx - BL::p4;
+        return frag_element<IN, OUT>(W, (BL::OTF * BL::IT * 4 + (j >> 6)) * 64 + (j & 63));            // partial tile: k step = it * 4 + r
+    }
+    if (idx >= BL::f32) {
+        const int j = idx - BL::f32, l = j & 63, kf = (j >> 6) % BL::KF, ot = (j >> 6) / BL::KF;
+        return frag_element<IN, OUT>(W, ((ot * BL::IT + BL::ITB) * 4 + kf) * 64 + l);
+    }
+    const int u = idx >> 2, p = idx & 3, l = u & 63, rest = u >> 6;
+    const int pc = rest % 3, c = (rest / 3) % BL::NCB, ot = rest / 3 / BL::NCB;
+    const int q = l >> 4, out = frag_out_feature<OUT>(ot, l);
+    bf16x2 v;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = 2 * p + k;
+        const float w = W[tile_feature<IN>(2 * c + (e >> 2), q, e & 3) * OUT + out];
+        const __bf16 hi = (__bf16)w;
+        const float r1 = w - (float)hi;
+        const __bf16 mid = (__bf16)r1;
+        const __bf16 lo = (__bf16)(r1 - (float)mid);
+        v[k] = pc == 0 ? hi : (pc == 1 ? mid : lo);
+    }
+    return __builtin_bit_cast(float, v);
+}
+
+template <int D1, int D2, int D3, bool HX, bool BX = false>
 __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedArgs a, float* img) {
-    using LO = FusedLds<D1, D2, D3, HX>;
+    using LO = FusedLds<D1, D2, D3, HX, BX>;
     const int e = blockIdx.x * kPackThreads + threadIdx.x;
     if (e >= LO::scratch) return;
     if (HX && e >= LO::hs) return;                     // the scales: written by head_scales_kernel before this launch
@@ -1025,14 +1056,21 @@ __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedAr
         if (e < LO::f1) v = frag_element<XD, XD>(a.w_last, e - LO::f_last);
         else if (e < LO::f2) v = frag_element<XD, D1>(a.hw1, e - LO::f1);
         else if (e < LO::f3) v = frag_element<D1, D2>(a.hw2, e - LO::f2);
+        else if constexpr (BX) v = bx_element<D2, D3>(a.hw3, e - LO::f3);
         else v = frag_element<D2, D3>(a.hw3, e - LO::f3);
     }
     img[e] = v;
 }
 
-// one packed image, in the layout of the kernel that will read it (hx: f16-split head fragments + scales)
-inline int launch_pack_image(const FusedArgs& a, float* img, bool hx, hipStream_t stream) {
-    if (hx) {
+// one packed image, in the layout of the kernel that will read it (mode 1: f16-split head fragments + scales; mode 2: the bf16 /
+// f32 hybrid of the last head matrix)
+enum { kModeF32 = 0, kModeHx = 1, kModeBx = 2 };
+inline int launch_pack_image(const FusedArgs& a, float* img, int mode, hipStream_t stream) {
+    if (mode == kModeBx) {
+        using LO = FusedLds<32, 100, 100, false, true>;
+        hipLaunchKernelGGL((pack_images_kernel<32, 100, 100, false, true>), dim3((unsigned)((LO::scratch + kPackThreads - 1) / kPackThreads)),
+                           dim3(kPackThreads), 0, stream, a, img);
+    } else if (mode == kModeHx) {
         using LO = FusedLds<32, 100, 100, true>;
         hipLaunchKernelGGL(head_scales_kernel, dim3(8), dim3(256), 0, stream, a, img, (int)LO::hs, 32, 100, 100);
         RGL_LAUNCH_CHECK();
@@ -1048,8 +1086,9 @@ inline int launch_pack_image(const FusedArgs& a, float* img, bool hx, hipStream_
 }
 
 // sized for the larger (f16-split) layout: one buffer size whatever the contraction mode
-constexpr size_t kImageFloats = FusedLds<32, 100, 100, true>::scratch > FusedLds<32, 100, 100, false>::scratch
-                                    ? FusedLds<32, 100, 100, true>::scratch : FusedLds<32, 100, 100, false>::scratch;
+constexpr size_t max3(size_t x, size_t y, size_t z) { return x > y ? (x > z ? x : z) : (y > z ? y : z); }
+constexpr size_t kImageFloats = max3(FusedLds<32, 100, 100, true>::scratch, FusedLds<32, 100, 100, false>::scratch,
+                                     FusedLds<32, 100, 100, false, true>::scratch);
 constexpr size_t kImageBytes = (kImageFloats * sizeof(float) + 255) & ~(size_t)255;
 
 struct FusedPlan {
@@ -1058,6 +1097,8 @@ struct FusedPlan {
     int grid;
     int hr, nt;
     bool hx;                       // f16-split head (RGL_CONTRACT_F16X3)
+    bool bx;                       // bf16 six-term hybrid of the last head matrix (RGL_CONTRACT_BF16X6)
+    int mode() const { return hx ? kModeHx : (bx ? kModeBx : kModeF32); }
     bool ok;
 };
 
@@ -1163,13 +1204,14 @@ inline ItemPlan plan_items(int P, int n_full, int rem, int unit) {
 
 // hx: the f16-split head is wanted (RGL_CONTRACT_F16X3).  It exists for the softmax similarities; such a plan takes every launch
 // size (the two-stage pair has no f16-split head, and the packed image is in this kernel's layout only).
-inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A, int H, int unit = 1, bool hx = false) {
+inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A, int H, int unit = 1, int mode = kModeF32) {
     FusedPlan pl;
     pl.ok = false;
-    pl.hx = hx && fast_similarity_mode(g) == SIM_SOFTMAX;
+    pl.hx = mode == kModeHx && fast_similarity_mode(g) == SIM_SOFTMAX;
+    pl.bx = mode == kModeBx;                    // any similarity: the head does not depend on it
     if (!fast_path_enabled() || !rank1_enabled() || fused_policy() < 0) return pl;
     static const int min_tiles = env_int("RGL_FUSED_MIN_TILES", 1200);
-    if (!pl.hx && fused_policy() == 0 && (long)P * ((A + 15) / 16) < min_tiles) return pl;
+    if (!pl.hx && !pl.bx && fused_policy() == 0 && (long)P * ((A + 15) / 16) < min_tiles) return pl;
     if (fast_similarity_mode(g) < 0 || g.layerwise_graph || g.x_dim != XD || g.num_layer != 2) return pl;
     if (!mlp_is(g.w_r, 9, HID, XD, true) || !mlp_is(g.w_h, 5, HID, XD, true)) return pl;
     if (head_variant(head) != 0) return pl;
@@ -1193,7 +1235,8 @@ inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A,
         a.tail = TailArgs{};
         pl.grid = ip.grid;
     }
-    pl.lds_bytes = (size_t)((pl.hx ? FusedLds<32, 100, 100, true>::scratch : FusedLds<32, 100, 100, false>::scratch) +
+    pl.lds_bytes = (size_t)((pl.hx ? FusedLds<32, 100, 100, true>::scratch
+                                   : pl.bx ? FusedLds<32, 100, 100, false, true>::scratch : FusedLds<32, 100, 100, false>::scratch) +
                             kFusedWaves * fused_scratch_floats(pl.hr, pl.nt, a.sim == SIM_SOFTMAX) + 4) * sizeof(float);   // + the arrival counter of the image
     if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
     a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];
@@ -1206,9 +1249,9 @@ inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A,
     return pl;
 }
 
-template <int HR, int NT, bool SKIP, bool SOFT, bool HX = false>
+template <int HR, int NT, bool SKIP, bool SOFT, bool HX = false, bool BX = false>
 int launch_fused_ts(const FusedPlan& pl, hipStream_t st) {
-    auto kern = children_fused_kernel<HR, NT, SKIP, SOFT, 32, 100, 100, HX>;
+    auto kern = children_fused_kernel<HR, NT, SKIP, SOFT, 32, 100, 100, HX, BX>;
     RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)pl.lds_bytes));
     const int grid = pl.grid;                        // persistent, one 8-wave workgroup per CU (LDS-bound)
@@ -1220,6 +1263,8 @@ int launch_fused_ts(const FusedPlan& pl, hipStream_t st) {
 template <int HR, int NT, bool SKIP>
 int launch_fused_t(const FusedPlan& pl, hipStream_t st) {
     if (pl.hx) return launch_fused_ts<HR, NT, SKIP, true, true>(pl, st);          // plan_fused: softmax similarities only
+    if (pl.bx) return pl.a.sim == SIM_SOFTMAX ? launch_fused_ts<HR, NT, SKIP, true, false, true>(pl, st)
+                                              : launch_fused_ts<HR, NT, SKIP, false, false, true>(pl, st);
     return pl.a.sim == SIM_SOFTMAX ? launch_fused_ts<HR, NT, SKIP, true>(pl, st) : launch_fused_ts<HR, NT, SKIP, false>(pl, st);
 }
 
@@ -1266,9 +1311,9 @@ const float* fused_workspace_image(const void* workspace, size_t workspace_bytes
 // 1 = the fused kernel does not apply (or the workspace cannot hold its images)
 int pack_children_images(const RglGraph* g, const RglMlp* head, int P, int A, int H, void* workspace, size_t workspace_bytes,
                          hipStream_t stream, int hx) {
-    FusedPlan fp = plan_fused(*g, *head, P, A, H, 1, hx != 0);
+    FusedPlan fp = plan_fused(*g, *head, P, A, H, 1, hx);                      // hx: kModeF32 / kModeHx / kModeBx
     if (!fp.ok || !workspace || workspace_bytes < fused_children_workspace_bytes(P, A, H)) return 1;
-    return launch_pack_image(fp.a, image_of(workspace, workspace_bytes), fp.hx, stream);
+    return launch_pack_image(fp.a, image_of(workspace, workspace_bytes), fp.mode(), stream);
 }
 
 // 1 = outside this kernel's envelope
@@ -1293,18 +1338,18 @@ int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, i
             chain = 1;
         }
     }
-    FusedPlan fp = plan_fused(*g, *head, P, A, H, unit, hx != 0);
+    FusedPlan fp = plan_fused(*g, *head, P, A, H, unit, hx);
     // the split-f16 image is 7 KB larger: crowds of 21..32 agents (lane = feature row pass, larger wave scratch) do not fit a CU
     // with it -- they run the f32 form of this kernel on an f32 image packed here (the caller's image is in the other layout)
     bool own_image = false;
-    if (!fp.ok && hx) {
-        fp = plan_fused(*g, *head, P, A, H, unit, false);
+    if (!fp.ok && hx) {                          // (the same for the bf16 hybrid image, 7 KB larger as well)
+        fp = plan_fused(*g, *head, P, A, H, unit, kModeF32);
         own_image = fp.ok;
     }
     if (!fp.ok) return 1;
     if (!workspace || workspace_bytes < fused_children_workspace_bytes(P, A, H)) return 1;
     if (own_image || (!image_ready && !caller_image)) {
-        int rc = launch_pack_image(fp.a, image_of(workspace, workspace_bytes), fp.hx, stream);
+        int rc = launch_pack_image(fp.a, image_of(workspace, workspace_bytes), fp.mode(), stream);
         if (rc) return rc;
     }
     const float* image = (caller_image && !own_image) ? caller_image : image_of(workspace, workspace_bytes);
@@ -1345,22 +1390,26 @@ static bool head_image_args(const RglGraph& g, const RglMlp& head, FusedArgs& a)
     return true;
 }
 
+static int image_mode_of(const MprlPlanner* planner) {
+    return planner->contraction_dtype == RGL_CONTRACT_F16X3 ? kModeHx : (planner->contraction_dtype == RGL_CONTRACT_BF16X6 ? kModeBx : kModeF32);
+}
+
 extern "C" size_t mprl_children_image_bytes(const MprlPlanner* planner) {
     if (!planner) return 0;
-    const bool hx = planner->contraction_dtype == RGL_CONTRACT_F16X3;
-    if (plan_fused(planner->value_graph, planner->value_head, 4096, 16, 1, 1, hx).ok) return kImageBytes;      // architecture test only
+    const int mode = image_mode_of(planner);
+    if (plan_fused(planner->value_graph, planner->value_head, 4096, 16, 1, 1, mode).ok) return kImageBytes;      // architecture test only
     FusedArgs a;
-    return (!hx && head_image_args(planner->value_graph, planner->value_head, a)) ? kImageBytes : 0;
+    return (mode == kModeF32 && head_image_args(planner->value_graph, planner->value_head, a)) ? kImageBytes : 0;
 }
 
 extern "C" int mprl_pack_children_image_f32(const MprlPlanner* planner, float* image, size_t image_bytes, rgl_stream_t stream) {
     if (!planner || !image) return RGL_ERR_NULL;
-    const bool hx = planner->contraction_dtype == RGL_CONTRACT_F16X3;
-    FusedPlan fp = plan_fused(planner->value_graph, planner->value_head, 4096, 16, 1, 1, hx);
+    const int mode = image_mode_of(planner);
+    FusedPlan fp = plan_fused(planner->value_graph, planner->value_head, 4096, 16, 1, 1, mode);
     if (!fp.ok) {
-        if (hx || !head_image_args(planner->value_graph, planner->value_head, fp.a)) return RGL_ERR_BAD_MODE;
-        fp.hx = false;
+        if (mode != kModeF32 || !head_image_args(planner->value_graph, planner->value_head, fp.a)) return RGL_ERR_BAD_MODE;
+        fp.hx = fp.bx = false;
     }
     if (image_bytes < kImageBytes) return RGL_ERR_WORKSPACE;
-    return launch_pack_image(fp.a, image, fp.hx, (hipStream_t)stream);
+    return launch_pack_image(fp.a, image, fp.mode(), (hipStream_t)stream);
 }

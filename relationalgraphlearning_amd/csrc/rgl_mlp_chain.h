@@ -164,7 +164,34 @@ struct HeadFragFloats {
     static constexpr int v = HX ? Tiles<OUT>::v * ((Tiles<IN>::v + 1) / 2) * 2 * 64 * 4 : Tiles<OUT>::v * Tiles<IN>::v * 4 * 64;
 };
 
-template <int D1, int D2, int D3, bool HX = false>
+// BX (round 5, RGL_CONTRACT_BF16X6): the D2 x D3 matrix of the value head -- 40 % of a tile's MFMA cycles -- with its first 64 input
+// features on the MATRIX pipe at full f32 operand width: every operand is three bf16 pieces by round-to-nearest (x = hi + mid + lo
+// EXACTLY: 8 + 8 + 8 significand bits, bf16 has f32's exponent range, no scaling), a K = 32 block is the six terms
+//   W_lo a_hi + W_mid a_mid + W_hi a_lo + W_mid a_hi + W_hi a_mid + W_hi a_hi          (v_mfma_f32_16x16x32_bf16, f32 accumulate)
+// and the three dropped ones are bounded by (2^-26 + 2^-26 + 2^-34) |W||a| < 2^-24 |W||a| -- below the rounding of one f32
+// product, and unbiased (signed pieces).  6 x 16 clocks replace 8 x 32 per 16 x 16 x 32 block, and unlike the f32 MFMA they do not
+// occupy the vector ALUs.  Why only 64 of the 100 input features of ONE matrix: three bf16 pieces are 6 bytes per
+// weight, and the kernel's LDS (106 KB image + 42 KB wave scratch of 160 KB) has 11.5 KB to spare -- two K = 32 chunks of the six
+// full output tiles cost +6.8 KB; the input features 64.., and the partial output tile, stay on the f32 MFMA
+// (profiles/r05_micro_bf16x3_split.txt: the whole head in this form would be 1.67x, and needs +44 KB).
+// Layout of the f3 region: [ot < OTF][chunk < 2][hi | mid | lo][lane] x 8 bf16  |  f32 fragments [ot < OTF][k step of input tiles
+// 4..][lane]  |  the partial output tile's 4 x 4 x 1 fragments [k step][lane].
+template <int IN, int OUT>
+struct BxLayout {
+    static constexpr int IT = Tiles<IN>::v, OT = Tiles<OUT>::v;
+    static constexpr bool P4 = Partial4<OUT>::v;
+    static constexpr int OTF = P4 ? OT - 1 : OT;
+    static constexpr int NCB = 2, ITB = 2 * NCB;                                         // bf16 chunks; input tiles they cover
+    static constexpr int KF = (IT - ITB - 1) * 4 + LastTileSteps<IN>::v;                 // f32 k steps per output tile
+    static constexpr int KP = (IT - 1) * 4 + LastTileSteps<IN>::v;                       // k steps of the partial output tile
+    static constexpr int b16 = 0;
+    static constexpr int f32 = b16 + OTF * NCB * 3 * 64 * 4;
+    static constexpr int p4 = f32 + OTF * KF * 64;
+    static constexpr int total = p4 + (P4 ? KP * 64 : 0);
+    static_assert(IT > ITB, "input tiles 0..3 are full tiles and there is at least one tile beyond them");
+};
+
+template <int D1, int D2, int D3, bool HX = false, bool BX = false>
 struct FusedLds {
     // child-side weight image
     static constexpr int wr1 = 0;
@@ -189,7 +216,8 @@ struct FusedLds {
     static constexpr int f1 = f_last + HeadFragFloats<XD, XD, HX>::v;
     static constexpr int f2 = f1 + HeadFragFloats<XD, D1, HX>::v;
     static constexpr int f3 = f2 + HeadFragFloats<D1, D2, HX>::v;
-    static constexpr int hs = f3 + HeadFragFloats<D2, D3, HX>::v;      // HX: 1 / scale of W_last, hw1, hw2, hw3, wr2, wa, w1, wh2
+    static_assert(!(HX && BX), "one split mode at a time");
+    static constexpr int hs = f3 + (BX ? BxLayout<D2, D3>::total : HeadFragFloats<D2, D3, HX>::v);      // HX: 1 / scale of W_last, hw1, hw2, hw3, wr2, wa, w1, wh2
                                                                          // (HX: the wr2 / wa / w1 / wh2 blocks hold f16 (hi, lo) fragments)
     static constexpr int scratch = hs + (HX ? 8 : 0);                    // per wave: fused_scratch_floats()
 };
@@ -257,6 +285,126 @@ __device__ __forceinline__ void layer_mfma(const float* frags, const f32x4 (&in)
         if constexpr (BIAS) v += bias[16 * OTF + 4 * q];
         out[OTF] = f32x4{v, 0.f, 0.f, 0.f};
     }
+}
+
+// ---- BX: three bf16 pieces per operand, six terms (BxLayout above) -----------------------------------------------------------
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Split3 { bf16x8 h, m, l; };
+
+// pieces of the D-layout tiles 2C, 2C + 1 as one K = 32 B-operand chunk (slot (q, e): tile 2C + e / 4, register e % 4 -- the D
+// registers of the previous layer, packed pairwise, ARE the operand; v_cvt_pk_bf16_f32 rounds to nearest even)
+template <int IT, int C>
+__device__ __forceinline__ Split3 split3_rn(const f32x4 (&in)[IT]) {
+    u32x4 H, M, L;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int t = 2 * C + (p >> 1), r0 = 2 * (p & 1);
+        const f32x2 x = f32x2{in[t][r0], in[t][r0 + 1]};
+        const bf16x2 h = __builtin_convertvector(x, bf16x2);
+        const f32x2 r1 = x - __builtin_convertvector(h, f32x2);             // exact
+        const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+        const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);            // exact, at most 7 significant bits left
+        const bf16x2 l = __builtin_convertvector(r2, bf16x2);               // exact
+        H[p] = __builtin_bit_cast(unsigned, h);
+        M[p] = __builtin_bit_cast(unsigned, m);
+        L[p] = __builtin_bit_cast(unsigned, l);
+    }
+    Split3 s;
+    s.h = __builtin_bit_cast(bf16x8, H);
+    s.m = __builtin_bit_cast(bf16x8, M);
+    s.l = __builtin_bit_cast(bf16x8, L);
+    return s;
+}
+
+// pieces of ONE pair of D-layout tiles (ta, tb) -> a K = 32 chunk
+__device__ __forceinline__ Split3 split3_pair(const f32x4& ta, const f32x4& tb) {
+    const f32x4 pair[2] = {ta, tb};
+    return split3_rn<2, 0>(pair);
+}
+
+// Register budget (the kernel around it holds ~100 VGPRs of crowd quantities across the tile loop and sits at 225 of 256 in its
+// f32 form): the partial output tile FIRST -- it is the only consumer of input tiles 0..3 besides their split -- then one chunk at a
+// time (its two input tiles die in the split), two output tiles per fragment load, then the f32 k steps of the remaining tiles.
+template <int IN, int OUT, bool BIAS>
+__device__ __forceinline__ void layer_mfma_bx(const float* frags, const f32x4 (&in)[Tiles<IN>::v], f32x4 (&out)[Tiles<OUT>::v],
+                                              int lane, const float* bias = nullptr) {
+    using BL = BxLayout<IN, OUT>;
+    constexpr int IT = BL::IT, OTF = BL::OTF, NCB = BL::NCB, ITB = BL::ITB, KF = BL::KF;
+    const int q = lane >> 4;
+    // ONE base register per access width for the whole region (57 KB: within the 64 KB reach of a ds instruction's immediate
+    // offset), made opaque to constant folding: the region sits beyond 64 KB from the start of LDS, and left to itself hipcc
+    // materialises `lane * 4 + constant` once per fragment -- dozens of loop-invariant address registers that it then spills
+    typedef const __attribute__((address_space(3))) float* lds_f;
+    typedef const __attribute__((address_space(3))) bf16x8* lds_b;
+    unsigned o32 = (unsigned)(size_t)(lds_f)(frags + lane), o128 = (unsigned)(size_t)(lds_f)(frags + 4 * lane);
+    asm volatile("" : "+v"(o32), "+v"(o128));
+    const lds_f fl = (lds_f)(size_t)o32;
+    const lds_b fq = (lds_b)(size_t)o128;
+    float v4 = 0.f;
+    if constexpr (BL::P4) {
+        f32x4 p4[2] = {zero4(), zero4()};
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            load_fence();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (it == IT - 1 && r >= LastTileSteps<IN>::v) continue;
+                p4[r & 1] = mfma4x4(fl[BL::p4 + (it * 4 + r) * 64], in[it][r], p4[r & 1]);
+            }
+        }
+        load_fence();
+        v4 = kgroups_reduce_scatter(p4[0] + p4[1]);
+        if constexpr (BIAS) v4 += bias[16 * OTF + 4 * q];
+    }
+#pragma unroll
+    for (int ot = 0; ot < OTF; ++ot) {
+        if constexpr (BIAS) out[ot] = *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * q]);
+        else out[ot] = zero4();
+    }
+    // matrix pipe: per chunk the six terms of two output tiles at a time, term-major (consecutive MFMAs hit different accumulators)
+    constexpr int G = 2;
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        load_fence();
+        const Split3 s = split3_pair(in[2 * c], in[2 * c + 1]);
+#pragma unroll
+        for (int o0 = 0; o0 < OTF; o0 += G) {
+            load_fence();
+            bf16x8 w[G][3];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    if (o0 + g < OTF)
+                        w[g][pc] = fq[(BL::b16 / 4) + (((o0 + g) * NCB + c) * 3 + pc) * 64];
+#define RGL_BX_TERM(WP, AP)                                                                                         \
+    _Pragma("unroll") for (int g = 0; g < G; ++g)                                                                   \
+        if (o0 + g < OTF) out[o0 + g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g][WP], s.AP, out[o0 + g], 0, 0, 0);
+            RGL_BX_TERM(2, h)          // small terms first
+            RGL_BX_TERM(1, m)
+            RGL_BX_TERM(0, l)
+            RGL_BX_TERM(1, h)
+            RGL_BX_TERM(0, m)
+            RGL_BX_TERM(0, h)
+#undef RGL_BX_TERM
+        }
+    }
+    // input tiles ITB.. on the f32 MFMA
+#pragma unroll
+    for (int it = ITB; it < IT; ++it) {
+        load_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (it == IT - 1 && r >= LastTileSteps<IN>::v) continue;
+#pragma unroll
+            for (int ot = 0; ot < OTF; ++ot)
+                out[ot] = mfma4(fl[BL::f32 + (ot * KF + (it - ITB) * 4 + r) * 64], in[it][r], out[ot]);
+        }
+    }
+    load_fence();
+    if constexpr (BL::P4) out[OTF] = f32x4{v4, 0.f, 0.f, 0.f};
 }
 
 // The same product on the f16 matrix pipe at (nearly) f32 accuracy: a = a_hi + a_lo, W = W_hi + W_lo with f16 halves, and

@@ -451,10 +451,11 @@ int tree_search(const MprlPlanner* planner, const float* robot, const float* hum
 
     // weight images of the value-of-children kernels: prepared once, every level copies them into LDS (0 = prepared)
     // (or handed in by the caller, packed once for fixed weights: MprlPlanner::children_image)
-    const int image_ready = (pl.contraction_dtype == RGL_CONTRACT_F32 || pl.contraction_dtype == RGL_CONTRACT_F16X3) &&
+    const int image_mode = pl.contraction_dtype == RGL_CONTRACT_F16X3 ? 1 : (pl.contraction_dtype == RGL_CONTRACT_BF16X6 ? 2 : 0);
+    const int image_ready = (pl.contraction_dtype == RGL_CONTRACT_F32 || image_mode != 0) &&
                             (pl.children_image != nullptr ||
                              rgl::pack_children_images(&pl.value_graph, &pl.value_head, (int)lv[D - 1].P, A, H, ws + scratch_off,
-                                                       (size_t)scratch_bytes, st, pl.contraction_dtype == RGL_CONTRACT_F16X3) == 0);
+                                                       (size_t)scratch_bytes, st, image_mode) == 0);
     const float* sp_image = pl.predictor_image;
     if (!sp_image && rgl::scene_image_bytes(&pl)) {
         float* img = (float*)(ws + align_up(scratch_off + scratch_bytes));

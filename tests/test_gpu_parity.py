@@ -1520,6 +1520,94 @@ def test_properties_of_the_other_baseline_workloads(tag, H, L, D, B, contraction
            % (tag, float((v4 - v1).abs().max())))
 
 
+def test_bf16x6_head_matrix_at_size_and_in_other_shapes(dev):
+    """RGL_CONTRACT_BF16X6 (ABI 6): the first 64 input features of the children kernel's 100 x 100 head matrix
+    as six bf16 MFMA terms over operands that keep all 24 significand bits (three round-to-nearest bf16 pieces each, no scaling:
+    layer_mfma_bx, rgl_mlp_chain.h).  Not a reduced-precision mode -- so it is held to what the f32 kernels are held to:
+    (1) configs[2] in full against the batched oracle at the REGRESSION bound of the f32 kernels (1e-6), decisions as for f32;
+    (2) against the library's own f32 path; (3) against a float64 evaluation of the same search: its deviation must not exceed the
+    f32 kernels' by more than the noise between two f32 summation orders; (4) any finite magnitude (bf16 has f32's exponent
+    range: head layers scaled by 3e4 / 2e-5 / 1e-9 match float64 as well as the f32 kernels do on the same inputs); (5) the other shapes of the kernel: one node tile, depth 3, a crowd whose wave scratch leaves no room for the
+    larger image (falls back to f32 on an image it packs itself), a non-softmax similarity, another head-size-compatible table."""
+    import bench
+
+    class Args:
+        pass
+    Args.layers, Args.depth, Args.width, Args.humans, Args.contraction = 2, 2, 2, 19, "bf16x6"
+    pol = bench.make_policy(Args, dev)
+    B, H = 2048, 19
+    robot, humans = bench.synth_scenes(1000, B, H)
+    act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
+    assert pol.tree_search().last["planner"].contraction_dtype == nat.CONTRACTION_DTYPES["bf16x6"]
+    oracle_out, v1, _ = _oracle_at_size(H, 2, 2, B, robot, humans)
+    err = close(val.cpu().numpy(), oracle_out[1].numpy(), reg=REG_F32)
+    check_decisions("at size, configs[2] in full, bf16x6 head matrix", act, val, oracle_out, [{"value1": v1}], TOL)
+    Args.contraction = "f32"
+    pol32 = bench.make_policy(Args, dev)
+    a32, v32 = pol32.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
+    d32 = float((val - v32).abs().max())
+    same = float((act == a32).float().mean())
+    assert d32 < 1e-6 and same > 0.998, (d32, same)
+    assert d32 > 0.0                                              # (the mode did run: bit-identical values would mean the f32 kernel)
+    n64 = 256
+    P64 = orc.MprlParams.from_checkpoint({k: {kk: vv.double() for kk, vv in v.items()} for k, v in gio.checkpoint("trained", 2).items()})
+    cfg64 = orc.OracleConfig(planning_depth=2, planning_width=2, do_action_clip=True)
+    with torch.no_grad():
+        _, v64, _, _ = orc.mprl_predict_batched(robot[:n64].double(), humans[:n64].double(), P64, cfg64)
+    e_b6 = float((val[:n64].double().cpu() - v64).abs().max())
+    e_32 = float((v32[:n64].double().cpu() - v64).abs().max())
+    r_b6 = float((val[:n64].double().cpu() - v64).pow(2).mean().sqrt())
+    r_32 = float((v32[:n64].double().cpu() - v64).pow(2).mean().sqrt())
+    report("bf16x6 head matrix, configs[2] in full: max |dV| vs the oracle %.2e, vs the f32 kernels %.2e, %.2f %% identical decisions; "
+           "deviation from float64 (256 roots): max %.2e rms %.2e against %.2e / %.2e for the f32 kernels"
+           % (err, d32, 100 * same, e_b6, r_b6, e_32, r_32))
+    assert e_b6 < 1e-7 and r_b6 <= 1.25 * r_32 + 1e-9, (e_b6, e_32, r_b6, r_32)
+    ts, ts32 = pol.tree_search(), pol32.tree_search()
+    r, h = robot[:64].to(dev), humans[:64].to(dev)
+    ex = ts.expand(r, h, parents_are_joint_states=False)
+    worst, worst32 = 0.0, 0.0
+    for scales in ((3e4, 1.0, 1.0, 1.0), (1.0, 2e-5, 3e4, 1.0), (3e4, 3e4, 3e4, 1e-9), (1e-6, 1e-6, 1.0, 1e6)):
+        rels = []
+        for p_, t_ in ((pol, ts), (pol32, ts32)):
+            lins = [m for m in p_.value_estimator.value_network if isinstance(m, torch.nn.Linear)]
+            saved = [(m.weight.detach().clone(), m.bias.detach().clone()) for m in lins]
+            with torch.no_grad():
+                for m, sc in zip(lins, scales):
+                    m.weight.mul_(sc)
+                    m.bias.mul_(sc)
+            got = t_.value_children(ex["child_robot"], ex["humans_next"]).double().cpu()
+            with torch.no_grad():
+                Pm = orc.MprlParams.from_checkpoint({k: {kk: vv.double().cpu() for kk, vv in v.items()} for k, v in p_.get_state_dict().items()})
+                A = t_.num_actions
+                want = orc.value_estimator_forward(ex["child_robot"].double().cpu().reshape(64 * A, 1, 9),
+                                                   ex["humans_next"].double().cpu()[:, None].expand(64, A, H, 5).reshape(64 * A, H, 5),
+                                                   Pm.ve_graph, Pm.value_network, orc.OracleConfig()).reshape(64, A)
+            rels.append(float((got - want).abs().max() / want.abs().max()))
+            with torch.no_grad():
+                for m, (w, b) in zip(lins, saved):
+                    m.weight.copy_(w)
+                    m.bias.copy_(b)
+        worst, worst32 = max(worst, rels[0]), max(worst32, rels[1])
+        # what float32 accumulation leaves of such a head is a few 1e-6 whatever the operand form: the mode must stay within 1.5x
+        # of the f32 kernels' own error on the same inputs (and inside 1e-5, what the f16 split is asked for)
+        assert rels[0] < 1e-5 and rels[0] <= 1.5 * rels[1] + 5e-7, (scales, rels)
+    report("bf16x6 head matrix under extreme layer scales (3e4 / 2e-5 / 1e-9 per layer): worst relative error vs float64 %.1e (f32 "
+           "kernels on the same inputs: %.1e)" % (worst, worst32))
+    for Hh, D, Bb, simf in ((5, 1, 64, "embedded_gaussian"), (19, 3, 24, "embedded_gaussian"), (30, 2, 12, "embedded_gaussian"),
+                            (12, 2, 300, "embedded_gaussian"), (19, 2, 40, "squared")):
+        p6 = make_mprl_policy("trained", D, 2, D > 1, device=dev, similarity=simf)
+        p6.contraction_dtype = "bf16x6"
+        p6.build_action_space(1.0)
+        rb, hb = bench.synth_scenes(77 + Hh, Bb, Hh)
+        a6, v6 = p6.predict_batch(rb.to(dev), hb.to(dev), roots_are_joint_states=True)
+        assert p6.tree_search().last["planner"].contraction_dtype == nat.CONTRACTION_DTYPES["bf16x6"]
+        cfg = orc.OracleConfig(planning_depth=D, planning_width=2, do_action_clip=D > 1, similarity=simf)
+        with torch.no_grad():
+            oa, ov, orv, okept, lv = orc.mprl_predict_batched(rb, hb, gio.oracle_params("trained", 2, "separate", simf), cfg, return_levels=True)
+        close(v6.cpu().numpy(), ov.numpy(), reg=REG_F32)
+        check_decisions("bf16x6, H=%d D=%d B=%d %s" % (Hh, D, Bb, simf), a6, v6, (oa, ov, orv, okept), lv)
+
+
 def test_f16x3_value_head_at_size_and_at_extreme_magnitudes(dev):
     """RGL_CONTRACT_F16X3 (ABI 4): the dense products of the fused children kernel -- value head, embedding chains, robot row / column
     of S, p Xh, the crowd quantities -- as three split-f16 MFMA terms over power-of-two-scaled operands (layer_mfma_hs, mfma_h3).  (1) configs[2] in full -- 2048 roots, bench.py's scenes and weights -- against the batched oracle at the
