@@ -242,7 +242,8 @@ def cpu_baseline(args, robot, humans, budget_s, device_values=None):
             _, v64, _, _ = orc.mprl_predict_batched(robot[:n64].double(), humans[:n64].double(), P64, cfg)
             _, v32, _, _ = orc.mprl_predict_batched(robot[:n64], humans[:n64], P, cfg)
         f64 = {"roots": n64, "max_abs_dV_vs_float64": {k: float((v[:n64].double().cpu() - v64).abs().max())
-                                                       for k, v in device_values.items()}}
+                                                       for k, v in device_values.items()},
+               "rms_dV_vs_float64": {k: float((v[:n64].double().cpu() - v64).pow(2).mean().sqrt()) for k, v in device_values.items()}}
         f64["max_abs_dV_vs_float64"]["f32 oracle (torch CPU)"] = float((v32.double() - v64).abs().max())
     return {"value": n_seq * per_root / t_seq, "unit": "evals/s", "cores": 1, "kind": "port", "float64_check": f64,
             "sample": "%d roots, reference-order batch-1 walk (%d value forwards/root), 1 thread, %.1f s"
@@ -268,8 +269,12 @@ def parse_args(argv=None):
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--depth", type=int, default=2)
     ap.add_argument("--width", type=int, default=2)
-    ap.add_argument("--contraction", choices=("f32", "f16", "f16x3", "bf16x6"), default="f32",
-                    help="f16: f16-input MFMA for the dense middle-layer products (BASELINE configs[4]; needs --layers 3); "
+    ap.add_argument("--contraction", choices=("auto", "f32", "f16", "f16x3", "bf16x6"), default="auto",
+                    help="auto (default): bf16x6 where the value-of-children kernel offers it (2-layer graphs, N <= 32), f32 otherwise, "
+                         "with the plain f32-MFMA line printed beside it at N = 1; "
+                         "bf16x6: f32-WIDTH operands (three bf16 pieces each, six MFMA terms) for the first 64 input features of the "
+                         "children kernel's 100 x 100 head matrix -- admitted to `value`: DESIGN.md 4; "
+                         "f16: f16-input MFMA for the dense middle-layer products (BASELINE configs[4]; needs --layers 3); "
                          "f16x3: the children kernel's dense products as three split-f16 MFMA terms (f32-equivalent to ~2^-21, L = 2, N <= 20)")
     ap.add_argument("--scenes", choices=("clearance", "uniform"), default="clearance",
                     help="human placement of the synthetic scenes: SURVEY 8(d)'s clearance re-draw (default) or the round-1/2 "
@@ -620,8 +625,20 @@ def kernel_sources_digest():
     return h.hexdigest()
 
 
+def resolve_contraction(args):
+    """`auto` -> the mode that carries `value` for this workload.  bf16x6 (RGL_CONTRACT_BF16X6) keeps every operand at f32's 24
+    significand bits and drops < 2^-24 |w||a| per product -- it is the reference's arithmetic width on another pipe, admitted by the
+    criteria of DESIGN.md 4 (suite under the mode, float64 deviation not above the f32 kernels') -- and exists where the fused
+    children kernel runs: two GCN layers, N <= 32.  Deterministic in the workload (never in a timing), so that the lines of
+    N = 1, 2, 4, 8 ranks are the same arithmetic."""
+    args.contraction_requested = args.contraction
+    if args.contraction == "auto":
+        args.contraction = "bf16x6" if (args.layers == 2 and args.humans + 1 <= 32 and not STUB) else "f32"
+    return args
+
+
 def main():
-    args = parse_args()
+    args = resolve_contraction(parse_args())
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -719,9 +736,33 @@ def main():
     # ---- auxiliary reading (never `value`): the same workload with the children kernel's dense products as three split-f16 MFMA
     # terms (contraction_dtype "f16x3": f32-equivalent to ~2^-21 per product, on the f16 matrix pipe), timed the same way, with
     # its deviation from the f32 kernels measured on this very batch
+    # ---- the plain f32-MFMA line beside a bf16x6 `value` ("the f32-MFMA line still printed beside it")
+    f32_line, ts32 = None, None
+    if not STUB and world == 1 and args.contraction == "bf16x6" and B > 0 and os.environ.get("RGL_BENCH_NO_F32_LINE") != "1":
+        import copy
+        a32 = copy.copy(args)
+        a32.contraction = "f32"
+        pol32 = make_policy(a32, device)
+        ts32 = pol32.tree_search()
+        leg32 = Leg(a32, ts32, device, world, rank, main_leg[1], main_leg[2], None)
+        e32, s32 = leg32.timed(args.steps, args.warmup, INIT_STEPS)
+        o_main = ts.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
+        o_main = {k: v.clone() for k, v in o_main.items() if torch.is_tensor(v)}
+        o32 = ts32.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
+        r32 = children_roofline(a32, ts32, device, N, H, None, leg.robot, leg.humans)
+        f32_line = {"value": per_root * total_roots * args.steps / e32, "ms_per_step": e32 / args.steps * 1e3,
+                    "step_ms_device_median": s32[len(s32) // 2], "dtype": "f32",
+                    "max_abs_dV_vs_value_kernels": float((o_main["best_value"] - o32["best_value"]).abs().max()),
+                    "identical_decisions": float((o_main["best_action"] == o32["best_action"]).float().mean()),
+                    "roofline": {k: r32[k] for k in ("achieved", "peak", "frac", "peak_note", "launch_ms", "standalone_launch_ms", "unit")},
+                    "note": "contraction_dtype f32: the same search with every product on v_mfma_f32_16x16x4_f32 / the VALU (what "
+                            "carried `value` until round 4), timed the same way in the same process right after the main leg"}
+        del leg32
+        ts.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
+
     x3 = None
     if (not STUB and world == 1 and args.contraction == "f32" and args.layers == 2 and N <= 32 and B > 0
-            and os.environ.get("RGL_BENCH_NO_F16X3") != "1"):
+            and os.environ.get("RGL_BENCH_F16X3") == "1"):
         import copy
         a3 = copy.copy(args)
         a3.contraction = "f16x3"
@@ -782,6 +823,19 @@ def main():
     }
     if x3 is not None:
         result["f16x3"] = x3
+    if f32_line is not None:
+        result["f32_mfma_line"] = f32_line
+    if args.contraction == "bf16x6":
+        result["admission"] = {
+            "mode": "RGL_CONTRACT_BF16X6", "operand_bits": 24, "pieces_per_operand": "3 x bf16, round to nearest, hi + mid + lo = x exactly",
+            "terms": "6 of 9 (lo*hi, mid*mid, hi*lo, mid*hi, hi*mid, hi*hi), f32 accumulate",
+            "dropped_terms_bound": "(2^-26 + 2^-26 + 2^-34) |w||a| < 2^-24 |w||a| per product",
+            "where": "first 64 input features of the 100 x 100 value-head matrix in children_fused_kernel; everything else f32",
+            "float64_check": "cpu_baseline.float64_check of this line (needs --cpu-seconds > 0); "
+                             "tests/test_gpu_parity.py::test_bf16x6_head_matrix_at_size_and_in_other_shapes asserts it",
+            "suite_under_the_mode": "profiles/r05_suite_under_bf16x6.txt (RGL_CONTRACT_F32_AS=bf16x6: every f32 search of the GPU suite in this mode)"}
+    result["config"]["contraction"] = args.contraction
+    result["config"]["contraction_requested"] = args.contraction_requested
     if STUB:
         result["stub_search"] = True
     if weak is not None:
@@ -790,8 +844,11 @@ def main():
         result["multi_gpu"] = multi
         result["ranks_seen"] = multi["ranks_seen"]
     if rank == 0 and world == 1 and args.cpu_seconds > 0 and not STUB:
-        dv = {"f32 kernels": ts.search(leg.robot[:64], leg.humans[:64], roots_are_joint_states=False,
-                                       want_root_values=False)["best_value"].clone()}
+        dv = {("%s kernels" % args.contraction): ts.search(leg.robot[:64], leg.humans[:64], roots_are_joint_states=False,
+                                                           want_root_values=False)["best_value"].clone()}
+        if ts32 is not None:
+            dv["f32 kernels"] = ts32.search(leg.robot[:64], leg.humans[:64], roots_are_joint_states=False,
+                                            want_root_values=False)["best_value"].clone()
         if x3 is not None:
             dv["f16x3 kernels"] = ts3.search(leg.robot[:64], leg.humans[:64], roots_are_joint_states=False,
                                              want_root_values=False)["best_value"].clone()

@@ -1548,7 +1548,8 @@ def test_bf16x6_head_matrix_at_size_and_in_other_shapes(dev):
     d32 = float((val - v32).abs().max())
     same = float((act == a32).float().mean())
     assert d32 < 1e-6 and same > 0.998, (d32, same)
-    assert d32 > 0.0                                              # (the mode did run: bit-identical values would mean the f32 kernel)
+    if not os.environ.get("RGL_CONTRACT_F32_AS"):
+        assert d32 > 0.0                                          # (the mode did run: bit-identical values would mean the f32 kernel)
     n64 = 256
     P64 = orc.MprlParams.from_checkpoint({k: {kk: vv.double() for kk, vv in v.items()} for k, v in gio.checkpoint("trained", 2).items()})
     cfg64 = orc.OracleConfig(planning_depth=2, planning_width=2, do_action_clip=True)
