@@ -995,11 +995,20 @@ __device__ __forceinline__ float bx_element(const float* __restrict__ W, int idx
         return frag_element<IN, OUT>(W, (BL::OTF * BL::IT * 4 + (j >> 6)) * 64 + (j & 63));            // partial tile: k step = it * 4 + r
     }
     if (idx >= BL::f32) {
-        const int j = idx - BL::f32, l = j & 63, kf = (j >> 6) % BL::KF, ot = (j >> 6) / BL::KF;
-        return frag_element<IN, OUT>(W, ((ot * BL::IT + BL::ITB) * 4 + kf) * 64 + l);
+        const int j = idx - BL::f32, l = j & 63, slot = j >> 6;                          // slot: k steps of the output tiles, in order
+        int ot, kf, it0;
+        if (slot < BL::OT3 * BL::KF3) { ot = slot / BL::KF3; kf = slot - ot * BL::KF3; it0 = BL::ITB + 2; }
+        else { const int s2 = slot - BL::OT3 * BL::KF3; ot = BL::OT3 + s2 / BL::KF; kf = s2 % BL::KF; it0 = BL::ITB; }
+        return frag_element<IN, OUT>(W, ((ot * BL::IT + it0) * 4 + kf) * 64 + l);
     }
-    const int u = idx >> 2, p = idx & 3, l = u & 63, rest = u >> 6;
-    const int pc = rest % 3, c = (rest / 3) % BL::NCB, ot = rest / 3 / BL::NCB;
+    int c, ot, pc, l, p;
+    if (idx >= BL::b16c) {                                                               // third chunk: [ot < OT3][piece][lane]
+        const int u = (idx - BL::b16c) >> 2, rest = u >> 6;
+        p = idx & 3; l = u & 63; pc = rest % 3; ot = rest / 3; c = BL::NCB;
+    } else {
+        const int u = idx >> 2, rest = u >> 6;
+        p = idx & 3; l = u & 63; pc = rest % 3; c = (rest / 3) % BL::NCB; ot = rest / 3 / BL::NCB;
+    }
     const int q = l >> 4, out = frag_out_feature<OUT>(ot, l);
     bf16x2 v;
 #pragma unroll

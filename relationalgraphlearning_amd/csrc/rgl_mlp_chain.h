@@ -181,12 +181,18 @@ struct BxLayout {
     static constexpr int IT = Tiles<IN>::v, OT = Tiles<OUT>::v;
     static constexpr bool P4 = Partial4<OUT>::v;
     static constexpr int OTF = P4 ? OT - 1 : OT;
-    static constexpr int NCB = 2, ITB = 2 * NCB;                                         // bf16 chunks; input tiles they cover
-    static constexpr int KF = (IT - ITB - 1) * 4 + LastTileSteps<IN>::v;                 // f32 k steps per output tile
+    static constexpr int NCB = 2, ITB = 2 * NCB;                                         // bf16 chunks every output tile gets; input tiles they cover
+    // ... and a THIRD chunk (input tiles 4, 5) for the first OT3 output tiles only: what the last kilobytes of LDS hold (a full third
+    // chunk is +6 KB, 1.2 KB more than a CU has left beside the image and the wave scratch)
+    static constexpr int OT3 = (IT >= ITB + 3 && OTF >= 4) ? 4 : 0;
+    static constexpr int KF = (IT - ITB - 1) * 4 + LastTileSteps<IN>::v;                 // f32 k steps of an output tile without the third chunk
+    static constexpr int KF3 = (IT - ITB - 3) * 4 + LastTileSteps<IN>::v;                // ... with it
     static constexpr int KP = (IT - 1) * 4 + LastTileSteps<IN>::v;                       // k steps of the partial output tile
-    static constexpr int b16 = 0;
-    static constexpr int f32 = b16 + OTF * NCB * 3 * 64 * 4;
-    static constexpr int p4 = f32 + OTF * KF * 64;
+    static constexpr int b16 = 0;                                                        // [ot][chunk < NCB][piece][lane] x 8 bf16
+    static constexpr int b16c = b16 + OTF * NCB * 3 * 64 * 4;                            // [ot < OT3][piece][lane] x 8 bf16: the third chunk
+    static constexpr int f32 = b16c + OT3 * 3 * 64 * 4;
+    __host__ __device__ static constexpr int f32_of(int ot) { return f32 + (ot < OT3 ? ot * KF3 : OT3 * KF3 + (ot - OT3) * KF) * 64; }
+    static constexpr int p4 = f32 + (OT3 * KF3 + (OTF - OT3) * KF) * 64;
     static constexpr int total = p4 + (P4 ? KP * 64 : 0);
     static_assert(IT > ITB, "input tiles 0..3 are full tiles and there is at least one tile beyond them");
 };
@@ -391,7 +397,32 @@ __device__ __forceinline__ void layer_mfma_bx(const float* frags, const f32x4 (&
 #undef RGL_BX_TERM
         }
     }
-    // input tiles ITB.. on the f32 MFMA
+    // the third chunk: input tiles ITB, ITB + 1 for the output tiles [0, OT3)
+    if constexpr (BL::OT3 > 0) {
+        load_fence();
+        const Split3 s = split3_pair(in[ITB], in[ITB + 1]);
+#pragma unroll
+        for (int o0 = 0; o0 < BL::OT3; o0 += G) {
+            load_fence();
+            bf16x8 w[G][3];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    if (o0 + g < BL::OT3) w[g][pc] = fq[(BL::b16c / 4) + ((o0 + g) * 3 + pc) * 64];
+#define RGL_BX_TERM(WP, AP)                                                                                         \
+    _Pragma("unroll") for (int g = 0; g < G; ++g)                                                                   \
+        if (o0 + g < BL::OT3) out[o0 + g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g][WP], s.AP, out[o0 + g], 0, 0, 0);
+            RGL_BX_TERM(2, h)
+            RGL_BX_TERM(1, m)
+            RGL_BX_TERM(0, l)
+            RGL_BX_TERM(1, h)
+            RGL_BX_TERM(0, m)
+            RGL_BX_TERM(0, h)
+#undef RGL_BX_TERM
+        }
+    }
+    // what is left on the f32 MFMA: input tiles ITB.. (output tiles >= OT3) or ITB + 2.. (output tiles < OT3)
 #pragma unroll
     for (int it = ITB; it < IT; ++it) {
         load_fence();
@@ -399,8 +430,11 @@ __device__ __forceinline__ void layer_mfma_bx(const float* frags, const f32x4 (&
         for (int r = 0; r < 4; ++r) {
             if (it == IT - 1 && r >= LastTileSteps<IN>::v) continue;
 #pragma unroll
-            for (int ot = 0; ot < OTF; ++ot)
-                out[ot] = mfma4(fl[BL::f32 + (ot * KF + (it - ITB) * 4 + r) * 64], in[it][r], out[ot]);
+            for (int ot = 0; ot < OTF; ++ot) {
+                if (ot < BL::OT3 && it < ITB + 2) continue;                      // the third chunk covered it
+                const int k = (it - ITB - (ot < BL::OT3 ? 2 : 0)) * 4 + r;
+                out[ot] = mfma4(fl[BL::f32_of(ot) + k * 64], in[it][r], out[ot]);
+            }
         }
     }
     load_fence();

@@ -2632,7 +2632,9 @@ def test_product_trainer_replays_stay_valid_while_the_memory_grows(dev):
     for a, e in ((ve_c, ve_e), (sp_c, sp_e)):
         for (k, pa), (_, pe) in zip(a.state_dict().items(), e.state_dict().items()):
             worst = max(worst, float((pa - pe).abs().max()))
-    assert worst <= 1e-5, worst
+    # eight Adam steps (value + predictor each) of two arithmetic paths -- capturable Adam + tile backward vs plain Adam + per-scene
+    # backward: measured 1.6e-5; a replay that gathered the wrong rows would be off by the learning rate per step (1e-3) and more
+    assert worst <= 1e-4, worst
     for (a, b), (c_, d) in zip(l_c, l_e):
         assert abs(a - c_) <= 1e-6 * max(1.0, abs(c_)) and abs(b - d) <= 1e-6 * max(1.0, abs(d))
     report("product MPRLTrainer: captured steps replayed across a growing (and wrapping) replay memory stay within %.1e of the eager "
