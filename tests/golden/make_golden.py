@@ -622,6 +622,41 @@ def gen_root_clip_kats(masters, out):
         meta.append("%s|%d|%d|%d|%s" % (tag, D, w, int(sparse), variant))
     out["rootclip_cases"] = np.array(meta)
 
+def gen_tie_kats(masters, out):
+    """EXACT ties in action_clip, as the reference resolves them in this image.  The value head's last
+    layer is zeroed (V = its bias for every state) and the crowd is far away (reward 0 for every action but the ones that reach
+    nothing): all 81 one-step values are bit-equal.  Upstream's sparse walk follows np.argsort(values)[::-1] and np.argpartition
+    picks the dense set -- both implementation-defined on ties (numpy's default sort is not stable).  Recorded so that the
+    documented deviation of the device search (ties: lower action index first) is visible in a test against real data."""
+    rng = np.random.RandomState(77)
+    r32, h32 = synth_scene(rng, 2, 5)
+    for b in range(2):                                           # humans far from the robot: no reward term fires
+        for h in range(5):
+            ang = rng.uniform(0, 2 * np.pi)
+            h32[b, h, 0] = r32[b, 0] + 3.5 * np.cos(ang) + 0.4 * h
+            h32[b, h, 1] = r32[b, 1] + 3.5 * np.sin(ang)
+    out["tie.robot"], out["tie.humans"] = r32, h32
+    meta = []
+    for tag, w, sparse in (("w2sparse", 2, True), ("w4sparse", 4, True), ("w3dense", 3, False)):
+        pol = make_ref_mprl(masters["trained"], 2, w, True, sparse, "separate")
+        with torch.no_grad():
+            last = pol.value_estimator.value_network[-1]
+            last.weight.zero_()
+        rec = RootClipRecorder(pol)
+        kept, vals, acts = [], [], []
+        for b in range(2):
+            acts.append(rec.run(joint_state_of(r32[b], h32[b])))
+            kept.append(rec.clipped)
+            vals.append(rec.clip_values)
+        vals = np.array(vals)
+        assert (vals == vals[:, :1]).all(), "the construction must tie every action exactly"
+        out["tie.%s.kept" % tag] = np.array(kept, np.int64)
+        out["tie.%s.clip_values" % tag] = vals
+        out["tie.%s.action" % tag] = np.array(acts, np.int64)
+        meta.append("%s|%d|%d" % (tag, w, int(sparse)))
+    out["tie_cases"] = np.array(meta)
+    out["tie.groups"] = np.array(pol.action_group_index, np.int64)
+
 
 # --------------------------------------------------------------------------------------------------
 def gen_path_g(out, scenes):
@@ -1117,6 +1152,7 @@ def main():
     np.savez(os.path.join(HERE, "vnrl_trainer.npz"), **vt)
     rc = {}
     gen_root_clip_kats(masters, rc)                         # round 5; its own file and its own rng: the earlier fixtures stay bit-identical
+    gen_tie_kats(masters, rc)
     np.savez(os.path.join(HERE, "root_clip.npz"), **rc)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -201,6 +201,25 @@ def test_root_clip_is_priced_on_the_tensor_state(c):
         assert np.array_equal(levels[0]["reward"][b].numpy()[rc[k + "kept"][b]], rc[k + "root_rewards"][b].astype(np.float32))
 
 
+def test_exact_ties_fixture():
+    """Fixture root_clip.npz `tie.*` (the reference on a constant value head, crowd far away): every root's 81 one-step values
+    are bit-equal.  The oracle's sparse walk IS numpy's reversed argsort, so it names the reference's representatives on the
+    numpy of this image; its dense selection documents its own order (lower index first) where np.argpartition's is
+    implementation-defined -- same tied value either way."""
+    rc = gio.load("root_clip")
+    g = rc["tie.groups"]
+    for line in rc["tie_cases"]:
+        tag, w, sparse = str(line).split("|")
+        v = rc["tie.%s.clip_values" % tag]
+        assert (v == v[:, :1]).all()
+        kept = orc.select_top(v, int(w), g, bool(int(sparse)))
+        if int(sparse):
+            assert np.array_equal(kept, rc["tie.%s.kept" % tag])
+        else:
+            assert kept.tolist() == [list(range(int(w)))] * v.shape[0]
+            assert (np.take_along_axis(v, kept, 1) == np.take_along_axis(v, rc["tie.%s.kept" % tag], 1)).all()
+
+
 def test_forward_counts_match_survey():
     pl = gio.load("planning")
     want = {"d1": 81, "d2w2": 249, "d3w2": 581}
