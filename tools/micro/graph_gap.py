@@ -1,0 +1,46 @@
+"""Micro-benchmark: why is a replayed search 3-5 % slower than the same launches issued directly?
+N dependent, launch-sized kernels (a 64-element in-place add: ~2 us of device time each, every one waiting for the one before),
+issued (a) directly on the stream, (b) as one captured hipGraph -- device time from the first start to the last end (HIP events
+around the burst), per kernel.  What differs between the two is only how ROCm 7.2 chains dependent kernel nodes: in-order queue
+packets with the barrier bit (stream) against the graph executor's own dependency handling."""
+import torch
+
+dev = torch.device("cuda:0")
+x = torch.zeros(64, device=dev)
+
+
+def burst(n):
+    for _ in range(n):
+        x.add_(1.0)
+
+
+def timed(fn, reps=200):
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(5):
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) / reps)
+    return best * 1e3          # us per call of fn
+
+
+print("dependent launch-sized kernels per burst: device us per burst, per kernel")
+for n in (4, 6, 8, 16):
+    direct = timed(lambda: burst(n))
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        burst(n)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        burst(n)
+    replay = timed(g.replay)
+    print("n = %2d   direct %7.2f us (%.2f per kernel)   graph replay %7.2f us (%.2f per kernel)   replay - direct = %+.2f us per kernel"
+          % (n, direct, direct / n, replay, replay / n, (replay - direct) / n))

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Everything profiles/r04_* is made of, in one GPU call, at the revision given as $2 (run after the last kernel commit):
-#   gpurun --timeout 2700 -- 'bash tools/round4_all.sh r04_final <git-hash>'
+# Everything profiles/<tag>_* is made of, in one GPU call, at the revision given as $2 (run after the last kernel commit):
+#   gpurun --timeout 2700 -- 'bash tools/round_all.sh r05_final <git-hash>'
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r04_final}
+TAG=${1:-r05_final}
 HASH=${2:-unknown}
 O=$R/gpurun_out
 mkdir -p $O
@@ -32,7 +32,7 @@ bash tools/timeline.sh $O/${TAG}_timeline.md --humans 49 --layers 3 --roots 256 
 # 3. configs[4]: kernel trace of the bench commands + PMC passes of the deep kernel / head kernel, f32 and f16 (VERDICT r3 missing 2)
 ( cd /tmp && export TMPDIR=/tmp
   { echo "# $TAG: BASELINE configs[4] per-GPU share (N = 50, L = 3, D = 2, w = 2, 256 roots), source revision $HASH"; echo;
-    for c in f32 f16; do rm -rf /tmp/prof_c5; RGL_BENCH_NO_F16X3=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_c5 -o c5 -- python $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0 --humans 49 --layers 3 --roots 256 --contraction $c > /tmp/c5.log 2>&1
+    for c in f32 f16; do rm -rf /tmp/prof_c5; RGL_BENCH_NO_F32_LINE=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_c5 -o c5 -- python $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0 --humans 49 --layers 3 --roots 256 --contraction $c > /tmp/c5.log 2>&1
       echo "== contraction $c"; echo; echo '```'; grep "^{" /tmp/c5.log; echo '```'; echo; python $R/tools/rocpd_summary.py $(find /tmp/prof_c5 -name "*results.db" | head -1) | head -12; echo; done; } > $O/${TAG}_c5_kernel_stats.md )
 bash tools/deep_pmc.sh 512 > /dev/null 2>&1
 cat $O/deep_pmc.md >> $O/${TAG}_c5_kernel_stats.md
@@ -43,5 +43,7 @@ python tools/train_step_time.py --graph 2>/dev/null | grep "^{" > $O/${TAG}_trai
 # 5. path G (with its roofline line), closed-loop episodes, PCIe-inclusive step, single-decision latency rides in other_configs.sh
 { python tools/gcn_trace.py; python tools/episodes.py; } > $O/${TAG}_path_g_and_episodes.txt 2>&1
 python tools/pcie_inclusive.py > $O/${TAG}_pcie_inclusive.txt 2>&1
-./tools/micro/mfma_4x4 > $O/${TAG}_micro_mfma_4x4.txt 2>&1
+bash tools/path_g_profile.sh $TAG > /dev/null 2>&1                 # kernel trace + counter passes of the path-G launches
+python tools/micro/graph_gap.py > $O/${TAG}_micro_graph_gap.txt 2>&1
+cat $O/${TAG}_micro_graph_gap.txt
 tail -12 $O/${TAG}_other_configs.log; tail -14 $O/${TAG}_share_regime.txt; cat $O/${TAG}_trainer_api.jsonl | cut -c1-220; grep "^{" $O/${TAG}_path_g_and_episodes.txt | cut -c1-300; head -c 700 $O/${TAG}_bench_driver_style.json

@@ -23,7 +23,7 @@ rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python $R/bench.py --st
   echo
   python $R/tools/rocpd_summary.py $(find $O/trace -name "*results.db" | head -1)
   echo
-  echo "## PMC counters, value-of-children kernels at P = 4096 parents (one tree level of the workload)"
+  echo "## PMC counters, value-of-children kernels at P = 4096 parents (one tree level of the workload), in the mode that carries \`value\` (bf16x6)"
   echo
   echo '`rocprofv3 --kernel-trace --pmc <list> -- python tools/profile_children.py`, separate passes per counter group; SQ values are per shader engine (32 SEs; SQ_ACTIVE_* / *_BUSY / WAVE / WAIT counters in quad-cycles); FETCH/WRITE_SIZE in KiB per dispatch.'
   echo
@@ -43,25 +43,25 @@ done
 echo '```' >> $O.md
 {
   echo
-  echo "## Split-f16 value head (contraction f16x3), same launch: co-execution of the f16 MFMAs with the VALU"
+  echo "## The plain f32-MFMA form of the same launch (contraction f32) beside it: instruction counts, co-execution"
   echo
-  echo '`rocprofv3 --kernel-trace --pmc <list> -- python tools/profile_children.py --contraction f16x3`'
+  echo '`rocprofv3 --kernel-trace --pmc <list> -- python tools/profile_children.py --contraction f32`'
   echo
   echo '```'
 } >> $O.md
 for grp in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_ANY"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp -d $O/pmc$i -o pmc -- python $R/tools/profile_children.py --contraction f16x3 > $O/pmc$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp -d $O/pmc$i -o pmc -- python $R/tools/profile_children.py --contraction f32 > $O/pmc$i.log 2>&1
   f=$(find $O/pmc$i -name "*results.db" | head -1)
   if [ -n "$f" ]; then python $R/tools/pmc_summary.py $f children_fused >> $O.md; else echo "(pass $i: $grp -- no database)" >> $O.md; fi
 done
 {
   echo '```'
   echo
-  echo "kernel durations of that mode (rocprofv3 --kernel-trace --stats -- python tools/profile_children.py --contraction f16x3):"
+  echo "kernel durations of that mode (rocprofv3 --kernel-trace --stats -- python tools/profile_children.py --contraction f32):"
   echo
 } >> $O.md
-rocprofv3 --kernel-trace --stats -d $O/x3trace -o x3 -- python $R/tools/profile_children.py --contraction f16x3 > $O/x3.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/x3trace -o x3 -- python $R/tools/profile_children.py --contraction f32 > $O/x3.log 2>&1
 python $R/tools/rocpd_summary.py $(find $O/x3trace -name "*results.db" | head -1) | head -6 >> $O.md
 python - <<PY
 import json, sqlite3, sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Timeline of ONE step out of a rocprofv3 kernel-trace database of `bench.py --graph off` (RGL_BENCH_NO_F16X3=1): every dispatch
+"""Timeline of ONE step out of a rocprofv3 kernel-trace database of `bench.py --graph off` (RGL_BENCH_NO_F32_LINE=1): every dispatch
 of the step in launch order with its start offset, duration, gap to the previous kernel's end and grid size -- where a short
 step's time goes.  The step is found as the period of the kernel-name sequence in the middle of the trace; it starts at the
 state-predictor kernel with the smallest grid (level 0).
