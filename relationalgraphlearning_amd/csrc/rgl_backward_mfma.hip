@@ -25,7 +25,8 @@
 // ...) do not cover -- other embedding MLPs, x_dim = 64 -- instead of the general VALU kernel; sibling scenes of a rollout share
 // their crowd's embedded rows.
 //
-// Envelope of both: embedded_gaussian or gaussian similarity, one adjacency for all layers, x_dim 32 | 64, 1-3 layers, N <= 64; any
+// Envelope of both: embedded_gaussian, gaussian, squared, equal_attention or diagonal similarity (round 5: the three plain-weight
+// normalisations), one adjacency for all layers, x_dim 32 | 64, 1-3 layers, N <= 64; any
 // embedding MLPs and heads within the ABI limits.  Outside it: return 1 (the caller falls back to rgl_backward.hip / the general kernel).
 //
 // Differentiated forward: graph_model.py:99-130, value_estimator.py:11-20, state_predictor.py:28-36, gcn.py:95-128.
@@ -535,6 +536,8 @@ struct GraphArgs {
     const float* Ws[3];
     float* slabs;                // [workgroups][(has w_a + L) * X * X]
     int S, N, skip, spc, hl_row0;
+    int norm;                    // row normalisation of the similarity block (graph_model.py:63-93): 0 softmax(S) (embedded_gaussian,
+                                 // gaussian); 1 squared: S^2 / sum_row S^2 (:86-89); 2 equal_attention: 1 / N (:90-91); 3 diagonal: I (:92-93)
     // floats between the robot rows of consecutive scenes / the human rows of consecutive crowds, in Xr / Xh and in dXr / dXh: X and
     // (N - 1) X for the compact arrays above, N X for both when a scene's rows are one [N][X] block (Xh = Xr + X)
     int xr_stride, xh_stride;
@@ -668,12 +671,25 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
                           [&](int k, int j) { return Wa[k * FLD + fn + j]; });
             put(G, acc);
         };
+        const int norm = a.norm;
+        const bool from_s = norm <= 1;                  // the adjacency is a function of S (it is a constant otherwise)
+        // squared similarity: A is kept SIGNED in LDS -- sign(S_ij) |A_ij| -- and the row's Z_i = sum_j S_ij^2 in the row's padding
+        // column, so that the backward pass gets S_ij = sign sqrt(|A_ij| Z_i) back without a buffer of its own; every consumer of
+        // A reads it through aval()
+        auto aval = [&](float x) { return norm == 1 ? fabsf(x) : x; };
         if (embedded) {
             make_G();
             __syncthreads();
         }
         const float* GX = embedded ? G : X;
-        if (a_on) {   // S = G X^T   (graph_model.py:64-69)
+        if (!from_s) {
+            const float c = norm == 2 ? 1.f / (float)N : 0.f;
+            for (int idx = threadIdx.x; idx < NP * ALD; idx += W * 64) {
+                const int row = idx / ALD, col = idx - row * ALD;
+                A[idx] = (row < N && col < N) ? (norm == 2 ? c : (row == col ? 1.f : 0.f)) : 0.f;
+            }
+        }
+        if (a_on && from_s) {   // S = G X^T   (graph_model.py:64-69)
             f32x4 acc[1][NTW];
             clear<1, NTW>(acc);
             mm<1, NTW, 8>(acc, XW / 4, [&](int i, int k) { return GX[min(am + i, last) * FLD + k]; },
@@ -684,8 +700,24 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
             });
         }
         __syncthreads();
+        // squared (graph_model.py:86-89): w = S^2 over its row sum
+        for (int row = wave * 4 + kq; norm == 1 && row < N; row += W * 4) {
+            float* r = A + row * ALD;
+            float sv[NT], w[NT], sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                sv[j] = l16 + 16 * j < N ? r[l16 + 16 * j] : 0.f;
+                w[j] = sv[j] * sv[j];
+                sum += w[j];
+            }
+            sum = row16_sum(sum);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                if (l16 + 16 * j < N) r[l16 + 16 * j] = copysignf(w[j] / sum, sv[j]);
+            if (l16 == 0) r[NT * 16] = sum;
+        }
         // row softmax: 16 lanes per row, four rows per wave and pass
-        for (int row = wave * 4 + kq; row < N; row += W * 4) {
+        for (int row = wave * 4 + kq; norm == 0 && row < N; row += W * 4) {
             float* r = A + row * ALD;
             float v[NT], mx = -3.4e38f;
 #pragma unroll
@@ -714,7 +746,7 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
             {   // T_l = A H_l
                 f32x4 acc[1][XTW];
                 clear<1, XTW>(acc);
-                mm<1, XTW, 8>(acc, NK, [&](int i, int k) { return A[min(fm + i, last) * ALD + k]; },
+                mm<1, XTW, 8>(acc, NK, [&](int i, int k) { return aval(A[min(fm + i, last) * ALD + k]); },
                               [&](int k, int j) { return Hc[k * FLD + fn + j]; });
                 put(Tl, acc);
             }
@@ -776,7 +808,7 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
                 {   // dH_l = A^T dT (+ dH_{l+1} through the skip connection); the next layer's dZ right away
                     f32x4 acc[1][XTW];
                     clear<1, XTW>(acc);
-                    mm<1, XTW, 8>(acc, NK, [&](int mi, int k) { return A[k * ALD + fm + mi]; },
+                    mm<1, XTW, 8>(acc, NK, [&](int mi, int k) { return aval(A[k * ALD + fm + mi]); },
                                   [&](int k, int j) { return dT[k * FLD + fn + j]; });
 #pragma unroll
                     for (int nt = 0; nt < XTW; ++nt)
@@ -796,11 +828,29 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
             if (a_on)
                 each<1, NTW>(dAacc, [&](int i, int j, float v, int, int, int) {
                     const int row = am + i, col = an + j;
-                    if (row < NP) dA[row * ALD + col] = (row < N && col < N) ? v : 0.f;
+                    if (row < NP) dA[row * ALD + col] = (row < N && col < N && from_s) ? v : 0.f;      // constant adjacency: dS = 0
                 });
             if (embedded) make_G();            // dT's buffer is free again
             __syncthreads();
-            for (int row = wave * 4 + kq; row < N; row += W * 4) {
+            // through the squared normalisation: dS_ij = 2 S_ij (dA_ij - sum_k dA_ik A_ik) / Z_i, S_ij = sign sqrt(|A_ij| Z_i)
+            for (int row = wave * 4 + kq; norm == 1 && row < N; row += W * 4) {
+                float* d = dA + row * ALD;
+                const float* p = A + row * ALD;
+                const float zi = p[NT * 16];
+                float dv[NT], pv[NT], dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const bool ok = l16 + 16 * j < N;
+                    dv[j] = ok ? d[l16 + 16 * j] : 0.f;
+                    pv[j] = ok ? p[l16 + 16 * j] : 0.f;
+                    dot = fmaf(dv[j], fabsf(pv[j]), dot);
+                }
+                dot = row16_sum(dot);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    if (l16 + 16 * j < N) d[l16 + 16 * j] = 2.f * copysignf(sqrtf(fabsf(pv[j]) / zi), pv[j]) * (dv[j] - dot);
+            }
+            for (int row = wave * 4 + kq; norm == 0 && row < N; row += W * 4) {
                 float* d = dA + row * ALD;
                 const float* p = A + row * ALD;
                 float dv[NT], pv[NT], dot = 0.f;
@@ -1134,12 +1184,22 @@ extern "C" int rgl_debug_read_backward_phase_cycles(unsigned long long* out16, i
 
 namespace {
 
-// what the tile kernels cover: embedded_gaussian / gaussian similarity, one adjacency for all layers, x_dim 32 or 64, 1-3 layers,
-// N <= 64; any embedding MLPs and heads within the ABI limits
+// what the tile kernels cover: embedded_gaussian / gaussian (softmax of S) and -- round 5 -- squared / equal_attention / diagonal
+// (plain weights: graph_model.py:86-93), one adjacency for all layers, x_dim 32 or 64, 1-3 layers, N <= 64; any embedding MLPs and
+// heads within the ABI limits.  The cosine family, the pair-MLP similarity and layerwise graphs stay on the per-scene kernels.
+int tiles_norm(const RglGraph& g) {
+    switch (g.similarity) {
+        case RGL_SIM_EMBEDDED_GAUSSIAN: case RGL_SIM_GAUSSIAN: return 0;
+        case RGL_SIM_SQUARED: return 1;
+        case RGL_SIM_EQUAL_ATTENTION: return 2;
+        case RGL_SIM_DIAGONAL: return 3;
+        default: return -1;
+    }
+}
 bool tiles_cover(const RglGraph& g, int H) {
     const int N = H + 1, L = g.num_layer;
     if ((g.x_dim != 32 && g.x_dim != 64) || g.layerwise_graph || L < 1 || L > 3 || N > 64 || H < 1) return false;
-    return g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN || g.similarity == RGL_SIM_GAUSSIAN;
+    return tiles_norm(g) >= 0;
 }
 
 void graph_args(GraphArgs& ga, const RglGraph& g, int S, int N, int spc) {
@@ -1147,6 +1207,7 @@ void graph_args(GraphArgs& ga, const RglGraph& g, int S, int N, int spc) {
     ga.w_a = g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN ? g.w_a : nullptr;
     for (int l = 0; l < g.num_layer; ++l) ga.Ws[l] = g.Ws[l];
     ga.S = S; ga.N = N; ga.skip = g.skip_connection ? 1 : 0; ga.spc = spc;
+    ga.norm = tiles_norm(g);
     ga.xr_stride = g.x_dim; ga.xh_stride = (N - 1) * g.x_dim;
 }
 

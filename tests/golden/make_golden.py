@@ -962,9 +962,11 @@ def gen_trainer_kats(masters, out):
     rewards = rng.uniform(-0.25, 1.0, (n, 1)).astype(np.float32)
     out["tr.robot"], out["tr.humans"], out["tr.next_robot"], out["tr.next_humans"], out["tr.rewards"] = robot, humans, robot2, humans2, rewards
     meta = []
-    for tag, detach in (("plain", False), ("detach", True)):
+    # ("squared", round 5): a non-default similarity function through the reference trainer (graph_model.py:86-89) -- what the tile
+    # backward's plain-weight normalisations are held against under RGL_BACKWARD_MFMA=2
+    for tag, detach, sim in (("plain", False, "embedded_gaussian"), ("detach", True, "embedded_gaussian"), ("squared", False, "squared")):
         torch.manual_seed(0)
-        pc, g1, g2, ve, sp = build_ref_modules(masters["trained"], 2, "embedded_gaussian", False, False)
+        pc, g1, g2, ve, sp = build_ref_modules(masters["trained"], 2, sim, False, False)
         memory = ReplayMemory(1000)
         for i in range(n):
             memory.push((torch.tensor(robot[i:i + 1]), torch.tensor(humans[i]), torch.zeros(1), torch.tensor(rewards[i]),
@@ -981,7 +983,7 @@ def gen_trainer_kats(masters, out):
             out.update(flat("tr.%s.%s." % (tag, name), mod.state_dict()))
         meta.append("%s|%d" % (tag, int(detach)))
     out["trainer_cases"] = np.array(meta)
-    policy_config(gcn__skip_connection=True)                     # restore the class-level config attribute
+    policy_config(gcn__skip_connection=True, gcn__similarity_function="embedded_gaussian")      # restore the class-level config attributes
 
 
 def gen_vnrl_trainer_kats(pg_fixture, out):
