@@ -252,8 +252,9 @@ typedef struct MprlPlanner {
                                  * a_lo + W_mid a_hi + W_hi a_mid + W_hi a_hi of v_mfma_f32_16x16x32_bf16 with f32  *
                                  * accumulation; the dropped terms are < 2^-24 |W||a| (below one f32 rounding).    *
                                  * Offered by the value-of-children kernel of the shipped shape for 8 192 of the   *
-                                 * 10 000 products of the 100 x 100 head matrix (what its LDS holds: DESIGN.md 4); *
-                                 * everything else, and every other kernel, computes plain f32.                    */
+                                 * 10 000 products of the 100 x 100 head matrix (what its LDS holds: DESIGN.md 4)  *
+                                 * and by the state predictor's scene kernel (softmax similarity, 17..32 nodes) for *
+                                 * its weight products (Wa, W_l, motion head); everything else computes plain f32. */
     double time_step;
     double gamma_bar;           /* gamma^(time_step * v_pref), get_normalized_gamma (:104-105)  */
     const double* actions;      /* device [A][2] float64, table of build_action_space (:155-190)*/
@@ -273,8 +274,10 @@ typedef struct MprlPlanner {
      * stand-alone mprl_value_children_f32 call) packs the image into its workspace first (~5 us). */
     const float* children_image;
     /* optional (NULL = absent; ABI 4): device buffer of mprl_predictor_image_bytes() bytes holding the state predictor's scene
-     * kernel weight image in the split-f16 layout (RGL_CONTRACT_F16X3 only), prepared by mprl_pack_predictor_image_f32 from THIS
-     * planner's predictor_graph / motion_head.  NULL: a search in that mode packs it into its workspace itself. */
+     * kernel weight image in the layout of the planner's split mode -- f16 (hi, lo) fragments + scales for RGL_CONTRACT_F16X3,
+     * three-piece bf16 fragments for RGL_CONTRACT_BF16X6 (ABI 6: the scene kernel's weight products Wa, W_l and the motion head as
+     * six bf16 MFMA terms; S and A H stay f32) -- prepared by mprl_pack_predictor_image_f32 from THIS planner's predictor_graph /
+     * motion_head.  NULL: a search in such a mode packs it into its workspace itself. */
     const float* predictor_image;
 } MprlPlanner;
 

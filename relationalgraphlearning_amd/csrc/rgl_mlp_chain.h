@@ -441,6 +441,78 @@ __device__ __forceinline__ void layer_mfma_bx(const float* frags, const f32x4 (&
     if constexpr (BL::P4) out[OTF] = f32x4{v4, 0.f, 0.f, 0.f};
 }
 
+// A whole layer in the six-term form (every input tile on the matrix pipe; full tiles only): the state predictor's scene kernel, whose
+// 30 KB weight image leaves the LDS room the children kernel does not have.  Fragments: [ot][chunk][hi | mid | lo][lane] x 8 bf16 --
+// the f16-split layout of layer_mfma_hs with a third piece and no scales.
+template <int IN, int OUT>
+struct B6Floats { static constexpr int v = Tiles<OUT>::v * ((Tiles<IN>::v + 1) / 2) * 3 * 64 * 4; };
+
+template <int IN, int OUT, bool BIAS>
+__device__ __forceinline__ void layer_mfma_b6(const float* frags, const f32x4 (&in)[Tiles<IN>::v], f32x4 (&out)[Tiles<OUT>::v],
+                                              int lane, const float* bias = nullptr) {
+    constexpr int IT = Tiles<IN>::v, OT = Tiles<OUT>::v, NC = (IT + 1) / 2;
+    static_assert(IN % 16 == 0, "full input tiles");
+    const int q = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+        if constexpr (BIAS) out[ot] = *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * q]);
+        else out[ot] = zero4();
+    }
+    constexpr int G = 2;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        load_fence();
+        const Split3 s = split3_pair(in[2 * c], 2 * c + 1 < IT ? in[2 * c + 1 < IT ? 2 * c + 1 : 0] : zero4());
+#pragma unroll
+        for (int o0 = 0; o0 < OT; o0 += G) {
+            load_fence();
+            bf16x8 w[G][3];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    if (o0 + g < OT) w[g][pc] = *reinterpret_cast<const bf16x8*>(&frags[((((o0 + g) * NC + c) * 3 + pc) * 64 + lane) * 4]);
+#define RGL_B6_TERM(WP, AP)                                                                                         \
+    _Pragma("unroll") for (int g = 0; g < G; ++g)                                                                   \
+        if (o0 + g < OT) out[o0 + g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g][WP], s.AP, out[o0 + g], 0, 0, 0);
+            RGL_B6_TERM(2, h)          // small terms first
+            RGL_B6_TERM(1, m)
+            RGL_B6_TERM(0, l)
+            RGL_B6_TERM(1, h)
+            RGL_B6_TERM(0, m)
+            RGL_B6_TERM(0, h)
+#undef RGL_B6_TERM
+        }
+    }
+    load_fence();
+}
+
+// float slot `idx` of the fragment image layer_mfma_b6 reads, for a k-major matrix W[in * ld + out] (columns >= n_out: 0): a pair of
+// bf16 pieces.  Unit u = idx / 4 = ((ot NC + c) 3 + piece) 64 + lane; element e of it is W[in = 16 (2c + e / 4) + 4 q + e % 4][out of
+// A-operand row lane % 16] -- hi = bf16(w), mid = bf16(w - hi), lo = w - hi - mid (exact).
+template <int IN, int OUT>
+__device__ __forceinline__ float frag_bf3_ld(const float* __restrict__ W, int ld, int n_out, int idx) {
+    constexpr int IT = Tiles<IN>::v, NC = (IT + 1) / 2;
+    const int u = idx >> 2, p = idx & 3;
+    const int l = u & 63, rest = u >> 6;
+    const int pc = rest % 3, c = (rest / 3) % NC, ot = rest / 3 / NC;
+    const int m = l & 15, q = l >> 4;
+    const int out = 16 * ot + m;
+    bf16x2 v;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = 2 * p + k, t = 2 * c + (e >> 2);
+        const int in = 16 * t + 4 * q + (e & 3);
+        const float w = (t < IT && in < IN && out < n_out) ? W[in * ld + out] : 0.f;
+        const __bf16 hi = (__bf16)w;
+        const float r1 = w - (float)hi;
+        const __bf16 mid = (__bf16)r1;
+        const __bf16 lo = (__bf16)(r1 - (float)mid);
+        v[k] = pc == 0 ? hi : (pc == 1 ? mid : lo);
+    }
+    return __builtin_bit_cast(float, v);
+}
+
 // The same product on the f16 matrix pipe at (nearly) f32 accuracy: a = a_hi + a_lo, W = W_hi + W_lo with f16 halves, and
 //   W^T a ~= W_hi^T a_hi + W_hi^T a_lo + W_lo^T a_hi            (three v_mfma_f32_16x16x32_f16, f32 accumulate; the dropped
 // W_lo^T a_lo term and the 2 bits the halves cannot hold are ~2^-21 relative).  One K = 32 instruction replaces eight f32 MFMAs:

@@ -91,6 +91,10 @@ struct SceneArgs {
     const float *eh_w1, *eh_b1, *eh_w2, *eh_b2;      // w_h
     int off_er, off_eh;                // LDS: fragment sets of the two MLPs (kRowMlpSetFloats each)
     int hx;                            // launch the split-f16 (HX) form of the kernel
+    int bx;                            // launch the bf16 six-term (BX) form: the WEIGHT products (Wa, W_l, motion head) as layer_mfma_b6
+                                       // over a packed image of three-piece fragments (RGL_CONTRACT_BF16X6); S and A H stay f32
+    int ws_stride;                     // floats between the layer matrices in the LDS image
+    int image_floats;                  // HX / BX: floats of the packed image
     const float* image;                // HX: the weight image [0, off_hs + 8) in this kernel's LDS layout (pack_scene_image)
     int off_hs;                        // HX kernels: 8 floats, 1 / scale of Wa, Ws[0..3], wm1, wm2 (their blocks hold f16 (hi, lo) fragments)
     const float* xh_rows;              // [n_crowds][H][32]  human embeddings
@@ -134,8 +138,9 @@ constexpr int M2LD = 20;   // LDS row stride of the [64][5 -> 16] motion output 
 // HX (RGL_CONTRACT_F16X3, softmax similarity): every product below as three split-f16 MFMA terms (layer_mfma_hs / mfma_h3,
 // rgl_mlp_chain.h); the weight image then holds f16 (hi, lo) fragments of the power-of-two-scaled matrices, converted when the
 // workgroup fills it (the scales from a max reduction over each matrix through LDS atomics).
-template <int NT, int SK, int WAVES, bool CH, bool SPLIT, bool EMB = false, bool HX = false>
+template <int NT, int SK, int WAVES, bool CH, bool SPLIT, bool EMB = false, bool HX = false, bool BX = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneArgs a, const ChildrenArgs ca, int grid_scene) {
+    static_assert(!BX || (SK == 0 && !HX), "six-term bf16 products: softmax similarity, not with the f16 split");
     static_assert(!SPLIT || (SK != 3 && NT > 1 && WAVES % NT == 0), "split scenes: whole scenes per workgroup, no pair-MLP similarity");
     static_assert(!HX || SK == 0, "split-f16 products: softmax similarity");
     constexpr int kSceneThreads = WAVES * 64;
@@ -187,10 +192,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
             ebias[3] = bias_load<XD>(a.eh_b2, tid);
         }
     };
-    if constexpr (HX) {
-        // split-f16 image, packed once per parameter state (or per search) in exactly this layout: b128 copies, every load of a
-        // thread in flight at once.  (Converting the matrices here -- two L2 round trips per fragment element -- cost 10 us per launch.)
-        const int n4 = (a.off_hs + 8) >> 2;
+    if constexpr (HX || BX) {
+        // split-f16 / three-piece bf16 image, packed once per parameter state (or per search) in exactly this layout: b128 copies, every
+        // load of a thread in flight at once.  (Converting the matrices here -- two L2 round trips per fragment element -- cost 10 us per launch.)
+        const int n4 = a.image_floats >> 2;
         for (int i = tid; i < n4; i += kSceneThreads)
             reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(a.image)[i];
     } else
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
     if constexpr (EMB) {
         float* w = lds;
         constexpr int F1 = 0, F2 = F1 + 4 * 1 * 4 * 64, B1 = F2 + 2 * 4 * 4 * 64, B2 = B1 + HID;
-        if constexpr (HX) emb_loads();
+        if constexpr (HX || BX) emb_loads();
         frag_store(er1, w + a.off_er + F1, tid);
         frag_store(er2, w + a.off_er + F2, tid);
         bias_store<HID>(ebias[0], w + a.off_er + B1, tid);
@@ -418,6 +423,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
             } else {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
+                if constexpr (BX) {
+                    load_fence();
+                    f32x4 xin[2];
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft)
+                        xin[ft] = *reinterpret_cast<const f32x4*>(&Hs[(16 * (ct + ctb) + n) * XLD + 16 * ft + 4 * q]);
+                    layer_mfma_b6<XD, XD, false>(wa, xin, gt_[ct], lane);
+                    continue;
+                }
                 gt_[ct][0] = zero4();
                 gt_[ct][1] = zero4();
                 load_fence();
@@ -583,7 +597,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                 }
                 break;
             }
-            const float* wl = ws + l * XD * WLD;
+            const float* wl = ws + l * a.ws_stride;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 load_fence();
@@ -592,6 +606,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                     SplitOperand<2> sa;
                     make_split<2>(acc[ct], sa);
                     layer_mfma_hs<XD, XD, false>(wl, sa, o, lane, nullptr, lds[a.off_hs + 1 + l]);
+                } else if constexpr (BX) {
+                    layer_mfma_b6<XD, XD, false>(wl, acc[ct], o, lane);
                 } else {
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft)
@@ -628,6 +644,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
                         make_split<4>(hm, sm);
                         f32x4 om1[1];
                         layer_mfma_hs<HID, 16, false>(wm2, sm, om1, lane, nullptr, lds[a.off_hs + 6]);
+                        om = om1[0];
+                    } else if constexpr (BX) {
+                        layer_mfma_b6<XD, HID, true>(wm1, o, hm, lane, bm1);
+#pragma unroll
+                        for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) hm[ht][r] = fmaxf(hm[ht][r], 0.f);
+                        f32x4 om1[1];
+                        layer_mfma_b6<HID, 16, false>(wm2, hm, om1, lane);
                         om = om1[0];
                     } else {
 #pragma unroll
@@ -668,16 +693,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
 }
 
 // ---- split-f16 weight image of the scene kernel (HX): global copy of the LDS region [0, off_hs + 8) -------------------------------
-struct SceneImageLayout { int off_wa, off_ws, off_wm1, off_bm1, off_wm2, off_bm2, off_hs, total; };
-inline SceneImageLayout scene_image_layout(int L) {
+struct SceneImageLayout { int off_wa, off_ws, off_wm1, off_bm1, off_wm2, off_bm2, off_hs, total, ws_stride; };
+// bx: the matrices as three-piece bf16 fragments (layer_mfma_b6: 6 bytes per weight) instead of k-major f32 rows / f16 (hi, lo) pairs
+inline SceneImageLayout scene_image_layout(int L, bool bx = false) {
     SceneImageLayout o;
     int off = 0;
     auto take = [&](int nfl) { int r = off; off += (nfl + 3) & ~3; return r; };
-    o.off_wa = take(XD * WLD);
-    o.off_ws = take(L * XD * WLD);
-    o.off_wm1 = take(XD * W1LD);
+    o.ws_stride = bx ? B6Floats<XD, XD>::v : XD * WLD;
+    o.off_wa = take(bx ? B6Floats<XD, XD>::v : XD * WLD);
+    o.off_ws = take(L * o.ws_stride);
+    o.off_wm1 = take(bx ? B6Floats<XD, HID>::v : XD * W1LD);
     o.off_bm1 = take(HID);
-    o.off_wm2 = take(HID * M2LD);
+    o.off_wm2 = take(bx ? B6Floats<HID, 16>::v : HID * M2LD);
     o.off_bm2 = take(16);
     o.off_hs = take(8);
     o.total = off;
@@ -744,6 +771,45 @@ __global__ __launch_bounds__(256) void scene_pack_kernel(const SceneImageArgs a,
     img[e] = v;
 }
 
+// the BX image: three-piece bf16 fragments of Wa, W_l, wm1, wm2 (no scales: bf16 has f32's exponent range) + the two bias vectors
+__global__ __launch_bounds__(256) void scene_pack_b6_kernel(const SceneImageArgs a, float* img) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const SceneImageLayout& lo = a.lo;
+    if (e >= lo.total) return;
+    float v = 0.f;
+    if (e < lo.off_ws) {
+        const int i = e - lo.off_wa;
+        if (i < B6Floats<XD, XD>::v) {
+            if (a.wa) v = frag_bf3_ld<XD, XD>(a.wa, XD, XD, i);
+            else {                                              // gaussian: Wa = I -> hi piece 1 on the diagonal
+                const int u = i >> 2, p = i & 3, l = u & 63, rest = u >> 6, pc = rest % 3, ot = rest / 3;
+                bf16x2 d;
+                for (int k = 0; k < 2; ++k) {
+                    const int ee = 2 * p + k, in = 16 * (ee >> 2) + 4 * (l >> 4) + (ee & 3), out = 16 * ot + (l & 15);
+                    d[k] = (__bf16)((pc == 0 && in == out) ? 1.f : 0.f);
+                }
+                v = __builtin_bit_cast(float, d);
+            }
+        }
+    } else if (e < lo.off_wm1) {
+        const int i = e - lo.off_ws, l = i / lo.ws_stride, j = i - l * lo.ws_stride;
+        if (l < a.L && j < B6Floats<XD, XD>::v) v = frag_bf3_ld<XD, XD>(a.Ws[l], XD, XD, j);
+    } else if (e < lo.off_bm1) {
+        const int i = e - lo.off_wm1;
+        if (a.wm1 && i < B6Floats<XD, HID>::v) v = frag_bf3_ld<XD, HID>(a.wm1, HID, HID, i);
+    } else if (e < lo.off_wm2) {
+        const int i = e - lo.off_bm1;
+        if (a.bm1 && i < HID) v = a.bm1[i];
+    } else if (e < lo.off_bm2) {
+        const int i = e - lo.off_wm2;
+        if (a.wm2 && i < B6Floats<HID, 16>::v) v = frag_bf3_ld<HID, 16>(a.wm2, 5, 5, i);
+    } else if (e < lo.off_hs) {
+        const int i = e - lo.off_bm2;
+        if (a.bm2 && i < 5) v = a.bm2[i];
+    }
+    img[e] = v;
+}
+
 inline RowMlpArgs row_mlp_args(const RglMlp& m, const float* rows, float* out, int M) {
     RowMlpArgs ra;
     ra.w1 = m.weight[0]; ra.b1 = m.bias[0]; ra.w2 = m.weight[1]; ra.b2 = m.bias[1];
@@ -784,10 +850,10 @@ inline int scene_split_below(int nt) {
     return nt == 2 ? 3072 : 4096;
 }
 
-template <int NT, int SK, int WAVES, bool SPLIT = false, bool EMB = false, bool HX = false>
+template <int NT, int SK, int WAVES, bool SPLIT = false, bool EMB = false, bool HX = false, bool BX = false>
 int launch_scene_k(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* children, hipStream_t st) {
     if constexpr (!SPLIT && SK != 3 && (NT == 2 || NT == 4)) {
-        if (sa.P < scene_split_below(NT)) return launch_scene_k<NT, SK, 8, true, EMB, HX>(sa, lds_bytes, children, st);
+        if (sa.P < scene_split_below(NT)) return launch_scene_k<NT, SK, 8, true, EMB, HX, BX>(sa, lds_bytes, children, st);
     }
     constexpr int kSlots = SPLIT ? WAVES / NT : WAVES;
     int grid = (sa.P + kSlots - 1) / kSlots;
@@ -800,7 +866,7 @@ int launch_scene_k(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* ch
         const long long blocks = ((long long)ca.P * ca.A + WAVES * 64 - 1) / (WAVES * 64);
         grid_children = (int)(blocks < 2048 ? blocks : 2048);
     }
-    auto kern = children ? scene_graph_kernel<NT, SK, WAVES, true, SPLIT, EMB, HX> : scene_graph_kernel<NT, SK, WAVES, false, SPLIT, EMB, HX>;
+    auto kern = children ? scene_graph_kernel<NT, SK, WAVES, true, SPLIT, EMB, HX, BX> : scene_graph_kernel<NT, SK, WAVES, false, SPLIT, EMB, HX, BX>;
     if (lds_bytes > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_bytes));
@@ -824,6 +890,9 @@ int launch_scene(const SceneArgs& sa, size_t lds_bytes, const ChildrenArgs* chil
         if (sa.hx)                                       // split-f16 products (softmax similarity, two node tiles)
             return sa.robot_rows ? launch_scene_k<2, 0, 8, true, true, true>(sa, lds_bytes, children, st)
                                  : launch_scene_k<2, 0, WAVES, false, false, true>(sa, lds_bytes, children, st);
+        if (sa.bx)                                       // six-term bf16 weight products (same envelope)
+            return sa.robot_rows ? launch_scene_k<2, 0, 8, true, true, false, true>(sa, lds_bytes, children, st)
+                                 : launch_scene_k<2, 0, WAVES, false, false, false, true>(sa, lds_bytes, children, st);
     }
     if constexpr (NT == 1) {
         if (sa.robot_rows) return launch_scene_k<1, 0, 8, false, true>(sa, lds_bytes, children, st);           // embeddings inside
@@ -852,7 +921,7 @@ static bool scene_kernel_covers(const RglGraph& g, int N) {
 static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* robot, const float* humans, int crowds_per, int P,
                              int H, float* humans_next, float* rows_out, float* x0_rows, float* xh_rows,
                              const ChildrenArgs* ca, hipStream_t stream, const ChildrenArgs* embed_children = nullptr,
-                             const float* sp_image = nullptr) {
+                             const float* sp_image = nullptr, int sp_mode = 1) {
     const int N = H + 1, n_crowds = P / crowds_per;
     const int NT0 = N > 64 ? 8 : (N + 15) / 16;
     // few scenes of the shipped shape: the scene kernel embeds its own node tiles (one launch for the level instead of two)
@@ -871,7 +940,9 @@ static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* r
     sa.eh_w1 = g.w_h.weight[0]; sa.eh_b1 = g.w_h.bias[0]; sa.eh_w2 = g.w_h.weight[1]; sa.eh_b2 = g.w_h.bias[1];
     sa.off_er = sa.off_eh = 0;
     // (one node tile: measured slower than the f32 form -- 0.0615 vs 0.0496 ms per configs[1] step: too few MFMAs to pay for the splits)
-    sa.hx = (sp_image && mh && scene_similarity_mode(g) == SIM_SOFTMAX && NT0 == 2 && g.num_layer <= 4) ? 1 : 0;
+    const bool split_ok = sp_image && mh && scene_similarity_mode(g) == SIM_SOFTMAX && NT0 == 2 && g.num_layer <= 4;
+    sa.hx = (split_ok && sp_mode == 1) ? 1 : 0;
+    sa.bx = (split_ok && sp_mode == 2) ? 1 : 0;
     sa.image = sp_image;
     sa.xh_rows = xh_rows; sa.x0_rows = x0_rows; sa.crowds_per = crowds_per;
     sa.wa = bilinear_wa(g);
@@ -888,9 +959,11 @@ static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* r
     int off = 0;
     auto take = [&](int nfl) { int o = off; off += (nfl + 3) & ~3; return o; };
     {   // the weight image: one layout for the LDS region and for its packed global copy
-        const SceneImageLayout lo = scene_image_layout(g.num_layer);
+        const SceneImageLayout lo = scene_image_layout(g.num_layer, sa.bx != 0);
         sa.off_wa = lo.off_wa; sa.off_ws = lo.off_ws; sa.off_wm1 = lo.off_wm1; sa.off_bm1 = lo.off_bm1;
         sa.off_wm2 = lo.off_wm2; sa.off_bm2 = lo.off_bm2; sa.off_hs = lo.off_hs;
+        sa.ws_stride = lo.ws_stride;
+        sa.image_floats = sa.bx ? lo.total : lo.off_hs + 8;
         off = lo.total;
     }
     sa.wc1 = sa.bc1 = sa.wc2 = sa.bc2 = nullptr;
@@ -926,10 +999,12 @@ namespace rgl {
 
 // The split-f16 weight image of the state predictor's scene kernel (RGL_CONTRACT_F16X3): depends on the weights only.
 size_t scene_image_bytes(const MprlPlanner* pl) {
-    if (!pl || pl->contraction_dtype != RGL_CONTRACT_F16X3 || pl->linear_state_predictor) return 0;
+    if (!pl || pl->linear_state_predictor) return 0;
+    const bool bx = pl->contraction_dtype == RGL_CONTRACT_BF16X6;
+    if (pl->contraction_dtype != RGL_CONTRACT_F16X3 && !bx) return 0;
     const RglGraph& g = pl->predictor_graph;
     if (!scene_kernel_covers(g, 20) || scene_similarity_mode(g) != SIM_SOFTMAX || !mlp_is(pl->motion_head, XD, HID, 5, false)) return 0;
-    return (((size_t)scene_image_layout(g.num_layer).total * sizeof(float)) + 255) & ~(size_t)255;
+    return (((size_t)scene_image_layout(g.num_layer, bx).total * sizeof(float)) + 255) & ~(size_t)255;
 }
 
 int pack_scene_image(const MprlPlanner* pl, float* image, hipStream_t stream) {
@@ -941,6 +1016,12 @@ int pack_scene_image(const MprlPlanner* pl, float* image, hipStream_t stream) {
     ia.wm1 = pl->motion_head.weight[0]; ia.bm1 = pl->motion_head.bias[0];
     ia.wm2 = pl->motion_head.weight[1]; ia.bm2 = pl->motion_head.bias[1];
     ia.L = g.num_layer;
+    if (pl->contraction_dtype == RGL_CONTRACT_BF16X6) {
+        ia.lo = scene_image_layout(g.num_layer, true);
+        hipLaunchKernelGGL(scene_pack_b6_kernel, dim3((ia.lo.total + 255) / 256), dim3(256), 0, stream, ia, image);
+        RGL_LAUNCH_CHECK();
+        return RGL_OK;
+    }
     ia.lo = scene_image_layout(g.num_layer);
     hipLaunchKernelGGL(scene_scales_kernel, dim3(7), dim3(256), 0, stream, ia, image);
     RGL_LAUNCH_CHECK();
@@ -979,7 +1060,9 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
     const ChildrenArgs* in_scene = (ca && P < 3072) ? ca : nullptr;
     const ChildrenArgs* in_embed = (ca && !in_scene) ? ca : nullptr;
     const int rc = run_scene_kernels(g, &mh, robot, humans, crowds_per, P, H, humans_next, nullptr, x0_rows, xh_rows, in_scene, stream,
-                                     in_embed, pl->contraction_dtype == RGL_CONTRACT_F16X3 ? sp_image : nullptr);
+                                     in_embed, (pl->contraction_dtype == RGL_CONTRACT_F16X3 || pl->contraction_dtype == RGL_CONTRACT_BF16X6)
+                                                   ? sp_image : nullptr,
+                                     pl->contraction_dtype == RGL_CONTRACT_BF16X6 ? 2 : 1);
     if (rc == RGL_OK && ca && children_done) *children_done = 1;
     return rc;
 }

@@ -124,7 +124,7 @@ class TreeSearch:
         pl.action_groups = None if grp is None else grp.data_ptr()
         image = self._children_image(pl, device)
         pl.children_image = None if image is None else image.data_ptr()
-        if not linear and self.contraction_dtype == "f16x3":
+        if not linear and mode in ("f16x3", "bf16x6"):
             image = self._predictor_image(pl, device)
             pl.predictor_image = None if image is None else image.data_ptr()
         return pl
@@ -134,7 +134,7 @@ class TreeSearch:
         when the predictor's descriptors were (re)built, into the same device buffer every time.  None when the mode or the
         predictor has no such kernel."""
         sp = self.state_predictor
-        key = (sp.graph_model._cache.epoch, sp._cache.epoch, self.contraction_dtype)     # the layout depends on the mode
+        key = (sp.graph_model._cache.epoch, sp._cache.epoch, self.contraction_dtype, os.environ.get("RGL_CONTRACT_F32_AS"))   # the layout depends on the mode
         dkey = str(device)
         ent = self._sp_images.get(dkey)
         if ent is not None and ent[0] == key:
