@@ -597,7 +597,7 @@ def children_roofline(args, ts, device, N, H, last, robot=None, humans=None):
         pass
     return {"bound": "mfma", "kernel": "value of sibling children, mprl_value_children_f32: " + kernel_path,
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "peak_note": peak_note,
-            "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes/launch",
+            "frac": achieved / peak, "frac_of_fp32_peak": achieved / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
             "traffic_source": traffic_src, "traffic_measured_at_revision": traffic_rev,
             "traffic_stale": stale,
             "algorithmic_bytes": scenes_per_launch * (9 * 4 + 4) + scenes_per_launch / A * H * 20,
@@ -729,7 +729,7 @@ def main():
         step_flops = n_nodes * (ts.num_actions * roofline["flop_per_scene"] + predictor_flops_per_scene(N, args.layers))
         step_tflops = step_flops / (elapsed / args.steps) / 1e12
         roofline_step = {"flops_per_step": step_flops, "achieved": step_tflops, "peak": roofline["peak"], "unit": "TFLOP/s",
-                         "frac": step_tflops / roofline["peak"],
+                         "frac": step_tflops / roofline["peak"], "frac_of_fp32_peak": step_tflops / FP32_PEAK_TFLOPS,
                          "note": "children value forwards (%d per tree node) + state-predictor graph forwards (one per tree node, "
                                  "%.0f FLOP), %d tree nodes on this GPU, over ms_per_step" % (ts.num_actions,
                                                                                          predictor_flops_per_scene(N, args.layers), n_nodes)}

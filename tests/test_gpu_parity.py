@@ -2700,7 +2700,7 @@ def test_product_trainer_replays_stay_valid_while_the_memory_grows(dev):
     # backward: measured 1.6e-5; a replay that gathered the wrong rows would be off by the learning rate per step (1e-3) and more
     assert worst <= 1e-4, worst
     for (a, b), (c_, d) in zip(l_c, l_e):
-        assert abs(a - c_) <= 1e-6 * max(1.0, abs(c_)) and abs(b - d) <= 1e-6 * max(1.0, abs(d))
+        assert abs(a - c_) <= 1e-5 * max(1.0, abs(c_)) and abs(b - d) <= 1e-5 * max(1.0, abs(d))      # losses of parameters 1.6e-5 apart
     report("product MPRLTrainer: captured steps replayed across a growing (and wrapping) replay memory stay within %.1e of the eager "
            "trainer's parameters" % worst)
 
