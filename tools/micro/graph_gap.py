@@ -54,18 +54,3 @@ run_table("dependent launch-sized kernels (64 elements) per burst: device us per
 # the stream; the replay pays its per-node dependency handling on top of the same kernels
 x = torch.zeros(24 * 1024 * 1024, device=dev)
 run_table("dependent ~30 us kernels (24 M elements) per burst", (4, 6, 8))
-raise SystemExit(0)
-print("dependent launch-sized kernels per burst: device us per burst, per kernel")
-for n in (4, 6, 8, 16):
-    direct = timed(lambda: burst(n))
-    g = torch.cuda.CUDAGraph()
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        burst(n)
-    torch.cuda.current_stream().wait_stream(s)
-    with torch.cuda.graph(g):
-        burst(n)
-    replay = timed(g.replay)
-    print("n = %2d   direct %7.2f us (%.2f per kernel)   graph replay %7.2f us (%.2f per kernel)   replay - direct = %+.2f us per kernel"
-          % (n, direct, direct / n, replay, replay / n, (replay - direct) / n))
