@@ -1653,6 +1653,19 @@ def test_bf16x6_head_matrix_at_size_and_in_other_shapes(dev):
             oa, ov, orv, okept, lv = orc.mprl_predict_batched(rb, hb, gio.oracle_params("trained", 2, "separate", simf), cfg, return_levels=True)
         close(v6.cpu().numpy(), ov.numpy(), reg=REG_F32)
         check_decisions("bf16x6, H=%d D=%d B=%d %s" % (Hh, D, Bb, simf), a6, v6, (oa, ov, orv, okept), lv)
+        if simf == "embedded_gaussian" and (Hh, D) in ((5, 1), (19, 3)):
+            # admission on the other BASELINE shapes too (configs[1]: N = 6, D = 1; configs[3]: D = 3): deviation from a float64
+            # evaluation of the same search next to the f32 kernels' on the same roots
+            p32 = make_mprl_policy("trained", D, 2, D > 1, device=dev, similarity=simf)
+            p32.build_action_space(1.0)
+            _, v32b = p32.predict_batch(rb.to(dev), hb.to(dev), roots_are_joint_states=True)
+            nb = min(Bb, 32)
+            with torch.no_grad():
+                _, v64b, _, _ = orc.mprl_predict_batched(rb[:nb].double(), hb[:nb].double(), P64, cfg)
+            e6 = float((v6[:nb].double().cpu() - v64b).abs().max())
+            e32 = float((v32b[:nb].double().cpu() - v64b).abs().max())
+            report("bf16x6 vs float64, H=%d D=%d (%d roots): max %.2e against %.2e for the f32 kernels" % (Hh, D, nb, e6, e32))
+            assert e6 <= 1.5 * e32 + 3e-9, (Hh, D, e6, e32)
 
 
 def test_f16x3_value_head_at_size_and_at_extreme_magnitudes(dev):
