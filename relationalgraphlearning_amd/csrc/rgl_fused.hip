@@ -99,6 +99,7 @@ __device__ __forceinline__ float head_chain(const float* lds, const f32x4 (&tin)
     relu_tiles<D1>(a1);
     f32x4 a2[Tiles<D2>::v];
     if constexpr (HX) layer_mfma_h<D1, D2, true>(lds + LO::f2, a1, a2, lane, lds + LO::b2, lds[LO::hs + 2]);
+    else if constexpr (BX) layer_mfma_bx1<D1, D2, true>(lds + LO::f2, a1, a2, lane, lds + LO::b2);
     else layer_mfma<D1, D2, true>(lds + LO::f2, a1, a2, lane, lds + LO::b2);
     relu_tiles<D2>(a2);
     f32x4 a3[Tiles<D3>::v];
@@ -172,6 +173,17 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
     auto item_at = [&](int k) { return k * kFusedWaves + ((k & 1) ? kFusedWaves - 1 - wave : wave); };
     const int n_tiles_inl = a.n_full + (a.inline_partial ? 1 : 0);      // tiles that run their own head
     float rin[3], hin[NT][2];
+    // BX: w_h's second matrix [64][32] as the A-operand elements my lane feeds to its 32 MFMAs of every crowd computation --
+    // fragment (ht, r, ot): row 16 ht + 4 q + r, column 16 ot + n -- held in registers for the whole kernel (see FusedLds::bh2)
+    float wh2r[BX ? 32 : 1];
+    if constexpr (BX) {
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) wh2r[(ht * 4 + r) * 2 + ot] = a.wh2[(16 * ht + 4 * q + r) * XD + 16 * ot + n];
+    }
     f32x4 gq[NT][2], xq[NT][2], ms[NT], zs[NT], xt[NT][2], uw4[HRL / 4];
     float xt1p[2] = {0.f, 0.f}, ms1 = 0.f, zs1 = 1.f;      // T1P: Xh^T[f][node 16 + q], msh / Zsh of node 16 + q
     // HX: the crowd operands as split-f16 halves.  gqs / xqs [node tile]: rows = nodes, k = features (the D layout of the crowd chain,
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int ot = 0; ot < 2; ++ot)
-                        xa[ot] = mfma4(wh2[(16 * ht + 4 * q + r) * WLD + 16 * ot + n], hacc[ht][r], xa[ot]);
+                        xa[ot] = mfma4(BX ? wh2r[BX ? (ht * 4 + r) * 2 + ot : 0] : wh2[(16 * ht + 4 * q + r) * WLD + 16 * ot + n], hacc[ht][r], xa[ot]);
             }
             load_fence();
 #pragma unroll
@@ -1024,6 +1036,30 @@ __device__ __forceinline__ float bx_element(const float* __restrict__ W, int idx
     return __builtin_bit_cast(float, v);
 }
 
+// one float of the BX f2 region (Bx1Layout)
+template <int IN, int OUT>
+__device__ __forceinline__ float bx1_element(const float* __restrict__ W, int idx) {
+    using BL = Bx1Layout<IN, OUT>;
+    if (idx >= BL::p4) {
+        const int j = idx - BL::p4;
+        return frag_element<IN, OUT>(W, (BL::OTF * Tiles<IN>::v * 4 + (j >> 6)) * 64 + (j & 63));        // partial tile: k step = it * 4 + r
+    }
+    const int u = idx >> 2, p = idx & 3, l = u & 63, rest = u >> 6;
+    const int pc = rest % 3, ot = rest / 3, q = l >> 4, out = frag_out_feature<OUT>(ot, l);
+    bf16x2 v;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = 2 * p + k;
+        const float w = W[tile_feature<IN>(e >> 2, q, e & 3) * OUT + out];
+        const __bf16 hi = (__bf16)w;
+        const float r1 = w - (float)hi;
+        const __bf16 mid = (__bf16)r1;
+        const __bf16 lo = (__bf16)(r1 - (float)mid);
+        v[k] = pc == 0 ? hi : (pc == 1 ? mid : lo);
+    }
+    return __builtin_bit_cast(float, v);
+}
+
 template <int D1, int D2, int D3, bool HX, bool BX = false>
 __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedArgs a, float* img) {
     using LO = FusedLds<D1, D2, D3, HX, BX>;
@@ -1064,8 +1100,10 @@ __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedAr
     } else {
         if (e < LO::f1) v = frag_element<XD, XD>(a.w_last, e - LO::f_last);
         else if (e < LO::f2) v = frag_element<XD, D1>(a.hw1, e - LO::f1);
-        else if (e < LO::f3) v = frag_element<D1, D2>(a.hw2, e - LO::f2);
-        else if constexpr (BX) v = bx_element<D2, D3>(a.hw3, e - LO::f3);
+        else if (e < LO::f3) {
+            if constexpr (BX) v = bx1_element<D1, D2>(a.hw2, e - LO::f2);
+            else v = frag_element<D1, D2>(a.hw2, e - LO::f2);
+        } else if constexpr (BX) v = bx_element<D2, D3>(a.hw3, e - LO::f3);
         else v = frag_element<D2, D3>(a.hw3, e - LO::f3);
     }
     img[e] = v;

@@ -170,9 +170,10 @@ struct HeadFragFloats {
 //   W_lo a_hi + W_mid a_mid + W_hi a_lo + W_mid a_hi + W_hi a_mid + W_hi a_hi          (v_mfma_f32_16x16x32_bf16, f32 accumulate)
 // and the three dropped ones are bounded by (2^-26 + 2^-26 + 2^-34) |W||a| < 2^-24 |W||a| -- below the rounding of one f32
 // product, and unbiased (signed pieces).  6 x 16 clocks replace 8 x 32 per 16 x 16 x 32 block, and unlike the f32 MFMA they do not
-// occupy the vector ALUs.  Why only 64 of the 100 input features of ONE matrix: three bf16 pieces are 6 bytes per
-// weight, and the kernel's LDS (106 KB image + 42 KB wave scratch of 160 KB) has 11.5 KB to spare -- two K = 32 chunks of the six
-// full output tiles cost +6.8 KB; the input features 64.., and the partial output tile, stay on the f32 MFMA
+// occupy the vector ALUs.  Why not the whole head: three bf16 pieces are 6 bytes per weight, and the kernel's LDS
+// (106 KB image + 42 KB wave scratch of 160 KB) had 11.5 KB to spare; w_h's second matrix moved into registers (FusedLds::bh2) frees
+// 9 KB more.  That holds three K = 32 chunks of this matrix's six full output tiles and the 32 x 100 layer before it (Bx1Layout);
+// input features 96.., the partial output tiles and the two 32 x 32 layers stay on the f32 MFMA
 // (profiles/r05_micro_bf16x3_split.txt: the whole head in this form would be 1.67x, and needs +44 KB).
 // Layout of the f3 region: [ot < OTF][chunk < 2][hi | mid | lo][lane] x 8 bf16  |  f32 fragments [ot < OTF][k step of input tiles
 // 4..][lane]  |  the partial output tile's 4 x 4 x 1 fragments [k step][lane].
@@ -182,9 +183,8 @@ struct BxLayout {
     static constexpr bool P4 = Partial4<OUT>::v;
     static constexpr int OTF = P4 ? OT - 1 : OT;
     static constexpr int NCB = 2, ITB = 2 * NCB;                                         // bf16 chunks every output tile gets; input tiles they cover
-    // ... and a THIRD chunk (input tiles 4, 5) for the first OT3 output tiles only: what the last kilobytes of LDS hold (a full third
-    // chunk is +6 KB, 1.2 KB more than a CU has left beside the image and the wave scratch)
-    static constexpr int OT3 = (IT >= ITB + 3 && OTF >= 4) ? 4 : 0;
+    // ... and a THIRD chunk (input tiles 4, 5) for the first OT3 output tiles (all of them since w_h's second matrix left the LDS)
+    static constexpr int OT3 = (IT >= ITB + 3) ? OTF : 0;
     static constexpr int KF = (IT - ITB - 1) * 4 + LastTileSteps<IN>::v;                 // f32 k steps of an output tile without the third chunk
     static constexpr int KF3 = (IT - ITB - 3) * 4 + LastTileSteps<IN>::v;                // ... with it
     static constexpr int KP = (IT - 1) * 4 + LastTileSteps<IN>::v;                       // k steps of the partial output tile
@@ -195,6 +195,20 @@ struct BxLayout {
     static constexpr int p4 = f32 + (OT3 * KF3 + (OTF - OT3) * KF) * 64;
     static constexpr int total = p4 + (P4 ? KP * 64 : 0);
     static_assert(IT > ITB, "input tiles 0..3 are full tiles and there is at least one tile beyond them");
+};
+
+// The same for a layer whose whole input is ONE K = 32 chunk (the 32 -> 100 head layer): [ot < OTF][hi | mid | lo][lane] x 8 bf16, then
+// the partial output tile's 4 x 4 x 1 fragments [k step][lane] (f32).
+template <int IN, int OUT>
+struct Bx1Layout {
+    static_assert(IN == 32, "one chunk");
+    static constexpr int OT = Tiles<OUT>::v;
+    static constexpr bool P4 = Partial4<OUT>::v;
+    static constexpr int OTF = P4 ? OT - 1 : OT;
+    static constexpr int KP = IN / 4;
+    static constexpr int b16 = 0;
+    static constexpr int p4 = b16 + OTF * 3 * 64 * 4;
+    static constexpr int total = p4 + (P4 ? KP * 64 : 0);
 };
 
 template <int D1, int D2, int D3, bool HX = false, bool BX = false>
@@ -210,7 +224,9 @@ struct FusedLds {
     static constexpr int wh1 = w1 + XD * WLD;
     static constexpr int bh1 = wh1 + 8 * W1LD;
     static constexpr int wh2 = bh1 + HID;
-    static constexpr int bh2 = wh2 + HID * WLD;
+    static constexpr int bh2 = wh2 + (BX ? 0 : HID * WLD);          // BX: w_h's second matrix lives in REGISTERS (32 per lane, loaded once
+                                                                   // per kernel: every crowd computation reads the same 32), its 9 KB
+                                                                   // of LDS hold bf16 fragments of the head instead
     // value head: per-feature vectors, then the A fragments (layout of rgl_head.hip).  Everything addressed with many different
     // lane patterns sits below 64 KB (the reach of a ds instruction's immediate offset from a shared base register); the large
     // f3 image, addressed with one pattern, spans the boundary.
@@ -221,7 +237,7 @@ struct FusedLds {
     static constexpr int f_last = w4 + Tiles<D3>::v * 16;
     static constexpr int f1 = f_last + HeadFragFloats<XD, XD, HX>::v;
     static constexpr int f2 = f1 + HeadFragFloats<XD, D1, HX>::v;
-    static constexpr int f3 = f2 + HeadFragFloats<D1, D2, HX>::v;
+    static constexpr int f3 = f2 + (BX ? Bx1Layout<D1, D2>::total : HeadFragFloats<D1, D2, HX>::v);
     static_assert(!(HX && BX), "one split mode at a time");
     static constexpr int hs = f3 + (BX ? BxLayout<D2, D3>::total : HeadFragFloats<D2, D3, HX>::v);      // HX: 1 / scale of W_last, hw1, hw2, hw3, wr2, wa, w1, wh2
                                                                          // (HX: the wr2 / wa / w1 / wh2 blocks hold f16 (hi, lo) fragments)
@@ -436,6 +452,58 @@ __device__ __forceinline__ void layer_mfma_bx(const float* frags, const f32x4 (&
                 out[ot] = mfma4(fl[BL::f32_of(ot) + k * 64], in[it][r], out[ot]);
             }
         }
+    }
+    load_fence();
+    if constexpr (BL::P4) out[OTF] = f32x4{v4, 0.f, 0.f, 0.f};
+}
+
+// The one-chunk layer (Bx1Layout): six terms per output tile, the partial tile on the f32 4 x 4 x 1 MFMA
+template <int IN, int OUT, bool BIAS>
+__device__ __forceinline__ void layer_mfma_bx1(const float* frags, const f32x4 (&in)[Tiles<IN>::v], f32x4 (&out)[Tiles<OUT>::v],
+                                               int lane, const float* bias = nullptr) {
+    using BL = Bx1Layout<IN, OUT>;
+    constexpr int OTF = BL::OTF;
+    const int q = lane >> 4;
+    float v4 = 0.f;
+    if constexpr (BL::P4) {
+        f32x4 p4[2] = {zero4(), zero4()};
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            load_fence();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p4[r & 1] = mfma4x4(frags[BL::p4 + (it * 4 + r) * 64 + lane], in[it][r], p4[r & 1]);
+        }
+        load_fence();
+        v4 = kgroups_reduce_scatter(p4[0] + p4[1]);
+        if constexpr (BIAS) v4 += bias[16 * OTF + 4 * q];
+    }
+#pragma unroll
+    for (int ot = 0; ot < OTF; ++ot) {
+        if constexpr (BIAS) out[ot] = *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * q]);
+        else out[ot] = zero4();
+    }
+    load_fence();
+    const Split3 s = split3_pair(in[0], in[1]);
+    constexpr int G = 2;
+#pragma unroll
+    for (int o0 = 0; o0 < OTF; o0 += G) {
+        load_fence();
+        bf16x8 w[G][3];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                if (o0 + g < OTF) w[g][pc] = *reinterpret_cast<const bf16x8*>(&frags[BL::b16 + (((o0 + g) * 3 + pc) * 64 + lane) * 4]);
+#define RGL_BX_TERM(WP, AP)                                                                                         \
+    _Pragma("unroll") for (int g = 0; g < G; ++g)                                                                   \
+        if (o0 + g < OTF) out[o0 + g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g][WP], s.AP, out[o0 + g], 0, 0, 0);
+        RGL_BX_TERM(2, h)
+        RGL_BX_TERM(1, m)
+        RGL_BX_TERM(0, l)
+        RGL_BX_TERM(1, h)
+        RGL_BX_TERM(0, m)
+        RGL_BX_TERM(0, h)
+#undef RGL_BX_TERM
     }
     load_fence();
     if constexpr (BL::P4) out[OTF] = f32x4{v4, 0.f, 0.f, 0.f};
