@@ -95,6 +95,7 @@ __device__ __forceinline__ float head_chain(const float* lds, const f32x4 (&tin)
         }
     f32x4 a1[Tiles<D1>::v];
     if constexpr (HX) layer_mfma_h<XD, D1, true>(lds + LO::f1, h, a1, lane, lds + LO::b1, lds[LO::hs + 1]);
+    else if constexpr (BX && D1 == 32) layer_mfma_bx1<XD, 32, true>(lds + LO::f1, h, a1, lane, lds + LO::b1);
     else layer_mfma<XD, D1, true>(lds + LO::f1, h, a1, lane, lds + LO::b1);
     relu_tiles<D1>(a1);
     f32x4 a2[Tiles<D2>::v];
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
             for (int s = 0; s < 2; ++s) {
                 const int k = 4 * s + q;
 #pragma unroll
-                for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wh1[k * W1LD + 16 * ht + n], hin[pct][s], hacc[ht]);
+                for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wh1[k * LO::WH1LD + 16 * ht + n], hin[pct][s], hacc[ht]);
             }
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) {
@@ -1080,7 +1081,7 @@ __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedAr
     } else if (e < LO::wh1) {
         if constexpr (HX) v = e - LO::w1 < HeadFragFloats<XD, XD, true>::v ? frag_half2<XD, XD>(a.w1, e - LO::w1, 1.f / img[LO::hs + 6]) : 0.f;
         else v = matrix_element<XD, XD, WLD>(a.w1, e - LO::w1);
-    } else if (e < LO::bh1) v = matrix_element<5, HID, W1LD>(a.wh1, e - LO::wh1);
+    } else if (e < LO::bh1) v = matrix_element<5, HID, LO::WH1LD>(a.wh1, e - LO::wh1);
     else if (e < LO::wh2) v = a.bh1[e - LO::bh1];
     else if (e < LO::bh2) {
         if constexpr (HX) v = e - LO::wh2 < HeadFragFloats<HID, XD, true>::v ? frag_half2<HID, XD>(a.wh2, e - LO::wh2, 1.f / img[LO::hs + 7]) : 0.f;
@@ -1099,7 +1100,10 @@ __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedAr
         else v = frag_half2<D2, D3>(a.hw3, e - LO::f3, 1.f / img[LO::hs + 3]);
     } else {
         if (e < LO::f1) v = frag_element<XD, XD>(a.w_last, e - LO::f_last);
-        else if (e < LO::f2) v = frag_element<XD, D1>(a.hw1, e - LO::f1);
+        else if (e < LO::f2) {
+            if constexpr (BX && D1 == 32) v = bx1_element<XD, 32>(a.hw1, e - LO::f1);
+            else v = frag_element<XD, D1>(a.hw1, e - LO::f1);
+        }
         else if (e < LO::f3) {
             if constexpr (BX) v = bx1_element<D1, D2>(a.hw2, e - LO::f2);
             else v = frag_element<D1, D2>(a.hw2, e - LO::f2);

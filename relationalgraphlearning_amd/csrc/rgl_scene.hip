@@ -1057,7 +1057,8 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
     float* xh_rows = x0_rows + (size_t)P * XD;               // [n_crowds][H][32]
     // the level's reward / next-state work rides in the scene kernel's launch while the scene workgroups leave LDS free (few scenes),
     // in the embedding launch otherwise: never a launch of its own on this path
-    const ChildrenArgs* in_scene = (ca && P < 3072) ? ca : nullptr;
+    static const int children_in_scene_below = [] { const char* e = getenv("RGL_SCENE_CHILDREN_BELOW"); return e ? atoi(e) : 3072; }();      // measurements
+    const ChildrenArgs* in_scene = (ca && P < children_in_scene_below) ? ca : nullptr;
     const ChildrenArgs* in_embed = (ca && !in_scene) ? ca : nullptr;
     const int rc = run_scene_kernels(g, &mh, robot, humans, crowds_per, P, H, humans_next, nullptr, x0_rows, xh_rows, in_scene, stream,
                                      in_embed, (pl->contraction_dtype == RGL_CONTRACT_F16X3 || pl->contraction_dtype == RGL_CONTRACT_BF16X6)
