@@ -1057,7 +1057,10 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
     float* xh_rows = x0_rows + (size_t)P * XD;               // [n_crowds][H][32]
     // the level's reward / next-state work rides in the scene kernel's launch while the scene workgroups leave LDS free (few scenes),
     // in the embedding launch otherwise: never a launch of its own on this path
-    static const int children_in_scene_below = [] { const char* e = getenv("RGL_SCENE_CHILDREN_BELOW"); return e ? atoi(e) : 3072; }();      // measurements
+    // cross-over: ~3 k scenes for the f32 scene kernel (round 2), ~1.1 k once its weight products run on the matrix pipe (round 5:
+    // 2048 roots 0.3022 -> 0.2988 ms, 1024 roots 0.1773 -> 0.1759, 512 roots unchanged); RGL_SCENE_CHILDREN_BELOW overrides (measurements)
+    static const int below_env = [] { const char* e = getenv("RGL_SCENE_CHILDREN_BELOW"); return e ? atoi(e) : -1; }();
+    const int children_in_scene_below = below_env >= 0 ? below_env : (pl->contraction_dtype == RGL_CONTRACT_BF16X6 ? 1100 : 3072);
     const ChildrenArgs* in_scene = (ca && P < children_in_scene_below) ? ca : nullptr;
     const ChildrenArgs* in_embed = (ca && !in_scene) ? ca : nullptr;
     const int rc = run_scene_kernels(g, &mh, robot, humans, crowds_per, P, H, humans_next, nullptr, x0_rows, xh_rows, in_scene, stream,
