@@ -566,10 +566,10 @@ def children_roofline(args, ts, device, N, H, last, robot=None, humans=None):
         peak_note = "blend: %.0f%% of the FLOPs as 3 split-f16 MFMA terms (a third of the dense f16 MFMA peak = %.0f), the rest at the fp32 peak (%.1f)" % (
             100.0 * dense / flop_per_scene, x3_peak, FP32_PEAK_TFLOPS)
     if args.contraction == "bf16x6":
-        # input features 0..95 of the 100 x 100 head matrix and all 32 of the 32 x 100 one, onto their 96 full-tile outputs, run on the
-        # bf16 matrix pipe as SIX terms, i.e. at a sixth of the dense bf16 MFMA peak; everything else at the fp32 rate:
-        # time-weighted peak
-        dense = 2 * 96 * 96 + 2 * 32 * 96
+        # input features 0..95 of the 100 x 100 head matrix, all 32 of the 32 x 100 one (onto their 96 full-tile outputs) and the
+        # 32 x 32 layer before them run on the bf16 matrix pipe as SIX terms, i.e. at a sixth of the dense bf16 MFMA peak; everything
+        # else at the fp32 rate: time-weighted peak
+        dense = 2 * 96 * 96 + 2 * 32 * 96 + 2 * 32 * 32
         b6_peak = F16_MFMA_PEAK_TFLOPS / 6.0
         peak = flop_per_scene / (dense / b6_peak + (flop_per_scene - dense) / FP32_PEAK_TFLOPS)
         peak_note = "blend: %.0f%% of the FLOPs as 6 bf16 MFMA terms over three-piece (24-bit) operands (a sixth of the dense bf16 MFMA peak = %.0f), the rest at the fp32 peak (%.1f)" % (
@@ -799,7 +799,7 @@ def main():
         "vs_baseline": None, "dtype": {"f32": "f32", "f16": "f16 inputs / f32 accumulate (middle-layer products only; everything else f32)",
                                        "f16x3": "f32 (dense products of the children kernel as three split-f16 MFMA terms with f32 accumulate, "
                                                 "~2^-21 relative per product; everything else f32)",
-                                       "bf16x6": "f32 (24-bit operands throughout; 12 288 of the 13 200 products of the children kernel's 32 x 100 and "
+                                       "bf16x6": "f32 (24-bit operands throughout; 13 312 of the 14 224 products of the children kernel's 32 x 32, 32 x 100 and "
                                                  "100 x 100 head matrices and the state predictor's weight products as six bf16 MFMA terms over three "
                                                  "round-to-nearest bf16 pieces per operand, f32 accumulate, dropped terms < 2^-24 |w||a|; "
                                                  "everything else on the f32 MFMA / VALU)"}[args.contraction],
@@ -832,8 +832,8 @@ def main():
             "mode": "RGL_CONTRACT_BF16X6", "operand_bits": 24, "pieces_per_operand": "3 x bf16, round to nearest, hi + mid + lo = x exactly",
             "terms": "6 of 9 (lo*hi, mid*mid, hi*lo, mid*hi, hi*mid, hi*hi), f32 accumulate",
             "dropped_terms_bound": "(2^-26 + 2^-26 + 2^-34) |w||a| < 2^-24 |w||a| per product",
-            "where": "children_fused_kernel: the 32 x 100 and 100 x 100 value-head matrices, input features 0..95 onto output features "
-                     "0..95 (what the CU's LDS holds as three bf16 pieces once w_h's second matrix sits in registers); scene_graph_kernel: "
+            "where": "children_fused_kernel: the 32 x 32, 32 x 100 and 100 x 100 value-head matrices, input features 0..95 onto output "
+                     "features 0..95 (what the CU's LDS holds as three bf16 pieces once w_h's second matrix sits in registers); scene_graph_kernel: "
                      "Wa, W_l, motion head; everything else f32",
             "float64_check": "cpu_baseline.float64_check of this line (needs --cpu-seconds > 0); "
                              "tests/test_gpu_parity.py::test_bf16x6_head_matrix_at_size_and_in_other_shapes asserts it",

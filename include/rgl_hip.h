@@ -251,8 +251,8 @@ typedef struct MprlPlanner {
                                  * exponent range, no scaling -- as the six terms W_lo a_hi + W_mid a_mid + W_hi    *
                                  * a_lo + W_mid a_hi + W_hi a_mid + W_hi a_hi of v_mfma_f32_16x16x32_bf16 with f32  *
                                  * accumulation; the dropped terms are < 2^-24 |W||a| (below one f32 rounding).    *
-                                 * Offered by the value-of-children kernel of the shipped shape for 12 288 of the  *
-                                 * 13 200 products of its 32 x 100 and 100 x 100 head matrices (what its LDS holds) *
+                                 * Offered by the value-of-children kernel of the shipped shape for 13 312 of the  *
+                                 * 14 224 products of its three value-head matrices (what its LDS holds) *
                                  * and by the state predictor's scene kernel (softmax similarity, 17..32 nodes) for *
                                  * its weight products (Wa, W_l, motion head); everything else computes plain f32. */
     double time_step;
