@@ -41,6 +41,25 @@ def test_struct_layout_matches_header_sizes():
     assert ctypes.sizeof(nat.GcnPlanner) == graph + mlp + 2 * 4 + 2 * 8 + 8 + 2 * 8
 
 
+def test_contraction_modes_and_level_view_match_the_header():
+    """ABI 6: the contraction-mode constants of include/rgl_hip.h are the ones the Python side sends; the level view exposes the
+    root's tensor-born reward array (reward_clip_off) at level 0 of a clipped search only."""
+    hdr = open(os.path.join(ROOT, "include", "rgl_hip.h")).read()
+    consts = {name: int(val) for name, val in re.findall(r"#define (RGL_CONTRACT_\w+)\s+(\d+)", hdr)}
+    assert consts == {"RGL_CONTRACT_F32": 0, "RGL_CONTRACT_F16": 1, "RGL_CONTRACT_F16X3": 2, "RGL_CONTRACT_BF16X6": 3}
+    assert nat.CONTRACTION_DTYPES == {"f32": 0, "f16": 1, "f16x3": 2, "bf16x6": 3}
+    assert int(re.search(r"#define RGL_ABI_VERSION (\d+)", hdr).group(1)) == nat.ABI_VERSION == 6
+    lib = nat.lib()
+    pl = nat.MprlPlanner()
+    pl.planning_depth, pl.planning_width, pl.num_actions, pl.do_action_clip = 2, 2, 81, 1
+    view = nat.MprlLevelView()
+    assert lib.mprl_tree_level_view(ctypes.byref(pl), 64, 19, 0, ctypes.byref(view)) == 0 and view.reward_clip_off > 0
+    assert view.reward_clip_off % 256 == 0 and view.reward_clip_off != view.reward_off
+    assert lib.mprl_tree_level_view(ctypes.byref(pl), 64, 19, 1, ctypes.byref(view)) == 0 and view.reward_clip_off == -1
+    pl.do_action_clip = 0
+    assert lib.mprl_tree_level_view(ctypes.byref(pl), 64, 19, 0, ctypes.byref(view)) == 0 and view.reward_clip_off == -1
+
+
 def test_host_side_argument_checks_without_gpu():
     lib = nat.lib()
     # NULL pointers and bad shapes are rejected on the host before any launch
