@@ -223,8 +223,7 @@ struct FusedLds {
     // crowd side: w_h
     static constexpr int wh1 = w1 + XD * WLD;
     static constexpr int WH1LD = BX ? 72 : W1LD;                    // BX: w_h's first matrix at row stride 72 (k-groups 8 banks apart: two
-                                                                   // lanes per bank, as at 80): the 64 floats saved are what the bf16
-                                                                   // fragments of the XD x D1 head layer (f1 below) were short of
+                                                                   // lanes per bank, as at 80) -- the 64 floats its image needs for ...
     static constexpr int bh1 = wh1 + 8 * WH1LD;
     static constexpr int wh2 = bh1 + HID;
     static constexpr int bh2 = wh2 + (BX ? 0 : HID * WLD);          // BX: w_h's second matrix lives in REGISTERS (32 per lane, loaded once
@@ -239,7 +238,7 @@ struct FusedLds {
     static constexpr int w4 = b3 + Tiles<D3>::v * 16;
     static constexpr int f_last = w4 + Tiles<D3>::v * 16;
     static constexpr int f1 = f_last + HeadFragFloats<XD, XD, HX>::v;
-    static constexpr int f2 = f1 + ((BX && D1 == 32) ? Bx1Layout<XD, 32>::total : HeadFragFloats<XD, D1, HX>::v);
+    static constexpr int f2 = f1 + ((BX && D1 == 32) ? Bx1Layout<XD, 32>::total : HeadFragFloats<XD, D1, HX>::v);    // ... the XD x D1 layer as bf16 pieces
     static constexpr int f3 = f2 + (BX ? Bx1Layout<D1, D2>::total : HeadFragFloats<D1, D2, HX>::v);
     static_assert(!(HX && BX), "one split mode at a time");
     static constexpr int hs = f3 + (BX ? BxLayout<D2, D3>::total : HeadFragFloats<D2, D3, HX>::v);      // HX: 1 / scale of W_last, hw1, hw2, hw3, wr2, wa, w1, wh2
