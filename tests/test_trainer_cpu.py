@@ -145,3 +145,23 @@ def test_trainer_contract_on_cpu():
     ns = types.ModuleType("crowd_nav_utils_trainer_stand_in")
     rga.register_trainers(ns)
     assert ns.MPRLTrainer is rga.MPRLTrainer and ns.VNRLTrainer is rga.VNRLTrainer and callable(ns.pad_batch)
+
+
+def test_fused_adam_steps_are_announced_to_the_descriptor_caches():
+    """torch's fused Adam kernel leaves autograd's version counters alone; the descriptor caches key on them.  The optimizer the
+    trainers build for a captured step carries a post-hook that bumps the counter of every parameter the step updated (and only
+    those), and an uncaptured trainer keeps upstream's plain Adam."""
+    net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.ReLU(), torch.nn.Linear(4, 1))
+    plain = tr._new_optimizer("Adam", net, 1e-3, capturable=False)
+    assert isinstance(plain, torch.optim.Adam) and not plain.defaults.get("fused") and not plain.defaults["capturable"]
+    assert not plain._optimizer_step_post_hooks
+    frozen = net[2].bias
+    net(torch.randn(5, 3)).sum().backward()
+    frozen.grad = None                                            # "not part of this step"
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    before = [p._version for p in net.parameters()]
+    tr._mark_parameters_changed(opt, (), {})
+    after = [p._version for p in net.parameters()]
+    assert [a - b for a, b in zip(after, before)] == [1, 1, 1, 0]
+    with pytest.raises(NotImplementedError):
+        tr._new_optimizer("RMSprop", net, 1e-3, capturable=False)
