@@ -537,7 +537,8 @@ struct GraphArgs {
     float* slabs;                // [workgroups][(has w_a + L) * X * X]
     int S, N, skip, spc, hl_row0;
     int norm;                    // row normalisation of the similarity block (graph_model.py:63-93): 0 softmax(S) (embedded_gaussian,
-                                 // gaussian); 1 squared: S^2 / sum_row S^2 (:86-89); 2 equal_attention: 1 / N (:90-91); 3 diagonal: I (:92-93)
+                                 // gaussian); 1 squared: S^2 / sum_row S^2 (:86-89); 2 equal_attention: 1 / N (:90-91); 3 diagonal: I (:92-93);
+                                 // 4 cosine: C_ij = S_ij / (m_i m_j), m_i = |row i of S| (:70-74); 5 cosine_softmax: softmax(C) (:75-79)
     // floats between the robot rows of consecutive scenes / the human rows of consecutive crowds, in Xr / Xh and in dXr / dXh: X and
     // (N - 1) X for the compact arrays above, N X for both when a scene's rows are one [N][X] block (Xh = Xr + X)
     int xr_stride, xh_stride;
@@ -582,7 +583,9 @@ struct GraphLds {
 // wave; [N][N] results NT x NT; the [X][X] weight gradients XT x XT over four waves -- with a workgroup barrier between phases, and
 // several workgroups per CU overlap each other's barriers.  The weight gradients stay in the accumulators of the waves that own
 // their tiles over all scenes of the workgroup (one slab per workgroup).
-template <int NT, int XT, int L, bool BWD>
+// COS: the build with the cosine family's passes (norm 4 / 5).  A build of its own, so that the shipped similarity functions keep
+// the register allocation they had without them (the passes cost the L = 2 backward 36 more bytes of scratch per lane otherwise).
+template <int NT, int XT, int L, bool BWD, bool COS>
 __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 : 2)) void graph_kernel(const GraphArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using Lds = GraphLds<NT, XT>;
@@ -672,7 +675,8 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
             put(G, acc);
         };
         const int norm = a.norm;
-        const bool from_s = norm <= 1;                  // the adjacency is a function of S (it is a constant otherwise)
+        const bool cosine = COS && norm >= 4;
+        const bool from_s = norm <= 1 || cosine;        // the adjacency is a function of S (it is a constant otherwise)
         // squared similarity: A is kept SIGNED in LDS -- sign(S_ij) |A_ij| -- and the row's Z_i = sum_j S_ij^2 in the row's padding
         // column, so that the backward pass gets S_ij = sign sqrt(|A_ij| Z_i) back without a buffer of its own; every consumer of
         // A reads it through aval()
@@ -715,6 +719,48 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
             for (int j = 0; j < NT; ++j)
                 if (l16 + 16 * j < N) r[l16 + 16 * j] = copysignf(w[j] / sum, sv[j]);
             if (l16 == 0) r[NT * 16] = sum;
+        }
+        // cosine family (graph_model.py:70-79): the norms of S's ROWS first (kept in the rows' padding column, like the squared sums:
+        // the backward pass needs them again), then C_ij = S_ij / (m_i m_j) and, cosine_softmax, its row softmax in the same pass
+        if constexpr (COS) {
+        for (int row = wave * 4 + kq; cosine && row < N; row += W * 4) {
+            float* r = A + row * ALD;
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float v = l16 + 16 * j < N ? r[l16 + 16 * j] : 0.f;
+                sum = fmaf(v, v, sum);
+            }
+            sum = row16_sum(sum);
+            if (l16 == 0) r[NT * 16] = sqrtf(sum);
+        }
+        if (cosine) __syncthreads();
+        for (int row = wave * 4 + kq; cosine && row < N; row += W * 4) {
+            float* r = A + row * ALD;
+            const float mi = r[NT * 16];
+            float v[NT], mx = -3.4e38f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = l16 + 16 * j;
+                v[j] = col < N ? r[col] / (mi * A[col * ALD + NT * 16]) : -3.4e38f;
+                mx = fmaxf(mx, v[j]);
+            }
+            if (norm == 5) {
+                mx = row16_maxf(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    v[j] = l16 + 16 * j < N ? expf(v[j] - mx) : 0.f;
+                    sum += v[j];
+                }
+                sum = row16_sum(sum);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) v[j] /= sum;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                if (l16 + 16 * j < N) r[l16 + 16 * j] = v[j];
+        }
         }
         // row softmax: 16 lanes per row, four rows per wave and pass
         for (int row = wave * 4 + kq; norm == 0 && row < N; row += W * 4) {
@@ -850,7 +896,7 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
                 for (int j = 0; j < NT; ++j)
                     if (l16 + 16 * j < N) d[l16 + 16 * j] = 2.f * copysignf(sqrtf(fabsf(pv[j]) / zi), pv[j]) * (dv[j] - dot);
             }
-            for (int row = wave * 4 + kq; norm == 0 && row < N; row += W * 4) {
+            for (int row = wave * 4 + kq; (norm == 0 || (COS && norm == 5)) && row < N; row += W * 4) {
                 float* d = dA + row * ALD;
                 const float* p = A + row * ALD;
                 float dv[NT], pv[NT], dot = 0.f;
@@ -865,6 +911,49 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     if (l16 + 16 * j < N) d[l16 + 16 * j] = pv[j] * (dv[j] - dot);
+            }
+            if constexpr (COS) if (cosine) {
+                // through C_ij = S_ij / (m_i m_j), m_i = sqrt(sum_k S_ik^2):
+                //   dS_ij = dC_ij / (m_i m_j) - (r_i + c_i) S_ij / m_i^2,   r_i = sum_j dC_ij C_ij,  c_i = sum_j dC_ji C_ji
+                // (m_i enters row i AND column i of C).  S is recomputed into A's buffer -- nothing reads the adjacency after the
+                // layer loop -- next to the norms the forward sweep left in the padding column; dA holds dC.
+                __syncthreads();
+                if (a_on) {
+                    f32x4 acc[1][NTW];
+                    clear<1, NTW>(acc);
+                    mm<1, NTW, 8>(acc, XW / 4, [&](int i, int k) { return X[min(am + i, last) * FLD + k]; },
+                                  [&](int k, int j) { return X[min(an + j, last) * FLD + k]; });
+                    each<1, NTW>(acc, [&](int i, int j, float v, int, int, int) {
+                        const int row = am + i, col = an + j;
+                        if (row < NP) A[row * ALD + col] = (row < N && col < N) ? v : 0.f;
+                    });
+                }
+                __syncthreads();
+                for (int row = wave * 4 + kq; row < N; row += W * 4) {          // r_i + c_i -> dA's padding column
+                    const float mi = A[row * ALD + NT * 16];
+                    float e = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int col = l16 + 16 * j;
+                        if (col < N) {
+                            const float inv = 1.f / (mi * A[col * ALD + NT * 16]);
+                            e = fmaf(dA[row * ALD + col], A[row * ALD + col] * inv, e);
+                            e = fmaf(dA[col * ALD + row], A[col * ALD + row] * inv, e);
+                        }
+                    }
+                    e = row16_sum(e);
+                    if (l16 == 0) dA[row * ALD + NT * 16] = e;
+                }
+                __syncthreads();
+                for (int row = wave * 4 + kq; row < N; row += W * 4) {
+                    float* d = dA + row * ALD;
+                    const float mi = A[row * ALD + NT * 16], back = d[NT * 16] / (mi * mi);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int col = l16 + 16 * j;
+                        if (col < N) d[col] = d[col] / (mi * A[col * ALD + NT * 16]) - back * A[row * ALD + col];
+                    }
+                }
             }
             __syncthreads();
             // S = G X^T:  dG = dS X ;  dX += dS^T G        G = X Wa:  dWa += X^T dG ;  dX += dG Wa^T     (gaussian: G = X, dX += dG)
@@ -1112,15 +1201,20 @@ int launch_rows(RowsArgs& all, hipStream_t st) {
     return RGL_OK;
 }
 
-template <int NT, int XT, int L>
-int launch_graph_nxl(const GraphArgs& ga, bool bwd, size_t lds, int grid, hipStream_t st) {
-    const void* fn = bwd ? reinterpret_cast<const void*>(graph_kernel<NT, XT, L, true>)
-                         : reinterpret_cast<const void*>(graph_kernel<NT, XT, L, false>);
-    if (lds > 64 * 1024) RGL_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (bwd) hipLaunchKernelGGL((graph_kernel<NT, XT, L, true>), dim3(grid), dim3(NT * 128), lds, st, ga);
-    else hipLaunchKernelGGL((graph_kernel<NT, XT, L, false>), dim3(grid), dim3(NT * 128), lds, st, ga);
+template <int NT, int XT, int L, bool BWD, bool COS>
+int launch_graph_kernel(const GraphArgs& ga, size_t lds, int grid, hipStream_t st) {
+    auto kern = graph_kernel<NT, XT, L, BWD, COS>;
+    if (lds > 64 * 1024)
+        RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 128), lds, st, ga);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
+}
+template <int NT, int XT, int L>
+int launch_graph_nxl(const GraphArgs& ga, bool bwd, size_t lds, int grid, hipStream_t st) {
+    if (ga.norm >= 4)
+        return bwd ? launch_graph_kernel<NT, XT, L, true, true>(ga, lds, grid, st) : launch_graph_kernel<NT, XT, L, false, true>(ga, lds, grid, st);
+    return bwd ? launch_graph_kernel<NT, XT, L, true, false>(ga, lds, grid, st) : launch_graph_kernel<NT, XT, L, false, false>(ga, lds, grid, st);
 }
 template <int NT, int XT>
 int launch_graph_nx(const GraphArgs& ga, int L, bool bwd, size_t lds, int grid, hipStream_t st) {
@@ -1185,14 +1279,17 @@ extern "C" int rgl_debug_read_backward_phase_cycles(unsigned long long* out16, i
 namespace {
 
 // what the tile kernels cover: embedded_gaussian / gaussian (softmax of S) and -- round 5 -- squared / equal_attention / diagonal
-// (plain weights: graph_model.py:86-93), one adjacency for all layers, x_dim 32 or 64, 1-3 layers, N <= 64; any embedding MLPs and
-// heads within the ABI limits.  The cosine family, the pair-MLP similarity and layerwise graphs stay on the per-scene kernels.
+// (plain weights: graph_model.py:86-93) and cosine / cosine_softmax (:70-79), one adjacency for all layers, x_dim 32 or 64, 1-3
+// layers, N <= 64; any embedding MLPs and heads within the ABI limits.  The pair-MLP similarity (concatenation) and layerwise graphs
+// stay on the per-scene kernels.
 int tiles_norm(const RglGraph& g) {
     switch (g.similarity) {
         case RGL_SIM_EMBEDDED_GAUSSIAN: case RGL_SIM_GAUSSIAN: return 0;
         case RGL_SIM_SQUARED: return 1;
         case RGL_SIM_EQUAL_ATTENTION: return 2;
         case RGL_SIM_DIAGONAL: return 3;
+        case RGL_SIM_COSINE: return 4;
+        case RGL_SIM_COSINE_SOFTMAX: return 5;
         default: return -1;
     }
 }

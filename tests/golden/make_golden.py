@@ -964,7 +964,9 @@ def gen_trainer_kats(masters, out):
     meta = []
     # ("squared", round 5): a non-default similarity function through the reference trainer (graph_model.py:86-89) -- what the tile
     # backward's plain-weight normalisations are held against under RGL_BACKWARD_MFMA=2
-    for tag, detach, sim in (("plain", False, "embedded_gaussian"), ("detach", True, "embedded_gaussian"), ("squared", False, "squared")):
+    # ("cosine_softmax"): the cosine family (:75-79), on the tile backward since the same round
+    for tag, detach, sim in (("plain", False, "embedded_gaussian"), ("detach", True, "embedded_gaussian"), ("squared", False, "squared"),
+                             ("cosine_softmax", False, "cosine_softmax")):
         torch.manual_seed(0)
         pc, g1, g2, ve, sp = build_ref_modules(masters["trained"], 2, sim, False, False)
         memory = ReplayMemory(1000)

@@ -1169,7 +1169,8 @@ def test_tile_kernels_across_node_counts(H, dev, monkeypatch):
     monkeypatch.setenv("RGL_BACKWARD_MFMA", "1")
     L = 3 if H in (2, 16, 31, 47) else 2
     skip = H % 3 != 0
-    c = dict(L=L, sim="embedded_gaussian" if H % 2 else "gaussian", layerwise=False, skip=skip, flavour="trained")
+    sim = "cosine" if H in (3, 17, 48) else ("cosine_softmax" if H in (15, 32, 62) else ("embedded_gaussian" if H % 2 else "gaussian"))
+    c = dict(L=L, sim=sim, layerwise=False, skip=skip, flavour="trained")
     g1, ve, sp = build_modules(c, dev)
     B = 7 if H < 40 else 3
     robot, humans = seeded_scenes(1300 + H, B, H)
@@ -2253,7 +2254,15 @@ def test_gradients_value_estimator_and_state_predictor(H, L, sim, skip, flavour,
     (19, 2, "equal_attention", True, "trained", 5),
     (7, 1, "equal_attention", False, "trained", 4),
     (19, 2, "diagonal", True, "trained", 5),
-    (12, 3, "diagonal", False, "trained", 4),])
+    (12, 3, "diagonal", False, "trained", 4),
+    # ... and the cosine family (graph_model.py:70-79: S over the outer product of the norms of S's ROWS, then softmax or not)
+    (5, 2, "cosine", True, "trained", 5),
+    (7, 3, "cosine", False, "trained", 3),
+    (33, 2, "cosine", True, "trained", 3),
+    (5, 2, "cosine_softmax", True, "trained", 5),
+    (19, 2, "cosine_softmax", True, "trained", 4),
+    (4, 3, "cosine_softmax", False, "trained", 6),
+    (40, 1, "cosine_softmax", True, "trained", 3),])
 def test_gradients_on_the_mfma_backward(H, L, sim, skip, flavour, B, dev, monkeypatch):
     """The tile pipeline of rgl_backward_mfma.hip (the large-batch backward: MFMA row kernels for the MLPs, one wave per scene for the
     graph block) forced on for the small oracle-autograd cases of the test above (it is chosen by batch size otherwise), and for the
@@ -2263,14 +2272,15 @@ def test_gradients_on_the_mfma_backward(H, L, sim, skip, flavour, B, dev, monkey
     test_gradients_rgl_output_and_path_g(dev)
 
 
-def test_reference_trainer_fixture_with_a_non_default_similarity_on_the_tile_backward(dev, monkeypatch):
-    """the reference MPRLTrainer's three Adam batches with the `squared` similarity function
-    (graph_model.py:86-89; fixture training_queryenv.npz, case `squared`) reproduced with the tile pipeline in MUST-RUN mode
-    (RGL_BACKWARD_MFMA=2: an error instead of the per-scene kernel) -- through the raw loop and through the public trainer's
-    captured step."""
+@pytest.mark.parametrize("tag", ["squared", "cosine_softmax"])
+def test_reference_trainer_fixture_with_a_non_default_similarity_on_the_tile_backward(tag, dev, monkeypatch):
+    """the reference MPRLTrainer's three Adam batches with the `squared` (graph_model.py:86-89) and the
+    `cosine_softmax` (:75-79) similarity functions (fixture training_queryenv.npz, cases of those names) reproduced with the tile
+    pipeline in MUST-RUN mode (RGL_BACKWARD_MFMA=2: an error instead of the per-scene kernel) -- through the raw loop and through the
+    public trainer's captured step."""
     monkeypatch.setenv("RGL_BACKWARD_MFMA", "2")
-    test_training_against_the_reference_trainer_fixture("squared", dev)
-    test_product_trainer_reproduces_the_reference_trainer_fixture("squared", dev)
+    test_training_against_the_reference_trainer_fixture(tag, dev)
+    test_product_trainer_reproduces_the_reference_trainer_fixture(tag, dev)
 
 
 @pytest.mark.parametrize("H,L,B", [(19, 2, 1024), (5, 2, 1500), (49, 3, 96), (31, 1, 200)])
@@ -2465,7 +2475,7 @@ def test_backward_refuses_stale_parameters_and_state_gradients(dev):
         ve((state[0], state[1].clone().requires_grad_(True)))
 
 
-@pytest.mark.parametrize("tag", ["plain", "detach", "squared"])
+@pytest.mark.parametrize("tag", ["plain", "detach", "squared", "cosine_softmax"])
 def test_training_against_the_reference_trainer_fixture(tag, dev):
     """Fixture training_queryenv.npz: the REFERENCE MPRLTrainer.optimize_batch (crowd_nav/utils/trainer.py:110-161) ran three
     un-shuffled batches of 16 transitions on the reference modules (Adam 1e-3, frozen target copy; skip_connection=False, the only
@@ -2473,7 +2483,7 @@ def test_training_against_the_reference_trainer_fixture(tag, dev):
     end at the same parameters and report the same losses."""
     import copy
     fx = gio.load("training_queryenv")
-    c = dict(L=2, sim="squared" if tag == "squared" else "embedded_gaussian", layerwise=False, skip=False, flavour="trained")
+    c = dict(L=2, sim=tag if tag in ("squared", "cosine_softmax") else "embedded_gaussian", layerwise=False, skip=False, flavour="trained")
     _, ve, sp = build_modules(c, dev)
     detach = tag == "detach"
     target = copy.deepcopy(ve)
@@ -2578,14 +2588,14 @@ class _ListDataset(torch.utils.data.Dataset):
         return len(self.items)
 
 
-@pytest.mark.parametrize("tag", ["plain", "detach", "squared"])
+@pytest.mark.parametrize("tag", ["plain", "detach", "squared", "cosine_softmax"])
 def test_product_trainer_reproduces_the_reference_trainer_fixture(tag, dev):
     """the fast optimisation step through the PUBLIC trainer (relationalgraphlearning_amd.MPRLTrainer: the
     reference's constructor / set_learning_rate / update_target_model / optimize_batch contract, every step after the first a
     replay of one captured hipGraph).  Same fixture as test_training_against_the_reference_trainer_fixture: the REFERENCE
     MPRLTrainer.optimize_batch over three un-shuffled batches of 16 transitions -- same final parameters, same reported losses."""
     fx = gio.load("training_queryenv")
-    c = dict(L=2, sim="squared" if tag == "squared" else "embedded_gaussian", layerwise=False, skip=False, flavour="trained")
+    c = dict(L=2, sim=tag if tag in ("squared", "cosine_softmax") else "embedded_gaussian", layerwise=False, skip=False, flavour="trained")
     _, ve, sp = build_modules(c, dev)
     items = [(torch.tensor(fx["tr.robot"][i]).unsqueeze(0).to(dev), torch.tensor(fx["tr.humans"][i]).to(dev),
               torch.zeros(1, device=dev), torch.tensor(fx["tr.rewards"][i]).reshape(1).to(dev),
