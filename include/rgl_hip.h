@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RGL_ABI_VERSION 6
+#define RGL_ABI_VERSION 7
 
 #define RGL_MAX_MLP_LAYERS 6
 #define RGL_MAX_GCN_LAYERS 8
@@ -175,6 +175,27 @@ typedef struct RglTransposeJob {
     int rows, cols;
 } RglTransposeJob;
 int rgl_transpose_many_f32(const RglTransposeJob* jobs, int n_jobs, rgl_stream_t stream);
+
+/* rgl_gather_rows_f32 (ABI 7) -- dst_j[i][:] = src_j[index[i]][:] for every field j of a replay memory in one launch per 8 fields:
+ * the batch a trainer draws (crowd_nav/utils/trainer.py:120 `for data in self.data_loader`; crowd_nav/utils/memory.py keeps tuples,
+ * this package's ReplayMemory mirrors them as one [capacity][row_floats] device array per field).  `jobs` is a HOST array; `index`
+ * device int64 [n_index], every entry in [0, src_rows) -- a row of NaN is written for an entry outside (torch's index_select traps). */
+typedef struct RglGatherJob {
+    const float* src;           /* device [src_rows][row_floats] */
+    float* dst;                 /* device [n_index][row_floats]  */
+    int row_floats, src_rows;
+} RglGatherJob;
+int rgl_gather_rows_f32(const RglGatherJob* jobs, int n_jobs, const long long* index, int n_index, rgl_stream_t stream);
+
+/* rgl_mse_step_f32 (ABI 7) -- the loss end of one optimisation step (crowd_nav/utils/trainer.py:130-137,145-153:
+ * `loss = self.criterion(outputs, target_values)` with nn.MSELoss(), `loss.backward()`, `v_losses += loss.data.item()`):
+ *   target_i  = target[i], or (target == NULL: the value update, :128-129) reward[i] + gamma * next_value[i] in two roundings
+ *   grad[i]   = (float)(2 / n) * (out[i] - target_i)          -- d loss / d out, exactly torch's mse_backward arithmetic
+ *   *loss_sum += (double)(float)(sum_i (out[i] - target_i)^2 / n)   -- float64 accumulation of the float32 loss upstream reports
+ * all device pointers, n floats each (loss_sum: one double, read-modify-written: calls on one stream are ordered).  One workgroup,
+ * fixed summation order. */
+int rgl_mse_step_f32(const float* out, const float* target, const float* reward, const float* next_value, float gamma, int n,
+                     float* grad, double* loss_sum, rgl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * gcn_rotate_f32 -- pairwise relation features: (R,14) [robot 9 | human 5] -> (R,13)

@@ -15,7 +15,7 @@ MAX_NODES = 128
 MAX_XDIM = 64
 MAX_WIDTH = 256
 MAX_ACTIONS = 256
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 SIMILARITY = {"embedded_gaussian": 0, "gaussian": 1, "cosine": 2, "cosine_softmax": 3, "concatenation": 4,
               "squared": 5, "equal_attention": 6, "diagonal": 7}
@@ -37,6 +37,10 @@ class RglMlp(C.Structure):
 
 class RglTransposeJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int)]
+
+
+class RglGatherJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_floats", C.c_int), ("src_rows", C.c_int)]
 
 
 class RglGraph(C.Structure):
@@ -88,6 +92,9 @@ SIGNATURES = {
                                          C.c_void_p, C.c_size_t, C.c_void_p]),
     "rgl_transpose_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rgl_transpose_many_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "rgl_gather_rows_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "rgl_mse_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
     "gcn_rotate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "gcn_prepare_f32": (C.c_int, [C.POINTER(GcnPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
@@ -151,6 +158,12 @@ def lib():
             raise NativeLibraryError("librgl_hip.so ABI %d != expected %d" % (handle.rgl_abi_version(), ABI_VERSION))
         _lib = handle
     return _lib
+
+
+def poison_workspaces():
+    """RGL_DEBUG_POISON_WORKSPACES=1 (tests): workspaces and output slabs are filled with NaN bit patterns before the kernels run, so
+    that a read of memory no kernel has written shows up as NaN instead of as whatever the allocator handed out."""
+    return os.environ.get("RGL_DEBUG_POISON_WORKSPACES", "0") == "1"
 
 
 def check(rc, what):

@@ -78,6 +78,9 @@ class GraphFunction(torch.autograd.Function):
         dh_t, dh = ptr("H")
         flat = torch.empty(n, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.rgl_graph_backward_workspace_bytes(C.byref(graph), vhp, mhp, S), dtype=torch.uint8, device=dev)
+        if nat.poison_workspaces():              # tests: a kernel that reads what nobody wrote turns the gradients into NaN
+            flat.fill_(float("nan"))
+            ws.fill_(255)
         with torch.cuda.device(dev):
             rc = lib.rgl_graph_backward_f32(C.byref(graph), vhp, mhp, robot.data_ptr(), humans.data_ptr(), S, H,
                                             int(spec.detach_graph), dv, dm, dh, flat.data_ptr(), ws.data_ptr(), ws.numel(),

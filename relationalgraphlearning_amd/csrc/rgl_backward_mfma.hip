@@ -1278,6 +1278,11 @@ extern "C" int rgl_debug_read_backward_phase_cycles(unsigned long long* out16, i
 
 namespace {
 
+// dst[0..n) = src[0..n), or zero (src == null); grid-stride
+__global__ __launch_bounds__(256) void init_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src ? src[i] : 0.f;
+}
+
 // what the tile kernels cover: embedded_gaussian / gaussian (softmax of S) and -- round 5 -- squared / equal_attention / diagonal
 // (plain weights: graph_model.py:86-93) and cosine / cosine_softmax (:70-79), one adjacency for all layers, x_dim 32 or 64, 1-3
 // layers, N <= 64; any embedding MLPs and heads within the ABI limits.  The pair-MLP similarity (concatenation) and layerwise graphs
@@ -1496,8 +1501,16 @@ static int backward_tiles(const RglGraph* graph, const RglMlp* vh, const RglMlp*
         if (rc) return rc;
     }
     // 3. heads: dH_L starts as the caller's d_H (or zero) and receives the heads' input gradients
-    if (d_H) RGL_HIP_TRY(hipMemcpyAsync(dHL, d_H, feat * sizeof(float), hipMemcpyDeviceToDevice, st));
-    else RGL_HIP_TRY(hipMemsetAsync(dHL, 0, feat * sizeof(float), st));
+    // (a kernel, not hipMemsetAsync / hipMemcpyAsync: recorded into a captured training step and replayed, the memset NODE was not
+    // reliably ordered against the kernel nodes around it -- on some boxes the heads' `+=` into dH_L met garbage (NaN parameters), on
+    // others the zeros arrived after it and a step lost the heads' gradient (sporadic 2e-3 deviations of the parameters; never in an
+    // eager step, never with the per-scene kernel, which has no memset: tools/micro/captured_step_repeatability.py))
+    {
+        const size_t n4 = (feat + 3) / 4;
+        const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(init_rows_kernel, dim3(blocks), dim3(256), 0, st, dHL, d_H, feat);
+        RGL_LAUNCH_CHECK();
+    }
     if (has_v || has_m) {
         RowsArgs ra{};
         ra.backward = 1;

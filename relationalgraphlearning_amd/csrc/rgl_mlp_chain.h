@@ -355,7 +355,7 @@ template <int IN, int OUT, bool BIAS>
 __device__ __forceinline__ void layer_mfma_bx(const float* frags, const f32x4 (&in)[Tiles<IN>::v], f32x4 (&out)[Tiles<OUT>::v],
                                               int lane, const float* bias = nullptr) {
     using BL = BxLayout<IN, OUT>;
-    constexpr int IT = BL::IT, OTF = BL::OTF, NCB = BL::NCB, ITB = BL::ITB, KF = BL::KF;
+    constexpr int IT = BL::IT, OTF = BL::OTF, NCB = BL::NCB, ITB = BL::ITB;
     const int q = lane >> 4;
     // ONE base register per access width for the whole region (57 KB: within the 64 KB reach of a ds instruction's immediate
     // offset), made opaque to constant folding: the region sits beyond 64 KB from the start of LDS, and left to itself hipcc

@@ -335,6 +335,10 @@ def graph_forward(graph, value_head, motion_head, robot, humans, scenes_per_crow
             if wbytes:
                 ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
                 wp = ws.data_ptr()
+        if nat.poison_workspaces():
+            for t in [ws] + list(out.values()):
+                if t is not None:
+                    t.fill_(255) if t.dtype == torch.uint8 else t.fill_(float("nan"))
         rc = lib.rgl_graph_forward_f32(C.byref(graph), vh, mh, robot.data_ptr(), humans.data_ptr(), S,
                                        scenes_per_crowd, H, Hp, Ap, vp, mp, wp, wbytes, _stream())
     nat.check(rc, "rgl_graph_forward_f32")

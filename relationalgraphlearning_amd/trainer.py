@@ -20,6 +20,7 @@ against the real DataLoader on CPU) -- and gathered with one index_select per fi
 by the caller, goes through the DataLoader itself.  SGD and shapes that change from batch to batch run the same step eagerly.
 """
 import copy
+import ctypes as C
 import logging
 import os
 
@@ -28,6 +29,7 @@ import torch.nn as nn
 import torch.optim as optim
 from torch.utils.data import DataLoader
 
+from . import _native as nat
 from .nets import invalidate_packed_weights
 
 
@@ -48,6 +50,30 @@ class _ShuffledIndexBatches(object):
         perm = torch.randperm(self.n, generator=g)
         for lo in range(0, self.n, self.batch_size):
             yield perm[lo:lo + self.batch_size]
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _gather_fields(fields, idx):
+    """[f.index_select(0, idx) for f in fields]; device float32 fields of one device in ONE launch (rgl_gather_rows_f32: a replayed
+    batch-100 step is launch-bound, and the gathers were five of its nodes), anything else through torch."""
+    dev = idx.device
+    if not (dev.type == "cuda" and idx.dtype == torch.int64 and idx.dim() == 1 and idx.is_contiguous() and len(fields) > 0 and
+            all(f.device == dev and f.dtype == torch.float32 and f.is_contiguous() and f.dim() >= 1 and f.shape[0] > 0 and f[0].numel() > 0
+                for f in fields)):
+        return [f.index_select(0, idx) for f in fields]
+    n = int(idx.shape[0])
+    outs = [torch.empty((n,) + tuple(f.shape[1:]), dtype=torch.float32, device=dev) for f in fields]
+    if n == 0:
+        return outs
+    jobs = (nat.RglGatherJob * len(fields))()
+    for j, (f, o) in enumerate(zip(fields, outs)):
+        jobs[j].src, jobs[j].dst, jobs[j].row_floats, jobs[j].src_rows = f.data_ptr(), o.data_ptr(), f[0].numel(), int(f.shape[0])
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().rgl_gather_rows_f32(jobs, len(fields), idx.data_ptr(), n, _stream()), "rgl_gather_rows_f32")
+    return outs
 
 
 class _Batch(object):
@@ -71,7 +97,7 @@ class _Batch(object):
     def tensors(self):
         if self._tensors is not None:
             return [t.contiguous() for t in self._tensors]
-        return [f.index_select(0, self._idx) for f in self._fields]
+        return _gather_fields(self._fields, self._idx)
 
     def identity(self):
         """What a captured step bakes in besides the shapes: the addresses of the memory's stacked fields it gathers from."""
@@ -84,7 +110,7 @@ class _Batch(object):
         if self._tensors is not None:
             return self.tensors(), fn
         fields = self._fields
-        return [self._idx.clone()], (lambda idx: fn(*[f.index_select(0, idx) for f in fields]))
+        return [self._idx.clone()], (lambda idx: fn(*_gather_fields(fields, idx)))
 
     def fill(self, static):
         if self._tensors is not None:
@@ -235,6 +261,37 @@ class _TrainerBase(object):
         v, s = self._loss.tolist()               # the one host read of the call
         return v, s
 
+    def _loss_backward(self, slot, outputs, target=None, bootstrap=None):
+        """`loss = self.criterion(outputs, target); loss.backward()` and the loss added to the call's running sum
+        (crowd_nav/utils/trainer.py:130-137,145-153,223-227).  `bootstrap` = (rewards, next values, gamma_bar) in place of `target`:
+        the value update's `rewards + gamma_bar * target_model(next state)` (:128-129,221-222).
+        On the device, with upstream's nn.MSELoss(): ONE launch (rgl_mse_step_f32: target, loss, its gradient -- torch's mse_backward
+        arithmetic bit for bit -- and the running sum) and `outputs.backward(gradient)`, where torch runs nine launch-sized kernels.
+        Any other criterion, dtype, broadcasting pair of shapes or device: torch, as upstream writes it."""
+        others = [target] if target is not None else [bootstrap[0], bootstrap[1]]
+        fused = (type(self.criterion) is nn.MSELoss and self.criterion.reduction == 'mean' and outputs.is_cuda and
+                 outputs.dtype == torch.float32 and outputs.numel() > 0 and os.environ.get("RGL_TRAINER_FUSED_LOSS", "1") != "0" and
+                 all(torch.is_tensor(t) and t.device == outputs.device and t.dtype == torch.float32 and t.shape == outputs.shape
+                     and not t.requires_grad for t in others))
+        if not fused:
+            if target is None:
+                target = bootstrap[0] + bootstrap[2] * bootstrap[1]
+            loss = self.criterion(outputs, target)
+            loss.backward()
+            self._loss[slot].add_(loss.detach())            # float64 += float32 in one kernel (the iterator converts)
+            return
+        out = outputs.contiguous()
+        grad = torch.empty_like(out)
+        ptr = [t.contiguous() for t in others]
+        with torch.cuda.device(out.device):
+            rc = nat.lib().rgl_mse_step_f32(out.data_ptr(), ptr[0].data_ptr() if target is not None else None,
+                                            None if target is not None else ptr[0].data_ptr(),
+                                            None if target is not None else ptr[1].data_ptr(),
+                                            0.0 if target is not None else float(bootstrap[2]), out.numel(), grad.data_ptr(),
+                                            self._loss.data_ptr() + 8 * slot, _stream())
+        nat.check(rc, "rgl_mse_step_f32")
+        out.backward(grad)
+
 
 class MPRLTrainer(_TrainerBase):
     def __init__(self, value_estimator, state_predictor, memory, device, policy, writer, batch_size, optimizer_str, human_num,
@@ -342,13 +399,13 @@ class MPRLTrainer(_TrainerBase):
         return (id(self.v_optimizer), id(self.s_optimizer), id(self.target_model), id(self.value_estimator), id(self.state_predictor),
                 bool(self.detach_state_predictor))
 
-    def _value_step(self, robot_states, human_states, target_values_fn):
+    def _value_step(self, robot_states, human_states, target=None, bootstrap=None):
+        """One value update; `bootstrap()` -> (rewards, next values, gamma_bar) is evaluated after the forward, like upstream's
+        target line."""
         self.v_optimizer.zero_grad()
         outputs = self.value_estimator((robot_states, human_states))
-        loss = self.criterion(outputs, target_values_fn())
-        loss.backward()
+        self._loss_backward(0, outputs, target, bootstrap() if bootstrap is not None else None)
         self.v_optimizer.step()
-        self._loss[0].add_(loss.detach())            # float64 += float32 in one kernel (the iterator converts)
 
     def _predictor_step(self, robot_states, human_states, next_human_states, detach):
         self.s_optimizer.zero_grad()
@@ -356,10 +413,8 @@ class MPRLTrainer(_TrainerBase):
             _, next_human_states_est = self.state_predictor((robot_states, human_states), None)
         else:
             _, next_human_states_est = self.state_predictor((robot_states, human_states), None, detach=detach)
-        loss = self.criterion(next_human_states_est, next_human_states)
-        loss.backward()
+        self._loss_backward(1, next_human_states_est, next_human_states)
         self.s_optimizer.step()
-        self._loss[1].add_(loss.detach())
 
     def optimize_epoch(self, num_epochs):
         if self.v_optimizer is None:
@@ -368,7 +423,7 @@ class MPRLTrainer(_TrainerBase):
 
         def il_step(update_sp):
             def fn(robot_states, human_states, values, next_human_states):
-                self._value_step(robot_states, human_states, lambda: values)
+                self._value_step(robot_states, human_states, target=values)
                 if update_sp:
                     self._predictor_step(robot_states, human_states, next_human_states, None)
             return fn
@@ -401,10 +456,10 @@ class MPRLTrainer(_TrainerBase):
 
         def rl_step(update_sp):
             def fn(robot_states, human_states, rewards, next_robot_states, next_human_states):
-                def target():
+                def bootstrap():
                     with torch.no_grad():          # the frozen copy: upstream lets autograd walk it and never uses the result
-                        return rewards + gamma_bar * self.target_model((next_robot_states, next_human_states))
-                self._value_step(robot_states, human_states, target)
+                        return rewards, self.target_model((next_robot_states, next_human_states)), gamma_bar
+                self._value_step(robot_states, human_states, bootstrap=bootstrap)
                 if update_sp:
                     self._predictor_step(robot_states, human_states, next_human_states, self.detach_state_predictor)
             return fn
@@ -497,13 +552,11 @@ class VNRLTrainer(_TrainerBase):
     def _signature(self):
         return (id(self.optimizer), id(self.target_model), id(self.model))
 
-    def _step(self, inputs, lengths, target_values_fn):
+    def _step(self, inputs, lengths, target=None, bootstrap=None):
         self.optimizer.zero_grad()
         outputs = self.model((inputs, lengths))
-        loss = self.criterion(outputs, target_values_fn())
-        loss.backward()
+        self._loss_backward(0, outputs, target, bootstrap() if bootstrap is not None else None)
         self.optimizer.step()
-        self._loss[0].add_(loss.detach())            # float64 += float32 in one kernel (the iterator converts)
 
     def _full_lengths(self, lengths, width):
         """The graph network takes whole batches of equally long sequences (gcn.ValueNetwork.forward's `lengths` only names the
@@ -523,7 +576,7 @@ class VNRLTrainer(_TrainerBase):
                 lengths = torch.as_tensor(lengths)
 
                 def fn(x, v, lengths=lengths):
-                    self._step(x, lengths, lambda: v)
+                    self._step(x, lengths, target=v)
                 if self._full_lengths(lengths, inputs.shape[1]):
                     self._run(("il",), fn, _Batch(tensors=[inputs, values]), [self.model], self._signature())
                 else:
@@ -548,10 +601,10 @@ class VNRLTrainer(_TrainerBase):
             lengths, next_lengths = torch.as_tensor(lengths), torch.as_tensor(next_lengths)
 
             def fn(x, r, x2, lengths=lengths, next_lengths=next_lengths):
-                def target():
+                def bootstrap():
                     with torch.no_grad():
-                        return r + gamma_bar * self.target_model((x2, next_lengths))
-                self._step(x, lengths, target)
+                        return r, self.target_model((x2, next_lengths)), gamma_bar
+                self._step(x, lengths, bootstrap=bootstrap)
             if self._full_lengths(lengths, inputs.shape[1]) and self._full_lengths(next_lengths, next_states.shape[1]):
                 self._run(("rl",), fn, _Batch(tensors=[inputs, rewards, next_states]), [self.model], self._signature())
             else:

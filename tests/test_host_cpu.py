@@ -39,16 +39,17 @@ def test_struct_layout_matches_header_sizes():
     assert ctypes.sizeof(nat.MprlLevelView) == 12 * 8               # ABI 6: + reward_clip_off
     assert ctypes.sizeof(nat.MprlPlanner) == 2 * graph + 2 * mlp + 8 * 4 + 2 * 8 + 2 * 8 + 2 * 8 + 8 + 8  # ABI 2: + float64 root pointers; ABI 3: + children_image; ABI 4: + predictor_image
     assert ctypes.sizeof(nat.GcnPlanner) == graph + mlp + 2 * 4 + 2 * 8 + 8 + 2 * 8
+    assert ctypes.sizeof(nat.RglTransposeJob) == 2 * 8 + 2 * 4 and ctypes.sizeof(nat.RglGatherJob) == 2 * 8 + 2 * 4      # ABI 7
 
 
 def test_contraction_modes_and_level_view_match_the_header():
-    """ABI 6: the contraction-mode constants of include/rgl_hip.h are the ones the Python side sends; the level view exposes the
+    """ABI 6 (7 adds entry points only): the contraction-mode constants of include/rgl_hip.h are the ones the Python side sends; the level view exposes the
     root's tensor-born reward array (reward_clip_off) at level 0 of a clipped search only."""
     hdr = open(os.path.join(ROOT, "include", "rgl_hip.h")).read()
     consts = {name: int(val) for name, val in re.findall(r"#define (RGL_CONTRACT_\w+)\s+(\d+)", hdr)}
     assert consts == {"RGL_CONTRACT_F32": 0, "RGL_CONTRACT_F16": 1, "RGL_CONTRACT_F16X3": 2, "RGL_CONTRACT_BF16X6": 3}
     assert nat.CONTRACTION_DTYPES == {"f32": 0, "f16": 1, "f16x3": 2, "bf16x6": 3}
-    assert int(re.search(r"#define RGL_ABI_VERSION (\d+)", hdr).group(1)) == nat.ABI_VERSION == 6
+    assert int(re.search(r"#define RGL_ABI_VERSION (\d+)", hdr).group(1)) == nat.ABI_VERSION == 7
     lib = nat.lib()
     pl = nat.MprlPlanner()
     pl.planning_depth, pl.planning_width, pl.num_actions, pl.do_action_clip = 2, 2, 81, 1
