@@ -192,10 +192,13 @@ int rgl_gather_rows_f32(const RglGatherJob* jobs, int n_jobs, const long long* i
  *   target_i  = target[i], or (target == NULL: the value update, :128-129) reward[i] + gamma * next_value[i] in two roundings
  *   grad[i]   = (float)(2 / n) * (out[i] - target_i)          -- d loss / d out, exactly torch's mse_backward arithmetic
  *   *loss_sum += (double)(float)(sum_i (out[i] - target_i)^2 / n)   -- float64 accumulation of the float32 loss upstream reports
- * all device pointers, n floats each (loss_sum: one double, read-modify-written: calls on one stream are ordered).  One workgroup,
- * fixed summation order. */
+ * all device pointers, n floats each (loss_sum: one double, read-modify-written: calls on one stream are ordered).
+ * workspace: device, RGL_MSE_WORKSPACE_BYTES, ZEROED ONCE by the caller and then left to this function (partial sums and an arrival
+ * counter that every launch leaves at zero); only touched when n > 8192 (several workgroups), may be NULL below that.  The partial
+ * sums are added in a fixed order: the reported loss does not depend on scheduling. */
+#define RGL_MSE_WORKSPACE_BYTES 2048
 int rgl_mse_step_f32(const float* out, const float* target, const float* reward, const float* next_value, float gamma, int n,
-                     float* grad, double* loss_sum, rgl_stream_t stream);
+                     float* grad, double* loss_sum, void* workspace, rgl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * gcn_rotate_f32 -- pairwise relation features: (R,14) [robot 9 | human 5] -> (R,13)

@@ -16,6 +16,7 @@ MAX_XDIM = 64
 MAX_WIDTH = 256
 MAX_ACTIONS = 256
 ABI_VERSION = 7
+MSE_WORKSPACE_BYTES = 2048
 
 SIMILARITY = {"embedded_gaussian": 0, "gaussian": 1, "cosine": 2, "cosine_softmax": 3, "concatenation": 4,
               "squared": 5, "equal_attention": 6, "diagonal": 7}
@@ -94,7 +95,7 @@ SIGNATURES = {
     "rgl_transpose_many_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "rgl_gather_rows_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "rgl_mse_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
-                                   C.c_void_p]),
+                                   C.c_void_p, C.c_void_p]),
     "gcn_rotate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "gcn_prepare_f32": (C.c_int, [C.POINTER(GcnPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),

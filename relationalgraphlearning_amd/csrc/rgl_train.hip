@@ -36,6 +36,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const GatherBatch b) {
 }
 
 constexpr int kMseThreads = 1024;
+constexpr int kMsePerBlock = 8 * kMseThreads;      // floats per workgroup before a launch takes a second one
+constexpr int kMseMaxBlocks = RGL_MSE_WORKSPACE_BYTES / 8 - 1;
 struct MseArgs {
     const float* out;
     const float* target;          // or null: target_i = reward_i + gamma * next_value_i
@@ -45,13 +47,16 @@ struct MseArgs {
     int n;
     float* grad;
     double* loss_sum;
+    double* partial;              // workspace: [kMseMaxBlocks] partial sums, then the arrival counter (launches of several workgroups)
 };
 
-// ONE workgroup (n is a batch of values or of next-state rows: 1e2 .. 1e5 floats), so the loss is summed in a fixed order
+// Workgroup b owns the elements b * 1024 + t, + gridDim * 1024, ..: the partial sums, and the order in which the LAST workgroup to
+// finish adds them up, do not depend on the scheduling -- the reported loss is the same number on every run.  A batch of values
+// (n = 100) is one workgroup and touches no workspace.
 __global__ __launch_bounds__(kMseThreads) void mse_step_kernel(const MseArgs a) {
     __shared__ double part[kMseThreads / 64];
     double s = 0.0;
-    for (int i = threadIdx.x; i < a.n; i += kMseThreads) {
+    for (int i = blockIdx.x * kMseThreads + threadIdx.x; i < a.n; i += gridDim.x * kMseThreads) {
         // two roundings, as `rewards + gamma_bar * V` has upstream -- two kernels there -- so no contraction into a fused multiply-add
         // here (hipcc's default is -ffp-contract=fast, and HIP's __fmul_rn is a plain product that it contracts all the same)
 #pragma clang fp contract(off)
@@ -64,12 +69,21 @@ __global__ __launch_bounds__(kMseThreads) void mse_step_kernel(const MseArgs a) 
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double tot = 0.0;
-        for (int w = 0; w < kMseThreads / 64; ++w) tot += part[w];
-        // the batch's loss as upstream reports it -- a float32 scalar -- added to the call's running float64 sum
-        a.loss_sum[0] += (double)(float)(tot / (double)a.n);
+    if (threadIdx.x != 0) return;
+    double tot = 0.0;
+    for (int w = 0; w < kMseThreads / 64; ++w) tot += part[w];
+    if (gridDim.x > 1) {
+        unsigned* arrivals = reinterpret_cast<unsigned*>(a.partial + kMseMaxBlocks);
+        a.partial[blockIdx.x] = tot;
+        __threadfence();
+        if (atomicAdd(arrivals, 1u) != gridDim.x - 1) return;
+        __threadfence();
+        tot = 0.0;
+        for (unsigned b = 0; b < gridDim.x; ++b) tot += __hip_atomic_load(&a.partial[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *arrivals = 0u;                        // ready for the next launch (launches on one stream are ordered)
     }
+    // the batch's loss as upstream reports it -- a float32 scalar -- added to the call's running float64 sum
+    a.loss_sum[0] += (double)(float)(tot / (double)a.n);
 }
 
 }  // namespace
@@ -101,14 +115,17 @@ extern "C" int rgl_gather_rows_f32(const RglGatherJob* jobs, int n_jobs, const l
 }
 
 extern "C" int rgl_mse_step_f32(const float* out, const float* target, const float* reward, const float* next_value, float gamma, int n,
-                                float* grad, double* loss_sum, rgl_stream_t stream) {
+                                float* grad, double* loss_sum, void* workspace, rgl_stream_t stream) {
     if (n < 1) return RGL_ERR_BAD_SHAPE;
     if (!out || !grad || !loss_sum || (!target && (!reward || !next_value))) return RGL_ERR_NULL;
+    int blocks = (n + kMsePerBlock - 1) / kMsePerBlock;
+    blocks = blocks > kMseMaxBlocks ? kMseMaxBlocks : blocks;
+    if (blocks > 1 && !workspace) return RGL_ERR_WORKSPACE;
     MseArgs a;
     a.out = out; a.target = target; a.reward = reward; a.next_value = next_value;
     a.gamma = gamma; a.grad_scale = (float)(2.0 / (double)n); a.n = n;
-    a.grad = grad; a.loss_sum = loss_sum;
-    hipLaunchKernelGGL(mse_step_kernel, dim3(1), dim3(kMseThreads), 0, (hipStream_t)stream, a);
+    a.grad = grad; a.loss_sum = loss_sum; a.partial = (double*)workspace;
+    hipLaunchKernelGGL(mse_step_kernel, dim3(blocks), dim3(kMseThreads), 0, (hipStream_t)stream, a);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }

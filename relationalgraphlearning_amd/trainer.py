@@ -255,6 +255,7 @@ class _TrainerBase(object):
     def _loss_begin(self):
         if self._loss is None:
             self._loss = torch.zeros(2, dtype=torch.float64, device=self.device)
+            self._loss_ws = torch.zeros(nat.MSE_WORKSPACE_BYTES, dtype=torch.uint8, device=self.device)   # rgl_mse_step_f32's, zeroed once
         self._loss.zero_()
 
     def _loss_read(self):
@@ -288,7 +289,7 @@ class _TrainerBase(object):
                                             None if target is not None else ptr[0].data_ptr(),
                                             None if target is not None else ptr[1].data_ptr(),
                                             0.0 if target is not None else float(bootstrap[2]), out.numel(), grad.data_ptr(),
-                                            self._loss.data_ptr() + 8 * slot, _stream())
+                                            self._loss.data_ptr() + 8 * slot, self._loss_ws.data_ptr(), _stream())
         nat.check(rc, "rgl_mse_step_f32")
         out.backward(grad)
 

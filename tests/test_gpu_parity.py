@@ -2886,23 +2886,31 @@ def test_mse_step_is_torchs_loss_and_backward(shape, dev):
     gamma_bar = pow(0.9, 0.25)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     acc = torch.full((2,), 0.5, dtype=torch.float64, device=dev)
+    ws = torch.zeros(nat.MSE_WORKSPACE_BYTES, dtype=torch.uint8, device=dev)            # zeroed once; every launch leaves it ready
     for mode, target in (("target", tgt), ("bootstrap", rew + gamma_bar * nxt)):
         out.grad = None
         loss = torch.nn.MSELoss()(out, target)
         loss.backward()
-        grad = torch.empty_like(out)
-        before = float(acc[1])
-        rc = nat.lib().rgl_mse_step_f32(out.data_ptr(), tgt.data_ptr() if mode == "target" else None,
-                                        None if mode == "target" else rew.data_ptr(), None if mode == "target" else nxt.data_ptr(),
-                                        0.0 if mode == "target" else gamma_bar, out.numel(), grad.data_ptr(), acc.data_ptr() + 8, st)
-        nat.check(rc, "rgl_mse_step_f32")
-        torch.cuda.synchronize()
-        assert torch.equal(grad, out.grad), (mode, float((grad - out.grad).abs().max()))
-        mine = float(acc[1]) - before
-        assert abs(mine - float(loss)) <= 2e-6 * max(1.0, abs(float(loss))), (mode, mine, float(loss))
-        assert float(acc[0]) == 0.5            # the neighbouring slot is not touched
-    assert nat.lib().rgl_mse_step_f32(out.data_ptr(), None, None, None, 0.0, 4, out.data_ptr(), acc.data_ptr(), st) == -3
-    assert nat.lib().rgl_mse_step_f32(out.data_ptr(), tgt.data_ptr(), None, None, 0.0, 0, out.data_ptr(), acc.data_ptr(), st) == -1
+        seen = []
+        for rep in range(3):                                  # several workgroups above 8192 floats: same bits every time
+            grad = torch.empty_like(out)
+            before = float(acc[1])
+            rc = nat.lib().rgl_mse_step_f32(out.data_ptr(), tgt.data_ptr() if mode == "target" else None,
+                                            None if mode == "target" else rew.data_ptr(), None if mode == "target" else nxt.data_ptr(),
+                                            0.0 if mode == "target" else gamma_bar, out.numel(), grad.data_ptr(), acc.data_ptr() + 8,
+                                            ws.data_ptr(), st)
+            nat.check(rc, "rgl_mse_step_f32")
+            torch.cuda.synchronize()
+            assert torch.equal(grad, out.grad), (mode, float((grad - out.grad).abs().max()))
+            seen.append(np.float32(float(acc[1]) - before))
+            acc[1] = 0.5
+        assert abs(float(seen[0]) - float(loss.detach())) <= 2e-6 * max(1.0, abs(float(loss.detach()))), (mode, seen, float(loss.detach()))
+        assert seen[0] == seen[1] == seen[2] and float(acc[0]) == 0.5            # repeatable; the neighbouring slot is not touched
+    assert nat.lib().rgl_mse_step_f32(out.data_ptr(), None, None, None, 0.0, 4, out.data_ptr(), acc.data_ptr(), ws.data_ptr(), st) == -3
+    assert nat.lib().rgl_mse_step_f32(out.data_ptr(), tgt.data_ptr(), None, None, 0.0, 0, out.data_ptr(), acc.data_ptr(), ws.data_ptr(), st) == -1
+    if out.numel() > 8192:
+        assert nat.lib().rgl_mse_step_f32(out.data_ptr(), tgt.data_ptr(), None, None, 0.0, out.numel(), grad.data_ptr(), acc.data_ptr(),
+                                          None, st) == -4                           # RGL_ERR_WORKSPACE
     report("rgl_mse_step_f32 == MSELoss + backward on %s (gradient bit-exact, both target forms)" % (shape,))
 
 
