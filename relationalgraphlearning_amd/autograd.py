@@ -97,4 +97,11 @@ class GraphFunction(torch.autograd.Function):
             # gradients: transposed views sent them down torch's strided slow path); Linear weights come in torch layout (out, in)
             grads_out.append(piece.view(*shape))
         assert off == n, (off, n)
+        if spec.detach_graph:
+            # StatePredictor(..., detach=True) cuts the graph model out of the autograd graph upstream (state_predictor.py:29-30): its
+            # parameters receive NO gradient -- `.grad` stays None after zero_grad() and the optimizer skips them.  Zeros are not the
+            # same thing: Adam keeps moving a parameter along its momentum (and counts a step) on a zero gradient, which is what the
+            # graph model would do through a whole RL phase after imitation learning has trained it (configs/icra_benchmark/mp_detach.py).
+            for i in range(spec.n_graph_params):
+                grads_out[i] = None
         return (None, None, None) + tuple(grads_out)

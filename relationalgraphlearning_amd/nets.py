@@ -94,6 +94,7 @@ class _Spec(object):
         for w in gm._graph_weights():
             self.params.append(w)
             self.param_shapes.append(("matrix", tuple(w.shape)))
+        self.n_graph_params = len(self.params)          # the graph model's share of `params` (the heads follow)
         if value_seq is not None:
             add_mlp(value_seq)
         if motion_seq is not None:

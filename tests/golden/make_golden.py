@@ -985,6 +985,32 @@ def gen_trainer_kats(masters, out):
             out.update(flat("tr.%s.%s." % (tag, name), mod.state_dict()))
         meta.append("%s|%d" % (tag, int(detach)))
     out["trainer_cases"] = np.array(meta)
+    # Imitation learning, then RL with detach_state_predictor (configs/icra_benchmark/mp_detach.py; train.py runs optimize_epoch
+    # before the RL episodes): two optimize_epoch passes train the predictor's graph model (state-predictor update on every 5th
+    # batch, trainer.py:87-99), then three RL batches in which StatePredictor(..., detach=True) gives that graph model NO gradient --
+    # `.grad` is None after zero_grad(), Adam skips its parameters although their momentum is non-zero by now.  Separate arrays: the
+    # older cases stay bit-identical.
+    values = rng.uniform(0.0, 1.0, (n, 1)).astype(np.float32)
+    out["tr.values"] = values
+    torch.manual_seed(0)
+    pc, g1, g2, ve, sp = build_ref_modules(masters["trained"], 2, "embedded_gaussian", False, False)
+    memory = ReplayMemory(1000)
+    for i in range(n):
+        memory.push((torch.tensor(robot[i:i + 1]), torch.tensor(humans[i]), torch.tensor(values[i]), torch.tensor(rewards[i]),
+                     torch.tensor(robot2[i:i + 1]), torch.tensor(humans2[i])))
+    tr = MPRLTrainer(ve, sp, memory, torch.device("cpu"), None, Writer(), 16, "Adam", 5, False, False, True, False)
+    tr.set_learning_rate(1e-3)
+    tr.update_target_model(ve)
+    tr.data_loader = DataLoader(memory, 16, shuffle=False)
+    with torch.enable_grad():
+        tr.optimize_epoch(2)
+        for name, mod in (("graph_model2", sp.graph_model), ("motion_predictor", sp.human_motion_predictor)):
+            out.update(flat("tr.il_then_detach.after_il.%s." % name, mod.state_dict()))
+        v_loss, s_loss = tr.optimize_batch(2, 0)
+    out["tr.il_then_detach.losses"] = np.array([v_loss, s_loss], np.float64)
+    for name, mod in (("graph_model1", ve.graph_model), ("value_network", ve.value_network), ("graph_model2", sp.graph_model),
+                      ("motion_predictor", sp.human_motion_predictor)):
+        out.update(flat("tr.il_then_detach.%s." % name, mod.state_dict()))
     policy_config(gcn__skip_connection=True, gcn__similarity_function="embedded_gaussian")      # restore the class-level config attributes
 
 

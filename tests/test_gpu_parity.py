@@ -2974,3 +2974,42 @@ def test_captured_trainer_steps_are_repeatable(dev):
     worst = float((outs[0] - eager).abs().max())
     assert worst <= 1e-5, worst
     report("captured trainer steps (2 epochs + 2 batch calls) x 6: bit-identical parameters, %.1e from the eager trainer's" % worst)
+
+
+def test_product_trainer_imitation_then_detached_rl_against_the_reference_fixture(dev):
+    """Fixture training_queryenv.npz, case il_then_detach: the REFERENCE MPRLTrainer ran optimize_epoch(2) -- which trains the state
+    predictor's graph model -- and then optimize_batch with detach_state_predictor (configs/icra_benchmark/mp_detach.py).  Upstream the
+    detached graph model gets NO gradient in the RL phase and Adam skips it although its momentum is non-zero: its parameters stay
+    bit for bit where imitation learning left them.  (A zero gradient is not the same: Adam would keep moving them -- what this
+    package did until round 5.)  Same final parameters and losses through the public trainer's captured steps."""
+    fx = gio.load("training_queryenv")
+    c = dict(L=2, sim="embedded_gaussian", layerwise=False, skip=False, flavour="trained")
+    _, ve, sp = build_modules(c, dev)
+    items = [(torch.tensor(fx["tr.robot"][i]).unsqueeze(0).to(dev), torch.tensor(fx["tr.humans"][i]).to(dev),
+              torch.tensor(fx["tr.values"][i]).reshape(1).to(dev), torch.tensor(fx["tr.rewards"][i]).reshape(1).to(dev),
+              torch.tensor(fx["tr.next_robot"][i]).unsqueeze(0).to(dev), torch.tensor(fx["tr.next_humans"][i]).to(dev)) for i in range(48)]
+    t = rga.MPRLTrainer(ve, sp, _ListDataset(items), dev, None, _Writer(), 16, "Adam", 5, reduce_sp_update_frequency=False,
+                        freeze_state_predictor=False, detach_state_predictor=True, share_graph_model=False)
+    t.set_learning_rate(1e-3)
+    t.update_target_model(ve)
+    t.data_loader = torch.utils.data.DataLoader(t.memory, 16, shuffle=False)          # the fixture's order
+    t.optimize_epoch(2)
+    after_il = {k: v.detach().clone() for k, v in sp.graph_model.state_dict().items()}
+    for name, mod in (("graph_model2", sp.graph_model), ("motion_predictor", sp.human_motion_predictor)):
+        for k, v in mod.state_dict().items():
+            assert float(np.abs(v.cpu().numpy() - fx["tr.il_then_detach.after_il.%s.%s" % (name, k)]).max()) <= 2e-5, (name, k)
+    av, as_ = t.optimize_batch(2, 0)
+    assert t._capturable and len(t._steps) == 3                                    # il with / without the predictor update, rl
+    for k, v in sp.graph_model.state_dict().items():
+        assert torch.equal(v, after_il[k]), (k, float((v - after_il[k]).abs().max()))          # frozen, as upstream
+    want_v, want_s = fx["tr.il_then_detach.losses"]
+    assert abs(av - want_v) <= 1e-5 * max(1.0, abs(want_v)) and abs(as_ - want_s) <= 1e-5 * max(1.0, abs(want_s)), (av, as_)
+    worst = 0.0
+    for name, mod in (("graph_model1", ve.graph_model), ("value_network", ve.value_network), ("graph_model2", sp.graph_model),
+                      ("motion_predictor", sp.human_motion_predictor)):
+        for k, v in mod.state_dict().items():
+            err = float(np.abs(v.cpu().numpy() - fx["tr.il_then_detach.%s.%s" % (name, k)]).max())
+            worst = max(worst, err)
+            assert err <= 2e-5, (name, k, err)
+    report("product MPRLTrainer, optimize_epoch(2) then detached optimize_batch: the predictor's graph model stays where imitation "
+           "learning left it (bit for bit); final parameters within %.1e of the reference trainer's, losses %.6f / %.6f" % (worst, av, as_))
