@@ -37,7 +37,8 @@ bash tools/timeline.sh $O/${TAG}_timeline.md --humans 49 --layers 3 --roots 256 
 bash tools/deep_pmc.sh 512 > /dev/null 2>&1
 cat $O/deep_pmc.md >> $O/${TAG}_c5_kernel_stats.md
 # 4. training: the public trainer, the raw step, the backward by batch
-python tools/trainer_time.py 2>/dev/null | grep "^{" > $O/${TAG}_trainer_api.jsonl
+bash tools/trainer_nodes.sh $TAG > /dev/null 2>&1          # ${TAG}_trainer_api.jsonl (+ _foreach_adam), ${TAG}_trainer_step_nodes.md
+python tools/micro/captured_step_repeatability.py 10 > $O/${TAG}_captured_step_repeatability.txt 2>&1
 python tools/train_step_time.py 2>/dev/null | grep "^{" > $O/${TAG}_train_step.jsonl
 python tools/train_step_time.py --graph 2>/dev/null | grep "^{" > $O/${TAG}_train_step_graph.jsonl
 # 5. path G (with its roofline line), closed-loop episodes, PCIe-inclusive step, single-decision latency rides in other_configs.sh
