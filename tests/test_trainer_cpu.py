@@ -165,3 +165,34 @@ def test_fused_adam_steps_are_announced_to_the_descriptor_caches():
     assert [a - b for a, b in zip(after, before)] == [1, 1, 1, 0]
     with pytest.raises(NotImplementedError):
         tr._new_optimizer("RMSprop", net, 1e-3, capturable=False)
+
+
+def test_loss_backward_torch_path_is_upstreams_three_lines():
+    """_loss_backward away from the device (or with another criterion) is upstream's `loss = criterion(outputs, target);
+    loss.backward(); losses += loss.item()` (crowd_nav/utils/trainer.py:130-137), with the value update's target formed as
+    `rewards + gamma_bar * next values` (:128-129) when it is handed over in pieces."""
+    class Host(tr._TrainerBase):
+        def __init__(self, criterion):
+            self.criterion = criterion
+            self.device = torch.device("cpu")
+            self._init_graphs()
+    g = torch.Generator().manual_seed(2)
+    net = torch.nn.Linear(4, 1)
+    x, tgt = torch.randn(16, 4, generator=g), torch.randn(16, 1, generator=g)
+    rew, nxt, gamma_bar = torch.rand(16, 1, generator=g), torch.randn(16, 1, generator=g), pow(0.9, 0.25)
+    for crit in (torch.nn.MSELoss(), torch.nn.SmoothL1Loss()):
+        for pieces in (False, True):
+            want_t = rew + gamma_bar * nxt if pieces else tgt
+            net.zero_grad()
+            loss = crit(net(x), want_t)
+            loss.backward()
+            want_g = [p.grad.clone() for p in net.parameters()]
+            h = Host(crit)
+            h._loss_begin()
+            net.zero_grad()
+            h._loss_backward(1, net(x), None if pieces else tgt, (rew, nxt, gamma_bar) if pieces else None)
+            h._loss_backward(1, net(x), None if pieces else tgt, (rew, nxt, gamma_bar) if pieces else None)     # accumulates
+            for p, w in zip(net.parameters(), want_g):
+                assert torch.equal(p.grad, 2 * w)
+            v, s = h._loss_read()
+            assert v == 0.0 and s == 2 * float(loss.detach())
