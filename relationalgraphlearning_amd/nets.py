@@ -292,6 +292,8 @@ def invalidate_packed_weights(*modules):
     i.e. after replaying a hipGraph that contains an optimizer step (a captured training step, tools/train_step_time.py --graph):
     replays mutate the parameters in place but do not bump `tensor._version`, which is what the caches key on."""
     for top in modules:
+        if not isinstance(top, nn.Module):                   # LinearStatePredictor is a plain object (state_predictor.py:63), no weights
+            continue
         for m in top.modules():
             m.__dict__.pop("_rgl_submodules", None)          # and the kept sub-module lists (_flat_params)
             for name in ("_cache", "_head_cache"):

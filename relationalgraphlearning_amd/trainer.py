@@ -232,7 +232,7 @@ class _TrainerBase(object):
                 return
             self._steps[key] = _CapturedStep(fn, batch, signature)            # its warm-up run WAS this batch's step
             for m in modules:
-                if all(m is not x for x in self._stale):
+                if isinstance(m, nn.Module) and all(m is not x for x in self._stale):
                     self._stale.append(m)
             return
         st.run(batch)

@@ -3013,3 +3013,53 @@ def test_product_trainer_imitation_then_detached_rl_against_the_reference_fixtur
             assert err <= 2e-5, (name, k, err)
     report("product MPRLTrainer, optimize_epoch(2) then detached optimize_batch: the predictor's graph model stays where imitation "
            "learning left it (bit for bit); final parameters within %.1e of the reference trainer's, losses %.6f / %.6f" % (worst, av, as_))
+
+
+@pytest.mark.parametrize("variant,detach", [("shared", False), ("shared", True), ("linear", False)])
+def test_trainer_on_the_other_wirings_captured_vs_eager(variant, detach, dev):
+    """model_predictive_rl.share_graph_model (one RGL under the value estimator AND the state predictor: both optimizers step its
+    parameters, model_predictive_rl.py:84-90) and linear_state_predictor (nothing to train on the predictor side: trainer.py:47,
+    `state_predictor.trainable`) through the public trainer: imitation epochs + RL batches from captured steps, three times over --
+    bit-identical repetitions, float32 noise away from the eager trainer."""
+    n, H = 300, 5
+    robot, humans = seeded_scenes(31, n, H)
+    robot2, humans2 = seeded_scenes(32, n, H)
+    rew = torch.rand(n, generator=torch.Generator().manual_seed(6))
+
+    def run(capture):
+        pol = make_mprl_policy("trained", 1, variant=variant, device=dev, skip=False)
+        if variant == "shared":
+            assert pol.value_estimator.graph_model is pol.state_predictor.graph_model
+        mem = rga.ReplayMemory(n)
+        for i in range(n):
+            mem.push((robot[i:i + 1].to(dev), humans[i].to(dev), rew[i:i + 1].to(dev) * 0.5, rew[i:i + 1].to(dev), robot2[i:i + 1].to(dev),
+                      humans2[i].to(dev)))
+        cls = rga.MPRLTrainer if capture else type("EagerTrainer", (rga.MPRLTrainer,), {"capture": False})
+        t = cls(pol.value_estimator, pol.state_predictor, mem, dev, pol, _Writer(), 100, "Adam", H, reduce_sp_update_frequency=False,
+                freeze_state_predictor=False, detach_state_predictor=detach, share_graph_model=(variant == "shared"))
+        t.set_learning_rate(1e-3)
+        assert (t.s_optimizer is None) == (variant == "linear")
+        t.update_target_model(pol.value_estimator)
+        torch.manual_seed(3)
+        t.optimize_epoch(2)
+        torch.manual_seed(4)
+        losses = t.optimize_batch(2, 0)
+        mods = [pol.value_estimator] + ([pol.state_predictor] if variant != "linear" else [])
+        seen, flat = set(), []
+        for m in mods:
+            for p in m.parameters():
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    flat.append(p.detach().flatten())
+        return torch.cat(flat).cpu(), losses
+    eager, eager_losses = run(False)
+    outs = [run(True) for _ in range(3)]
+    assert bool(torch.isfinite(outs[0][0]).all())
+    for o, l in outs[1:]:
+        assert torch.equal(o, outs[0][0]) and l == outs[0][1]
+    worst = float((outs[0][0] - eager).abs().max())
+    assert worst <= 1e-5, worst
+    for a, b in zip(outs[0][1], eager_losses):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (a, b)
+    report("MPRLTrainer on the %s wiring (detach %s): captured steps x 3 bit-identical, %.1e from the eager trainer's parameters"
+           % (variant, detach, worst))
