@@ -3063,3 +3063,40 @@ def test_trainer_on_the_other_wirings_captured_vs_eager(variant, detach, dev):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (a, b)
     report("MPRLTrainer on the %s wiring (detach %s): captured steps x 3 bit-identical, %.1e from the eager trainer's parameters"
            % (variant, detach, worst))
+
+
+@pytest.mark.parametrize("tag", ["sgd", "reduce", "freeze"])
+def test_product_trainer_switches_against_the_reference_fixture(tag, dev):
+    """Fixture training_queryenv.npz, cases sgd / reduce / freeze: the REFERENCE MPRLTrainer.optimize_batch with optimizer 'SGD'
+    (momentum 0.9 on the value side, none on the predictor's: trainer.py:49-52; lr 1e-2), with reduce_sp_update_frequency (no
+    predictor update on batch 0 of every five, :138-139) and with freeze_state_predictor (:136-137), three un-shuffled batches of 16.
+    The product trainer -- eager steps for SGD, captured ones (two kinds under `reduce`) for Adam -- ends at the same parameters and
+    reports the same losses."""
+    fx = gio.load("training_queryenv")
+    c = dict(L=2, sim="embedded_gaussian", layerwise=False, skip=False, flavour="trained")
+    _, ve, sp = build_modules(c, dev)
+    items = [(torch.tensor(fx["tr.robot"][i]).unsqueeze(0).to(dev), torch.tensor(fx["tr.humans"][i]).to(dev),
+              torch.zeros(1, device=dev), torch.tensor(fx["tr.rewards"][i]).reshape(1).to(dev),
+              torch.tensor(fx["tr.next_robot"][i]).unsqueeze(0).to(dev), torch.tensor(fx["tr.next_humans"][i]).to(dev)) for i in range(48)]
+    t = rga.MPRLTrainer(ve, sp, _ListDataset(items), dev, None, _Writer(), 16, "SGD" if tag == "sgd" else "Adam", 5,
+                        reduce_sp_update_frequency=(tag == "reduce"), freeze_state_predictor=(tag == "freeze"),
+                        detach_state_predictor=False, share_graph_model=False)
+    t.set_learning_rate(1e-2 if tag == "sgd" else 1e-3)
+    t.update_target_model(ve)
+    t.data_loader = torch.utils.data.DataLoader(t.memory, 16, shuffle=False)          # the fixture's order
+    before = {k: v.detach().clone() for k, v in sp.state_dict().items()}
+    av, as_ = t.optimize_batch(2, 0)
+    assert len(t._steps) == {"sgd": 0, "reduce": 2, "freeze": 1}[tag]
+    if tag == "freeze":
+        assert as_ == 0.0 and all(torch.equal(v, before[k]) for k, v in sp.state_dict().items())
+    want_v, want_s = fx["tr.%s.losses" % tag]
+    assert abs(av - want_v) <= 1e-5 * max(1.0, abs(want_v)) and abs(as_ - want_s) <= 1e-5 * max(1.0, abs(want_s)), (av, as_)
+    worst = 0.0
+    for name, mod in (("graph_model1", ve.graph_model), ("value_network", ve.value_network), ("graph_model2", sp.graph_model),
+                      ("motion_predictor", sp.human_motion_predictor)):
+        for k, v in mod.state_dict().items():
+            err = float(np.abs(v.cpu().numpy() - fx["tr.%s.%s.%s" % (tag, name, k)]).max())
+            worst = max(worst, err)
+            assert err <= 2e-5, (name, k, err)
+    report("product MPRLTrainer.optimize_batch (%s): final parameters within %.1e of the reference trainer's, losses %.6f / %.6f"
+           % (tag, worst, av, as_))
