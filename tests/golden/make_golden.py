@@ -1071,6 +1071,27 @@ def gen_vnrl_trainer_kats(pg_fixture, out):
         out.update(flat("vn.%s.model." % tag, pol.model.state_dict()))
         meta.append("%s|%d|%d|%d" % (tag, L, int(lw), int(sk)))
     out["vnrl_cases"] = np.array(meta)
+    # imitation learning then RL through the reference's VNRLTrainer (trainer.py:199-250; train.py's order): optimize_epoch(2) on
+    # seeded values, then optimize_batch(2), shipped configuration.  New arrays only.
+    values = rng.uniform(0.0, 1.0, (n,)).astype(np.float32)
+    out["vn.values"] = values
+    pc = policy_config("rgl", gcn__num_layer=2, gcn__layerwise_graph=False, gcn__skip_connection=True)
+    pol = policy_factory["gcn"]()
+    pol.configure(pc)
+    pol.model.load_state_dict({k[len("g.weights."):]: torch.tensor(v) for k, v in pg_fixture.items() if k.startswith("g.weights.")})
+    memory = ReplayMemory(1000)
+    for i in range(n):
+        memory.push((torch.tensor(states[i]), torch.tensor(values[i:i + 1]), torch.tensor(rewards[i:i + 1]), torch.tensor(next_states[i])))
+    tr = VNRLTrainer(pol.model, memory, torch.device("cpu"), pol, 16, "Adam", Writer())
+    tr.set_learning_rate(1e-3)
+    tr.update_target_model(pol.model)
+    tr.data_loader = DataLoader(memory, 16, shuffle=False, collate_fn=pad_batch)
+    with torch.enable_grad():
+        il = tr.optimize_epoch(2)
+        out.update(flat("vn.il_then_rl.after_il.model.", pol.model.state_dict()))
+        rl = tr.optimize_batch(2, 0)
+    out["vn.il_then_rl.losses"] = np.array([il, rl], np.float64)
+    out.update(flat("vn.il_then_rl.model.", pol.model.state_dict()))
     policy_config("rgl", gcn__num_layer=2, gcn__layerwise_graph=False, gcn__skip_connection=True)
 
 

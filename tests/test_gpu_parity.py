@@ -3100,3 +3100,38 @@ def test_product_trainer_switches_against_the_reference_fixture(tag, dev):
             assert err <= 2e-5, (name, k, err)
     report("product MPRLTrainer.optimize_batch (%s): final parameters within %.1e of the reference trainer's, losses %.6f / %.6f"
            % (tag, worst, av, as_))
+
+
+def test_product_vnrl_trainer_imitation_then_rl_against_the_reference_fixture(dev):
+    """Fixture vnrl_trainer.npz, case il_then_rl: the REFERENCE VNRLTrainer ran optimize_epoch(2) and then optimize_batch(2)
+    (trainer.py:199-250, train.py's order) on path G's shipped network.  The product trainer's captured steps (one for the imitation
+    batches, one for the RL batches) end at the same parameters after each phase and report the same two losses; twice over, bit for
+    bit."""
+    fx = gio.load("vnrl_trainer")
+    from relationalgraphlearning_amd.trainer import pad_batch
+
+    def run():
+        pol = make_gcn_policy(2, False, True, device=dev)
+        items = [(torch.tensor(fx["vn.states"][i]).to(dev), torch.tensor(fx["vn.values"][i]).reshape(1).to(dev),
+                  torch.tensor(fx["vn.rewards"][i]).reshape(1).to(dev), torch.tensor(fx["vn.next_states"][i]).to(dev)) for i in range(48)]
+        t = rga.VNRLTrainer(pol.model, _ListDataset(items), dev, pol, 16, "Adam", _Writer())
+        t.set_learning_rate(1e-3)
+        t.update_target_model(pol.model)
+        t.data_loader = torch.utils.data.DataLoader(t.memory, 16, shuffle=False, collate_fn=pad_batch)
+        il = t.optimize_epoch(2)
+        after_il = {k: v.detach().cpu().numpy().copy() for k, v in pol.model.state_dict().items()}
+        rl = t.optimize_batch(2, 0)
+        assert t._capturable and len(t._steps) == 2
+        return il, rl, after_il, {k: v.detach().cpu().numpy().copy() for k, v in pol.model.state_dict().items()}
+    il, rl, after_il, final = run()
+    want_il, want_rl = fx["vn.il_then_rl.losses"]
+    assert abs(il - want_il) <= 1e-5 * max(1.0, abs(want_il)) and abs(rl - want_rl) <= 1e-5 * max(1.0, abs(want_rl)), (il, rl)
+    worst = 0.0
+    for k in final:
+        worst = max(worst, float(np.abs(after_il[k] - fx["vn.il_then_rl.after_il.model.%s" % k]).max()),
+                    float(np.abs(final[k] - fx["vn.il_then_rl.model.%s" % k]).max()))
+    assert worst <= 2e-5, worst
+    il2, rl2, _, final2 = run()
+    assert (il2, rl2) == (il, rl) and all(np.array_equal(final[k], final2[k]) for k in final)
+    report("product VNRLTrainer, optimize_epoch(2) then optimize_batch(2): parameters within %.1e of the reference trainer's after "
+           "each phase, losses %.6f / %.6f; a second run bit-identical" % (worst, il, rl))
