@@ -1011,6 +1011,28 @@ def gen_trainer_kats(masters, out):
     for name, mod in (("graph_model1", ve.graph_model), ("value_network", ve.value_network), ("graph_model2", sp.graph_model),
                       ("motion_predictor", sp.human_motion_predictor)):
         out.update(flat("tr.il_then_detach.%s." % name, mod.state_dict()))
+    # train.py's own order (crowd_nav/train.py:134-176): imitation learning at il_learning_rate, NEW optimizers at rl_learning_rate,
+    # the target model refreshed, RL batches, the target refreshed again, more RL batches.
+    torch.manual_seed(0)
+    pc, g1, g2, ve, sp = build_ref_modules(masters["trained"], 2, "embedded_gaussian", False, False)
+    memory = ReplayMemory(1000)
+    for i in range(n):
+        memory.push((torch.tensor(robot[i:i + 1]), torch.tensor(humans[i]), torch.tensor(values[i]), torch.tensor(rewards[i]),
+                     torch.tensor(robot2[i:i + 1]), torch.tensor(humans2[i])))
+    tr = MPRLTrainer(ve, sp, memory, torch.device("cpu"), None, Writer(), 16, "Adam", 5, False, False, False, False)
+    tr.data_loader = DataLoader(memory, 16, shuffle=False)
+    with torch.enable_grad():
+        tr.set_learning_rate(1e-2)
+        tr.optimize_epoch(1)
+        tr.set_learning_rate(1e-3)
+        tr.update_target_model(ve)
+        first = tr.optimize_batch(2, 0)
+        tr.update_target_model(ve)
+        second = tr.optimize_batch(2, 1)
+    out["tr.train_py_order.losses"] = np.array([first[0], first[1], second[0], second[1]], np.float64)
+    for name, mod in (("graph_model1", ve.graph_model), ("value_network", ve.value_network), ("graph_model2", sp.graph_model),
+                      ("motion_predictor", sp.human_motion_predictor)):
+        out.update(flat("tr.train_py_order.%s." % name, mod.state_dict()))
     # The trainer's other switches through the reference itself (trainer.py:43-61,134-141): SGD (momentum 0.9 on the value side, plain
     # on the predictor side), reduce_sp_update_frequency (NO predictor update on batches 0, 5, 10 ..), freeze_state_predictor.
     for tag, opt, reduce, freeze in (("sgd", "SGD", False, False), ("reduce", "Adam", True, False), ("freeze", "Adam", False, True)):

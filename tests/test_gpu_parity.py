@@ -3135,3 +3135,41 @@ def test_product_vnrl_trainer_imitation_then_rl_against_the_reference_fixture(de
     assert (il2, rl2) == (il, rl) and all(np.array_equal(final[k], final2[k]) for k in final)
     report("product VNRLTrainer, optimize_epoch(2) then optimize_batch(2): parameters within %.1e of the reference trainer's after "
            "each phase, losses %.6f / %.6f; a second run bit-identical" % (worst, il, rl))
+
+
+def test_product_trainer_in_train_py_order_against_the_reference_fixture(dev):
+    """Fixture training_queryenv.npz, case train_py_order -- what crowd_nav/train.py:134-176 does to a trainer: imitation learning at
+    the IL rate, NEW optimizers at the RL rate (the captured steps of the first phase are dropped with the old ones), the target model
+    refreshed, RL batches, the target refreshed IN PLACE under the captured RL step, more RL batches.  Same four losses and the same
+    final parameters as the reference trainer."""
+    fx = gio.load("training_queryenv")
+    c = dict(L=2, sim="embedded_gaussian", layerwise=False, skip=False, flavour="trained")
+    _, ve, sp = build_modules(c, dev)
+    items = [(torch.tensor(fx["tr.robot"][i]).unsqueeze(0).to(dev), torch.tensor(fx["tr.humans"][i]).to(dev),
+              torch.tensor(fx["tr.values"][i]).reshape(1).to(dev), torch.tensor(fx["tr.rewards"][i]).reshape(1).to(dev),
+              torch.tensor(fx["tr.next_robot"][i]).unsqueeze(0).to(dev), torch.tensor(fx["tr.next_humans"][i]).to(dev)) for i in range(48)]
+    t = rga.MPRLTrainer(ve, sp, _ListDataset(items), dev, None, _Writer(), 16, "Adam", 5, reduce_sp_update_frequency=False,
+                        freeze_state_predictor=False, detach_state_predictor=False, share_graph_model=False)
+    t.data_loader = torch.utils.data.DataLoader(t.memory, 16, shuffle=False)
+    t.set_learning_rate(1e-2)
+    t.optimize_epoch(1)
+    assert len(t._steps) == 2
+    t.set_learning_rate(1e-3)
+    assert len(t._steps) == 0                                                        # the optimizers are new
+    t.update_target_model(ve)
+    first = t.optimize_batch(2, 0)
+    t.update_target_model(ve)
+    assert len(t._steps) == 1                                                        # ... and stays: the target is refreshed in place
+    second = t.optimize_batch(2, 1)
+    got = np.array(list(first) + list(second))
+    want = fx["tr.train_py_order.losses"]
+    assert np.all(np.abs(got - want) <= 1e-5 * np.maximum(1.0, np.abs(want))), (got, want)
+    worst = 0.0
+    for name, mod in (("graph_model1", ve.graph_model), ("value_network", ve.value_network), ("graph_model2", sp.graph_model),
+                      ("motion_predictor", sp.human_motion_predictor)):
+        for k, v in mod.state_dict().items():
+            err = float(np.abs(v.cpu().numpy() - fx["tr.train_py_order.%s.%s" % (name, k)]).max())
+            worst = max(worst, err)
+            assert err <= 5e-5, (name, k, err)
+    report("product MPRLTrainer in train.py's order (IL at 1e-2, new optimizers at 1e-3, target refreshed twice): final parameters "
+           "within %.1e of the reference trainer's, losses %s" % (worst, np.round(got, 6).tolist()))
