@@ -6,17 +6,19 @@ update, two optimizers) and `VNRLTrainer` (:164-250, path G) -- same constructor
 batch bookkeeping (including upstream's `batch_count > num_batches` off-by-one and its division by `num_batches`).
 `register_trainers(module)` puts them into the namespace crowd_nav/train.py imports its trainers from.
 
-What is different is how a step runs.  Upstream's step is ~60 launches of launch-sized work driven from Python (1.0-1.6 ms at batch
-100 on this box, host-bound); here the whole step -- both forwards, both backwards (rgl_graph_backward_f32), the Adam updates, the
-repacking of the k-major weight copies, the loss accumulation -- is captured once per batch shape into a hipGraph and replayed
-(0.36-0.37 ms): the library allocates only through torch, never synchronises and repacks on the capture stream, which is what makes
-the capture legal.  Per batch the host copies the batch into the graph's static input buffers and launches
-the graph; losses accumulate on the device (float64, the sum upstream forms from `loss.data.item()`), read once per call.
+What is different is how a step runs.  Upstream's step is ~60 launches of launch-sized work driven from Python (1.4-1.9 ms at batch
+100 on this box, host-bound); here the whole step -- the batch gather, both forwards, the loss with its gradient and running sum
+(rgl_mse_step_f32), both backwards (rgl_graph_backward_f32), the fused Adam updates, the repacking of the k-major weight copies -- is
+captured once per batch shape into a hipGraph of 26 kernel nodes and replayed (0.21-0.23 ms): the library allocates only through
+torch, never synchronises, repacks on the capture stream and records KERNELS only (a replayed hipMemsetAsync node was not reliably
+ordered against its neighbours on ROCm 7.2: DESIGN.md section 4.3), which is what makes the capture legal and its replays
+repeatable bit for bit.  Per batch the host copies the batch's indices (or the batch) into the graph's static input buffers and
+launches the graph; losses accumulate on the device (float64, the sum upstream forms from `loss.data.item()`), read once per call.
 
 Batches: upstream draws them with `DataLoader(memory, batch_size, shuffle=True)`.  A `memory` that offers `as_tensors()` (this
 package's ReplayMemory: the experience as stacked device tensors) is sampled by index instead -- the SAME indices in the same
 order, drawn from torch's global generator exactly as the DataLoader's RandomSampler would (`_ShuffledIndexBatches`, checked
-against the real DataLoader on CPU) -- and gathered with one index_select per field; any other dataset, and a `data_loader` set
+against the real DataLoader on CPU) -- and gathered in one launch (rgl_gather_rows_f32); any other dataset, and a `data_loader` set
 by the caller, goes through the DataLoader itself.  SGD and shapes that change from batch to batch run the same step eagerly.
 """
 import copy
