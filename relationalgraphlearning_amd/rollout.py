@@ -35,6 +35,8 @@ class _Workspace:
     def get(self, nbytes, device):
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
             self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        if nat.poison_workspaces() and not torch.cuda.is_current_stream_capturing():
+            self.buf.fill_(255)                  # tests: NaN bit patterns wherever a kernel reads what no kernel of THIS search wrote
         return self.buf
 
 
