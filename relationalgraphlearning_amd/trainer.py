@@ -201,6 +201,23 @@ class _TrainerBase(object):
 
     capture = True                # class-level switch: False = every step eager (measurements, debugging)
 
+    # what both upstream constructors set besides their own arguments (trainer.py:18-36,172-186): no target copy and no loader yet,
+    # the MSE criterion on the device, and the constants of the value update target  r + gamma^(time_step * v_pref) V'
+    _VALUE_UPDATE = (("gamma", 0.9), ("time_step", 0.25), ("v_pref", 1))
+
+    def _adopt(self, device, memory, batch_size, optimizer_str, writer, **own):
+        shared = dict(device=device, memory=memory, batch_size=batch_size, optimizer_str=optimizer_str, writer=writer,
+                      target_model=None, data_loader=None, criterion=nn.MSELoss().to(device))
+        for name, value in list(shared.items()) + list(own.items()) + list(self._VALUE_UPDATE):
+            setattr(self, name, value)
+        self._capturable = False
+        self._init_graphs()
+
+    @staticmethod
+    def _require_learning_rate(optimizer):
+        if optimizer is None:
+            raise ValueError('Learning rate is not set!')
+
     def _init_graphs(self):
         self._steps = {}          # (kind, shapes...) -> _CapturedStep
         self._loss = None         # device float64 [2]: accumulated value / predictor loss of the current call
@@ -299,31 +316,13 @@ class _TrainerBase(object):
 class MPRLTrainer(_TrainerBase):
     def __init__(self, value_estimator, state_predictor, memory, device, policy, writer, batch_size, optimizer_str, human_num,
                  reduce_sp_update_frequency, freeze_state_predictor, detach_state_predictor, share_graph_model):
-        """Train the trainable models of a ModelPredictiveRL policy (crowd_nav/utils/trainer.py:10-36, same arguments)."""
-        self.value_estimator = value_estimator
-        self.state_predictor = state_predictor
-        self.device = device
-        self.writer = writer
-        self.target_policy = policy
-        self.target_model = None
-        self.criterion = nn.MSELoss().to(device)
-        self.memory = memory
-        self.data_loader = None
-        self.batch_size = batch_size
-        self.optimizer_str = optimizer_str
-        self.reduce_sp_update_frequency = reduce_sp_update_frequency
-        self.state_predictor_update_interval = human_num
-        self.freeze_state_predictor = freeze_state_predictor
-        self.detach_state_predictor = detach_state_predictor
-        self.share_graph_model = share_graph_model
-        self.v_optimizer = None
-        self.s_optimizer = None
-        # for value update
-        self.gamma = 0.9
-        self.time_step = 0.25
-        self.v_pref = 1
-        self._capturable = False
-        self._init_graphs()
+        """Train the trainable models of a ModelPredictiveRL policy (crowd_nav/utils/trainer.py:10-36, same arguments; the attribute
+        names are part of the contract -- train.py and user code read them)."""
+        self._adopt(device, memory, batch_size, optimizer_str, writer,
+                    value_estimator=value_estimator, state_predictor=state_predictor, target_policy=policy,
+                    reduce_sp_update_frequency=reduce_sp_update_frequency, state_predictor_update_interval=human_num,
+                    freeze_state_predictor=freeze_state_predictor, detach_state_predictor=detach_state_predictor,
+                    share_graph_model=share_graph_model, v_optimizer=None, s_optimizer=None)
 
     # -- the reference's set-up calls ------------------------------------------------------------------------------------------
     def update_target_model(self, target_model):
@@ -420,8 +419,7 @@ class MPRLTrainer(_TrainerBase):
         self.s_optimizer.step()
 
     def optimize_epoch(self, num_epochs):
-        if self.v_optimizer is None:
-            raise ValueError('Learning rate is not set!')
+        self._require_learning_rate(self.v_optimizer)
         modules = [self.value_estimator, self.state_predictor]
 
         def il_step(update_sp):
@@ -452,8 +450,7 @@ class MPRLTrainer(_TrainerBase):
         return
 
     def optimize_batch(self, num_batches, episode):
-        if self.v_optimizer is None:
-            raise ValueError('Learning rate is not set!')
+        self._require_learning_rate(self.v_optimizer)
         gamma_bar = pow(self.gamma, self.time_step * self.v_pref)
         modules = [self.value_estimator, self.state_predictor]
 
@@ -514,24 +511,8 @@ def pad_batch(batch):
 
 class VNRLTrainer(_TrainerBase):
     def __init__(self, model, memory, device, policy, batch_size, optimizer_str, writer):
-        """Train the value network of a path-G policy (crowd_nav/utils/trainer.py:164-186, same arguments)."""
-        self.model = model
-        self.device = device
-        self.policy = policy
-        self.target_model = None
-        self.criterion = nn.MSELoss().to(device)
-        self.memory = memory
-        self.data_loader = None
-        self.batch_size = batch_size
-        self.optimizer_str = optimizer_str
-        self.optimizer = None
-        self.writer = writer
-        # for value update
-        self.gamma = 0.9
-        self.time_step = 0.25
-        self.v_pref = 1
-        self._capturable = False
-        self._init_graphs()
+        """Train the value network of a path-G policy (crowd_nav/utils/trainer.py:164-186, same arguments and attribute names)."""
+        self._adopt(device, memory, batch_size, optimizer_str, writer, model=model, policy=policy, optimizer=None)
 
     update_target_model = MPRLTrainer.update_target_model
     _same_structure = staticmethod(MPRLTrainer._same_structure)
@@ -567,8 +548,7 @@ class VNRLTrainer(_TrainerBase):
         return bool((torch.as_tensor(lengths) == width).all())
 
     def optimize_epoch(self, num_epochs):
-        if self.optimizer is None:
-            raise ValueError('Learning rate is not set!')
+        self._require_learning_rate(self.optimizer)
         average_epoch_loss = 0
         for epoch in range(num_epochs):
             self._loss_begin()
@@ -593,8 +573,7 @@ class VNRLTrainer(_TrainerBase):
         return average_epoch_loss
 
     def optimize_batch(self, num_batches, episode=None):
-        if self.optimizer is None:
-            raise ValueError('Learning rate is not set!')
+        self._require_learning_rate(self.optimizer)
         gamma_bar = pow(self.gamma, self.time_step * self.v_pref)
         self._loss_begin()
         batch_count = 0

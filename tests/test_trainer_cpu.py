@@ -196,3 +196,26 @@ def test_loss_backward_torch_path_is_upstreams_three_lines():
                 assert torch.equal(p.grad, 2 * w)
             v, s = h._loss_read()
             assert v == 0.0 and s == 2 * float(loss.detach())
+
+
+def test_vnrl_trainer_contract_on_cpu():
+    """Constructor arguments, attributes and errors of path G's trainer (crowd_nav/utils/trainer.py:164-197)."""
+    pol = make_gcn_policy(2)
+    mem = rga.ReplayMemory(100)
+    t = rga.VNRLTrainer(pol.model, mem, torch.device("cpu"), pol, 100, "Adam", None)
+    for name in ("model", "device", "policy", "target_model", "criterion", "memory", "data_loader", "batch_size", "optimizer_str",
+                 "optimizer", "writer", "gamma", "time_step", "v_pref"):
+        assert hasattr(t, name), name
+    assert t.model is pol.model and t.policy is pol and t.memory is mem and t.batch_size == 100 and t.optimizer is None
+    assert isinstance(t.criterion, torch.nn.MSELoss) and t.target_model is None and t.data_loader is None
+    assert (t.gamma, t.time_step, t.v_pref) == (0.9, 0.25, 1)
+    for call in (lambda: t.optimize_batch(1), lambda: t.optimize_epoch(1)):
+        with pytest.raises(ValueError, match="Learning rate is not set"):
+            call()
+    t.set_learning_rate(1e-3)
+    assert isinstance(t.optimizer, torch.optim.Adam) and not t._capturable and t._steps == {}
+    t.optimizer_str = "SGD"
+    t.set_learning_rate(1e-2)
+    assert isinstance(t.optimizer, torch.optim.SGD) and t.optimizer.defaults["momentum"] == 0.9
+    t.update_target_model(pol.model)
+    assert t.target_model is not pol.model
