@@ -1117,6 +1117,75 @@ def gen_vnrl_trainer_kats(pg_fixture, out):
     policy_config("rgl", gcn__num_layer=2, gcn__layerwise_graph=False, gcn__skip_connection=True)
 
 
+def gen_trainer_host_kats(out):
+    """The reference trainers (crowd_nav/utils/trainer.py) driving tests/trainer_standins.py's small CPU modules: what the product
+    trainers' host logic -- batching (un-shuffled AND shuffled: the loader's draws from torch's global generator), step order,
+    optimizers, target model, loss bookkeeping -- is held against in the CPU suite.  Three flows, final parameters and losses."""
+    from crowd_nav.utils.trainer import MPRLTrainer, VNRLTrainer, pad_batch
+    from crowd_nav.utils.memory import ReplayMemory
+    from torch.utils.data import DataLoader
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE_SRC)))
+    from tests.trainer_standins import StandInValue, StandInPredictor, StandInPathG, seeded, flat_params
+
+    class Writer(object):
+        def add_scalar(self, *a, **k):
+            pass
+    rng = np.random.RandomState(77)
+    n, H = 70, 4                                                    # 70 = 4 batches of 16 + one of 6: a short last batch
+    robot = rng.uniform(-2, 2, (n, 1, 9)).astype(np.float32)
+    humans = rng.uniform(-2, 2, (n, H, 5)).astype(np.float32)
+    robot2 = rng.uniform(-2, 2, (n, 1, 9)).astype(np.float32)
+    humans2 = rng.uniform(-2, 2, (n, H, 5)).astype(np.float32)
+    values = rng.uniform(0, 1, (n, 1)).astype(np.float32)
+    rewards = rng.uniform(-0.25, 1, (n, 1)).astype(np.float32)
+    states = rng.uniform(-2, 2, (n, H, 13)).astype(np.float32)
+    next_states = rng.uniform(-2, 2, (n, H, 13)).astype(np.float32)
+    for k, v in (("robot", robot), ("humans", humans), ("next_robot", robot2), ("next_humans", humans2), ("values", values),
+                 ("rewards", rewards), ("states", states), ("next_states", next_states)):
+        out["th." + k] = v
+
+    def mprl_memory():
+        memory = ReplayMemory(1000)
+        for i in range(n):
+            memory.push((torch.tensor(robot[i]), torch.tensor(humans[i]), torch.tensor(values[i]), torch.tensor(rewards[i]),
+                         torch.tensor(robot2[i]), torch.tensor(humans2[i])))
+        return memory
+    for tag, shuffle, detach, reduce, opt in (("ordered", False, True, False, "Adam"), ("shuffled", True, False, True, "Adam"),
+                                              ("shuffled_sgd", True, False, False, "SGD")):
+        ve, sp = seeded(StandInValue, 11), seeded(StandInPredictor, 12)
+        tr = MPRLTrainer(ve, sp, mprl_memory(), torch.device("cpu"), None, Writer(), 16, opt, 3, reduce, False, detach, False)
+        if not shuffle:
+            tr.data_loader = DataLoader(tr.memory, 16, shuffle=False)
+        torch.manual_seed(5)                                        # the shuffled loaders draw from here on
+        with torch.enable_grad():
+            tr.set_learning_rate(1e-2)
+            tr.optimize_epoch(2)
+            tr.set_learning_rate(1e-3)
+            tr.update_target_model(ve)
+            first = tr.optimize_batch(2, 0)
+            tr.update_target_model(ve)
+            second = tr.optimize_batch(3, 1)
+        out["th.mprl.%s.losses" % tag] = np.array(list(first) + list(second), np.float64)
+        out["th.mprl.%s.params" % tag] = flat_params(ve, sp)
+    for tag, shuffle in (("ordered", False), ("shuffled", True)):
+        model = seeded(StandInPathG, 13)
+        memory = ReplayMemory(1000)
+        for i in range(n):
+            memory.push((torch.tensor(states[i]), torch.tensor(values[i]), torch.tensor(rewards[i]), torch.tensor(next_states[i])))
+        tr = VNRLTrainer(model, memory, torch.device("cpu"), None, 16, "Adam", Writer())
+        if not shuffle:
+            tr.data_loader = DataLoader(memory, 16, shuffle=False, collate_fn=pad_batch)
+        torch.manual_seed(6)
+        with torch.enable_grad():
+            tr.set_learning_rate(1e-2)
+            il = tr.optimize_epoch(2)
+            tr.set_learning_rate(1e-3)
+            tr.update_target_model(model)
+            rl = tr.optimize_batch(3, 0)
+        out["th.vnrl.%s.losses" % tag] = np.array([il, rl], np.float64)
+        out["th.vnrl.%s.params" % tag] = flat_params(model)
+
+
 def gen_greedy_kats(out):
     """MultiHumanRL.predict with an EMPTY crowd (multi_human_rl.py:27-31) -> CADRL.select_greedy_action (cadrl.py:193-228): the
     table action closest to the straight-to-goal velocity.  Holonomic (the unicycle branch's last case raises upstream: a
@@ -1242,6 +1311,9 @@ def main():
     gen_greedy_kats(vt)
     gen_vnrl_trainer_kats(pg, vt)
     np.savez(os.path.join(HERE, "vnrl_trainer.npz"), **vt)
+    th = {}
+    gen_trainer_host_kats(th)                               # round 5; its own file
+    np.savez(os.path.join(HERE, "trainer_host.npz"), **th)
     rc = {}
     gen_root_clip_kats(masters, rc)                         # round 5; its own file and its own rng: the earlier fixtures stay bit-identical
     gen_tie_kats(masters, rc)

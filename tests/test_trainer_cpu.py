@@ -2,6 +2,7 @@
 (the DataLoader's own, index for index), the stacked view of the replay memory, the reference's contract."""
 import types
 
+import numpy as np
 import pytest
 import torch
 from torch.utils.data import DataLoader
@@ -219,3 +220,87 @@ def test_vnrl_trainer_contract_on_cpu():
     assert isinstance(t.optimizer, torch.optim.SGD) and t.optimizer.defaults["momentum"] == 0.9
     t.update_target_model(pol.model)
     assert t.target_model is not pol.model
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the trainers' host logic against the REFERENCE trainers, on a CPU (fixture trainer_host.npz: tests/golden/make_golden.py drove
+# crowd_nav/utils/trainer.py's MPRLTrainer / VNRLTrainer over tests/trainer_standins.py's small modules)
+# ---------------------------------------------------------------------------------------------------------------------------------
+from tests import golden_io as gio                                             # noqa: E402
+from tests.trainer_standins import StandInValue, StandInPredictor, StandInPathG, seeded, flat_params   # noqa: E402
+
+
+class _Scalars(object):
+    def __init__(self):
+        self.rows = []
+
+    def add_scalar(self, tag, value, step):
+        self.rows.append((tag, float(value), step))
+
+
+@pytest.mark.parametrize("tag,shuffle,detach,reduce,opt,memory_kind", [
+    ("ordered", False, True, False, "Adam", "list"),
+    ("shuffled", True, False, True, "Adam", "list"),            # the product's own DataLoader, created lazily like upstream's
+    ("shuffled", True, False, True, "Adam", "replay"),          # index-sampled from ReplayMemory.as_tensors(): the same batches
+    ("shuffled_sgd", True, False, False, "SGD", "replay"),
+])
+def test_mprl_trainer_host_logic_against_the_reference_trainer(tag, shuffle, detach, reduce, opt, memory_kind):
+    """train.py's order -- imitation epochs at one rate, new optimizers at another, target refreshed, RL batches, target refreshed, RL
+    batches -- with a short last batch (70 transitions, batches of 16), the predictor updated on every third imitation batch, `reduce`
+    / `detach` / SGD variants, un-shuffled and SHUFFLED batches (the loader's two draws from torch's global generator per pass): same
+    final parameters and the same four reported losses as the reference MPRLTrainer on the same modules."""
+    fx = gio.load("trainer_host")
+    n = fx["th.robot"].shape[0]
+    items = [tuple(torch.tensor(fx["th." + k][i]) for k in ("robot", "humans", "values", "rewards", "next_robot", "next_humans"))
+             for i in range(n)]
+    if memory_kind == "replay":
+        memory = rga.ReplayMemory(1000)
+        for it in items:
+            memory.push(it)
+    else:
+        memory = items
+    ve, sp = seeded(StandInValue, 11), seeded(StandInPredictor, 12)
+    writer = _Scalars()
+    t = rga.MPRLTrainer(ve, sp, memory, torch.device("cpu"), None, writer, 16, opt, 3, reduce, False, detach, False)
+    if not shuffle:
+        t.data_loader = DataLoader(memory, 16, shuffle=False)
+    torch.manual_seed(5)
+    t.set_learning_rate(1e-2)
+    assert t.optimize_epoch(2) is None
+    t.set_learning_rate(1e-3)
+    t.update_target_model(ve)
+    first = t.optimize_batch(2, 0)
+    t.update_target_model(ve)
+    second = t.optimize_batch(3, 1)
+    assert not t._capturable and t._steps == {}
+    got = np.array(list(first) + list(second))
+    want = fx["th.mprl.%s.losses" % tag]
+    assert np.all(np.abs(got - want) <= 1e-6 * np.maximum(1.0, np.abs(want))), (got, want)
+    err = float(np.abs(flat_params(ve, sp) - fx["th.mprl.%s.params" % tag]).max())
+    assert err <= 1e-6, err
+    assert [r[0] for r in writer.rows] == ["IL/epoch_v_loss", "IL/epoch_s_loss"] * 2 + ["RL/average_v_loss", "RL/average_s_loss"] * 2
+    assert [r[2] for r in writer.rows] == [0, 0, 1, 1, 0, 0, 1, 1]
+
+
+@pytest.mark.parametrize("tag,shuffle", [("ordered", False), ("shuffled", True)])
+def test_vnrl_trainer_host_logic_against_the_reference_trainer(tag, shuffle):
+    """Path G's trainer the same way (pad_batch collate, imitation epochs then RL batches, shuffled loader included)."""
+    fx = gio.load("trainer_host")
+    n = fx["th.states"].shape[0]
+    items = [tuple(torch.tensor(fx["th." + k][i]) for k in ("states", "values", "rewards", "next_states")) for i in range(n)]
+    model = seeded(StandInPathG, 13)
+    writer = _Scalars()
+    t = rga.VNRLTrainer(model, items, torch.device("cpu"), None, 16, "Adam", writer)
+    if not shuffle:
+        t.data_loader = DataLoader(items, 16, shuffle=False, collate_fn=tr.pad_batch)
+    torch.manual_seed(6)
+    t.set_learning_rate(1e-2)
+    il = t.optimize_epoch(2)
+    t.set_learning_rate(1e-3)
+    t.update_target_model(model)
+    rl = t.optimize_batch(3, 0)
+    want = fx["th.vnrl.%s.losses" % tag]
+    assert abs(il - want[0]) <= 1e-6 * max(1.0, abs(want[0])) and abs(rl - want[1]) <= 1e-6 * max(1.0, abs(want[1])), (il, rl, want)
+    err = float(np.abs(flat_params(model) - fx["th.vnrl.%s.params" % tag]).max())
+    assert err <= 1e-6, err
+    assert [r[0] for r in writer.rows] == ["IL/average_epoch_loss"] * 2
