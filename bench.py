@@ -269,13 +269,12 @@ def parse_args(argv=None):
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--depth", type=int, default=2)
     ap.add_argument("--width", type=int, default=2)
-    ap.add_argument("--contraction", choices=("auto", "f32", "f16", "f16x3", "bf16x6"), default="auto",
+    ap.add_argument("--contraction", choices=("auto", "f32", "f16", "bf16x6"), default="auto",
                     help="auto (default): bf16x6 where the value-of-children kernel offers it (2-layer graphs, N <= 32), f32 otherwise, "
                          "with the plain f32-MFMA line printed beside it at N = 1; "
                          "bf16x6: f32-WIDTH operands (three bf16 pieces each, six MFMA terms) for the first 64 input features of the "
                          "children kernel's 100 x 100 head matrix -- admitted to `value`: DESIGN.md 4; "
-                         "f16: f16-input MFMA for the dense middle-layer products (BASELINE configs[4]; needs --layers 3); "
-                         "f16x3: the children kernel's dense products as three split-f16 MFMA terms (f32-equivalent to ~2^-21, L = 2, N <= 20)")
+                         "f16: f16-input MFMA for the dense middle-layer products (BASELINE configs[4]; needs --layers 3)")
     ap.add_argument("--scenes", choices=("clearance", "uniform"), default="clearance",
                     help="human placement of the synthetic scenes: SURVEY 8(d)'s clearance re-draw (default) or the round-1/2 "
                          "uniform draw")
@@ -552,19 +551,6 @@ def children_roofline(args, ts, device, N, H, last, robot=None, humans=None):
         kern_ms = float(sum(in_search) / len(in_search))
     achieved = scenes_per_launch * flop_per_scene / (kern_ms * 1e-3) / 1e12
     peak, peak_note = FP32_PEAK_TFLOPS, "fp32 vector == f32-MFMA peak (the two do not co-execute on gfx950)"
-    if args.contraction == "f16x3":
-        # every dense product of the fused kernel but the two input layers (K = 9 / 5) runs on the f16 matrix pipe as THREE split
-        # terms, i.e. at a third of the dense f16 MFMA peak; the rest (input layers, softmax scalars, the row pass) at the fp32 rate:
-        # time-weighted peak
-        Hh = N - 1
-        crowd_dense = (Hh * (4736 - 2 * 5 * 64) + 2 * Hh * 32 * 32 + 2 * Hh * Hh * 32 + 2 * Hh * Hh * 32 + 2 * Hh * 32 * 32) / A
-        dense = ((5248 - 2 * 9 * 64) + 2 * 2 * 32 * 32 + 4 * N * 32 + 2 * N * 32 + 2 * 32 * 32      # embedding, x0 Wa / W1, S row + column, p Xh, T_0 W1
-                 + 2 * 32 * 32 + 2 * (32 * 32 + 32 * 100 + 100 * 100) + crowd_dense)                 # last layer, value head, crowd quantities
-        dense = min(dense, flop_per_scene)
-        x3_peak = F16_MFMA_PEAK_TFLOPS / 3.0
-        peak = flop_per_scene / (dense / x3_peak + (flop_per_scene - dense) / FP32_PEAK_TFLOPS)
-        peak_note = "blend: %.0f%% of the FLOPs as 3 split-f16 MFMA terms (a third of the dense f16 MFMA peak = %.0f), the rest at the fp32 peak (%.1f)" % (
-            100.0 * dense / flop_per_scene, x3_peak, FP32_PEAK_TFLOPS)
     if args.contraction == "bf16x6":
         # input features 0..95 of the 100 x 100 head matrix, all 32 of the 32 x 100 one (onto their 96 full-tile outputs) and the
         # 32 x 32 layer before them run on the bf16 matrix pipe as SIX terms, i.e. at a sixth of the dense bf16 MFMA peak; everything
@@ -734,9 +720,6 @@ def main():
                                  "%.0f FLOP), %d tree nodes on this GPU, over ms_per_step" % (ts.num_actions,
                                                                                          predictor_flops_per_scene(N, args.layers), n_nodes)}
 
-    # ---- auxiliary reading (never `value`): the same workload with the children kernel's dense products as three split-f16 MFMA
-    # terms (contraction_dtype "f16x3": f32-equivalent to ~2^-21 per product, on the f16 matrix pipe), timed the same way, with
-    # its deviation from the f32 kernels measured on this very batch
     # ---- the plain f32-MFMA line beside a bf16x6 `value` ("the f32-MFMA line still printed beside it")
     f32_line, ts32 = None, None
     if not STUB and world == 1 and args.contraction == "bf16x6" and B > 0 and os.environ.get("RGL_BENCH_NO_F32_LINE") != "1":
@@ -761,31 +744,6 @@ def main():
         del leg32
         ts.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
 
-    x3 = None
-    if (not STUB and world == 1 and args.contraction == "f32" and args.layers == 2 and N <= 32 and B > 0
-            and os.environ.get("RGL_BENCH_F16X3") == "1"):
-        import copy
-        a3 = copy.copy(args)
-        a3.contraction = "f16x3"
-        pol3 = make_policy(a3, device)
-        ts3 = pol3.tree_search()
-        leg3 = Leg(a3, ts3, device, world, rank, main_leg[1], main_leg[2], None)
-        e3, s3 = leg3.timed(args.steps, args.warmup, INIT_STEPS)
-        o32 = ts.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
-        o3 = ts3.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
-        r3 = children_roofline(a3, ts3, device, N, H, None, leg.robot, leg.humans)
-        x3 = {"value": per_root * total_roots * args.steps / e3, "ms_per_step": e3 / args.steps * 1e3,
-              "step_ms_device_median": s3[len(s3) // 2],
-              "max_abs_dV_vs_f32_kernels": float((o3["best_value"] - o32["best_value"]).abs().max()),
-              "identical_decisions": float((o3["best_action"] == o32["best_action"]).float().mean()),
-              "roofline": {k: r3[k] for k in ("achieved", "peak", "frac", "peak_note", "launch_ms", "standalone_launch_ms", "unit")},
-              "note": "contraction_dtype f16x3 (MprlPlanner.contraction_dtype = RGL_CONTRACT_F16X3): same search, the dense "
-                      "products of the value-of-children kernel (value head, embedding chains, robot row / column of S, p Xh, crowd "
-                      "quantities) as W^T a = W_hi a_hi + W_hi a_lo + W_lo a_hi on v_mfma_f32_16x16x32_f16 with f32 accumulation over "
-                      "power-of-two-scaled operands; reported beside the f32 line, never as `value`"}
-        del leg3
-        ts.search(leg.robot, leg.humans, roots_are_joint_states=False, want_root_values=False)
-
     metric = "agent-graph forward evals/sec (N=%d, %d-layer GCN, depth-%d tree)" % (N, args.layers, args.depth)
     result = {
         "metric": ("STUB SEARCH, NOT A MEASUREMENT: " if STUB else "") + metric,
@@ -797,11 +755,9 @@ def main():
                                 {"median": leg.cold_ms[len(leg.cold_ms) // 2], "max": leg.cold_ms[-1],
                                  "note": "set-up steps 2..9 of this process, before the device reached its steady clock (not timed into `value`)"}),
         "vs_baseline": None, "dtype": {"f32": "f32", "f16": "f16 inputs / f32 accumulate (middle-layer products only; everything else f32)",
-                                       "f16x3": "f32 (dense products of the children kernel as three split-f16 MFMA terms with f32 accumulate, "
-                                                "~2^-21 relative per product; everything else f32)",
                                        "bf16x6": "f32 (24-bit operands throughout; 13 312 of the 14 224 products of the children kernel's 32 x 32, 32 x 100 and "
                                                  "100 x 100 head matrices and the state predictor's weight products as six bf16 MFMA terms over three "
-                                                 "round-to-nearest bf16 pieces per operand, f32 accumulate, dropped terms < 2^-24 |w||a|; "
+                                                 "round-to-nearest bf16 pieces per operand, f32 accumulate, dropped terms <= 2^-23 |w||a| (worst case); "
                                                  "everything else on the f32 MFMA / VALU)"}[args.contraction],
         "data": "synthetic",
         "config": {"workload": "%s: N=%d agents (H=%d humans), %d-layer GCN, depth-%d width-%d "
@@ -823,15 +779,13 @@ def main():
         "roofline_step": roofline_step,
         "decisions": digest,
     }
-    if x3 is not None:
-        result["f16x3"] = x3
     if f32_line is not None:
         result["f32_mfma_line"] = f32_line
     if args.contraction == "bf16x6":
         result["admission"] = {
             "mode": "RGL_CONTRACT_BF16X6", "operand_bits": 24, "pieces_per_operand": "3 x bf16, round to nearest, hi + mid + lo = x exactly",
             "terms": "6 of 9 (lo*hi, mid*mid, hi*lo, mid*hi, hi*mid, hi*hi), f32 accumulate",
-            "dropped_terms_bound": "(2^-26 + 2^-26 + 2^-34) |w||a| < 2^-24 |w||a| per product",
+            "dropped_terms_bound": "w_mid a_lo + w_lo a_mid + w_lo a_lo <= (2^-24 + 2^-24 + 2^-32) |w||a| < 2^-22.99 |w||a| per product in the worst case (|mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|), ~2^-25 typically; unbiased",
             "where": "children_fused_kernel: the 32 x 32, 32 x 100 and 100 x 100 value-head matrices, input features 0..95 onto output "
                      "features 0..95 (what the CU's LDS holds as three bf16 pieces once w_h's second matrix sits in registers); scene_graph_kernel: "
                      "Wa, W_l, motion head; everything else f32",
@@ -853,9 +807,6 @@ def main():
         if ts32 is not None:
             dv["f32 kernels"] = ts32.search(leg.robot[:64], leg.humans[:64], roots_are_joint_states=False,
                                             want_root_values=False)["best_value"].clone()
-        if x3 is not None:
-            dv["f16x3 kernels"] = ts3.search(leg.robot[:64], leg.humans[:64], roots_are_joint_states=False,
-                                             want_root_values=False)["best_value"].clone()
         result["cpu_baseline"] = cpu_baseline(args, leg.robot_cpu, leg.humans_cpu, args.cpu_seconds, dv)
     elif rank == 0:
         result["cpu_baseline"] = None

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RGL_ABI_VERSION 7
+#define RGL_ABI_VERSION 8
 
 #define RGL_MAX_MLP_LAYERS 6
 #define RGL_MAX_GCN_LAYERS 8
@@ -56,7 +56,8 @@ extern "C" {
 #define RGL_ERR_WORKSPACE (-4)      /* workspace too small (see mprl_tree_workspace_bytes)     */
 #define RGL_CONTRACT_F32 0
 #define RGL_CONTRACT_F16 1
-#define RGL_CONTRACT_F16X3 2        /* ABI 4: f32-equivalent dense products as three split-f16 MFMA terms */
+/* 2 was RGL_CONTRACT_F16X3 (ABI 4..7: 22-23 operand bits as two f16 halves); superseded by RGL_CONTRACT_BF16X6 and removed in ABI 8:
+ * a planner that asks for it gets RGL_ERR_BAD_MODE */
 #define RGL_CONTRACT_BF16X6 3       /* ABI 6: f32-WIDTH products on the matrix pipe: three bf16 pieces per operand, six terms */
 
 #define RGL_ERR_LDS (-5)            /* configuration does not fit the 160 KiB LDS of one CU    */
@@ -263,18 +264,13 @@ typedef struct MprlPlanner {
                                  * accumulate for the dense products of the middle GCN layer of the children's  *
                                  * value graph (BASELINE configs[4]); RGL_ERR_BAD_MODE when the configuration   *
                                  * has no such kernel (needs embedded_gaussian, L = 3, N <= 64)                 *
-                                 * | RGL_CONTRACT_F16X3 (ABI 4): the dense products of the value-of-children    *
-                                 * kernel of the shipped shape (L = 2, N <= 20, head 32-100-100-1, softmax        *
-                                 * similarities: value head, embedding chains, S row / column, crowd) computed as *
-                                 * W_hi a_hi + W_hi a_lo + W_lo a_hi with f16 halves of power-of-two-scaled      *
-                                 * operands and f32 accumulation: ~2^-21 relative per product (f32 rounding is   *
-                                 * 2^-24), 5x the MFMA rate of the f32 form, any finite input.  Where no kernel   *
-                                 * offers it, plain f32 runs (never less accurate), nothing is refused.           *
                                  * | RGL_CONTRACT_BF16X6 (ABI 6): products whose operands keep all 24 significand   *
                                  * bits -- x = hi + mid + lo exactly, three bf16 pieces by round-to-nearest, f32's  *
                                  * exponent range, no scaling -- as the six terms W_lo a_hi + W_mid a_mid + W_hi    *
                                  * a_lo + W_mid a_hi + W_hi a_mid + W_hi a_hi of v_mfma_f32_16x16x32_bf16 with f32  *
-                                 * accumulation; the dropped terms are < 2^-24 |W||a| (below one f32 rounding).    *
+                                 * accumulation; the dropped terms W_mid a_lo + W_lo a_mid + W_lo a_lo are at most   *
+                                 * 2^-23 |W||a| (|mid| <= 2^-8 |x|, |lo| <= 2^-16 |x| in the worst case; ~2^-25      *
+                                 * typically) -- the size of one f32 rounding of the product, and unbiased.          *
                                  * Offered by the value-of-children kernel of the shipped shape for 13 312 of the  *
                                  * 14 224 products of its three value-head matrices (what its LDS holds) *
                                  * and by the state predictor's scene kernel (softmax similarity, 17..32 nodes) for *
@@ -298,7 +294,7 @@ typedef struct MprlPlanner {
      * stand-alone mprl_value_children_f32 call) packs the image into its workspace first (~5 us). */
     const float* children_image;
     /* optional (NULL = absent; ABI 4): device buffer of mprl_predictor_image_bytes() bytes holding the state predictor's scene
-     * kernel weight image in the layout of the planner's split mode -- f16 (hi, lo) fragments + scales for RGL_CONTRACT_F16X3,
+     * kernel weight image in the layout of the planner's split mode --
      * three-piece bf16 fragments for RGL_CONTRACT_BF16X6 (ABI 6: the scene kernel's weight products Wa, W_l and the motion head as
      * six bf16 MFMA terms; S and A H stay f32) -- prepared by mprl_pack_predictor_image_f32 from THIS planner's predictor_graph /
      * motion_head.  NULL: a search in such a mode packs it into its workspace itself. */
@@ -307,7 +303,7 @@ typedef struct MprlPlanner {
 
 /* Bytes of the weight image above; 0 when the configuration has no image-based children kernel (the searches then ignore
  * `children_image`).  Depends on the architecture only (not on the weights, P, A or H).  Round 4: also offered for three-layer
- * graphs and crowds beyond 32 agents with the shipped embedding / head shapes (f32 layout, not in RGL_CONTRACT_F16X3): there the
+ * graphs and crowds beyond 32 agents with the shipped embedding / head shapes (f32 layout): there the
  * image feeds the stage-2 head, which with an image at hand runs inside the stage-1 launch (children_deep_kernel) instead of in
  * a launch of its own. */
 size_t mprl_children_image_bytes(const MprlPlanner* planner);

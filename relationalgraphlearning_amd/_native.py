@@ -15,13 +15,13 @@ MAX_NODES = 128
 MAX_XDIM = 64
 MAX_WIDTH = 256
 MAX_ACTIONS = 256
-ABI_VERSION = 7
+ABI_VERSION = 8
 MSE_WORKSPACE_BYTES = 2048
 
 SIMILARITY = {"embedded_gaussian": 0, "gaussian": 1, "cosine": 2, "cosine_softmax": 3, "concatenation": 4,
               "squared": 5, "equal_attention": 6, "diagonal": 7}
 KINEMATICS = {"holonomic": 0, "unicycle": 1}
-CONTRACTION_DTYPES = {"f32": 0, "f16": 1, "f16x3": 2, "bf16x6": 3}
+CONTRACTION_DTYPES = {"f32": 0, "f16": 1, "bf16x6": 3}      # 2 was "f16x3" (ABI 4..7)
 
 ERRORS = {-1: "RGL_ERR_BAD_SHAPE", -2: "RGL_ERR_BAD_MODE", -3: "RGL_ERR_NULL", -4: "RGL_ERR_WORKSPACE",
           -5: "RGL_ERR_LDS"}

@@ -89,10 +89,10 @@ int launch_head_rows(const RglGraph* g, const RglMlp* head, const float* rows, i
 int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, int H, const float* child_robot,
                           const float* humans_next, float* child_value, void* workspace, size_t workspace_bytes,
                           int image_ready, hipStream_t stream, const float* caller_image = nullptr,
-                          const void* tail = nullptr, size_t tail_bytes = 0, int* tail_done = nullptr, int hx = 0);
-// hx: the value head as f16-split MFMAs (RGL_CONTRACT_F16X3): the image then holds f16 (hi, lo) fragments for that kernel only
+                          const void* tail = nullptr, size_t tail_bytes = 0, int* tail_done = nullptr, int mode = 0);
+// mode 2: the six-term bf16 products (RGL_CONTRACT_BF16X6): the image then holds three-piece bf16 fragments for that kernel only
 int pack_children_images(const RglGraph* g, const RglMlp* head, int P, int A, int H, void* workspace, size_t workspace_bytes,
-                         hipStream_t stream, int hx = 0);   // P = the largest launch; 1 = the fused kernel does not apply
+                         hipStream_t stream, int mode = 0);   // P = the largest launch; 1 = the fused kernel does not apply
 size_t fused_children_workspace_bytes(int P, int A, int H);
 const float* fused_workspace_image(const void* workspace, size_t workspace_bytes);   // where pack_children_images put the image
 int launch_value_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
@@ -103,13 +103,13 @@ size_t value_children_workspace_bytes(const MprlPlanner* pl, int P, int H);     
 // `children` (optional): a ChildrenArgs (rgl_children.h, passed opaquely with its size) describing the level's independent
 // next-state / reward work; when the MFMA scene kernel runs, it executes that work on extra workgroups of the same launch
 // and sets *children_done.
-// `sp_image`: the split-f16 weight image of the scene kernel (scene_image_bytes, pack_scene_image) when the planner's mode is
-// RGL_CONTRACT_F16X3; without one the f32 form of the kernel runs
+// `sp_image`: the three-piece bf16 weight image of the scene kernel (scene_image_bytes, pack_scene_image) when the planner's mode is
+// RGL_CONTRACT_BF16X6; without one the f32 form of the kernel runs
 int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float* humans, int crowds_per, int P, int H,
                           float* humans_next, void* workspace, size_t workspace_bytes, hipStream_t stream,
                           const void* children = nullptr, size_t children_bytes = 0, int* children_done = nullptr,
                           const float* sp_image = nullptr);                                                           // rgl_scene.hip
-size_t scene_image_bytes(const MprlPlanner* pl);                      // 0: no split-f16 scene kernel for this planner
+size_t scene_image_bytes(const MprlPlanner* pl);                      // 0: no six-term bf16 scene kernel for this planner
 int pack_scene_image(const MprlPlanner* pl, float* image, hipStream_t stream);
 
 int launch_scene_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,

@@ -36,14 +36,11 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
     const int A = pl->num_actions;
     const int hv = head_variant(pl->value_head);
     const bool want_f16 = pl->contraction_dtype == RGL_CONTRACT_F16;
-    // RGL_CONTRACT_F16X3: f32-equivalent products on the f16 matrix pipe (three split-f16 terms) where a kernel offers them -- the
-    // fused kernel's value head; every other kernel computes plain f32, which is at least as accurate, so nothing is refused
     // RGL_CONTRACT_BF16X6 (round 5): f32-WIDTH products (three bf16 pieces per operand, six terms) on the matrix pipe where a kernel
     // offers them -- the first 64 input features of the fused kernel's last head matrix; plain f32 everywhere else
     const bool want_b6 = pl->contraction_dtype == RGL_CONTRACT_BF16X6;
-    const bool want_x3 = pl->contraction_dtype == RGL_CONTRACT_F16X3 || want_b6;      // "the image is in the fused kernel's layout only"
-    const int fused_mode = want_b6 ? 2 : (want_x3 ? 1 : 0);
-    if (pl->contraction_dtype != RGL_CONTRACT_F32 && !want_f16 && !want_x3) return RGL_ERR_BAD_MODE;
+    const int fused_mode = want_b6 ? 2 : 0;           // kModeBx / kModeF32 (rgl_fused.hip)
+    if (pl->contraction_dtype != RGL_CONTRACT_F32 && !want_f16 && !want_b6) return RGL_ERR_BAD_MODE;      // (2, the split-f16 mode of ABI 4..7, is gone)
     const bool staged = hv >= 0 && workspace && workspace_bytes >= value_children_workspace_bytes(pl, P, H);
     // stage 1, in order of preference: rank-1 (L = 2, N <= 32), shared-crowd deep (L in {2,3}, N <= 60), tiles (softmax
     // similarities, any depth, N <= 64); everything else, or a head without a stage-2 kernel: the general kernel
@@ -56,7 +53,7 @@ int launch_value_children(const MprlPlanner* pl, const float* child_robot, const
     }
     // packed weight image of the value estimator (the caller's, or this search's at the end of the workspace): the two-stage pair
     // copies its weight images from it instead of building them from the raw matrices (most of a small launch)
-    const float* image = (!staged || want_x3) ? nullptr          // (an f16-split image is in the fused kernel's layout only)
+    const float* image = (!staged || want_b6) ? nullptr          // (a three-piece bf16 image is in the fused kernel's layout only)
                          : pl->children_image ? pl->children_image
                          : image_ready ? fused_workspace_image(workspace, workspace_bytes) : nullptr;
     if (staged) {

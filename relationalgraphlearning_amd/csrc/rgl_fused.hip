@@ -79,12 +79,11 @@ constexpr int kFusedWaves = 8;
 
 // h = relu(t W_last)(+hprev), value head 32 -> D1 -> D2 -> D3 -> 1 for the 16 children of a tile (lane (n, q): child n, D-layout
 // registers); returns the value of child n in every lane of its column (without the last bias)
-template <class LO, int D1, int D2, int D3, bool SKIP, bool HX = false, bool BX = false>
+template <class LO, int D1, int D2, int D3, bool SKIP, bool BX = false>
 __device__ __forceinline__ float head_chain(const float* lds, const f32x4 (&tin)[2], const f32x4 (&hp)[2], int lane) {
     const int q = lane >> 4;
     f32x4 h[2];
-    if constexpr (HX) layer_mfma_h<XD, XD, false>(lds + LO::f_last, tin, h, lane, nullptr, lds[LO::hs + 0]);
-    else layer_mfma<XD, XD, false>(lds + LO::f_last, tin, h, lane);
+    layer_mfma<XD, XD, false>(lds + LO::f_last, tin, h, lane);
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -94,18 +93,15 @@ __device__ __forceinline__ float head_chain(const float* lds, const f32x4 (&tin)
             h[ot][r] = x;
         }
     f32x4 a1[Tiles<D1>::v];
-    if constexpr (HX) layer_mfma_h<XD, D1, true>(lds + LO::f1, h, a1, lane, lds + LO::b1, lds[LO::hs + 1]);
-    else if constexpr (BX && D1 == 32) layer_mfma_bx1<XD, 32, true>(lds + LO::f1, h, a1, lane, lds + LO::b1);
+    if constexpr (BX && D1 == 32) layer_mfma_bx1<XD, 32, true>(lds + LO::f1, h, a1, lane, lds + LO::b1);
     else layer_mfma<XD, D1, true>(lds + LO::f1, h, a1, lane, lds + LO::b1);
     relu_tiles<D1>(a1);
     f32x4 a2[Tiles<D2>::v];
-    if constexpr (HX) layer_mfma_h<D1, D2, true>(lds + LO::f2, a1, a2, lane, lds + LO::b2, lds[LO::hs + 2]);
-    else if constexpr (BX) layer_mfma_bx1<D1, D2, true>(lds + LO::f2, a1, a2, lane, lds + LO::b2);
+    if constexpr (BX) layer_mfma_bx1<D1, D2, true>(lds + LO::f2, a1, a2, lane, lds + LO::b2);
     else layer_mfma<D1, D2, true>(lds + LO::f2, a1, a2, lane, lds + LO::b2);
     relu_tiles<D2>(a2);
     f32x4 a3[Tiles<D3>::v];
-    if constexpr (HX) layer_mfma_h<D2, D3, true>(lds + LO::f3, a2, a3, lane, lds + LO::b3, lds[LO::hs + 3]);
-    else if constexpr (BX) layer_mfma_bx<D2, D3, true>(lds + LO::f3, a2, a3, lane, lds + LO::b3);
+    if constexpr (BX) layer_mfma_bx<D2, D3, true>(lds + LO::f3, a2, a3, lane, lds + LO::b3);
     else layer_mfma<D2, D3, true>(lds + LO::f3, a2, a3, lane, lds + LO::b3);
     relu_tiles<D3>(a3);
     float v = 0.f;
@@ -122,13 +118,12 @@ __device__ __forceinline__ float head_chain(const float* lds, const f32x4 (&tin)
 constexpr float kRowScale = 0x1p-110f, kRowUnscale = 0x1p110f;
 
 // HR >= N: human rows of UW held in registers (padded rows contribute exactly 0); SOFT: softmax row normalisation
-// HX: the value head's dense products as f16-split MFMAs (layer_mfma_h; MprlPlanner::contraction_dtype = RGL_CONTRACT_F16X3)
 // BX: the D2 x D3 head matrix's first 64 input features as six bf16 terms on the matrix pipe (layer_mfma_bx; RGL_CONTRACT_BF16X6)
-template <int HR, int NT, bool SKIP, bool SOFT, int D1, int D2, int D3, bool HX = false, bool BX = false>
+template <int HR, int NT, bool SKIP, bool SOFT, int D1, int D2, int D3, bool BX = false>
 __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const FusedArgs a) {
     const int sim = SOFT ? (int)SIM_SOFTMAX : a.sim;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    using LO = FusedLds<D1, D2, D3, HX, BX>;
+    using LO = FusedLds<D1, D2, D3, BX>;
     constexpr int NP = 16 * NT;
     constexpr int nthreads = kFusedWaves * 64;
     const int tid = threadIdx.x;
@@ -139,7 +134,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
     // from v_mfma_f32_4x4x1_16B_f32 (rgl_mlp_chain.h: 12 clocks instead of 32 per k step) and land, after a reduce-scatter over
     // the k-groups, as node 16 + q in register 0 of lane (n, q): the tile's node order is 16 + 4 r + q, registers 1..3 are
     // padding -- their exps, table entries and k steps of p Xh are not computed at all.
-    constexpr bool T1P = PK && NT == 2 && HR <= 20 && !HX;
+    constexpr bool T1P = PK && NT == 2 && HR <= 20;
     constexpr int HRL = HR < NP ? HR : NP;              // rows of UW the row pass visits (rows >= N are zero)
     constexpr int SLDK = HRL + 2;
     const int N = a.N, A = a.A, SLD = PK ? SLDK : a.SLD;
@@ -187,10 +182,6 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
     }
     f32x4 gq[NT][2], xq[NT][2], ms[NT], zs[NT], xt[NT][2], uw4[HRL / 4];
     float xt1p[2] = {0.f, 0.f}, ms1 = 0.f, zs1 = 1.f;      // T1P: Xh^T[f][node 16 + q], msh / Zsh of node 16 + q
-    // HX: the crowd operands as split-f16 halves.  gqs / xqs [node tile]: rows = nodes, k = features (the D layout of the crowd chain,
-    // packed pairwise); xts [feature tile]: rows = features, k = nodes.  One power-of-two scale per family (they serve as A operands).
-    SplitOperand<2> gqs[NT], xqs[NT];
-    SplitOperand<NT> xts[2];
     // item wi = (order position o, local parent), o-major; group j = (o + rot) % items_per_parent covers the full tiles j G ..; the
     // LAST group (the short one) also carries the parent's partial tile, which it runs first.  Tile sequence ts .. t1-1, where
     // t < t0 means "the partial tile".
@@ -260,21 +251,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                 for (int r = 0; r < 4; ++r) hacc[ht][r] = relu1(hacc[ht][r] + bb[r]);
             }
             f32x4 xa[2] = {zero4(), zero4()};
-            if constexpr (HX) {
-                SplitOperand<4> sh;
-                make_split<4>(hacc, sh);
-                layer_mfma_hs<HID, XD, true>(lds + LO::wh2, sh, xa, lane, bh2, lds[LO::hs + 7]);
-#pragma unroll
-                for (int ot = 0; ot < 2; ++ot) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xa[ot][r] = node_ok ? relu1(xa[ot][r]) : 0.f;
-                    *reinterpret_cast<f32x4*>(&Xs[node * XLD + 16 * ot + 4 * q]) = xa[ot];
-                    xq[pct][ot] = xa[ot];
-                }
-                SplitOperand<2> sxa;
-                make_split<2>(xa, sxa);
-                layer_mfma_hs<XD, XD, false>(lds + LO::wa, sxa, gq[pct], lane, nullptr, lds[LO::hs + 5]);
-            } else {
+            {
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) {
                 load_fence();
@@ -323,37 +300,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         }
         load_fence();
         __builtin_amdgcn_wave_barrier();
-        if constexpr (HX) {
-            // one scale for every Xh operand (xqs, xts) and one for G: they are A operands of the products below and of the tiles'
-            float mx_x = 0.f, mx_g = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        mx_x = fmaxf(mx_x, fabsf(xq[nt][ot][r]));
-                        mx_g = fmaxf(mx_g, fabsf(gq[nt][ot][r]));
-                    }
-            float sc_x, inv_x, sc_g, inv_g;
-            pow2_scale(row16_max(kgroups_max(mx_x)), sc_x, inv_x);
-            pow2_scale(row16_max(kgroups_max(mx_g)), sc_g, inv_g);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                split_tiles<2>(xq[nt], sc_x, xqs[nt]);
-                xqs[nt].inv = inv_x;
-                split_tiles<2>(gq[nt], sc_g, gqs[nt]);
-                gqs[nt].inv = inv_g;
-            }
-#pragma unroll
-            for (int ot = 0; ot < 2; ++ot) {
-                f32x4 col[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) col[nt] = xt[nt][ot];
-                split_tiles<NT>(col, sc_x, xts[ot]);
-                xts[ot].inv = inv_x;
-            }
-        }
+        
         // part 2 (every Xh row is in registers now): S_ij = G_i . Xh_j over humans j, msh / E / Zsh, U = E Xh, UW = U W1
 #pragma unroll
         for (int pct = 0; pct < NT; ++pct) {
@@ -364,12 +311,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
                 f32x4 sacc = zero4();
-                if constexpr (HX) {
-                    sacc = mfma_h3(xqs[jt].hi[0], xqs[jt].lo[0], gqs[pct].hi[0], gqs[pct].lo[0], sacc);
-                    const float post = xqs[jt].inv * gqs[pct].inv;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sacc[r] *= post;
-                } else {
+                {
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
@@ -402,21 +344,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
             }
             f32x4 u[2] = {zero4(), zero4()};
             f32x4 uw[2] = {zero4(), zero4()};
-            if constexpr (HX) {
-                SplitOperand<NT> se;
-                make_split<NT>(e, se);
-                const float post = xts[0].inv * se.inv;
-#pragma unroll
-                for (int ot = 0; ot < 2; ++ot) {
-#pragma unroll
-                    for (int c = 0; c < (NT + 1) / 2; ++c) u[ot] = mfma_h3(xts[ot].hi[c], xts[ot].lo[c], se.hi[c], se.lo[c], u[ot]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) u[ot][r] *= post;
-                }
-                SplitOperand<2> su;
-                make_split<2>(u, su);
-                layer_mfma_hs<XD, XD, false>(lds + LO::w1, su, uw, lane, nullptr, lds[LO::hs + 6]);
-            } else {
+            {
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -533,7 +461,6 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
 
         // ---------------- embedding: x0 = w_r(robot'), y = x0 W1, g0 = x0 Wa (transposed MFMA chain) ----------------
         f32x4 xacc[2] = {zero4(), zero4()}, gacc[2] = {zero4(), zero4()}, yacc[2] = {zero4(), zero4()};
-        SplitOperand<2> sxs;                   // HX: x0 of my 16 children as split-f16 operand (embedding products, column of S)
         float s00 = 0.f;
         {
             f32x4 hacc[4] = {zero4(), zero4(), zero4(), zero4()};
@@ -550,18 +477,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hacc[ht][r] = relu1(hacc[ht][r] + bb[r]);
             }
-            if constexpr (HX) {
-                SplitOperand<4> sh;
-                make_split<4>(hacc, sh);
-                layer_mfma_hs<HID, XD, true>(lds + LO::wr2, sh, xacc, lane, br2, lds[LO::hs + 4]);
-#pragma unroll
-                for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xacc[ot][r] = relu1(xacc[ot][r]);
-                make_split<2>(xacc, sxs);
-                layer_mfma_hs<XD, XD, false>(lds + LO::wa, sxs, gacc, lane, nullptr, lds[LO::hs + 5]);
-                layer_mfma_hs<XD, XD, false>(lds + LO::w1, sxs, yacc, lane, nullptr, lds[LO::hs + 6]);
-            } else {
+            {
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) {
                 load_fence();
@@ -610,8 +526,6 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         {
             f32x4 s0t[NT], sct[NT];
             float mx0 = NEG_INF;
-            SplitOperand<2> sgs;
-            if constexpr (HX) make_split<2>(gacc, sgs);
             float sc1 = NEG_INF, p1 = NEG_INF;           // T1P: S_c[16 + q][0], then S_c[0][16 + q] -> p of node 16 + q
             if constexpr (T1P) {
                 f32x4 psc[2] = {zero4(), zero4()}, ps0[2] = {zero4(), zero4()};
@@ -630,13 +544,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
 #pragma unroll
             for (int nt = 0; nt < (T1P ? 1 : NT); ++nt) {
                 f32x4 sc = zero4(), s0 = zero4();
-                if constexpr (HX) {
-                    sc = mfma_h3(gqs[nt].hi[0], gqs[nt].lo[0], sxs.hi[0], sxs.lo[0], sc);
-                    s0 = mfma_h3(xqs[nt].hi[0], xqs[nt].lo[0], sgs.hi[0], sgs.lo[0], s0);
-                    const float pc = gqs[nt].inv * sxs.inv, p0 = xqs[nt].inv * sgs.inv;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { sc[r] *= pc; s0[r] *= p0; }
-                } else {
+                {
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -677,18 +585,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                 for (int r = 0; r < 4; ++r) s0t[nt][r] *= iz0;                       // p = A_c[0][:] (0 beyond row N-1)
             p00 = kgroups_sum(q == 0 ? s0t[0][0] : 0.f);
             // (p_c Xh)^T[f][c] = sum_j Xh^T[f][j] p_c[j]: the D registers of the robot-row product are already the B operand
-            if constexpr (HX) {
-                SplitOperand<NT> sp;                             // p in [0, 1]: a fixed scale
-                split_tiles<NT>(s0t, 512.f, sp);
-                const float post = xts[0].inv * (1.f / 512.f);
-#pragma unroll
-                for (int ot = 0; ot < 2; ++ot) {
-#pragma unroll
-                    for (int c = 0; c < (NT + 1) / 2; ++c) t0h[ot] = mfma_h3(xts[ot].hi[c], xts[ot].lo[c], sp.hi[c], sp.lo[c], t0h[ot]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) t0h[ot][r] *= post;
-                }
-            } else {
+            {
 #pragma unroll
             for (int nt = 0; nt < (T1P ? 1 : NT); ++nt)
 #pragma unroll
@@ -835,16 +732,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         f32x4 tin[2], hp[2];
         {
             f32x4 o[2] = {zero4(), zero4()};
-            if constexpr (HX) {
-                f32x4 tb[2];
-#pragma unroll
-                for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tb[ft][r] = fmaf(p00, xacc[ft][r], t0h[ft][r]);      // T_0 = p_c Xh + p_c[0] x0_c
-                SplitOperand<2> stb;
-                make_split<2>(tb, stb);
-                layer_mfma_hs<XD, XD, false>(lds + LO::w1, stb, o, lane, nullptr, lds[LO::hs + 6]);
-            } else {
+            {
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
                 load_fence();
@@ -889,7 +777,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
 
         // ---------------- last GCN layer on the robot row + value head: one register-resident MFMA chain -------------------
         await_image();
-        const float v = head_chain<LO, D1, D2, D3, SKIP, HX, BX>(lds, tin, hp, lane);
+        const float v = head_chain<LO, D1, D2, D3, SKIP, BX>(lds, tin, hp, lane);
         if (q == 0 && c < A) a.value[(size_t)p * A + c] = v + hb4;
         PHASE_MARK(6);
       }
@@ -913,7 +801,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                 tin[ot] = valid ? *reinterpret_cast<const f32x4*>(row + 16 * ot + 4 * q) : zero4();
                 hp[ot] = valid ? *reinterpret_cast<const f32x4*>(row + 32 + 16 * ot + 4 * q) : zero4();
             }
-            const float v = head_chain<LO, D1, D2, D3, SKIP, HX, BX>(lds, tin, hp, lane);
+            const float v = head_chain<LO, D1, D2, D3, SKIP, BX>(lds, tin, hp, lane);
             if (valid && q == 0) a.value[(size_t)p * A + 16 * a.n_full + k] = v + hb4;
         }
     }
@@ -973,30 +861,6 @@ template <int ROWS, int COLS, int LD>
 __device__ __forceinline__ float matrix_element(const float* __restrict__ W, int e) {
     const int r = e / LD, c = e - r * LD;
     return (r < ROWS && c < COLS) ? W[r * COLS + c] : 0.f;
-}
-
-// 1 / scale of the four head matrices (HX images): scale = the power of two that brings max |W| into [512, 1024)
-__global__ __launch_bounds__(256) void head_scales_kernel(const FusedArgs a, float* img, int hs_off, int d1, int d2, int d3) {
-    __shared__ float red[256];
-    // blocks 0..3: W_last, hw1, hw2, hw3 (value head); 4..7: wr2, wa, w1, wh2 (embedding / graph matrices of the tile and crowd chains)
-    const float* Ws[8] = {a.w_last, a.hw1, a.hw2, a.hw3, a.wr2, a.wa, a.w1, a.wh2};
-    const int ns[8] = {XD * XD, XD * d1, d1 * d2, d2 * d3, HID * XD, XD * XD, XD * XD, HID * XD};
-    const float* W = Ws[blockIdx.x];
-    const int n = ns[blockIdx.x];
-    float m = 0.f;
-    if (W)
-        for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(W[i]));
-    else m = 1.f;                                                  // the identity (gaussian: Wa = I)
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const unsigned E = __float_as_uint(red[0]) >> 23;
-        img[hs_off + blockIdx.x] = (E < 32u || E > 254u) ? 1.f : __uint_as_float((E - 9u) << 23);      // 1 / 2^(136 - E)
-    }
 }
 
 // one float of the BX f3 region (BxLayout): a pair of bf16 pieces of the matrix-pipe fragments, or an f32 fragment element
@@ -1061,44 +925,33 @@ __device__ __forceinline__ float bx1_element(const float* __restrict__ W, int id
     return __builtin_bit_cast(float, v);
 }
 
-template <int D1, int D2, int D3, bool HX, bool BX = false>
+template <int D1, int D2, int D3, bool BX = false>
 __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedArgs a, float* img) {
-    using LO = FusedLds<D1, D2, D3, HX, BX>;
+    using LO = FusedLds<D1, D2, D3, BX>;
     const int e = blockIdx.x * kPackThreads + threadIdx.x;
     if (e >= LO::scratch) return;
-    if (HX && e >= LO::hs) return;                     // the scales: written by head_scales_kernel before this launch
     float v;
     if (e < LO::br1) v = matrix_element<9, HID, W1LD>(a.wr1, e - LO::wr1);
     else if (e < LO::wr2) v = a.br1[e - LO::br1];
     else if (e < LO::br2) {
-        if constexpr (HX) v = e - LO::wr2 < HeadFragFloats<HID, XD, true>::v ? frag_half2<HID, XD>(a.wr2, e - LO::wr2, 1.f / img[LO::hs + 4]) : 0.f;
-        else v = matrix_element<HID, XD, WLD>(a.wr2, e - LO::wr2);
+        v = matrix_element<HID, XD, WLD>(a.wr2, e - LO::wr2);
     } else if (e < LO::wa) v = a.br2[e - LO::br2];
     else if (e < LO::w1) {
         const int k = e - LO::wa, r = k / WLD, col = k - r * WLD;
-        if constexpr (HX) v = k < HeadFragFloats<XD, XD, true>::v ? frag_half2<XD, XD>(a.wa, k, 1.f / img[LO::hs + 5]) : 0.f;   // null: Wa = I
-        else v = a.wa ? matrix_element<XD, XD, WLD>(a.wa, k) : ((col < XD && r == col) ? 1.f : 0.f);      // gaussian: Wa = I
+        v = a.wa ? matrix_element<XD, XD, WLD>(a.wa, k) : ((col < XD && r == col) ? 1.f : 0.f);      // gaussian: Wa = I
     } else if (e < LO::wh1) {
-        if constexpr (HX) v = e - LO::w1 < HeadFragFloats<XD, XD, true>::v ? frag_half2<XD, XD>(a.w1, e - LO::w1, 1.f / img[LO::hs + 6]) : 0.f;
-        else v = matrix_element<XD, XD, WLD>(a.w1, e - LO::w1);
+        v = matrix_element<XD, XD, WLD>(a.w1, e - LO::w1);
     } else if (e < LO::bh1) v = matrix_element<5, HID, LO::WH1LD>(a.wh1, e - LO::wh1);
     else if (e < LO::wh2) v = a.bh1[e - LO::bh1];
     else if (e < LO::bh2) {
-        if constexpr (HX) v = e - LO::wh2 < HeadFragFloats<HID, XD, true>::v ? frag_half2<HID, XD>(a.wh2, e - LO::wh2, 1.f / img[LO::hs + 7]) : 0.f;
-        else v = matrix_element<HID, XD, WLD>(a.wh2, e - LO::wh2);
+        v = matrix_element<HID, XD, WLD>(a.wh2, e - LO::wh2);
     }
     else if (e < LO::b1) v = a.bh2[e - LO::bh2];
     else if (e < LO::b2) v = bias_element<D1>(a.hb1, e - LO::b1);
     else if (e < LO::b3) v = bias_element<D2>(a.hb2, e - LO::b2);
     else if (e < LO::w4) v = bias_element<D3>(a.hb3, e - LO::b3);
     else if (e < LO::f_last) v = bias_element<D3>(a.hw4, e - LO::w4);          // w4 is [D3][1]: same padded vector layout as a bias
-    else if constexpr (HX) {
-        // scale of matrix l = 1 / img[hs + l] (a power of two, so the reciprocal is exact)
-        if (e < LO::f1) v = frag_half2<XD, XD>(a.w_last, e - LO::f_last, 1.f / img[LO::hs + 0]);
-        else if (e < LO::f2) v = frag_half2<XD, D1>(a.hw1, e - LO::f1, 1.f / img[LO::hs + 1]);
-        else if (e < LO::f3) v = frag_half2<D1, D2>(a.hw2, e - LO::f2, 1.f / img[LO::hs + 2]);
-        else v = frag_half2<D2, D3>(a.hw3, e - LO::f3, 1.f / img[LO::hs + 3]);
-    } else {
+    else {
         if (e < LO::f1) v = frag_element<XD, XD>(a.w_last, e - LO::f_last);
         else if (e < LO::f2) {
             if constexpr (BX && D1 == 32) v = bx1_element<XD, 32>(a.hw1, e - LO::f1);
@@ -1113,18 +966,12 @@ __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedAr
     img[e] = v;
 }
 
-// one packed image, in the layout of the kernel that will read it (mode 1: f16-split head fragments + scales; mode 2: the bf16 /
+// one packed image, in the layout of the kernel that will read it (mode 2: the bf16 /
 // f32 hybrid of the last head matrix)
-enum { kModeF32 = 0, kModeHx = 1, kModeBx = 2 };
+enum { kModeF32 = 0, kModeBx = 2 };      // (1 was the split-f16 mode of ABI 4..7)
 inline int launch_pack_image(const FusedArgs& a, float* img, int mode, hipStream_t stream) {
     if (mode == kModeBx) {
-        using LO = FusedLds<32, 100, 100, false, true>;
-        hipLaunchKernelGGL((pack_images_kernel<32, 100, 100, false, true>), dim3((unsigned)((LO::scratch + kPackThreads - 1) / kPackThreads)),
-                           dim3(kPackThreads), 0, stream, a, img);
-    } else if (mode == kModeHx) {
         using LO = FusedLds<32, 100, 100, true>;
-        hipLaunchKernelGGL(head_scales_kernel, dim3(8), dim3(256), 0, stream, a, img, (int)LO::hs, 32, 100, 100);
-        RGL_LAUNCH_CHECK();
         hipLaunchKernelGGL((pack_images_kernel<32, 100, 100, true>), dim3((unsigned)((LO::scratch + kPackThreads - 1) / kPackThreads)),
                            dim3(kPackThreads), 0, stream, a, img);
     } else {
@@ -1136,10 +983,9 @@ inline int launch_pack_image(const FusedArgs& a, float* img, int mode, hipStream
     return RGL_OK;
 }
 
-// sized for the larger (f16-split) layout: one buffer size whatever the contraction mode
-constexpr size_t max3(size_t x, size_t y, size_t z) { return x > y ? (x > z ? x : z) : (y > z ? y : z); }
-constexpr size_t kImageFloats = max3(FusedLds<32, 100, 100, true>::scratch, FusedLds<32, 100, 100, false>::scratch,
-                                     FusedLds<32, 100, 100, false, true>::scratch);
+// sized for the larger layout: one buffer size whatever the contraction mode
+constexpr size_t max2(size_t x, size_t y) { return x > y ? x : y; }
+constexpr size_t kImageFloats = max2(FusedLds<32, 100, 100, false>::scratch, FusedLds<32, 100, 100, true>::scratch);
 constexpr size_t kImageBytes = (kImageFloats * sizeof(float) + 255) & ~(size_t)255;
 
 struct FusedPlan {
@@ -1147,9 +993,8 @@ struct FusedPlan {
     size_t lds_bytes;
     int grid;
     int hr, nt;
-    bool hx;                       // f16-split head (RGL_CONTRACT_F16X3)
     bool bx;                       // bf16 six-term hybrid of the last head matrix (RGL_CONTRACT_BF16X6)
-    int mode() const { return hx ? kModeHx : (bx ? kModeBx : kModeF32); }
+    int mode() const { return bx ? kModeBx : kModeF32; }
     bool ok;
 };
 
@@ -1253,16 +1098,15 @@ inline ItemPlan plan_items(int P, int n_full, int rem, int unit) {
     return best;
 }
 
-// hx: the f16-split head is wanted (RGL_CONTRACT_F16X3).  It exists for the softmax similarities; such a plan takes every launch
-// size (the two-stage pair has no f16-split head, and the packed image is in this kernel's layout only).
+// mode kModeBx: the six-term bf16 products are wanted (RGL_CONTRACT_BF16X6): such a plan takes every launch size (the two-stage pair
+// has no such head, and the packed image is in this kernel's layout only).
 inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A, int H, int unit = 1, int mode = kModeF32) {
     FusedPlan pl;
     pl.ok = false;
-    pl.hx = mode == kModeHx && fast_similarity_mode(g) == SIM_SOFTMAX;
     pl.bx = mode == kModeBx;                    // any similarity: the head does not depend on it
     if (!fast_path_enabled() || !rank1_enabled() || fused_policy() < 0) return pl;
     static const int min_tiles = env_int("RGL_FUSED_MIN_TILES", 1200);
-    if (!pl.hx && !pl.bx && fused_policy() == 0 && (long)P * ((A + 15) / 16) < min_tiles) return pl;
+    if (!pl.bx && fused_policy() == 0 && (long)P * ((A + 15) / 16) < min_tiles) return pl;
     if (fast_similarity_mode(g) < 0 || g.layerwise_graph || g.x_dim != XD || g.num_layer != 2) return pl;
     if (!mlp_is(g.w_r, 9, HID, XD, true) || !mlp_is(g.w_h, 5, HID, XD, true)) return pl;
     if (head_variant(head) != 0) return pl;
@@ -1286,8 +1130,7 @@ inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A,
         a.tail = TailArgs{};
         pl.grid = ip.grid;
     }
-    pl.lds_bytes = (size_t)((pl.hx ? FusedLds<32, 100, 100, true>::scratch
-                                   : pl.bx ? FusedLds<32, 100, 100, false, true>::scratch : FusedLds<32, 100, 100, false>::scratch) +
+    pl.lds_bytes = (size_t)((pl.bx ? FusedLds<32, 100, 100, true>::scratch : FusedLds<32, 100, 100, false>::scratch) +
                             kFusedWaves * fused_scratch_floats(pl.hr, pl.nt, a.sim == SIM_SOFTMAX) + 4) * sizeof(float);   // + the arrival counter of the image
     if (pl.lds_bytes > (size_t)rgl::kLdsBytesPerCu) return pl;
     a.wr1 = g.w_r.weight[0]; a.br1 = g.w_r.bias[0]; a.wr2 = g.w_r.weight[1]; a.br2 = g.w_r.bias[1];
@@ -1300,9 +1143,9 @@ inline FusedPlan plan_fused(const RglGraph& g, const RglMlp& head, int P, int A,
     return pl;
 }
 
-template <int HR, int NT, bool SKIP, bool SOFT, bool HX = false, bool BX = false>
+template <int HR, int NT, bool SKIP, bool SOFT, bool BX = false>
 int launch_fused_ts(const FusedPlan& pl, hipStream_t st) {
-    auto kern = children_fused_kernel<HR, NT, SKIP, SOFT, 32, 100, 100, HX, BX>;
+    auto kern = children_fused_kernel<HR, NT, SKIP, SOFT, 32, 100, 100, BX>;
     RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)pl.lds_bytes));
     const int grid = pl.grid;                        // persistent, one 8-wave workgroup per CU (LDS-bound)
@@ -1313,9 +1156,8 @@ int launch_fused_ts(const FusedPlan& pl, hipStream_t st) {
 
 template <int HR, int NT, bool SKIP>
 int launch_fused_t(const FusedPlan& pl, hipStream_t st) {
-    if (pl.hx) return launch_fused_ts<HR, NT, SKIP, true, true>(pl, st);          // plan_fused: softmax similarities only
-    if (pl.bx) return pl.a.sim == SIM_SOFTMAX ? launch_fused_ts<HR, NT, SKIP, true, false, true>(pl, st)
-                                              : launch_fused_ts<HR, NT, SKIP, false, false, true>(pl, st);
+    if (pl.bx) return pl.a.sim == SIM_SOFTMAX ? launch_fused_ts<HR, NT, SKIP, true, true>(pl, st)
+                                              : launch_fused_ts<HR, NT, SKIP, false, true>(pl, st);
     return pl.a.sim == SIM_SOFTMAX ? launch_fused_ts<HR, NT, SKIP, true>(pl, st) : launch_fused_ts<HR, NT, SKIP, false>(pl, st);
 }
 
@@ -1361,8 +1203,8 @@ const float* fused_workspace_image(const void* workspace, size_t workspace_bytes
 
 // 1 = the fused kernel does not apply (or the workspace cannot hold its images)
 int pack_children_images(const RglGraph* g, const RglMlp* head, int P, int A, int H, void* workspace, size_t workspace_bytes,
-                         hipStream_t stream, int hx) {
-    FusedPlan fp = plan_fused(*g, *head, P, A, H, 1, hx);                      // hx: kModeF32 / kModeHx / kModeBx
+                         hipStream_t stream, int mode) {
+    FusedPlan fp = plan_fused(*g, *head, P, A, H, 1, mode);                    // kModeF32 / kModeBx
     if (!fp.ok || !workspace || workspace_bytes < fused_children_workspace_bytes(P, A, H)) return 1;
     return launch_pack_image(fp.a, image_of(workspace, workspace_bytes), fp.mode(), stream);
 }
@@ -1371,7 +1213,7 @@ int pack_children_images(const RglGraph* g, const RglMlp* head, int P, int A, in
 int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, int H, const float* child_robot,
                           const float* humans_next, float* child_value, void* workspace, size_t workspace_bytes,
                           int image_ready, hipStream_t stream, const float* caller_image, const void* tail, size_t tail_bytes,
-                          int* tail_done, int hx) {
+                          int* tail_done, int mode) {
     if (tail_done) *tail_done = 0;
     // the search's tail: selection always; the back-up chain + root step at the deepest level when handing whole roots to
     // workgroups does not starve the GPU (few roots with many parents each -- unclipped deep searches -- keep unit = 1)
@@ -1389,11 +1231,11 @@ int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, i
             chain = 1;
         }
     }
-    FusedPlan fp = plan_fused(*g, *head, P, A, H, unit, hx);
-    // the split-f16 image is 7 KB larger: crowds of 21..32 agents (lane = feature row pass, larger wave scratch) do not fit a CU
+    FusedPlan fp = plan_fused(*g, *head, P, A, H, unit, mode);
+    // the bf16 hybrid image is larger: crowds of 21..32 agents (lane = feature row pass, larger wave scratch) do not fit a CU
     // with it -- they run the f32 form of this kernel on an f32 image packed here (the caller's image is in the other layout)
     bool own_image = false;
-    if (!fp.ok && hx) {                          // (the same for the bf16 hybrid image, 7 KB larger as well)
+    if (!fp.ok && mode) {
         fp = plan_fused(*g, *head, P, A, H, unit, kModeF32);
         own_image = fp.ok;
     }
@@ -1423,7 +1265,7 @@ int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, i
 
 }  // namespace rgl
 
-// The image depends on the weights (and on the contraction mode: f16-split head fragments for RGL_CONTRACT_F16X3) only: a caller
+// The image depends on the weights (and on the contraction mode: three-piece bf16 fragments for RGL_CONTRACT_BF16X6) only: a caller
 // with fixed weights packs it once (MprlPlanner::children_image).
 // Outside the fused kernel's envelope (three layers, crowds beyond 32 agents) the image still serves the stage-2 head -- launched
 // on its own or run by children_deep_kernel behind its parents -- as long as the shipped head and embedding shapes are there: the
@@ -1442,7 +1284,7 @@ static bool head_image_args(const RglGraph& g, const RglMlp& head, FusedArgs& a)
 }
 
 static int image_mode_of(const MprlPlanner* planner) {
-    return planner->contraction_dtype == RGL_CONTRACT_F16X3 ? kModeHx : (planner->contraction_dtype == RGL_CONTRACT_BF16X6 ? kModeBx : kModeF32);
+    return planner->contraction_dtype == RGL_CONTRACT_BF16X6 ? kModeBx : kModeF32;
 }
 
 extern "C" size_t mprl_children_image_bytes(const MprlPlanner* planner) {
@@ -1459,7 +1301,7 @@ extern "C" int mprl_pack_children_image_f32(const MprlPlanner* planner, float* i
     FusedPlan fp = plan_fused(planner->value_graph, planner->value_head, 4096, 16, 1, 1, mode);
     if (!fp.ok) {
         if (mode != kModeF32 || !head_image_args(planner->value_graph, planner->value_head, fp.a)) return RGL_ERR_BAD_MODE;
-        fp.hx = fp.bx = false;
+        fp.bx = false;
     }
     if (image_bytes < kImageBytes) return RGL_ERR_WORKSPACE;
     return launch_pack_image(fp.a, image, fp.mode(), (hipStream_t)stream);

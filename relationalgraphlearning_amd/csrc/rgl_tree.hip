@@ -451,7 +451,7 @@ int tree_search(const MprlPlanner* planner, const float* robot, const float* hum
 
     // weight images of the value-of-children kernels: prepared once, every level copies them into LDS (0 = prepared)
     // (or handed in by the caller, packed once for fixed weights: MprlPlanner::children_image)
-    const int image_mode = pl.contraction_dtype == RGL_CONTRACT_F16X3 ? 1 : (pl.contraction_dtype == RGL_CONTRACT_BF16X6 ? 2 : 0);
+    const int image_mode = pl.contraction_dtype == RGL_CONTRACT_BF16X6 ? 2 : 0;
     const int image_ready = (pl.contraction_dtype == RGL_CONTRACT_F32 || image_mode != 0) &&
                             (pl.children_image != nullptr ||
                              rgl::pack_children_images(&pl.value_graph, &pl.value_head, (int)lv[D - 1].P, A, H, ws + scratch_off,

@@ -65,7 +65,7 @@ class TreeSearch:
         self.last = None            # outputs of the most recent search (device tensors)
         self._decisions = {}        # (H, device) -> captured single-scene search (decide())
         self._images = {}           # device -> (parameter-state key, weight image of the value-of-children kernel)
-        self._sp_images = {}        # device -> (parameter-state key, split-f16 weight image of the state predictor's scene kernel)
+        self._sp_images = {}        # device -> (parameter-state key, three-piece bf16 weight image of the state predictor's scene kernel)
 
     # -- descriptors -----------------------------------------------------------------------------
     @property
@@ -118,6 +118,9 @@ class TreeSearch:
         mode = self.contraction_dtype
         if mode == "f32" and os.environ.get("RGL_CONTRACT_F32_AS"):
             mode = os.environ["RGL_CONTRACT_F32_AS"]
+        if mode not in nat.CONTRACTION_DTYPES:
+            raise ValueError("contraction mode %r (contraction_dtype / RGL_CONTRACT_F32_AS): one of %s"
+                             % (mode, sorted(nat.CONTRACTION_DTYPES)))
         pl.contraction_dtype = nat.CONTRACTION_DTYPES[mode]
         pl.time_step = self.time_step
         pl.gamma_bar = self.gamma_bar
@@ -126,13 +129,13 @@ class TreeSearch:
         pl.action_groups = None if grp is None else grp.data_ptr()
         image = self._children_image(pl, device)
         pl.children_image = None if image is None else image.data_ptr()
-        if not linear and mode in ("f16x3", "bf16x6"):
+        if not linear and mode == "bf16x6":
             image = self._predictor_image(pl, device)
             pl.predictor_image = None if image is None else image.data_ptr()
         return pl
 
     def _predictor_image(self, pl, device):
-        """MprlPlanner.predictor_image (ABI 4): the state predictor's scene-kernel weight image in the split-f16 layout, packed
+        """MprlPlanner.predictor_image (ABI 4): the state predictor's scene-kernel weight image in the three-piece bf16 layout, packed
         when the predictor's descriptors were (re)built, into the same device buffer every time.  None when the mode or the
         predictor has no such kernel."""
         sp = self.state_predictor
@@ -160,7 +163,7 @@ class TreeSearch:
         ve = self.value_estimator
         gcache, hcache = ve.graph_model._cache, ve._cache
         # process-wide pack serials (nets._PACK_SERIAL) identify the parameter state; the image's LAYOUT depends on the
-        # contraction mode (f32 matrices vs split-f16 fragments, same byte size): a mode changed on a live object repacks
+        # contraction mode (f32 matrices vs three-piece bf16 fragments, same byte size): a mode changed on a live object repacks
         key = (gcache.epoch, hcache.epoch, self.contraction_dtype, os.environ.get("RGL_CONTRACT_F32_AS"))
         dkey = str(device)
         ent = self._images.get(dkey)

@@ -190,6 +190,14 @@ def _new_optimizer(kind, module, learning_rate, capturable, predictor_side=False
     return optimizer
 
 
+def _loss_signature(trainer):
+    """What the loss end of a captured step bakes in: gamma_bar's ingredients (passed to rgl_mse_step_f32 by value when the step
+    is recorded) and the criterion (its type and reduction select the fused loss or the torch one while recording)."""
+    crit = trainer.criterion
+    return (float(trainer.gamma), float(trainer.time_step) if trainer.time_step is not None else None,
+            float(trainer.v_pref) if trainer.v_pref is not None else None, id(crit), type(crit), getattr(crit, "reduction", None))
+
+
 def _log_learning_rate(learning_rate, modules, kind):
     """The line upstream logs from set_learning_rate (its format is part of the contract: logs are diffed against upstream runs)."""
     names = [name for m in modules for name, _ in m.named_parameters()]
@@ -332,6 +340,8 @@ class MPRLTrainer(_TrainerBase):
             with torch.no_grad():
                 for dst, src in zip(self.target_model.parameters(), target_model.parameters()):
                     dst.copy_(src)
+                for dst, src in zip(self.target_model.buffers(), target_model.buffers()):      # what deepcopy would snapshot as well
+                    dst.copy_(src)
             if next(self.target_model.parameters()).is_cuda:
                 invalidate_packed_weights(self.target_model)
                 self._refresh_packed(self.target_model)
@@ -341,8 +351,15 @@ class MPRLTrainer(_TrainerBase):
 
     @staticmethod
     def _same_structure(a, b):
-        pa, pb = list(a.parameters()), list(b.parameters())
-        return len(pa) == len(pb) and all(x.shape == y.shape and x.device == y.device for x, y in zip(pa, pb))
+        """Same module classes in the same order, same parameter / buffer shapes, dtypes and devices: only then may the in-place
+        copy stand in for upstream's `copy.deepcopy` (anything else falls back to it and drops the captured steps)."""
+        ma, mb = list(a.modules()), list(b.modules())
+        if len(ma) != len(mb) or any(type(x) is not type(y) for x, y in zip(ma, mb)):
+            return False
+        for ta, tb in ((list(a.parameters()), list(b.parameters())), (list(a.buffers()), list(b.buffers()))):
+            if len(ta) != len(tb) or any(x.shape != y.shape or x.dtype != y.dtype or x.device != y.device for x, y in zip(ta, tb)):
+                return False
+        return True
 
     @staticmethod
     def _refresh_packed(model):
@@ -398,8 +415,10 @@ class MPRLTrainer(_TrainerBase):
 
     # -- the two kinds of step ---------------------------------------------------------------------------------------------------
     def _signature(self):
+        # everything a recorded step bakes in by value or by identity: upstream re-reads gamma / time_step / v_pref and the criterion
+        # on every batch (crowd_nav/utils/trainer.py:128-131), so a change of any of them must force a new recording
         return (id(self.v_optimizer), id(self.s_optimizer), id(self.target_model), id(self.value_estimator), id(self.state_predictor),
-                bool(self.detach_state_predictor))
+                bool(self.detach_state_predictor)) + _loss_signature(self)
 
     def _value_step(self, robot_states, human_states, target=None, bootstrap=None):
         """One value update; `bootstrap()` -> (rewards, next values, gamma_bar) is evaluated after the forward, like upstream's
@@ -534,7 +553,7 @@ class VNRLTrainer(_TrainerBase):
             yield data
 
     def _signature(self):
-        return (id(self.optimizer), id(self.target_model), id(self.model))
+        return (id(self.optimizer), id(self.target_model), id(self.model)) + _loss_signature(self)
 
     def _step(self, inputs, lengths, target=None, bootstrap=None):
         self.optimizer.zero_grad()

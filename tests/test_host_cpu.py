@@ -47,9 +47,9 @@ def test_contraction_modes_and_level_view_match_the_header():
     root's tensor-born reward array (reward_clip_off) at level 0 of a clipped search only."""
     hdr = open(os.path.join(ROOT, "include", "rgl_hip.h")).read()
     consts = {name: int(val) for name, val in re.findall(r"#define (RGL_CONTRACT_\w+)\s+(\d+)", hdr)}
-    assert consts == {"RGL_CONTRACT_F32": 0, "RGL_CONTRACT_F16": 1, "RGL_CONTRACT_F16X3": 2, "RGL_CONTRACT_BF16X6": 3}
-    assert nat.CONTRACTION_DTYPES == {"f32": 0, "f16": 1, "f16x3": 2, "bf16x6": 3}
-    assert int(re.search(r"#define RGL_ABI_VERSION (\d+)", hdr).group(1)) == nat.ABI_VERSION == 7
+    assert consts == {"RGL_CONTRACT_F32": 0, "RGL_CONTRACT_F16": 1, "RGL_CONTRACT_BF16X6": 3}      # 2 (F16X3) left with ABI 8
+    assert nat.CONTRACTION_DTYPES == {"f32": 0, "f16": 1, "bf16x6": 3}
+    assert int(re.search(r"#define RGL_ABI_VERSION (\d+)", hdr).group(1)) == nat.ABI_VERSION == 8
     lib = nat.lib()
     pl = nat.MprlPlanner()
     pl.planning_depth, pl.planning_width, pl.num_actions, pl.do_action_clip = 2, 2, 81, 1

@@ -17,7 +17,7 @@ run --humans 49 --layers 3 --roots 256
 run --humans 49 --layers 3 --roots 256 --contraction f16
 run --contraction f32 --steps 50
 run --depth 3 --roots 512 --contraction f32
-run --contraction f16x3 --steps 50
+
 python tools/kiter.py > $O/${TAG}_pair_by_size_dispatch.txt 2>&1
 RGL_CHILDREN_FUSED=1 python tools/kiter.py --quick > $O/${TAG}_pair_by_size_fused.txt 2>&1
 RGL_CHILDREN_TWO_STAGE=1 python tools/kiter.py --quick > $O/${TAG}_pair_by_size_two_stage.txt 2>&1

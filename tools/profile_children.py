@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--humans", type=int, default=19)
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--contraction", choices=("f32", "f16", "f16x3", "bf16x6"), default="bf16x6",
+    ap.add_argument("--contraction", choices=("f32", "f16", "bf16x6"), default="bf16x6",
                     help="default: the mode bench.py's `value` runs in for this shape (--contraction auto)")
     ap.add_argument("--tree", action="store_true", help="run whole tree searches instead of the kernel pair")
     args = ap.parse_args()
