@@ -75,6 +75,8 @@ struct FusedArgs {
 };
 
 constexpr int kFusedWaves = 8;
+static_assert(B6Floats<HID, XD>::v == HID * XD * 3 / 2 && B6Floats<XD, XD>::v == XD * XD * 3 / 2, "FusedLds sizes its BX matrices so");
+static_assert((FusedLds<32, 100, 100, true>::scratch + kFusedWaves * 1344 + 4) * 4 <= 160 * 1024, "the BX image + 8 wave scratches fit a CU");
 
 
 // h = relu(t W_last)(+hprev), value head 32 -> D1 -> D2 -> D3 -> 1 for the 16 children of a tile (lane (n, q): child n, D-layout
@@ -271,6 +273,8 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                 xq[pct][ot] = xa[ot];
             }
             f32x4 pg[2] = {zero4(), zero4()};
+            if constexpr (BX) layer_mfma_b6<XD, XD, false>(wa, xa, pg, lane);
+            else {
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
                 load_fence();
@@ -281,6 +285,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                         pg[gt] = mfma4(wa[(16 * ot + 4 * q + r) * WLD + 16 * gt + n], xa[ot][r], pg[gt]);
             }
             load_fence();
+            }
             gq[pct][0] = pg[0];
             gq[pct][1] = pg[1];
             }
@@ -352,6 +357,8 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                     u[0] = mfma4(xt[jt][0][r], e[jt][r], u[0]);                               // U^T[f][i] = sum_j Xh[j][f] E[i][j]
                     u[1] = mfma4(xt[jt][1][r], e[jt][r], u[1]);
                 }
+            if constexpr (BX) layer_mfma_b6<XD, XD, false>(w1, u, uw, lane);
+            else {
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
                 load_fence();
@@ -362,6 +369,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
                         uw[ot] = mfma4(w1[(16 * ft + 4 * q + r) * WLD + 16 * ot + n], u[ft][r], uw[ot]);
             }
             load_fence();
+            }
             }
             if constexpr (PK) {                                                              // UW rows over the (consumed) Xh rows
                 if (node < HRL) {
@@ -477,7 +485,18 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hacc[ht][r] = relu1(hacc[ht][r] + bb[r]);
             }
-            {
+            if constexpr (BX) {
+                // round 6: the tile chain's weight products -- hidden -> x0 (64 x 32), x0 Wa, x0 W1 -- as six bf16 terms over three-piece
+                // operands too (fragments in the image where the f32 matrices were; x0 is split once for both products)
+                layer_mfma_b6<HID, XD, true>(wr2, hacc, xacc, lane, br2);
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xacc[ot][r] = relu1(xacc[ot][r]);
+                const Split3 sx = split3_pair(xacc[0], xacc[1]);
+                layer_mfma_b6_pre<XD, false>(wa, sx, gacc, lane);
+                layer_mfma_b6_pre<XD, false>(w1, sx, yacc, lane);
+            } else {
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) {
                 load_fence();
@@ -732,7 +751,14 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         f32x4 tin[2], hp[2];
         {
             f32x4 o[2] = {zero4(), zero4()};
-            {
+            if constexpr (BX) {
+                f32x4 tb[2];
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tb[ft][r] = fmaf(p00, xacc[ft][r], t0h[ft][r]);      // T_0 = p_c Xh + p_c[0] x0_c
+                layer_mfma_b6<XD, XD, false>(w1, tb, o, lane);
+            } else {
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
                 load_fence();
@@ -867,9 +893,10 @@ __device__ __forceinline__ float matrix_element(const float* __restrict__ W, int
 template <int IN, int OUT>
 __device__ __forceinline__ float bx_element(const float* __restrict__ W, int idx) {
     using BL = BxLayout<IN, OUT>;
-    if (idx >= BL::p4) {
-        const int j = idx - BL::p4;
-        return frag_element<IN, OUT>(W, (BL::OTF * BL::IT * 4 + (j >> 6)) * 64 + (j & 63));            // partial tile: k step = it * 4 + r
+    if (idx >= BL::p4) {                                           // partial tile, compact: row (q, lane % 4), k step = it * 4 + r
+        using PC = P4Compact<BL::KP>;
+        const int j = idx - BL::p4, row = j / PC::KPAD, ks = j - row * PC::KPAD;
+        return ks < BL::KP ? frag_element<IN, OUT>(W, (BL::OTF * BL::IT * 4 + ks) * 64 + 16 * (row >> 2) + (row & 3)) : 0.f;
     }
     if (idx >= BL::f32) {
         const int j = idx - BL::f32, l = j & 63, slot = j >> 6;                          // slot: k steps of the output tiles, in order
@@ -905,9 +932,10 @@ __device__ __forceinline__ float bx_element(const float* __restrict__ W, int idx
 template <int IN, int OUT>
 __device__ __forceinline__ float bx1_element(const float* __restrict__ W, int idx) {
     using BL = Bx1Layout<IN, OUT>;
-    if (idx >= BL::p4) {
-        const int j = idx - BL::p4;
-        return frag_element<IN, OUT>(W, (BL::OTF * Tiles<IN>::v * 4 + (j >> 6)) * 64 + (j & 63));        // partial tile: k step = it * 4 + r
+    if (idx >= BL::p4) {                                           // partial tile, compact: row (q, lane % 4), k step = it * 4 + r
+        using PC = P4Compact<BL::KP>;
+        const int j = idx - BL::p4, row = j / PC::KPAD, ks = j - row * PC::KPAD;
+        return ks < BL::KP ? frag_element<IN, OUT>(W, (BL::OTF * Tiles<IN>::v * 4 + ks) * 64 + 16 * (row >> 2) + (row & 3)) : 0.f;
     }
     const int u = idx >> 2, p = idx & 3, l = u & 63, rest = u >> 6;
     const int pc = rest % 3, ot = rest / 3, q = l >> 4, out = frag_out_feature<OUT>(ot, l);
@@ -934,13 +962,16 @@ __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedAr
     if (e < LO::br1) v = matrix_element<9, HID, W1LD>(a.wr1, e - LO::wr1);
     else if (e < LO::wr2) v = a.br1[e - LO::br1];
     else if (e < LO::br2) {
-        v = matrix_element<HID, XD, WLD>(a.wr2, e - LO::wr2);
+        if constexpr (BX) v = frag_bf3_ld<HID, XD>(a.wr2, XD, XD, e - LO::wr2);
+        else v = matrix_element<HID, XD, WLD>(a.wr2, e - LO::wr2);
     } else if (e < LO::wa) v = a.br2[e - LO::br2];
     else if (e < LO::w1) {
         const int k = e - LO::wa, r = k / WLD, col = k - r * WLD;
-        v = a.wa ? matrix_element<XD, XD, WLD>(a.wa, k) : ((col < XD && r == col) ? 1.f : 0.f);      // gaussian: Wa = I
+        if constexpr (BX) v = a.wa ? frag_bf3_ld<XD, XD>(a.wa, XD, XD, k) : frag_bf3_identity<XD>(k);      // gaussian: Wa = I
+        else v = a.wa ? matrix_element<XD, XD, WLD>(a.wa, k) : ((col < XD && r == col) ? 1.f : 0.f);      // gaussian: Wa = I
     } else if (e < LO::wh1) {
-        v = matrix_element<XD, XD, WLD>(a.w1, e - LO::w1);
+        if constexpr (BX) v = frag_bf3_ld<XD, XD>(a.w1, XD, XD, e - LO::w1);
+        else v = matrix_element<XD, XD, WLD>(a.w1, e - LO::w1);
     } else if (e < LO::bh1) v = matrix_element<5, HID, LO::WH1LD>(a.wh1, e - LO::wh1);
     else if (e < LO::wh2) v = a.bh1[e - LO::bh1];
     else if (e < LO::bh2) {

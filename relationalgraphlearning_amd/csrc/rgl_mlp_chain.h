@@ -174,7 +174,28 @@ struct HeadFragFloats {
 // input features 96.., the partial output tiles and the two 32 x 32 layers stay on the f32 MFMA
 // (profiles/r05_micro_bf16x3_split.txt: the whole head in this form would be 1.67x, and needs +44 KB).
 // Layout of the f3 region: [ot < OTF][chunk < 2][hi | mid | lo][lane] x 8 bf16  |  f32 fragments [ot < OTF][k step of input tiles
-// 4..][lane]  |  the partial output tile's 4 x 4 x 1 fragments [k step][lane].
+// 4..][lane]  |  the partial output tile's 4 x 4 x 1 fragments, compact (P4Compact).
+// The A operand of a 4 x 4 x 1 block row holds 16 distinct values per k step -- A row = lane % 4, k slot = lane / 16; the four blocks
+// n / 4 of a k-group repeat them -- so a partial output tile's fragments are stored COMPACT (round 6): row (q, lane % 4) of KPAD
+// floats, k steps consecutive, read as b128 (four k steps per load, the rows of a 16-lane access group on disjoint banks).  A quarter of the 64-floats-per-k-step form and a quarter of its LDS reads.
+template <int KP>
+struct P4Compact {
+    static constexpr int KV = (KP + 3) / 4;                         // b128 loads per lane
+    // a 16-lane access group of ds_read_b128 meets 8 distinct rows: their 4-bank windows (row * KPAD mod 64) must not overlap
+    __host__ __device__ static constexpr bool disjoint(int kpad) {
+        for (int r = 0; r < 8; ++r)
+            for (int t = r + 1; t < 8; ++t) {
+                const int d = ((t - r) * kpad) % 64;
+                if (d < 4 || d > 60) return false;
+            }
+        return true;
+    }
+    static constexpr int KPAD = disjoint(4 * KV) ? 4 * KV : (disjoint(4 * KV + 4) ? 4 * KV + 4 : 4 * KV + 8);
+    static_assert(disjoint(KPAD), "bank-conflict-free row stride");
+    static constexpr int floats = 16 * KPAD;
+    __host__ __device__ static constexpr int row_of_lane(int lane) { return 4 * (lane >> 4) + (lane & 3); }
+};
+
 template <int IN, int OUT>
 struct BxLayout {
     static constexpr int IT = Tiles<IN>::v, OT = Tiles<OUT>::v;
@@ -191,12 +212,12 @@ struct BxLayout {
     static constexpr int f32 = b16c + OT3 * 3 * 64 * 4;
     __host__ __device__ static constexpr int f32_of(int ot) { return f32 + (ot < OT3 ? ot * KF3 : OT3 * KF3 + (ot - OT3) * KF) * 64; }
     static constexpr int p4 = f32 + (OT3 * KF3 + (OTF - OT3) * KF) * 64;
-    static constexpr int total = p4 + (P4 ? KP * 64 : 0);
+    static constexpr int total = p4 + (P4 ? P4Compact<KP>::floats : 0);
     static_assert(IT > ITB, "input tiles 0..3 are full tiles and there is at least one tile beyond them");
 };
 
 // The same for a layer whose whole input is ONE K = 32 chunk (the 32 -> 100 head layer): [ot < OTF][hi | mid | lo][lane] x 8 bf16, then
-// the partial output tile's 4 x 4 x 1 fragments [k step][lane] (f32).
+// the partial output tile's 4 x 4 x 1 fragments, compact (f32).
 template <int IN, int OUT>
 struct Bx1Layout {
     static_assert(IN == 32, "one chunk");
@@ -206,7 +227,7 @@ struct Bx1Layout {
     static constexpr int KP = IN / 4;
     static constexpr int b16 = 0;
     static constexpr int p4 = b16 + OTF * 3 * 64 * 4;
-    static constexpr int total = p4 + (P4 ? KP * 64 : 0);
+    static constexpr int total = p4 + (P4 ? P4Compact<KP>::floats : 0);
 };
 
 template <int D1, int D2, int D3, bool BX = false>
@@ -215,11 +236,13 @@ struct FusedLds {
     static constexpr int wr1 = 0;
     static constexpr int br1 = wr1 + 12 * W1LD;
     static constexpr int wr2 = br1 + HID;
-    static constexpr int br2 = wr2 + HID * WLD;
+    // BX (round 6): wr2, wa, w1 as three-piece bf16 fragments (layer_mfma_b6's layout: 6 bytes per weight instead of 4.5 with the
+    // padded f32 rows) -- the room comes from the compact partial-tile fragments of the head (P4Compact)
+    static constexpr int br2 = wr2 + (BX ? HID * XD * 3 / 2 : HID * WLD);
     static constexpr int wa = br2 + XD;
-    static constexpr int w1 = wa + XD * WLD;
+    static constexpr int w1 = wa + (BX ? XD * XD * 3 / 2 : XD * WLD);
     // crowd side: w_h
-    static constexpr int wh1 = w1 + XD * WLD;
+    static constexpr int wh1 = w1 + (BX ? XD * XD * 3 / 2 : XD * WLD);
     static constexpr int WH1LD = BX ? 72 : W1LD;                    // BX: w_h's first matrix at row stride 72 (k-groups 8 banks apart: two
                                                                    // lanes per bank, as at 80) -- the 64 floats its image needs for ...
     static constexpr int bh1 = wh1 + 8 * WH1LD;
@@ -343,6 +366,34 @@ __device__ __forceinline__ Split3 split3_pair(const f32x4& ta, const f32x4& tb) 
     return split3_rn<2, 0>(pair);
 }
 
+// The <= 4 features of a partial output tile from compact fragments (P4Compact): lane (n, q) gets feature 16 OTF + q's pre-bias sum in
+// its return value.  k step ks = 4 it + r (steps over the padding of a partial last INPUT tile are not stored); two accumulators so
+// that consecutive 4 x 4 x 1 MFMAs do not wait for each other; the loads go out in batches of four b128 (16 VGPRs).
+template <int IN, int KP>
+__device__ __forceinline__ float partial4_compact(const float* frags, const f32x4 (&in)[Tiles<IN>::v], int lane) {
+    using PC = P4Compact<KP>;
+    constexpr int IT = Tiles<IN>::v;
+    const f32x4* row = reinterpret_cast<const f32x4*>(frags + PC::row_of_lane(lane) * PC::KPAD);
+    f32x4 p4[2] = {zero4(), zero4()};
+#pragma unroll
+    for (int v0 = 0; v0 < PC::KV; v0 += 4) {
+        load_fence();
+        f32x4 w[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if (v0 + v < PC::KV) w[v] = row[v0 + v];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ks = 4 * (v0 + v) + r;                      // == 4 it + r: full input tiles before the last take 4 steps each
+                if (v0 + v < PC::KV && ks < KP) p4[r & 1] = mfma4x4(w[v][r], in[(v0 + v) < IT ? (v0 + v) : 0][r], p4[r & 1]);
+            }
+    }
+    load_fence();
+    return kgroups_reduce_scatter(p4[0] + p4[1]);
+}
+
 // Register budget (the kernel around it holds ~100 VGPRs of crowd quantities across the tile loop and sits at 225 of 256 in its
 // f32 form): the partial output tile FIRST -- it is the only consumer of input tiles 0..3 besides their split -- then one chunk at a
 // time (its two input tiles die in the split), two output tiles per fragment load, then the f32 k steps of the remaining tiles.
@@ -363,18 +414,7 @@ __device__ __forceinline__ void layer_mfma_bx(const float* frags, const f32x4 (&
     const lds_b fq = (lds_b)(size_t)o128;
     float v4 = 0.f;
     if constexpr (BL::P4) {
-        f32x4 p4[2] = {zero4(), zero4()};
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            load_fence();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (it == IT - 1 && r >= LastTileSteps<IN>::v) continue;
-                p4[r & 1] = mfma4x4(fl[BL::p4 + (it * 4 + r) * 64], in[it][r], p4[r & 1]);
-            }
-        }
-        load_fence();
-        v4 = kgroups_reduce_scatter(p4[0] + p4[1]);
+        v4 = partial4_compact<IN, BL::KP>(frags + BL::p4, in, lane);
         if constexpr (BIAS) v4 += bias[16 * OTF + 4 * q];
     }
 #pragma unroll
@@ -463,15 +503,7 @@ __device__ __forceinline__ void layer_mfma_bx1(const float* frags, const f32x4 (
     const int q = lane >> 4;
     float v4 = 0.f;
     if constexpr (BL::P4) {
-        f32x4 p4[2] = {zero4(), zero4()};
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            load_fence();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) p4[r & 1] = mfma4x4(frags[BL::p4 + (it * 4 + r) * 64 + lane], in[it][r], p4[r & 1]);
-        }
-        load_fence();
-        v4 = kgroups_reduce_scatter(p4[0] + p4[1]);
+        v4 = partial4_compact<IN, BL::KP>(frags + BL::p4, in, lane);
         if constexpr (BIAS) v4 += bias[16 * OTF + 4 * q];
     }
 #pragma unroll
@@ -552,6 +584,41 @@ __device__ __forceinline__ void layer_mfma_b6(const float* frags, const f32x4 (&
     load_fence();
 }
 
+// The same with the ONE chunk of a 32-wide input already split (x0 of a tile feeds Wa and W1: one split, two products)
+template <int OUT, bool BIAS>
+__device__ __forceinline__ void layer_mfma_b6_pre(const float* frags, const Split3& s, f32x4 (&out)[Tiles<OUT>::v], int lane,
+                                                  const float* bias = nullptr) {
+    constexpr int OT = Tiles<OUT>::v;
+    const int q = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+        if constexpr (BIAS) out[ot] = *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * q]);
+        else out[ot] = zero4();
+    }
+    constexpr int G = 2;
+#pragma unroll
+    for (int o0 = 0; o0 < OT; o0 += G) {
+        load_fence();
+        bf16x8 w[G][3];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                if (o0 + g < OT) w[g][pc] = *reinterpret_cast<const bf16x8*>(&frags[(((o0 + g) * 3 + pc) * 64 + lane) * 4]);
+#define RGL_B6_TERM(WP, AP)                                                                                         \
+    _Pragma("unroll") for (int g = 0; g < G; ++g)                                                                   \
+        if (o0 + g < OT) out[o0 + g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g][WP], s.AP, out[o0 + g], 0, 0, 0);
+        RGL_B6_TERM(2, h)
+        RGL_B6_TERM(1, m)
+        RGL_B6_TERM(0, l)
+        RGL_B6_TERM(1, h)
+        RGL_B6_TERM(0, m)
+        RGL_B6_TERM(0, h)
+#undef RGL_B6_TERM
+    }
+    load_fence();
+}
+
 // float slot `idx` of the fragment image layer_mfma_b6 reads, for a k-major matrix W[in * ld + out] (columns >= n_out: 0): a pair of
 // bf16 pieces.  Unit u = idx / 4 = ((ot NC + c) 3 + piece) 64 + lane; element e of it is W[in = 16 (2c + e / 4) + 4 q + e % 4][out of
 // A-operand row lane % 16] -- hi = bf16(w), mid = bf16(w - hi), lo = w - hi - mid (exact).
@@ -574,6 +641,22 @@ __device__ __forceinline__ float frag_bf3_ld(const float* __restrict__ W, int ld
         const __bf16 mid = (__bf16)r1;
         const __bf16 lo = (__bf16)(r1 - (float)mid);
         v[k] = pc == 0 ? hi : (pc == 1 ? mid : lo);
+    }
+    return __builtin_bit_cast(float, v);
+}
+
+// the identity matrix in that layout (gaussian similarity: Wa = I): hi piece 1 on the diagonal
+template <int D>
+__device__ __forceinline__ float frag_bf3_identity(int idx) {
+    constexpr int IT = Tiles<D>::v, NC = (IT + 1) / 2;
+    const int u = idx >> 2, p = idx & 3;
+    const int l = u & 63, rest = u >> 6;
+    const int pc = rest % 3, c = (rest / 3) % NC, ot = rest / 3 / NC;
+    bf16x2 v;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = 2 * p + k, in = 16 * (2 * c + (e >> 2)) + 4 * (l >> 4) + (e & 3), out = 16 * ot + (l & 15);
+        v[k] = (__bf16)((pc == 0 && in == out) ? 1.f : 0.f);
     }
     return __builtin_bit_cast(float, v);
 }
