@@ -198,6 +198,8 @@ __device__ __forceinline__ void children_pa(const ChildrenArgs& ca, int p, int a
         c[2] = (float)((double)cs * a0);
         c[3] = (float)((double)sn * a0);
     }
+    // (the nine strided dword stores per lane are not what the launch waits for: without them the level-0 embedding + reward launch
+    // of a 2048-root step takes 15.3 instead of 16.3 us -- profiles/r06_d_timeline_child_store_ab.md)
     float* co = ca.child_robot + (size_t)idx * 9;
 #pragma unroll
     for (int i = 0; i < 9; ++i) co[i] = c[i];

@@ -71,6 +71,9 @@ struct FusedArgs {
     int image_sync;               // measurements: stage the whole weight image through registers before anything else (round 3)
     int inline_partial;           // few parents per workgroup: the partial tile is an ordinary (padded) tile with its own head
                                   // instead of a row hand-off to the tile-packed pass at the end (a barrier + a serial head)
+    int phase_delay;              // measurements (RGL_FUSED_PHASE_DELAY): waves 4..7 start this many 512-cycle sleeps late
+    int prio;                     // RGL_FUSED_PRIO: bit 1 (default) = s_setprio 2 inside the head: -0.6 % / -1.3 % at 2048 / 4096 parents; bit 0
+                                  // (measurements) = static s_setprio 1 for waves 4..7: nothing (profiles/r06_c_phase_prio_ab.txt)
     TailArgs tail;                // tail.enabled: select (+ back-up chain + root step) for the owned parents at the end
 };
 
@@ -449,6 +452,10 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
         asm volatile("" ::: "memory");
         image_complete = true;
     };
+    if (wave >= 4) {
+        for (int i = 0; i < a.phase_delay; ++i) __builtin_amdgcn_s_sleep(8);
+        if (a.prio & 1) __builtin_amdgcn_s_setprio(1);
+    }
     PHASE_START();
     for (int pass = 0; pass < n_pass; ++pass) {
         const int wi = item_at(pass);
@@ -803,7 +810,9 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
 
         // ---------------- last GCN layer on the robot row + value head: one register-resident MFMA chain -------------------
         await_image();
+        if (a.prio & 2) __builtin_amdgcn_s_setprio(2);
         const float v = head_chain<LO, D1, D2, D3, SKIP, BX>(lds, tin, hp, lane);
+        if (a.prio & 2) { if ((a.prio & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         if (q == 0 && c < A) a.value[(size_t)p * A + c] = v + hb4;
         PHASE_MARK(6);
       }
@@ -1285,6 +1294,9 @@ int launch_fused_children(const RglGraph* g, const RglMlp* head, int P, int A, i
     fp.a.rows_left = rows_left;
     static const int image_sync = env_int("RGL_FUSED_IMAGE_SYNC", 0);
     fp.a.image_sync = image_sync;
+    static const int phase_delay = env_int("RGL_FUSED_PHASE_DELAY", 0), prio = env_int("RGL_FUSED_PRIO", 2);
+    fp.a.phase_delay = phase_delay;
+    fp.a.prio = prio;
     if (ta) {
         fp.a.tail = *ta;
         fp.a.tail.chain = chain;

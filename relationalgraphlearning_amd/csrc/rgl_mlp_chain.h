@@ -394,18 +394,35 @@ __device__ __forceinline__ float partial4_compact(const float* frags, const f32x
     return kgroups_reduce_scatter(p4[0] + p4[1]);
 }
 
-// Register budget (the kernel around it holds ~100 VGPRs of crowd quantities across the tile loop and sits at 225 of 256 in its
-// f32 form): the partial output tile FIRST -- it is the only consumer of input tiles 0..3 besides their split -- then one chunk at a
-// time (its two input tiles die in the split), two output tiles per fragment load, then the f32 k steps of the remaining tiles.
+// pieces of one pair of D-layout elements (a "unit" of a K = 32 chunk: word p of the hi / mid / lo operands)
+__device__ __forceinline__ void split3_unit(f32x2 x, unsigned& H, unsigned& M, unsigned& L) {
+    const bf16x2 h = __builtin_convertvector(x, bf16x2);
+    const f32x2 r1 = x - __builtin_convertvector(h, f32x2);
+    const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+    const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+    H = __builtin_bit_cast(unsigned, h);
+    M = __builtin_bit_cast(unsigned, m);
+    L = __builtin_bit_cast(unsigned, l);
+}
+
+// The D2 x D3 head layer (BxLayout) as a software pipeline (round 6).  Register budget: the kernel around it holds ~100 VGPRs of crowd
+// quantities across the tile loop; the partial output tile goes FIRST (it reads every input tile), then one chunk at a time, two
+// output tiles per fragment load, then the f32 k steps that are left.  tools/micro/pipe_overlap.hip: ONE wave that issues up to two plain VALU instructions
+// behind each v_mfma_f32_16x16x32_bf16 gets them for free (16.7 / 18.8 cycles per group with one / two against 16.2 for the MFMA alone),
+// while the partner wave of the SIMD cannot fill the matrix pipe's shadow (the older wave's next MFMA blocks the issue port).  So the
+// split of chunk c + 1 (44 VALU) and the fragment loads of the next pair of output tiles are issued BETWEEN the twelve MFMAs of a
+// pair of output tiles of chunk c (sched_group_barrier pins the order); only chunk 0's split stays in front.
 template <int IN, int OUT, bool BIAS>
 __device__ __forceinline__ void layer_mfma_bx(const float* frags, const f32x4 (&in)[Tiles<IN>::v], f32x4 (&out)[Tiles<OUT>::v],
-                                              int lane, const float* bias = nullptr) {
+                                                   int lane, const float* bias = nullptr) {
     using BL = BxLayout<IN, OUT>;
     constexpr int IT = BL::IT, OTF = BL::OTF, NCB = BL::NCB, ITB = BL::ITB;
+    static_assert(BL::OT3 == OTF || BL::OT3 == 0, "every output tile takes the same chunks");
+    constexpr int NC = NCB + (BL::OT3 > 0 ? 1 : 0);
+    static_assert(OTF % 2 == 0, "pairs of output tiles");
+    constexpr int NP = OTF / 2;                                    // pairs of output tiles = pipeline stages per chunk
     const int q = lane >> 4;
-    // ONE base register per access width for the whole region (57 KB: within the 64 KB reach of a ds instruction's immediate
-    // offset), made opaque to constant folding: the region sits beyond 64 KB from the start of LDS, and left to itself hipcc
-    // materialises `lane * 4 + constant` once per fragment -- dozens of loop-invariant address registers that it then spills
     typedef const __attribute__((address_space(3))) float* lds_f;
     typedef const __attribute__((address_space(3))) bf16x8* lds_b;
     unsigned o32 = (unsigned)(size_t)(lds_f)(frags + lane), o128 = (unsigned)(size_t)(lds_f)(frags + 4 * lane);
@@ -422,69 +439,87 @@ __device__ __forceinline__ void layer_mfma_bx(const float* frags, const f32x4 (&
         if constexpr (BIAS) out[ot] = *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * q]);
         else out[ot] = zero4();
     }
-    // matrix pipe: per chunk the six terms of two output tiles at a time, term-major (consecutive MFMAs hit different accumulators)
-    constexpr int G = 2;
+    auto frag_at = [&](int c, int ot, int pc) {
+        return c < NCB ? fq[(BL::b16 / 4) + ((ot * NCB + c) * 3 + pc) * 64] : fq[(BL::b16c / 4) + (ot * 3 + pc) * 64];
+    };
+    auto unit_of = [&](int c, int p) { const int t = 2 * c + (p >> 1), r0 = 2 * (p & 1); return f32x2{in[t][r0], in[t][r0 + 1]}; };
+    unsigned H[4], M[4], L[4];
 #pragma unroll
-    for (int c = 0; c < NCB; ++c) {
-        load_fence();
-        const Split3 s = split3_pair(in[2 * c], in[2 * c + 1]);
+    for (int p = 0; p < 4; ++p) split3_unit(unit_of(0, p), H[p], M[p], L[p]);
+    unsigned Hn_[4] = {0u, 0u, 0u, 0u}, Mn_[4] = {0u, 0u, 0u, 0u}, Ln_[4] = {0u, 0u, 0u, 0u};      // the next chunk's pieces, filled stage by stage
+#ifndef RGL_BX_PIPE_WBUF
+#define RGL_BX_PIPE_WBUF 1
+#endif
+    constexpr int WB = RGL_BX_PIPE_WBUF;                           // 2: the next stage's fragments are loaded under this stage's MFMAs (+24 VGPRs:
+                                                                   // 11 spill in the children kernel; -1.8 % instead of -1.2 %, profiles/r06_f_*)
+    bf16x8 w[WB][2][3];                                            // [buffer][tile of the pair][piece]
+    if constexpr (WB == 2) {
 #pragma unroll
-        for (int o0 = 0; o0 < OTF; o0 += G) {
-            load_fence();
-            bf16x8 w[G][3];
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int g = 0; g < G; ++g)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    if (o0 + g < OTF)
-                        w[g][pc] = fq[(BL::b16 / 4) + (((o0 + g) * NCB + c) * 3 + pc) * 64];
-#define RGL_BX_TERM(WP, AP)                                                                                         \
-    _Pragma("unroll") for (int g = 0; g < G; ++g)                                                                   \
-        if (o0 + g < OTF) out[o0 + g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g][WP], s.AP, out[o0 + g], 0, 0, 0);
-            RGL_BX_TERM(2, h)          // small terms first
-            RGL_BX_TERM(1, m)
-            RGL_BX_TERM(0, l)
-            RGL_BX_TERM(1, h)
-            RGL_BX_TERM(0, m)
-            RGL_BX_TERM(0, h)
-#undef RGL_BX_TERM
-        }
+            for (int pc = 0; pc < 3; ++pc) w[0][g][pc] = frag_at(0, g, pc);
     }
-    // the third chunk: input tiles ITB, ITB + 1 for the output tiles [0, OT3)
-    if constexpr (BL::OT3 > 0) {
-        load_fence();
-        const Split3 s = split3_pair(in[ITB], in[ITB + 1]);
+    static_for<0, NC * NP>([&](auto stc) {
+        constexpr int st = decltype(stc)::value, c = st / NP, pr = st % NP, buf = WB == 2 ? (st & 1) : 0;
+        constexpr bool has_next = st + 1 < NC * NP;
+        constexpr int cn = (st + 1) / NP, prn = (st + 1) % NP;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (WB == 2 && has_next) {
 #pragma unroll
-        for (int o0 = 0; o0 < BL::OT3; o0 += G) {
-            load_fence();
-            bf16x8 w[G][3];
+            for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int g = 0; g < G; ++g)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    if (o0 + g < BL::OT3) w[g][pc] = fq[(BL::b16c / 4) + ((o0 + g) * 3 + pc) * 64];
-#define RGL_BX_TERM(WP, AP)                                                                                         \
-    _Pragma("unroll") for (int g = 0; g < G; ++g)                                                                   \
-        if (o0 + g < BL::OT3) out[o0 + g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g][WP], s.AP, out[o0 + g], 0, 0, 0);
-            RGL_BX_TERM(2, h)
-            RGL_BX_TERM(1, m)
-            RGL_BX_TERM(0, l)
-            RGL_BX_TERM(1, h)
-            RGL_BX_TERM(0, m)
-            RGL_BX_TERM(0, h)
-#undef RGL_BX_TERM
+                for (int pc = 0; pc < 3; ++pc) w[WB == 2 ? buf ^ 1 : 0][g][pc] = frag_at(cn, 2 * prn + g, pc);
         }
-    }
-    // what is left on the f32 MFMA: input tiles ITB.. (output tiles >= OT3) or ITB + 2.. (output tiles < OT3)
+        if constexpr (WB == 1) {
 #pragma unroll
-    for (int it = ITB; it < IT; ++it) {
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) w[0][g][pc] = frag_at(c, 2 * pr + g, pc);
+        }
+        const bf16x8 sh = __builtin_bit_cast(bf16x8, u32x4{H[0], H[1], H[2], H[3]}), sm = __builtin_bit_cast(bf16x8, u32x4{M[0], M[1], M[2], M[3]}),
+                     sl = __builtin_bit_cast(bf16x8, u32x4{L[0], L[1], L[2], L[3]});
+#define RGL_BX_TERM(WP, AP)                                                                                         \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                                   \
+        out[2 * pr + g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[buf][g][WP], AP, out[2 * pr + g], 0, 0, 0);
+        RGL_BX_TERM(2, sh)          // small terms first
+        RGL_BX_TERM(1, sm)
+        RGL_BX_TERM(0, sl)
+        RGL_BX_TERM(1, sh)
+        RGL_BX_TERM(0, sm)
+        RGL_BX_TERM(0, sh)
+#undef RGL_BX_TERM
+        // the next chunk's pieces, spread over this chunk's stages (four units over NP stages)
+        if constexpr (c + 1 < NC) {
+            constexpr int u0 = (4 * pr) / NP, u1 = (4 * (pr + 1)) / NP;
+            static_for<u0, u1>([&](auto uc) {
+                constexpr int p = decltype(uc)::value;
+                split3_unit(unit_of(c + 1, p), Hn_[p], Mn_[p], Ln_[p]);
+            });
+        }
+        // order: the next stage's six fragment reads early (their latency under this stage's MFMAs), then 1 MFMA : 2 VALU
+        if constexpr (WB == 1) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (WB == 2) __builtin_amdgcn_sched_group_barrier(0x100, has_next ? 6 : 0, 0);
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        if constexpr (pr == NP - 1 && c + 1 < NC) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { H[p] = Hn_[p]; M[p] = Mn_[p]; L[p] = Ln_[p]; }
+        }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    // what is left on the f32 MFMA: input tiles beyond the chunks
+#pragma unroll
+    for (int it = ITB + (BL::OT3 > 0 ? 2 : 0); it < IT; ++it) {
         load_fence();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (it == IT - 1 && r >= LastTileSteps<IN>::v) continue;
 #pragma unroll
             for (int ot = 0; ot < OTF; ++ot) {
-                if (ot < BL::OT3 && it < ITB + 2) continue;                      // the third chunk covered it
                 const int k = (it - ITB - (ot < BL::OT3 ? 2 : 0)) * 4 + r;
                 out[ot] = mfma4(fl[BL::f32_of(ot) + k * 64], in[it][r], out[ot]);
             }

@@ -23,14 +23,14 @@ def time_calls(fn, reps):
     over torch's heap (tens of ms during which no kernel is issued; bench.py freezes the heap for the same reason), and a mean
     of three hands that to the reader as if it were kernel time."""
     import gc
-    for _ in range(10):
+    for _ in range(max(10, reps)):
         fn()
     torch.cuda.synchronize()
     gc.collect()
     gc.disable()
     try:
         ms = []
-        for _ in range(5):
+        for _ in range(9 if reps >= 50 else 5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--contraction", default="f32")
     ap.add_argument("--parents", type=int, nargs="*", default=[256, 512, 1024, 2048, 4096])
     ap.add_argument("--quick", action="store_true", help="skip the whole-search timings")
+    ap.add_argument("--reps", type=int, default=20, help="calls per timed batch (>= 50: nine batches and as many warm-up calls)")
     args = ap.parse_args()
     args.depth, args.width = 2, 2
     dev = torch.device("cuda:0")
@@ -87,7 +88,7 @@ def main():
             rc = lib.mprl_value_children_f32(C.byref(pl), cr.data_ptr(), hn.data_ptr(), P, H, out.data_ptr(), ws.data_ptr(),
                                              ws.numel(), stream)
             assert rc == 0, rc
-        best, mean = time_calls(call, 20)
+        best, mean = time_calls(call, args.reps)
         print("pair P=%5d: best %.4f ms  median %.4f ms   %.1f TFLOP/s  frac %.3f" % (
             P, best, mean, P * A * flop / (mean * 1e-3) / 1e12, P * A * flop / (mean * 1e-3) / 1e12 / bench.FP32_PEAK_TFLOPS))
     if args.quick:
