@@ -190,9 +190,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void scene_graph_kernel(const SceneA
     if constexpr (BX) {
         // three-piece bf16 image, packed once per parameter state (or per search) in exactly this layout: b128 copies, every
         // load of a thread in flight at once.  (Converting the matrices here -- two L2 round trips per fragment element -- cost 10 us per launch.)
-        const int n4 = a.image_floats >> 2;
-        for (int i = tid; i < n4; i += kSceneThreads)
-            reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(a.image)[i];
+        // (round 6: LDS-direct loads, every chunk of a wave in flight at once.  The b128 copy loop this replaces compiled to load -> wait
+        // -> store per iteration: 19 dependent L2 round trips, ~2.5 us of every launch.)
+        constexpr int kChunk = 256;                                            // floats per wave and instruction
+        const int n_chunks = (a.image_floats + kChunk - 1) / kChunk;
+        for (int c = wave; c < n_chunks; c += WAVES) {
+            const int fl = c * kChunk + lane * 4;
+            if (fl < a.image_floats)                                           // the last chunk is partial (image_floats % 4 == 0)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.image + fl),
+                                                 (__attribute__((address_space(3))) void*)(lds + c * kChunk), 16, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0): my chunks have landed (the barrier below: everyone's)
     } else
     {   // weight image in two phases -- every global load of the thread first, then the LDS stores -- so that the whole
         // 30 KB image costs ONE L2 round trip (filling matrix by matrix cost one per matrix: ~9 us of a ~35 us launch)
