@@ -217,7 +217,8 @@ int gcn_rotate_f32(const float* joint14, float* rotated13, int n_rows, int kinem
  * compute_reward (:73-96) and CADRL.propagate (cadrl.py:113-138).
  *   robot  device [B][9], humans device [B][H][5], actions device [A][2] (float64; (vx,vy) or (v,r))
  *   workspace device, >= gcn_predict_workspace_bytes(B, H, A) bytes
- *   action_values device [B][A] (float32), best_action device [B] (int32)
+ *   action_values device [B][A] (float32), best_action device [B] (int32), best_value device [B] (float32; may be NULL;
+ *   ABI 8) = action_values[b][best_action[b]] (0 where no action was selected: best_action = -1)
  * ------------------------------------------------------------------------------------------- */
 typedef struct GcnPlanner {
     RglGraph graph;             /* w_r.dims[0] = 6, w_h.dims[0] = 7                             */
@@ -232,6 +233,10 @@ typedef struct GcnPlanner {
      * works on the simulator's python floats (cadrl.py:113-138, multi_human_rl.py:73-96) and rounds once, at to_tensor. */
     const double* root_robot_f64;
     const double* root_humans_f64;
+    int contraction_dtype;      /* ABI 8: RGL_CONTRACT_F32 (0, the reference's arithmetic) | RGL_CONTRACT_BF16X6: the weight products   *
+                                 * (Wa, W_l) of the graph forward as six bf16 MFMA terms over three-piece operands where the scene kernel *
+                                 * offers them (softmax similarities, 17..32 nodes); everything else plain f32; other values: BAD_MODE  */
+    int reserved;
 } GcnPlanner;
 
 /* The first step of gcn_predict_f32 on its own (ABI 5): for every (root b, action a) CADRL.propagate (cadrl.py:113-138) of the
@@ -243,7 +248,7 @@ int gcn_prepare_f32(const GcnPlanner* planner, const float* robot, const float* 
 size_t gcn_predict_workspace_bytes(int B, int H, int A);
 int gcn_predict_f32(const GcnPlanner* planner, const float* robot, const float* humans, int B, int H,
                     void* workspace, size_t workspace_bytes,
-                    float* action_values, int* best_action, rgl_stream_t stream);
+                    float* action_values, int* best_action, float* best_value, rgl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Path M: model-predictive rollout (crowd_nav/policy/model_predictive_rl.py:192-357).

@@ -54,7 +54,7 @@ class RglGraph(C.Structure):
 class GcnPlanner(C.Structure):
     _fields_ = [("graph", RglGraph), ("value_head", RglMlp), ("kinematics", C.c_int), ("num_actions", C.c_int),
                 ("time_step", C.c_double), ("gamma", C.c_double), ("actions", C.c_void_p),
-                ("root_robot_f64", C.c_void_p), ("root_humans_f64", C.c_void_p)]
+                ("root_robot_f64", C.c_void_p), ("root_humans_f64", C.c_void_p), ("contraction_dtype", C.c_int), ("reserved", C.c_int)]
 
 
 class MprlPlanner(C.Structure):
@@ -101,7 +101,7 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p]),
     "gcn_predict_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "gcn_predict_f32": (C.c_int, [C.POINTER(GcnPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
-                                  C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mprl_expand_f32": (C.c_int, [C.POINTER(MprlPlanner), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                   C.c_void_p]),

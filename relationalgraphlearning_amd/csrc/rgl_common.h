@@ -61,7 +61,9 @@ size_t scene_forward_workspace_bytes(const RglGraph* g, const RglMlp* value_head
                                      int H);                                                                        // rgl_scene.hip
 int launch_scene_forward(const RglGraph* g, const RglMlp* value_head, const RglMlp* motion_head, const float* robot,
                          const float* humans, int S, int crowds_per, int H, float* value_out, float* humans_next, void* workspace,
-                         size_t workspace_bytes, hipStream_t stream);                                               // rgl_scene.hip
+                         size_t workspace_bytes, hipStream_t stream, const float* value_rows_image = nullptr);      // rgl_scene.hip
+// `value_rows_image`: the three-piece bf16 image of the graph's matrices (scene_image_bytes_for / pack_scene_image_for with no motion
+// head): the value forward's weight products then run as six bf16 MFMA terms where the scene kernel offers them
 int launch_generic_forward(const RglGraph* graph, const RglMlp* value_head, const RglMlp* motion_head,
                            const float* robot, const float* humans, int n_scenes, int scenes_per_crowd, int H,
                            float* H_out, float* A_out, float* value_out, float* humans_next, hipStream_t stream);   // rgl_generic.hip
@@ -111,6 +113,8 @@ int launch_predict_humans(const MprlPlanner* pl, const float* robot, const float
                           const float* sp_image = nullptr);                                                           // rgl_scene.hip
 size_t scene_image_bytes(const MprlPlanner* pl);                      // 0: no six-term bf16 scene kernel for this planner
 int pack_scene_image(const MprlPlanner* pl, float* image, hipStream_t stream);
+size_t scene_image_bytes_for(const RglGraph& g, const RglMlp* motion_head);          // the same for a graph (+ optional motion head)
+int pack_scene_image_for(const RglGraph& g, const RglMlp* motion_head, float* image, hipStream_t stream);
 
 int launch_scene_children(const MprlPlanner* pl, const float* child_robot, const float* humans_next, int P, int H,
                           float* child_value, void* workspace, size_t workspace_bytes, hipStream_t stream);         // rgl_scene.hip

@@ -88,7 +88,8 @@ template <class LO, int D1, int D2, int D3, bool SKIP, bool BX = false>
 __device__ __forceinline__ float head_chain(const float* lds, const f32x4 (&tin)[2], const f32x4 (&hp)[2], int lane) {
     const int q = lane >> 4;
     f32x4 h[2];
-    layer_mfma<XD, XD, false>(lds + LO::f_last, tin, h, lane);
+    if constexpr (BX) layer_mfma_b6<XD, XD, false>(lds + LO::f_last, tin, h, lane);
+    else layer_mfma<XD, XD, false>(lds + LO::f_last, tin, h, lane);
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
     constexpr int SLDK = HRL + 2;
     const int N = a.N, A = a.A, SLD = PK ? SLDK : a.SLD;
     const float NEG_INF = -INFINITY;
-    const float* wr1 = lds + LO::wr1;   // [12][W1LD], rows 9..11 zero
+    const float* wr1 = lds + LO::wr1;   // [12][W1LD], rows 9..11 zero (BX: [9][72], see FusedLds)
     const float* br1 = lds + LO::br1;
     const float* wr2 = lds + LO::wr2;   // [HID][WLD]
     const float* br2 = lds + LO::br2;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
     // are zero rows / contribute nothing).  The MFMA D layout of the chain (lane (n, q): node 16 pct + n, features 16 ot + 4 q + r)
     // is the A-operand layout of the S products; Xh^T and the feature-major UW go through the wave's scratch (free between items).
     auto crowd_compute = [&]() {
-        const float* wh1 = lds + LO::wh1;   // [8][W1LD], rows 5..7 zero
+        const float* wh1 = lds + LO::wh1;   // [8][W1LD], rows 5..7 zero (BX: [5][72])
         const float* bh1 = lds + LO::bh1;
         const float* wh2 = lds + LO::wh2;   // [HID][WLD]
         const float* bh2 = lds + LO::bh2;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
             for (int s = 0; s < 2; ++s) {
                 const int k = 4 * s + q;
 #pragma unroll
-                for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wh1[k * LO::WH1LD + 16 * ht + n], hin[pct][s], hacc[ht]);
+                for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wh1[(k < LO::WH1ROWS ? k : LO::WH1ROWS - 1) * LO::WH1LD + 16 * ht + n], hin[pct][s], hacc[ht]);
             }
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) {
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void children_fused_kernel(const 
             for (int s = 0; s < 3; ++s) {
                 const int k = 4 * s + q;
 #pragma unroll
-                for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wr1[k * W1LD + 16 * ht + n], rin[s], hacc[ht]);
+                for (int ht = 0; ht < 4; ++ht) hacc[ht] = mfma4(wr1[(k < LO::WR1ROWS ? k : LO::WR1ROWS - 1) * LO::WR1LD + 16 * ht + n], rin[s], hacc[ht]);
             }
             if (ti + 1 < t1) robot_rows(p, ti + 1);      // robot rows of my next tile: in flight under this tile's work
 #pragma unroll
@@ -968,7 +969,7 @@ __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedAr
     const int e = blockIdx.x * kPackThreads + threadIdx.x;
     if (e >= LO::scratch) return;
     float v;
-    if (e < LO::br1) v = matrix_element<9, HID, W1LD>(a.wr1, e - LO::wr1);
+    if (e < LO::br1) v = matrix_element<9, HID, LO::WR1LD>(a.wr1, e - LO::wr1);
     else if (e < LO::wr2) v = a.br1[e - LO::br1];
     else if (e < LO::br2) {
         if constexpr (BX) v = frag_bf3_ld<HID, XD>(a.wr2, XD, XD, e - LO::wr2);
@@ -992,7 +993,10 @@ __global__ __launch_bounds__(kPackThreads) void pack_images_kernel(const FusedAr
     else if (e < LO::w4) v = bias_element<D3>(a.hb3, e - LO::b3);
     else if (e < LO::f_last) v = bias_element<D3>(a.hw4, e - LO::w4);          // w4 is [D3][1]: same padded vector layout as a bias
     else {
-        if (e < LO::f1) v = frag_element<XD, XD>(a.w_last, e - LO::f_last);
+        if (e < LO::f1) {
+            if constexpr (BX) v = frag_bf3_ld<XD, XD>(a.w_last, XD, XD, e - LO::f_last);
+            else v = frag_element<XD, XD>(a.w_last, e - LO::f_last);
+        }
         else if (e < LO::f2) {
             if constexpr (BX && D1 == 32) v = bx1_element<XD, 32>(a.hw1, e - LO::f1);
             else v = frag_element<XD, D1>(a.hw1, e - LO::f1);

@@ -234,7 +234,11 @@ template <int D1, int D2, int D3, bool BX = false>
 struct FusedLds {
     // child-side weight image
     static constexpr int wr1 = 0;
-    static constexpr int br1 = wr1 + 12 * W1LD;
+    // BX (round 6): the first embedding matrices hold their VALID rows only (9 of 12, 5 of 8) at row stride 72 -- the k slots past the
+    // input width multiply an input that is exactly 0, so their A operand may be any finite weight: the lanes re-read the last valid row
+    // -- which frees the 512 floats W_last's three-piece bf16 fragments need beyond its f32 ones
+    static constexpr int WR1LD = BX ? 72 : W1LD, WR1ROWS = BX ? 9 : 12;
+    static constexpr int br1 = wr1 + WR1ROWS * WR1LD;
     static constexpr int wr2 = br1 + HID;
     // BX (round 6): wr2, wa, w1 as three-piece bf16 fragments (layer_mfma_b6's layout: 6 bytes per weight instead of 4.5 with the
     // padded f32 rows) -- the room comes from the compact partial-tile fragments of the head (P4Compact)
@@ -245,7 +249,8 @@ struct FusedLds {
     static constexpr int wh1 = w1 + (BX ? XD * XD * 3 / 2 : XD * WLD);
     static constexpr int WH1LD = BX ? 72 : W1LD;                    // BX: w_h's first matrix at row stride 72 (k-groups 8 banks apart: two
                                                                    // lanes per bank, as at 80) -- the 64 floats its image needs for ...
-    static constexpr int bh1 = wh1 + 8 * WH1LD;
+    static constexpr int WH1ROWS = BX ? 5 : 8;
+    static constexpr int bh1 = wh1 + WH1ROWS * WH1LD;
     static constexpr int wh2 = bh1 + HID;
     static constexpr int bh2 = wh2 + (BX ? 0 : HID * WLD);          // BX: w_h's second matrix lives in REGISTERS (32 per lane, loaded once
                                                                    // per kernel: every crowd computation reads the same 32), its 9 KB
@@ -258,7 +263,7 @@ struct FusedLds {
     static constexpr int b3 = b2 + Tiles<D2>::v * 16;
     static constexpr int w4 = b3 + Tiles<D3>::v * 16;
     static constexpr int f_last = w4 + Tiles<D3>::v * 16;
-    static constexpr int f1 = f_last + HeadFragFloats<XD, XD>::v;
+    static constexpr int f1 = f_last + (BX ? XD * XD * 3 / 2 : HeadFragFloats<XD, XD>::v);      // BX: W_last as three-piece bf16 fragments (layer_mfma_b6)
     static constexpr int f2 = f1 + ((BX && D1 == 32) ? Bx1Layout<XD, 32>::total : HeadFragFloats<XD, D1>::v);    // ... the XD x D1 layer as bf16 pieces
     static constexpr int f3 = f2 + (BX ? Bx1Layout<D1, D2>::total : HeadFragFloats<D1, D2>::v);
     static constexpr int scratch = f3 + (BX ? BxLayout<D2, D3>::total : HeadFragFloats<D2, D3>::v);      // per wave: fused_scratch_floats()

@@ -808,7 +808,7 @@ static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* r
     sa.eh_w1 = g.w_h.weight[0]; sa.eh_b1 = g.w_h.bias[0]; sa.eh_w2 = g.w_h.weight[1]; sa.eh_b2 = g.w_h.bias[1];
     sa.off_er = sa.off_eh = 0;
     // (one node tile: measured slower than the f32 form -- 0.0615 vs 0.0496 ms per configs[1] step: too few MFMAs to pay for the splits)
-    const bool split_ok = sp_image && mh && scene_similarity_mode(g) == SIM_SOFTMAX && NT0 == 2 && g.num_layer <= 4;
+    const bool split_ok = sp_image && scene_similarity_mode(g) == SIM_SOFTMAX && NT0 == 2 && g.num_layer <= 4;      // (mh == null: value rows)
     sa.bx = split_ok ? 1 : 0;
     sa.image = sp_image;
     sa.xh_rows = xh_rows; sa.x0_rows = x0_rows; sa.crowds_per = crowds_per;
@@ -865,22 +865,31 @@ static int run_scene_kernels(const RglGraph& g, const RglMlp* mh, const float* r
 namespace rgl {
 
 // The three-piece bf16 weight image of the state predictor's scene kernel (RGL_CONTRACT_BF16X6): depends on the weights only.
+// (graph + optional motion head: the state predictor's form; mh == null: the value-rows form of path G / the module forwards)
+size_t scene_image_bytes_for(const RglGraph& g, const RglMlp* mh) {
+    if (!scene_kernel_covers(g, 20) || scene_similarity_mode(g) != SIM_SOFTMAX) return 0;
+    if (mh && !mlp_is(*mh, XD, HID, 5, false)) return 0;
+    return (((size_t)scene_image_layout(g.num_layer, true).total * sizeof(float)) + 255) & ~(size_t)255;
+}
+
 size_t scene_image_bytes(const MprlPlanner* pl) {
     if (!pl || pl->linear_state_predictor) return 0;
     if (pl->contraction_dtype != RGL_CONTRACT_BF16X6) return 0;
-    const RglGraph& g = pl->predictor_graph;
-    if (!scene_kernel_covers(g, 20) || scene_similarity_mode(g) != SIM_SOFTMAX || !mlp_is(pl->motion_head, XD, HID, 5, false)) return 0;
-    return (((size_t)scene_image_layout(g.num_layer, true).total * sizeof(float)) + 255) & ~(size_t)255;
+    return scene_image_bytes_for(pl->predictor_graph, &pl->motion_head);
 }
 
 int pack_scene_image(const MprlPlanner* pl, float* image, hipStream_t stream) {
     if (!scene_image_bytes(pl)) return 1;
-    const RglGraph& g = pl->predictor_graph;
+    return pack_scene_image_for(pl->predictor_graph, &pl->motion_head, image, stream);
+}
+
+int pack_scene_image_for(const RglGraph& g, const RglMlp* mh, float* image, hipStream_t stream) {
+    if (!scene_image_bytes_for(g, mh)) return 1;
     SceneImageArgs ia;
     ia.wa = bilinear_wa(g);
     for (int l = 0; l < 4; ++l) ia.Ws[l] = l < g.num_layer ? g.Ws[l] : nullptr;
-    ia.wm1 = pl->motion_head.weight[0]; ia.bm1 = pl->motion_head.bias[0];
-    ia.wm2 = pl->motion_head.weight[1]; ia.bm2 = pl->motion_head.bias[1];
+    ia.wm1 = mh ? mh->weight[0] : nullptr; ia.bm1 = mh ? mh->bias[0] : nullptr;
+    ia.wm2 = mh ? mh->weight[1] : nullptr; ia.bm2 = mh ? mh->bias[1] : nullptr;
     ia.L = g.num_layer;
     ia.lo = scene_image_layout(g.num_layer, true);
     hipLaunchKernelGGL(scene_pack_b6_kernel, dim3((ia.lo.total + 255) / 256), dim3(256), 0, stream, ia, image);
@@ -947,7 +956,7 @@ size_t scene_forward_workspace_bytes(const RglGraph* g, const RglMlp* vh, const 
 
 int launch_scene_forward(const RglGraph* g, const RglMlp* vh, const RglMlp* mh, const float* robot, const float* humans, int S,
                          int crowds_per, int H, float* value_out, float* humans_next, void* workspace, size_t workspace_bytes,
-                         hipStream_t stream) {
+                         hipStream_t stream, const float* value_rows_image) {
     if (!scene_forward_covers(*g, vh, mh, S, crowds_per, H)) return 1;
     if (!workspace || workspace_bytes < scene_forward_workspace_bytes(g, vh, mh, S, crowds_per, H)) return 1;
     const bool has_v = vh && vh->n_layers > 0, has_m = mh && mh->n_layers > 0;
@@ -959,7 +968,8 @@ int launch_scene_forward(const RglGraph* g, const RglMlp* vh, const RglMlp* mh, 
         if (rc) return rc;
     }
     if (has_v) {
-        int rc = run_scene_kernels(*g, nullptr, robot, humans, crowds_per, S, H, nullptr, rows, x0_rows, xh_rows, nullptr, stream);
+        int rc = run_scene_kernels(*g, nullptr, robot, humans, crowds_per, S, H, nullptr, rows, x0_rows, xh_rows, nullptr, stream, nullptr,
+                                   value_rows_image);
         if (rc) return rc;
         return launch_head_rows(g, vh, rows, S, value_out, stream);
     }

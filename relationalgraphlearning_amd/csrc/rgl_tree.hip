@@ -197,7 +197,7 @@ __global__ void gcn_prepare_kernel(const float* __restrict__ robot, const float*
 // cost 25 us per call
 __global__ void gcn_argmax_kernel(const float* __restrict__ robot, const float* __restrict__ reward,
                                   const float* __restrict__ value, int B, int A, double gamma, double dt,
-                                  float* __restrict__ action_values, int* __restrict__ best_action) {
+                                  float* __restrict__ action_values, int* __restrict__ best_action, float* __restrict__ best_value) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = t / kRootLanes, sub = t % kRootLanes;
     const bool live = b < B;
@@ -224,7 +224,10 @@ __global__ void gcn_argmax_kernel(const float* __restrict__ robot, const float* 
             ba = oa;
         }
     }
-    if (live && sub == 0) best_action[b] = ba;
+    if (live && sub == 0) {
+        best_action[b] = ba;
+        if (best_value) best_value[b] = ba >= 0 ? (float)best : 0.f;      // = action_values[b][ba]: what callers used to gather
+    }
 }
 
 inline dim3 grid_for(long long n, int block = kBlock) { return dim3((unsigned)((n + block - 1) / block)); }
@@ -645,17 +648,20 @@ extern "C" int gcn_prepare_f32(const GcnPlanner* planner, const float* robot, co
     return RGL_OK;
 }
 
+constexpr long long kGcnImageBytes = 64 * 1024;      // >= scene_image_bytes_for(): Wa + 4 layer matrices + motion-head slots as 6-byte weights
+
 extern "C" size_t gcn_predict_workspace_bytes(int B, int H, int A) {
     if (B < 1 || H < 1 || A < 1) return 0;
     const long long S = (long long)B * A;
     // rotated features, rewards, values + the scratch of the MFMA forward (embeddings [S][32], [S][H][32], value rows [S][64])
+    // + room for the scene kernel's three-piece bf16 weight image (RGL_CONTRACT_BF16X6: packed per call, 4 layer matrices at most)
     return (size_t)(align_up(S * 6 * 4) + align_up(S * H * 7 * 4) + align_up(S * 4) + align_up(S * 4) +
-                    align_up(S * (32 + (long long)H * 32 + 64) * 4));
+                    align_up(S * (32 + (long long)H * 32 + 64) * 4) + kGcnImageBytes);
 }
 
 extern "C" int gcn_predict_f32(const GcnPlanner* planner, const float* robot, const float* humans, int B, int H,
                                void* workspace, size_t workspace_bytes, float* action_values, int* best_action,
-                               rgl_stream_t stream) {
+                               float* best_value, rgl_stream_t stream) {
     if (!planner || !robot || !humans || !workspace || !action_values || !best_action) return RGL_ERR_NULL;
     if (B < 1) return RGL_ERR_BAD_SHAPE;
     const GcnPlanner& pl = *planner;
@@ -666,6 +672,7 @@ extern "C" int gcn_predict_f32(const GcnPlanner* planner, const float* robot, co
     if (pl.graph.w_r.dims[0] != 6 || pl.graph.w_h.dims[0] != 7) return RGL_ERR_BAD_SHAPE;
     rc = rgl::validate_mlp(pl.value_head, pl.graph.x_dim, 1);
     if (rc) return rc;
+    if (pl.contraction_dtype != RGL_CONTRACT_F32 && pl.contraction_dtype != RGL_CONTRACT_BF16X6) return RGL_ERR_BAD_MODE;
     const int A = pl.num_actions;
     if (workspace_bytes < gcn_predict_workspace_bytes(B, H, A)) return RGL_ERR_WORKSPACE;
     const long long S = (long long)B * A;
@@ -677,6 +684,16 @@ extern "C" int gcn_predict_f32(const GcnPlanner* planner, const float* robot, co
     void* fwd_ws = ws;
     const size_t fwd_bytes = (size_t)align_up(S * (32 + (long long)H * 32 + 64) * 4);
     hipStream_t st = (hipStream_t)stream;
+    // RGL_CONTRACT_BF16X6: the graph's Wa / W_l as three-piece bf16 fragments for the scene kernel's value-rows mode, packed here
+    // (one ~4 us launch beside a forward of hundreds; the weights may have changed since the last call)
+    const float* rows_image = nullptr;
+    if (pl.contraction_dtype == RGL_CONTRACT_BF16X6) {
+        const size_t ib = rgl::scene_image_bytes_for(pl.graph, nullptr);
+        if (ib && ib <= kGcnImageBytes) {
+            float* img = (float*)(ws + fwd_bytes);
+            if (rgl::pack_scene_image_for(pl.graph, nullptr, img, st) == RGL_OK) rows_image = img;
+        }
+    }
     const int prep_threads = (H >= kBlock ? 1 : kBlock / H) * H;        // whole (root, action) groups per workgroup
     hipLaunchKernelGGL(gcn_prepare_kernel, grid_for(S * H, prep_threads), dim3(prep_threads), prep_threads * sizeof(double), st, robot, humans,
                        pl.root_robot_f64 && pl.root_humans_f64 ? pl.root_robot_f64 : nullptr,
@@ -686,7 +703,7 @@ extern "C" int gcn_predict_f32(const GcnPlanner* planner, const float* robot, co
     // the B x A rotated scenes: one wave per scene on the MFMA kernel where it covers the model (the shipped ValueNetwork: 6 / 7
     // inputs, 64-32 embeddings, head 150-100-100-1), else the general kernel
     rc = rgl::launch_scene_forward(&pl.graph, &pl.value_head, nullptr, self6, hum7, (int)S, 1, H, value, nullptr, fwd_ws, fwd_bytes,
-                                   st);
+                                   st, rows_image);
     if (rc == 1)      // other embedding MLPs (x_dim 32: what this workspace is sized for): the tile kernels of rgl_backward_mfma.hip
         rc = rgl::launch_tiles_forward(&pl.graph, &pl.value_head, nullptr, self6, hum7, (int)S, 1, H, nullptr, value, nullptr, fwd_ws,
                                        fwd_bytes, st);
@@ -698,7 +715,7 @@ extern "C" int gcn_predict_f32(const GcnPlanner* planner, const float* robot, co
     }
     if (rc) return rc;
     hipLaunchKernelGGL(gcn_argmax_kernel, grid_for((long long)B * kRootLanes, 256), dim3(256), 0, st, robot, reward, value, B, A, pl.gamma,
-                       pl.time_step, action_values, best_action);
+                       pl.time_step, action_values, best_action, best_value);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }

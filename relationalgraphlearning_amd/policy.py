@@ -470,10 +470,11 @@ class GCN(Policy):
         self._search = None
 
     def gcn_search(self):
-        key = (self.kinematics, self.time_step, self.gamma)
+        mode = getattr(self, "contraction_dtype", "f32")       # additive: "bf16x6" = the graph's weight products on the matrix pipe
+        key = (self.kinematics, self.time_step, self.gamma, mode)
         if self._search is None or self._search[0] != key:
             self._search = (key, GcnSearch(self.model, act.as_array(self.action_space), self.kinematics,
-                                           self.time_step, self.gamma))
+                                           self.time_step, self.gamma, mode))
         return self._search[1]
 
     def predict(self, state):
@@ -513,8 +514,9 @@ class GCN(Policy):
         if self.action_space is None:
             self.build_action_space(float(robot[0, 7]))
         with torch.no_grad():
-            vals, best = self.gcn_search().search(robot, humans)
-        return best, vals.gather(1, best.long().clamp(min=0)[:, None])[:, 0]
+            search = self.gcn_search()
+            vals, best = search.search(robot, humans)
+        return best, search.last_best_value
 
     def _search_querying_env(self, robot, r64):
         """query_env=True (multi_human_rl.py:43-44): next human states and the reward of every action come from the simulator's

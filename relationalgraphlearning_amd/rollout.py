@@ -445,7 +445,10 @@ class TreeSearch:
 class GcnSearch:
     """One-step lookahead over the rotation-major action table with the path-G ValueNetwork."""
 
-    def __init__(self, value_network, actions, kinematics="holonomic", time_step=0.25, gamma=0.9):
+    def __init__(self, value_network, actions, kinematics="holonomic", time_step=0.25, gamma=0.9, contraction_dtype="f32"):
+        if contraction_dtype not in ("f32", "bf16x6"):
+            raise ValueError("path G contraction mode %r: 'f32' (the reference's arithmetic) or 'bf16x6'" % (contraction_dtype,))
+        self.contraction_dtype = contraction_dtype     # "bf16x6": the graph's weight products as six bf16 MFMA terms (GcnPlanner, ABI 8)
         self.model = value_network
         self.actions_np = np.ascontiguousarray(np.asarray(actions, dtype=np.float64))
         self.kinematics = kinematics
@@ -473,6 +476,7 @@ class GcnSearch:
             pl.num_actions = A
             pl.time_step = self.time_step
             pl.gamma = self.gamma
+            pl.contraction_dtype = nat.CONTRACTION_DTYPES[self.contraction_dtype]
             pl.actions = self._dev_tables[key].data_ptr()
             if roots64 is not None:
                 r64, h64 = _check_roots64(roots64, B, H)
@@ -481,9 +485,11 @@ class GcnSearch:
             ws = self._ws.get(lib.gcn_predict_workspace_bytes(B, H, A), dev)
             vals = torch.empty(B, A, dtype=torch.float32, device=dev)
             best = torch.empty(B, dtype=torch.int32, device=dev)
+            best_value = torch.empty(B, dtype=torch.float32, device=dev)
             rc = lib.gcn_predict_f32(C.byref(pl), robot.data_ptr(), humans.data_ptr(), B, H, ws.data_ptr(), ws.numel(),
-                                     vals.data_ptr(), best.data_ptr(), _stream())
+                                     vals.data_ptr(), best.data_ptr(), best_value.data_ptr(), _stream())
         nat.check(rc, "gcn_predict_f32")
+        self.last_best_value = best_value        # value of the chosen action per root, from the argmax kernel itself (no gather launches)
         return vals, best
 
 

@@ -2035,6 +2035,38 @@ def test_path_g_predict(dev):
     close(vals.cpu().numpy(), g["g.pred_action_values"])
 
 
+def test_path_g_bf16x6_weight_products_at_size(dev):
+    """ABI 8: GcnPlanner.contraction_dtype = RGL_CONTRACT_BF16X6 -- the graph's weight products (Wa, W_0) of the scene kernel's value-rows
+    mode as six bf16 MFMA terms over three-piece operands (N = 20: two node tiles).  Held to the f32 bounds against the batched
+    oracle, next to the f32 kernels' own deviation; a crowd the mode does not cover (N = 6: one node tile) runs plain f32 bit for bit."""
+    import bench
+    H, B = 19, 512
+    robot, humans = bench.synth_scenes(2000 + H, B, H)
+    ob, ov = orc.gcn_predict_batched(robot.numpy(), humans.numpy(), gio.path_g_sd(), orc.OracleConfig())
+    out = {}
+    for mode in ("f32", "bf16x6"):
+        pol = make_gcn_policy(device=dev)
+        pol.contraction_dtype = mode
+        pol.build_action_space(1.0)
+        vals, best = pol.gcn_search().search(robot.to(dev), humans.to(dev))
+        out[mode] = (vals.cpu().numpy().astype(np.float64), best.cpu().numpy().astype(np.int64))
+    e32 = close(out["f32"][0], ov)
+    e6 = close(out["bf16x6"][0], ov)
+    assert not np.array_equal(out["f32"][0], out["bf16x6"][0])          # the mode did run
+    for b in np.nonzero(out["bf16x6"][1] != ob)[0]:
+        assert ov[b, ob[b]] - ov[b, out["bf16x6"][1][b]] <= TOL
+    assert e6 <= 2.0 * e32 + 5e-8, (e6, e32)              # the mode keeps 24-bit operands: no worse than the f32 kernels' own deviation
+    report("path G, bf16x6 weight products, H=19 B=512: max |d action value| vs the oracle %.2e (f32 kernels: %.2e)" % (e6, e32))
+    r5, h5 = bench.synth_scenes(2005, 64, 5)
+    got = []
+    for mode in ("f32", "bf16x6"):
+        pol = make_gcn_policy(device=dev)
+        pol.contraction_dtype = mode
+        pol.build_action_space(1.0)
+        got.append(pol.gcn_search().search(r5.to(dev), h5.to(dev))[0])
+    assert torch.equal(got[0], got[1])
+
+
 @pytest.mark.parametrize("H,B,kin", [(5, 512, "holonomic"), (19, 512, "holonomic"), (19, 96, "unicycle"), (49, 64, "holonomic")])
 def test_path_g_at_size_against_the_batched_oracle(H, B, kin, dev):
     """path G beyond the five fixture scenes -- B x 81 rotated scenes at H = 5 / 19 (and a dense H = 49 crowd)
@@ -2054,6 +2086,10 @@ def test_path_g_at_size_against_the_batched_oracle(H, B, kin, dev):
     differ = np.nonzero(got_a != ob)[0]
     for b in differ:                              # a different action only on a tie in the oracle
         assert ov[b, ob[b]] - ov[b, got_a[b]] <= TOL, (b, ov[b, ob[b]], ov[b, got_a[b]])
+    # the value of the chosen action as the argmax kernel itself reports it (ABI 8: gcn_predict_f32's best_value; predict_batch hands
+    # it on instead of gathering): bit for bit the entry of the action-value table
+    pa, pv = pol.predict_batch(robot.to(dev), humans.to(dev))
+    assert torch.equal(pa, best) and torch.equal(pv, vals.gather(1, best.long()[:, None])[:, 0])
     report("path G at size, H=%d B=%d %s: %d of %d decisions differ from the oracle (ties in the oracle); max |d action value| = %.2e"
            % (H, B, kin, len(differ), B, err))
 

@@ -35,10 +35,11 @@ def scene_flops(N):
 
 dev = torch.device("cuda:0")
 ONLY_H = os.environ.get("RGL_GCN_TRACE_ONLY_H")          # counter passes: one crowd size, so per-kernel averages mean one shape
-for H, B in ((5, 2048), (19, 2048)):
+for H, B, mode in ((5, 2048, "f32"), (19, 2048, "f32"), (19, 2048, "bf16x6")):
     if ONLY_H and int(ONLY_H) != H:
         continue
     pol = make_gcn_policy(device=dev)
+    pol.contraction_dtype = mode          # "bf16x6" (ABI 8): the graph's Wa / W_0 products of the scene kernel as six bf16 MFMA terms
     robot, humans = seeded_scenes(11, B, H)
     r, h = robot.to(dev), humans.to(dev)
     for _ in range(10):
@@ -51,8 +52,8 @@ for H, B in ((5, 2048), (19, 2048)):
     ms = (time.perf_counter() - t0) / 50 * 1e3
     A = len(pol.action_space)
     fl = scene_flops(H + 1)
-    print("path G H=%d B=%d: %.3f ms per predict_batch" % (H, B, ms))
-    print(json.dumps({"workload": "path G, GCN.predict_batch: %d roots x %d actions, N = %d" % (B, A, H + 1), "ms_per_batch": ms,
+    print("path G H=%d B=%d %s: %.3f ms per predict_batch" % (H, B, mode, ms))
+    print(json.dumps({"workload": "path G, GCN.predict_batch: %d roots x %d actions, N = %d, contraction %s" % (B, A, H + 1, mode), "ms_per_batch": ms,
                       "rotated_scenes": B * A, "flop_per_rotated_scene": fl,
                       "roofline": {"bound": "mfma", "achieved": B * A * fl / (ms * 1e-3) / 1e12, "peak": PEAK / 1e12, "unit": "TFLOP/s",
                                    "frac": B * A * fl / (ms * 1e-3) / PEAK,
