@@ -304,6 +304,10 @@ typedef struct MprlPlanner {
      * six bf16 MFMA terms; S and A H stay f32) -- prepared by mprl_pack_predictor_image_f32 from THIS planner's predictor_graph /
      * motion_head.  NULL: a search in such a mode packs it into its workspace itself. */
     const float* predictor_image;
+    /* optional (0 = absent; ABI 8): an upper bound of the action table's speeds -- max |(vx, vy)| (holonomic) or max |v| (unicycle)
+     * over `actions`, any value >= the true maximum.  The reward step uses it to rule out, per parent, the humans no action can bring
+     * within reach; without it every wave of that step derives it from the table (same results, ~1.5 us more latency per launch). */
+    double action_speed_bound;
 } MprlPlanner;
 
 /* Bytes of the weight image above; 0 when the configuration has no image-based children kernel (the searches then ignore

@@ -64,7 +64,7 @@ class MprlPlanner(C.Structure):
                 ("do_action_clip", C.c_int), ("sparse_search", C.c_int), ("contraction_dtype", C.c_int),
                 ("time_step", C.c_double), ("gamma_bar", C.c_double), ("actions", C.c_void_p),
                 ("action_groups", C.c_void_p), ("root_robot_f64", C.c_void_p), ("root_humans_f64", C.c_void_p),
-                ("children_image", C.c_void_p), ("predictor_image", C.c_void_p)]
+                ("children_image", C.c_void_p), ("predictor_image", C.c_void_p), ("action_speed_bound", C.c_double)]
 
 
 class CrowdSimConfig(C.Structure):

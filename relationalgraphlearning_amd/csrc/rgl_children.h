@@ -20,6 +20,11 @@ struct ChildrenArgs {
     const double* humans64;
     float* reward_clip;        // null, or [P][A]: the same rewards read as a TENSOR-BORN state (joint = 0 on the fp32 rows) -- what
                                // upstream's root action_clip sees of a joint-state root (model_predictive_rl.py:216-218,246-248)
+    int p_base, c_base;        // `robot` / `humans` start at parent p_base / crowd c_base (0 for whole-level arrays; a workgroup that staged
+                               // its own parents' rows in LDS hands in its sub-range -- no pointer is ever rebased below its buffer:
+                               // a flat LDS address that leaves the aperture faults, HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION)
+    float v_max;               // > 0: an upper bound of the table's speeds (MprlPlanner::action_speed_bound, ABI 8); 0: every wave derives
+                               // it from the table (two dependent float64 loads + a square root + a wave reduction: ~1.5 us of latency)
 };
 
 __device__ __forceinline__ double seg_point_dist_origin(double px, double py, double ex, double ey, bool f32_degenerate,
@@ -44,8 +49,8 @@ __device__ __forceinline__ double seg_point_dist_origin(double px, double py, do
 // `near_mask`: bit h clear = human h provably cannot influence any child of this parent (children_wave), skipped outright.
 __device__ __forceinline__ double pair_reward(const ChildrenArgs& ca, int p, int a, unsigned long long near_mask, int joint,
                                               bool use64) {
-    const float* __restrict__ r = ca.robot + (size_t)p * 9;
-    const float* __restrict__ hs = ca.humans + (size_t)(p / ca.humans_per) * ca.H * 5;
+    const float* __restrict__ r = ca.robot + (size_t)(p - ca.p_base) * 9;
+    const float* __restrict__ hs = ca.humans + (size_t)(p / ca.humans_per - ca.c_base) * ca.H * 5;
     const double* r64 = use64 && ca.robot64 ? ca.robot64 + (size_t)p * 9 : nullptr;          // float64 roots (humans_per == 1 there)
     const double* hs64 = use64 && ca.humans64 ? ca.humans64 + (size_t)p * ca.H * 5 : nullptr;
     auto R = [&](int i) { return r64 ? r64[i] : (double)r[i]; };
@@ -70,8 +75,9 @@ __device__ __forceinline__ double pair_reward(const ChildrenArgs& ca, int p, int
     bool collision = false;
     double dmin = INFINITY;
     const float favx = (float)avx, favy = (float)avy, fdt = (float)dt;
-    for (int h = 0; h < H; ++h) {
-        if (h < 64 && !((near_mask >> h) & 1ull)) continue;
+    // the near humans by index, then (crowds beyond 64, which carry no mask) the rest: one visit per human that can matter instead of
+    // H mask tests (round 6: a crowd of 19 spread over the arena has 1-3 of them)
+    auto visit = [&](int h) {
         const float* hu = hs + h * 5;
         {
             // fp32 pre-test of the exact shortcut below: with T = radii + 0.25, |p|^2 >= 2 (|e - p|^2 + T^2) proves that this
@@ -81,7 +87,7 @@ __device__ __forceinline__ double pair_reward(const ChildrenArgs& ca, int p, int
             const float qx = hu[0] - r[0], qy = hu[1] - r[1];
             const float sxf = (hu[2] - favx) * fdt, syf = (hu[3] - favy) * fdt;
             const float Tf = hu[4] + r[4] + 0.25f;
-            if (qx * qx + qy * qy >= 2.002f * (sxf * sxf + syf * syf + Tf * Tf)) continue;
+            if (qx * qx + qy * qy >= 2.002f * (sxf * sxf + syf * syf + Tf * Tf)) return;
         }
         const double* hu64 = hs64 ? hs64 + h * 5 : nullptr;
         auto HU = [&](int i) { return hu64 ? hu64[i] : (double)hu[i]; };
@@ -105,14 +111,25 @@ __device__ __forceinline__ double pair_reward(const ChildrenArgs& ca, int p, int
         {
             const double T = HU(4) + R(4) + 0.25;
             const double sx = ex - px, sy = ey - py;
-            if (px * px + py * py >= 2.0 * (sx * sx + sy * sy + T * T)) continue;
+            if (px * px + py * py >= 2.0 * (sx * sx + sy * sy + T * T)) return;
         }
         const double d = seg_point_dist_origin(px, py, ex, ey, !joint, fpx, fpy) - HU(4) - R(4);
         if (d < 0.0) collision = true;
         if (d < dmin) dmin = d;
+    };
+    unsigned long long todo = H >= 64 ? near_mask : (near_mask & ((1ull << H) - 1ull));
+    while (todo) {
+        const int h = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        visit(h);
     }
+    for (int h = 64; h < H; ++h) visit(h);
     const double gx = nx - R(5), gy = ny - R(6);
-    const bool reaching = sqrt(gx * gx + gy * gy) < R(4);
+    // norm < radius (model_predictive_rl.py:336-345): away from the boundary the squares decide -- a 1e-12 relative margin is four
+    // orders above every rounding of x, r^2 and the root -- and the float64 square root runs only inside it
+    const double gd2 = gx * gx + gy * gy, gr2 = R(4) * R(4);
+    const bool reaching = (R(4) > 0.0 && gd2 <= gr2 * (1.0 - 1e-12)) ? true
+                          : ((R(4) > 0.0 && gd2 >= gr2 * (1.0 + 1e-12)) ? false : sqrt(gd2) < R(4));
     if (collision) return -0.25;
     if (reaching) return 1.0;
     if (dmin < 0.2) return (dmin - 0.2) * 0.5 * dt;
@@ -128,13 +145,12 @@ __device__ __forceinline__ double pair_reward(const ChildrenArgs& ca, int p, int
 // root_clip.npz, action 0.  Each operation below is one float32 numpy scalar operation of utils.py:4-26 / :316-355, in order;
 // with v = 0 both kinematics reduce to the same arithmetic (v * cos(..) = +-0).
 __device__ __forceinline__ double stop_reward_f32(const ChildrenArgs& ca, int p, unsigned long long near_mask) {
-    const float* __restrict__ r = ca.robot + (size_t)p * 9;
-    const float* __restrict__ hs = ca.humans + (size_t)(p / ca.humans_per) * ca.H * 5;
+    const float* __restrict__ r = ca.robot + (size_t)(p - ca.p_base) * 9;
+    const float* __restrict__ hs = ca.humans + (size_t)(p / ca.humans_per - ca.c_base) * ca.H * 5;
     const float fdt = (float)ca.dt;
     bool collision = false;
     float dmin = INFINITY;
-    for (int h = 0; h < ca.H; ++h) {
-        if (h < 64 && !((near_mask >> h) & 1ull)) continue;
+    auto visit = [&](int h) {
         const float* hu = hs + h * 5;
         const float px = __fsub_rn(hu[0], r[0]), py = __fsub_rn(hu[1], r[1]);
         const float ex = __fadd_rn(px, __fmul_rn(hu[2], fdt)), ey = __fadd_rn(py, __fmul_rn(hu[3], fdt));
@@ -142,7 +158,7 @@ __device__ __forceinline__ double stop_reward_f32(const ChildrenArgs& ca, int p,
         {
             // the same exact shortcut as pair_reward: provably >= 0.25 of clearance, the human cannot influence the reward
             const float Tf = hu[4] + r[4] + 0.25f;
-            if (px * px + py * py >= 2.002f * (sx * sx + sy * sy + Tf * Tf)) continue;
+            if (px * px + py * py >= 2.002f * (sx * sx + sy * sy + Tf * Tf)) return;
         }
         float dist;
         if (sx == 0.f && sy == 0.f) {
@@ -156,7 +172,54 @@ __device__ __forceinline__ double stop_reward_f32(const ChildrenArgs& ca, int p,
         const float d = __fsub_rn(__fsub_rn(dist, hu[4]), r[4]);
         if (d < 0.f) collision = true;
         if (d < dmin) dmin = d;
+    };
+    unsigned long long todo = ca.H >= 64 ? near_mask : (near_mask & ((1ull << ca.H) - 1ull));
+    while (todo) {
+        const int h = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        visit(h);
     }
+    for (int h = 64; h < ca.H; ++h) visit(h);
+    const float gx = __fsub_rn(r[0], r[5]), gy = __fsub_rn(r[1], r[6]);
+    const bool reaching = sqrtf(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy))) < r[4];
+    if (collision) return -0.25;
+    if (reaching) return 1.0;
+    if (dmin < 0.2f) return (double)__fmul_rn(__fmul_rn(__fsub_rn(dmin, 0.2f), 0.5f), fdt);
+    return 0.0;
+}
+
+// stop_reward_f32 by one WHOLE wave (H <= 64): lane h takes human h, the minimum and the collision flag meet in a wave reduction -- the
+// same float32 operations per human, min / any over the same set, so the same bits.  Round 6: inside children_wave the one stop pair
+// among a wave's 64 made EVERY lane wait through this second loop over the crowd (the two reward forms are divergent branches).
+__device__ __forceinline__ double stop_reward_wave(const ChildrenArgs& ca, int p) {
+    const int lane = threadIdx.x & 63;
+    const float* __restrict__ r = ca.robot + (size_t)(p - ca.p_base) * 9;
+    const float* __restrict__ hs = ca.humans + (size_t)(p / ca.humans_per - ca.c_base) * ca.H * 5;
+    const float fdt = (float)ca.dt;
+    float d = INFINITY;                                   // my human's clearance (inf: no such human, or provably >= 0.25)
+    if (lane < ca.H) {
+        const float* hu = hs + lane * 5;
+        const float px = __fsub_rn(hu[0], r[0]), py = __fsub_rn(hu[1], r[1]);
+        const float ex = __fadd_rn(px, __fmul_rn(hu[2], fdt)), ey = __fadd_rn(py, __fmul_rn(hu[3], fdt));
+        const float sx = __fsub_rn(ex, px), sy = __fsub_rn(ey, py);
+        const float Tf = hu[4] + r[4] + 0.25f;
+        if (!(px * px + py * py >= 2.002f * (sx * sx + sy * sy + Tf * Tf))) {
+            float dist;
+            if (sx == 0.f && sy == 0.f) {
+                dist = sqrtf(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)));
+            } else {
+                float u = __fdiv_rn(__fadd_rn(__fmul_rn(-px, sx), __fmul_rn(-py, sy)), __fadd_rn(__fmul_rn(sx, sx), __fmul_rn(sy, sy)));
+                u = u > 1.f ? 1.f : (u < 0.f ? 0.f : u);
+                const float cx = __fadd_rn(px, __fmul_rn(u, sx)), cy = __fadd_rn(py, __fmul_rn(u, sy));
+                dist = sqrtf(__fadd_rn(__fmul_rn(cx, cx), __fmul_rn(cy, cy)));
+            }
+            d = __fsub_rn(__fsub_rn(dist, hu[4]), r[4]);
+        }
+    }
+    const bool collision = __ballot(d < 0.f) != 0ull;
+    float dmin = d;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, s));
     const float gx = __fsub_rn(r[0], r[5]), gy = __fsub_rn(r[1], r[6]);
     const bool reaching = sqrtf(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy))) < r[4];
     if (collision) return -0.25;
@@ -175,9 +238,11 @@ __device__ __forceinline__ bool is_python_int_stop(const ChildrenArgs& ca, int a
 // for and, when `reward_clip` is set (joint-state roots of a clipped search), ALSO as the tensor-born state upstream's root
 // action_clip is handed (model_predictive_rl.py:216-218 -> :246-248): the root's selection and the root's values price the same
 // action with two different roundings there.
-__device__ __forceinline__ void children_pa(const ChildrenArgs& ca, int p, int a, unsigned long long near_mask = ~0ull) {
+// `coop_stop`: the caller evaluates stop_reward_f32 itself (children_wave: by the whole wave), this call skips the outputs that need it
+__device__ __forceinline__ void children_pa(const ChildrenArgs& ca, int p, int a, unsigned long long near_mask = ~0ull,
+                                            bool coop_stop = false) {
     const long long idx = (long long)p * ca.A + a;
-    const float* r = ca.robot + (size_t)p * 9;
+    const float* r = ca.robot + (size_t)(p - ca.p_base) * 9;
     const double a0 = ca.actions[2 * a], a1 = ca.actions[2 * a + 1];
     const double dt = ca.dt;
     float c[9];
@@ -204,8 +269,9 @@ __device__ __forceinline__ void children_pa(const ChildrenArgs& ca, int p, int a
 #pragma unroll
     for (int i = 0; i < 9; ++i) co[i] = c[i];
     const bool stop = is_python_int_stop(ca, a);
-    ca.reward[idx] = (float)(!ca.joint && stop ? stop_reward_f32(ca, p, near_mask) : pair_reward(ca, p, a, near_mask, ca.joint, true));
-    if (ca.reward_clip)
+    if (!(coop_stop && stop && !ca.joint))
+        ca.reward[idx] = (float)(!ca.joint && stop ? stop_reward_f32(ca, p, near_mask) : pair_reward(ca, p, a, near_mask, ca.joint, true));
+    if (ca.reward_clip && !(coop_stop && stop))
         ca.reward_clip[idx] = (float)(stop ? stop_reward_f32(ca, p, near_mask) : pair_reward(ca, p, a, near_mask, 0, false));
 }
 
@@ -227,10 +293,12 @@ __device__ __forceinline__ void children_wave(const ChildrenArgs& ca, long long 
     const int lane = threadIdx.x & 63;
     const int A = ca.A, H = ca.H;
     const int pA = (int)(idx0 / A);
+    const int p_end = (int)((total + A - 1) / A);        // parents with pairs below `total` (a caller may own a sub-range of the level and
+                                                         // hand in row pointers that are valid for its own parents only)
     auto near_of = [&](int pm, int h) {
-        if (h >= H || pm >= ca.P) return false;
-        const float* r = ca.robot + (size_t)pm * 9;
-        const float* hu = ca.humans + ((size_t)(pm / ca.humans_per) * H + h) * 5;
+        if (h >= H || pm >= p_end || pm >= ca.P) return false;
+        const float* r = ca.robot + (size_t)(pm - ca.p_base) * 9;
+        const float* hu = ca.humans + ((size_t)(pm / ca.humans_per - ca.c_base) * H + h) * 5;
         const float qx = hu[0] - r[0], qy = hu[1] - r[1];
         const float sm = (sqrtf(hu[2] * hu[2] + hu[3] * hu[3]) + v_max) * (float)ca.dt;
         const float Tf = hu[4] + r[4] + 0.25f;
@@ -246,14 +314,29 @@ __device__ __forceinline__ void children_wave(const ChildrenArgs& ca, long long 
         mask_b = __ballot(near_of(pA + 1, lane));
     }
     const long long idx = idx0 + lane;
+    bool my_stop = false;
     if (idx < total) {
-        const int p = (int)(idx / A);
-        children_pa(ca, p, (int)(idx - (long long)p * A), p == pA ? mask_a : mask_b);
+        const int p = (int)(idx / A), a = (int)(idx - (long long)p * A);
+        children_pa(ca, p, a, p == pA ? mask_a : mask_b, true);
+        my_stop = is_python_int_stop(ca, a) && (!ca.joint || ca.reward_clip != nullptr);
+    }
+    // the stop pairs among my 64 (at most two: one per parent), each by the whole wave over the humans
+    unsigned long long stops = __ballot(my_stop);
+    while (stops) {
+        const int l = __ffsll((long long)stops) - 1;
+        stops &= stops - 1ull;
+        const long long sidx = idx0 + l;
+        const float rv = (float)stop_reward_wave(ca, (int)(sidx / A));
+        if (lane == l) {
+            if (!ca.joint) ca.reward[sidx] = rv;
+            if (ca.reward_clip) ca.reward_clip[sidx] = rv;
+        }
     }
 }
 
 // largest action speed of the table (holonomic: |(vx, vy)|, unicycle: |v|), by one whole wave; slightly rounded up
 __device__ __forceinline__ float table_speed_bound(const ChildrenArgs& ca) {
+    if (ca.v_max > 0.f) return ca.v_max;
     const int lane = threadIdx.x & 63;
     float m = 0.f;
     for (int k = lane; k < ca.A; k += 64) {

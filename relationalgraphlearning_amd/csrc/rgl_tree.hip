@@ -312,10 +312,16 @@ int expand_level(const MprlPlanner& pl, const float* robot, const float* humans,
     ca.robot = robot; ca.humans = humans; ca.humans_per = humans_per; ca.actions = pl.actions;
     ca.P = P; ca.H = H; ca.A = A; ca.kinematics = pl.kinematics; ca.dt = pl.time_step; ca.joint = joint;
     ca.child_robot = child_robot; ca.reward = reward;
+    ca.v_max = pl.action_speed_bound > 0.0 ? (float)pl.action_speed_bound * 1.0001f : 0.f;
+    ca.p_base = ca.c_base = 0;
     const bool roots64 = joint && humans_per == 1 && pl.root_robot_f64 && pl.root_humans_f64;
     ca.robot64 = roots64 ? pl.root_robot_f64 : nullptr;
     ca.humans64 = roots64 ? pl.root_humans_f64 : nullptr;
     int children_done = 0;              // set when the state predictor's scene kernel ran them on its extra workgroups
+    // (Round 6: the reward work inside the children launch -- every workgroup for the parents it owns, in its prologue under the
+    // weight image's DMA, inputs staged in LDS -- was built and measured: the embedding launch drops from 13.6 / 15.6 to 7.9 / 7.3 us,
+    // the children launches grow by 7.3 / 5.9: 277.6 against 279.0 us per 2048-root step, not worth a second home for that code;
+    // profiles/r06_p_timeline_rewards_in_children_ab.md.  The step is ~2-3 us of divergent float64 arithmetic per wave wherever it runs.)
     // (Running mprl_children_kernel beside the state predictor on a side stream was measured: the two overlap -- 34 us together
     // instead of 27 + 15 -- but the event fork / join costs more than that on the critical path: 0.405 vs 0.398 ms per step.)
     if (pl.linear_state_predictor) {
@@ -574,6 +580,8 @@ extern "C" int mprl_estimate_reward_f32(const MprlPlanner* planner, const float*
     ca.robot = robot; ca.humans = humans; ca.humans_per = 1; ca.actions = pl.actions;
     ca.P = P; ca.H = H; ca.A = pl.num_actions; ca.kinematics = pl.kinematics; ca.dt = pl.time_step; ca.joint = parents_are_joint_states;
     ca.child_robot = child_robot; ca.reward = reward;
+    ca.v_max = pl.action_speed_bound > 0.0 ? (float)pl.action_speed_bound * 1.0001f : 0.f;
+    ca.p_base = ca.c_base = 0;
     const bool roots64 = parents_are_joint_states && pl.root_robot_f64 && pl.root_humans_f64;
     ca.robot64 = roots64 ? pl.root_robot_f64 : nullptr;
     ca.humans64 = roots64 ? pl.root_humans_f64 : nullptr;

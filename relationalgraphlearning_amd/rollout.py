@@ -88,6 +88,14 @@ class TreeSearch:
         root_clip = A if self.do_action_clip else 0
         return root_clip + w * V(D)
 
+    def _speed_bound(self):
+        """MprlPlanner.action_speed_bound (ABI 8): max speed over the action table, once per table."""
+        if getattr(self, "_speed_bound_cache", None) is None:
+            a = self.actions_np
+            v = np.hypot(a[:, 0], a[:, 1]) if self.kinematics == "holonomic" else np.abs(a[:, 0])
+            self._speed_bound_cache = float(v.max()) if a.shape[0] else 0.0
+        return self._speed_bound_cache
+
     def _tables(self, device):
         key = str(device)
         if key not in self._dev_tables:
@@ -127,6 +135,7 @@ class TreeSearch:
         act, grp = self._tables(device)
         pl.actions = act.data_ptr()
         pl.action_groups = None if grp is None else grp.data_ptr()
+        pl.action_speed_bound = self._speed_bound()
         image = self._children_image(pl, device)
         pl.children_image = None if image is None else image.data_ptr()
         if not linear and mode == "bf16x6":

@@ -37,7 +37,7 @@ def test_struct_layout_matches_header_sizes():
     graph = 2 * mlp + 6 * 4 + 8 + mlp + 8 * 8
     assert ctypes.sizeof(nat.RglGraph) == graph
     assert ctypes.sizeof(nat.MprlLevelView) == 12 * 8               # ABI 6: + reward_clip_off
-    assert ctypes.sizeof(nat.MprlPlanner) == 2 * graph + 2 * mlp + 8 * 4 + 2 * 8 + 2 * 8 + 2 * 8 + 8 + 8  # ABI 2: + float64 root pointers; ABI 3: + children_image; ABI 4: + predictor_image
+    assert ctypes.sizeof(nat.MprlPlanner) == 2 * graph + 2 * mlp + 8 * 4 + 2 * 8 + 2 * 8 + 2 * 8 + 8 + 8 + 8  # ABI 8: + action_speed_bound; ABI 2: + float64 root pointers; ABI 3: + children_image; ABI 4: + predictor_image
     assert ctypes.sizeof(nat.GcnPlanner) == graph + mlp + 2 * 4 + 2 * 8 + 8 + 2 * 8 + 2 * 4        # ABI 8: + contraction_dtype, reserved
     assert ctypes.sizeof(nat.RglTransposeJob) == 2 * 8 + 2 * 4 and ctypes.sizeof(nat.RglGatherJob) == 2 * 8 + 2 * 4      # ABI 7
 
