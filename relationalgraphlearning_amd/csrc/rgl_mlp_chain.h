@@ -595,32 +595,38 @@ __device__ __forceinline__ void layer_mfma_b6(const float* frags, const f32x4 (&
         if constexpr (BIAS) out[ot] = *reinterpret_cast<const f32x4*>(&bias[16 * ot + 4 * q]);
         else out[ot] = zero4();
     }
-    constexpr int G = 2;
+    // Blocks (chunk c, pair of output tiles) in order, their fragments double-buffered (round 6): block b + 1's six b128 reads are issued
+    // in front of block b's twelve MFMAs, and the first block's in front of the first split -- the LDS latency sits under work
+    // instead of in front of every block (ddddddw BBBBBBBBBBBB in the round-5 instruction stream).
+    constexpr int G = 2, NOB = (OT + G - 1) / G, NB = NC * NOB;
+    bf16x8 w[2][G][3];
+    auto load_block = [&](int b, int buf) {
+        const int c = b / NOB, o0 = G * (b % NOB);
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                if (o0 + g < OT) w[buf][g][pc] = *reinterpret_cast<const bf16x8*>(&frags[((((o0 + g) * NC + c) * 3 + pc) * 64 + lane) * 4]);
+    };
+    load_fence();
+    load_block(0, 0);
+    Split3 s;
+    static_for<0, NB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value, c = b / NOB, o0 = G * (b % NOB), buf = b & 1;
+        if constexpr (b % NOB == 0) s = split3_pair(in[2 * c], 2 * c + 1 < IT ? in[2 * c + 1 < IT ? 2 * c + 1 : 0] : zero4());
         load_fence();
-        const Split3 s = split3_pair(in[2 * c], 2 * c + 1 < IT ? in[2 * c + 1 < IT ? 2 * c + 1 : 0] : zero4());
-#pragma unroll
-        for (int o0 = 0; o0 < OT; o0 += G) {
-            load_fence();
-            bf16x8 w[G][3];
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    if (o0 + g < OT) w[g][pc] = *reinterpret_cast<const bf16x8*>(&frags[((((o0 + g) * NC + c) * 3 + pc) * 64 + lane) * 4]);
+        if constexpr (b + 1 < NB) load_block(b + 1, buf ^ 1);
 #define RGL_B6_TERM(WP, AP)                                                                                         \
     _Pragma("unroll") for (int g = 0; g < G; ++g)                                                                   \
-        if (o0 + g < OT) out[o0 + g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g][WP], s.AP, out[o0 + g], 0, 0, 0);
-            RGL_B6_TERM(2, h)          // small terms first
-            RGL_B6_TERM(1, m)
-            RGL_B6_TERM(0, l)
-            RGL_B6_TERM(1, h)
-            RGL_B6_TERM(0, m)
-            RGL_B6_TERM(0, h)
+        if (o0 + g < OT) out[o0 + g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[buf][g][WP], s.AP, out[o0 + g], 0, 0, 0);
+        RGL_B6_TERM(2, h)          // small terms first
+        RGL_B6_TERM(1, m)
+        RGL_B6_TERM(0, l)
+        RGL_B6_TERM(1, h)
+        RGL_B6_TERM(0, m)
+        RGL_B6_TERM(0, h)
 #undef RGL_B6_TERM
-        }
-    }
+    });
     load_fence();
 }
 
