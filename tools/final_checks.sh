@@ -15,4 +15,6 @@ echo "gpu tests rc=$?"; tail -2 $O/${TAG}_gpu_tests.log
   RGL_CONTRACT_F32_AS=bf16x6 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -150; } > $O/${TAG}_suite_under_bf16x6.txt
 tail -2 $O/${TAG}_suite_under_bf16x6.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+{ echo "# RGL_DEBUG_POISON_WORKSPACES=1 python -m pytest tests -m gpu -q   (workspaces and output slabs pre-filled with NaN patterns), source revision $HASH"; RGL_DEBUG_POISON_WORKSPACES=1 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3; } > $O/${TAG}_suite_poisoned_workspaces.txt
+tail -1 $O/${TAG}_suite_poisoned_workspaces.txt
 bash tools/round_all.sh $TAG $HASH
