@@ -794,7 +794,7 @@ def main():
                      "Wa, W_l, motion head; everything else f32",
             "float64_check": "cpu_baseline.float64_check of this line (needs --cpu-seconds > 0); "
                              "tests/test_gpu_parity.py::test_bf16x6_head_matrix_at_size_and_in_other_shapes asserts it",
-            "suite_under_the_mode": "profiles/r05_final_suite_under_bf16x6.txt (RGL_CONTRACT_F32_AS=bf16x6: every f32 search of the GPU suite in this mode)"}
+            "suite_under_the_mode": "profiles/r06_final_suite_under_bf16x6.txt (RGL_CONTRACT_F32_AS=bf16x6: every f32 search of the GPU suite in this mode)"}
     result["config"]["contraction"] = args.contraction
     result["config"]["contraction_requested"] = args.contraction_requested
     if STUB:
