@@ -273,3 +273,23 @@ def test_tree_search_image_caches_are_keyed_on_the_contraction_mode():
     for fn in (rollout.TreeSearch._children_image, rollout.TreeSearch._predictor_image):
         src = inspect.getsource(fn)
         assert "self.contraction_dtype" in src.split("ent = ")[0], fn.__name__
+
+
+def test_planner_speed_bound_and_path_g_contraction_modes():
+    """ABI 8 host side: MprlPlanner.action_speed_bound is the top speed of the search's own action table (holonomic: |(vx, vy)|,
+    unicycle: |v|) -- the reward step prunes far humans with it, so it must never be below a table entry; path G's search accepts the
+    two contraction modes GcnPlanner knows and refuses anything else before any device work."""
+    import numpy as np
+    from relationalgraphlearning_amd import actions as act
+    from relationalgraphlearning_amd.rollout import GcnSearch, TreeSearch
+    table = act.speed_major_table(1.0, 5, 16, "holonomic", np.pi / 3)[0]
+    arr = act.as_array(table)
+    ts = TreeSearch(None, None, arr, None, "holonomic")
+    assert ts._speed_bound() == float(np.hypot(arr[:, 0], arr[:, 1]).max()) and ts._speed_bound() >= 1.0 - 1e-12
+    uni = act.speed_major_table(1.0, 5, 16, "unicycle", np.pi / 3)[0]
+    ua = act.as_array(uni)
+    assert TreeSearch(None, None, ua, None, "unicycle")._speed_bound() == float(np.abs(ua[:, 0]).max())
+    for mode in ("f32", "bf16x6"):
+        assert GcnSearch(None, arr, contraction_dtype=mode).contraction_dtype == mode
+    with pytest.raises(ValueError):
+        GcnSearch(None, arr, contraction_dtype="f16")
