@@ -154,6 +154,62 @@ def test_expand_level_against_oracle(dev):
     assert np.abs(got["reward"].cpu().numpy() - ar["rew.sweep_joint"]).max() < 1e-7
 
 
+@pytest.mark.parametrize("kin", ["holonomic", "unicycle"])
+def test_reward_step_over_crowd_sizes_and_dense_scenes(kin, dev):
+    """Round 6 rewrote the reward step's inner structure (rgl_children.h: one visit per SET BIT of the far-human mask, the python-int stop
+    action evaluated by the whole wave over the humans, the goal test on squares away from the boundary, the planner's speed bound).
+    None of that may move a bit: estimate_reward + compute_next_state on their own (mprl_estimate_reward_f32) against the oracle's
+    vectorised transcription (pinned on the reference's own rewards by tests/test_oracle_golden.py) for crowd sizes around every
+    width the masks care about -- 1, 31 / 32 / 33 (two parents per ballot up to 32), 63 / 64 (one ballot per parent), 65 (no masks:
+    the per-thread path) -- with DENSE crowds (humans within 0.4-1.6 m: several near humans per parent, collisions, discomfort
+    values, robots at their goals), an odd parent count (a partial last wave), tensor-born and joint-state readings."""
+    cfg = orc.OracleConfig(kinematics=kin)
+    acts, _ = orc.mprl_action_space(cfg, 1.0)
+    pol = make_mprl_policy("trained", D=1, device=dev)
+    pol.kinematics = kin
+    pol.build_action_space(1.0)
+    ts = pol.tree_search()
+    assert np.array_equal(ts.actions_np, acts)
+    rng = np.random.RandomState(606)
+    n_coll = n_disc = n_goal = 0
+    for H in (1, 2, 31, 32, 33, 63, 64, 65):
+        P = 37
+        robot = np.zeros((P, 9), np.float32)
+        robot[:, 0:2] = rng.uniform(-3, 3, (P, 2))
+        robot[:, 2:4] = rng.uniform(-0.5, 0.5, (P, 2))
+        robot[:, 4] = 0.3
+        robot[:, 5:7] = robot[:, 0:2] + rng.uniform(-0.6, 0.6, (P, 2)) * (rng.rand(P, 1) < 0.3) + rng.uniform(-4, 4, (P, 2)) * (rng.rand(P, 1) < 0.7)
+        robot[:, 7] = 1.0
+        robot[:, 8] = rng.uniform(-np.pi, np.pi, P)
+        humans = np.zeros((P, H, 5), np.float32)
+        ang = rng.uniform(0, 2 * np.pi, (P, H))
+        rad = np.where(rng.rand(P, H) < 0.25, rng.uniform(0.45, 1.6, (P, H)), rng.uniform(1.6, 6.0, (P, H)))      # a quarter of them close
+        humans[:, :, 0] = robot[:, None, 0] + rad * np.cos(ang)
+        humans[:, :, 1] = robot[:, None, 1] + rad * np.sin(ang)
+        humans[:, :, 2:4] = rng.uniform(-1, 1, (P, H, 2))
+        humans[:, :, 4] = 0.3
+        rt, ht = torch.tensor(robot), torch.tensor(humans)
+        want_child = orc._children_robot(rt, acts, cfg).numpy()
+        for joint in (False, True):
+            child, reward = ts.estimate_reward(rt.to(dev), ht.to(dev), parents_are_joint_states=joint)
+            want = orc.estimate_reward_batched(rt, ht, acts, cfg, root=joint)
+            got = reward.cpu().numpy()
+            if kin == "holonomic":
+                assert np.array_equal(child.cpu().numpy(), want_child), (H, joint)
+                assert np.array_equal(got, want.astype(np.float32)), (H, joint, float(np.abs(got - want).max()))
+            else:
+                # the device's cos / sin are not the host libm's (last-bit differences in the heading terms): the bound of
+                # test_unicycle_kinematics_both_paths; a branch of the reward may only differ where the oracle itself is within 1e-6
+                # of that branch's threshold
+                assert np.abs(child.cpu().numpy() - want_child).max() < 1e-6, (H, joint)
+                off = np.abs(got - want) > 1e-6
+                assert off.mean() < 2e-3, (H, joint, float(off.mean()))
+            n_coll += int((want == -0.25).sum()); n_disc += int(((want < 0) & (want > -0.25)).sum()); n_goal += int((want == 1.0).sum())
+    assert n_coll > 100 and n_disc > 100 and n_goal > 100, (n_coll, n_disc, n_goal)          # every branch of the reward is exercised
+    report("reward step, %s, H in {1..65}, dense crowds: float32 rewards and child rows %s (%d collisions, %d discomfort "
+           "values, %d goals among the pairs)" % (kin, "bit for bit" if kin == "holonomic" else "to 1e-6 (device cos / sin)", n_coll, n_disc, n_goal))
+
+
 def test_reward_kats(dev):
     ar = gio.load("actions_rewards")
     pol = make_mprl_policy("trained", D=1, device=dev)
