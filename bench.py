@@ -553,10 +553,10 @@ def children_roofline(args, ts, device, N, H, last, robot=None, humans=None):
     peak, peak_note = FP32_PEAK_TFLOPS, "fp32 vector == f32-MFMA peak (the two do not co-execute on gfx950)"
     if args.contraction == "bf16x6":
         # input features 0..95 of the 100 x 100 head matrix, all 32 of the 32 x 100 one (onto their 96 full-tile outputs), the 32 x 32
-        # layer before them and (round 6) the tile chain's weight products -- hidden -> x0 (64 x 32), x0 Wa, x0 W1, T_0 W1 -- plus the
-        # crowd's Xh Wa / U W1 (H rows per parent, shared by its A children) run on the bf16 matrix pipe as SIX terms, i.e. at a sixth of
+        # layer before them and (round 6) the tile chain's weight products -- hidden -> x0 (64 x 32), x0 Wa, x0 W1, T_0 W1, W_last --
+        # plus the crowd's Xh Wa / U W1 (H rows per parent, shared by its A children) run on the bf16 matrix pipe as SIX terms, i.e. at a sixth of
         # the dense bf16 MFMA peak; everything else at the fp32 rate: time-weighted peak
-        dense = (2 * 96 * 96 + 2 * 32 * 96 + 2 * 32 * 32) + (2 * 64 * 32 + 3 * 2 * 32 * 32) + 2.0 * (N - 1) * 2 * 32 * 32 / A
+        dense = (2 * 96 * 96 + 2 * 32 * 96 + 2 * 32 * 32) + (2 * 64 * 32 + 4 * 2 * 32 * 32) + 2.0 * (N - 1) * 2 * 32 * 32 / A
         b6_peak = F16_MFMA_PEAK_TFLOPS / 6.0
         peak = flop_per_scene / (dense / b6_peak + (flop_per_scene - dense) / FP32_PEAK_TFLOPS)
         peak_note = "blend: %.0f%% of the FLOPs as 6 bf16 MFMA terms over three-piece (24-bit) operands (a sixth of the dense bf16 MFMA peak = %.0f), the rest at the fp32 peak (%.1f)" % (
@@ -757,7 +757,7 @@ def main():
                                  "note": "set-up steps 2..9 of this process, before the device reached its steady clock (not timed into `value`)"}),
         "vs_baseline": None, "dtype": {"f32": "f32", "f16": "f16 inputs / f32 accumulate (middle-layer products only; everything else f32)",
                                        "bf16x6": "f32 (24-bit operands throughout; 13 312 of the 14 224 products of the children kernel's 32 x 32, 32 x 100 and "
-                                                 "100 x 100 head matrices, its embedding / graph weight products (w_r's second layer, Wa, W1) "
+                                                 "100 x 100 head matrices, its embedding / graph weight products (w_r's second layer, Wa, W1, W_last) "
                                                  "and the state predictor's weight products as six bf16 MFMA terms over three "
                                                  "round-to-nearest bf16 pieces per operand, f32 accumulate, dropped terms <= 2^-23 |w||a| (worst case); "
                                                  "everything else on the f32 MFMA / VALU)"}[args.contraction],
@@ -789,7 +789,7 @@ def main():
             "terms": "6 of 9 (lo*hi, mid*mid, hi*lo, mid*hi, hi*mid, hi*hi), f32 accumulate",
             "dropped_terms_bound": "w_mid a_lo + w_lo a_mid + w_lo a_lo <= (2^-24 + 2^-24 + 2^-32) |w||a| < 2^-22.99 |w||a| per product in the worst case (|mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|), ~2^-25 typically; unbiased",
             "where": "children_fused_kernel: the 32 x 32, 32 x 100 and 100 x 100 value-head matrices, input features 0..95 onto output "
-                     "features 0..95, and (round 6) w_r's 64 x 32 layer, Wa and W1 in the tile chain and the crowd computation (what the CU's LDS "
+                     "features 0..95, and (round 6) w_r's 64 x 32 layer, Wa, W1 and W_last in the tile chain and the crowd computation (what the CU's LDS "
                      "holds as three bf16 pieces with w_h's second matrix in registers and the 4 x 4 x 1 fragments stored compact); scene_graph_kernel: "
                      "Wa, W_l, motion head; everything else f32",
             "float64_check": "cpu_baseline.float64_check of this line (needs --cpu-seconds > 0); "
