@@ -49,6 +49,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+INIT_MS = float(os.environ.get("RGL_BENCH_INIT_MS", "80"))  # least duration of the set-up phase (device clock ramp), see main()
 STUB = os.environ.get("RGL_BENCH_STUB_SEARCH") == "1"       # launcher / exchange test switch: no device, no kernels, no measurement
 
 import relationalgraphlearning_amd as rga  # noqa: E402
@@ -404,6 +405,7 @@ class Leg:
         # is recorded whatever `init_steps` is (with 4..10 set-up steps the last one never was, and elapsed_time raised)
         n_cold = min(init_steps, 10)
         cold = None if STUB or n_cold == 0 else [torch.cuda.Event(enable_timing=True) for _ in range(n_cold + 1)]
+        t_init = time.perf_counter()
         for i in range(init_steps):
             if cold and i <= n_cold:
                 cold[i].record()
@@ -412,6 +414,21 @@ class Leg:
             cold[n_cold].record()
         self.drain()
         self.fence()
+        # ... and the set-up phase lasts INIT_MS of device work at least (the clock ramp is a matter of time, not of steps: with
+        # the step at 0.26 ms, 40 of them end before the device holds its clock -- profiles/r06_init_sweep.txt)
+        self.init_steps_run = init_steps
+        if init_steps > 0:
+            spent = (time.perf_counter() - t_init) * 1e3
+            more = min(20000, int(max(0.0, INIT_MS - spent) / max(spent / init_steps, 1e-3)))
+            if self.dist is not None:          # every rank runs the same number of steps (each one is an exchange)
+                t = torch.tensor([more], dtype=torch.int64, device=self.device)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+                more = int(t.item())
+            for _ in range(more):
+                self.step()
+            self.drain()
+            self.fence()
+            self.init_steps_run += more
         # steps 2.. of the set-up phase (the very first ones also pay for code objects and workspaces): a cold device's step time
         self.cold_ms = (sorted(cold[i].elapsed_time(cold[i + 1]) for i in range(2, n_cold))
                         if cold and n_cold > 3 else None)
@@ -683,6 +700,9 @@ def main():
     # the device needs ~15 ms of work to reach the clock it then holds: measured on one box with `--steps 20 --warmup 5`
     # (profiles/r04_init_steps.txt), 3 set-up steps: 0.398 ms per timed step, 40 or 150: 0.375-0.377.  The line reports what
     # the first steps cost (`step_ms_device_cold`: HIP events around set-up steps 2..9) beside the steady figure.
+    # Round 6: the ramp is a matter of TIME -- with the step at 0.26 ms, 40 set-up steps (10 ms) left the driver's 20 timed steps on a
+    # device still below its clock: 0.268-0.276 ms against 0.260 with 40 ms or more of set-up, three repeats each on one box
+    # (profiles/r06_init_sweep.txt) -- so the set-up phase now runs INIT_STEPS steps and at least RGL_BENCH_INIT_MS of them.
     INIT_STEPS = int(os.environ.get("RGL_BENCH_INIT_STEPS", "40"))
     leg = Leg(args, ts, device, world, rank, main_leg[1], main_leg[2], dist)
     gc.collect()
@@ -766,7 +786,7 @@ def main():
                                "action-tree rollout, %s" % (workload_name(N, args, main_leg[0]), N, H, args.layers, args.depth, args.width,
                                                             ("%d root scenes per GPU" % B) if main_leg[0] == "weak" else
                                                             ("%d root scenes in total over %d GPU(s)" % (total_roots, world))),
-                   "roots_per_gpu": B, "total_roots": total_roots, "logical_value_evals_per_root": per_root, "init_steps": INIT_STEPS,
+                   "roots_per_gpu": B, "total_roots": total_roots, "logical_value_evals_per_root": per_root, "init_steps": getattr(leg, "init_steps_run", INIT_STEPS), "init_ms": INIT_MS,
                    # what changed in HOW the line is measured, so that round-over-round deltas can be read: 1 = rounds
                    # 1-3 (3 set-up steps, event marks inside the timed loop); 2 = round 4 on (40 untimed set-up steps in front of
                    # --warmup so the device holds its steady clock; per-step event marks in a second pass after the timed region)

@@ -45,6 +45,23 @@
     } while (0)
 #define RGL_LAUNCH_CHECK() RGL_HIP_TRY(hipGetLastError())
 
+// -DRGL_PHASE_TIMING -DRGL_PHASE_HEAD: the phase counters belong to mlp_rows_kernel (the value head) instead of mlp2_rows_kernel
+#ifdef RGL_PHASE_HEAD
+#define HEAD_PHASE_START() PHASE_START()
+#define HEAD_PHASE_MARK(i) PHASE_MARK(i)
+#define HEAD_PHASE_FLUSH() PHASE_FLUSH()
+#define ROWS2_PHASE_START() do { } while (0)
+#define ROWS2_PHASE_MARK(i) do { } while (0)
+#define ROWS2_PHASE_FLUSH() do { } while (0)
+#else
+#define HEAD_PHASE_START() do { } while (0)
+#define HEAD_PHASE_MARK(i) do { } while (0)
+#define HEAD_PHASE_FLUSH() do { } while (0)
+#define ROWS2_PHASE_START() PHASE_START()
+#define ROWS2_PHASE_MARK(i) PHASE_MARK(i)
+#define ROWS2_PHASE_FLUSH() PHASE_FLUSH()
+#endif
+
 namespace {
 
 __device__ __forceinline__ void wave_sync() {         // LDS written by some lanes of the wave, read by others
@@ -53,10 +70,18 @@ __device__ __forceinline__ void wave_sync() {         // LDS written by some lan
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier for waves that talk through LDS only: __syncthreads() also waits for every global store of the wave to be
+// acknowledged (vmcnt(0): ~2.8 k cycles behind each layer's gradient stores in mlp_rows_kernel), this one orders LDS alone.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // C[MT*16][NTL*16] += A[.][k] B[k][.] over `ksteps` groups of four k: fa(row, k) / fb(k, col) fetch the operand elements
 // (LDS or L1-resident weights; the callers clamp / zero what lies outside their matrices).  One A fragment per row tile and one B
 // fragment per column tile feed MT*NTL MFMAs.  D row 4 (lane / 16) + r, column lane % 16 is element r of a lane's accumulator.
-template <int MT, int NTL, int U, class FA, class FB>
+template <int MT, int NTL, int U, bool PIN, class FA, class FB>
 __device__ __forceinline__ void mm_steps(f32x4 (&acc)[MT][NTL], int ks0, FA& fa, FB& fb) {
     const int l16 = threadIdx.x & 15, kk = (threadIdx.x & 63) >> 4;
     float av[U][MT], bv[U][NTL];
@@ -68,6 +93,10 @@ __device__ __forceinline__ void mm_steps(f32x4 (&acc)[MT][NTL], int ks0, FA& fa,
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) bv[u][nt] = fb(k, nt * 16 + l16);
     }
+    // PIN: every fragment of the batch requested before its first MFMA (left alone, the scheduler sinks the loads to their uses and
+    // reuses two registers: an LDS round trip per two k steps -- fine where other waves cover it, not for a workgroup that owns one
+    // tile; pinned everywhere, the wide kernels of this file spill)
+    if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -76,15 +105,15 @@ __device__ __forceinline__ void mm_steps(f32x4 (&acc)[MT][NTL], int ks0, FA& fa,
             for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = mfma4(av[u][mt], bv[u][nt], acc[mt][nt]);
     load_fence();            // the next batch's loads stay behind this batch (hoisting them all costs hundreds of VGPRs)
 }
-template <int MT, int NTL, int U, class FA, class FB>
+template <int MT, int NTL, int U, bool PIN, class FA, class FB>
 __device__ __forceinline__ void mm_from(f32x4 (&acc)[MT][NTL], int& ks, int ksteps, FA& fa, FB& fb) {
-    for (; ks + U <= ksteps; ks += U) mm_steps<MT, NTL, U>(acc, ks, fa, fb);
-    if constexpr (U > 1) mm_from<MT, NTL, U / 2>(acc, ks, ksteps, fa, fb);        // the remainder in halving batches
+    for (; ks + U <= ksteps; ks += U) mm_steps<MT, NTL, U, PIN>(acc, ks, fa, fb);
+    if constexpr (U > 1) mm_from<MT, NTL, U / 2, PIN>(acc, ks, ksteps, fa, fb);        // the remainder in halving batches
 }
-template <int MT, int NTL, int UNROLL = 2, class FA, class FB>
+template <int MT, int NTL, int UNROLL = 2, bool PIN = false, class FA, class FB>
 __device__ __forceinline__ void mm(f32x4 (&acc)[MT][NTL], int ksteps, FA fa, FB fb) {
     int ks = 0;
-    mm_from<MT, NTL, UNROLL>(acc, ks, ksteps, fa, fb);
+    mm_from<MT, NTL, UNROLL, PIN>(acc, ks, ksteps, fa, fb);
 }
 template <int MT, int NTL>
 __device__ __forceinline__ void clear(f32x4 (&acc)[MT][NTL]) {
@@ -151,7 +180,7 @@ struct RowsJob {
     int wg_begin, n_wgs, waves_per_wg;
     int coop;                                                   // mlp_rows_kernel: one tile per WORKGROUP (n_waves counts workgroups)
     int wave_floats;                                            // LDS of one wave
-    int kind;                                                   // 0: mlp_rows_kernel; 10 T0 + T2: mlp2_rows_kernel<T0, T2>
+    int kind;                                                   // 0: mlp_rows_kernel; 1: head_rows_kernel; 10 T0 + T2: mlp2_rows_kernel<T0, T2>
     int need_din, din_add;
     RowMap in, out, d_out, d_in;      // out: forward-only launches; d_out (null = zeros) / d_in: backward launches
     float* slabs;                     // [n_waves][n_params]
@@ -161,36 +190,86 @@ struct RowsArgs {
     int n_jobs, backward;
 };
 
-// weights and bias of layer l of the job's MLP -> the workgroup's LDS
-__device__ __forceinline__ void stage_layer(const RowsJob& J, float* lds, int l) {
+// weights and biases of layers [l0, l1) of the job's MLP -> the workgroup's LDS.  The layers are cut into chunks of U elements per
+// thread (element e of a layer: weight e of torch-transposed [in][out], then the biases) and the chunks run as a two-deep pipeline:
+// the next chunk's loads are in flight while this one's values are stored.  (Round 5 staged a column at a time, eight loads deep:
+// nine dependent trips to L2 / the Infinity Cache -- the weights were just written by the optimizer step -- for the value head.)
+template <int U>
+__device__ __forceinline__ void stage_layers(const RowsJob& J, float* lds, int l0, int l1) {
     const RglMlp& m = J.m;
-    const int in = m.dims[l], out = m.dims[l + 1], ld = J.w_ld[l];
-    float* Wl = lds + J.w_lds[l];
-    const float* __restrict__ W = m.weight[l];
-    // thread (k0 = t / 32, c = t % 32): columns c, c + 32, .. of rows k0, k0 + 8, ..   (no divisions in the loops)
-    for (int c = threadIdx.x & 31; c < out; c += 32)
-        gather<8>(in, threadIdx.x >> 5, blockDim.x >> 5, [&](int k) { return W[k * out + c]; },
-                  [&](int k, float v) { Wl[k * ld + c] = v; });
-    for (int c = threadIdx.x; c < out; c += blockDim.x) lds[J.b_lds[l] + c] = m.bias[l][c];
-}
-// all layers (ends with a barrier); a job whose layers are staged one at a time (coop == 2) stages nothing here
-__device__ __forceinline__ void stage_weights(const RowsJob& J, float* lds) {
-    if (J.coop != 2)
-        for (int l = 0; l < J.m.n_layers; ++l) stage_layer(J, lds, l);
-    __syncthreads();
+    const int step = blockDim.x, span = U * step;
+    auto issue = [&](int l, int base, float (&v)[U]) {
+        const int out = m.dims[l + 1], nw = m.dims[l] * out;
+        const float* __restrict__ W = m.weight[l];
+        const float* __restrict__ B = m.bias[l];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {       // one unconditional load per element (a guarded one is a branch, and the loads serialise)
+            const int e = base + threadIdx.x + u * step;
+            const float* p = e < nw ? W + e : B + min(e - nw, out - 1);
+            v[u] = *p;
+        }
+    };
+    auto store = [&](int l, int base, const float (&v)[U]) {
+        const int out = m.dims[l + 1], nw = m.dims[l] * out, n = nw + out, ld = J.w_ld[l];
+        const float rcp = 1.0f / (float)out;
+        float* Wl = lds + J.w_lds[l];
+        float* Bl = lds + J.b_lds[l];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = base + threadIdx.x + u * step;
+            if (e < nw) {
+                const int k = (int)(((float)e + 0.5f) * rcp);      // e / out, exact: e < 2^16 and the quotient is at most 256
+                Wl[k * ld + (e - k * out)] = v[u];
+            } else if (e < n) {
+                Bl[e - nw] = v[u];
+            }
+        }
+    };
+    if (l0 >= l1) return;
+    // chunk (l, base) -> the one behind it; false behind the last one
+    auto advance = [&](int& l, int& base) {
+        base += span;
+        if (base >= (m.dims[l] + 1) * m.dims[l + 1]) { ++l; base = 0; }
+        return l < l1;
+    };
+    float va[U], vb[U];                 // ping and pong (a copy between them would wait for the loads it copies)
+    int l = l0, base = 0;
+    issue(l, base, va);
+    while (true) {
+        int ln = l, bn = base;
+        bool more = advance(ln, bn);
+        if (more) issue(ln, bn, vb);
+        store(l, base, va);
+        if (!more) break;
+        l = ln; base = bn;
+        more = advance(ln, bn);
+        if (more) issue(ln, bn, va);
+        store(l, base, vb);
+        if (!more) break;
+        l = ln; base = bn;
+    }
 }
 
 // Workgroups of up to four waves: the MLP's weights are staged once per workgroup in LDS (k-major rows of odd stride: the forward's
 // B-operand reads and the transposed reads of the delta products both stay within two-way bank conflicts), then every wave works
 // through its own 16-row tiles without further barriers: every layer's activations of the tile in LDS ([16][act_ld]) together with
 // two delta buffers ([16][d_ld]).  A wave's first tile writes its gradient slab, later tiles add to it (L2-resident).
+//
+// Round 6: a workgroup that owns ONE tile (few tiles: the value head at the reference's batch) now runs head_rows_kernel below;
+// what stays here is the many-tiles form and, under RGL_HEAD_ROWS_DIRECT=0, the one-tile form as the A/B partner
+// (profiles/r06_head_rows.txt: 35.7 us in round 5 -> 30.3 us here -> 23.0 us there).  What this kernel gained on the way: the first
+// tile's rows, its upstream gradient and (where they are added to) its input gradients are requested BEFORE the weights, which
+// arrive as a pipeline of chunks; the ReLU masks are applied where a delta is produced instead of in passes of their own with a
+// barrier each; the barriers order LDS only (__syncthreads() waits for the gradient stores' acknowledgements); a shared tile's
+// products deal single column tiles to the eight waves with eight k steps of operands requested at once.
 constexpr int kCoopWaves = 8;          // waves of a workgroup that shares one tile (mlp_rows_kernel, coop)
+constexpr int kRowsPre = 8;            // elements per lane of a 16-row tile that are requested ahead (rows of up to 32 columns)
 __global__ __launch_bounds__(kCoopWaves * 64) void mlp_rows_kernel(const RowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l16 = lane & 15;
     const int ji = (a.n_jobs > 1 && (int)blockIdx.x >= a.job[1].wg_begin) ? 1 : 0;
     const RowsJob& J = a.job[ji];
-    stage_weights(J, lds);
+    HEAD_PHASE_START();
     // coop (few tiles, wide layers: the value head): the eight waves of the workgroup share ONE tile -- the column tiles of every
     // product are dealt to them, with a workgroup barrier between phases -- instead of a tile each
     // (coop == 2: the MLP's weights do not fit LDS next to the tile -- path G's 150-100-100-1 head is 121 KB -- and every layer is
@@ -198,92 +277,184 @@ __global__ __launch_bounds__(kCoopWaves * 64) void mlp_rows_kernel(const RowsArg
     const bool coop = J.coop != 0, per_layer = J.coop == 2;
     const int WV = coop ? kCoopWaves : 1, wv = coop ? wave : 0;
     const int w = coop ? (int)blockIdx.x - J.wg_begin : ((int)blockIdx.x - J.wg_begin) * J.waves_per_wg + wave;
-    if ((!coop && wave >= J.waves_per_wg) || w >= J.n_waves) return;
-    auto sync = [&]() { if (coop) __syncthreads(); else wave_sync(); };
+    const bool mine = !((!coop && wave >= J.waves_per_wg) || w >= J.n_waves);
     const RglMlp& m = J.m;
     const int L = m.n_layers, ald = J.act_ld, dld = J.d_ld;
+    // element-wise passes over the tile: lane -> (row rr = lane / 4, columns c4, c4 + 4, ..)
+    const int rr = lane >> 2, c4 = lane & 3;
+    const int d0 = m.dims[0], d0p = (d0 + 3) & ~3, dL = m.dims[L], dLp = (dL + 3) & ~3;
+    const bool relu_top = m.last_relu != 0;
+    // what the first tile reads from global memory, requested ahead of the weights (rows of up to 32 columns: the value head's 32)
+    const bool pre_in = mine && d0p <= 4 * kRowsPre, pre_dout = mine && a.backward && dLp <= 4 * kRowsPre;
+    const bool pre_din = mine && a.backward && J.need_din && J.din_add && d0 <= 4 * kRowsPre;
+    float xin[kRowsPre], dov[kRowsPre], dinv[kRowsPre];
+    {
+        const int r0 = w * 16;
+        const bool rok = mine && r0 + rr < J.n_rows;
+        const int rrow = rok ? r0 + rr : (J.n_rows > 0 ? J.n_rows - 1 : 0);
+        // unconditional loads from clamped addresses, the guards where the values are used, behind the barrier (a guarded load -- or
+        // a guarded use the load can sink to -- is a branch with a wait inside: 24 round trips one after the other)
+#pragma unroll
+        for (int u = 0; u < kRowsPre; ++u) xin[u] = dov[u] = dinv[u] = 0.f;
+        if (pre_in) {
+            const float* src = row_at(J.in, rrow);
+#pragma unroll
+            for (int u = 0; u < kRowsPre; ++u) xin[u] = src[min(c4 + 4 * u, d0 - 1)];
+        }
+        if (pre_dout && J.d_out.p) {
+            const float* src = row_at(J.d_out, rrow);
+#pragma unroll
+            for (int u = 0; u < kRowsPre; ++u) dov[u] = src[min(c4 + 4 * u, dL - 1)];
+        }
+        if (pre_din) {
+            const float* src = row_at(J.d_in, rrow);
+#pragma unroll
+            for (int u = 0; u < kRowsPre; ++u) dinv[u] = src[min(c4 + 4 * u, d0 - 1)];
+        }
+    }
+    if (!per_layer) stage_layers<16>(J, lds, 0, L);
+    lds_barrier();
+    HEAD_PHASE_MARK(0);
+    if (!mine) {
+        HEAD_PHASE_FLUSH();
+        return;
+    }
+    auto sync = [&]() { if (coop) lds_barrier(); else wave_sync(); };
     float* acts = lds + J.weight_floats + (coop ? 0 : wave) * (16 * ald + 32 * dld);
     float* dcur = acts + 16 * ald;
     float* dnxt = dcur + 16 * dld;
     float* slab = J.slabs + (size_t)w * J.n_params;
     bool first = true;
-    // element-wise passes over the tile: lane -> (row rr = lane / 4, columns c4, c4 + 4, ..)
-    const int rr = lane >> 2, c4 = lane & 3;
+    // C[16][NTL * 16] blocks of a product dealt to the waves that share the tile: one column tile each (coop) or pairs (a wave alone)
+    auto product = [&](int cols, int ksteps, auto fa, auto fb, auto init, auto emit) {
+        if (coop) {
+            for (int jt = wv; jt * 16 < cols; jt += WV) {
+                f32x4 acc[1][1];
+                acc[0][0] = init(jt * 16 + l16);
+                mm<1, 1, 8, true>(acc, ksteps, fa, [&](int k, int c) { return fb(k, jt * 16 + c); });
+                each<1, 1>(acc, [&](int row, int c, float v, int, int, int) { emit(row, jt * 16 + c, v); });
+            }
+        } else {
+            for (int jt = 0; jt * 16 < cols; jt += 2) {
+                f32x4 acc[1][2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[0][nt] = init((jt + nt) * 16 + l16);
+                mm<1, 2, 4, true>(acc, ksteps, fa, [&](int k, int c) { return fb(k, jt * 16 + c); });
+                each<1, 2>(acc, [&](int row, int c, float v, int, int, int) { emit(row, jt * 16 + c, v); });
+            }
+        }
+    };
     for (int t = w; t < J.n_tiles; t += J.n_waves, first = false) {
         const int r0 = t * 16;
         const bool rok = r0 + rr < J.n_rows;
         const int rrow = rok ? r0 + rr : J.n_rows - 1;
-        {   // input rows (zero beyond the end, zero in the padding columns)
-            const int d0 = m.dims[0], d0p = (d0 + 3) & ~3;
+        // input rows (zero beyond the end, zero in the padding columns)
+        if (first && pre_in) {
+#pragma unroll
+            for (int u = 0; u < kRowsPre; ++u)
+                if (c4 + 4 * u < d0p) acts[rr * ald + c4 + 4 * u] = (rok && c4 + 4 * u < d0) ? xin[u] : 0.f;
+        } else {
             const float* src = row_at(J.in, rrow);
             gather<8>(d0p, c4, 4, [&](int c) { return (rok && c < d0) ? src[c] : 0.f; }, [&](int c, float v) { acts[rr * ald + c] = v; });
         }
         sync();
+        HEAD_PHASE_MARK(1);
         for (int l = 0; l < L; ++l) {
             const int in = m.dims[l], out = m.dims[l + 1], inp = (in + 3) & ~3, outp = (out + 3) & ~3;
             const int ioff = J.act_off[l], ooff = J.act_off[l + 1];
-            const bool relu = (l != L - 1) || m.last_relu;
+            const bool relu = (l != L - 1) || relu_top;
             const float* W = lds + J.w_lds[l];
             const float* b = lds + J.b_lds[l];
             const int wld = J.w_ld[l];
             if (per_layer) {              // the previous layer's reads of the region ended at its barrier
-                stage_layer(J, lds, l);
-                __syncthreads();
+                stage_layers<16>(J, lds, l, l + 1);
+                lds_barrier();
             }
-            for (int jt = 2 * wv; jt * 16 < out; jt += 2 * WV) {
-                f32x4 acc[1][2];
+            if (coop && out <= 4) {
+                // up to four outputs (the value head's last layer): a dot product per row on the VALU -- lane (row rr, quarter c4) sums
+                // every fourth input, the four lanes of a row add up -- instead of one wave's chain of in / 4 dependent MFMAs
+                // while seven waves wait
+                if (wv == 0) {
+                    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int k0 = c4; k0 < inp; k0 += 32) {
+                        float av[8], wv4[8][4];
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int col = (jt + nt) * 16 + l16;
-                    const float bv = col < out ? b[col] : 0.f;
-                    acc[0][nt] = f32x4{bv, bv, bv, bv};
+                        for (int u = 0; u < 8; ++u) {
+                            const int k = k0 + 4 * u;
+                            // (a select between a load and a constant is turned into a branch around the load: a factor instead)
+                            av[u] = acts[rr * ald + ioff + min(k, inp - 1)] * (k < inp ? 1.f : 0.f);
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) wv4[u][o] = W[min(k, in - 1) * wld + min(o, out - 1)];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) sum[o] = fmaf(av[u], wv4[u][o], sum[o]);
+                    }
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        sum[o] += __shfl_xor(sum[o], 1);
+                        sum[o] += __shfl_xor(sum[o], 2);
+                        if (c4 == o && o < outp) {
+                            const float v = sum[o] + b[min(o, out - 1)];
+                            acts[rr * ald + ooff + o] = o < out ? (relu ? fmaxf(v, 0.f) : v) : 0.f;
+                        }
+                    }
                 }
-                mm<1, 2, 4>(acc, inp >> 2,
-                            [&](int row, int k) { return acts[row * ald + ioff + k]; },
-                            // clamped addresses, no guards (a guard becomes a branch and an LDS round trip per k step): the padding
-                            // columns of the activations are zero, and output columns past the end are never stored
-                            [&](int k, int c) { return W[min(k, in - 1) * wld + min(jt * 16 + c, out - 1)]; });
-                each<1, 2>(acc, [&](int row, int c, float v, int, int, int) {
-                    const int col = jt * 16 + c;
-                    if (col < outp) acts[row * ald + ooff + col] = col < out ? (relu ? fmaxf(v, 0.f) : v) : 0.f;
-                });
+                sync();
+                continue;
             }
+            // clamped addresses, no guards (a guard becomes a branch and an LDS round trip per k step): the padding columns of the
+            // activations are zero, and output columns past the end are never stored
+            product(out, inp >> 2,
+                    [&](int row, int k) { return acts[row * ald + ioff + k]; },
+                    [&](int k, int col) { return W[min(k, in - 1) * wld + min(col, out - 1)]; },
+                    [&](int col) { const float b0 = b[min(col, out - 1)], bv = col < out ? b0 : 0.f; return f32x4{bv, bv, bv, bv}; },
+                    [&](int row, int col, float v) {
+                        if (col < outp) acts[row * ald + ooff + col] = col < out ? (relu ? fmaxf(v, 0.f) : v) : 0.f;
+                    });
             sync();
         }
+        HEAD_PHASE_MARK(2);
         if (!a.backward) {
-            const int out = m.dims[L], ooff = J.act_off[L];
+            const int ooff = J.act_off[L];
             float* dst = row_at(J.out, rrow);
             if (rok && wv == 0)
-                for (int c = c4; c < out; c += 4) dst[c] = acts[rr * ald + ooff + c];
+                for (int c = c4; c < dL; c += 4) dst[c] = acts[rr * ald + ooff + c];
             sync();
             continue;
         }
-        {   // upstream gradient of the tile's rows
-            const int out = m.dims[L], outp = (out + 3) & ~3;
-            const float* src = J.d_out.p ? row_at(J.d_out, rrow) : nullptr;
-            gather<8>(outp, c4, 4, [&](int c) { return (src && rok && c < out) ? src[c] : 0.f; },
-                      [&](int c, float v) { dcur[rr * dld + c] = v; });
+        {   // upstream gradient of the tile's rows, through the top layer's ReLU if it has one
+            const int ooff = J.act_off[L];
+            auto put = [&](int c, float v) {
+                dcur[rr * dld + c] = (relu_top && !(acts[rr * ald + ooff + c] > 0.f)) ? 0.f : v;
+            };
+            if (first && pre_dout) {
+#pragma unroll
+                for (int u = 0; u < kRowsPre; ++u)
+                    if (c4 + 4 * u < dLp) put(c4 + 4 * u, (J.d_out.p && rok && c4 + 4 * u < dL) ? dov[u] : 0.f);
+            } else {
+                const float* src = J.d_out.p ? row_at(J.d_out, rrow) : nullptr;
+                gather<8>(dLp, c4, 4, [&](int c) { return (src && rok && c < dL) ? src[c] : 0.f; }, put);
+            }
         }
         sync();
+        HEAD_PHASE_MARK(3);
         for (int l = L - 1; l >= 0; --l) {
             const int in = m.dims[l], out = m.dims[l + 1], inp = (in + 3) & ~3, outp = (out + 3) & ~3;
-            const int ioff = J.act_off[l], ooff = J.act_off[l + 1];
-            const bool relu = (l != L - 1) || m.last_relu;
+            const int ioff = J.act_off[l];
             const float* W = lds + J.w_lds[l];
             const int wld = J.w_ld[l];
-            if (per_layer && (l > 0 || J.need_din)) stage_layer(J, lds, l);      // read after the barriers below
-            if (relu) {
-                for (int c = c4; c < out; c += 4)
-                    if (!(acts[rr * ald + ooff + c] > 0.f)) dcur[rr * dld + c] = 0.f;
-                sync();
-            }
+            if (per_layer && (l > 0 || J.need_din)) stage_layers<16>(J, lds, l, l + 1);      // read after the barrier below
+            HEAD_PHASE_MARK(4);
             // dW^T[o][i] = sum_rows delta[row][o] act[row][i]   (M = outputs, N = inputs, K = the tile's 16 rows: the tile's columns
             // run along the contiguous dimension of torch's [out][in] layout, so a wave's stores are 64-byte runs)
             float* gW = slab + J.w_off[l];
-            int block = 0;
-            for (int ot = 0; ot * 16 < out; ++ot)
-                for (int it = 0; it * 16 < in; it += 2) {
-                    if ((block++ & (WV - 1)) != wv) continue;
+            // blocks (ot, it) of 16 outputs x 32 inputs, dealt round-robin to the waves that share the tile
+            const int nit = (in + 31) >> 5, nblocks = ((out + 15) >> 4) * nit;
+            for (int blk = wv, ot = 0, itp = wv; blk < nblocks; blk += WV, itp += WV) {
+                    while (itp >= nit) { itp -= nit; ++ot; }
+                    const int it = 2 * itp;
                     f32x4 acc[1][2];
                     clear<1, 2>(acc);
                     if (!first) {                    // later tiles of the wave: the MFMAs accumulate on top of the slab's values
@@ -296,7 +467,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void mlp_rows_kernel(const RowsArg
                                 if (i < in && o < out) acc[0][nt][r] = gW[(size_t)o * in + i];
                             }
                     }
-                    mm<1, 2, 4>(acc, 4,
+                    mm<1, 2, 4, true>(acc, 4,
                                 [&](int mo, int k) { return dcur[k * dld + min(ot * 16 + mo, outp - 1)]; },
                                 [&](int k, int c) { return acts[k * ald + ioff + min(it * 16 + c, inp - 1)]; });
                     each<1, 2>(acc, [&](int mo, int c, float v, int, int, int) {
@@ -311,34 +482,271 @@ __global__ __launch_bounds__(kCoopWaves * 64) void mlp_rows_kernel(const RowsArg
                 for (int r = 0; r < 16; ++r) s += dcur[r * dld + c];
                 gb[c] = first ? s : gb[c] + s;
             }
+            HEAD_PHASE_MARK(5);
             if (l > 0 || J.need_din) {
-                // delta_in[row][i] = sum_o delta[row][o] W[i][o]
-                if (per_layer) __syncthreads();
-                for (int jt = 2 * wv; jt * 16 < in; jt += 2 * WV) {
-                    f32x4 acc[1][2];
-                    clear<1, 2>(acc);
-                    mm<1, 2, 4>(acc, outp >> 2,
-                                [&](int row, int k) { return dcur[row * dld + k]; },
-                                [&](int k, int c) { return W[min(jt * 16 + c, in - 1) * wld + min(k, out - 1)]; });
-                    each<1, 2>(acc, [&](int row, int c, float v, int, int, int) {
-                        const int i = jt * 16 + c;
-                        if (i < inp) dnxt[row * dld + i] = i < in ? v : 0.f;
-                    });
-                }
+                // delta_in[row][i] = sum_o delta[row][o] W[i][o], through the ReLU that produced input i (every layer below the top
+                // one has it; the MLP's own input has none)
+                if (per_layer) lds_barrier();
+                const bool mask = l > 0;
+                product(in, outp >> 2,
+                        [&](int row, int k) { return dcur[row * dld + k]; },
+                        [&](int k, int col) { return W[min(col, in - 1) * wld + min(k, out - 1)]; },
+                        [&](int) { return zero4(); },
+                        [&](int row, int i, float v) {
+                            const float ai = acts[row * ald + ioff + min(i, inp - 1)];       // read unguarded, selected below
+                            if (i < inp) dnxt[row * dld + i] = (i < in && !(mask && !(ai > 0.f))) ? v : 0.f;
+                        });
             }
             sync();
+            HEAD_PHASE_MARK(6);
             float* tmp = dcur;
             dcur = dnxt;
             dnxt = tmp;
         }
         if (J.need_din && wv == 0) {
-            const int d0 = m.dims[0];
             float* dst = row_at(J.d_in, rrow);
-            gather<8>(d0, c4, 4, [&](int c) { return (J.din_add && rok) ? dst[c] : 0.f; },
-                      [&](int c, float v) { if (rok) dst[c] = v + dcur[rr * dld + c]; });
+            if (first && (pre_din || (!J.din_add && d0 <= 4 * kRowsPre))) {
+#pragma unroll
+                for (int u = 0; u < kRowsPre; ++u) {
+                    const int c = c4 + 4 * u;
+                    if (rok && c < d0) dst[c] = (pre_din ? dinv[u] : 0.f) + dcur[rr * dld + c];
+                }
+            } else {
+                gather<8>(d0, c4, 4, [&](int c) { return (J.din_add && rok) ? dst[c] : 0.f; },
+                          [&](int c, float v) { if (rok) dst[c] = v + dcur[rr * dld + c]; });
+            }
         }
         sync();
+        HEAD_PHASE_MARK(7);
     }
+    HEAD_PHASE_FLUSH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// rows of a wide MLP, a workgroup per 16-row tile, the weights straight from L2 (round 6)
+// ------------------------------------------------------------------------------------------------
+// The value head's rows at the reference's batch (100 scenes = 7 tiles) are latency, not work: with one tile per workgroup every
+// weight is used ONCE per product, so staging the matrices in LDS (mlp_rows_kernel) only adds a round trip and an LDS read per
+// MFMA operand -- 35.7 us for 0.6 us of MFMA time in round 5 (profiles/r06_head_rows.txt).  Here the B operands of every product come from
+// global memory as the loads of a whole column tile in flight at once, LDS holds the tile's activations and deltas only (so any MLP
+// of the ABI fits: path G's 150-100-100-1 head needs no per-layer staging), and the k slots of the MFMA are permuted -- slot
+// (g, kk, u) <-> k = 16 g + 4 kk + u -- so that a lane's four k of a group are adjacent: one b128 read of its A row, and for the
+// transposed products (delta_in: W[i][o] along o) one dwordx4 load per group.  Same arithmetic as mlp_rows_kernel up to the order
+// of the k sum inside a product.  23.0 us against 30.3 for the batch-100 value head (7 workgroups); what remains is seven dependent
+// products of ~2 us each -- one compute unit pulling a 40 KB matrix out of L2 per product -- and ~5 us of launch, row traffic and
+// barriers (ablations in DESIGN §9).
+constexpr int kDirectGroups = 8;       // 16-k groups of operands requested per batch (128 k: 32 + 32 registers)
+
+// acc += A[16][16 K16] B[16 K16][16]: `arow` = this lane's A row (LDS, 16-byte aligned groups, zeros where k is past the end),
+// fb(g, kk) = the four B values of k = 16 g + 4 kk .. + 3 for this lane's column
+template <class FB>
+__device__ __forceinline__ void direct_mm(f32x4& acc, const float* arow, int K16, FB fb) {
+    const int kk = (threadIdx.x & 63) >> 4;
+    for (int g0 = 0; g0 < K16; g0 += kDirectGroups) {
+        f32x4 bv[kDirectGroups], av[kDirectGroups];
+#pragma unroll
+        for (int g = 0; g < kDirectGroups; ++g) bv[g] = fb(min(g0 + g, K16 - 1), kk);       // past the end: the last group again
+#pragma unroll
+        for (int g = 0; g < kDirectGroups; ++g) av[g] = *reinterpret_cast<const f32x4*>(arow + 16 * min(g0 + g, K16 - 1) + 4 * kk);
+        __builtin_amdgcn_sched_barrier(0);             // every operand requested before the first MFMA
+#pragma unroll
+        for (int g = 0; g < kDirectGroups; ++g)
+            if (g0 + g < K16) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = mfma4(av[g][u], bv[g][u], acc);
+            }
+    }
+}
+
+__global__ __launch_bounds__(kCoopWaves * 64) void head_rows_kernel(const RowsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l16 = lane & 15, kq = lane >> 4;
+    const int ji = (a.n_jobs > 1 && (int)blockIdx.x >= a.job[1].wg_begin) ? 1 : 0;
+    const RowsJob& J = a.job[ji];
+    HEAD_PHASE_START();
+    const int w = (int)blockIdx.x - J.wg_begin;
+    if (w >= J.n_waves) return;
+    const RglMlp& m = J.m;
+    const int L = m.n_layers, ald = J.act_ld, dld = J.d_ld;
+    float* acts = lds;                         // [16][ald]: every layer's activations, each in a region of a multiple of 16 columns
+    float* dcur = acts + 16 * ald;             // [16][dld] twice: the deltas of the layer at hand and of the one below
+    float* dnxt = dcur + 16 * dld;
+    float* slab = J.slabs + (size_t)w * J.n_params;
+    const int rr = lane >> 2, c4 = lane & 3;   // element-wise passes: lane -> (row rr, columns c4, c4 + 4, ..)
+    const int d0 = m.dims[0], dL = m.dims[L];
+    const bool relu_top = m.last_relu != 0;
+    bool first = true;
+    for (int t = w; t < J.n_tiles; t += J.n_waves, first = false) {
+        const int r0 = t * 16;
+        const bool rok = r0 + rr < J.n_rows;
+        const int rrow = rok ? r0 + rr : J.n_rows - 1;
+        {   // input rows: every column of the region written (zeros beyond the row's end and beyond the last row)
+            const float* src = row_at(J.in, rrow);
+            const int d16 = (d0 + 15) & ~15;
+            for (int c0 = c4; c0 < d16; c0 += 32) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[min(c0 + 4 * u, d0 - 1)];          // unguarded loads, guarded values
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (c0 + 4 * u < d16)        // a factor, not a select: a select around a load becomes a branch with a wait inside
+                        acts[rr * ald + c0 + 4 * u] = v[u] * ((rok && c0 + 4 * u < d0) ? 1.f : 0.f);
+            }
+        }
+        lds_barrier();
+        HEAD_PHASE_MARK(1);
+        for (int l = 0; l < L; ++l) {
+            const int in = m.dims[l], out = m.dims[l + 1], K16 = (in + 15) >> 4;
+            const int ioff = J.act_off[l], ooff = J.act_off[l + 1];
+            const bool relu = (l != L - 1) || relu_top;
+            const float* __restrict__ W = m.weight[l];
+            const float* __restrict__ B = m.bias[l];
+            {
+                for (int jt = wv; jt * 16 < out; jt += kCoopWaves) {
+                    const int col = jt * 16 + l16, colc = min(col, out - 1);
+                    const float bv = B[colc];
+                    f32x4 acc = f32x4{bv, bv, bv, bv};
+                    // Addresses: a wave-uniform base (row 16 g + u of the matrix: scalar arithmetic) plus ONE 32-bit offset per lane
+                    // that serves every load of the tile -- per-load 64-bit multiplies and clamps cost more VALU time than the
+                    // product's MFMAs.  Only the last group of a ragged K clamps its rows (their A values are zeros).
+                    const unsigned lane_off = (unsigned)(4 * kq * out + colc);
+                    direct_mm(acc, acts + l16 * ald + ioff, K16, [&](int g, int kk) {
+                        if (16 * g + 15 < in) {
+                            const float* __restrict__ Wg = W + (size_t)(16 * g) * (size_t)out;
+                            return f32x4{Wg[lane_off], (Wg + out)[lane_off], (Wg + 2 * out)[lane_off], (Wg + 3 * out)[lane_off]};
+                        }
+                        const int k = 16 * g + 4 * kk;
+                        const float* __restrict__ Wc = W + colc;
+                        return f32x4{Wc[(size_t)min(k, in - 1) * out], Wc[(size_t)min(k + 1, in - 1) * out],
+                                     Wc[(size_t)min(k + 2, in - 1) * out], Wc[(size_t)min(k + 3, in - 1) * out]};
+                    });
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acts[(4 * kq + r) * ald + ooff + col] = col < out ? (relu ? fmaxf(acc[r], 0.f) : acc[r]) : 0.f;
+                }
+            }
+            lds_barrier();
+        }
+        HEAD_PHASE_MARK(2);
+        if (!a.backward) {
+            const int ooff = J.act_off[L];
+            float* dst = row_at(J.out, rrow);
+            if (rok && wv == 0)
+                for (int c = c4; c < dL; c += 4) dst[c] = acts[rr * ald + ooff + c];
+            lds_barrier();
+            continue;
+        }
+        {   // upstream gradient of the tile's rows, through the top layer's ReLU if it has one; zeros up to a multiple of 16 columns
+            const int ooff = J.act_off[L], d16 = (dL + 15) & ~15;
+            const float* src = J.d_out.p ? row_at(J.d_out, rrow) : row_at(J.in, rrow);
+            const bool have = J.d_out.p != nullptr;
+            for (int c0 = c4; c0 < d16; c0 += 32) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[have ? min(c0 + 4 * u, dL - 1) : 0];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + 4 * u;
+                    if (c < d16) {
+                        const float ac = acts[rr * ald + ooff + c];
+                        dcur[rr * dld + c] = v[u] * ((have && rok && c < dL && !(relu_top && !(ac > 0.f))) ? 1.f : 0.f);
+                    }
+                }
+            }
+        }
+        lds_barrier();
+        HEAD_PHASE_MARK(3);
+        for (int l = L - 1; l >= 0; --l) {
+            const int in = m.dims[l], out = m.dims[l + 1], in16 = (in + 15) & ~15, out16 = (out + 15) & ~15;
+            const int ioff = J.act_off[l];
+            const float* __restrict__ W = m.weight[l];
+            // dW^T[o][i] = sum_rows delta[row][o] act[row][i]   (M = outputs, N = inputs, K = the tile's 16 rows: the tile's columns
+            // run along the contiguous dimension of torch's [out][in] layout, so a wave's stores are 64-byte runs); blocks (ot, it) of
+            // 16 outputs x 32 inputs, dealt round-robin to the waves
+            float* gW = slab + J.w_off[l];
+            const int nit = (in + 31) >> 5, nblocks = (out16 >> 4) * nit;
+            for (int blk = wv, ot = 0, itp = wv; blk < nblocks; blk += kCoopWaves, itp += kCoopWaves) {
+                while (itp >= nit) { itp -= nit; ++ot; }
+                const int it = 2 * itp;
+                f32x4 acc[1][2];
+                clear<1, 2>(acc);
+                if (!first) {                    // later tiles of the workgroup: the MFMAs accumulate on top of the slab's values
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int o = ot * 16 + 4 * kq + r, i = (it + nt) * 16 + l16;
+                            if (i < in && o < out) acc[0][nt][r] = gW[(size_t)o * in + i];
+                        }
+                }
+                mm<1, 2, 4, true>(acc, 4,
+                                  [&](int mo, int k) { return dcur[k * dld + ot * 16 + mo]; },
+                                  [&](int k, int c) { return acts[k * ald + ioff + min(it * 16 + c, in16 - 1)]; });
+                each<1, 2>(acc, [&](int mo, int c, float v, int, int, int) {
+                    const int o = ot * 16 + mo, i = it * 16 + c;
+                    if (i < in && o < out) gW[(size_t)o * in + i] = v;
+                });
+            }
+            float* gb = slab + J.b_off[l];
+            for (int c = lane + 64 * wv; c < out; c += 64 * kCoopWaves) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += dcur[r * dld + c];
+                gb[c] = first ? s : gb[c] + s;
+            }
+            HEAD_PHASE_MARK(5);
+            if (l > 0 || J.need_din) {
+                // delta_in[row][i] = sum_o delta[row][o] W[i][o], through the ReLU that produced input i (every layer below the top
+                // one has it; the MLP's own input has none).  W[i][.] is contiguous along the sum: a dwordx4 per group where the
+                // row length allows the alignment
+                const bool mask = l > 0, vec = (out & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+                const int K16 = out16 >> 4;
+                for (int jt = wv; jt * 16 < in16; jt += kCoopWaves) {
+                    const int i = jt * 16 + l16, ic = min(i, in - 1);
+                    const float* __restrict__ Wi = W + (size_t)ic * out;
+                    f32x4 acc = zero4();
+                    const unsigned lane_off = (unsigned)(ic * out + 4 * kq);
+                    if (vec)
+                        direct_mm(acc, dcur + l16 * dld, K16, [&](int g, int kk) {
+                            if (16 * g + 15 < out)           // uniform base + the lane's offset, as in the forward products
+                                return *reinterpret_cast<const f32x4*>(W + 16 * g + lane_off);
+                            // a quad past the row's end: the last one again (its delta values are zeros)
+                            return *reinterpret_cast<const f32x4*>(Wi + min(16 * g + 4 * kk, out - 4));
+                        });
+                    else
+                        direct_mm(acc, dcur + l16 * dld, K16, [&](int g, int kk) {
+                            const int k = 16 * g + 4 * kk;
+                            return f32x4{Wi[min(k, out - 1)], Wi[min(k + 1, out - 1)], Wi[min(k + 2, out - 1)], Wi[min(k + 3, out - 1)]};
+                        });
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 4 * kq + r;
+                        const float ai = acts[row * ald + ioff + i];                   // i < in16: inside the region
+                        dnxt[row * dld + i] = (i < in && !(mask && !(ai > 0.f))) ? acc[r] : 0.f;
+                    }
+                }
+            }
+            lds_barrier();
+            HEAD_PHASE_MARK(6);
+            float* tmp = dcur;
+            dcur = dnxt;
+            dnxt = tmp;
+        }
+        if (J.need_din && wv == 0) {
+            float* dst = row_at(J.d_in, rrow);
+            for (int c0 = c4; c0 < d0; c0 += 32) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = J.din_add ? dst[min(c0 + 4 * u, d0 - 1)] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (rok && c0 + 4 * u < d0) dst[c0 + 4 * u] = v[u] + dcur[rr * dld + c0 + 4 * u];
+            }
+        }
+        lds_barrier();
+        HEAD_PHASE_MARK(7);
+    }
+    HEAD_PHASE_FLUSH();
 }
 
 // The shipped narrow MLPs -- in -> 64 -> out with in, out <= 32: w_r, w_h (9 | 5 | 6 | 7 -> 64 -> 32), the motion head
@@ -355,7 +763,7 @@ __global__ __launch_bounds__(kNarrowWaves * 64, 3) void mlp2_rows_kernel(const R
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15;
     const int ji = (a.n_jobs > 1 && (int)blockIdx.x >= a.job[1].wg_begin) ? 1 : 0;
     const RowsJob& J = a.job[ji];
-    PHASE_START();
+    ROWS2_PHASE_START();
     const int w = ((int)blockIdx.x - J.wg_begin) * J.waves_per_wg + wave;
     const bool on = wave < J.waves_per_wg && w < J.n_waves;
     const RglMlp& m = J.m;
@@ -414,7 +822,7 @@ __global__ __launch_bounds__(kNarrowWaves * 64, 3) void mlp2_rows_kernel(const R
                   });
     }
     __syncthreads();
-    PHASE_MARK(0);
+    ROWS2_PHASE_MARK(0);
     if (!on) return;
     for (int t = w; t < J.n_tiles; t += J.n_waves) {
         const int r0 = t * 16;
@@ -427,7 +835,7 @@ __global__ __launch_bounds__(kNarrowWaves * 64, 3) void mlp2_rows_kernel(const R
         for (int u = 0; u < T2 * 4; ++u) vdc[u] = vd[u];
         fetch(t + J.n_waves);
         wave_sync();
-        PHASE_MARK(1);
+        ROWS2_PHASE_MARK(1);
         {   // hidden = relu(x W0 + b0)
             f32x4 acc[1][HT];
 #pragma unroll
@@ -440,7 +848,7 @@ __global__ __launch_bounds__(kNarrowWaves * 64, 3) void mlp2_rows_kernel(const R
             each<1, HT>(acc, [&](int row, int c, float v, int, int, int) { hid[row * HLD + c] = fmaxf(v, 0.f); });
         }
         wave_sync();
-        PHASE_MARK(2);
+        ROWS2_PHASE_MARK(2);
         {   // y = hidden W1 + b1 (ReLU when the MLP ends with one)
             f32x4 acc[1][T2];
 #pragma unroll
@@ -454,7 +862,7 @@ __global__ __launch_bounds__(kNarrowWaves * 64, 3) void mlp2_rows_kernel(const R
             each<1, T2>(acc, [&](int row, int c, float v, int, int, int) { d1[row * OLD + c] = last_relu ? fmaxf(v, 0.f) : v; });
         }
         wave_sync();
-        PHASE_MARK(3);
+        ROWS2_PHASE_MARK(3);
         if (!a.backward) {
             float* dst = row_at(J.out, rrow);
             if (rok)
@@ -470,7 +878,7 @@ __global__ __launch_bounds__(kNarrowWaves * 64, 3) void mlp2_rows_kernel(const R
             }
         }
         wave_sync();
-        PHASE_MARK(4);
+        ROWS2_PHASE_MARK(4);
         // dW1^T[o][h] += sum_rows delta1[row][o] hidden[row][h]
         mm<T2, HT, 4>(gW1, 4, [&](int mo, int k) { return d1[k * OLD + mo]; }, [&](int k, int c) { return hid[k * HLD + c]; });
         if (lane < T2 * 16) {
@@ -485,12 +893,12 @@ __global__ __launch_bounds__(kNarrowWaves * 64, 3) void mlp2_rows_kernel(const R
             each<1, HT>(acc, [&](int row, int c, float v, int, int, int) { d0[row * HLD + c] = hid[row * HLD + c] > 0.f ? v : 0.f; });
         }
         wave_sync();
-        PHASE_MARK(5);
+        ROWS2_PHASE_MARK(5);
         // dW0^T[h][i] += sum_rows delta0[row][h] x[row][i]
         mm<HT, T0, 4>(gW0, 4, [&](int mh, int k) { return d0[k * HLD + mh]; }, [&](int k, int c) { return xin[k * IN_LD + c]; });
 #pragma unroll
         for (int r = 0; r < 16; ++r) gb0 += d0[r * HLD + lane];
-        PHASE_MARK(6);
+        ROWS2_PHASE_MARK(6);
         if (J.need_din) {
             f32x4 acc[1][T0];
             clear<1, T0>(acc);
@@ -510,9 +918,9 @@ __global__ __launch_bounds__(kNarrowWaves * 64, 3) void mlp2_rows_kernel(const R
             }
         }
         wave_sync();
-        PHASE_MARK(7);
+        ROWS2_PHASE_MARK(7);
     }
-    PHASE_FLUSH();
+    ROWS2_PHASE_FLUSH();
     if (a.backward) {
         float* slab = J.slabs + (size_t)w * J.n_params;
         each<HT, T0>(gW0, [&](int h, int i, float v, int, int, int) { if (i < in) slab[J.w_off[0] + h * in + i] = v; });
@@ -1098,6 +1506,26 @@ void plan_rows_job(RowsJob& J, const RglMlp& m, int n_rows, int max_waves) {
         J.wave_floats = 16 * ((T0 * 16 + 2) + 66 + (T2 * 16 + 2));
         return;
     }
+    static const bool direct_rows = [] { const char* e = getenv("RGL_HEAD_ROWS_DIRECT"); return !e || atoi(e) != 0; }();
+    if (direct_rows && J.n_tiles <= 1024) {
+        // few tiles: a workgroup per tile, the weights straight from L2 (head_rows_kernel): the tile's activations and deltas are all
+        // that lives in LDS, every layer in a region of a multiple of 16 columns, rows 16 bytes aligned and four banks apart
+        col = 0; widest = 0;
+        for (int l = 0; l <= m.n_layers; ++l) {
+            J.act_off[l] = col;
+            col += (m.dims[l] + 15) & ~15;
+            widest = m.dims[l] > widest ? m.dims[l] : widest;
+        }
+        J.act_ld = col + 4;
+        J.d_ld = ((widest + 15) & ~15) + 4;
+        J.wave_floats = 16 * J.act_ld + 32 * J.d_ld;
+        J.weight_floats = 0;
+        J.kind = 1;
+        J.coop = 1;
+        J.waves_per_wg = 1;
+        J.n_wgs = J.n_waves;
+        return;
+    }
     J.wave_floats = 16 * J.act_ld + 32 * J.d_ld;
     if (J.n_tiles <= 1024 && ((size_t)wl + J.wave_floats) * sizeof(float) <= (size_t)rgl::kLdsBytesPerCu - 1024) {
         J.coop = 1;                             // few tiles: a workgroup per tile (the value head: one row per scene)
@@ -1147,7 +1575,7 @@ int launch_rows_kernel(K kernel, RowsArgs& ra, hipStream_t st) {
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     bool any_coop = false;
     for (int j = 0; j < ra.n_jobs; ++j) any_coop |= ra.job[j].coop != 0;
-    hipLaunchKernelGGL(kernel, dim3(wgs), dim3(ra.job[0].kind ? kNarrowWaves * 64 : (any_coop ? kCoopWaves * 64 : 256)), lds, st, ra);
+    hipLaunchKernelGGL(kernel, dim3(wgs), dim3(ra.job[0].kind >= 10 ? kNarrowWaves * 64 : (any_coop ? kCoopWaves * 64 : 256)), lds, st, ra);
     RGL_LAUNCH_CHECK();
     return RGL_OK;
 }
@@ -1157,7 +1585,7 @@ int launch_rows_kernel(K kernel, RowsArgs& ra, hipStream_t st) {
 // plus a second round for the overflow.
 void balance_narrow(RowsJob* const* jobs, int n, int max_waves) {
     for (int j = 0; j < n; ++j) {
-        if (!jobs[j] || !jobs[j]->kind) continue;
+        if (!jobs[j] || jobs[j]->kind < 10) continue;
         bool first_of_kind = true;
         long tiles = 0;
         for (int i = 0; i < n; ++i)
@@ -1194,6 +1622,7 @@ int launch_rows(RowsArgs& all, hipStream_t st) {
             case 12: rc = launch_rows_kernel(mlp2_rows_kernel<1, 2>, ra, st); break;
             case 21: rc = launch_rows_kernel(mlp2_rows_kernel<2, 1>, ra, st); break;
             case 22: rc = launch_rows_kernel(mlp2_rows_kernel<2, 2>, ra, st); break;
+            case 1: rc = launch_rows_kernel(head_rows_kernel, ra, st); break;
             default: rc = launch_rows_kernel(mlp_rows_kernel, ra, st); break;
         }
         if (rc) return rc;

@@ -780,6 +780,14 @@ def test_tile_pipeline_forced_over_the_module_and_training_tests(dev):
                          cwd=root, env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     report("tile kernels forced over the forward KATs, predictor, head, gradient and trainer-fixture tests: " + out.stdout.strip().splitlines()[-1])
+    # round 6: the wide heads' rows run head_rows_kernel (weights straight from L2); its A/B partner -- mlp_rows_kernel with one tile per
+    # workgroup, weights staged in LDS, the form batches beyond 1024 tiles still take -- over the head and gradient tests as well
+    env["RGL_HEAD_ROWS_DIRECT"] = "0"
+    out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                          "-k", "non_default_value_heads or gradients or training_step_matches"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    report("the same with the heads' rows on the staged kernel (RGL_HEAD_ROWS_DIRECT=0): " + out.stdout.strip().splitlines()[-1])
 
 
 def test_tile_kernel_variant_forced(dev):
