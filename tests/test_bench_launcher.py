@@ -36,6 +36,9 @@ def test_bench_launches_its_own_ranks_and_reports_both_readings():
     assert r["weak_total_roots"] == 22 and r["weak_roots_per_gpu"] == 11 and r["weak_value"] > 0
     assert r["weak_multi_gpu"]["roots_per_rank"] == [11, 11] and r["weak_multi_gpu"]["ranks_seen"] == 2
     assert r["cpu_baseline"] is None and r["roofline"] is None
+    # the untimed set-up phase lasts RGL_BENCH_INIT_MS at least (round 6: the device's clock ramp is a matter of time): more than its
+    # 40 steps here, the same count on every rank -- a step is an exchange, ranks that disagreed would hang -- and the line says so
+    assert r["config"]["init_ms"] == 80.0 and r["config"]["init_steps"] > 40
 
 
 def test_eight_ranks_uneven_shards_and_the_single_process_decisions():
@@ -65,6 +68,9 @@ def test_single_rank_line_keeps_its_shape():
     r = _run(["--steps", "3", "--warmup", "1", "--roots", "7"])
     assert r["n_gpus"] == 1 and r["scaling"] == "weak" and r["config"]["total_roots"] == 7 and "weak_value" not in r
     assert "multi_gpu" not in r and "ranks_seen" not in r
+    assert r["config"]["init_steps"] >= 40 and r["config"]["init_ms"] == 80.0
+    short = _run(["--steps", "3", "--warmup", "1", "--roots", "7"], extra_env={"RGL_BENCH_INIT_MS": "0", "RGL_BENCH_INIT_STEPS": "3"})
+    assert short["config"]["init_steps"] == 3 and short["decisions"] == r["decisions"]
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "step_ms_device", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "decisions"):
         assert key in r, key
