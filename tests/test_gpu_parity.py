@@ -983,6 +983,28 @@ def test_tree_vs_batched_oracle(H, D, w, clip, B, L, dev):
     check_decisions("tree vs batched oracle H=%d D=%d w=%d B=%d" % (H, D, w, B), act, val, (oa, ov, orv, okept), lv)
 
 
+@pytest.mark.parametrize("contraction", ["f32", "bf16x6"])
+@pytest.mark.parametrize("H,D,w,clip,B,kin", [(19, 2, 2, True, 24, "holonomic"), (5, 1, 1, False, 64, "holonomic"),
+                                               (19, 2, 2, True, 12, "unicycle")])
+def test_tree_vs_batched_oracle_over_seeds(H, D, w, clip, B, kin, contraction, dev):
+    """test_tree_vs_batched_oracle's check over eight more seeded scene sets per shape, in both arithmetic modes of the search (round
+    6: every other search test draws ONE set; a top-k over near-ties is where a rare seed would show)."""
+    pol = make_mprl_policy("trained", D, w, clip, L=2, device=dev, kinematics=kin)
+    pol.contraction_dtype = contraction
+    cfg = orc.OracleConfig(num_layer=2, planning_depth=D, planning_width=w, do_action_clip=clip, kinematics=kin)
+    worst, differ = 0.0, 0
+    for seed in range(2001, 2009):
+        robot, humans = seeded_scenes(seed + H, B, H)
+        with torch.no_grad():
+            oa, ov, orv, okept, lv = orc.mprl_predict_batched(robot, humans, gio.oracle_params("trained", 2), cfg, return_levels=True)
+        act, val = pol.predict_batch(robot.to(dev), humans.to(dev), roots_are_joint_states=True)
+        close(val.cpu().numpy(), ov.numpy())
+        differ += check_decisions("seed %d H=%d D=%d %s %s" % (seed, H, D, kin, contraction), act, val, (oa, ov, orv, okept), lv)
+        worst = max(worst, float((val.cpu() - ov).abs().max()))
+    report("tree vs batched oracle over 8 seeds, H=%d D=%d %s, %s kernels: %d of %d decisions differ (ties in the oracle), max |dV| %.2e"
+           % (H, D, kin, contraction, differ, 8 * B, worst))
+
+
 @pytest.mark.parametrize("H,sim,L,layerwise", [(64, "embedded_gaussian", 2, False), (99, "embedded_gaussian", 2, False),
                                                (127, "embedded_gaussian", 3, False), (80, "cosine_softmax", 2, True),
                                                (99, "squared", 2, False), (70, "concatenation", 2, False)])
