@@ -49,6 +49,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+EXCHANGE_DIAG = os.environ.get("RGL_BENCH_EXCHANGE_DIAG", "")   # measurements only: "nowait" = the steps never order themselves after the gathers
 INIT_MS = float(os.environ.get("RGL_BENCH_INIT_MS", "80"))  # least duration of the set-up phase (device clock ramp), see main()
 STUB = os.environ.get("RGL_BENCH_STUB_SEARCH") == "1"       # launcher / exchange test switch: no device, no kernels, no measurement
 
@@ -381,7 +382,7 @@ class Leg:
     # every timed step's exchange finishes inside the timed region.
     def step(self):
         nxt = self.sharded.launch_local(self.robot, self.humans, self.total_roots)
-        if self.pending is not None:
+        if self.pending is not None and EXCHANGE_DIAG != "nowait":
             self.pending.wait()              # exchange of the previous step complete (stream-ordered); .result() unpacks
         self.pending = nxt
 
