@@ -2329,7 +2329,8 @@ def test_reference_trainer_fixture_with_a_non_default_similarity_on_the_tile_bac
     test_product_trainer_reproduces_the_reference_trainer_fixture(tag, dev)
 
 
-@pytest.mark.parametrize("H,L,B", [(19, 2, 1024), (5, 2, 1500), (49, 3, 96), (31, 1, 200)])
+@pytest.mark.parametrize("H,L,B", [(19, 2, 1024), (5, 2, 1500), (49, 3, 96), (31, 1, 200),
+                                   (3, 2, 16500)])      # beyond 1024 row tiles of the value head: mlp_rows_kernel's many-tiles form
 def test_mfma_backward_at_size(H, L, B, dev, monkeypatch):
     """Batches the vector explorer feeds: every parameter gradient of the value estimator and of the state
     predictor from the tile pipeline against torch autograd over the oracle AND against the per-scene VALU kernel of
