@@ -1,5 +1,5 @@
 #!/bin/bash
-# The two suite runs and smoke() of tools/final_checks.sh on their own (after test-only commits: the kernel records stay valid while
+# The three suite runs and smoke() of tools/final_checks.sh on their own (after test-only commits: the kernel records stay valid while
 # bench.py's kernel_sources_digest matches profiles/<tag>_traffic.json):  gpurun -- 'bash tools/suites_only.sh <tag> <git-hash>'
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r05_final}
@@ -14,6 +14,8 @@ echo "gpu tests rc=$?"; tail -2 $O/${TAG}_gpu_tests.log
   RGL_CONTRACT_F32_AS=bf16x6 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -170; } > $O/${TAG}_suite_under_bf16x6.txt
 tail -2 $O/${TAG}_suite_under_bf16x6.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+{ echo "# RGL_DEBUG_POISON_WORKSPACES=1 python -m pytest tests -m gpu -q   (workspaces and output slabs pre-filled with NaN patterns), source revision $HASH"; RGL_DEBUG_POISON_WORKSPACES=1 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3; } > $O/${TAG}_suite_poisoned_workspaces.txt
+tail -1 $O/${TAG}_suite_poisoned_workspaces.txt
 python -c "
 import sys; sys.path.insert(0, '.')
 import bench, json
