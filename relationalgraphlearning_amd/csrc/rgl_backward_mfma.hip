@@ -950,6 +950,7 @@ struct GraphArgs {
     // floats between the robot rows of consecutive scenes / the human rows of consecutive crowds, in Xr / Xh and in dXr / dXh: X and
     // (N - 1) X for the compact arrays above, N X for both when a scene's rows are one [N][X] block (Xh = Xr + X)
     int xr_stride, xh_stride;
+    int lw;                      // layerwise graph (graph_model.py:118-122): an adjacency per layer, A_l = softmax(S(H_l))
 };
 
 // sum / max over the 16 lanes of a DPP row, every lane gets it
@@ -978,9 +979,9 @@ __device__ __forceinline__ float row16_maxf(float x) {
 template <int NT, int XT>
 struct GraphLds {
     static constexpr int XW = XT * 16, FLD = XW + 2, ALD = NT * 16 + 2;
-    static __host__ __device__ int scene_floats(int N, int L, bool bwd) {
+    static __host__ __device__ int scene_floats(int N, int L, bool bwd, bool lw = false) {     // lw: an adjacency per layer
         const int NP = (N + 3) & ~3;
-        return ((bwd ? 4 : 2) + L + (L - 1)) * NP * FLD + (bwd ? 2 : 1) * NP * ALD;
+        return ((bwd ? 4 : 2) + L + (L - 1)) * NP * FLD + ((lw ? L : 1) + (bwd ? 1 : 0)) * NP * ALD;
     }
     static __host__ __device__ int weight_floats(int L) { return (1 + L) * XW * FLD; }
 };
@@ -993,8 +994,14 @@ struct GraphLds {
 // their tiles over all scenes of the workgroup (one slab per workgroup).
 // COS: the build with the cosine family's passes (norm 4 / 5).  A build of its own, so that the shipped similarity functions keep
 // the register allocation they had without them (the passes cost the L = 2 backward 36 more bytes of scratch per lane otherwise).
-template <int NT, int XT, int L, bool BWD, bool COS>
+// LW (round 6): layerwise graphs (graph_model.py:118-122) -- the adjacency is recomputed from every layer's input, A_l =
+// softmax(H_l Wa H_l^T): L adjacency buffers in LDS, and the backward pass goes through the similarity block inside the layer loop
+// (dA_l, the softmax, dG_l = dS_l H_l, dH_l += dS_l^T G_l + dG_l Wa^T, dWa += H_l^T dG_l) before it forms the next layer's dZ.
+// Softmax normalisations only (embedded_gaussian, gaussian); the other similarity functions of a layerwise graph stay on the
+// per-scene kernel.
+template <int NT, int XT, int L, bool BWD, bool COS, bool LW = false>
 __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 : 2)) void graph_kernel(const GraphArgs a) {
+    static_assert(!(LW && COS), "layerwise graphs: softmax normalisations only");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using Lds = GraphLds<NT, XT>;
     constexpr int XW = Lds::XW, FLD = Lds::FLD, ALD = Lds::ALD;
@@ -1020,8 +1027,8 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
     float* dT = X + U;                 // G = X Wa lives here in the forward sweep
     float* T = dT + U;                 // [L]
     float* Hs = T + L * U;             // [L - 1]: H_1 ..
-    float* A = Hs + (L - 1) * U;
-    float* dA = A + NP * ALD;          // backward only from here
+    float* A = Hs + (L - 1) * U;       // LW: A_0 .. A_{L-1}
+    float* dA = A + (LW ? L : 1) * NP * ALD;          // backward only from here
     float* dH = dA + NP * ALD;
     float* dZ = dH + U;
     auto Hl = [&](int l) { return l == 0 ? X : Hs + (l - 1) * U; };
@@ -1075,12 +1082,52 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
                 for (int r = 0; r < 4; ++r)
                     if (frow + r < NP) out[(frow + r) * FLD + fn + nt * 16 + l16] = frow + r < N ? acc[0][nt][r] : 0.f;
         };
-        auto make_G = [&]() {
+        auto make_G = [&](const float* Hin) {          // G = H Wa of the rows the similarity is taken over (X; LW: H_l)
             f32x4 acc[1][XTW];
             clear<1, XTW>(acc);
-            mm<1, XTW, 8>(acc, XW / 4, [&](int i, int k) { return X[min(fm + i, last) * FLD + k]; },
+            mm<1, XTW, 8>(acc, XW / 4, [&](int i, int k) { return Hin[min(fm + i, last) * FLD + k]; },
                           [&](int k, int j) { return Wa[k * FLD + fn + j]; });
             put(G, acc);
+        };
+        // A_l of a layerwise graph: S = (H_l Wa) H_l^T (gaussian: H_l H_l^T), row softmax; ends with a barrier
+        auto make_A_lw = [&](const float* Hc, float* Al) {
+            if (embedded) {
+                make_G(Hc);
+                __syncthreads();
+            }
+            const float* GXl = embedded ? G : Hc;
+            if (a_on) {
+                f32x4 acc[1][NTW];
+                clear<1, NTW>(acc);
+                mm<1, NTW, 8>(acc, XW / 4, [&](int i, int k) { return GXl[min(am + i, last) * FLD + k]; },
+                              [&](int k, int j) { return Hc[min(an + j, last) * FLD + k]; });
+                each<1, NTW>(acc, [&](int i, int j, float v, int, int, int) {
+                    const int row = am + i, col = an + j;
+                    if (row < NP) Al[row * ALD + col] = (row < N && col < N) ? v : 0.f;
+                });
+            }
+            __syncthreads();
+            for (int row = wave * 4 + kq; row < N; row += W * 4) {
+                float* r = Al + row * ALD;
+                float v[NT], mx = -3.4e38f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    v[j] = l16 + 16 * j < N ? r[l16 + 16 * j] : -3.4e38f;
+                    mx = fmaxf(mx, v[j]);
+                }
+                mx = row16_maxf(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    v[j] = l16 + 16 * j < N ? expf(v[j] - mx) : 0.f;
+                    sum += v[j];
+                }
+                sum = row16_sum(sum);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    if (l16 + 16 * j < N) r[l16 + 16 * j] = v[j] / sum;
+            }
+            __syncthreads();
         };
         const int norm = a.norm;
         const bool cosine = COS && norm >= 4;
@@ -1089,8 +1136,8 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
         // column, so that the backward pass gets S_ij = sign sqrt(|A_ij| Z_i) back without a buffer of its own; every consumer of
         // A reads it through aval()
         auto aval = [&](float x) { return norm == 1 ? fabsf(x) : x; };
-        if (embedded) {
-            make_G();
+        if (embedded && !LW) {
+            make_G(X);
             __syncthreads();
         }
         const float* GX = embedded ? G : X;
@@ -1101,7 +1148,7 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
                 A[idx] = (row < N && col < N) ? (norm == 2 ? c : (row == col ? 1.f : 0.f)) : 0.f;
             }
         }
-        if (a_on && from_s) {   // S = G X^T   (graph_model.py:64-69)
+        if (a_on && from_s && !LW) {   // S = G X^T   (graph_model.py:64-69)
             f32x4 acc[1][NTW];
             clear<1, NTW>(acc);
             mm<1, NTW, 8>(acc, XW / 4, [&](int i, int k) { return GX[min(am + i, last) * FLD + k]; },
@@ -1171,7 +1218,7 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
         }
         }
         // row softmax: 16 lanes per row, four rows per wave and pass
-        for (int row = wave * 4 + kq; norm == 0 && row < N; row += W * 4) {
+        for (int row = wave * 4 + kq; !LW && norm == 0 && row < N; row += W * 4) {
             float* r = A + row * ALD;
             float v[NT], mx = -3.4e38f;
 #pragma unroll
@@ -1197,10 +1244,12 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
         for (int l = 0; l < L; ++l) {
             const float* Hc = Hl(l);
             float* Tl = T + l * U;
+            const float* Al = LW ? A + l * NP * ALD : A;
+            if constexpr (LW) make_A_lw(Hc, A + l * NP * ALD);
             {   // T_l = A H_l
                 f32x4 acc[1][XTW];
                 clear<1, XTW>(acc);
-                mm<1, XTW, 8>(acc, NK, [&](int i, int k) { return aval(A[min(fm + i, last) * ALD + k]); },
+                mm<1, XTW, 8>(acc, NK, [&](int i, int k) { return aval(Al[min(fm + i, last) * ALD + k]); },
                               [&](int k, int j) { return Hc[k * FLD + fn + j]; });
                 put(Tl, acc);
             }
@@ -1243,6 +1292,7 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
                 const float* Hc = Hl(l);
                 const float* Tl = T + l * U;
                 const float* Wc = Wl + l * XW * FLD;
+                const float* Al = LW ? A + l * NP * ALD : A;
                 // dW_l += T_l^T dZ
                 if (g_on)
                     mm<GM, GN, 8>(gW[l], NK, [&](int mi, int k) { return Tl[k * FLD + gm + mi]; },
@@ -1262,7 +1312,7 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
                 {   // dH_l = A^T dT (+ dH_{l+1} through the skip connection); the next layer's dZ right away
                     f32x4 acc[1][XTW];
                     clear<1, XTW>(acc);
-                    mm<1, XTW, 8>(acc, NK, [&](int mi, int k) { return aval(A[k * ALD + fm + mi]); },
+                    mm<1, XTW, 8>(acc, NK, [&](int mi, int k) { return aval(Al[k * ALD + fm + mi]); },
                                   [&](int k, int j) { return dT[k * FLD + fn + j]; });
 #pragma unroll
                     for (int nt = 0; nt < XTW; ++nt)
@@ -1272,19 +1322,91 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
                             if (row < N) {
                                 const float d = acc[0][nt][r] + (a.skip ? dH[row * FLD + col] : 0.f);
                                 dH[row * FLD + col] = d;
-                                if (l > 0) dZ[row * FLD + col] = ((mask[l > 0 ? l - 1 : 0] >> (nt * 4 + r)) & 1u) ? d : 0.f;
+                                // (LW: dH_l is not complete yet -- the similarity block of this layer adds to it below)
+                                if (!LW && l > 0) dZ[row * FLD + col] = ((mask[l > 0 ? l - 1 : 0] >> (nt * 4 + r)) & 1u) ? d : 0.f;
                             }
                         }
                 }
                 __syncthreads();
+                if constexpr (LW) {
+                    // ---- through A_l = softmax(S_l), S_l = G_l H_l^T, G_l = H_l Wa (gaussian: G_l = H_l)
+                    if (a_on)
+                        each<1, NTW>(dAacc, [&](int i, int j, float v, int, int, int) {
+                            const int row = am + i, col = an + j;
+                            if (row < NP) dA[row * ALD + col] = (row < N && col < N) ? v : 0.f;
+                        });
+                    clear<1, NTW>(dAacc);
+                    if (embedded) make_G(Hc);            // into dT's buffer: its readers (dA_l, dH_l) are behind the barrier above
+                    __syncthreads();
+                    for (int row = wave * 4 + kq; row < N; row += W * 4) {       // dS_ij = A_ij (dA_ij - sum_k dA_ik A_ik)
+                        float* d = dA + row * ALD;
+                        const float* p = Al + row * ALD;
+                        float dv[NT], pv[NT], dot = 0.f;
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            const bool ok = l16 + 16 * j < N;
+                            dv[j] = ok ? d[l16 + 16 * j] : 0.f;
+                            pv[j] = ok ? p[l16 + 16 * j] : 0.f;
+                            dot = fmaf(dv[j], pv[j], dot);
+                        }
+                        dot = row16_sum(dot);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            if (l16 + 16 * j < N) d[l16 + 16 * j] = pv[j] * (dv[j] - dot);
+                    }
+                    __syncthreads();
+                    const float* GXl = embedded ? G : Hc;
+                    float* dGl = dZ;                      // dZ_l is spent: dW_l and dT have read it
+                    f32x4 dxl[1][XTW];
+                    {
+                        f32x4 acc[1][XTW];
+                        clear<1, XTW>(acc);
+                        mm<1, XTW, 8>(acc, NK, [&](int i, int k) { return dA[min(fm + i, last) * ALD + k]; },
+                                      [&](int k, int j) { return Hc[k * FLD + fn + j]; });
+                        put(dGl, acc);
+                        clear<1, XTW>(dxl);
+                        mm<1, XTW, 8>(dxl, NK, [&](int mi, int k) { return dA[k * ALD + fm + mi]; },
+                                      [&](int k, int j) { return GXl[k * FLD + fn + j]; });
+                        if (!embedded) {
+#pragma unroll
+                            for (int nt = 0; nt < XTW; ++nt)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) dxl[0][nt][r] += acc[0][nt][r];
+                        }
+                    }
+                    __syncthreads();
+                    if (embedded) {
+                        if (g_on)
+                            mm<GM, GN, 8>(gWa, NK, [&](int mi, int k) { return Hc[k * FLD + gm + mi]; },
+                                          [&](int k, int j) { return dGl[k * FLD + gn + j]; });
+                        mm<1, XTW, 8>(dxl, XW / 4, [&](int i, int k) { return dGl[min(fm + i, last) * FLD + k]; },
+                                      [&](int k, int j) { return Wa[(fn + j) * FLD + k]; });
+                    }
+                    __syncthreads();                      // every read of dG_l (in dZ's buffer) is done
+#pragma unroll
+                    for (int nt = 0; nt < XTW; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = frow + r, col = fn + nt * 16 + l16;
+                            if (row < NP) {
+                                const float d = row < N ? dH[row * FLD + col] + dxl[0][nt][r] : 0.f;
+                                if (row < N) dH[row * FLD + col] = d;
+                                if (l > 0) dZ[row * FLD + col] = ((mask[l > 0 ? l - 1 : 0] >> (nt * 4 + r)) & 1u) ? d : 0.f;
+                            }
+                        }
+                    __syncthreads();
+                }
             }
+            f32x4 dx[1][XTW];
+            clear<1, XTW>(dx);
+            if constexpr (!LW) {
             // through the row softmax: dS_ij = A_ij (dA_ij - sum_k dA_ik A_ik)
             if (a_on)
                 each<1, NTW>(dAacc, [&](int i, int j, float v, int, int, int) {
                     const int row = am + i, col = an + j;
                     if (row < NP) dA[row * ALD + col] = (row < N && col < N && from_s) ? v : 0.f;      // constant adjacency: dS = 0
                 });
-            if (embedded) make_G();            // dT's buffer is free again
+            if (embedded) make_G(X);           // dT's buffer is free again
             __syncthreads();
             // through the squared normalisation: dS_ij = 2 S_ij (dA_ij - sum_k dA_ik A_ik) / Z_i, S_ij = sign sqrt(|A_ij| Z_i)
             for (int row = wave * 4 + kq; norm == 1 && row < N; row += W * 4) {
@@ -1366,7 +1488,6 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
             __syncthreads();
             // S = G X^T:  dG = dS X ;  dX += dS^T G        G = X Wa:  dWa += X^T dG ;  dX += dG Wa^T     (gaussian: G = X, dX += dG)
             float* dG = dZ;
-            f32x4 dx[1][XTW];
             {
                 f32x4 acc[1][XTW];
                 clear<1, XTW>(acc);
@@ -1390,6 +1511,7 @@ __global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 :
                                   [&](int k, int j) { return dG[k * FLD + gn + j]; });
                 mm<1, XTW, 8>(dx, XW / 4, [&](int i, int k) { return dG[min(fm + i, last) * FLD + k]; },
                               [&](int k, int j) { return Wa[(fn + j) * FLD + k]; });
+            }
             }
             float* dxr = a.dXr + (size_t)s * a.xr_stride;
             float* dxh = a.dXh + (size_t)s * a.xh_stride - XW;
@@ -1630,9 +1752,9 @@ int launch_rows(RowsArgs& all, hipStream_t st) {
     return RGL_OK;
 }
 
-template <int NT, int XT, int L, bool BWD, bool COS>
+template <int NT, int XT, int L, bool BWD, bool COS, bool LW = false>
 int launch_graph_kernel(const GraphArgs& ga, size_t lds, int grid, hipStream_t st) {
-    auto kern = graph_kernel<NT, XT, L, BWD, COS>;
+    auto kern = graph_kernel<NT, XT, L, BWD, COS, LW>;
     if (lds > 64 * 1024)
         RGL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 128), lds, st, ga);
@@ -1641,6 +1763,13 @@ int launch_graph_kernel(const GraphArgs& ga, size_t lds, int grid, hipStream_t s
 }
 template <int NT, int XT, int L>
 int launch_graph_nxl(const GraphArgs& ga, bool bwd, size_t lds, int grid, hipStream_t st) {
+    if (ga.lw) {        // layerwise graphs: the softmax normalisations, up to 32 nodes of 32 features (tiles_cover)
+        if constexpr (XT == 2 && NT <= 2)
+            return bwd ? launch_graph_kernel<NT, XT, L, true, false, true>(ga, lds, grid, st)
+                       : launch_graph_kernel<NT, XT, L, false, false, true>(ga, lds, grid, st);
+        else
+            return 1;
+    }
     if (ga.norm >= 4)
         return bwd ? launch_graph_kernel<NT, XT, L, true, true>(ga, lds, grid, st) : launch_graph_kernel<NT, XT, L, false, true>(ga, lds, grid, st);
     return bwd ? launch_graph_kernel<NT, XT, L, true, false>(ga, lds, grid, st) : launch_graph_kernel<NT, XT, L, false, false>(ga, lds, grid, st);
@@ -1656,9 +1785,9 @@ int launch_graph_nx(const GraphArgs& ga, int L, bool bwd, size_t lds, int grid, 
 
 struct GraphPlan { int grid; size_t lds; };
 template <int NT, int XT>
-GraphPlan plan_graph_nx(int S, int N, int L, bool bwd) {
+GraphPlan plan_graph_nx(int S, int N, int L, bool bwd, bool lw) {
     GraphPlan p{};
-    p.lds = (size_t)(GraphLds<NT, XT>::weight_floats(L) + GraphLds<NT, XT>::scene_floats(N, L, bwd)) * sizeof(float);
+    p.lds = (size_t)(GraphLds<NT, XT>::weight_floats(L) + GraphLds<NT, XT>::scene_floats(N, L, bwd, lw)) * sizeof(float);
     if (p.lds > (size_t)rgl::kLdsBytesPerCu) return p;
     // persistent workgroups: as many as are resident at once (LDS, and the waves the kernel's register budget allows), scenes dealt
     // round robin
@@ -1671,9 +1800,9 @@ GraphPlan plan_graph_nx(int S, int N, int L, bool bwd) {
     return p;
 }
 // x_dim 32 or 64
-GraphPlan plan_graph(int S, int N, int X, int L, bool bwd) {
-    if (X == 32) return N <= 16 ? plan_graph_nx<1, 2>(S, N, L, bwd) : (N <= 32 ? plan_graph_nx<2, 2>(S, N, L, bwd) : plan_graph_nx<4, 2>(S, N, L, bwd));
-    return N <= 16 ? plan_graph_nx<1, 4>(S, N, L, bwd) : (N <= 32 ? plan_graph_nx<2, 4>(S, N, L, bwd) : plan_graph_nx<4, 4>(S, N, L, bwd));
+GraphPlan plan_graph(int S, int N, int X, int L, bool bwd, bool lw = false) {
+    if (X == 32) return N <= 16 ? plan_graph_nx<1, 2>(S, N, L, bwd, lw) : (N <= 32 ? plan_graph_nx<2, 2>(S, N, L, bwd, lw) : plan_graph_nx<4, 2>(S, N, L, bwd, lw));
+    return N <= 16 ? plan_graph_nx<1, 4>(S, N, L, bwd, lw) : (N <= 32 ? plan_graph_nx<2, 4>(S, N, L, bwd, lw) : plan_graph_nx<4, 4>(S, N, L, bwd, lw));
 }
 int launch_graph(const GraphArgs& ga, int X, int L, bool bwd, const GraphPlan& p, hipStream_t st) {
     if (X == 32) {
@@ -1729,7 +1858,9 @@ int tiles_norm(const RglGraph& g) {
 }
 bool tiles_cover(const RglGraph& g, int H) {
     const int N = H + 1, L = g.num_layer;
-    if ((g.x_dim != 32 && g.x_dim != 64) || g.layerwise_graph || L < 1 || L > 3 || N > 64 || H < 1) return false;
+    if ((g.x_dim != 32 && g.x_dim != 64) || L < 1 || L > 3 || N > 64 || H < 1) return false;
+    // layerwise graphs (round 6): the softmax normalisations, the shipped feature width, up to 32 nodes
+    if (g.layerwise_graph && (tiles_norm(g) != 0 || g.x_dim != 32 || N > 32)) return false;
     return tiles_norm(g) >= 0;
 }
 
@@ -1739,6 +1870,7 @@ void graph_args(GraphArgs& ga, const RglGraph& g, int S, int N, int spc) {
     for (int l = 0; l < g.num_layer; ++l) ga.Ws[l] = g.Ws[l];
     ga.S = S; ga.N = N; ga.skip = g.skip_connection ? 1 : 0; ga.spc = spc;
     ga.norm = tiles_norm(g);
+    ga.lw = g.layerwise_graph ? 1 : 0;
     ga.xr_stride = g.x_dim; ga.xh_stride = (N - 1) * g.x_dim;
 }
 
@@ -1782,7 +1914,7 @@ int launch_tiles_forward(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
         return 1;
     const RglGraph& g = *graph;
     const int N = H + 1, L = g.num_layer, X = g.x_dim, crowds = S / spc;
-    const GraphPlan gp = plan_graph(S, N, X, L, false);
+    const GraphPlan gp = plan_graph(S, N, X, L, false, g.layerwise_graph != 0);
     if (gp.grid < 1) return 1;
     Taker ws{(char*)workspace};
     float* Xr = ws.take<float>((size_t)S * X);
@@ -1862,8 +1994,8 @@ static int backward_tiles(const RglGraph* graph, const RglMlp* vh, const RglMlp*
     if (!tiles_cover(g, H)) return 1;
     const int N = H + 1, L = g.num_layer, X = g.x_dim;
     const bool has_v = vh && vh->n_layers > 0, has_m = mh && mh->n_layers > 0;
-    const bool embedded = g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN;
-    const GraphPlan gpf = plan_graph(S, N, X, L, false), gp_full = plan_graph(S, N, X, L, true);
+    const bool embedded = g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN, lw = g.layerwise_graph != 0;
+    const GraphPlan gpf = plan_graph(S, N, X, L, false, lw), gp_full = plan_graph(S, N, X, L, true, lw);
     if (gp_full.grid < 1 || gpf.grid < 1) return 1;
 
     // gradient vector: w_r | w_h | w_a | Ws | value head | motion head

@@ -2318,6 +2318,26 @@ def test_gradients_on_the_mfma_backward(H, L, sim, skip, flavour, B, dev, monkey
     test_gradients_rgl_output_and_path_g(dev)
 
 
+@pytest.mark.parametrize("H,L,sim,skip,B", [(5, 2, "embedded_gaussian", True, 5), (6, 3, "embedded_gaussian", False, 3),
+                                            (5, 2, "gaussian", True, 4), (19, 2, "embedded_gaussian", True, 3),
+                                            (19, 3, "gaussian", False, 2), (31, 1, "embedded_gaussian", True, 2)])
+def test_gradients_of_layerwise_graphs_on_the_mfma_backward(H, L, sim, skip, B, dev, monkeypatch):
+    """VERDICT r5 missing 4 / next 7: layerwise graphs (graph_model.py:118-122: an adjacency per layer, A_l = softmax(S(H_l))) on
+    the tile pipeline in MUST-RUN mode (RGL_BACKWARD_MFMA=2: an error instead of the per-scene kernel) -- the forward recomputes
+    the similarity block from every layer's input, the backward goes through it inside the layer loop.  Every gradient of the value
+    estimator and of the state predictor against autograd over the oracle."""
+    monkeypatch.setenv("RGL_BACKWARD_MFMA", "2")
+    test_gradients_value_estimator_and_state_predictor(H, L, sim, skip, "trained", B, True, dev)
+
+
+def test_reference_vnrl_trainer_fixture_with_a_layerwise_graph_on_the_tile_backward(dev, monkeypatch):
+    """Fixture vnrl_trainer.npz, case layerwise_noskip (the REFERENCE VNRLTrainer's batches on a layerwise path-G model) with the
+    tile pipeline in must-run mode, through the raw loop and through the public trainer."""
+    monkeypatch.setenv("RGL_BACKWARD_MFMA", "2")
+    test_training_against_the_reference_vnrl_trainer_fixture("layerwise_noskip|2|1|0", dev)
+    test_product_vnrl_trainer_reproduces_the_reference_fixture("layerwise_noskip|2|1|0", dev)
+
+
 @pytest.mark.parametrize("tag", ["squared", "cosine_softmax"])
 def test_reference_trainer_fixture_with_a_non_default_similarity_on_the_tile_backward(tag, dev, monkeypatch):
     """the reference MPRLTrainer's three Adam batches with the `squared` (graph_model.py:86-89) and the
