@@ -26,8 +26,8 @@
 // their crowd's embedded rows.
 //
 // Envelope of both: embedded_gaussian, gaussian, squared, equal_attention or diagonal similarity (round 5: the three plain-weight
-// normalisations), one adjacency for all layers, x_dim 32 | 64, 1-3 layers, N <= 64; any
-// embedding MLPs and heads within the ABI limits.  Outside it: return 1 (the caller falls back to rgl_backward.hip / the general kernel).
+// normalisations), one adjacency for all layers -- or, round 6, one per layer (layerwise graphs) for the softmax normalisations at
+// x_dim 32 and N <= 32 --, x_dim 32 | 64, 1-3 layers, N <= 64; any embedding MLPs and heads within the ABI limits.  Outside it: return 1 (the caller falls back to rgl_backward.hip / the general kernel).
 //
 // Differentiated forward: graph_model.py:99-130, value_estimator.py:11-20, state_predictor.py:28-36, gcn.py:95-128.
 #include "rgl_mfma.h"
@@ -1843,8 +1843,8 @@ __global__ __launch_bounds__(256) void init_rows_kernel(float* __restrict__ dst,
 
 // what the tile kernels cover: embedded_gaussian / gaussian (softmax of S) and -- round 5 -- squared / equal_attention / diagonal
 // (plain weights: graph_model.py:86-93) and cosine / cosine_softmax (:70-79), one adjacency for all layers, x_dim 32 or 64, 1-3
-// layers, N <= 64; any embedding MLPs and heads within the ABI limits.  The pair-MLP similarity (concatenation) and layerwise graphs
-// stay on the per-scene kernels.
+// layers, N <= 64; any embedding MLPs and heads within the ABI limits; layerwise graphs (round 6) with embedded_gaussian / gaussian
+// at x_dim 32, N <= 32.  The pair-MLP similarity (concatenation) and the other layerwise graphs stay on the per-scene kernels.
 int tiles_norm(const RglGraph& g) {
     switch (g.similarity) {
         case RGL_SIM_EMBEDDED_GAUSSIAN: case RGL_SIM_GAUSSIAN: return 0;

@@ -14,7 +14,7 @@ from tests.test_gpu_parity import seeded_scenes  # noqa: E402
 
 def main():
     dev = torch.device("cuda:0")
-    pol = make_mprl_policy("trained", 1, device=dev)
+    pol = make_mprl_policy("trained", 1, device=dev, layerwise=os.environ.get("BT_LAYERWISE") == "1")     # BT_LAYERWISE=1: an adjacency per layer
     ve, sp = pol.value_estimator, pol.state_predictor
     print("| H | batch | module | per-scene kernel ms | tile pipeline ms | ratio |")
     print("|---|---|---|---|---|---|")
