@@ -999,8 +999,10 @@ struct GraphLds {
 // (dA_l, the softmax, dG_l = dS_l H_l, dH_l += dS_l^T G_l + dG_l Wa^T, dWa += H_l^T dG_l) before it forms the next layer's dZ.
 // Softmax normalisations only (embedded_gaussian, gaussian); the other similarity functions of a layerwise graph stay on the
 // per-scene kernel.
+// (two workgroups per CU at least for the layerwise form: its backward carries the similarity block's accumulators through the
+// layer loop and spills 50-88 registers under the four-workgroup budget of the one-adjacency form)
 template <int NT, int XT, int L, bool BWD, bool COS, bool LW = false>
-__global__ __launch_bounds__(NT * 128, (NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 : 2)) void graph_kernel(const GraphArgs a) {
+__global__ __launch_bounds__(NT * 128, LW ? 2 : ((NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 : 2))) void graph_kernel(const GraphArgs a) {
     static_assert(!(LW && COS), "layerwise graphs: softmax normalisations only");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using Lds = GraphLds<NT, XT>;
@@ -1792,7 +1794,7 @@ GraphPlan plan_graph_nx(int S, int N, int L, bool bwd, bool lw) {
     // persistent workgroups: as many as are resident at once (LDS, and the waves the kernel's register budget allows), scenes dealt
     // round robin
     int per_cu = (int)((size_t)rgl::kLdsBytesPerCu / p.lds);
-    const int by_waves = ((NT == 2 && XT == 2) ? 16 : (NT == 1 ? 12 : 8)) / (2 * NT);
+    const int by_waves = lw ? 2 : ((NT == 2 && XT == 2) ? 16 : (NT == 1 ? 12 : 8)) / (2 * NT);
     per_cu = per_cu > by_waves ? by_waves : per_cu;
     per_cu = per_cu < 1 ? 1 : per_cu;
     const int resident = 256 * per_cu;
