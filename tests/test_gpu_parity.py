@@ -1167,10 +1167,13 @@ from oracle import rgl_oracle as orc
 from tests.test_gpu_parity import seeded_scenes
 dev = torch.device("cuda:0")
 worst, worst_g = 0.0, 0.0
-for X, wr, wh, H, L, D, B, sim in ((64, [64, 64], [64, 64], 5, 2, 2, 6, "embedded_gaussian"), (32, [128, 64, 32], [48, 32], 19, 2, 1, 5, "embedded_gaussian"),
-                                   (64, [32, 64], [100, 64], 33, 2, 1, 2, "embedded_gaussian"), (32, [64, 32], [32, 32], 5, 1, 2, 7, "gaussian"),
-                                   (64, [64], [256, 64], 12, 2, 2, 4, "gaussian")):
+for X, wr, wh, H, L, D, B, sim, lw in ((64, [64, 64], [64, 64], 5, 2, 2, 6, "embedded_gaussian", False), (32, [128, 64, 32], [48, 32], 19, 2, 1, 5, "embedded_gaussian", False),
+                                   (64, [32, 64], [100, 64], 33, 2, 1, 2, "embedded_gaussian", False), (32, [64, 32], [32, 32], 5, 1, 2, 7, "gaussian", False),
+                                   (64, [64], [256, 64], 12, 2, 2, 4, "gaussian", False),
+                                   # round 6: layerwise graphs (an adjacency per layer) of other embedding MLPs on the tile kernels
+                                   (32, [128, 64, 32], [48, 32], 7, 2, 2, 4, "embedded_gaussian", True), (32, [48, 32], [64, 64, 32], 19, 3, 1, 3, "gaussian", True)):
     cfgp = policy_config("model_predictive_rl", gcn__num_layer=L, gcn__X_dim=X, gcn__final_state_dim=X, gcn__wr_dims=wr, gcn__wh_dims=wh,
+                         gcn__layerwise_graph=lw,
                          gcn__similarity_function=sim, model_predictive_rl__planning_depth=D, model_predictive_rl__planning_width=2,
                          model_predictive_rl__do_action_clip=D > 1, model_predictive_rl__value_network_dims=[X, 100, 100, 1])
     torch.manual_seed(X * 100 + H)
@@ -1184,7 +1187,7 @@ for X, wr, wh, H, L, D, B, sim in ((64, [64, 64], [64, 64], 5, 2, 2, 6, "embedde
                     p_.mul_(1.0 / X ** 0.5)
     pol.set_time_step(0.25); pol.set_phase("test"); pol.set_device(dev)
     robot, humans = seeded_scenes(900 + H, B, H)
-    cfg = orc.OracleConfig(num_layer=L, similarity=sim, planning_depth=D, planning_width=2, do_action_clip=D > 1)
+    cfg = orc.OracleConfig(num_layer=L, similarity=sim, planning_depth=D, planning_width=2, do_action_clip=D > 1, layerwise_graph=lw)
     Pm = orc.MprlParams.from_checkpoint({k: ({kk: vv.cpu() for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in pol.get_state_dict().items()})
     r, h = robot.unsqueeze(1).to(dev), humans.to(dev)
     with torch.no_grad():
@@ -1202,7 +1205,7 @@ for X, wr, wh, H, L, D, B, sim in ((64, [64, 64], [64, 64], 5, 2, 2, 6, "embedde
     same = (act.cpu().long() == oa).float().mean().item()
     assert same == 1.0 or e2 < 1e-6, (X, wr, wh, same)
     worst = max(worst, e1, e2, e3)
-    print("forward / search ok:", X, wr, wh, H, L, D, sim, e1, e2, e3, flush=True)
+    print("forward / search ok:", X, wr, wh, H, L, D, sim, "layerwise" if lw else "", e1, e2, e3, flush=True)
     # gradients of the value estimator through the tile pipeline against autograd over the oracle
     ve = pol.value_estimator
     wv = torch.linspace(-1.0, 1.5, B).reshape(B, 1)
