@@ -26,8 +26,8 @@
 // their crowd's embedded rows.
 //
 // Envelope of both: embedded_gaussian, gaussian, squared, equal_attention or diagonal similarity (round 5: the three plain-weight
-// normalisations), one adjacency for all layers -- or, round 6, one per layer (layerwise graphs) for the softmax normalisations at
-// x_dim 32 and N <= 32 --, x_dim 32 | 64, 1-3 layers, N <= 64; any embedding MLPs and heads within the ABI limits.  Outside it: return 1 (the caller falls back to rgl_backward.hip / the general kernel).
+// normalisations), one adjacency for all layers -- or, round 6, one per layer (layerwise graphs) for the softmax and squared
+// normalisations at x_dim 32 and N <= 32 --, x_dim 32 | 64, 1-3 layers, N <= 64; any embedding MLPs and heads within the ABI limits.  Outside it: return 1 (the caller falls back to rgl_backward.hip / the general kernel).
 //
 // Differentiated forward: graph_model.py:99-130, value_estimator.py:11-20, state_predictor.py:28-36, gcn.py:95-128.
 #include "rgl_mfma.h"
@@ -997,13 +997,14 @@ struct GraphLds {
 // LW (round 6): layerwise graphs (graph_model.py:118-122) -- the adjacency is recomputed from every layer's input, A_l =
 // softmax(H_l Wa H_l^T): L adjacency buffers in LDS, and the backward pass goes through the similarity block inside the layer loop
 // (dA_l, the softmax, dG_l = dS_l H_l, dH_l += dS_l^T G_l + dG_l Wa^T, dWa += H_l^T dG_l) before it forms the next layer's dZ.
-// Softmax normalisations only (embedded_gaussian, gaussian); the other similarity functions of a layerwise graph stay on the
-// per-scene kernel.
+// The softmax normalisations (embedded_gaussian, gaussian) and the squared one; equal_attention / diagonal adjacencies are
+// constants, so their layerwise graphs ARE the one-adjacency form; the cosine family and the pair-MLP similarity of a layerwise
+// graph stay on the per-scene kernel.
 // (two workgroups per CU at least for the layerwise form: its backward carries the similarity block's accumulators through the
 // layer loop and spills 50-88 registers under the four-workgroup budget of the one-adjacency form)
 template <int NT, int XT, int L, bool BWD, bool COS, bool LW = false>
 __global__ __launch_bounds__(NT * 128, LW ? 2 : ((NT == 2 && XT == 2) ? 4 : (NT == 1 ? 3 : 2))) void graph_kernel(const GraphArgs a) {
-    static_assert(!(LW && COS), "layerwise graphs: softmax normalisations only");
+    static_assert(!(LW && COS), "layerwise graphs: the softmax and squared normalisations only");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using Lds = GraphLds<NT, XT>;
     constexpr int XW = Lds::XW, FLD = Lds::FLD, ALD = Lds::ALD;
@@ -1091,7 +1092,8 @@ __global__ __launch_bounds__(NT * 128, LW ? 2 : ((NT == 2 && XT == 2) ? 4 : (NT 
                           [&](int k, int j) { return Wa[k * FLD + fn + j]; });
             put(G, acc);
         };
-        // A_l of a layerwise graph: S = (H_l Wa) H_l^T (gaussian: H_l H_l^T), row softmax; ends with a barrier
+        const int norm = a.norm;
+        // A_l of a layerwise graph: S = (H_l Wa) H_l^T (gaussian, squared: H_l H_l^T), its row normalisation; ends with a barrier
         auto make_A_lw = [&](const float* Hc, float* Al) {
             if (embedded) {
                 make_G(Hc);
@@ -1109,7 +1111,22 @@ __global__ __launch_bounds__(NT * 128, LW ? 2 : ((NT == 2 && XT == 2) ? 4 : (NT 
                 });
             }
             __syncthreads();
-            for (int row = wave * 4 + kq; row < N; row += W * 4) {
+            for (int row = wave * 4 + kq; norm == 1 && row < N; row += W * 4) {       // squared: as in the one-adjacency form below
+                float* r = Al + row * ALD;
+                float sv[NT], w[NT], sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    sv[j] = l16 + 16 * j < N ? r[l16 + 16 * j] : 0.f;
+                    w[j] = sv[j] * sv[j];
+                    sum += w[j];
+                }
+                sum = row16_sum(sum);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    if (l16 + 16 * j < N) r[l16 + 16 * j] = copysignf(w[j] / sum, sv[j]);
+                if (l16 == 0) r[NT * 16] = sum;
+            }
+            for (int row = wave * 4 + kq; norm == 0 && row < N; row += W * 4) {
                 float* r = Al + row * ALD;
                 float v[NT], mx = -3.4e38f;
 #pragma unroll
@@ -1131,7 +1148,6 @@ __global__ __launch_bounds__(NT * 128, LW ? 2 : ((NT == 2 && XT == 2) ? 4 : (NT 
             }
             __syncthreads();
         };
-        const int norm = a.norm;
         const bool cosine = COS && norm >= 4;
         const bool from_s = norm <= 1 || cosine;        // the adjacency is a function of S (it is a constant otherwise)
         // squared similarity: A is kept SIGNED in LDS -- sign(S_ij) |A_ij| -- and the row's Z_i = sum_j S_ij^2 in the row's padding
@@ -1340,7 +1356,24 @@ __global__ __launch_bounds__(NT * 128, LW ? 2 : ((NT == 2 && XT == 2) ? 4 : (NT 
                     clear<1, NTW>(dAacc);
                     if (embedded) make_G(Hc);            // into dT's buffer: its readers (dA_l, dH_l) are behind the barrier above
                     __syncthreads();
-                    for (int row = wave * 4 + kq; row < N; row += W * 4) {       // dS_ij = A_ij (dA_ij - sum_k dA_ik A_ik)
+                    for (int row = wave * 4 + kq; norm == 1 && row < N; row += W * 4) {     // squared: dS = 2 S (dA - sum dA A) / Z
+                        float* d = dA + row * ALD;
+                        const float* p = Al + row * ALD;
+                        const float zi = p[NT * 16];
+                        float dv[NT], pv[NT], dot = 0.f;
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            const bool ok = l16 + 16 * j < N;
+                            dv[j] = ok ? d[l16 + 16 * j] : 0.f;
+                            pv[j] = ok ? p[l16 + 16 * j] : 0.f;
+                            dot = fmaf(dv[j], fabsf(pv[j]), dot);
+                        }
+                        dot = row16_sum(dot);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            if (l16 + 16 * j < N) d[l16 + 16 * j] = 2.f * copysignf(sqrtf(fabsf(pv[j]) / zi), pv[j]) * (dv[j] - dot);
+                    }
+                    for (int row = wave * 4 + kq; norm == 0 && row < N; row += W * 4) {       // softmax: dS_ij = A_ij (dA_ij - sum_k dA_ik A_ik)
                         float* d = dA + row * ALD;
                         const float* p = Al + row * ALD;
                         float dv[NT], pv[NT], dot = 0.f;
@@ -1765,7 +1798,7 @@ int launch_graph_kernel(const GraphArgs& ga, size_t lds, int grid, hipStream_t s
 }
 template <int NT, int XT, int L>
 int launch_graph_nxl(const GraphArgs& ga, bool bwd, size_t lds, int grid, hipStream_t st) {
-    if (ga.lw) {        // layerwise graphs: the softmax normalisations, up to 32 nodes of 32 features (tiles_cover)
+    if (ga.lw) {        // layerwise graphs: the softmax / squared normalisations, up to 32 nodes of 32 features (tiles_cover)
         if constexpr (XT == 2 && NT <= 2)
             return bwd ? launch_graph_kernel<NT, XT, L, true, false, true>(ga, lds, grid, st)
                        : launch_graph_kernel<NT, XT, L, false, false, true>(ga, lds, grid, st);
@@ -1846,7 +1879,8 @@ __global__ __launch_bounds__(256) void init_rows_kernel(float* __restrict__ dst,
 // what the tile kernels cover: embedded_gaussian / gaussian (softmax of S) and -- round 5 -- squared / equal_attention / diagonal
 // (plain weights: graph_model.py:86-93) and cosine / cosine_softmax (:70-79), one adjacency for all layers, x_dim 32 or 64, 1-3
 // layers, N <= 64; any embedding MLPs and heads within the ABI limits; layerwise graphs (round 6) with embedded_gaussian / gaussian
-// at x_dim 32, N <= 32.  The pair-MLP similarity (concatenation) and the other layerwise graphs stay on the per-scene kernels.
+// / squared at x_dim 32, N <= 32 (and equal_attention / diagonal, whose adjacency is a constant).  The pair-MLP similarity
+// (concatenation) and layerwise graphs of the cosine family stay on the per-scene kernels.
 int tiles_norm(const RglGraph& g) {
     switch (g.similarity) {
         case RGL_SIM_EMBEDDED_GAUSSIAN: case RGL_SIM_GAUSSIAN: return 0;
@@ -1861,8 +1895,12 @@ int tiles_norm(const RglGraph& g) {
 bool tiles_cover(const RglGraph& g, int H) {
     const int N = H + 1, L = g.num_layer;
     if ((g.x_dim != 32 && g.x_dim != 64) || L < 1 || L > 3 || N > 64 || H < 1) return false;
-    // layerwise graphs (round 6): the softmax normalisations, the shipped feature width, up to 32 nodes
-    if (g.layerwise_graph && (tiles_norm(g) != 0 || g.x_dim != 32 || N > 32)) return false;
+    // layerwise graphs (round 6): the softmax and the squared normalisations at the shipped feature width, up to 32 nodes; the
+    // constant adjacencies (equal_attention, diagonal) do not depend on the layer's input at all -- the one-adjacency kernels
+    if (g.layerwise_graph) {
+        const int nm = tiles_norm(g);
+        if (!(nm == 2 || nm == 3 || ((nm == 0 || nm == 1) && g.x_dim == 32 && N <= 32))) return false;
+    }
     return tiles_norm(g) >= 0;
 }
 
@@ -1872,7 +1910,7 @@ void graph_args(GraphArgs& ga, const RglGraph& g, int S, int N, int spc) {
     for (int l = 0; l < g.num_layer; ++l) ga.Ws[l] = g.Ws[l];
     ga.S = S; ga.N = N; ga.skip = g.skip_connection ? 1 : 0; ga.spc = spc;
     ga.norm = tiles_norm(g);
-    ga.lw = g.layerwise_graph ? 1 : 0;
+    ga.lw = (g.layerwise_graph && ga.norm <= 1) ? 1 : 0;        // constant adjacencies: layerwise or not is the same graph
     ga.xr_stride = g.x_dim; ga.xh_stride = (N - 1) * g.x_dim;
 }
 
@@ -1916,7 +1954,7 @@ int launch_tiles_forward(const RglGraph* graph, const RglMlp* vh, const RglMlp* 
         return 1;
     const RglGraph& g = *graph;
     const int N = H + 1, L = g.num_layer, X = g.x_dim, crowds = S / spc;
-    const GraphPlan gp = plan_graph(S, N, X, L, false, g.layerwise_graph != 0);
+    const GraphPlan gp = plan_graph(S, N, X, L, false, g.layerwise_graph != 0 && tiles_norm(g) <= 1);
     if (gp.grid < 1) return 1;
     Taker ws{(char*)workspace};
     float* Xr = ws.take<float>((size_t)S * X);
@@ -1996,7 +2034,7 @@ static int backward_tiles(const RglGraph* graph, const RglMlp* vh, const RglMlp*
     if (!tiles_cover(g, H)) return 1;
     const int N = H + 1, L = g.num_layer, X = g.x_dim;
     const bool has_v = vh && vh->n_layers > 0, has_m = mh && mh->n_layers > 0;
-    const bool embedded = g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN, lw = g.layerwise_graph != 0;
+    const bool embedded = g.similarity == RGL_SIM_EMBEDDED_GAUSSIAN, lw = g.layerwise_graph != 0 && tiles_norm(g) <= 1;
     const GraphPlan gpf = plan_graph(S, N, X, L, false, lw), gp_full = plan_graph(S, N, X, L, true, lw);
     if (gp_full.grid < 1 || gpf.grid < 1) return 1;
 

@@ -2323,12 +2323,16 @@ def test_gradients_on_the_mfma_backward(H, L, sim, skip, flavour, B, dev, monkey
 
 @pytest.mark.parametrize("H,L,sim,skip,B", [(5, 2, "embedded_gaussian", True, 5), (6, 3, "embedded_gaussian", False, 3),
                                             (5, 2, "gaussian", True, 4), (19, 2, "embedded_gaussian", True, 3),
-                                            (19, 3, "gaussian", False, 2), (31, 1, "embedded_gaussian", True, 2)])
+                                            (19, 3, "gaussian", False, 2), (31, 1, "embedded_gaussian", True, 2),
+                                            (5, 2, "squared", True, 4), (19, 3, "squared", False, 2),
+                                            # constant adjacencies: a layerwise graph of these IS the one-adjacency graph
+                                            (7, 2, "equal_attention", True, 3), (12, 3, "diagonal", False, 2)])
 def test_gradients_of_layerwise_graphs_on_the_mfma_backward(H, L, sim, skip, B, dev, monkeypatch):
     """VERDICT r5 missing 4 / next 7: layerwise graphs (graph_model.py:118-122: an adjacency per layer, A_l = softmax(S(H_l))) on
     the tile pipeline in MUST-RUN mode (RGL_BACKWARD_MFMA=2: an error instead of the per-scene kernel) -- the forward recomputes
-    the similarity block from every layer's input, the backward goes through it inside the layer loop.  Every gradient of the value
-    estimator and of the state predictor against autograd over the oracle."""
+    the similarity block from every layer's input, the backward goes through it inside the layer loop (softmax and squared
+    normalisations; equal_attention / diagonal adjacencies do not depend on the input).  Every gradient of the value estimator and of
+    the state predictor against autograd over the oracle."""
     monkeypatch.setenv("RGL_BACKWARD_MFMA", "2")
     test_gradients_value_estimator_and_state_predictor(H, L, sim, skip, "trained", B, True, dev)
 
