@@ -633,7 +633,7 @@ def kernel_sources_digest():
 
 def resolve_contraction(args):
     """`auto` -> the mode that carries `value` for this workload.  bf16x6 (RGL_CONTRACT_BF16X6) keeps every operand at f32's 24
-    significand bits and drops < 2^-24 |w||a| per product -- it is the reference's arithmetic width on another pipe, admitted by the
+    significand bits and drops <= 2^-23 |w||a| per product in the worst case (~2^-25 typically) -- it is the reference's arithmetic width on another pipe, admitted by the
     criteria of DESIGN.md 4 (suite under the mode, float64 deviation not above the f32 kernels') -- and exists where the fused
     children kernel runs: two GCN layers, N <= 32.  Deterministic in the workload (never in a timing), so that the lines of
     N = 1, 2, 4, 8 ranks are the same arithmetic."""
