@@ -6,6 +6,7 @@
 // Follows crowd_nav/policy/model_predictive_rl.py:228-231 (strict '>' argmax), :242-269 (action_clip), :271-302 (V_planning).
 #pragma once
 #include "rgl_common.h"
+#include "rgl_mfma.h"
 
 namespace {
 
@@ -115,16 +116,22 @@ __device__ __forceinline__ void tail_select(const TailArgs& t, int p, int* kl) {
                     bv = v;
                 }
             }
-            // wave argmax over (value, index)
+            // wave argmax over (value, index) on the VALU: the maximum over the lanes that hold a number (DPP row steps + two
+            // permlane swaps), then the lowest action index among the lanes that attain it by ballots, slot by slot (lane l's
+            // candidates are l, l + 64, ...).  The ds_bpermute butterfly this replaces -- twelve trips through the LDS crossbar per
+            // kept action, each waited for -- was most of the step's time (profiles/r06_z_tail_ab.md).
+            {
+                const bool have = bi >= 0, number = have && bv == bv;
+                const bool numbers = __ballot(number) != 0ull;
+                const float m = kgroups_max(row16_max(number ? bv : -INFINITY));
+                const bool win = numbers ? (number && bv == m) : have;          // only NaNs left: the lowest index among them
+                int wbi = -1;
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float ov = __shfl_xor(bv, off);
-                const int oi = __shfl_xor(bi, off);
-                const bool take = oi >= 0 && (bi < 0 || ov > bv || (bv != bv && ov == ov) || (ov == bv && oi < bi));
-                if (take) {
-                    bv = ov;
-                    bi = oi;
+                for (int k = 3; k >= 0; --k) {
+                    const unsigned long long mk = __ballot(win && (bi >> 6) == k);
+                    if (mk) wbi = __ffsll((long long)mk) - 1 + 64 * k;
                 }
+                bi = wbi;
             }
             if (bi < 0) break;                          // nothing left (wave-uniform)
 #pragma unroll
@@ -228,16 +235,17 @@ __device__ __forceinline__ void tail_root(const TailArgs& t, int b, int sub, boo
             }
         }
     }
-    // first maximum over the 16 lanes: a slot beats no slot, then the larger value, then the smaller slot index
-#pragma unroll
-    for (int m = kRootLanes / 2; m >= 1; m >>= 1) {
-        const float ov = __shfl_xor(best, m);
-        const int ok = __shfl_xor(bk, m);
-        const bool take = ok >= 0 && (bk < 0 || ov > best || (ov == best && ok < bk));
-        if (take) {
-            best = ov;
-            bk = ok;
-        }
+    // first maximum over the 16 lanes (one DPP row): a slot beats no slot, then the larger value, then the smaller slot index --
+    // the row's maximum over the lanes that hold a slot, then the smallest slot among the lanes that attain it (slot indices are
+    // exact in fp32), both as DPP row reductions instead of eight trips through the LDS crossbar.  A lane's `best` is a number
+    // whenever it holds a slot (strict '>' above never takes a NaN).
+    static_assert(kRootLanes == 16, "one DPP row per root");
+    {
+        const bool have = bk >= 0;
+        const float m = row16_max(have ? best : -INFINITY);
+        const float nk = row16_max(have && best == m ? -(float)bk : -INFINITY);
+        bk = nk > -INFINITY ? (int)(-nk) : -1;
+        best = m;
     }
     if (live && sub == 0) {
         t.best_action[b] = bk >= 0 ? L.keep[(size_t)b * W + bk] : -1;   // -1 <=> 'Value network is not well trained'
