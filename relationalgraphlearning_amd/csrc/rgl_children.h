@@ -3,6 +3,7 @@
 // Follows crowd_nav/policy/state_predictor.py:41-60, model_predictive_rl.py:304-357, crowd_sim/envs/utils/utils.py:4-26.
 #pragma once
 #include "rgl_common.h"
+#include "rgl_mfma.h"
 
 namespace {
 
@@ -217,9 +218,8 @@ __device__ __forceinline__ double stop_reward_wave(const ChildrenArgs& ca, int p
         }
     }
     const bool collision = __ballot(d < 0.f) != 0ull;
-    float dmin = d;
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, s));
+    // wave minimum on the VALU (DPP row maxima + permlane swaps of the negated value: exact) instead of six ds_bpermute trips
+    const float dmin = -kgroups_max(row16_max(-d));
     const float gx = __fsub_rn(r[0], r[5]), gy = __fsub_rn(r[1], r[6]);
     const bool reaching = sqrtf(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy))) < r[4];
     if (collision) return -0.25;
